@@ -1,0 +1,194 @@
+/*
+ * qip_hip.h — C ABI of the MI355X (gfx950) state-vector backend for RustQIP's
+ * gate-application hot path.
+ *
+ * Everything here is plain C: pointers, sizes, integers.  No torch / HIP types
+ * appear in any signature, so the library can be bound from Rust (`extern "C"`),
+ * ctypes, cgo, ... unchanged.  Each entry point names the reference interface
+ * (file:line under the RustQIP tree, qip 1.5.0) it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero QIP_ERR_* code on
+ *     failure; the message is available from qip_hip_last_error() (thread-local).
+ *     Nothing aborts or throws across the ABI.  (The reference has no error
+ *     channel in the kernel — malformed ops panic, qip/src/builder.rs:517
+ *     `.unwrap()`s — so a Rust shim turns non-zero into CircuitError / panic.)
+ *   - amplitudes are interleaved {re, im}: bit-compatible with
+ *     num_complex::Complex<f64> / Complex<f32> (#[repr(C)]).
+ *   - qubit q of an n-qubit state is bit (n-1-q) of the amplitude index
+ *     (qip-iterators/src/matrix_ops.rs:18,28).
+ *   - a state handle is driven by one host thread; calls are asynchronous on
+ *     the handle's HIP stream; download / measure* / sync synchronise.
+ */
+#ifndef QIP_HIP_H
+#define QIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- value types ------------------------------------------------------ */
+
+typedef struct { double re, im; } qip_c64; /* Complex<f64>  (qip/src/types.rs:6-13) */
+typedef struct { float re, im; } qip_c32;  /* Complex<f32> */
+
+enum qip_dtype { QIP_C64 = 0, QIP_C32 = 1 };
+
+/* MatrixOp<P> variants (qip-iterators/src/iterators/ops.rs:11-20). */
+enum qip_op_kind {
+  QIP_OP_MATRIX = 0,  /* Matrix(indices, 4^k row-major data)                  */
+  QIP_OP_SPARSE = 1,  /* SparseMatrix(indices, rows of (col, val)) as CSR      */
+  QIP_OP_SWAP = 2,    /* Swap(h, A-indices ++ B-indices), n_indices = 2h       */
+  QIP_OP_CONTROL = 3  /* Control(nc, control-indices ++ op-indices, inner)     */
+};
+
+/*
+ * Flat mirror of the recursive Rust enum MatrixOp<P>.
+ *   indices      n_indices qubit indices.  CONTROL: the n_controls control
+ *                indices first, then the inner op's indices (ops.rs:19,84-91).
+ *                SWAP: the A half then the B half (ops.rs:66-79).
+ *   dense        MATRIX only: 4^k entries, row-major, element type chosen by the
+ *                `dtype` argument of the call (qip_c64 or qip_c32).
+ *   sparse_*     SPARSE only: CSR flattening of Vec<Vec<(usize, P)>>; row r is
+ *                entries [rowptr[r], rowptr[r+1]); stored order is preserved and
+ *                nothing is filtered (qubit_iterators.rs:87-101).
+ *   inner        CONTROL only.  inner->indices are ignored at apply time, exactly
+ *                as in the reference (matrix_ops.rs:108, ops.rs:44); nested
+ *                CONTROLs accumulate their controls (ops.rs:150-154).
+ */
+typedef struct qip_op {
+  int32_t kind;
+  uint32_t n_indices;
+  const uint64_t* indices;
+  uint32_t n_controls;
+  const void* dense;
+  const uint64_t* sparse_rowptr; /* 2^k + 1 entries */
+  const uint64_t* sparse_cols;
+  const void* sparse_vals;
+  const struct qip_op* inner;
+} qip_op;
+
+/* error codes */
+enum qip_status {
+  QIP_OK = 0,
+  QIP_ERR_INVALID = 1,     /* what make_*_op would reject, or a malformed descriptor */
+  QIP_ERR_DEVICE = 2,      /* HIP runtime error (message carries hipGetErrorString) */
+  QIP_ERR_NO_DEVICE = 3,   /* no gfx950 device visible: there is no CPU fallback    */
+  QIP_ERR_UNSUPPORTED = 4
+};
+
+typedef struct qip_hip_state qip_hip_state; /* opaque device-resident state */
+
+/* ---- library ----------------------------------------------------------- */
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* qip_hip_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int qip_hip_device_count(void);
+/* ABI version of this header (bumped on incompatible change). */
+int qip_hip_abi_version(void);
+/* Process-wide options.  "force_generic" = 1 routes every op (including the host twin
+ * below) through the literal gather kernel; used by the parity tests to check both the
+ * specialised kernels and the fallback against the oracle. */
+int qip_hip_set_global_option(const char* key, int64_t value);
+
+/* ---- op validation ------------------------------------------------------
+ * Re-validates what the reference constructors validate
+ * (qip/src/state_ops/matrix_ops.rs:12-27 make_matrix_op, :32-81
+ * make_sparse_matrix_op, :84-100 make_swap_op, :103-122 make_control_op) plus
+ * what would make the reference kernel panic (index >= n, duplicate index,
+ * sparse column >= 2^k).  Pure host code: works without a GPU. */
+int qip_hip_validate_op(uint32_t n, const qip_op* op);
+
+/* Algorithmic bytes one application of `op` moves on an n-qubit state of the
+ * given dtype: every amplitude that can change is read once and written once
+ * (SURVEY.md §8(d)).  Pure host code. */
+int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op* op, double* bytes);
+
+/* ---- inner seam: host-pointer twin of apply_op / apply_op_overwrite -----
+ * Replaces qip_iterators::matrix_ops::apply_op (matrix_ops.rs:98-123,
+ * accumulate != 0: out[r] += ...) and apply_op_overwrite (:127-152,
+ * accumulate == 0: out[r] = ...), including the input/output window offsets
+ * (:74-90: a column outside [in_off, in_off+in_len) contributes zero).
+ * `in` and `out` are HOST pointers and must not alias; the call uploads,
+ * runs the HIP kernels, downloads and synchronises.  It exists for parity
+ * tests and small states, not for speed (see the device-resident API below). */
+int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op,
+                          const void* in, uint64_t in_len,
+                          void* out, uint64_t out_len,
+                          uint64_t in_off, uint64_t out_off, int accumulate);
+
+/* ---- outer seam: device-resident state ----------------------------------
+ * Replaces the two host Vecs `state` / `arena` that
+ * LocalBuilder::calculate_state_with_init allocates and ping-pongs
+ * (qip/src/builder.rs:406-407,514).  Amplitudes stay in HBM between gates. */
+
+/* Allocate 2^n amplitudes on `device` (all zero).  A second buffer of the
+ * same size is allocated lazily, only if an op needs the out-of-place path. */
+int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_state** out);
+/* Wrap caller-owned device memory (e.g. a torch tensor): `amps` holds 2^n
+ * amplitudes, `scratch` (may be NULL) a second buffer of the same size,
+ * `stream` is a hipStream_t (NULL = the handle creates its own). The handle
+ * never frees wrapped memory. */
+int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps, void* scratch,
+                       void* stream, qip_hip_state** out);
+int qip_hip_state_destroy(qip_hip_state* s);
+
+/* state[i] = (i == index) ? 1 : 0      (builder.rs:406-421) */
+int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index);
+/* Copy amplitudes [offset, offset+len) from / to host memory. */
+int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len);
+int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offset, uint64_t len);
+/* Device pointer of the current amplitude buffer (may change after apply_op
+ * when the out-of-place path swapped buffers). */
+int qip_hip_state_device_ptr(qip_hip_state* s, void** amps);
+int qip_hip_state_sync(qip_hip_state* s);
+
+/* state <- op · state.  Equivalent to apply_op_overwrite(n, op, state, arena, 0, 0)
+ * followed by the buffer swap (builder.rs:499,514). */
+int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op);
+/* Apply `count` ops in order (one FFI crossing per circuit instead of per gate). */
+int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count);
+
+/* Options: key is one of
+ *   "force_generic"  1 = route every op through the literal gather kernel
+ *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)
+ *   "lowbit_shuffle" 1 = cross-lane variant of the 1-qubit kernel for low bit positions
+ */
+int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);
+
+/* Per-kernel-class timing, collected when option "profile" = 1.
+ * classes: see qip_hip_kernel_class_name(). Resets with *_profile_reset. */
+int qip_hip_kernel_class_count(void);
+const char* qip_hip_kernel_class_name(int cls);
+int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
+                              double* total_ms, double* algorithmic_bytes);
+int qip_hip_state_profile_reset(qip_hip_state* s);
+
+/* ---- measurement (qip/src/state_ops/measurement_ops.rs) ----------------- */
+
+/* Σ|amp|²  (prob_magnitude, measurement_ops.rs:11-13) */
+int qip_hip_state_norm_sqr(qip_hip_state* s, double* out);
+/* out[m] for m in [0, 2^k): probability of reading m from `indices`
+ * (bit i of m ↔ indices[i]; measure_probs :115-127, measure_prob :44-112). */
+int qip_hip_state_measure_probs(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                double* out);
+int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, const uint64_t* indices,
+                               uint32_t k, double* out);
+/* soft_measure (:153-176) with the uniform sample supplied by the caller
+ * (`rand_u01` in [0,1)), so the Rust side keeps using `rand`. */
+int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                               double rand_u01, uint64_t* measured);
+/* measure (:190-214): forced >= 0 plays MeasuredCondition.measured;
+ * forced < 0 samples with rand_u01.  Collapses and renormalises in place
+ * (measure_state :220-269; no-op when the probability is 0). */
+int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                          int64_t forced, double rand_u01, uint64_t* measured, double* prob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QIP_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI declared in include/qip_hip.h.
+
+The shared library is the product: if it is missing or fails to load, importing this
+module raises — there is no Python / CPU fallback for any compute entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqip_hip.so")
+
+QIP_C64, QIP_C32 = 0, 1
+QIP_OP_MATRIX, QIP_OP_SPARSE, QIP_OP_SWAP, QIP_OP_CONTROL = 0, 1, 2, 3
+QIP_OK, QIP_ERR_INVALID, QIP_ERR_DEVICE, QIP_ERR_NO_DEVICE, QIP_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+
+class QipOp(C.Structure):
+    """struct qip_op (include/qip_hip.h): flat mirror of MatrixOp<P> (ops.rs:11-20)."""
+
+
+QipOp._fields_ = [
+    ("kind", C.c_int32),
+    ("n_indices", C.c_uint32),
+    ("indices", C.POINTER(C.c_uint64)),
+    ("n_controls", C.c_uint32),
+    ("dense", C.c_void_p),
+    ("sparse_rowptr", C.POINTER(C.c_uint64)),
+    ("sparse_cols", C.POINTER(C.c_uint64)),
+    ("sparse_vals", C.c_void_p),
+    ("inner", C.POINTER(QipOp)),
+]
+
+# name -> (restype, argtypes); every symbol include/qip_hip.h declares
+_u32, _u64, _i64, _int, _dbl = C.c_uint32, C.c_uint64, C.c_int64, C.c_int, C.c_double
+_vp, _cp = C.c_void_p, C.c_char_p
+_opp = C.POINTER(QipOp)
+_u64p = C.POINTER(C.c_uint64)
+_dblp = C.POINTER(C.c_double)
+_statep = C.c_void_p
+
+SIGNATURES = {
+    "qip_hip_last_error": (_cp, []),
+    "qip_hip_device_count": (_int, []),
+    "qip_hip_abi_version": (_int, []),
+    "qip_hip_set_global_option": (_int, [_cp, _i64]),
+    "qip_hip_validate_op": (_int, [_u32, _opp]),
+    "qip_hip_op_algorithmic_bytes": (_int, [_int, _u32, _opp, _dblp]),
+    "qip_hip_apply_op_host": (_int, [_int, _u32, _opp, _vp, _u64, _vp, _u64, _u64, _u64, _int]),
+    "qip_hip_state_create": (_int, [_u32, _int, _int, C.POINTER(_statep)]),
+    "qip_hip_state_wrap": (_int, [_u32, _int, _int, _vp, _vp, _vp, C.POINTER(_statep)]),
+    "qip_hip_state_destroy": (_int, [_statep]),
+    "qip_hip_state_init_basis": (_int, [_statep, _u64]),
+    "qip_hip_state_upload": (_int, [_statep, _vp, _u64, _u64]),
+    "qip_hip_state_download": (_int, [_statep, _vp, _u64, _u64]),
+    "qip_hip_state_device_ptr": (_int, [_statep, C.POINTER(_vp)]),
+    "qip_hip_state_sync": (_int, [_statep]),
+    "qip_hip_state_apply_op": (_int, [_statep, _opp]),
+    "qip_hip_state_apply_ops": (_int, [_statep, _opp, _u64]),
+    "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
+    "qip_hip_kernel_class_count": (_int, []),
+    "qip_hip_kernel_class_name": (_cp, [_int]),
+    "qip_hip_state_profile_get": (_int, [_statep, _int, _u64p, _dblp, _dblp]),
+    "qip_hip_state_profile_reset": (_int, [_statep]),
+    "qip_hip_state_norm_sqr": (_int, [_statep, _dblp]),
+    "qip_hip_state_measure_probs": (_int, [_statep, _u64p, _u32, _dblp]),
+    "qip_hip_state_measure_prob": (_int, [_statep, _u64, _u64p, _u32, _dblp]),
+    "qip_hip_state_soft_measure": (_int, [_statep, _u64p, _u32, _dbl, _u64p]),
+    "qip_hip_state_measure": (_int, [_statep, _u64p, _u32, _i64, _dbl, _u64p, _dblp]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). rustqip_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.qip_hip_last_error().decode("utf-8", "replace")

@@ -1,0 +1,36 @@
+"""Compile the HIP extension in-tree: rustqip_amd/csrc/*.hip -> rustqip_amd/lib/libqip_hip.so.
+
+hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off is part of the numerics
+contract (no product may be fused into an add; see csrc/qip_kernels.h)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "qip_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "qip_kernels.h"), os.path.join(HERE, "..", "include", "qip_hip.h")]
+OUT = os.path.join(HERE, "lib", "libqip_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False) -> str:
+    if force or needs_build():
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        cmd = [HIPCC, *FLAGS, "-o", OUT, SRC]
+        print("[rustqip_amd.build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,488 @@
+// qip_kernels.h — gfx950 (CDNA4, wave64) kernels for the gate-application hot path.
+//
+// Data layout: the 2^n amplitudes are one interleaved {re,im} array in HBM
+// (16 B per Complex<f64>, 8 B per Complex<f32>); qubit q is index bit n-1-q
+// (qip-iterators/src/matrix_ops.rs:18,28).  All fast kernels update the vector
+// IN PLACE: every amplitude that can change is read once and written once, which is
+// the algorithmic-byte count of SURVEY.md §8(d).  The reference instead gathers into
+// a second 2^n buffer per gate (matrix_ops.rs:127-152); only the literal fallback
+// kernel (k_gather_generic) keeps that out-of-place shape.
+//
+// All kernels are HBM-bandwidth bound (a dense 1-qubit gate is 14 flop per 32 B), so
+// the design rules are: 16-B per-lane accesses, contiguous 1-KiB wave rows whenever the
+// touched bit positions allow it, several independent loads in flight per lane, and no
+// fused multiply-add (the file is compiled with -ffp-contract=off so products and sums
+// round exactly as the reference's unfused num-complex arithmetic does).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qipk {
+
+constexpr int kBlock = 256;   // 4 waves of 64
+constexpr int kMaxIns = 64;   // max bit positions removed from the work index
+
+template <typename T> struct V2;
+// native clang vectors (not HIP's double2 wrapper struct): they stay in registers when held in
+// small arrays and load/store as one global_load_dwordx4 / dwordx2
+template <> struct V2<double> { using type = double __attribute__((ext_vector_type(2))); };
+template <> struct V2<float> { using type = float __attribute__((ext_vector_type(2))); };
+template <typename T> using amp_t = typename V2<T>::type;
+
+// ---- index arithmetic ------------------------------------------------------
+
+// Sorted-ascending bit positions to open up in a dense work index, plus bits to set.
+// A work index w in [0, 2^(n-npos)) becomes the amplitude index whose bits at `pos`
+// are zero (then OR-ed with `ormask`): the kernel-side replacement of the reference's
+// per-row full_to_sub / sub_to_full bit loops (matrix_ops.rs:12-30).
+struct Ins {
+  uint64_t ormask;
+  uint32_t npos;
+  uint32_t pos[kMaxIns];
+};
+
+// NP >= 0: number of positions known at compile time (fully unrolled, positions live in
+// SGPRs straight from the kernel-argument segment); NP < 0: run-time count.
+template <int NP>
+__device__ __forceinline__ uint64_t insert_bits(uint64_t w, const Ins& ins) {
+  if constexpr (NP >= 0) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t p = ins.pos[j];
+      const uint64_t low = w & ((1ull << p) - 1ull);
+      w = ((w >> p) << (p + 1)) | low;
+    }
+  } else {
+    for (uint32_t j = 0; j < ins.npos; ++j) {
+      const uint32_t p = ins.pos[j];
+      const uint64_t low = w & ((1ull << p) - 1ull);
+      w = ((w >> p) << (p + 1)) | low;
+    }
+  }
+  return w | ins.ormask;
+}
+
+// ---- complex arithmetic, num-complex formulas, never contracted -------------
+
+template <typename A> __device__ __forceinline__ A cmul(A a, A b) {
+  A r;
+  r.x = a.x * b.x - a.y * b.y;
+  r.y = a.x * b.y + a.y * b.x;
+  return r;
+}
+template <typename A> __device__ __forceinline__ A cadd(A a, A b) {
+  A r;
+  r.x = a.x + b.x;
+  r.y = a.y + b.y;
+  return r;
+}
+template <typename A> __device__ __forceinline__ A czero() {
+  A r;
+  r.x = 0;
+  r.y = 0;
+  return r;
+}
+
+// 2x2 gate, row-major, plus a 4-bit mask of entries that are not exactly zero:
+// MatrixOpIterator skips zero entries (qubit_iterators.rs:49), so they add no term.
+template <typename T> struct Mat2 {
+  amp_t<T> m[4];
+  uint32_t nz;
+};
+
+// The streaming kernels below come in two shapes selected by the launcher:
+//   <U = 4, GUARD = false>  work-item count is a multiple of kBlock*U (every count is a
+//                           power of two), no bounds checks, 4 independent 16-B loads per
+//                           stream in flight per lane;
+//   <U = 1, GUARD = true>   tiny states.
+
+// ---- 1-qubit gate, pair per lane ---------------------------------------------
+// Work item = one (|0>,|1>) pair of the target bit inside the all-controls-one subspace.
+// `ins` opens the target bit and every control bit; ormask sets the controls.
+// out0 = m00*a0 + m01*a1 ; out1 = m10*a0 + m11*a1, folded from 0 in column order
+// (matrix_ops.rs:78-93, ops.rs:104-110).
+template <typename T, int U, bool GUARD, int NP>
+__global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ st, uint64_t npairs,
+                                                        Ins ins, uint64_t tmask, Mat2<T> g) {
+  using A = amp_t<T>;
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (GUARD && base >= npairs) return;
+  uint64_t i0[U];
+  A a0[U], a1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
+    a0[u] = st[i0[u]];
+    a1[u] = st[i0[u] | tmask];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    A r0 = czero<A>(), r1 = czero<A>();
+    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0[u]));
+    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1[u]));
+    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0[u]));
+    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1[u]));
+    st[i0[u]] = r0;
+    st[i0[u] | tmask] = r1;
+  }
+}
+
+// ---- 1-qubit gate, amplitude per lane, partner by cross-lane exchange -----------
+// For a target bit that lands inside the lane index (work-index bit tb < 6) the wave
+// keeps fully contiguous 1-KiB rows: each lane loads ONE amplitude, fetches its partner
+// from lane ^ (1<<tb) and computes only its own output row.  `ins` opens only the
+// control bits.  Requires the work-item count to be a multiple of 64.
+template <typename T, int U, bool GUARD, int NP>
+__global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ st, uint64_t namps,
+                                                         Ins ins, uint32_t tb, Mat2<T> g) {
+  using A = amp_t<T>;
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (GUARD && base >= namps) return;  // whole waves leave together (namps % 64 == 0)
+  const bool hi = (threadIdx.x >> tb) & 1u;  // this lane holds the |1> member
+  // row of the gate this lane evaluates: (m_lo, m_hi) multiply (|0> member, |1> member)
+  const A m_lo = hi ? g.m[2] : g.m[0];
+  const A m_hi = hi ? g.m[3] : g.m[1];
+  const bool nz_lo = hi ? (g.nz & 4u) : (g.nz & 1u);
+  const bool nz_hi = hi ? (g.nz & 8u) : (g.nz & 2u);
+  uint64_t idx[U];
+  A own[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    idx[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
+    own[u] = st[idx[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    A other;
+    other.x = __shfl_xor(own[u].x, 1 << tb, 64);
+    other.y = __shfl_xor(own[u].y, 1 << tb, 64);
+    const A lo = hi ? other : own[u];
+    const A hv = hi ? own[u] : other;
+    A r = czero<A>();
+    if (nz_lo) r = cadd(r, cmul(m_lo, lo));
+    if (nz_hi) r = cadd(r, cmul(m_hi, hv));
+    st[idx[u]] = r;
+  }
+}
+
+// ---- scalar phase on a subspace ----------------------------------------------------
+// Every amplitude whose bits at `ins.pos` equal `ins.ormask` is multiplied by `value`.
+// This is Z/S/T, controlled-phase, multi-controlled Z...: a diagonal gate whose other
+// diagonal entries are exactly 1 leaves those amplitudes untouched (1*x == x), so they
+// are neither read nor written.
+template <typename T, int U, bool GUARD, int NP>
+__global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+                                                  amp_t<T> value) {
+  using A = amp_t<T>;
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (GUARD && base >= count) return;
+  uint64_t idx[U];
+  A x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    idx[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
+    x[u] = st[idx[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) st[idx[u]] = cmul(value, x[u]);
+}
+
+// ---- exchange of two index bits (Swap with h = 1, optionally controlled) ---------------
+// SwapOpIterator (qubit_iterators.rs:208-218) yields the single column whose A and B
+// halves are exchanged, with value 1: a pure move.  Only amplitudes whose two bits differ
+// change, so a work item is one (01,10) pair and the other half of the vector is untouched.
+template <typename T, int U, bool GUARD, int NP>
+__global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st, uint64_t npairs,
+                                                      Ins ins, uint64_t amask, uint64_t bmask) {
+  using A = amp_t<T>;
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (GUARD && base >= npairs) return;
+  uint64_t i0[U];
+  A xa[U], xb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
+    xa[u] = st[i0[u] | amask];
+    xb[u] = st[i0[u] | bmask];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    st[i0[u] | amask] = xb[u];
+    st[i0[u] | bmask] = xa[u];
+  }
+}
+
+// ---- general diagonal gate on k qubits ------------------------------------------------
+// Amplitude per lane inside the control subspace; factor = diag[sub-index].  Entries equal
+// to exactly 1 are skipped (not loaded).  `tpos[j]` is the bit position of op index j
+// (j = 0 is the MSB of the sub-index, matrix_ops.rs:12-21).
+struct DiagDesc {
+  uint32_t k;
+  uint32_t tpos[32];
+};
+
+template <typename T, int U>
+__global__ __launch_bounds__(kBlock) void k_diag(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+                                                 DiagDesc d, const amp_t<T>* __restrict__ diag) {
+  using A = amp_t<T>;
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t w = base + (uint64_t)u * kBlock;
+    if (w >= count) continue;
+    const uint64_t i = insert_bits<-1>(w, ins);
+    uint32_t sub = 0;
+    for (uint32_t j = 0; j < d.k; ++j) sub = (sub << 1) | (uint32_t)((i >> d.tpos[j]) & 1ull);
+    const A f = diag[sub];
+    if (f.x == (T)1 && f.y == (T)0) continue;
+    st[i] = cmul(f, st[i]);
+  }
+}
+
+// ---- dense k-qubit gate held in registers (k = 2..4) ------------------------------------
+// One lane owns the 2^K amplitudes of one sub-space; `ins` opens the K target bits and the
+// controls.  off[c] is the amplitude-index offset of sub-index c.  The matrix is read
+// through wave-uniform (scalar) loads.  Zero entries are multiplied, not skipped: for
+// finite amplitudes 0*x adds +-0, which leaves every sum IEEE-equal to the reference's.
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, uint64_t ngroups,
+                                                    Ins ins, DiagDesc d,
+                                                    const amp_t<T>* __restrict__ mat) {
+  using A = amp_t<T>;
+  constexpr int S = 1 << K;
+  const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= ngroups) return;
+  const uint64_t i0 = insert_bits<-1>(w, ins);
+  uint64_t off[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if ((c >> (K - 1 - j)) & 1) o |= 1ull << d.tpos[j];
+    off[c] = o;
+  }
+  A x[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) x[c] = st[i0 | off[c]];
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    A acc = czero<A>();
+#pragma unroll
+    for (int c = 0; c < S; ++c) acc = cadd(acc, cmul(mat[r * S + c], x[c]));
+    st[i0 | off[r]] = acc;
+  }
+}
+
+// ---- literal fallback: one output row per lane, out of place ------------------------------
+// The gather formulation of the reference, variant by variant (matrix_ops.rs:62-94,
+// ops.rs:100-156, qubit_iterators.rs).  Correct for every descriptor the reference accepts,
+// including window offsets and accumulate; used for SparseMatrix, large dense matrices,
+// descriptors with repeated indices, and the host-pointer twin of apply_op.
+struct GatherDesc {
+  uint32_t n;
+  uint32_t k_all;       // indices of the outer op
+  uint32_t n_control;   // flattened controls (0 when not a Control)
+  uint32_t n_op;        // indices the innermost iterator is built with
+  int32_t inner_kind;   // QIP_OP_MATRIX / SPARSE / SWAP
+  int32_t accumulate;
+  uint64_t in_len, out_len, in_off, out_off;
+  uint32_t pos[kMaxIns];  // pos[j] = n-1-indices[j]
+};
+
+__device__ __forceinline__ uint64_t g_full_to_sub(const GatherDesc& d, uint64_t full) {
+  uint64_t acc = 0;
+  for (uint32_t j = 0; j < d.k_all; ++j) acc |= ((full >> d.pos[j]) & 1ull) << (d.k_all - 1 - j);
+  return acc;
+}
+__device__ __forceinline__ uint64_t g_sub_to_full(const GatherDesc& d, uint64_t sub, uint64_t base) {
+  uint64_t acc = base;
+  for (uint32_t j = 0; j < d.k_all; ++j) {
+    const uint64_t bit = (sub >> (d.k_all - 1 - j)) & 1ull;
+    acc = (acc & ~(1ull << d.pos[j])) | (bit << d.pos[j]);
+  }
+  return acc;
+}
+
+template <typename T>
+__device__ __forceinline__ amp_t<T> g_term(const GatherDesc& d, uint64_t row, uint64_t col,
+                                           amp_t<T> val, const amp_t<T>* __restrict__ in) {
+  using A = amp_t<T>;
+  const uint64_t colbits = g_sub_to_full(d, col, row);
+  if (colbits < d.in_off) return czero<A>();
+  const uint64_t vecrow = colbits - d.in_off;
+  if (vecrow >= d.in_len) return czero<A>();
+  return cmul(val, in[vecrow]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_generic(const amp_t<T>* __restrict__ in,
+                                                           amp_t<T>* __restrict__ out, GatherDesc d,
+                                                           const amp_t<T>* __restrict__ dense,
+                                                           const uint64_t* __restrict__ rowptr,
+                                                           const uint64_t* __restrict__ cols,
+                                                           const amp_t<T>* __restrict__ vals) {
+  using A = amp_t<T>;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < d.out_len; r += stride) {
+    const uint64_t row = d.out_off + r;
+    const uint64_t matrow = g_full_to_sub(d, row);
+    A acc = czero<A>();
+    A one;
+    one.x = 1;
+    one.y = 0;
+    uint64_t shift = 0, irow = matrow;
+    bool identity_row = false;
+    if (d.n_control > 0) {
+      const uint64_t thr = (1ull << (d.n_control + d.n_op)) - (1ull << d.n_op);
+      if (matrow >= thr) {
+        shift = thr;
+        irow = matrow - thr;
+      } else {
+        identity_row = true;
+      }
+    }
+    if (identity_row) {
+      acc = cadd(acc, g_term<T>(d, row, matrow, one, in));
+    } else if (d.inner_kind == 0) {  // MATRIX
+      const uint64_t side = 1ull << d.n_op;
+      const A* rowdata = dense + irow * side;
+      for (uint64_t c = 0; c < side; ++c) {
+        const A v = rowdata[c];
+        if (!(v.x == (T)0 && v.y == (T)0)) acc = cadd(acc, g_term<T>(d, row, c + shift, v, in));
+      }
+    } else if (d.inner_kind == 1) {  // SPARSE
+      for (uint64_t p = rowptr[irow]; p < rowptr[irow + 1]; ++p)
+        acc = cadd(acc, g_term<T>(d, row, cols[p] + shift, vals[p], in));
+    } else {  // SWAP
+      const uint32_t half_n = d.n_op >> 1;
+      const uint64_t lower_mask = ~(~0ull << half_n);
+      const uint64_t col = ((irow & lower_mask) << half_n) + (irow >> half_n);
+      acc = cadd(acc, g_term<T>(d, row, col + shift, one, in));
+    }
+    if (d.accumulate) {
+      out[r] = cadd(out[r], acc);
+    } else {
+      out[r] = acc;
+    }
+  }
+}
+
+// out[i] += in[i]  (accumulate leg of the host twin when a fast in-place kernel produced `in`)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add_into(amp_t<T>* __restrict__ out,
+                                                     const amp_t<T>* __restrict__ in, uint64_t len) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride)
+    out[i] = cadd(out[i], in[i]);
+}
+
+// ---- measurement (qip/src/state_ops/measurement_ops.rs) -------------------------------------
+
+__device__ __forceinline__ double block_reduce_sum(double v, double* smem) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) smem[wv] = v;
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kBlock / 64; ++i) t += smem[i];
+  return t;  // valid in thread 0
+}
+
+// partial[m * gridDim.x + blockIdx.x] = sum of |amp|^2 over this block's slice of the
+// sub-space whose measured bits read m (measure_prob_fn, measurement_ops.rs:65-112).
+// `ins` opens the measured bit positions; mbits[m] are precomputed by the host? no:
+// bit i of m goes to position mpos[i] (LSB-first, :72-79).
+struct MeasDesc {
+  uint32_t k;
+  uint32_t mpos[kMaxIns];
+};
+
+__device__ __forceinline__ uint64_t meas_template(const MeasDesc& md, uint64_t m) {
+  uint64_t t = 0;
+  for (uint32_t i = 0; i < md.k; ++i) t |= ((m >> i) & 1ull) << md.mpos[i];
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_measure_probs(const amp_t<T>* __restrict__ st,
+                                                          uint64_t count, Ins ins, MeasDesc md,
+                                                          uint64_t m_first,
+                                                          double* __restrict__ partial) {
+  __shared__ double smem[kBlock / 64];
+  const uint64_t m = m_first + blockIdx.y;
+  const uint64_t templ = meas_template(md, m);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  double s = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < count; w += stride) {
+    const amp_t<T> x = st[insert_bits<-1>(w, ins) | templ];
+    s += (double)(x.x * x.x + x.y * x.y);
+  }
+  const double t = block_reduce_sum(s, smem);
+  if (threadIdx.x == 0) partial[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// probabilities of many outcomes: every amplitude adds |amp|^2 to out[its outcome]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_measure_probs_scatter(const amp_t<T>* __restrict__ st,
+                                                                  uint64_t namps, MeasDesc md,
+                                                                  double* __restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
+    const amp_t<T> x = st[i];
+    if (x.x == (T)0 && x.y == (T)0) continue;  // measurement_ops.rs:98-99
+    uint64_t m = 0;
+    for (uint32_t b = 0; b < md.k; ++b) m |= ((i >> md.mpos[b]) & 1ull) << b;
+    atomicAdd(&out[m], (double)(x.x * x.x + x.y * x.y));
+  }
+}
+
+// partial[b] = sum |amp|^2 over the b-th contiguous chunk of `chunk` amplitudes
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_chunk_norms(const amp_t<T>* __restrict__ st,
+                                                        uint64_t namps, uint64_t chunk,
+                                                        double* __restrict__ partial) {
+  __shared__ double smem[kBlock / 64];
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+  const uint64_t hi = lo + chunk < namps ? lo + chunk : namps;
+  double s = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const amp_t<T> x = st[i];
+    s += (double)(x.x * x.x + x.y * x.y);
+  }
+  const double t = block_reduce_sum(s, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// measure_state (measurement_ops.rs:220-269): zero what disagrees with the outcome,
+// scale the rest by 1/sqrt(p) (Complex * real = (re*p, im*p)).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_collapse(amp_t<T>* __restrict__ st, uint64_t namps,
+                                                     uint64_t row_mask, uint64_t measured_mask,
+                                                     T p_mult) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
+    amp_t<T> x;
+    if (((i & row_mask) ^ measured_mask) != 0) {
+      x.x = 0;
+      x.y = 0;
+    } else {
+      x = st[i];
+      x.x = x.x * p_mult;
+      x.y = x.y * p_mult;
+    }
+    st[i] = x;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fill_zero(amp_t<T>* __restrict__ st, uint64_t namps) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride)
+    st[i] = czero<amp_t<T>>();
+}
+
+}  // namespace qipk

@@ -1,0 +1,236 @@
+"""apply_op / apply_op_overwrite (host-pointer twins) and the device-resident state.
+
+Mirrors, for the hot path only:
+  qip_iterators::matrix_ops::apply_op            (qip-iterators/src/matrix_ops.rs:98-123)
+  qip_iterators::matrix_ops::apply_op_overwrite  (:127-152)
+  the state / arena pair of LocalBuilder::calculate_state_with_init (qip/src/builder.rs:400-519)
+  qip::state_ops::measurement_ops                (qip/src/state_ops/measurement_ops.rs)
+Every function calls straight into libqip_hip.so (HIP kernels); nothing is computed on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .ops import CircuitError, MatrixOp, complex_dtype
+
+
+class QipHipError(RuntimeError):
+    """A non-zero status from the C ABI that is not a descriptor-validation error."""
+
+
+def _check(rc: int) -> None:
+    if rc == _ffi.QIP_OK:
+        return
+    msg = _ffi.last_error()
+    if rc == _ffi.QIP_ERR_INVALID:
+        raise CircuitError(msg)
+    raise QipHipError(f"qip_hip status {rc}: {msg}")
+
+
+def device_count() -> int:
+    return int(_ffi.lib.qip_hip_device_count())
+
+
+def set_global_option(key: str, value: int) -> None:
+    _check(_ffi.lib.qip_hip_set_global_option(key.encode(), int(value)))
+
+
+def _dtype_of(arr: np.ndarray) -> int:
+    if arr.dtype == np.complex128:
+        return _ffi.QIP_C64
+    if arr.dtype == np.complex64:
+        return _ffi.QIP_C32
+    raise CircuitError(f"unsupported amplitude dtype {arr.dtype}; use complex128 or complex64")
+
+
+def _apply_host(n, op, input, output, input_offset, output_offset, accumulate):
+    if not (isinstance(input, np.ndarray) and isinstance(output, np.ndarray)):
+        raise TypeError("input and output must be numpy arrays")
+    dtype = _dtype_of(output)
+    if _dtype_of(input) != dtype:
+        raise CircuitError("input and output precision differ")
+    if not (input.flags.c_contiguous and output.flags.c_contiguous and output.flags.writeable):
+        raise CircuitError("input/output must be contiguous, output writeable")
+    if np.shares_memory(input, output):
+        raise CircuitError("input and output must not alias (&[P] vs &mut [P])")
+    cop = op.to_c(dtype)
+    _check(
+        _ffi.lib.qip_hip_apply_op_host(
+            dtype, n, C.byref(cop), input.ctypes.data, input.size, output.ctypes.data, output.size,
+            int(input_offset), int(output_offset), int(accumulate),
+        )
+    )
+
+
+def apply_op(n: int, op: MatrixOp, input: np.ndarray, output: np.ndarray, input_offset: int = 0,
+             output_offset: int = 0) -> None:
+    """output[r] += (op · input)[r]   — matrix_ops.rs:98-123, same argument order."""
+    _apply_host(n, op, input, output, input_offset, output_offset, True)
+
+
+def apply_op_overwrite(n: int, op: MatrixOp, input: np.ndarray, output: np.ndarray, input_offset: int = 0,
+                       output_offset: int = 0) -> None:
+    """output[r] = (op · input)[r]   — matrix_ops.rs:127-152."""
+    _apply_host(n, op, input, output, input_offset, output_offset, False)
+
+
+def make_op_matrix(n: int, op: MatrixOp, dtype=np.complex128) -> np.ndarray:
+    """Full 2^n x 2^n matrix of `op`, column by column through apply_op on basis vectors —
+    the reference's test/debug helper (qip/src/state_ops/matrix_ops.rs:246-257,
+    qip-iterators/src/matrix_ops.rs:229-255).  Returns M with M[r, c] = <r|op|c>."""
+    N = 1 << n
+    cols = []
+    for i in range(N):
+        inp = np.zeros(N, dtype=dtype)
+        out = np.zeros(N, dtype=dtype)
+        inp[i] = 1
+        apply_op(n, op, inp, out, 0, 0)
+        cols.append(out)
+    return np.stack(cols, axis=1)
+
+
+def _u64_array(values: Sequence[int]):
+    arr = (C.c_uint64 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+class HipState:
+    """2^n amplitudes resident in HBM; gates are applied in place by HIP kernels.
+
+    Replaces the `state` / `arena` Vec pair of the reference run loop (builder.rs:406-407,514).
+    """
+
+    def __init__(self, n: int, dtype=np.complex128, device: int = 0, *, wrap_ptr: Optional[int] = None,
+                 scratch_ptr: Optional[int] = None, stream: Optional[int] = None):
+        self.n = int(n)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = _dtype_of(np.empty(0, dtype=dtype))
+        self._h = C.c_void_p()
+        if wrap_ptr is None:
+            _check(_ffi.lib.qip_hip_state_create(self.n, self.dtype, device, C.byref(self._h)))
+        else:
+            _check(
+                _ffi.lib.qip_hip_state_wrap(self.n, self.dtype, device, C.c_void_p(wrap_ptr),
+                                            C.c_void_p(scratch_ptr or 0), C.c_void_p(stream or 0),
+                                            C.byref(self._h))
+            )
+
+    # -- lifetime --------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _ffi.lib.qip_hip_state_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self) -> int:
+        return 1 << self.n
+
+    # -- data movement -----------------------------------------------------------------
+    def init_basis(self, index: int) -> None:
+        _check(_ffi.lib.qip_hip_state_init_basis(self._h, int(index)))
+
+    def upload(self, amps: np.ndarray, offset: int = 0) -> None:
+        amps = np.ascontiguousarray(amps, dtype=self.np_dtype)
+        _check(_ffi.lib.qip_hip_state_upload(self._h, amps.ctypes.data, int(offset), amps.size))
+
+    def download(self, offset: int = 0, length: Optional[int] = None) -> np.ndarray:
+        length = (1 << self.n) - offset if length is None else int(length)
+        out = np.empty(length, dtype=self.np_dtype)
+        _check(_ffi.lib.qip_hip_state_download(self._h, out.ctypes.data, int(offset), length))
+        return out
+
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        _check(_ffi.lib.qip_hip_state_device_ptr(self._h, C.byref(p)))
+        return int(p.value or 0)
+
+    def sync(self) -> None:
+        _check(_ffi.lib.qip_hip_state_sync(self._h))
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(_ffi.lib.qip_hip_state_set_option(self._h, key.encode(), int(value)))
+
+    # -- gates ---------------------------------------------------------------------------
+    def apply_op(self, op: MatrixOp) -> None:
+        """state <- op · state  (apply_op_overwrite + swap, builder.rs:499,514)."""
+        cop = op.to_c(self.dtype)
+        _check(_ffi.lib.qip_hip_state_apply_op(self._h, C.byref(cop)))
+
+    def compile_ops(self, ops: Iterable[MatrixOp]):
+        """Marshal a circuit once; returns an opaque object for apply_compiled."""
+        cops = [op.to_c(self.dtype) for op in ops]
+        arr = (_ffi.QipOp * len(cops))(*cops)
+        return (arr, cops)  # cops keeps the buffers alive
+
+    def apply_compiled(self, compiled) -> None:
+        arr, _keep = compiled
+        _check(_ffi.lib.qip_hip_state_apply_ops(self._h, arr, len(arr)))
+
+    def apply_ops(self, ops: Iterable[MatrixOp]) -> None:
+        self.apply_compiled(self.compile_ops(list(ops)))
+
+    # -- measurement (measurement_ops.rs) ------------------------------------------------
+    def norm_sqr(self) -> float:
+        out = C.c_double()
+        _check(_ffi.lib.qip_hip_state_norm_sqr(self._h, C.byref(out)))
+        return out.value
+
+    def measure_probs(self, indices: Sequence[int]) -> np.ndarray:
+        k = len(indices)
+        out = np.empty(1 << k, dtype=np.float64)
+        _check(_ffi.lib.qip_hip_state_measure_probs(self._h, _u64_array(indices), k,
+                                                    out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def measure_prob(self, measured: int, indices: Sequence[int]) -> float:
+        out = C.c_double()
+        _check(_ffi.lib.qip_hip_state_measure_prob(self._h, int(measured), _u64_array(indices), len(indices),
+                                                   C.byref(out)))
+        return out.value
+
+    def soft_measure(self, indices: Sequence[int], rand_u01: float) -> int:
+        out = C.c_uint64()
+        _check(_ffi.lib.qip_hip_state_soft_measure(self._h, _u64_array(indices), len(indices), float(rand_u01),
+                                                   C.byref(out)))
+        return int(out.value)
+
+    def measure(self, indices: Sequence[int], measured: Optional[int] = None,
+                rand_u01: float = 0.0) -> Tuple[int, float]:
+        m = C.c_uint64()
+        p = C.c_double()
+        forced = -1 if measured is None else int(measured)
+        _check(_ffi.lib.qip_hip_state_measure(self._h, _u64_array(indices), len(indices), forced,
+                                              float(rand_u01), C.byref(m), C.byref(p)))
+        return int(m.value), p.value
+
+    # -- profiling -----------------------------------------------------------------------
+    def profile(self) -> dict:
+        """Per-kernel-class {launches, total_ms, algorithmic_bytes} gathered while option
+        'profile' = 1 (HIP events on the handle's stream)."""
+        out = {}
+        for cls in range(_ffi.lib.qip_hip_kernel_class_count()):
+            launches, ms, by = C.c_uint64(), C.c_double(), C.c_double()
+            _check(_ffi.lib.qip_hip_state_profile_get(self._h, cls, C.byref(launches), C.byref(ms), C.byref(by)))
+            if launches.value:
+                out[_ffi.lib.qip_hip_kernel_class_name(cls).decode()] = {
+                    "launches": int(launches.value), "total_ms": ms.value, "algorithmic_bytes": by.value,
+                }
+        return out
+
+    def profile_reset(self) -> None:
+        _check(_ffi.lib.qip_hip_state_profile_reset(self._h))
