@@ -145,6 +145,12 @@ int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offset, uint64_
 /* Device pointer of the current amplitude buffer (may change after apply_op
  * when the out-of-place path swapped buffers). */
 int qip_hip_state_device_ptr(qip_hip_state* s, void** amps);
+/* Device pointer of the second (scratch / arena) buffer, allocating it if needed, and the
+ * exchange of the two buffers.  Together they let an external out-of-place step — the RCCL
+ * all-to-all of the multi-GPU qubit remap — write the scratch buffer and then make it current,
+ * the way the reference swaps `state` and `arena` (builder.rs:514). */
+int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch);
+int qip_hip_state_swap_buffers(qip_hip_state* s);
 int qip_hip_state_sync(qip_hip_state* s);
 
 /* state <- op · state.  Equivalent to apply_op_overwrite(n, op, state, arena, 0, 0)
@@ -187,6 +193,13 @@ int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indices, uint32
  * (measure_state :220-269; no-op when the probability is 0). */
 int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
                           int64_t forced, double rand_u01, uint64_t* measured, double* prob);
+
+/* measure_state (:220-269) with the outcome and its probability supplied by the caller
+ * (MeasuredCondition{measured, prob: Some(p)}, :181-186,199-203): zero what disagrees with
+ * `measured`, scale the rest by 1/sqrt(prob); no-op when prob == 0.  k may be 0 (pure rescale).
+ * A sharded state collapses each shard with the GLOBAL probability through this entry. */
+int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                uint64_t measured, double prob);
 
 #ifdef __cplusplus
 }

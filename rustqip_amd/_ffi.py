@@ -55,6 +55,8 @@ SIGNATURES = {
     "qip_hip_state_upload": (_int, [_statep, _vp, _u64, _u64]),
     "qip_hip_state_download": (_int, [_statep, _vp, _u64, _u64]),
     "qip_hip_state_device_ptr": (_int, [_statep, C.POINTER(_vp)]),
+    "qip_hip_state_scratch_ptr": (_int, [_statep, C.POINTER(_vp)]),
+    "qip_hip_state_swap_buffers": (_int, [_statep]),
     "qip_hip_state_sync": (_int, [_statep]),
     "qip_hip_state_apply_op": (_int, [_statep, _opp]),
     "qip_hip_state_apply_ops": (_int, [_statep, _opp, _u64]),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "qip_hip_state_measure_prob": (_int, [_statep, _u64, _u64p, _u32, _dblp]),
     "qip_hip_state_soft_measure": (_int, [_statep, _u64p, _u32, _dbl, _u64p]),
     "qip_hip_state_measure": (_int, [_statep, _u64p, _u32, _i64, _dbl, _u64p, _dblp]),
+    "qip_hip_state_measure_state": (_int, [_statep, _u64p, _u32, _u64, _dbl]),
 }
 
 

@@ -100,7 +100,7 @@ def c4_clifford_t(n: int, n_gates: int = 256, seed: int = 32) -> List[MatrixOp]:
 
 def c5_grover_iteration(n: int, dense_k3: bool = False) -> List[MatrixOp]:
     """configs[4]: one Grover iteration for the marked item |0...0>:
-    oracle = X^n · C^{n-1}Z · X^n ; diffusion = H^n · X^n · C^{n-1}Z · X^n · H^n (6n+2 ops).
+    mark = X^n · C^{n-1}Z · X^n (phase flip of the marked item); diffusion = H^n · X^n · C^{n-1}Z · X^n · H^n (6n+2 ops).
     With dense_k3 the H (and X) on the three lowest-bit-position qubits n-3..n-1 are merged into
     one 8x8 Matrix op (the dense k=3 path)."""
     def layer(m):

@@ -548,6 +548,22 @@ extern "C" int qip_hip_state_device_ptr(qip_hip_state* s, void** amps) {
   return QIP_OK;
 }
 
+extern "C" int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch) {
+  STATE_ENTER(s);
+  if (!scratch) return fail(QIP_ERR_INVALID, "null argument");
+  QCHK(ensure_alt(s));
+  *scratch = s->alt;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) {
+  STATE_ENTER(s);
+  QCHK(ensure_alt(s));
+  std::swap(s->cur, s->alt);
+  std::swap(s->owns_cur, s->owns_alt);
+  return QIP_OK;
+}
+
 extern "C" int qip_hip_state_sync(qip_hip_state* s) {
   STATE_ENTER(s);
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1082,6 +1098,8 @@ extern "C" int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, c
                              : measure_probs_t<float>(s, md, pos, measured, 1, out);
 }
 
+static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p);
+
 // soft_measure (measurement_ops.rs:153-176): first index at which r - Σ|amp|² <= 0.  The
 // device sums contiguous chunks; the host walks the chunk sums, then replays the
 // reference's sequential loop inside the one chunk that crosses zero.
@@ -1150,9 +1168,13 @@ extern "C" int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, 
                            : measure_probs_t<float>(s, md, pos, m, 1, &p));
   *measured = m;
   *prob = p;
+  return collapse(s, md, m, p);
+}
+
+static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p) {
   if (p == 0.0) return QIP_OK;  // measure_state is a no-op (:230)
   uint64_t row_mask = 0, measured_mask = 0;
-  for (uint32_t i = 0; i < k; ++i) {
+  for (uint32_t i = 0; i < md.k; ++i) {
     row_mask |= 1ull << md.mpos[i];
     measured_mask |= ((m >> i) & 1ull) << md.mpos[i];
   }
@@ -1167,4 +1189,16 @@ extern "C" int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, 
   }
   HIPCHK(hipGetLastError());
   return QIP_OK;
+}
+
+extern "C" int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                           uint64_t measured, double prob) {
+  STATE_ENTER(s);
+  MeasDesc md;
+  memset(&md, 0, sizeof md);
+  std::vector<uint32_t> pos;
+  if (k > 0) QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  if (k < 64 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
+  if (!(prob >= 0.0)) return fail(QIP_ERR_INVALID, "probability must be >= 0");
+  return collapse(s, md, measured, prob);
 }

@@ -159,6 +159,15 @@ class HipState:
         _check(_ffi.lib.qip_hip_state_device_ptr(self._h, C.byref(p)))
         return int(p.value or 0)
 
+    def scratch_ptr(self) -> int:
+        p = C.c_void_p()
+        _check(_ffi.lib.qip_hip_state_scratch_ptr(self._h, C.byref(p)))
+        return int(p.value or 0)
+
+    def swap_buffers(self) -> None:
+        """make the scratch buffer current (after an external out-of-place step wrote it)"""
+        _check(_ffi.lib.qip_hip_state_swap_buffers(self._h))
+
     def sync(self) -> None:
         _check(_ffi.lib.qip_hip_state_sync(self._h))
 
@@ -217,6 +226,11 @@ class HipState:
         _check(_ffi.lib.qip_hip_state_measure(self._h, _u64_array(indices), len(indices), forced,
                                               float(rand_u01), C.byref(m), C.byref(p)))
         return int(m.value), p.value
+
+    def measure_state(self, indices: Sequence[int], measured: int, prob: float) -> None:
+        """measure_state (measurement_ops.rs:220-269) with a caller-supplied probability."""
+        _check(_ffi.lib.qip_hip_state_measure_state(self._h, _u64_array(indices), len(indices), int(measured),
+                                                    float(prob)))
 
     # -- profiling -----------------------------------------------------------------------
     def profile(self) -> dict:

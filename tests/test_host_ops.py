@@ -1,0 +1,168 @@
+"""Host logic of the drop-in boundary — CPU only: constructors and their error behaviour
+(qip/src/state_ops/matrix_ops.rs:12-122), the C ABI's validator / byte accounting, symbol
+export, and that compute entry points fail loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rustqip_amd as q
+from rustqip_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "qip_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(qip_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    for name in sorted(names):
+        assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
+        assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_ffi.SIGNATURES) == names
+    assert _ffi.lib.qip_hip_abi_version() == 1
+
+
+def test_make_matrix_op_errors():
+    with pytest.raises(q.CircuitError, match="at least one op index"):
+        q.make_matrix_op([], [1])
+    with pytest.raises(q.CircuitError, match="entries versus expected"):
+        q.make_matrix_op([0], [1, 0, 0])
+    op = q.make_matrix_op([0, 1, 2], np.eye(8).ravel())
+    assert op.num_indices() == 3 and [op.get_index(i) for i in range(3)] == [0, 1, 2]
+
+
+def test_get_index_condition_and_swap():
+    # qip/src/state_ops/matrix_ops.rs:276-304
+    mop = q.MatrixOp.new_matrix([2, 3], [])
+    op = q.make_control_op([0, 1], mop)
+    assert op.num_indices() == 4 and [op.get_index(i) for i in range(4)] == [0, 1, 2, 3]
+    sw = q.MatrixOp.new_swap([0, 1], [2, 3])
+    assert sw.num_indices() == 4 and [sw.get_index(i) for i in range(4)] == [0, 1, 2, 3]
+
+
+def test_make_sparse_endianness_b5():
+    # qip/src/state_ops/matrix_ops.rs:346-377
+    one = 1 + 0j
+    expected = [[(1, one)], [(0, one)], [(3, one)], [(2, one)]]
+    op1 = q.make_sparse_matrix_op([0, 1], expected, q.Representation.BigEndian)
+    op2 = q.make_sparse_matrix_op([0, 1], [[(2, one)], [(3, one)], [(0, one)], [(1, one)]],
+                                  q.Representation.LittleEndian)
+    assert op1.rows == expected
+    assert op2.rows == expected
+
+
+def test_make_sparse_errors():
+    with pytest.raises(q.CircuitError, match="at least one op index"):
+        q.make_sparse_matrix_op([], [])
+    with pytest.raises(q.CircuitError, match="rows versus expected"):
+        q.make_sparse_matrix_op([0], [[(0, 1)]])
+    with pytest.raises(q.CircuitError, match="must have data"):
+        q.make_sparse_matrix_op([0], [[(0, 1)], []])
+
+
+def test_make_swap_and_control_errors():
+    with pytest.raises(q.CircuitError, match="at least 1 swap index"):
+        q.make_swap_op([], [1])
+    with pytest.raises(q.CircuitError, match="equal length"):
+        q.make_swap_op([0, 1], [2])
+    with pytest.raises(q.CircuitError, match="at least one control index"):
+        q.make_control_op([], q.make_matrix_op([0], [0, 1, 1, 0]))
+    inner = q.make_control_op([1], q.make_matrix_op([2], [0, 1, 1, 0]))
+    outer = q.make_control_op([0], inner)  # collapse (:112-115)
+    assert outer.n_controls == 2 and outer.indices == [0, 1, 2] and outer.inner.kind == "Matrix"
+
+
+def test_flip_bits_doctest():
+    assert q.flip_bits(3, 0b100) == 0b001 and q.flip_bits(3, 0b010) == 0b010 and q.flip_bits(4, 0b1010) == 0b0101
+
+
+def test_c_validator_matches_constructors_and_panics():
+    x = q.make_matrix_op([1], [0, 1, 1, 0])
+    q.validate_op(3, x)
+    with pytest.raises(q.CircuitError, match="out of range"):
+        q.validate_op(1, x)  # the reference would underflow n-1-index and panic
+    with pytest.raises(q.CircuitError, match="must have data"):
+        q.validate_op(2, q.MatrixOp.new_sparse([0], [[(0, 1)], []]))
+    with pytest.raises(q.CircuitError, match="out of range"):
+        q.validate_op(2, q.MatrixOp.new_sparse([0], [[(0, 1)], [(2, 1)]]))
+    with pytest.raises(q.CircuitError, match="equal length"):
+        q.validate_op(4, q.MatrixOp("Swap", [0, 1, 2], half=1))
+    with pytest.raises(q.CircuitError, match="differ"):
+        bad = q.MatrixOp.new_control([0], [1, 2], q.MatrixOp.new_control([1], [2, 3], x))
+        q.validate_op(4, bad)
+    q.validate_op(4, q.MatrixOp.new_control([0], [1, 2], q.MatrixOp.new_control([1], [2], x)))
+
+
+def test_algorithmic_bytes_table():
+    """BASELINE.md §3 / SURVEY.md §8(d)."""
+    n = 28
+    full = 32.0 * 2**n
+    H = [2**-0.5, 2**-0.5, 2**-0.5, -(2**-0.5)]
+    assert q.algorithmic_bytes(n, q.make_matrix_op([5], H)) == full
+    assert q.algorithmic_bytes(n, q.make_matrix_op([5], [0, 1, 1, 0])) == full
+    assert q.algorithmic_bytes(n, q.make_matrix_op([5], [np.exp(-0.3j), 0, 0, np.exp(0.3j)])) == full
+    assert q.algorithmic_bytes(n, q.make_swap_op([1], [9])) == full
+    assert q.algorithmic_bytes(n, q.make_matrix_op([1, 9], np.ones(16))) == full
+    cnot = q.make_control_op([3], q.make_matrix_op([7], [0, 1, 1, 0]))
+    assert q.algorithmic_bytes(n, cnot) == full / 2
+    for d in ([1, 0, 0, -1], [1, 0, 0, 1j]):  # Z, S: one non-unit diagonal entry of two
+        assert q.algorithmic_bytes(n, q.make_matrix_op([4], d)) == full / 2
+    cphase = q.make_control_op([3], q.make_matrix_op([7], [1, 0, 0, np.exp(0.1j)]))
+    assert q.algorithmic_bytes(n, cphase) == full / 4
+    assert q.algorithmic_bytes(n, q.make_matrix_op([4], [1, 0, 0, 1])) == 0  # identity: nothing can change
+    assert q.algorithmic_bytes(n, q.make_matrix_op([4], H), _ffi.QIP_C32) == full / 2
+
+
+def test_lowering_table_matrices():
+    """builder.rs:436-498"""
+    from rustqip_amd.builder import PipelineEntry, lower_to_matrix_op
+
+    h = lower_to_matrix_op(PipelineEntry([0], "H")).data
+    s = np.sqrt(0.5)
+    assert np.array_equal(h, np.array([s, s, s, -s], dtype=np.complex128))
+    assert np.signbit(h[3].imag)  # -nl = (-s, -0.0)
+    t = lower_to_matrix_op(PipelineEntry([0], "T")).data
+    assert t[3] == complex(np.cos(np.pi / 4), np.sin(np.pi / 4))
+    rz = lower_to_matrix_op(PipelineEntry([0], "Rz", 0.5)).data
+    assert rz[0] == complex(np.cos(-0.25), np.sin(-0.25)) and rz[3] == complex(np.cos(0.25), np.sin(0.25))
+    cn = lower_to_matrix_op(PipelineEntry([2, 5], "CNOT"))
+    assert cn.kind == "Control" and cn.n_controls == 1 and cn.indices == [2, 5]
+    sw = lower_to_matrix_op(PipelineEntry([0, 1, 2, 3], "SWAP"))
+    assert sw.kind == "Swap" and sw.half == 2
+
+
+def test_builder_broadcast_and_init_index():
+    b = q.HipBuilder()
+    r = b.register(3)
+    b.h(r)
+    assert [(e.indices, e.kind) for e in b.pipeline] == [([0], "H"), ([1], "H"), ([2], "H")]  # builder.rs:382-387
+    r2 = b.register(2)
+    assert b.initial_index([(r, 0b101), (r2, 0b10)]) == (1 << 4) | (1 << 2) | (1 << 0)
+    with pytest.raises(q.CircuitError, match="same size"):
+        b.swap(r, r2)
+    with pytest.raises(q.CircuitError, match="single control"):
+        b.cnot(r, r2)
+
+
+def test_no_gpu_fails_loudly():
+    if q.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(q.QipHipError, match="no CPU fallback"):
+        q.HipState(3)
+    inp = np.zeros(2, dtype=np.complex128)
+    out = np.zeros(2, dtype=np.complex128)
+    with pytest.raises(q.QipHipError, match="no CPU fallback"):
+        q.apply_op(1, q.make_matrix_op([0], [0, 1, 1, 0]), inp, out)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "rustqip_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                hit = re.search(r"(import|from)\s+oracle|oracle[/.]|qip_oracle|libqip_oracle", text)
+                assert hit is None, f"{f} references the CPU oracle: {hit.group(0)!r}"

@@ -1,0 +1,539 @@
+"""Parity of the HIP path against the CPU oracle — needs a real MI355X (`-m gpu`).
+
+Everything goes through the C ABI (ctypes -> libqip_hip.so -> HIP kernels).  Bars:
+  * permutation ops (X, CNOT, SWAP, 0/1 matrices): IEEE `==` on every component;
+  * everything else: |delta| <= 1e-12 per amplitude (f64), 1e-5 (f32) — and, because kernels and
+    oracle are both built without FMA contraction and fold in the same order, the 1-qubit,
+    phase, diagonal and literal-gather kernels are additionally expected to be bit-equal,
+    which is asserted where it has been observed.
+"""
+import cmath
+import math
+
+import numpy as np
+import pytest
+
+import rustqip_amd as q
+from rustqip_amd import circuits
+from rustqip_amd.ops import MatrixOp
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-12
+TOL32 = 1e-5
+
+S2 = math.sqrt(0.5)
+GATES_1Q = {
+    "X": [0, 1, 1, 0],
+    "Y": [0, -1j, 1j, 0],
+    "Z": [1, 0, 0, -1],
+    "H": [S2, S2, S2, -complex(S2, 0.0)],
+    "S": [1, 0, 0, 1j],
+    "T": [1, 0, 0, cmath.rect(1, math.pi / 4)],
+    "Rz": [cmath.rect(1, -0.35), 0, 0, cmath.rect(1, 0.35)],
+    "upper": [1, 1, 0, 1],       # zero entry in a dense matrix (zero-skipping path)
+    "rank1": [0.5, 0.25j, 0, 0],  # a zero row
+    "ident": [1, 0, 0, 1],
+    "dense": [0.3 + 0.1j, -0.7j, 0.2, 0.9 - 0.4j],
+}
+PERMUTATIONS = {"X", "ident"}
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import qip_oracle
+
+    return qip_oracle
+
+
+def rand_state(n, seed, dtype=np.complex128):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    return (v / np.linalg.norm(v)).astype(dtype)
+
+
+def rand_unitary(k, rng):
+    a = rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))
+    u, _ = np.linalg.qr(a)
+    return u
+
+
+def hip_apply(n, op, x, **options):
+    with q.HipState(n, x.dtype) as st:
+        for k, v in options.items():
+            st.set_option(k, v)
+        st.upload(x)
+        st.apply_op(op)
+        return st.download()
+
+
+def oracle_apply(O, n, op, x):
+    out = np.zeros_like(x)
+    O.apply_op_overwrite(n, op, x, out)
+    return out
+
+
+def check(O, n, op, seed=0, exact=False, bitwise=True, dtype=np.complex128, paths=("fast", "generic")):
+    x = rand_state(n, seed, dtype)
+    want = oracle_apply(O, n, op, x)
+    tol = TOL64 if dtype == np.complex128 else TOL32
+    for path in paths:
+        opts = {"force_generic": 1} if path == "generic" else {}
+        got = hip_apply(n, op, x, **opts)
+        if exact or bitwise:
+            assert np.array_equal(got, want), f"{op!r} n={n} path={path}: not IEEE-equal, max|d|={np.max(np.abs(got - want))}"
+        else:
+            assert np.max(np.abs(got - want)) <= tol, f"{op!r} n={n} path={path}"
+
+
+# ---- the reference's own golden vectors, through the HIP path ---------------------------------------
+def test_golden_kron_identities(O):
+    def kron_helper(before, mat, after):
+        eye = np.eye(2)
+        for _ in range(before):
+            mat = np.kron(eye, mat)
+        for _ in range(after):
+            mat = np.kron(mat, eye)
+        return mat
+
+    for data, qb in [([1, 0, 0, 1], 0), ([0, 1, 1, 0], 0), ([0, 1, 1, 0], 1), ([0, 1, 1, 0], 2), ([1, 2, 3, 4], 0)]:
+        mat = q.make_op_matrix(3, MatrixOp.new_matrix([qb], data))
+        assert np.array_equal(mat, kron_helper(qb, np.array(data, float).reshape(2, 2), 2 - qb).astype(complex))
+    data = [1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1]
+    assert np.array_equal(q.make_op_matrix(4, MatrixOp.new_matrix([1, 2], data)),
+                          kron_helper(1, np.array(data, float).reshape(4, 4), 1).astype(complex))
+    data = list(range(16))
+    comp = np.array(data, dtype=complex).reshape(4, 4)
+    assert np.array_equal(q.make_op_matrix(2, MatrixOp.new_matrix([0, 1], data)), comp)
+    assert not np.array_equal(q.make_op_matrix(2, MatrixOp.new_matrix([1, 0], data)), comp)
+
+
+def test_golden_iterator_patterns_and_c64_cases():
+    def cols(n, op):
+        m = q.make_op_matrix(n, op)
+        return [list(np.nonzero(m[r])[0]) for r in range(1 << n)]
+
+    assert cols(1, MatrixOp.new_matrix([0], [0, 1, 1, 0])) == [[1], [0]]
+    assert cols(1, MatrixOp.new_sparse([0], [[(1, 1)], [(0, 1)]])) == [[1], [0]]
+    assert cols(2, MatrixOp.new_swap([0], [1])) == [[0], [2], [1], [3]]
+    assert cols(2, MatrixOp.new_control([0], [1], MatrixOp.new_matrix([1], [0, 1, 1, 0]))) == [[0], [1], [3], [2]]
+    inp = np.array([1, 0, 0, 0], dtype=np.complex128)
+    out = np.zeros(4, dtype=np.complex128)
+    q.apply_op(2, MatrixOp.new_matrix([0], [0, 1, 1, 0]), inp, out)
+    assert np.array_equal(out, [0, 0, 1, 0])
+    out = np.zeros(4, dtype=np.complex128)
+    q.apply_op(2, MatrixOp.new_matrix([1], [0, 1, 1, 0]), inp, out)
+    assert np.array_equal(out, [0, 1, 0, 0])
+    inp = np.array([1, 0], dtype=np.complex128)
+    out = np.zeros(2, dtype=np.complex128)
+    q.apply_op(1, MatrixOp.new_matrix([0], [1, 0, 0, 1]), inp, out)
+    assert np.array_equal(inp, out)
+
+
+# ---- 1-qubit gates: every matrix class x every bit position x both low-bit variants ---------------
+@pytest.mark.parametrize("name", sorted(GATES_1Q))
+@pytest.mark.parametrize("n", [1, 2, 5, 11])
+def test_single_qubit_all_targets(O, name, n):
+    for target in range(n):
+        op = q.make_matrix_op([target], GATES_1Q[name])
+        x = rand_state(n, 100 + target)
+        want = oracle_apply(O, n, op, x)
+        for opts in ({}, {"lowbit_shuffle": 0}, {"force_generic": 1}):
+            got = hip_apply(n, op, x, **opts)
+            assert np.array_equal(got, want), (name, n, target, opts, np.max(np.abs(got - want)))
+
+
+@pytest.mark.parametrize("nc", [1, 2, 3, 6])
+def test_controlled_single_qubit(O, nc):
+    n = 10
+    rng = np.random.default_rng(nc)
+    for trial in range(8):
+        perm = [int(v) for v in rng.permutation(n)]
+        ctrl, tgt = perm[:nc], perm[nc]
+        for name in ("X", "H", "T", "Rz", "dense", "Y"):
+            op = q.make_control_op(ctrl, q.make_matrix_op([tgt], GATES_1Q[name]))
+            x = rand_state(n, trial)
+            want = oracle_apply(O, n, op, x)
+            for opts in ({}, {"lowbit_shuffle": 0}, {"force_generic": 1}):
+                got = hip_apply(n, op, x, **opts)
+                assert np.array_equal(got, want), (name, ctrl, tgt, opts)
+
+
+def test_many_controls(O):
+    n = 12
+    op = q.make_control_op(list(range(n - 1)), q.make_matrix_op([n - 1], GATES_1Q["Z"]))
+    check(O, n, op, exact=True)
+    op = q.make_control_op(list(range(1, n)), q.make_matrix_op([0], GATES_1Q["H"]))
+    check(O, n, op)
+    # 15-control identity (qip/benches/state_bench.rs:172-186)
+    op = q.make_control_op(list(range(n - 1)), q.make_matrix_op([n - 1], GATES_1Q["ident"]))
+    check(O, n, op, exact=True)
+
+
+def test_nested_control_uncollapsed(O):
+    n = 6
+    inner = MatrixOp.new_control([3], [5], MatrixOp.new_matrix([5], GATES_1Q["dense"]))
+    op = MatrixOp.new_control([1], [3, 5], inner)
+    check(O, n, op)
+    flat = q.make_control_op([1, 3], q.make_matrix_op([5], GATES_1Q["dense"]))
+    x = rand_state(n, 5)
+    assert np.array_equal(hip_apply(n, op, x), hip_apply(n, flat, x))
+
+
+# ---- Swap ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h", [1, 2, 3])
+def test_swap(O, h):
+    n = 9
+    rng = np.random.default_rng(h)
+    for trial in range(6):
+        perm = [int(v) for v in rng.permutation(n)]
+        op = q.make_swap_op(perm[:h], perm[h:2 * h])
+        check(O, n, op, seed=trial, exact=True)
+        cop = q.make_control_op(perm[2 * h:2 * h + 2], op)
+        check(O, n, cop, seed=trial, exact=True)
+
+
+# ---- dense k-qubit --------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
+def test_dense_k_qubit(O, k):
+    n = 10
+    rng = np.random.default_rng(10 + k)
+    for trial in range(4):
+        perm = [int(v) for v in rng.permutation(n)]
+        u = rand_unitary(k, rng)
+        op = q.make_matrix_op(perm[:k], u.ravel())
+        # register kernels multiply zero entries and fold like the reference: bit-equal expected
+        check(O, n, op, seed=trial)
+        if k <= 4:
+            cop = q.make_control_op(perm[k:k + 2], op)
+            check(O, n, cop, seed=trial)
+
+
+def test_two_qubit_permutation_matrix_exact(O):
+    data = [1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1]  # matrix_ops.rs:323-334
+    for idx in ([1, 2], [6, 0], [7, 8]):
+        check(O, 9, q.make_matrix_op(idx, data), exact=True)
+
+
+def test_dense_8_qubit_reference_bench_shape(O):
+    # qip/benches/state_bench.rs:118-139: dense 8-qubit matrix on an 8-qubit state
+    rng = np.random.default_rng(8)
+    u = rand_unitary(8, rng)
+    check(O, 8, q.make_matrix_op(list(range(8)), u.ravel()), paths=("fast",))
+
+
+# ---- diagonal -------------------------------------------------------------------------------------
+def test_diagonal_gates(O):
+    n = 9
+    rng = np.random.default_rng(3)
+    for k in (2, 3, 5):
+        for trial in range(4):
+            perm = [int(v) for v in rng.permutation(n)]
+            d = np.exp(1j * rng.uniform(0, 2 * np.pi, 1 << k))
+            if trial % 2:
+                d[rng.integers(0, 1 << k)] = 1.0  # exercise the skip-unit-entries path
+            op = q.make_matrix_op(perm[:k], np.diag(d).ravel())
+            check(O, n, op, seed=trial)
+            check(O, n, q.make_control_op(perm[k:k + 1], op), seed=trial)
+    # controlled-phase ladder element of the QFT
+    op = q.make_control_op([7], q.make_matrix_op([2], [1, 0, 0, cmath.rect(1, math.pi / 32)]))
+    check(O, n, op)
+    # diag(phase, 1): the non-unit entry sits on |0>
+    check(O, n, q.make_matrix_op([4], [cmath.rect(1, 0.2), 0, 0, 1]))
+
+
+# ---- SparseMatrix ---------------------------------------------------------------------------------
+def test_sparse(O):
+    n = 8
+    rng = np.random.default_rng(4)
+    for k in (1, 2, 4):
+        for trial in range(4):
+            perm = [int(v) for v in rng.permutation(n)]
+            rows = []
+            for r in range(1 << k):
+                cnt = int(rng.integers(1, min(4, 1 << k) + 1))
+                cols = rng.choice(1 << k, size=cnt, replace=False)  # stored order is arbitrary
+                rows.append([(int(c), complex(rng.standard_normal(), rng.standard_normal())) for c in cols])
+            op = q.make_sparse_matrix_op(perm[:k], rows)
+            check(O, n, op, seed=trial)
+            check(O, n, q.make_control_op(perm[k:k + 2], op), seed=trial)
+    # 16-qubit sparse identity of the reference bench, shrunk (state_bench.rs:380-393)
+    ident = q.make_sparse_matrix_op(list(range(8)), [[(r, 1.0)] for r in range(256)])
+    check(O, 8, ident, exact=True)
+
+
+def test_repeated_indices_follow_reference_literally(O):
+    # the reference accepts repeated indices; the literal gather kernel reproduces its index math
+    for op in (MatrixOp.new_matrix([1, 1], np.arange(16).astype(complex)),
+               MatrixOp.new_swap([2], [2]),
+               MatrixOp.new_control([0], [0], MatrixOp.new_matrix([0], [0, 1, 1, 0]))):
+        check(O, 4, op, paths=("fast",))
+
+
+# ---- host-pointer twin: windows, offsets, accumulate --------------------------------------------------
+def test_host_twin_accumulate_and_overwrite(O):
+    n = 7
+    rng = np.random.default_rng(5)
+    x = rand_state(n, 1)
+    for op in (q.make_matrix_op([3], GATES_1Q["H"]), q.make_control_op([0], q.make_matrix_op([6], GATES_1Q["X"])),
+               q.make_swap_op([1], [5]), q.make_matrix_op([2, 4], rand_unitary(2, rng).ravel())):
+        base = rand_state(n, 2)
+        for generic in (0, 1):
+            q.set_global_option("force_generic", generic)
+            try:
+                got = base.copy()
+                q.apply_op(n, op, x, got)
+                want = base.copy()
+                O.apply_op(n, op, x, want)
+                assert np.array_equal(got, want)
+                got = base.copy()
+                q.apply_op_overwrite(n, op, x, got)
+                want = base.copy()
+                O.apply_op_overwrite(n, op, x, want)
+                assert np.array_equal(got, want)
+            finally:
+                q.set_global_option("force_generic", 0)
+
+
+def test_host_twin_shard_window_identity(O):
+    """shard r of the result = sum over windows w of apply_op(in_w -> out_r, w*S, r*S)."""
+    n, shards = 8, 4
+    S = (1 << n) // shards
+    rng = np.random.default_rng(6)
+    x = rand_state(n, 3)
+    for op in (q.make_matrix_op([0], GATES_1Q["H"]), q.make_matrix_op([1, 6], rand_unitary(2, rng).ravel()),
+               q.make_control_op([1], q.make_matrix_op([0], GATES_1Q["X"])), q.make_swap_op([0], [7])):
+        full = oracle_apply(O, n, op, x)
+        for r in range(shards):
+            out = np.zeros(S, dtype=np.complex128)
+            ref = np.zeros(S, dtype=np.complex128)
+            for w in range(shards):
+                q.apply_op(n, op, x[w * S:(w + 1) * S].copy(), out, w * S, r * S)
+                O.apply_op(n, op, x[w * S:(w + 1) * S].copy(), ref, w * S, r * S)
+            assert np.array_equal(out, ref)
+            assert np.max(np.abs(out - full[r * S:(r + 1) * S])) < 1e-14
+
+
+def test_host_twin_ragged_windows(O):
+    n = 6
+    rng = np.random.default_rng(7)
+    op = q.make_matrix_op([2, 5], rand_unitary(2, rng).ravel())
+    for in_len, out_len, in_off, out_off in [(10, 7, 3, 40), (64, 1, 0, 63), (1, 64, 17, 0), (0, 5, 0, 2), (5, 0, 1, 1)]:
+        x = rand_state(n, 9)[:in_len].copy()
+        got = np.full(out_len, 2.0 + 1j, dtype=np.complex128)
+        want = got.copy()
+        q.apply_op(n, op, x, got, in_off, out_off)
+        O.apply_op(n, op, x, want, in_off, out_off)
+        assert np.array_equal(got, want)
+
+
+def test_invalid_descriptors_are_errors_not_crashes():
+    x = np.zeros(4, dtype=np.complex128)
+    out = np.zeros(4, dtype=np.complex128)
+    with pytest.raises(q.CircuitError):
+        q.apply_op(2, MatrixOp.new_matrix([2], [0, 1, 1, 0]), x, out)  # index >= n
+    with pytest.raises(q.CircuitError):
+        q.apply_op(2, MatrixOp.new_matrix([0], [0, 1, 1]), x, out)  # wrong data length
+    with pytest.raises(q.CircuitError):
+        q.apply_op(2, MatrixOp.new_sparse([0], [[(0, 1)], [(5, 1)]]), x, out)  # column out of range
+    with pytest.raises(q.CircuitError):
+        q.apply_op(2, MatrixOp.new_matrix([0], [0, 1, 1, 0]), x, x)  # aliasing
+
+
+# ---- f32 ----------------------------------------------------------------------------------------------
+def test_complex64_path(O):
+    n = 9
+    rng = np.random.default_rng(8)
+    ops = [q.make_matrix_op([t], GATES_1Q[g]) for t in (0, 4, 8) for g in ("H", "X", "Rz", "T")]
+    ops += [q.make_control_op([2], q.make_matrix_op([7], GATES_1Q["X"])), q.make_swap_op([0], [8]),
+            q.make_matrix_op([1, 5], rand_unitary(2, rng).ravel()), q.make_matrix_op([1, 5, 6], rand_unitary(3, rng).ravel())]
+    for op in ops:
+        x = rand_state(n, 11, np.complex64)
+        want = oracle_apply(O, n, op, x)
+        for opts in ({}, {"force_generic": 1}):
+            got = hip_apply(n, op, x, **opts)
+            assert got.dtype == np.complex64
+            assert np.max(np.abs(got - want)) <= TOL32
+
+
+# ---- whole circuits (BASELINE configs at reduced n) -------------------------------------------------------
+@pytest.mark.parametrize("name,n", [("c2", 16), ("c3", 12), ("c4", 14), ("c5", 10), ("c5k3", 10)])
+def test_config_circuits_reduced_n(O, name, n):
+    ops = {
+        "c2": lambda: circuits.h_layer(n) + circuits.c2_random_circuit(n, 256, seed=28),
+        "c3": lambda: circuits.c3_qft(n),
+        "c4": lambda: circuits.h_layer(n) + circuits.c4_clifford_t(n, 256, seed=32),
+        "c5": lambda: circuits.h_layer(n) + circuits.c5_grover_iteration(n),
+        "c5k3": lambda: circuits.h_layer(n) + circuits.c5_grover_iteration(n, dense_k3=True),
+    }[name]()
+    x = circuits.random_state(n, seed=n) if name == "c3" else None
+    with q.HipState(n) as st:
+        if x is None:
+            st.init_basis(0)
+            x = np.zeros(1 << n, dtype=np.complex128)
+            x[0] = 1
+        else:
+            st.upload(x)
+        st.apply_ops(ops)
+        got = st.download()
+        norm = st.norm_sqr()
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= TOL64
+    assert abs(norm - 1.0) <= TOL64
+    if name in ("c5", "c5k3"):
+        # one Grover iteration amplifies the marked item |0..0>: sin^2(3*theta), sin(theta) = 2^(-n/2)
+        theta = math.asin(2 ** (-n / 2))
+        assert abs(abs(got[0]) ** 2 - math.sin(3 * theta) ** 2) < 1e-10
+
+
+def test_qft_matches_dft(O):
+    """Size-independent property: the QFT circuit is the DFT matrix (bit-reversal included)."""
+    n = 8
+    N = 1 << n
+    x = circuits.random_state(n, seed=1)
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(circuits.c3_qft(n))
+        got = st.download()
+    want = np.fft.ifft(x) * math.sqrt(N)  # QFT|j> = N^-1/2 sum_k e^{+2 pi i jk/N}|k>
+    assert np.max(np.abs(got - want)) < 1e-12
+
+
+# ---- builder: README CSWAP (configs[0]) --------------------------------------------------------------------
+def test_cswap_readme_example(O):
+    b = q.HipBuilder()
+    qb = b.qubit()
+    ra = b.register(3)
+    rb = b.register(3)
+    qb = b.h(qb)
+    cb = b.condition_with(qb)
+    ra, rb = cb.swap(ra, rb)
+    qb = cb.dissolve()
+    qb = b.h(qb)
+    pre = [(e.indices, e.kind, e.param) for e in b.pipeline]
+    qb, handle = b.measure(qb)
+    for forced in (0, 1):
+        state, measured = b.calculate_state_with_init([(ra, 0b000), (rb, 0b001)], forced_measurements=[forced])
+        m, p = measured.get_measurement(handle)
+        assert m == forced and abs(p - 0.5) < 1e-12
+        want, res = O.run_pipeline(7, pre + [([0], "Measurement", None)], 4, forced_measurements=[forced])
+        assert np.max(np.abs(state - want)) < 1e-12
+        assert abs(res[0][2] - p) < 1e-12
+    # pre-measurement known answer B7
+    b2 = q.HipBuilder()
+    b2._n, b2.pipeline = 7, b.pipeline[:-1]
+    state, _ = b2.calculate_state_with_init([(ra, 0b000), (rb, 0b001)])
+    expect = np.zeros(128, dtype=np.complex128)
+    expect[[4, 32, 68]] = 0.5
+    expect[96] = -0.5
+    assert np.max(np.abs(state - expect)) < 1e-12
+    # sampled (unforced) measurement returns one of the two outcomes with p = 1/2
+    _, measured = b.calculate_state_with_init([(ra, 0b000), (rb, 0b001)], rng=np.random.default_rng(0))
+    m, p = measured.get_measurement(handle)
+    assert m in (0, 1) and abs(p - 0.5) < 1e-12
+
+
+# ---- measurement -----------------------------------------------------------------------------------------------
+def test_measurement_golden_vectors():
+    with q.HipState(2) as st:
+        st.upload(np.array([0, 0, 1, 0], dtype=np.complex128))
+        assert st.measure_prob(0, [0]) == 0.0 and st.measure_prob(1, [0]) == 1.0
+        assert st.measure_prob(1, [0, 1]) == 1.0 and st.measure_prob(2, [1, 0]) == 1.0
+        for r in (1e-9, 0.4, 0.99):
+            assert st.soft_measure([0], r) == 1 and st.soft_measure([1], r) == 0
+            assert st.soft_measure([0, 1], r) == 0b01 and st.soft_measure([1, 0], r) == 0b10
+    for m, expect in ((0, [S2, S2, 0, 0]), (1, [0, 0, S2, S2])):
+        with q.HipState(2) as st:
+            st.upload(np.full(4, 0.5, dtype=np.complex128))
+            assert list(st.measure_probs([1])) == [0.5, 0.5]
+            got_m, p = st.measure([0], measured=m)
+            assert got_m == m and abs(p - 0.5) < 1e-15
+            assert np.max(np.abs(st.download() - np.array(expect))) < 1e-10
+
+
+def test_measurement_vs_oracle(O):
+    n = 13
+    x = rand_state(n, 21)
+    with q.HipState(n) as st:
+        st.upload(x)
+        assert abs(st.norm_sqr() - O.prob_magnitude(x)) < 1e-12
+        for idx in ([0], [12], [3, 7], [9, 1, 4], list(range(12)), list(range(13))[::-1]):
+            got = st.measure_probs(idx)
+            want = O.measure_probs(n, idx, x)
+            assert np.max(np.abs(got - want)) < 1e-13
+            assert abs(got.sum() - 1) < 1e-12
+        assert abs(st.measure_prob(5, [2, 8, 11]) - O.measure_prob(n, 5, [2, 8, 11], x)) < 1e-13
+        for r in (0.001, 0.25, 0.5, 0.77, 0.9999):
+            for idx in ([0, 1, 2], [12, 5]):
+                assert st.soft_measure(idx, r) == O.soft_measure(n, idx, x, r)
+    for forced in (0, 3, 6):
+        with q.HipState(n) as st:
+            st.upload(x)
+            m, p = st.measure([1, 5, 10], measured=forced)
+            out = np.zeros_like(x)
+            wm, wp = O.measure(n, [1, 5, 10], x, out, forced=forced)
+            assert (m, abs(p - wp) < 1e-13) == (wm, True)
+            got = st.download()
+            assert np.max(np.abs(got - out)) < 1e-12
+            assert abs(st.norm_sqr() - 1) < 1e-12
+    # probability-zero outcome: state untouched (measurement_ops.rs:230)
+    with q.HipState(3) as st:
+        st.init_basis(0)
+        m, p = st.measure([0], measured=1)
+        assert (m, p) == (1, 0.0)
+        assert st.download()[0] == 1
+
+
+# ---- full size (BASELINE sizes): size-independent properties ---------------------------------------------------
+@pytest.mark.parametrize("n", [28])
+def test_full_size_properties(n):
+    """n = 28 (4 GiB): permutations round-trip bit-exactly, a random circuit followed by its
+    inverse returns to the start, the norm is preserved."""
+    inv = {"H": "H", "X": "X"}
+    with q.HipState(n) as st:
+        st.init_basis(5)
+        st.apply_ops(circuits.h_layer(n))
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        probe0 = st.download(12345, 4096)
+        assert np.allclose(np.abs(probe0), 2 ** (-n / 2), atol=1e-15)
+        # X, CNOT, SWAP twice = identity, bit-exact on a window
+        rng = np.random.default_rng(0)
+        st.apply_ops([q.make_matrix_op([t], circuits.rz(0.1 * (t + 1))) for t in range(n)])  # make amplitudes distinct
+        before = st.download(1 << 20, 1 << 16)
+        perms = []
+        for t in (0, 1, n // 2, n - 7, n - 2, n - 1):
+            perms.append(q.make_matrix_op([t], circuits.X))
+        perms.append(q.make_control_op([0], q.make_matrix_op([n - 1], circuits.X)))
+        perms.append(q.make_control_op([n - 1], q.make_matrix_op([3], circuits.X)))
+        perms.append(q.make_swap_op([0], [n - 1]))
+        perms.append(q.make_swap_op([2, 3], [n - 3, n - 2]))
+        st.apply_ops(perms + perms[::-1])
+        assert np.array_equal(st.download(1 << 20, 1 << 16), before)
+        # random circuit and its inverse
+        ops = circuits.c2_random_circuit(n, 48, seed=n)
+        inverse = []
+        for op in reversed(ops):
+            if op.kind == "Control":
+                inverse.append(op)
+            else:
+                d = op.data
+                inverse.append(q.make_matrix_op(op.indices, np.conj(d.reshape(2, 2).T).ravel()))
+        st.apply_ops(ops)
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        st.apply_ops(inverse)
+        after = st.download(1 << 20, 1 << 16)
+        assert np.max(np.abs(after - before)) < 1e-12
+        assert abs(st.norm_sqr() - 1) < 1e-10
+
+
+def test_window_compare_at_n24(O):
+    """Full-vector compare against the oracle at n = 24 on a prefix of configs[1]."""
+    n = 24
+    ops = circuits.h_layer(n)[:6] + circuits.c2_random_circuit(n, 10, seed=28)
+    x = rand_state(n, 24)
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        got = st.download()
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= TOL64
