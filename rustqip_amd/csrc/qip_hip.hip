@@ -689,24 +689,34 @@ template <typename F> static void dispatch_np(uint32_t npos, F&& f) {
   }
 }
 
-constexpr int kU = 4;  // independent 16-B accesses per stream per lane
+// States that cannot stay in the 256-MiB Infinity Cache stream with non-temporal accesses.
+static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_bytes >= (1ull << 30); }
 
-// LAUNCH_STREAMING(kernel, T, count, args...): <U=4, no guard> when the power-of-two work-item
-// count fills whole blocks, else the guarded single-item shape.
-#define LAUNCH_STREAMING(KERNEL, T, COUNT, INS, ...)                                              \
-  dispatch_np((INS).npos, [&](auto np_) {                                                         \
-    constexpr int NP = decltype(np_)::value;                                                      \
-    if ((COUNT) >= (uint64_t)kBlock * kU) {                                                       \
-      hipLaunchKernelGGL((KERNEL<T, kU, false, NP>), dim3(grid_for((COUNT), kBlock * kU)),       \
-                         dim3(kBlock), 0, s->stream, __VA_ARGS__);                                \
-    } else {                                                                                      \
-      hipLaunchKernelGGL((KERNEL<T, 1, true, NP>), dim3(grid_for((COUNT), kBlock)), dim3(kBlock), \
-                         0, s->stream, __VA_ARGS__);                                              \
-    }                                                                                             \
+// LAUNCH_STREAMING(kernel, T, U, count, ins, args...): the unguarded <U> shape with the 32-KiB lane
+// spacing when the power-of-two work-item count allows it, else the guarded single-item shape.
+#define LAUNCH_STREAMING(KERNEL, T, UU, COUNT, INS, ...)                                           \
+  dispatch_np((INS).npos, [&](auto np_) {                                                          \
+    constexpr int NP = decltype(np_)::value;                                                       \
+    if ((COUNT) >= ((uint64_t)(UU) << kStrideShift)) {                                             \
+      if (use_nt(s))                                                                               \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP>), dim3(grid_for((COUNT), kBlock * (UU))), \
+                           dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
+      else                                                                                         \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP>), dim3(grid_for((COUNT), kBlock * (UU))), \
+                           dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
+    } else {                                                                                       \
+      hipLaunchKernelGGL((KERNEL<T, 1, true, false, NP>), dim3(grid_for((COUNT), kBlock)),        \
+                         dim3(kBlock), 0, s->stream, __VA_ARGS__);                                 \
+    }                                                                                              \
   })
 
+// independent accesses per stream per lane (tools/tune_gate1q.hip, MI355X, n = 30)
+constexpr int kUPair = 2;   // two streams per item: 4 loads in flight per lane
+constexpr int kUXlane = 4;
+constexpr int kUPhase = 2;
+
 template <typename T>
-static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
   const uint32_t n = s->n;
   const uint32_t tpos = p.opos[0];
   Mat2<T> g;
@@ -721,14 +731,15 @@ static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const uint64_t namps_sub = 1ull << (n - (uint32_t)p.cpos.size());
   if (s->lowbit_shuffle && tb < 6 && namps_sub >= 64) {
     Ins ins = make_ins(p.cpos, cmask);
-    LAUNCH_STREAMING(k_gate1q_xlane, T, namps_sub, ins, st, namps_sub, ins, tb, g);
+    *actual_cls = KC_GATE1Q_XLANE;
+    LAUNCH_STREAMING(k_gate1q_xlane, T, kUXlane, namps_sub, ins, st, namps_sub, ins, tb, g);
   } else {
     std::vector<uint32_t> pos = p.cpos;
     pos.push_back(tpos);
     Ins ins = make_ins(pos, cmask);
     const uint64_t npairs = namps_sub >> 1;
     const uint64_t tmask = 1ull << tpos;
-    LAUNCH_STREAMING(k_gate1q_pair, T, npairs, ins, st, npairs, ins, tmask, g);
+    LAUNCH_STREAMING(k_gate1q_pair, T, kUPair, npairs, ins, st, npairs, ins, tmask, g);
   }
   HIPCHK(hipGetLastError());
   return QIP_OK;
@@ -746,7 +757,7 @@ static int launch_phase(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   Ins ins = make_ins(pos, ones);
   const uint64_t count = 1ull << (s->n - (uint32_t)pos.size());
   const amp_t<T> value = mk<T>(p.phase[0], p.phase[1]);
-  LAUNCH_STREAMING(k_phase, T, count, ins, st, count, ins, value);
+  LAUNCH_STREAMING(k_phase, T, kUPhase, count, ins, st, count, ins, value);
   HIPCHK(hipGetLastError());
   return QIP_OK;
 }
@@ -761,6 +772,15 @@ static DiagDesc make_diagdesc(const Plan& p) {
 
 template <typename T>
 static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+  if (p.opos.size() == 1) {  // Rz-like: no table, factor picked by the target bit
+    Ins ins1 = make_ins(p.cpos, mask_of(p.cpos));
+    const uint64_t cnt = 1ull << (s->n - (uint32_t)p.cpos.size());
+    const uint64_t tmask = 1ull << p.opos[0];
+    const amp_t<T> d0 = mk<T>(p.table[0], p.table[1]), d1 = mk<T>(p.table[2], p.table[3]);
+    LAUNCH_STREAMING(k_diag1q, T, kUPhase, cnt, ins1, st, cnt, ins1, tmask, d0, d1);
+    HIPCHK(hipGetLastError());
+    return QIP_OK;
+  }
   QCHK(upload_table<T>(s, p.table));
   Ins ins = make_ins(p.cpos, mask_of(p.cpos));
   const uint64_t count = 1ull << (s->n - (uint32_t)p.cpos.size());
@@ -785,7 +805,7 @@ static int launch_swap(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
     Ins ins = make_ins(pos, cmask);
     const uint64_t npairs = 1ull << (s->n - (uint32_t)pos.size());
     const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
-    LAUNCH_STREAMING(k_swap_bits, T, npairs, ins, st, npairs, ins, amask, bmask);
+    LAUNCH_STREAMING(k_swap_bits, T, kUPair, npairs, ins, st, npairs, ins, amask, bmask);
     HIPCHK(hipGetLastError());
   }
   return QIP_OK;
@@ -873,11 +893,12 @@ static int apply_op_t(qip_hip_state* s, const qip_op* op) {
     return QIP_OK;
   }
   ProfRec rec;
+  rec.cls = p.cls;
   if (s->profile) QCHK(prof_begin(s, p.cls, p.alg_bytes, &rec));
   amp_t<T>* st = (amp_t<T>*)s->cur;
   int rc = QIP_OK;
   switch (p.cls) {
-    case KC_GATE1Q_PAIR: rc = launch_gate1q<T>(s, p, st); break;
+    case KC_GATE1Q_PAIR: rc = launch_gate1q<T>(s, p, st, &rec.cls); break;
     case KC_PHASE: rc = launch_phase<T>(s, p, st); break;
     case KC_DIAG: rc = launch_diag<T>(s, p, st); break;
     case KC_SWAP_BITS: rc = launch_swap<T>(s, p, st); break;

@@ -92,29 +92,55 @@ template <typename T> struct Mat2 {
 };
 
 // The streaming kernels below come in two shapes selected by the launcher:
-//   <U = 4, GUARD = false>  work-item count is a multiple of kBlock*U (every count is a
-//                           power of two), no bounds checks, 4 independent 16-B loads per
-//                           stream in flight per lane;
+//   <U, GUARD = false, NT>  the power-of-two work-item count is a multiple of 2^(kStrideShift+log2 U):
+//                           no bounds checks; a block's 256 lanes cover 256 consecutive work items
+//                           (4 contiguous 1-KiB wave rows) and a lane's U items sit 2^kStrideShift
+//                           items = 32 KiB apart.  Measured on MI355X at n = 30 (tools/tune_gate1q.hip,
+//                           profiles/r01_tuning.md): adjacent 4-KiB runs per lane reach ~5.3 TB/s, the
+//                           32-KiB spacing ~6.2 TB/s; 16 KiB or >= 64 KiB spacing is slower again.
+//                           NT = non-temporal loads/stores for states that cannot live in the 256-MiB
+//                           Infinity Cache anyway (+8 % at n = 30; every amplitude is touched once per gate).
 //   <U = 1, GUARD = true>   tiny states.
+constexpr int kStrideShift = 11;  // 2^11 work items x 16 B = 32 KiB between a lane's accesses
+
+template <int LOGU> __device__ __forceinline__ uint64_t work_index(uint32_t u) {
+  constexpr int S = kStrideShift - 8;  // kBlock = 2^8
+  const uint64_t blk = blockIdx.x;
+  return ((blk >> S) << (kStrideShift + LOGU)) | ((uint64_t)u << kStrideShift) |
+         ((blk & ((1u << S) - 1u)) << 8) | threadIdx.x;
+}
+template <int U> struct Log2;
+template <> struct Log2<1> { static constexpr int v = 0; };
+template <> struct Log2<2> { static constexpr int v = 1; };
+template <> struct Log2<4> { static constexpr int v = 2; };
+template <> struct Log2<8> { static constexpr int v = 3; };
+
+template <bool NT, typename A> __device__ __forceinline__ A ldg(const A* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename A> __device__ __forceinline__ void stg(A* p, A v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 // ---- 1-qubit gate, pair per lane ---------------------------------------------
 // Work item = one (|0>,|1>) pair of the target bit inside the all-controls-one subspace.
 // `ins` opens the target bit and every control bit; ormask sets the controls.
 // out0 = m00*a0 + m01*a1 ; out1 = m10*a0 + m11*a1, folded from 0 in column order
 // (matrix_ops.rs:78-93, ops.rs:104-110).
-template <typename T, int U, bool GUARD, int NP>
+template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ st, uint64_t npairs,
                                                         Ins ins, uint64_t tmask, Mat2<T> g) {
   using A = amp_t<T>;
-  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
-  if (GUARD && base >= npairs) return;
+  if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A a0[U], a1[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    i0[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
-    a0[u] = st[i0[u]];
-    a1[u] = st[i0[u] | tmask];
+    i0[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    a0[u] = ldg<NT>(st + i0[u]);
+    a1[u] = ldg<NT>(st + (i0[u] | tmask));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -123,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ s
     if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1[u]));
     if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0[u]));
     if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1[u]));
-    st[i0[u]] = r0;
-    st[i0[u] | tmask] = r1;
+    stg<NT>(st + i0[u], r0);
+    stg<NT>(st + (i0[u] | tmask), r1);
   }
 }
 
@@ -133,12 +159,11 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ s
 // keeps fully contiguous 1-KiB rows: each lane loads ONE amplitude, fetches its partner
 // from lane ^ (1<<tb) and computes only its own output row.  `ins` opens only the
 // control bits.  Requires the work-item count to be a multiple of 64.
-template <typename T, int U, bool GUARD, int NP>
+template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ st, uint64_t namps,
                                                          Ins ins, uint32_t tb, Mat2<T> g) {
   using A = amp_t<T>;
-  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
-  if (GUARD && base >= namps) return;  // whole waves leave together (namps % 64 == 0)
+  if (GUARD && work_index<0>(0) >= namps) return;  // whole waves leave together (namps % 64 == 0)
   const bool hi = (threadIdx.x >> tb) & 1u;  // this lane holds the |1> member
   // row of the gate this lane evaluates: (m_lo, m_hi) multiply (|0> member, |1> member)
   const A m_lo = hi ? g.m[2] : g.m[0];
@@ -149,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
   A own[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    idx[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
-    own[u] = st[idx[u]];
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    own[u] = ldg<NT>(st + idx[u]);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
     A r = czero<A>();
     if (nz_lo) r = cadd(r, cmul(m_lo, lo));
     if (nz_hi) r = cadd(r, cmul(m_hi, hv));
-    st[idx[u]] = r;
+    stg<NT>(st + idx[u], r);
   }
 }
 
@@ -171,45 +196,61 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
 // This is Z/S/T, controlled-phase, multi-controlled Z...: a diagonal gate whose other
 // diagonal entries are exactly 1 leaves those amplitudes untouched (1*x == x), so they
 // are neither read nor written.
-template <typename T, int U, bool GUARD, int NP>
+template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
                                                   amp_t<T> value) {
   using A = amp_t<T>;
-  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
-  if (GUARD && base >= count) return;
+  if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    idx[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
-    x[u] = st[idx[u]];
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    x[u] = ldg<NT>(st + idx[u]);
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) st[idx[u]] = cmul(value, x[u]);
+  for (int u = 0; u < U; ++u) stg<NT>(st + idx[u], cmul(value, x[u]));
+}
+
+// ---- diagonal 1-qubit gate with both entries != 1 (Rz), optionally controlled ----------
+// Amplitude per lane inside the control subspace; the factor is picked by the target bit.
+template <typename T, int U, bool GUARD, bool NT, int NP>
+__global__ __launch_bounds__(kBlock) void k_diag1q(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+                                                   uint64_t tmask, amp_t<T> d0, amp_t<T> d1) {
+  using A = amp_t<T>;
+  if (GUARD && work_index<0>(0) >= count) return;
+  uint64_t idx[U];
+  A x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    x[u] = ldg<NT>(st + idx[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) stg<NT>(st + idx[u], cmul((idx[u] & tmask) ? d1 : d0, x[u]));
 }
 
 // ---- exchange of two index bits (Swap with h = 1, optionally controlled) ---------------
 // SwapOpIterator (qubit_iterators.rs:208-218) yields the single column whose A and B
 // halves are exchanged, with value 1: a pure move.  Only amplitudes whose two bits differ
 // change, so a work item is one (01,10) pair and the other half of the vector is untouched.
-template <typename T, int U, bool GUARD, int NP>
+template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st, uint64_t npairs,
                                                       Ins ins, uint64_t amask, uint64_t bmask) {
   using A = amp_t<T>;
-  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
-  if (GUARD && base >= npairs) return;
+  if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A xa[U], xb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    i0[u] = insert_bits<NP>(base + (uint64_t)u * kBlock, ins);
-    xa[u] = st[i0[u] | amask];
-    xb[u] = st[i0[u] | bmask];
+    i0[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    xa[u] = ldg<NT>(st + (i0[u] | amask));
+    xb[u] = ldg<NT>(st + (i0[u] | bmask));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    st[i0[u] | amask] = xb[u];
-    st[i0[u] | bmask] = xa[u];
+    stg<NT>(st + (i0[u] | amask), xb[u]);
+    stg<NT>(st + (i0[u] | bmask), xa[u]);
   }
 }
 
