@@ -188,15 +188,18 @@ enum KernelClass {
   KC_GATE1Q_XLANE,
   KC_PHASE,
   KC_DIAG,
+  KC_DIAG1Q,
   KC_SWAP_BITS,
   KC_GATE_KQ,
+  KC_GATE_KQ_MFMA,
   KC_GATHER_GENERIC,
   KC_NOOP,
   KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
-    "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",
-    "k_swap_bits",   "k_gate_kq",      "k_gather_generic", "noop_identity"};
+    "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
+    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_gather_generic",
+    "noop_identity"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
 extern "C" const char* qip_hip_kernel_class_name(int cls) {
@@ -234,7 +237,8 @@ static void read_dense(const void* dense, uint64_t count, std::vector<double>* o
   for (uint64_t i = 0; i < count * 2; ++i) (*out)[i] = (double)p[i];
 }
 
-static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers
+static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
+static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5
 static constexpr uint32_t kMaxDiagK = 20;   // diagonal tables shipped to the device
 
 static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p) {
@@ -309,7 +313,8 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     }
     return QIP_OK;
   }
-  if (k <= kMaxRegK) {
+  if (k <= kMaxRegK || k <= kMaxMfmaK) {
+    // the launcher picks the matrix-core form for f64, k in 3..5, when >= 16 groups exist
     p->cls = KC_GATE_KQ;
     p->table = d;
     return QIP_OK;
@@ -360,6 +365,7 @@ struct qip_hip_state {
   int64_t force_generic = 0;
   int64_t profile = 0;
   int64_t lowbit_shuffle = 1;
+  int64_t mfma = 1;
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
   std::vector<ProfRec> pending;
@@ -575,6 +581,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   if (!strcmp(key, "force_generic")) s->force_generic = value;
   else if (!strcmp(key, "profile")) s->profile = value;
   else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
+  else if (!strcmp(key, "mfma")) s->mfma = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
@@ -711,7 +718,8 @@ static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_byt
   })
 
 // independent accesses per stream per lane (tools/tune_gate1q.hip, MI355X, n = 30)
-constexpr int kUPair = 2;   // two streams per item: 4 loads in flight per lane
+constexpr int kUPair = 8;   // two streams per item (the zero-skip branches need the longer load phase)
+constexpr int kUSwap = 4;
 constexpr int kUXlane = 4;
 constexpr int kUPhase = 2;
 
@@ -771,8 +779,9 @@ static DiagDesc make_diagdesc(const Plan& p) {
 }
 
 template <typename T>
-static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
-  if (p.opos.size() == 1) {  // Rz-like: no table, factor picked by the target bit
+static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
+  if (p.opos.size() == 1) {
+    *actual_cls = KC_DIAG1Q;  // Rz-like: no table, factor picked by the target bit
     Ins ins1 = make_ins(p.cpos, mask_of(p.cpos));
     const uint64_t cnt = 1ull << (s->n - (uint32_t)p.cpos.size());
     const uint64_t tmask = 1ull << p.opos[0];
@@ -805,16 +814,97 @@ static int launch_swap(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
     Ins ins = make_ins(pos, cmask);
     const uint64_t npairs = 1ull << (s->n - (uint32_t)pos.size());
     const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
-    LAUNCH_STREAMING(k_swap_bits, T, kUPair, npairs, ins, st, npairs, ins, amask, bmask);
+    LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask);
     HIPCHK(hipGetLastError());
   }
   return QIP_OK;
 }
 
 template <typename T>
-static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
-  QCHK(upload_table<T>(s, p.table));
+static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_t in_len,
+                         amp_t<T>* out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
+                         int accumulate);
+
+// A operand of k_gate_kq_mfma, one double per (tile row block, K-step, lane); see the kernel header.
+static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out) {
   const uint32_t k = (uint32_t)p.opos.size();
+  const uint32_t S = 1u << k, TT = S / 8, KS = S / 2;
+  uint32_t perm_bit[8];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
+  for (uint32_t b = 0; b < k; ++b)
+    for (uint32_t j = 0; j < k; ++j)
+      if (p.opos[j] == tau[b]) perm_bit[b] = k - 1 - j;
+  auto c_of = [&](uint32_t ct) {
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < k; ++b) c |= ((ct >> b) & 1u) << perm_bit[b];
+    return c;
+  };
+  out->assign((size_t)TT * KS * 64, 0.0);
+  for (uint32_t rb = 0; rb < TT; ++rb)
+    for (uint32_t s = 0; s < KS; ++s)
+      for (uint32_t l = 0; l < 64; ++l) {
+        const uint32_t i = l & 15, kk = l >> 4;
+        const uint32_t qp = i & 3, reg = i >> 2, partp = reg & 1, t = reg >> 1;
+        const uint32_t ctp = 4 * (2 * rb + t) + qp, ct = 4 * (s >> 1) + kk, part = s & 1;
+        const size_t e = (size_t)c_of(ctp) * S + c_of(ct);
+        const double re = p.table[2 * e], im = p.table[2 * e + 1];
+        (*out)[((size_t)rb * KS + s) * 64 + l] = partp == 0 ? (part == 0 ? re : -im) : (part == 0 ? im : re);
+      }
+}
+
+static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag);
+  QCHK(ensure_arena(s, afrag.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(s->arena, afrag.data(), afrag.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  MfmaDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
+  const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
+  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * 8);
+  const dim3 grid(blocks), block(kBlock);
+  const double* af = (const double*)s->arena;
+  const bool nt = use_nt(s);
+#define MF(K)                                                                                            \
+  do {                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
+    else hipLaunchKernelGGL((k_gate_kq_mfma<K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+  } while (0)
+  switch (k) {
+    case 3: MF(3); break;
+    case 4: MF(4); break;
+    case 5: MF(5); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "matrix-core kernel for k = %u", k);
+  }
+#undef MF
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+template <typename T>
+static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  const uint32_t used = (uint32_t)(p.opos.size() + p.cpos.size());
+  if constexpr (std::is_same<T, double>::value) {
+    if (s->mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
+      *actual_cls = KC_GATE_KQ_MFMA;
+      return launch_kq_mfma(s, p, st);
+    }
+  }
+  if (k > kMaxRegK) {  // no register form: literal kernel, out of place
+    *actual_cls = KC_GATHER_GENERIC;
+    QCHK(ensure_alt(s));
+    QCHK(launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0, 0, 0));
+    std::swap(s->cur, s->alt);
+    std::swap(s->owns_cur, s->owns_alt);
+    return QIP_OK;
+  }
+  QCHK(upload_table<T>(s, p.table));
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
   Ins ins = make_ins(pos, mask_of(p.cpos));
@@ -900,9 +990,9 @@ static int apply_op_t(qip_hip_state* s, const qip_op* op) {
   switch (p.cls) {
     case KC_GATE1Q_PAIR: rc = launch_gate1q<T>(s, p, st, &rec.cls); break;
     case KC_PHASE: rc = launch_phase<T>(s, p, st); break;
-    case KC_DIAG: rc = launch_diag<T>(s, p, st); break;
+    case KC_DIAG: rc = launch_diag<T>(s, p, st, &rec.cls); break;
     case KC_SWAP_BITS: rc = launch_swap<T>(s, p, st); break;
-    case KC_GATE_KQ: rc = launch_kq<T>(s, p, st); break;
+    case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
     default: {
       QCHK(ensure_alt(s));
       rc = launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0,

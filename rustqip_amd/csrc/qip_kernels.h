@@ -316,6 +316,84 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, u
   }
 }
 
+// ---- dense k-qubit gate on the f64 matrix cores (k = 3, 4, 5) ----------------------------------
+// For k >= 3 the per-group update really is a small complex GEMM: with S = 2^k, the real form
+// [y_re; y_im] = [[G_re, -G_im], [G_im, G_re]] [x_re; x_im] is a (2S x 2S) x (2S x 16) product for 16
+// independent groups, i.e. (S/8)^2 tiles x (S/2) K-steps of v_mfma_f64_16x16x4_f64.  FLOPs per
+// amplitude = 8S against 32 B of traffic (k=3: 2 flop/B, k=5: 8 flop/B; f64 MFMA peak / HBM peak
+// ~ 10 flop/B), so the sweep stays HBM-bound through k = 5 while the VALU form does not.
+//
+// Mapping (one wave = 16 groups x S amplitudes per step; lane l: j = l & 15 group, q = l >> 4):
+//   * sub-index bits are re-ordered by bit position (c~ bit b <-> b-th lowest target position) so
+//     q = c~ & 3 walks the two lowest target bits and each 16-B load instruction covers the longest
+//     contiguous runs the target positions allow; the 16 groups are the 4 lowest non-target bits;
+//   * B operand of K-step s: lane supplies X[row (c~ = 4*(s>>1) + q, part = s&1)][group j], i.e. the
+//     .x / .y of the ONE amplitude it loaded with a 16-B access (no re/im shuffles);
+//   * f64 C/D layout (differs from every other dtype on gfx950): col = lane & 15,
+//     row = (lane >> 4) + 4*reg.  Row (q + 4*reg) of tile rb is assigned to (c~' = 8*rb + 4*(reg>>1) + q,
+//     part = reg & 1), so a lane ends up with re AND im of exactly the amplitudes it loaded and
+//     stores them back in place with 16-B accesses;
+//   * the A operand (gate matrix in that row/column order) is precomputed on the host per lane
+//     (afrag[(rb*KS + s)*64 + lane]) and held in registers across the wave's grid-stride loop.
+// Rounding: an MFMA is a k-ordered fma chain, so results differ from the reference's unfused fold
+// by a few ulp (covered by the 1e-12 bar); 0/1 permutation matrices stay exact for finite data.
+struct MfmaDesc {
+  uint32_t tau[8];  // target bit positions, ascending
+};
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int K, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restrict__ st,
+                                                         uint64_t nitems, Ins ins, MfmaDesc d,
+                                                         const double* __restrict__ afrag) {
+  using A = amp_t<double>;
+  constexpr int S = 1 << K;
+  constexpr int TT = S / 8;   // 16x16 tiles per dimension of the (2S x 2S) real matrix
+  constexpr int KS = S / 2;   // K-steps of 4
+  constexpr int NA = S / 4;   // amplitudes per lane
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t j = lane & 15u, q = lane >> 4;
+  double a[TT][KS];
+#pragma unroll
+  for (int rb = 0; rb < TT; ++rb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[rb][s] = afrag[(rb * KS + s) * 64 + lane];
+  const uint64_t offq = ((uint64_t)(q & 1u) << d.tau[0]) | ((uint64_t)(q >> 1) << d.tau[1]);
+  uint64_t offm[NA];
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < K - 2; ++b)
+      if ((m >> b) & 1) o |= 1ull << d.tau[b + 2];
+    offm[m] = o;
+  }
+  const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / 64);
+  for (uint64_t w = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < nitems; w += nwaves) {
+    const uint64_t base = insert_bits<-1>((w << 4) | j, ins) | offq;
+    A x[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) x[m] = ldg<NT>(st + (base | offm[m]));
+#pragma unroll
+    for (int rb = 0; rb < TT; ++rb) {
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][s], (s & 1) ? x[s >> 1].y : x[s >> 1].x, acc, 0, 0, 0);
+      A y0, y1;
+      y0.x = acc[0];
+      y0.y = acc[1];
+      y1.x = acc[2];
+      y1.y = acc[3];
+      // all of this wave's loads were issued before its first store (x[] is complete), and no other
+      // wave touches these amplitudes, so the update is in place
+      stg<NT>(st + (base | offm[2 * rb]), y0);
+      stg<NT>(st + (base | offm[2 * rb + 1]), y1);
+    }
+  }
+}
+
 // ---- literal fallback: one output row per lane, out of place ------------------------------
 // The gather formulation of the reference, variant by variant (matrix_ops.rs:62-94,
 // ops.rs:100-156, qubit_iterators.rs).  Correct for every descriptor the reference accepts,

@@ -196,17 +196,62 @@ def test_swap(O, h):
 # ---- dense k-qubit --------------------------------------------------------------------------------
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
 def test_dense_k_qubit(O, k):
+    """k = 2: register kernel (bit-equal).  k = 3..5 on f64: matrix-core kernel (fma chains, so the
+    stated 1e-12 bar applies, not bit equality); with option mfma = 0 the VALU register kernel
+    (k <= 4) / the literal kernel (k >= 5) must again be bit-equal."""
     n = 10
     rng = np.random.default_rng(10 + k)
-    for trial in range(4):
+    for trial in range(6):
         perm = [int(v) for v in rng.permutation(n)]
+        if trial == 4:
+            perm = list(range(n))[::-1]  # targets on the lowest bit positions
+        if trial == 5:
+            perm = list(range(n))        # targets on the highest bit positions
         u = rand_unitary(k, rng)
         op = q.make_matrix_op(perm[:k], u.ravel())
-        # register kernels multiply zero entries and fold like the reference: bit-equal expected
-        check(O, n, op, seed=trial)
-        if k <= 4:
+        x = rand_state(n, trial)
+        want = oracle_apply(O, n, op, x)
+        got = hip_apply(n, op, x)
+        if k == 2 or k == 6:
+            assert np.array_equal(got, want)
+        else:
+            assert np.max(np.abs(got - want)) <= TOL64, (k, perm[:k])
+        assert np.array_equal(hip_apply(n, op, x, mfma=0), want)
+        assert np.array_equal(hip_apply(n, op, x, force_generic=1), want)
+        if k <= 5 and n - k >= 6:
             cop = q.make_control_op(perm[k:k + 2], op)
-            check(O, n, cop, seed=trial)
+            want = oracle_apply(O, n, cop, x)
+            assert np.max(np.abs(hip_apply(n, cop, x) - want)) <= TOL64
+            assert np.array_equal(hip_apply(n, cop, x, mfma=0), want)
+
+
+def test_dense_permutations_stay_exact_on_matrix_cores(O):
+    """0/1 permutation matrices through the MFMA path: fma(1, x, 0) is exact, so IEEE `==` holds."""
+    n = 9
+    toffoli = np.eye(8)
+    toffoli[6:, 6:] = [[0, 1], [1, 0]]
+    fredkin = np.eye(8)
+    fredkin[[5, 6]] = fredkin[[6, 5]]
+    cyc = np.roll(np.eye(16), 3, axis=0)
+    for mat, idxs in ((toffoli, ([0, 4, 8], [8, 7, 6], [2, 0, 1])), (fredkin, ([1, 2, 3], [8, 0, 4])),
+                      (cyc, ([0, 1, 2, 3], [8, 6, 4, 2]))):
+        for idx in idxs:
+            check(O, n, q.make_matrix_op(idx, mat.ravel()), exact=True)
+
+
+def test_matrix_core_kernel_sizes(O):
+    """k = 3 on the smallest state the MFMA path accepts (n = k + 4) and one below it (fallback)."""
+    rng = np.random.default_rng(77)
+    for n in (6, 7, 8, 12):
+        u = rand_unitary(3, rng)
+        op = q.make_matrix_op([n - 1, 0, n // 2], u.ravel())
+        x = rand_state(n, n)
+        assert np.max(np.abs(hip_apply(n, op, x) - oracle_apply(O, n, op, x))) <= TOL64
+    u5 = rand_unitary(5, rng)
+    for n in (8, 9, 13):
+        op = q.make_matrix_op([n - 1, 0, 3, 2, n - 2], u5.ravel())
+        x = rand_state(n, n)
+        assert np.max(np.abs(hip_apply(n, op, x) - oracle_apply(O, n, op, x))) <= TOL64
 
 
 def test_two_qubit_permutation_matrix_exact(O):

@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Per-op-class throughput table on one MI355X (not the contract bench; feeds DESIGN.md / profiles/).
+
+  python tools/bench_ops.py [n] > gpurun_out/ops_table.md
+Each row: one op type applied REPS times to a resident 2^n Complex<f64> state; GB/s uses the
+algorithmic bytes of SURVEY.md §8(d) (qip_hip_op_algorithmic_bytes)."""
+import cmath
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustqip_amd as q  # noqa: E402
+from rustqip_amd import circuits  # noqa: E402
+
+
+def rand_unitary(k, rng):
+    a = rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))
+    u, _ = np.linalg.qr(a)
+    return u
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    reps = 6
+    rng = np.random.default_rng(0)
+    hi, mid, lo = 0, n // 2, n - 1  # qubit indices: bit positions n-1, ~n/2, 0
+    cases = [
+        ("H, target bit n-1", q.make_matrix_op([hi], circuits.H), {}),
+        ("H, target bit n/2", q.make_matrix_op([mid], circuits.H), {}),
+        ("H, target bit 0 (cross-lane)", q.make_matrix_op([lo], circuits.H), {}),
+        ("H, target bit 0 (pair kernel)", q.make_matrix_op([lo], circuits.H), {"lowbit_shuffle": 0}),
+        ("X, target bit n/2", q.make_matrix_op([mid], circuits.X), {}),
+        ("Rz, target bit n/2", q.make_matrix_op([mid], circuits.rz(0.3)), {}),
+        ("Z (phase), bit n/2", q.make_matrix_op([mid], circuits.Z), {}),
+        ("T (phase), bit 0", q.make_matrix_op([lo], circuits.T), {}),
+        ("CNOT c=n-1 t=n/2", q.make_control_op([hi], q.make_matrix_op([mid], circuits.X)), {}),
+        ("CNOT c=0 t=n/2 (control in cache line)", q.make_control_op([lo], q.make_matrix_op([mid], circuits.X)), {}),
+        ("CNOT c=n/2 t=0", q.make_control_op([mid], q.make_matrix_op([lo], circuits.X)), {}),
+        ("Toffoli", q.make_control_op([hi, 3], q.make_matrix_op([mid], circuits.X)), {}),
+        ("controlled-phase", q.make_control_op([hi], q.make_matrix_op([mid], [1, 0, 0, cmath.rect(1, 0.1)])), {}),
+        ("Swap(1) bits n-1 <-> 0", q.make_swap_op([hi], [lo]), {}),
+        ("Swap(2)", q.make_swap_op([hi, 1], [mid, lo]), {}),
+        ("dense k=2 (VALU regs)", q.make_matrix_op([hi, mid], rand_unitary(2, rng).ravel()), {}),
+        ("dense k=2, low bits", q.make_matrix_op([lo, lo - 1], rand_unitary(2, rng).ravel()), {}),
+        ("dense k=3 (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {}),
+        ("dense k=3 (VALU regs)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 0}),
+        ("dense k=3 low bits (MFMA f64)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {}),
+        ("dense k=3 low bits (VALU regs)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {"mfma": 0}),
+        ("dense k=4 (MFMA f64)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {}),
+        ("dense k=4 (VALU regs)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {"mfma": 0}),
+        ("dense k=5 (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {}),
+        ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
+        ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
+        ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
+        ("H via literal gather", q.make_matrix_op([mid], circuits.H), {"force_generic": 1}),
+    ]
+    print(f"| op (n={n}, Complex<f64>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(circuits.h_layer(n))
+        for name, op, opts in cases:
+            for k in ("lowbit_shuffle", "mfma", "force_generic"):
+                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0}[k])
+            for k, v in opts.items():
+                st.set_option(k, v)
+            comp = st.compile_ops([op] * reps)
+            st.set_option("profile", 0)
+            st.apply_compiled(st.compile_ops([op]))
+            st.sync()
+            st.set_option("profile", 1)
+            st.profile_reset()
+            t0 = time.perf_counter()
+            st.apply_compiled(comp)
+            st.sync()
+            dt = (time.perf_counter() - t0) / reps
+            prof = st.profile()
+            st.profile_reset()
+            kern = "+".join(prof) or "-"
+            by = q.algorithmic_bytes(n, op)
+            print(f"| {name} | `{kern}` | {dt*1e3:.3f} | {by/dt/1e9:.0f} | {100*by/dt/1e9/8000:.1f} |")
+        st.set_option("profile", 0)
+        for name, fn, by in (("norm_sqr", st.norm_sqr, 16.0 * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), 16.0 * 2**n),
+                             ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), 16.0 * 2**n),
+                             ("measure_probs k=12 (scatter)", lambda: st.measure_probs(list(range(12))), 16.0 * 2**n)):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            dt = (time.perf_counter() - t0) / 3
+            print(f"| {name} | reduction | {dt*1e3:.3f} | {by/dt/1e9:.0f} | {100*by/dt/1e9/8000:.1f} |")
+        print(f"\nnorm after all ops: {st.norm_sqr():.15f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -3,9 +3,11 @@
 // (32 * 2^n bytes per launch) per target bit position.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/tune_gate1q.hip -o tools/tune_gate1q
 #include <hip/hip_runtime.h>
+#include "../rustqip_amd/csrc/qip_kernels.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -155,6 +157,18 @@ template <int U, int LOGU, int SHIFT, bool NT> void L_pair_str(d2* s, uint64_t N
 template <int U, int LOGU, int SHIFT, int MODE> void L_xs_str(d2* s, uint64_t N, uint32_t b, G g, hipStream_t st_) {
   hipLaunchKernelGGL((k_xs_str<256, U, LOGU, SHIFT, true, true>), dim3(N / (256 * U)), dim3(256), 0, st_, s, N, b, g, MODE);
 }
+// the product kernels themselves (rustqip_amd/csrc/qip_kernels.h), for A/B against the variants here
+template <int U> void L_prod_pair(d2* s, uint64_t N, uint32_t b, G g, hipStream_t st_) {
+  qipk::Ins ins; memset(&ins, 0, sizeof ins); ins.npos = 1; ins.pos[0] = b;
+  qipk::Mat2<double> m; for (int e = 0; e < 4; ++e) m.m[e] = g.m[e]; m.nz = 15;
+  const uint64_t np = N / 2;
+  hipLaunchKernelGGL((qipk::k_gate1q_pair<double, U, false, true, 1>), dim3(np / (256 * U)), dim3(256), 0, st_, (qipk::amp_t<double>*)s, np, ins, 1ull << b, m);
+}
+template <int U> void L_prod_xlane(d2* s, uint64_t N, uint32_t b, G g, hipStream_t st_) {
+  qipk::Ins ins; memset(&ins, 0, sizeof ins);
+  qipk::Mat2<double> m; for (int e = 0; e < 4; ++e) m.m[e] = g.m[e]; m.nz = 15;
+  hipLaunchKernelGGL((qipk::k_gate1q_xlane<double, U, false, true, 0>), dim3(N / (256 * U)), dim3(256), 0, st_, (qipk::amp_t<double>*)s, N, ins, b, m);
+}
 template <int BLOCK, int U, bool NTL, bool NTS, int PER_CU> void L_pair_gs(d2* s, uint64_t N, uint32_t b, G g, hipStream_t st_) {
   const uint64_t np = N / 2; hipLaunchKernelGGL((k_pair_gs<BLOCK, U, NTL, NTS>), dim3(256 * PER_CU), dim3(BLOCK), 0, st_, s, np, b, g);
 }
@@ -181,23 +195,13 @@ int main(int argc, char** argv) {
   G g; g.m[0] = (d2){h, 0}; g.m[1] = (d2){h, 0}; g.m[2] = (d2){h, 0}; g.m[3] = (d2){-h, 0};
   std::vector<Variant> vs = {
       {"pair u2 str32K nt      ", L_pair_str<2, 1, 11, true>, false, false},
-      {"pair u2 str16K nt      ", L_pair_str<2, 1, 10, true>, false, false},
-      {"pair u2 str64K nt      ", L_pair_str<2, 1, 12, true>, false, false},
-      {"pair u2 str128K nt     ", L_pair_str<2, 1, 13, true>, false, false},
-      {"pair u2 str1M nt       ", L_pair_str<2, 1, 16, true>, false, false},
-      {"pair u4 str32K nt      ", L_pair_str<4, 2, 11, true>, false, false},
+      {"PRODUCT pair u2        ", L_prod_pair<2>, false, false},
+      {"PRODUCT pair u4        ", L_prod_pair<4>, false, false},
+      {"PRODUCT pair u8        ", L_prod_pair<8>, false, false},
       {"pair u8 str32K nt      ", L_pair_str<8, 3, 11, true>, false, false},
-      {"pair u4 str8K nt       ", L_pair_str<4, 2, 9, true>, false, false},
-      {"pair u4 str16K nt      ", L_pair_str<4, 2, 10, true>, false, false},
-      {"pair u1 nt             ", L_pair<256, 1, true, true>, false, false},
-      {"xlane u1 nt            ", L_xlane<256, 1, true, true>, true, false},
-      {"xlane u2 str32K nt     ", L_xs_str<2, 1, 11, 1>, true, false},
       {"xlane u4 str32K nt     ", L_xs_str<4, 2, 11, 1>, true, false},
-      {"xlane u2 str64K nt     ", L_xs_str<2, 1, 12, 1>, true, false},
-      {"scale u1 nt            ", L_scale<256, 1, true, true>, false, true},
-      {"scale u2 str32K nt     ", L_xs_str<2, 1, 11, 0>, false, true},
-      {"scale u4 str32K nt     ", L_xs_str<4, 2, 11, 0>, false, true},
-      {"scale u2 str64K nt     ", L_xs_str<2, 1, 12, 0>, false, true},
+      {"PRODUCT xlane u4       ", L_prod_xlane<4>, true, false},
+      {"PRODUCT xlane u2       ", L_prod_xlane<2>, true, false},
   };
   const std::vector<int> bits = {0, 2, 5, 6, 8, 10, 11, 12, 13, 16, 20, 24, n - 1};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
