@@ -131,8 +131,10 @@ int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op,
 int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_state** out);
 /* Wrap caller-owned device memory (e.g. a torch tensor): `amps` holds 2^n
  * amplitudes, `scratch` (may be NULL) a second buffer of the same size,
- * `stream` is a hipStream_t (NULL = the handle creates its own). The handle
- * never frees wrapped memory. */
+ * `stream` is the caller's hipStream_t, used as is (NULL = the HIP null / legacy
+ * default stream, which is torch's default stream on ROCm), so kernels are ordered
+ * with the caller's other work such as RCCL collectives.  The handle never frees
+ * wrapped memory and never creates a stream of its own. */
 int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps, void* scratch,
                        void* stream, qip_hip_state** out);
 int qip_hip_state_destroy(qip_hip_state* s);

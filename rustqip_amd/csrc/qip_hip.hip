@@ -459,17 +459,10 @@ extern "C" int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps,
   qip_hip_state* s = *out;
   s->cur = amps;
   s->alt = scratch;
-  if (stream) {
-    s->stream = (hipStream_t)stream;
-  } else {
-    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      delete s;
-      *out = nullptr;
-      return fail(QIP_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
-    }
-    s->owns_stream = true;
-  }
+  // the caller's stream as is; NULL is the HIP null (legacy default) stream, which is what
+  // torch.cuda.current_stream().cuda_stream reports for torch's default stream on ROCm
+  s->stream = (hipStream_t)stream;
+  s->owns_stream = false;
   return QIP_OK;
 }
 

@@ -1,0 +1,445 @@
+// qip_hip.hpp — C++17 host mirror of the reference's interface for the gate-application path,
+// over the C ABI in include/qip_hip.h.  Header-only; link with -lqip_hip.
+//
+// The reference is Rust and no Rust toolchain exists in the build image, so the compiled-language
+// host side is written in C++ with the reference's names, argument order and error behaviour:
+//   qip::MatrixOp<P>                          qip-iterators/src/iterators/ops.rs:11-91
+//   qip::make_matrix_op / make_sparse_matrix_op / make_swap_op / make_control_op
+//                                             qip/src/state_ops/matrix_ops.rs:12-122
+//   qip::apply_op / apply_op_overwrite        qip-iterators/src/matrix_ops.rs:98-152
+//   qip::CircuitError                         qip/src/errors.rs:6-22
+//   qip::HipBuilder<P>                        LocalBuilder<P>'s recording + run loop, qip/src/builder.rs:325-519
+// Nothing in this file touches amplitudes: every compute call goes to libqip_hip.so (HIP kernels).
+#pragma once
+
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "qip_hip.h"
+
+namespace qip {
+
+/// qip::errors::CircuitError::Generic(String)
+class CircuitError : public std::runtime_error {
+ public:
+  explicit CircuitError(const std::string& msg) : std::runtime_error(msg) {}
+};
+
+/// qip/src/types.rs:16-22
+enum class Representation { BigEndian, LittleEndian };
+
+template <typename P> struct dtype_of;
+template <> struct dtype_of<double> { static constexpr int value = QIP_C64; };
+template <> struct dtype_of<float> { static constexpr int value = QIP_C32; };
+
+inline void check(int rc) {
+  if (rc == QIP_OK) return;
+  throw CircuitError(std::string(qip_hip_last_error()));
+}
+
+/// qip-iterators/src/utils.rs:22-25
+inline size_t flip_bits(size_t n, size_t num) {
+  size_t out = 0;
+  for (size_t b = 0; b < n; ++b)
+    if ((num >> b) & 1) out |= size_t(1) << (n - 1 - b);
+  return out;
+}
+
+/// MatrixOp<P> (ops.rs:11-20).  P is the real precision; amplitudes are std::complex<P>, which is
+/// layout-compatible with qip_c64 / qip_c32 and with num_complex::Complex<P>.
+template <typename P> class MatrixOp {
+ public:
+  using C = std::complex<P>;
+  using SparseRows = std::vector<std::vector<std::pair<size_t, C>>>;
+  enum class Kind { Matrix, SparseMatrix, Swap, Control };
+
+  static MatrixOp new_matrix(std::vector<size_t> indices, std::vector<C> data) {
+    MatrixOp op(Kind::Matrix, std::move(indices));
+    op.data_ = std::move(data);
+    return op;
+  }
+  static MatrixOp new_sparse(std::vector<size_t> indices, SparseRows rows) {
+    MatrixOp op(Kind::SparseMatrix, std::move(indices));
+    op.rows_ = std::move(rows);
+    return op;
+  }
+  static MatrixOp new_swap(std::vector<size_t> a, const std::vector<size_t>& b) {
+    const size_t h = a.size();
+    a.insert(a.end(), b.begin(), b.end());
+    MatrixOp op(Kind::Swap, std::move(a));
+    op.half_ = h;
+    return op;
+  }
+  static MatrixOp new_control(std::vector<size_t> c, const std::vector<size_t>& r, MatrixOp inner) {
+    const size_t nc = c.size();
+    c.insert(c.end(), r.begin(), r.end());
+    MatrixOp op(Kind::Control, std::move(c));
+    op.n_controls_ = nc;
+    op.inner_ = std::make_shared<MatrixOp>(std::move(inner));
+    return op;
+  }
+
+  Kind kind() const { return kind_; }
+  size_t num_indices() const { return kind_ == Kind::Swap ? 2 * half_ : indices_.size(); }  // ops.rs:24-36
+  const std::vector<size_t>& indices() const { return indices_; }                           // ops.rs:39-46
+  size_t n_controls() const { return n_controls_; }
+  const std::vector<C>& data() const { return data_; }
+  const SparseRows& rows() const { return rows_; }
+  const MatrixOp* inner() const { return inner_.get(); }
+  std::shared_ptr<MatrixOp> inner_ptr() const { return inner_; }
+
+  /// The `struct qip_op` tree for the C ABI plus the buffers it points into.
+  struct CView {
+    qip_op op{};
+    std::vector<uint64_t> idx, rowptr, cols;
+    std::vector<C> vals;
+    std::unique_ptr<CView> inner;
+  };
+  std::unique_ptr<CView> to_c() const {
+    auto v = std::make_unique<CView>();
+    v->idx.assign(indices_.begin(), indices_.end());
+    v->op.n_indices = (uint32_t)v->idx.size();
+    v->op.indices = v->idx.data();
+    switch (kind_) {
+      case Kind::Matrix:
+        v->op.kind = QIP_OP_MATRIX;
+        if (data_.size() != (size_t(1) << (2 * indices_.size())))
+          throw CircuitError("Matrix data has " + std::to_string(data_.size()) + " entries versus expected 2^2*" +
+                             std::to_string(indices_.size()));
+        v->op.dense = data_.data();
+        break;
+      case Kind::SparseMatrix:
+        v->op.kind = QIP_OP_SPARSE;
+        if (rows_.size() != (size_t(1) << indices_.size()))
+          throw CircuitError("Sparse matrix has " + std::to_string(rows_.size()) + " rows versus expected 2^" +
+                             std::to_string(indices_.size()));
+        v->rowptr.push_back(0);
+        for (const auto& row : rows_) {
+          for (const auto& e : row) {
+            v->cols.push_back(e.first);
+            v->vals.push_back(e.second);
+          }
+          v->rowptr.push_back(v->cols.size());
+        }
+        v->op.sparse_rowptr = v->rowptr.data();
+        v->op.sparse_cols = v->cols.data();
+        v->op.sparse_vals = v->vals.data();
+        break;
+      case Kind::Swap:
+        v->op.kind = QIP_OP_SWAP;
+        break;
+      case Kind::Control:
+        v->op.kind = QIP_OP_CONTROL;
+        v->op.n_controls = (uint32_t)n_controls_;
+        if (!inner_) throw CircuitError("Control op without inner op");
+        v->inner = inner_->to_c();
+        v->op.inner = &v->inner->op;
+        break;
+    }
+    return v;
+  }
+
+ private:
+  MatrixOp(Kind k, std::vector<size_t> idx) : kind_(k), indices_(std::move(idx)) {}
+  Kind kind_;
+  std::vector<size_t> indices_;
+  std::vector<C> data_;
+  SparseRows rows_;
+  size_t half_ = 0, n_controls_ = 0;
+  std::shared_ptr<MatrixOp> inner_;
+};
+
+/// get_index (matrix_ops.rs:33-35)
+template <typename P> size_t get_index(const MatrixOp<P>& op, size_t i) { return op.indices()[i]; }
+
+// ---- validated constructors (qip/src/state_ops/matrix_ops.rs:12-122) -------------------------------
+template <typename P>
+MatrixOp<P> make_matrix_op(std::vector<size_t> indices, std::vector<std::complex<P>> dat) {
+  const size_t n = indices.size();
+  if (indices.empty()) throw CircuitError("Must supply at least one op index");
+  if (dat.size() != (size_t(1) << (2 * n)))
+    throw CircuitError("Matrix data has " + std::to_string(dat.size()) + " entries versus expected 2^2*" +
+                       std::to_string(n));
+  return MatrixOp<P>::new_matrix(std::move(indices), std::move(dat));
+}
+
+template <typename P>
+MatrixOp<P> make_sparse_matrix_op(std::vector<size_t> indices, typename MatrixOp<P>::SparseRows dat,
+                                  Representation order = Representation::BigEndian) {
+  const size_t n = indices.size();
+  if (indices.empty()) throw CircuitError("Must supply at least one op index");
+  if (dat.size() != (size_t(1) << n))
+    throw CircuitError("Sparse matrix has " + std::to_string(dat.size()) + " rows versus expected 2^" +
+                       std::to_string(n));
+  for (size_t r = 0; r < dat.size(); ++r)
+    if (dat[r].empty())
+      throw CircuitError("All rows of sparse matrix must have data (" + std::to_string(r) + " is empty)");
+  if (order == Representation::LittleEndian) {  // :62-77
+    typename MatrixOp<P>::SparseRows out(dat.size());
+    for (size_t r = 0; r < dat.size(); ++r) {
+      for (auto& e : dat[r]) e.first = flip_bits(n, e.first);
+      out[flip_bits(n, r)] = std::move(dat[r]);
+    }
+    dat = std::move(out);
+  }
+  return MatrixOp<P>::new_sparse(std::move(indices), std::move(dat));
+}
+
+template <typename P>
+MatrixOp<P> make_swap_op(std::vector<size_t> a_indices, const std::vector<size_t>& b_indices) {
+  if (a_indices.empty() || b_indices.empty()) throw CircuitError("Need at least 1 swap index for a and b");
+  if (a_indices.size() != b_indices.size())
+    throw CircuitError("Swap must be performed on two sets of indices of equal length, found " +
+                       std::to_string(a_indices.size()) + " vs " + std::to_string(b_indices.size()));
+  return MatrixOp<P>::new_swap(std::move(a_indices), b_indices);
+}
+
+template <typename P> MatrixOp<P> make_control_op(std::vector<size_t> c_indices, MatrixOp<P> op) {
+  if (c_indices.empty()) throw CircuitError("Must supply at least one control index");
+  if (op.kind() == MatrixOp<P>::Kind::Control) {  // collapse (:112-115)
+    const size_t nc = c_indices.size() + op.n_controls();
+    std::vector<size_t> all = std::move(c_indices);
+    all.insert(all.end(), op.indices().begin(), op.indices().end());
+    std::vector<size_t> ctrl(all.begin(), all.begin() + nc), rest(all.begin() + nc, all.end());
+    return MatrixOp<P>::new_control(std::move(ctrl), rest, *op.inner());
+  }
+  std::vector<size_t> r = op.indices();
+  return MatrixOp<P>::new_control(std::move(c_indices), r, std::move(op));
+}
+
+// ---- inner seam: apply_op / apply_op_overwrite (matrix_ops.rs:98-152) --------------------------------
+template <typename P>
+void apply_op(size_t n, const MatrixOp<P>& op, const std::vector<std::complex<P>>& input,
+              std::vector<std::complex<P>>& output, size_t input_offset, size_t output_offset) {
+  auto c = op.to_c();
+  check(qip_hip_apply_op_host(dtype_of<P>::value, (uint32_t)n, &c->op, input.data(), input.size(), output.data(),
+                              output.size(), input_offset, output_offset, 1));
+}
+template <typename P>
+void apply_op_overwrite(size_t n, const MatrixOp<P>& op, const std::vector<std::complex<P>>& input,
+                        std::vector<std::complex<P>>& output, size_t input_offset, size_t output_offset) {
+  auto c = op.to_c();
+  check(qip_hip_apply_op_host(dtype_of<P>::value, (uint32_t)n, &c->op, input.data(), input.size(), output.data(),
+                              output.size(), input_offset, output_offset, 0));
+}
+
+// ---- outer seam: device-resident state ---------------------------------------------------------------
+template <typename P> class HipState {
+ public:
+  using C = std::complex<P>;
+  explicit HipState(size_t n, int device = 0) : n_(n) {
+    check(qip_hip_state_create((uint32_t)n, dtype_of<P>::value, device, &h_));
+  }
+  ~HipState() { qip_hip_state_destroy(h_); }
+  HipState(const HipState&) = delete;
+  HipState& operator=(const HipState&) = delete;
+
+  size_t n() const { return n_; }
+  void init_basis(size_t index) { check(qip_hip_state_init_basis(h_, index)); }
+  void upload(const std::vector<C>& v, size_t offset = 0) { check(qip_hip_state_upload(h_, v.data(), offset, v.size())); }
+  std::vector<C> download() const {
+    std::vector<C> out(size_t(1) << n_);
+    check(qip_hip_state_download(h_, out.data(), 0, out.size()));
+    return out;
+  }
+  void apply_op(const MatrixOp<P>& op) {
+    auto c = op.to_c();
+    check(qip_hip_state_apply_op(h_, &c->op));
+  }
+  double norm_sqr() const {
+    double v = 0;
+    check(qip_hip_state_norm_sqr(h_, &v));
+    return v;
+  }
+  std::vector<double> measure_probs(const std::vector<size_t>& indices) const {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    std::vector<double> out(size_t(1) << idx.size());
+    check(qip_hip_state_measure_probs(h_, idx.data(), (uint32_t)idx.size(), out.data()));
+    return out;
+  }
+  /// measure (measurement_ops.rs:190-214); forced < 0 samples with rand_u01.
+  std::pair<size_t, double> measure(const std::vector<size_t>& indices, int64_t forced, double rand_u01) {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    uint64_t m = 0;
+    double p = 0;
+    check(qip_hip_state_measure(h_, idx.data(), (uint32_t)idx.size(), forced, rand_u01, &m, &p));
+    return {size_t(m), p};
+  }
+  qip_hip_state* handle() { return h_; }
+
+ private:
+  size_t n_;
+  qip_hip_state* h_ = nullptr;
+};
+
+// ---- LocalBuilder<P>'s recording and run loop (qip/src/builder.rs:325-519) ----------------------------
+struct Register {
+  std::vector<size_t> indices;
+  size_t n() const { return indices.size(); }
+};
+
+struct MeasurementResult {
+  bool stochastic = false;
+  size_t measured = 0;
+  double prob = 0;
+  std::vector<double> probs;
+};
+
+template <typename P> class HipBuilder {
+ public:
+  using C = std::complex<P>;
+  enum class Obj { X, Y, Z, H, S, T, CNOT, SWAP, Rz, MAT, GlobalPhase, Measurement, StochasticMeasurement };
+  struct Entry {
+    std::vector<size_t> indices;
+    Obj obj;
+    P theta = 0;
+    std::vector<C> mat;
+  };
+
+  size_t n() const { return n_; }
+  Register register_(size_t n) {
+    if (n == 0) throw CircuitError("register size must be non-zero");
+    Register r;
+    for (size_t i = 0; i < n; ++i) r.indices.push_back(n_ + i);
+    n_ += n;
+    return r;
+  }
+  Register qubit() { return register_(1); }
+
+  // CliffordTBuilder (a 1-qubit object on a wider register is broadcast, builder.rs:382-387)
+  Register x(Register r) { return apply1(std::move(r), Obj::X); }
+  Register y(Register r) { return apply1(std::move(r), Obj::Y); }
+  Register z(Register r) { return apply1(std::move(r), Obj::Z); }
+  Register h(Register r) { return apply1(std::move(r), Obj::H); }
+  Register s(Register r) { return apply1(std::move(r), Obj::S); }
+  Register t(Register r) { return apply1(std::move(r), Obj::T); }
+  Register s_dagger(Register r) { return s(z(std::move(r))); }         // builder_traits.rs:419-422
+  Register t_dagger(Register r) { return t(s_dagger(std::move(r))); }  // :408-411
+  Register rz(Register r, P theta) {
+    for (size_t q : r.indices) pipeline_.push_back({{q}, Obj::Rz, theta, {}});
+    return r;
+  }
+  std::pair<Register, Register> cnot(Register cr, Register r) {  // :425-451
+    if (cr.n() > 1) throw CircuitError("Clifford CNOT can only have a single control qubit.");
+    for (size_t q : r.indices) pipeline_.push_back({{cr.indices[0], q}, Obj::CNOT, 0, {}});
+    return {std::move(cr), std::move(r)};
+  }
+  std::pair<Register, Register> swap(Register ra, Register rb) {  // :454-482: three CNOTs per pair
+    if (ra.n() != rb.n()) throw CircuitError("Swap must be between registers of the same size.");
+    for (size_t i = 0; i < ra.n(); ++i) {
+      Register a{{ra.indices[i]}}, b{{rb.indices[i]}};
+      cnot(a, b);
+      cnot(b, a);
+      cnot(a, b);
+    }
+    return {std::move(ra), std::move(rb)};
+  }
+  std::pair<Register, Register> swap_op(Register ra, Register rb) {  // UnitaryMatrixObject::SWAP
+    if (ra.n() != rb.n()) throw CircuitError("Swap must be between registers of the same size.");
+    std::vector<size_t> idx = ra.indices;
+    idx.insert(idx.end(), rb.indices.begin(), rb.indices.end());
+    pipeline_.push_back({idx, Obj::SWAP, 0, {}});
+    return {std::move(ra), std::move(rb)};
+  }
+  Register apply_matrix(Register r, std::vector<C> data) {  // UnitaryBuilder::apply_vec_matrix
+    if (data.size() != (size_t(1) << (2 * r.n()))) throw CircuitError("Matrix has incorrect N and cannot be broadcast");
+    pipeline_.push_back({r.indices, Obj::MAT, 0, std::move(data)});
+    return r;
+  }
+  std::pair<Register, size_t> measure(Register r) {
+    pipeline_.push_back({r.indices, Obj::Measurement, 0, {}});
+    return {std::move(r), n_measurements_++};
+  }
+  std::pair<Register, size_t> measure_stochastic(Register r) {
+    pipeline_.push_back({r.indices, Obj::StochasticMeasurement, 0, {}});
+    return {std::move(r), n_measurements_++};
+  }
+  const std::vector<Entry>& pipeline() const { return pipeline_; }
+
+  /// The lowering table of the reference run loop (builder.rs:436-498).
+  static MatrixOp<P> lower(const Entry& e) {
+    const C l(1, 0), o(0, 0), i(0, 1);
+    switch (e.obj) {
+      case Obj::X: return make_matrix_op<P>(e.indices, {o, l, l, o});
+      case Obj::Y: return make_matrix_op<P>(e.indices, {o, -i, i, o});
+      case Obj::Z: return make_matrix_op<P>(e.indices, {l, o, o, -l});
+      case Obj::H: {
+        const C nl = C(1, 0) * P(0.70710678118654752440);  // Complex::one() * FRAC_1_SQRT_2
+        return make_matrix_op<P>(e.indices, {nl, nl, nl, -nl});
+      }
+      case Obj::S: return make_matrix_op<P>(e.indices, {l, o, o, i});
+      case Obj::T: return make_matrix_op<P>(e.indices, {l, o, o, std::polar(P(1), P(0.78539816339744830962))});
+      case Obj::CNOT: {
+        std::vector<size_t> rest(e.indices.begin() + 1, e.indices.end());
+        return make_control_op<P>({e.indices[0]}, make_matrix_op<P>(rest, {o, l, l, o}));
+      }
+      case Obj::MAT: return make_matrix_op<P>(e.indices, e.mat);
+      case Obj::SWAP: {
+        const size_t x = e.indices.size() / 2;
+        std::vector<size_t> a(e.indices.begin(), e.indices.begin() + x), b(e.indices.begin() + x, e.indices.end());
+        return make_swap_op<P>(a, b);
+      }
+      case Obj::Rz: {
+        const P h_theta = e.theta * P(0.5);
+        return make_matrix_op<P>(e.indices, {std::polar(P(1), -h_theta), o, o, std::polar(P(1), h_theta)});
+      }
+      default: throw CircuitError("cannot lower this pipeline entry");
+    }
+  }
+
+  /// calculate_state_with_init (builder.rs:400-519).  `rand_u01` supplies the uniform samples for the
+  /// collapsing measurements in order (the reference draws rand::random::<f64>() itself, :160);
+  /// `forced` (if non-empty) plays MeasuredCondition instead.  The stale-buffer quirk of the reference
+  ///  is deliberately not reproduced.
+  std::pair<std::vector<C>, std::vector<MeasurementResult>> calculate_state_with_init(
+      const std::vector<std::pair<const Register*, size_t>>& init, std::vector<double> rand_u01 = {},
+      std::vector<int64_t> forced = {}) {
+    if (n_ == 0) throw CircuitError("empty circuit");
+    size_t index = 0;
+    for (const auto& rx : init)  // :409-421: bit k of x sets qubit r.indices[k]
+      for (size_t k = 0; k < rx.first->indices.size(); ++k)
+        index |= ((rx.second >> k) & 1) << (n_ - 1 - rx.first->indices[k]);
+    HipState<P> st(n_);
+    st.init_basis(index);
+    std::vector<MeasurementResult> results;
+    size_t mi = 0;
+    for (const auto& e : pipeline_) {
+      if (e.obj == Obj::GlobalPhase) continue;
+      if (e.obj == Obj::Measurement) {
+        const int64_t f = mi < forced.size() ? forced[mi] : -1;
+        const double r = mi < rand_u01.size() ? rand_u01[mi] : 0.5;
+        ++mi;
+        auto mp = st.measure(e.indices, f, r);
+        MeasurementResult res;
+        res.measured = mp.first;
+        res.prob = mp.second;
+        results.push_back(res);
+      } else if (e.obj == Obj::StochasticMeasurement) {
+        MeasurementResult res;
+        res.stochastic = true;
+        res.probs = st.measure_probs(e.indices);
+        results.push_back(res);
+      } else {
+        st.apply_op(lower(e));
+      }
+    }
+    return {st.download(), results};
+  }
+
+ private:
+  Register apply1(Register r, Obj o) {
+    for (size_t q : r.indices) pipeline_.push_back({{q}, o, 0, {}});
+    return r;
+  }
+  size_t n_ = 0, n_measurements_ = 0;
+  std::vector<Entry> pipeline_;
+};
+
+}  // namespace qip

@@ -107,12 +107,16 @@ class HipBackend:
     """2^L amplitudes in HBM allocated by torch (two buffers: current + exchange target), driven by
     HipState on torch's current stream."""
 
-    def __init__(self, n_local: int, device: int):
+    def __init__(self, n_local: int, device: int, host_staged_exchange: bool = False):
         import torch
 
         from .state import HipState
 
         self.torch = torch
+        # host_staged_exchange: run the all-to-all on CPU copies (gloo).  Only for exercising this
+        # backend with several ranks on ONE GPU (tests); the product path exchanges device buffers
+        # over RCCL.
+        self.host_staged = host_staged_exchange
         self.n_local = n_local
         self.dev = torch.device("cuda", device)
         N = 1 << n_local
@@ -143,6 +147,15 @@ class HipBackend:
         prof = self.state.profile()
         self.state.profile_reset()
         return prof
+
+    def all_to_all(self, dist, recv, send) -> None:
+        if self.host_staged:
+            h_send = send.cpu()
+            h_recv = self.torch.empty_like(h_send)
+            dist.all_to_all_single(h_recv, h_send)
+            recv.copy_(h_recv)
+        else:
+            dist.all_to_all_single(recv, send)
 
     def timed_collective(self, fn):
         e0 = self.torch.cuda.Event(enable_timing=True)
@@ -181,7 +194,8 @@ class HipBackend:
         self.torch.cuda.synchronize(self.dev)
 
     def reduce_tensor(self, arr: np.ndarray):
-        return self.torch.as_tensor(arr, dtype=self.torch.float64, device=self.dev)
+        dev = "cpu" if self.host_staged else self.dev
+        return self.torch.as_tensor(arr, dtype=self.torch.float64, device=dev)
 
 
 # ---- the sharded state ------------------------------------------------------------------------------------
@@ -277,7 +291,7 @@ class ShardedState:
             self.stats["local_swaps"] += 1
         # one all-to-all: chunk c of rank r  ->  chunk r of rank c
         send, recv = self.backend.exchange_buffers()
-        self.backend.timed_collective(lambda: self.dist.all_to_all_single(recv, send))
+        self.backend.timed_collective(lambda: self.backend.all_to_all(self.dist, recv, send))
         self.backend.adopt_recv()
         for j in range(g):
             a, b = self._logical_at(L - g + j), self._logical_at(L + j)

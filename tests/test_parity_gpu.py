@@ -582,3 +582,33 @@ def test_window_compare_at_n24(O):
         got = st.download()
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.max(np.abs(got - want)) <= TOL64
+
+
+# ---- N > 1 on one GPU: virtual shards (real kernels, host-staged exchange) and RCCL plumbing ----------------
+def _run_dist(nproc, extra):
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py")] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return res.stdout
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_virtual_shards_on_one_gpu(world):
+    out = _run_dist(world, [])
+    assert out.count("ok n=") == 8
+
+
+def test_sharded_rccl_plumbing_world1():
+    out = _run_dist(1, ["--nccl"])
+    assert out.count("ok n=") == 8
