@@ -716,6 +716,35 @@ constexpr int kUSwap = 4;
 constexpr int kUXlane = 4;
 constexpr int kUPhase = 2;
 
+// Split selector bit positions (controls / phase bits, all required to be 1 unless `ones` says
+// otherwise) into the ones opened in the grid (>= kLineBits) and the in-line predicate (`Sel`).
+struct Split {
+  std::vector<uint32_t> hi;  // positions opened in the work index
+  uint64_t hi_ones = 0;      // bits to set among them
+  Sel low{0, 0};
+};
+static Split split_selectors(const std::vector<uint32_t>& pos, uint64_t ones_mask) {
+  Split sp;
+  for (uint32_t p : pos) {
+    const uint64_t bit = 1ull << p;
+    if (p < kLineBits) {
+      sp.low.mask |= bit;
+      sp.low.val |= ones_mask & bit;
+    } else {
+      sp.hi.push_back(p);
+      sp.hi_ones |= ones_mask & bit;
+    }
+  }
+  return sp;
+}
+// work-index bit that amplitude-index bit `pos` maps to once the opened positions below it are removed
+static uint32_t work_bit(uint32_t pos, const std::vector<uint32_t>& opened) {
+  uint32_t below = 0;
+  for (uint32_t o : opened)
+    if (o < pos) ++below;
+  return pos - below;
+}
+
 template <typename T>
 static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
   const uint32_t n = s->n;
@@ -723,24 +752,20 @@ static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* act
   Mat2<T> g;
   for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(p.m[2 * e], p.m[2 * e + 1]);
   g.nz = p.nz;
-  const uint64_t cmask = mask_of(p.cpos);
-  // position of the target bit inside the work index once the control bits below it are removed
-  uint32_t below = 0;
-  for (uint32_t c : p.cpos)
-    if (c < tpos) ++below;
-  const uint32_t tb = tpos - below;
-  const uint64_t namps_sub = 1ull << (n - (uint32_t)p.cpos.size());
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
+  const uint32_t tb = work_bit(tpos, sp.hi);
+  const uint64_t namps_sub = 1ull << (n - (uint32_t)sp.hi.size());
   if (s->lowbit_shuffle && tb < 6 && namps_sub >= 64) {
-    Ins ins = make_ins(p.cpos, cmask);
+    Ins ins = make_ins(sp.hi, sp.hi_ones);
     *actual_cls = KC_GATE1Q_XLANE;
-    LAUNCH_STREAMING(k_gate1q_xlane, T, kUXlane, namps_sub, ins, st, namps_sub, ins, tb, g);
+    LAUNCH_STREAMING(k_gate1q_xlane, T, kUXlane, namps_sub, ins, st, namps_sub, ins, tb, sp.low, g);
   } else {
-    std::vector<uint32_t> pos = p.cpos;
+    std::vector<uint32_t> pos = sp.hi;
     pos.push_back(tpos);
-    Ins ins = make_ins(pos, cmask);
+    Ins ins = make_ins(pos, sp.hi_ones);
     const uint64_t npairs = namps_sub >> 1;
     const uint64_t tmask = 1ull << tpos;
-    LAUNCH_STREAMING(k_gate1q_pair, T, kUPair, npairs, ins, st, npairs, ins, tmask, g);
+    LAUNCH_STREAMING(k_gate1q_pair, T, kUPair, npairs, ins, st, npairs, ins, tmask, sp.low, g);
   }
   HIPCHK(hipGetLastError());
   return QIP_OK;
@@ -755,10 +780,11 @@ static int launch_phase(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
     pos.push_back(p.opos[j]);
     if ((p.phase_ones >> (k - 1 - j)) & 1ull) ones |= 1ull << p.opos[j];
   }
-  Ins ins = make_ins(pos, ones);
-  const uint64_t count = 1ull << (s->n - (uint32_t)pos.size());
+  const Split sp = split_selectors(pos, ones);
+  Ins ins = make_ins(sp.hi, sp.hi_ones);
+  const uint64_t count = 1ull << (s->n - (uint32_t)sp.hi.size());
   const amp_t<T> value = mk<T>(p.phase[0], p.phase[1]);
-  LAUNCH_STREAMING(k_phase, T, kUPhase, count, ins, st, count, ins, value);
+  LAUNCH_STREAMING(k_phase, T, kUPhase, count, ins, st, count, ins, sp.low, value);
   HIPCHK(hipGetLastError());
   return QIP_OK;
 }
@@ -773,22 +799,21 @@ static DiagDesc make_diagdesc(const Plan& p) {
 
 template <typename T>
 static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
-  if (p.opos.size() == 1) {
-    *actual_cls = KC_DIAG1Q;  // Rz-like: no table, factor picked by the target bit
-    Ins ins1 = make_ins(p.cpos, mask_of(p.cpos));
-    const uint64_t cnt = 1ull << (s->n - (uint32_t)p.cpos.size());
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
+  Ins ins = make_ins(sp.hi, sp.hi_ones);
+  const uint64_t count = 1ull << (s->n - (uint32_t)sp.hi.size());
+  if (p.opos.size() == 1) {  // Rz-like: no table, factor picked by the target bit
+    *actual_cls = KC_DIAG1Q;
     const uint64_t tmask = 1ull << p.opos[0];
     const amp_t<T> d0 = mk<T>(p.table[0], p.table[1]), d1 = mk<T>(p.table[2], p.table[3]);
-    LAUNCH_STREAMING(k_diag1q, T, kUPhase, cnt, ins1, st, cnt, ins1, tmask, d0, d1);
+    LAUNCH_STREAMING(k_diag1q, T, kUPhase, count, ins, st, count, ins, tmask, sp.low, d0, d1);
     HIPCHK(hipGetLastError());
     return QIP_OK;
   }
   QCHK(upload_table<T>(s, p.table));
-  Ins ins = make_ins(p.cpos, mask_of(p.cpos));
-  const uint64_t count = 1ull << (s->n - (uint32_t)p.cpos.size());
-  constexpr int U = 4;
-  hipLaunchKernelGGL((k_diag<T, U>), dim3(grid_for(count, kBlock * U)), dim3(kBlock), 0, s->stream,
-                     st, count, ins, make_diagdesc(p), (const amp_t<T>*)s->arena);
+  const DiagDesc dd = make_diagdesc(p);
+  const amp_t<T>* table = (const amp_t<T>*)s->arena;
+  LAUNCH_STREAMING(k_diag, T, kUPhase, count, ins, st, count, ins, sp.low, dd, table);
   HIPCHK(hipGetLastError());
   return QIP_OK;
 }
@@ -798,16 +823,32 @@ static int launch_swap(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact,
   // so applying them one after another is bit-identical to the single permutation.
   const uint32_t h = (uint32_t)p.opos.size() / 2;
-  const uint64_t cmask = mask_of(p.cpos);
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
   for (uint32_t j = 0; j < h; ++j) {
-    const uint32_t pa = p.opos[j], pb = p.opos[h + j];
-    std::vector<uint32_t> pos = p.cpos;
-    pos.push_back(pa);
-    pos.push_back(pb);
-    Ins ins = make_ins(pos, cmask);
-    const uint64_t npairs = 1ull << (s->n - (uint32_t)pos.size());
-    const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
-    LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask);
+    uint32_t pa = p.opos[j], pb = p.opos[h + j];
+    if (pa > pb) std::swap(pa, pb);  // pa < pb
+    const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
+    const uint64_t nsub = 1ull << (s->n - (uint32_t)sp.hi.size());
+    if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
+      Ins ins = make_ins(sp.hi, sp.hi_ones);
+      LAUNCH_STREAMING(k_swap_xlane1, T, kUXlane, nsub, ins, st, nsub, ins, wa, wb, sp.low);
+    } else if (wa < 6 && nsub >= 128) {  // low bit in the lane index, high bit picks the row
+      std::vector<uint32_t> pos = sp.hi;
+      pos.push_back(pb);
+      Ins ins = make_ins(pos, sp.hi_ones);
+      const uint64_t nitems = nsub >> 1;
+      const uint64_t hmask = 1ull << pb;
+      // wa is unchanged by opening pb (pb > pa)
+      LAUNCH_STREAMING(k_swap_xlane2, T, kUSwap, nitems, ins, st, nitems, ins, wa, hmask, sp.low);
+    } else {
+      std::vector<uint32_t> pos = sp.hi;
+      pos.push_back(pa);
+      pos.push_back(pb);
+      Ins ins = make_ins(pos, sp.hi_ones);
+      const uint64_t npairs = nsub >> 2;
+      const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
+      LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask, sp.low);
+    }
     HIPCHK(hipGetLastError());
   }
   return QIP_OK;
@@ -859,19 +900,20 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   memset(&d, 0, sizeof d);
   for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
   const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
-  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * 8);
+  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * 8);  // waves loop over items
   const dim3 grid(blocks), block(kBlock);
   const double* af = (const double*)s->arena;
   const bool nt = use_nt(s);
-#define MF(K)                                                                                            \
-  do {                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
-    else hipLaunchKernelGGL((k_gate_kq_mfma<K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+#define MF(K, WU)                                                                                            \
+  do {                                                                                                       \
+    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<K, WU, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
+    else hipLaunchKernelGGL((k_gate_kq_mfma<K, WU, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
   } while (0)
+  // WU items per iteration so that WU * 2^k / 4 = 8 loads are in flight per lane (nitems is a power of two)
   switch (k) {
-    case 3: MF(3); break;
-    case 4: MF(4); break;
-    case 5: MF(5); break;
+    case 3: if (nitems >= 4) MF(3, 4); else MF(3, 1); break;
+    case 4: if (nitems >= 2) MF(4, 2); else MF(4, 1); break;
+    case 5: MF(5, 1); break;
     default: return fail(QIP_ERR_UNSUPPORTED, "matrix-core kernel for k = %u", k);
   }
 #undef MF
@@ -906,9 +948,18 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   const dim3 grid(grid_for(groups, kBlock)), block(kBlock);
   const amp_t<T>* mat = (const amp_t<T>*)s->arena;
   switch (k) {
-    case 2: hipLaunchKernelGGL((k_gate_kq<T, 2>), grid, block, 0, s->stream, st, groups, ins, d, mat); break;
-    case 3: hipLaunchKernelGGL((k_gate_kq<T, 3>), grid, block, 0, s->stream, st, groups, ins, d, mat); break;
-    case 4: hipLaunchKernelGGL((k_gate_kq<T, 4>), grid, block, 0, s->stream, st, groups, ins, d, mat); break;
+    case 2:
+      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 2, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      else hipLaunchKernelGGL((k_gate_kq<T, 2, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      break;
+    case 3:
+      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 3, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      else hipLaunchKernelGGL((k_gate_kq<T, 3, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      break;
+    case 4:
+      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 4, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      else hipLaunchKernelGGL((k_gate_kq<T, 4, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      break;
     default: return fail(QIP_ERR_UNSUPPORTED, "register kernel for k = %u", k);
   }
   HIPCHK(hipGetLastError());
@@ -1146,24 +1197,59 @@ template <typename T>
 static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vector<uint32_t>& pos,
                            uint64_t m_first, uint64_t m_count, double* out) {
   const uint32_t k = md.k;
-  if (k <= 10 || m_count == 1) {
-    Ins ins = make_ins(pos, 0);
-    const uint64_t count = 1ull << (s->n - k);
-    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(count / (kBlock * 8), 1), 1024);
-    // grid.y is limited to 65535; k <= 10 keeps m_count <= 1024
-    QCHK(ensure_partial(s, (size_t)gx * m_count));
-    hipLaunchKernelGGL((k_measure_probs<T>), dim3(gx, (unsigned)m_count), dim3(kBlock), 0, s->stream,
-                       (const amp_t<T>*)s->cur, count, ins, md, m_first, s->d_partial);
+  if (m_count == (1ull << k) && k <= 4) {
+    // all outcomes of a few qubits: one coalesced pass, 2^k running sums per lane
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(s->namps / (kBlock * 8), 1), 2048);
+    const size_t M = (size_t)1 << k;
+    QCHK(ensure_partial(s, (size_t)gx * M));
+    const amp_t<T>* st = (const amp_t<T>*)s->cur;
+    switch (k) {
+      case 1: hipLaunchKernelGGL((k_measure_probs_small<T, 1>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      case 2: hipLaunchKernelGGL((k_measure_probs_small<T, 2>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      case 3: hipLaunchKernelGGL((k_measure_probs_small<T, 3>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      default: hipLaunchKernelGGL((k_measure_probs_small<T, 4>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+    }
     HIPCHK(hipGetLastError());
-    std::vector<double> part((size_t)gx * m_count);
+    std::vector<double> part((size_t)gx * M);
     HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost,
                           s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (uint64_t m = 0; m < m_count; ++m) {
+    for (size_t m = 0; m < M; ++m) {
       double t = 0;
-      for (unsigned b = 0; b < gx; ++b) t += part[m * gx + b];
+      for (unsigned b = 0; b < gx; ++b) t += part[(size_t)b * M + m];
       out[m] = t;
     }
+    return QIP_OK;
+  }
+  if (m_count == (1ull << k) && k <= 12) {
+    // a moderate number of outcomes: per-block LDS histogram + one global atomic per bin per block
+    const uint32_t nbins = 1u << k;
+    QCHK(ensure_partial(s, nbins));
+    HIPCHK(hipMemsetAsync(s->d_partial, 0, nbins * sizeof(double), s->stream));
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(s->namps / (kBlock * 16), 1), 1024);
+    hipLaunchKernelGGL((k_measure_probs_hist<T>), dim3(gx), dim3(kBlock), nbins * sizeof(double), s->stream,
+                       (const amp_t<T>*)s->cur, s->namps, md, nbins, s->d_partial);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s->d_partial, nbins * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return QIP_OK;
+  }
+  if (m_count == 1) {
+    // one outcome: sum over the sub-space whose measured bits read m (measure_prob_fn :65-112)
+    Ins ins = make_ins(pos, 0);
+    const uint64_t count = 1ull << (s->n - k);
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(count / (kBlock * 8), 1), 1024);
+    QCHK(ensure_partial(s, (size_t)gx));
+    hipLaunchKernelGGL((k_measure_probs<T>), dim3(gx, 1), dim3(kBlock), 0, s->stream,
+                       (const amp_t<T>*)s->cur, count, ins, md, m_first, s->d_partial);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)gx);
+    HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double t = 0;
+    for (unsigned b = 0; b < gx; ++b) t += part[b];
+    out[0] = t;
     return QIP_OK;
   }
   // many outcomes: scatter-add |amp|^2 into a device table of 2^k doubles

@@ -124,14 +124,27 @@ template <bool NT, typename A> __device__ __forceinline__ void stg(A* p, A v) {
   else *p = v;
 }
 
+// Selector bits below bit kLineBits (inside one 128-B line = 8 amplitudes) are NOT removed from the
+// grid: a control or phase bit there would leave every line half-touched, and a partially written
+// line costs a read-for-ownership on top of the write (measured on MI355X at n = 30: T on bit 0 took
+// 8.8 ms as a strided half-line sweep vs 5.3 ms for a full sweep; CNOT with control bit 0: 9.4 ms vs
+// 2.7 ms with a high control).  Such bits become a per-lane predicate instead — `(idx & mask) == val`
+// picks between the updated and the unchanged amplitude — and the sweep reads and writes whole lines.
+constexpr uint32_t kLineBits = 3;
+struct Sel {
+  uint64_t mask, val;
+};
+__device__ __forceinline__ bool sel_hit(uint64_t idx, const Sel& s) { return (idx & s.mask) == s.val; }
+
 // ---- 1-qubit gate, pair per lane ---------------------------------------------
 // Work item = one (|0>,|1>) pair of the target bit inside the all-controls-one subspace.
-// `ins` opens the target bit and every control bit; ormask sets the controls.
+// `ins` opens the target bit and every control bit >= kLineBits; ormask sets those controls;
+// `low` carries the controls below kLineBits.
 // out0 = m00*a0 + m01*a1 ; out1 = m10*a0 + m11*a1, folded from 0 in column order
 // (matrix_ops.rs:78-93, ops.rs:104-110).
 template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ st, uint64_t npairs,
-                                                        Ins ins, uint64_t tmask, Mat2<T> g) {
+                                                        Ins ins, uint64_t tmask, Sel low, Mat2<T> g) {
   using A = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
@@ -149,8 +162,9 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ s
     if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1[u]));
     if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0[u]));
     if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1[u]));
-    stg<NT>(st + i0[u], r0);
-    stg<NT>(st + (i0[u] | tmask), r1);
+    const bool hit = sel_hit(i0[u], low);
+    stg<NT>(st + i0[u], hit ? r0 : a0[u]);
+    stg<NT>(st + (i0[u] | tmask), hit ? r1 : a1[u]);
   }
 }
 
@@ -158,10 +172,10 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ s
 // For a target bit that lands inside the lane index (work-index bit tb < 6) the wave
 // keeps fully contiguous 1-KiB rows: each lane loads ONE amplitude, fetches its partner
 // from lane ^ (1<<tb) and computes only its own output row.  `ins` opens only the
-// control bits.  Requires the work-item count to be a multiple of 64.
+// control bits >= kLineBits.  Requires the work-item count to be a multiple of 64.
 template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ st, uint64_t namps,
-                                                         Ins ins, uint32_t tb, Mat2<T> g) {
+                                                         Ins ins, uint32_t tb, Sel low, Mat2<T> g) {
   using A = amp_t<T>;
   if (GUARD && work_index<0>(0) >= namps) return;  // whole waves leave together (namps % 64 == 0)
   const bool hi = (threadIdx.x >> tb) & 1u;  // this lane holds the |1> member
@@ -187,18 +201,18 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
     A r = czero<A>();
     if (nz_lo) r = cadd(r, cmul(m_lo, lo));
     if (nz_hi) r = cadd(r, cmul(m_hi, hv));
-    stg<NT>(st + idx[u], r);
+    stg<NT>(st + idx[u], sel_hit(idx[u], low) ? r : own[u]);
   }
 }
 
 // ---- scalar phase on a subspace ----------------------------------------------------
-// Every amplitude whose bits at `ins.pos` equal `ins.ormask` is multiplied by `value`.
-// This is Z/S/T, controlled-phase, multi-controlled Z...: a diagonal gate whose other
-// diagonal entries are exactly 1 leaves those amplitudes untouched (1*x == x), so they
-// are neither read nor written.
+// Every amplitude whose involved bits match is multiplied by `value`: Z/S/T, controlled-phase,
+// multi-controlled Z...  A diagonal gate whose other diagonal entries are exactly 1 leaves those
+// amplitudes untouched (1*x == x), so whole lines outside the subspace are neither read nor
+// written.  `ins` opens the involved bits >= kLineBits; `low` carries the ones inside a line.
 template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
-                                                  amp_t<T> value) {
+                                                  Sel low, amp_t<T> value) {
   using A = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
@@ -209,14 +223,14 @@ __global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uin
     x[u] = ldg<NT>(st + idx[u]);
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) stg<NT>(st + idx[u], cmul(value, x[u]));
+  for (int u = 0; u < U; ++u) stg<NT>(st + idx[u], sel_hit(idx[u], low) ? cmul(value, x[u]) : x[u]);
 }
 
 // ---- diagonal 1-qubit gate with both entries != 1 (Rz), optionally controlled ----------
 // Amplitude per lane inside the control subspace; the factor is picked by the target bit.
 template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_diag1q(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
-                                                   uint64_t tmask, amp_t<T> d0, amp_t<T> d1) {
+                                                   uint64_t tmask, Sel low, amp_t<T> d0, amp_t<T> d1) {
   using A = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
@@ -227,16 +241,18 @@ __global__ __launch_bounds__(kBlock) void k_diag1q(amp_t<T>* __restrict__ st, ui
     x[u] = ldg<NT>(st + idx[u]);
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) stg<NT>(st + idx[u], cmul((idx[u] & tmask) ? d1 : d0, x[u]));
+  for (int u = 0; u < U; ++u)
+    stg<NT>(st + idx[u], sel_hit(idx[u], low) ? cmul((idx[u] & tmask) ? d1 : d0, x[u]) : x[u]);
 }
 
 // ---- exchange of two index bits (Swap with h = 1, optionally controlled) ---------------
 // SwapOpIterator (qubit_iterators.rs:208-218) yields the single column whose A and B
 // halves are exchanged, with value 1: a pure move.  Only amplitudes whose two bits differ
 // change, so a work item is one (01,10) pair and the other half of the vector is untouched.
+// Used when both bits are >= 6 (whole 1-KiB wave rows move).
 template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st, uint64_t npairs,
-                                                      Ins ins, uint64_t amask, uint64_t bmask) {
+                                                      Ins ins, uint64_t amask, uint64_t bmask, Sel low) {
   using A = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
@@ -249,35 +265,102 @@ __global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st,
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    stg<NT>(st + (i0[u] | amask), xb[u]);
-    stg<NT>(st + (i0[u] | bmask), xa[u]);
+    const bool hit = sel_hit(i0[u], low);
+    stg<NT>(st + (i0[u] | amask), hit ? xb[u] : xa[u]);
+    stg<NT>(st + (i0[u] | bmask), hit ? xa[u] : xb[u]);
+  }
+}
+
+// ---- exchange of two index bits when one (or both) lies inside the lane index -----------
+// Whole rows stay contiguous: a lane loads the row element(s) it owns and receives the value that
+// moves into its slot from another lane (ds_bpermute), then full lines are written back.
+//   two-row form (lb < 6 <= hb): `ins` opens bit hb (and high controls); a lane holds r0 (hb = 0)
+//     and r1 (hb = 1) at the same low index; slot (lb=1, hb=0) <-> slot (lb=0, hb=1).
+//   one-row form (both < 6): work-index bits la, lb (after control removal) are both lane bits:
+//     the lane reads from the lane whose two bits are exchanged.
+template <typename T, int U, bool GUARD, bool NT, int NP>
+__global__ __launch_bounds__(kBlock) void k_swap_xlane2(amp_t<T>* __restrict__ st, uint64_t nitems,
+                                                        Ins ins, uint32_t lb_w, uint64_t hmask, Sel low) {
+  using A = amp_t<T>;
+  if (GUARD && work_index<0>(0) >= nitems) return;
+  const bool lbit = (threadIdx.x >> lb_w) & 1u;
+  uint64_t i0[U];
+  A r0[U], r1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    r0[u] = ldg<NT>(st + i0[u]);
+    r1[u] = ldg<NT>(st + (i0[u] | hmask));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // lanes with lb = 1 give away their r0 (slot lb=1,hb=0); lanes with lb = 0 give away their r1
+    const A give = lbit ? r0[u] : r1[u];
+    A got;
+    got.x = __shfl_xor(give.x, 1 << lb_w, 64);
+    got.y = __shfl_xor(give.y, 1 << lb_w, 64);
+    // the partner lane has the same control bits (they are not lb), so one predicate serves both
+    const bool hit = sel_hit(i0[u], low);
+    const A n0 = (hit && lbit) ? got : r0[u];
+    const A n1 = (hit && !lbit) ? got : r1[u];
+    stg<NT>(st + i0[u], n0);
+    stg<NT>(st + (i0[u] | hmask), n1);
+  }
+}
+
+template <typename T, int U, bool GUARD, bool NT, int NP>
+__global__ __launch_bounds__(kBlock) void k_swap_xlane1(amp_t<T>* __restrict__ st, uint64_t nitems,
+                                                        Ins ins, uint32_t la_w, uint32_t lb_w, Sel low) {
+  using A = amp_t<T>;
+  if (GUARD && work_index<0>(0) >= nitems) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t ba = (lane >> la_w) & 1u, bb = (lane >> lb_w) & 1u;
+  const uint32_t src = (lane & ~((1u << la_w) | (1u << lb_w))) | (bb << la_w) | (ba << lb_w);
+  uint64_t idx[U];
+  A x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    x[u] = ldg<NT>(st + idx[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    A got;
+    got.x = __shfl(x[u].x, (int)src, 64);
+    got.y = __shfl(x[u].y, (int)src, 64);
+    stg<NT>(st + idx[u], sel_hit(idx[u], low) ? got : x[u]);
   }
 }
 
 // ---- general diagonal gate on k qubits ------------------------------------------------
-// Amplitude per lane inside the control subspace; factor = diag[sub-index].  Entries equal
-// to exactly 1 are skipped (not loaded).  `tpos[j]` is the bit position of op index j
-// (j = 0 is the MSB of the sub-index, matrix_ops.rs:12-21).
+// Amplitude per lane inside the control subspace; factor = diag[sub-index] (table in the arena, served
+// by the caches).  `tpos[j]` is the bit position of op index j (j = 0 is the MSB of the sub-index,
+// matrix_ops.rs:12-21).  Every amplitude of the subspace is rewritten (1*x == x exactly for finite x),
+// which keeps the sweep line-granular whatever the target bits are.
 struct DiagDesc {
   uint32_t k;
   uint32_t tpos[32];
 };
 
-template <typename T, int U>
+template <typename T, int U, bool GUARD, bool NT, int NP>
 __global__ __launch_bounds__(kBlock) void k_diag(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
-                                                 DiagDesc d, const amp_t<T>* __restrict__ diag) {
+                                                 Sel low, DiagDesc d, const amp_t<T>* __restrict__ diag) {
   using A = amp_t<T>;
-  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (GUARD && work_index<0>(0) >= count) return;
+  uint64_t idx[U];
+  A x[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const uint64_t w = base + (uint64_t)u * kBlock;
-    if (w >= count) continue;
-    const uint64_t i = insert_bits<-1>(w, ins);
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    x[u] = ldg<NT>(st + idx[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
     uint32_t sub = 0;
-    for (uint32_t j = 0; j < d.k; ++j) sub = (sub << 1) | (uint32_t)((i >> d.tpos[j]) & 1ull);
+    for (uint32_t j = 0; j < d.k; ++j) sub = (sub << 1) | (uint32_t)((idx[u] >> d.tpos[j]) & 1ull);
     const A f = diag[sub];
-    if (f.x == (T)1 && f.y == (T)0) continue;
-    st[i] = cmul(f, st[i]);
+    const bool unit = f.x == (T)1 && f.y == (T)0;
+    stg<NT>(st + idx[u], (sel_hit(idx[u], low) && !unit) ? cmul(f, x[u]) : x[u]);
   }
 }
 
@@ -286,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_diag(amp_t<T>* __restrict__ st, uint
 // controls.  off[c] is the amplitude-index offset of sub-index c.  The matrix is read
 // through wave-uniform (scalar) loads.  Zero entries are multiplied, not skipped: for
 // finite amplitudes 0*x adds +-0, which leaves every sum IEEE-equal to the reference's.
-template <typename T, int K>
+template <typename T, int K, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, uint64_t ngroups,
                                                     Ins ins, DiagDesc d,
                                                     const amp_t<T>* __restrict__ mat) {
@@ -306,13 +389,13 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, u
   }
   A x[S];
 #pragma unroll
-  for (int c = 0; c < S; ++c) x[c] = st[i0 | off[c]];
+  for (int c = 0; c < S; ++c) x[c] = ldg<NT>(st + (i0 | off[c]));
 #pragma unroll
   for (int r = 0; r < S; ++r) {
     A acc = czero<A>();
 #pragma unroll
     for (int c = 0; c < S; ++c) acc = cadd(acc, cmul(mat[r * S + c], x[c]));
-    st[i0 | off[r]] = acc;
+    stg<NT>(st + (i0 | off[r]), acc);
   }
 }
 
@@ -343,7 +426,7 @@ struct MfmaDesc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-template <int K, bool NT>
+template <int K, int WU, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restrict__ st,
                                                          uint64_t nitems, Ins ins, MfmaDesc d,
                                                          const double* __restrict__ afrag) {
@@ -351,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
   constexpr int S = 1 << K;
   constexpr int TT = S / 8;   // 16x16 tiles per dimension of the (2S x 2S) real matrix
   constexpr int KS = S / 2;   // K-steps of 4
-  constexpr int NA = S / 4;   // amplitudes per lane
+  constexpr int NA = S / 4;   // amplitudes per lane per item
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t j = lane & 15u, q = lane >> 4;
   double a[TT][KS];
@@ -369,27 +452,37 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
       if ((m >> b) & 1) o |= 1ull << d.tau[b + 2];
     offm[m] = o;
   }
+  // WU items (16 groups each) per iteration keep WU*NA = 8 independent 16-B loads in flight per lane
   const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / 64);
-  for (uint64_t w = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < nitems; w += nwaves) {
-    const uint64_t base = insert_bits<-1>((w << 4) | j, ins) | offq;
-    A x[NA];
+  for (uint64_t w = ((uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * WU; w < nitems;
+       w += nwaves * WU) {
+    uint64_t base[WU];
+    A x[WU][NA];
 #pragma unroll
-    for (int m = 0; m < NA; ++m) x[m] = ldg<NT>(st + (base | offm[m]));
+    for (int i = 0; i < WU; ++i) {
+      base[i] = insert_bits<-1>(((w + i) << 4) | j, ins) | offq;
 #pragma unroll
-    for (int rb = 0; rb < TT; ++rb) {
-      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int m = 0; m < NA; ++m) x[i][m] = ldg<NT>(st + (base[i] | offm[m]));
+    }
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][s], (s & 1) ? x[s >> 1].y : x[s >> 1].x, acc, 0, 0, 0);
-      A y0, y1;
-      y0.x = acc[0];
-      y0.y = acc[1];
-      y1.x = acc[2];
-      y1.y = acc[3];
-      // all of this wave's loads were issued before its first store (x[] is complete), and no other
-      // wave touches these amplitudes, so the update is in place
-      stg<NT>(st + (base | offm[2 * rb]), y0);
-      stg<NT>(st + (base | offm[2 * rb + 1]), y1);
+    for (int i = 0; i < WU; ++i) {
+#pragma unroll
+      for (int rb = 0; rb < TT; ++rb) {
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][s], (s & 1) ? x[i][s >> 1].y : x[i][s >> 1].x,
+                                                     acc, 0, 0, 0);
+        A y0, y1;
+        y0.x = acc[0];
+        y0.y = acc[1];
+        y1.x = acc[2];
+        y1.y = acc[3];
+        // every load of this iteration was issued before its first store, and no other wave touches
+        // these amplitudes, so the update is in place
+        stg<NT>(st + (base[i] | offm[2 * rb]), y0);
+        stg<NT>(st + (base[i] | offm[2 * rb + 1]), y1);
+      }
     }
   }
 }
@@ -508,6 +601,7 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* smem) {
   double t = 0;
   if (threadIdx.x == 0)
     for (int i = 0; i < kBlock / 64; ++i) t += smem[i];
+  __syncthreads();  // smem may be reused by the next call
   return t;  // valid in thread 0
 }
 
@@ -542,6 +636,56 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs(const amp_t<T>* __rest
   }
   const double t = block_reduce_sum(s, smem);
   if (threadIdx.x == 0) partial[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// few outcomes (k <= 4): ONE fully coalesced pass over the vector; every lane keeps 2^K running sums
+// (select-by-compare, no dynamic register indexing) and blocks write partial[blockIdx.x * 2^K + m].
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void k_measure_probs_small(const amp_t<T>* __restrict__ st,
+                                                                uint64_t namps, MeasDesc md,
+                                                                double* __restrict__ partial) {
+  constexpr int M = 1 << K;
+  __shared__ double smem[kBlock / 64];
+  double acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = 0.0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
+    const amp_t<T> x = __builtin_nontemporal_load(st + i);
+    const double p = (double)(x.x * x.x + x.y * x.y);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int b = 0; b < K; ++b) mine |= (uint32_t)((i >> md.mpos[b]) & 1ull) << b;
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] += (mine == (uint32_t)m) ? p : 0.0;
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double t = block_reduce_sum(acc[m], smem);
+    if (threadIdx.x == 0) partial[(uint64_t)blockIdx.x * M + m] = t;
+  }
+}
+
+// a moderate number of outcomes (2^k doubles fit in LDS): per-block LDS histogram, then one global
+// atomic per bin per block
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_measure_probs_hist(const amp_t<T>* __restrict__ st,
+                                                               uint64_t namps, MeasDesc md, uint32_t nbins,
+                                                               double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double hist[];
+  for (uint32_t b = threadIdx.x; b < nbins; b += kBlock) hist[b] = 0.0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
+    const amp_t<T> x = __builtin_nontemporal_load(st + i);
+    if (x.x == (T)0 && x.y == (T)0) continue;  // measurement_ops.rs:98-99
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < md.k; ++b) m |= (uint32_t)((i >> md.mpos[b]) & 1ull) << b;
+    atomicAdd(&hist[m], (double)(x.x * x.x + x.y * x.y));
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbins; b += kBlock)
+    if (hist[b] != 0.0) atomicAdd(&out[b], hist[b]);
 }
 
 // probabilities of many outcomes: every amplitude adds |amp|^2 to out[its outcome]

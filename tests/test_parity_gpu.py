@@ -193,6 +193,53 @@ def test_swap(O, h):
         check(O, n, cop, seed=trial, exact=True)
 
 
+def test_swap_every_bit_pair_and_low_controls(O):
+    """every (a, b) transposition at n = 9: lane-permutation form (both < 6), two-row cross-lane form
+    (a < 6 <= b) and row-move form (both >= 6), bare and under controls that sit inside a 128-B line."""
+    n = 9
+    x = rand_state(n, 3)
+    for qa in range(n):
+        for qb in range(n):
+            if qa == qb:
+                continue
+            op = q.make_swap_op([qa], [qb])
+            assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), (qa, qb)
+    for qa, qb, ctrl in ((8, 0, [7]), (8, 7, [6]), (0, 1, [8, 2]), (5, 2, [8, 7, 6]), (3, 4, [7, 0])):
+        op = q.make_control_op(ctrl, q.make_swap_op([qa], [qb]))
+        assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), (qa, qb, ctrl)
+
+
+def test_selectors_inside_a_cache_line(O):
+    """controls / phase bits at bit positions 0..2 become lane predicates (full-line sweeps)."""
+    n = 10
+    x = rand_state(n, 4)
+    low_q = [n - 1, n - 2, n - 3]  # qubits at bit positions 0, 1, 2
+    for ctrl in ([low_q[0]], [low_q[1]], [low_q[2]], low_q[:2], low_q, [low_q[0], 1], [low_q[2], 0, 4]):
+        for tgt in (0, 5, 3):
+            for name in ("X", "H", "Rz", "T", "Z", "dense"):
+                op = q.make_control_op(ctrl, q.make_matrix_op([tgt], GATES_1Q[name]))
+                want = oracle_apply(O, n, op, x)
+                for opts in ({}, {"lowbit_shuffle": 0}):
+                    assert np.array_equal(hip_apply(n, op, x, **opts), want), (ctrl, tgt, name, opts)
+        # low target with low control (cross-lane kernel with a predicate)
+        free_low = [t for t in low_q if t not in ctrl]
+        if free_low:
+            op = q.make_control_op(ctrl, q.make_matrix_op([free_low[0]], GATES_1Q["H"]))
+            assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x))
+    for tq in low_q + [n - 4, 0]:
+        for name in ("T", "Z", "S", "Rz"):
+            op = q.make_matrix_op([tq], GATES_1Q[name])
+            assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), (tq, name)
+    rng = np.random.default_rng(1)
+    d = np.exp(1j * rng.uniform(0, 6, 8))
+    d[3] = 1.0
+    for idx in ([n - 1, n - 2, 0], [0, n - 1, 4], [n - 3, n - 2, n - 1]):
+        op = q.make_matrix_op(idx, np.diag(d).ravel())
+        assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), idx
+        cop = q.make_control_op([5 if 5 not in idx else 6], op)
+        assert np.array_equal(hip_apply(n, cop, x), oracle_apply(O, n, cop, x)), idx
+
+
 # ---- dense k-qubit --------------------------------------------------------------------------------
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
 def test_dense_k_qubit(O, k):
