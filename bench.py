@@ -230,6 +230,26 @@ def main():
         dt = time.perf_counter() - t
         extras["single_qubit_only"] = {"n": n, "gates": len(single), "GBps": sum(circuit_bytes(q, n, single)) / dt / 1e9,
                                        "gates_per_s": len(single) / dt, "frac_of_8TBps": sum(circuit_bytes(q, n, single)) / dt / 1e9 / HBM_PEAK_GBPS}
+        # gate fusion: the same circuit with option fuse = 5 — one sweep per fused gate
+        st.set_option("fuse", 5)
+        st.set_option("profile", 1)
+        st.profile_reset()
+        cf = st.compile_ops(ops)
+        st.apply_compiled(cf)
+        st.sync()
+        st.profile_reset()
+        t = time.perf_counter()
+        st.apply_compiled(cf)
+        st.sync()
+        dt = time.perf_counter() - t
+        prof_f = st.profile()
+        sweeps = sum(v["launches"] for v in prof_f.values())
+        sweep_bytes = sum(v["algorithmic_bytes"] for v in prof_f.values())
+        extras["fused_k5"] = {"gates": len(ops), "sweeps": sweeps, "gates_per_s": len(ops) / dt, "ms_per_step": 1e3 * dt,
+                              "sweep_GBps": sweep_bytes / dt / 1e9,
+                              "note": "per-sweep bytes (32*2^n per fused dense gate), never per-gate bytes over sweep time"}
+        st.set_option("fuse", 0)
+        st.set_option("profile", 0)
         st.close()
         # configs[1] exactly: n = 28
         n28 = 28

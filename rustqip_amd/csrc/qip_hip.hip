@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -366,6 +368,7 @@ struct qip_hip_state {
   int64_t profile = 0;
   int64_t lowbit_shuffle = 1;
   int64_t mfma = 1;
+  int64_t fuse = 0;  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
   std::vector<ProfRec> pending;
@@ -575,6 +578,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "profile")) s->profile = value;
   else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
   else if (!strcmp(key, "mfma")) s->mfma = value;
+  else if (!strcmp(key, "fuse")) s->fuse = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
@@ -912,7 +916,7 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   // WU items per iteration so that WU * 2^k / 4 = 8 loads are in flight per lane (nitems is a power of two)
   switch (k) {
     case 3: if (nitems >= 4) MF(3, 4); else MF(3, 1); break;
-    case 4: if (nitems >= 2) MF(4, 2); else MF(4, 1); break;
+    case 4: MF(4, 1); break;
     case 5: MF(5, 1); break;
     default: return fail(QIP_ERR_UNSUPPORTED, "matrix-core kernel for k = %u", k);
   }
@@ -925,8 +929,19 @@ template <typename T>
 static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
   const uint32_t k = (uint32_t)p.opos.size();
   const uint32_t used = (uint32_t)(p.opos.size() + p.cpos.size());
+  // how many target bits sit inside the lane index (a lane's 2^k accesses then share 1-KiB rows
+  // with its neighbours only partially)
+  uint32_t low_targets = 0, min_target = 64;
+  for (uint32_t t : p.opos) {
+    if (t < 6) ++low_targets;
+    min_target = std::min(min_target, t);
+  }
   if constexpr (std::is_same<T, double>::value) {
-    if (s->mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
+    // matrix cores: always for k = 5 (no register form), and for k = 3, 4 when two or more targets are
+    // low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
+    // register form does not (measured at n = 30: profiles/r01_ops_table*.md)
+    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2);
+    if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
       return launch_kq_mfma(s, p, st);
     }
@@ -949,15 +964,15 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   const amp_t<T>* mat = (const amp_t<T>*)s->arena;
   switch (k) {
     case 2:
-      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 2, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 2, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       else hipLaunchKernelGGL((k_gate_kq<T, 2, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       break;
     case 3:
-      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 3, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 3, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       else hipLaunchKernelGGL((k_gate_kq<T, 3, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       break;
     case 4:
-      if (use_nt(s)) hipLaunchKernelGGL((k_gate_kq<T, 4, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
+      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 4, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       else hipLaunchKernelGGL((k_gate_kq<T, 4, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
       break;
     default: return fail(QIP_ERR_UNSUPPORTED, "register kernel for k = %u", k);
@@ -1058,9 +1073,201 @@ extern "C" int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op) {
   return s->dtype == QIP_C64 ? apply_op_t<double>(s, op) : apply_op_t<float>(s, op);
 }
 
+// ---------------------------------------------------------------------------------------
+// gate fusion: option "fuse" = K merges consecutive small gates into dense
+// gates on <= K qubits, applied in ONE sweep each.  The reference has no analogue (its apply_ops
+// multi-op path is unused and inconsistent); this is pure host bookkeeping on
+// 2^K x 2^K matrices.  Results equal the gate-by-gate path up to the rounding of the matrix
+// products (|delta| ~ 1e-15 per fused gate), so fused runs are held to the 1e-12 bar, never to
+// bit equality.  Open clusters always act on pairwise disjoint qubit sets, so they commute and
+// may be flushed in any order; an op is merged only into clusters it overlaps, or into a
+// disjoint one (which also commutes with every other open cluster).
+// ---------------------------------------------------------------------------------------
+typedef std::complex<double> cd;
+struct Cluster {
+  std::vector<uint32_t> pos;  // bit positions, descending: pos[0] is the MSB of the sub-index
+  std::vector<cd> m;          // 2^q x 2^q, row-major
+};
+
+// dense matrix of a flattened op over its own index list (controls first), MSB-first order
+template <typename T>
+static bool op_to_dense(uint32_t n, const FlatOp& f, uint32_t max_k, std::vector<uint32_t>* pos,
+                        std::vector<cd>* mat) {
+  if (!f.distinct || f.k_all > max_k) return false;
+  const uint32_t kt = f.k_all, k = f.n_op;
+  const size_t S = (size_t)1 << kt, Si = (size_t)1 << k, thr = S - Si;
+  pos->clear();
+  for (uint32_t j = 0; j < kt; ++j) pos->push_back(n - 1 - (uint32_t)f.outer->indices[j]);
+  mat->assign(S * S, cd(0, 0));
+  for (size_t r = 0; r < thr; ++r) (*mat)[r * S + r] = cd(1, 0);
+  const T* dense = static_cast<const T*>(f.inner->dense);
+  const T* vals = static_cast<const T*>(f.inner->sparse_vals);
+  for (size_t r = 0; r < Si; ++r) {
+    switch (f.inner->kind) {
+      case QIP_OP_MATRIX:
+        for (size_t c = 0; c < Si; ++c)
+          (*mat)[(thr + r) * S + thr + c] = cd(dense[2 * (r * Si + c)], dense[2 * (r * Si + c) + 1]);
+        break;
+      case QIP_OP_SPARSE:
+        for (uint64_t e = f.inner->sparse_rowptr[r]; e < f.inner->sparse_rowptr[r + 1]; ++e)
+          (*mat)[(thr + r) * S + thr + f.inner->sparse_cols[e]] += cd(vals[2 * e], vals[2 * e + 1]);
+        break;
+      default: {  // SWAP
+        const uint32_t h = k >> 1;
+        const size_t c = ((r & (((size_t)1 << h) - 1)) << h) + (r >> h);
+        (*mat)[(thr + r) * S + thr + c] = cd(1, 0);
+      }
+    }
+  }
+  return true;
+}
+
+// matrix of `m` (over positions `pos`, MSB first) embedded into the space of `upos` (descending)
+static std::vector<cd> embed(const std::vector<cd>& m, const std::vector<uint32_t>& pos,
+                             const std::vector<uint32_t>& upos) {
+  const uint32_t u = (uint32_t)upos.size(), k = (uint32_t)pos.size();
+  const size_t U = (size_t)1 << u, S = (size_t)1 << k;
+  std::vector<uint32_t> bit_in_u(k);
+  size_t opmask = 0;
+  for (uint32_t i = 0; i < k; ++i)
+    for (uint32_t j = 0; j < u; ++j)
+      if (upos[j] == pos[i]) {
+        bit_in_u[i] = u - 1 - j;
+        opmask |= (size_t)1 << (u - 1 - j);
+      }
+  auto sub = [&](size_t r) {
+    size_t s_ = 0;
+    for (uint32_t i = 0; i < k; ++i) s_ |= ((r >> bit_in_u[i]) & 1) << (k - 1 - i);
+    return s_;
+  };
+  std::vector<cd> e(U * U, cd(0, 0));
+  for (size_t r = 0; r < U; ++r)
+    for (size_t c = 0; c < U; ++c)
+      if ((r & ~opmask) == (c & ~opmask)) e[r * U + c] = m[sub(r) * S + sub(c)];
+  return e;
+}
+
+static void cluster_apply(Cluster* cl, const std::vector<uint32_t>& pos, const std::vector<cd>& m) {
+  std::vector<uint32_t> upos = cl->pos;
+  for (uint32_t p : pos)
+    if (std::find(upos.begin(), upos.end(), p) == upos.end()) upos.push_back(p);
+  std::sort(upos.begin(), upos.end(), std::greater<uint32_t>());
+  const size_t U = (size_t)1 << upos.size();
+  const std::vector<cd> a = embed(m, pos, upos);              // the new gate, applied after
+  const std::vector<cd> b = embed(cl->m, cl->pos, upos);      // what the cluster already holds
+  std::vector<cd> out(U * U, cd(0, 0));
+  for (size_t r = 0; r < U; ++r)
+    for (size_t k = 0; k < U; ++k) {
+      const cd v = a[r * U + k];
+      if (v == cd(0, 0)) continue;
+      for (size_t c = 0; c < U; ++c) out[r * U + c] += v * b[k * U + c];
+    }
+  cl->pos = upos;
+  cl->m = out;
+}
+
+template <typename T>
+static int flush_cluster(qip_hip_state* s, const Cluster& cl) {
+  const size_t S = (size_t)1 << cl.pos.size();
+  std::vector<uint64_t> idx;
+  for (uint32_t p : cl.pos) idx.push_back(s->n - 1 - p);
+  std::vector<T> data(2 * S * S);
+  for (size_t e = 0; e < S * S; ++e) {
+    data[2 * e] = (T)cl.m[e].real();
+    data[2 * e + 1] = (T)cl.m[e].imag();
+  }
+  qip_op op;
+  memset(&op, 0, sizeof op);
+  op.kind = QIP_OP_MATRIX;
+  op.n_indices = (uint32_t)idx.size();
+  op.indices = idx.data();
+  op.dense = data.data();
+  return apply_op_t<T>(s, &op);
+}
+
+template <typename T>
+static int apply_ops_fused(qip_hip_state* s, const qip_op* ops, uint64_t count, uint32_t K) {
+  std::vector<Cluster> open;
+  auto overlaps = [](const Cluster& c, const std::vector<uint32_t>& pos) {
+    for (uint32_t p : pos)
+      if (std::find(c.pos.begin(), c.pos.end(), p) != c.pos.end()) return true;
+    return false;
+  };
+  auto flush_overlapping = [&](const std::vector<uint32_t>& pos) -> int {
+    for (size_t i = 0; i < open.size();) {
+      if (overlaps(open[i], pos)) {
+        QCHK(flush_cluster<T>(s, open[i]));
+        open.erase(open.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+    return QIP_OK;
+  };
+  for (uint64_t i = 0; i < count; ++i) {
+    FlatOp f;
+    int rc = flatten_op(s->n, &ops[i], false, &f);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+    std::vector<uint32_t> pos;
+    std::vector<cd> m;
+    if (!op_to_dense<T>(s->n, f, K, &pos, &m)) {
+      // not fusable (too many qubits / repeated indices): everything it touches goes first
+      std::vector<uint32_t> all;
+      for (uint32_t j = 0; j < f.k_all; ++j) all.push_back(s->n - 1 - (uint32_t)f.outer->indices[j]);
+      QCHK(flush_overlapping(all));
+      QCHK(apply_op_t<T>(s, &ops[i]));
+      continue;
+    }
+    std::vector<size_t> hit;
+    size_t union_size = pos.size();
+    for (size_t c = 0; c < open.size(); ++c)
+      if (overlaps(open[c], pos)) {
+        hit.push_back(c);
+        for (uint32_t p : open[c].pos)
+          if (std::find(pos.begin(), pos.end(), p) == pos.end()) ++union_size;
+      }
+    if (hit.empty()) {
+      // disjoint from every open cluster: join the fullest one that still has room
+      size_t best = open.size();
+      for (size_t c = 0; c < open.size(); ++c)
+        if (open[c].pos.size() + pos.size() <= K && (best == open.size() || open[c].pos.size() > open[best].pos.size()))
+          best = c;
+      if (best == open.size()) {
+        Cluster cl;
+        cl.pos = {};
+        cl.m = {cd(1, 0)};
+        open.push_back(cl);
+      }
+      cluster_apply(&open[best], pos, m);
+    } else if (union_size <= K) {
+      // merge the overlapped clusters (mutually disjoint => their product is a Kronecker product)
+      for (size_t h = 1; h < hit.size(); ++h) cluster_apply(&open[hit[0]], open[hit[h]].pos, open[hit[h]].m);
+      for (size_t h = hit.size(); h-- > 1;) open.erase(open.begin() + hit[h]);
+      cluster_apply(&open[hit[0]], pos, m);
+    } else {
+      QCHK(flush_overlapping(pos));
+      Cluster cl;
+      cl.pos = {};
+      cl.m = {cd(1, 0)};
+      cluster_apply(&cl, pos, m);
+      open.push_back(cl);
+    }
+  }
+  for (const Cluster& cl : open) QCHK(flush_cluster<T>(s, cl));
+  return QIP_OK;
+}
+
 extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) {
   STATE_ENTER(s);
   if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
+  if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
+    const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, s->dtype == QIP_C64 ? kMaxMfmaK : kMaxRegK);
+    if (s->n >= K + 4)
+      return s->dtype == QIP_C64 ? apply_ops_fused<double>(s, ops, count, K) : apply_ops_fused<float>(s, ops, count, K);
+  }
   for (uint64_t i = 0; i < count; ++i) {
     int rc = s->dtype == QIP_C64 ? apply_op_t<double>(s, &ops[i]) : apply_op_t<float>(s, &ops[i]);
     if (rc != QIP_OK) {

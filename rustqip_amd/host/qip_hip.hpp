@@ -95,11 +95,12 @@ template <typename P> class MatrixOp {
   const MatrixOp* inner() const { return inner_.get(); }
   std::shared_ptr<MatrixOp> inner_ptr() const { return inner_; }
 
-  /// The `struct qip_op` tree for the C ABI plus the buffers it points into.
+  /// The `struct qip_op` tree for the C ABI.  It owns every buffer it points into (including a copy
+  /// of the matrix data), so it stays valid after the MatrixOp it was made from is gone.
   struct CView {
     qip_op op{};
     std::vector<uint64_t> idx, rowptr, cols;
-    std::vector<C> vals;
+    std::vector<C> vals, dense;
     std::unique_ptr<CView> inner;
   };
   std::unique_ptr<CView> to_c() const {
@@ -113,7 +114,8 @@ template <typename P> class MatrixOp {
         if (data_.size() != (size_t(1) << (2 * indices_.size())))
           throw CircuitError("Matrix data has " + std::to_string(data_.size()) + " entries versus expected 2^2*" +
                              std::to_string(indices_.size()));
-        v->op.dense = data_.data();
+        v->dense = data_;
+        v->op.dense = v->dense.data();
         break;
       case Kind::SparseMatrix:
         v->op.kind = QIP_OP_SPARSE;

@@ -158,7 +158,9 @@ static void gpu_checks() {
       want[m] += std::norm(st[i]);
     }
     for (int m = 0; m < 4; ++m) {
-      EXPECT(std::abs(res.second[0].probs[m] - want[m]) < 1e-12);
+      if (!(std::abs(res.second[0].probs[m] - want[m]) < 1e-12 * (1.0 + want[m])))
+        std::printf("  probs[%d] = %.17g, oracle-side sum = %.17g\n", m, res.second[0].probs[m], want[m]);
+      EXPECT(std::abs(res.second[0].probs[m] - want[m]) < 1e-12 * (1.0 + want[m]));
       psum += res.second[0].probs[m];
     }
     std::printf("builder circuit: max|delta| vs oracle = %.3e, sum of probs = %.15f\n", maxd, psum);

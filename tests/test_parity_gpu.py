@@ -478,6 +478,48 @@ def test_config_circuits_reduced_n(O, name, n):
         assert abs(abs(got[0]) ** 2 - math.sin(3 * theta) ** 2) < 1e-10
 
 
+@pytest.mark.parametrize("K", [2, 3, 4, 5])
+def test_gate_fusion_matches_gate_by_gate(O, K):
+    """option fuse = K: consecutive gates merged into dense <= K-qubit gates, one sweep each.
+    Same state as the gate-by-gate oracle to the 1e-12 bar (matrix products round differently)."""
+    n = 12
+    rng = np.random.default_rng(K)
+    mixed = []
+    for _ in range(40):
+        perm = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 7))
+        if kind == 0:
+            mixed.append(q.make_swap_op([perm[0]], [perm[1]]))
+        elif kind == 1:
+            mixed.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], GATES_1Q["dense"])))
+        elif kind == 2:
+            mixed.append(q.make_sparse_matrix_op(perm[:2], [[(1, 0.5j)], [(0, 2.0)], [(3, 1.0)], [(2, -1.0), (3, 0.25)]]))
+        elif kind == 3:
+            mixed.append(q.make_control_op(perm[:7], q.make_matrix_op([perm[7]], GATES_1Q["Z"])))  # not fusable
+        elif kind == 4:
+            mixed.append(q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()))
+        else:
+            mixed.append(q.make_matrix_op([perm[0]], GATES_1Q[["H", "T", "Rz", "X"][int(rng.integers(0, 4))]]))
+    for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 200, seed=28)),
+                      ("qft", circuits.c3_qft(n)),
+                      ("c4", circuits.c4_clifford_t(n, 200, seed=32)),
+                      ("grover", circuits.h_layer(n) + circuits.c5_grover_iteration(n)),
+                      ("mixed", mixed)):
+        x = circuits.random_state(n, seed=K)
+        with q.HipState(n) as st:
+            st.set_option("fuse", K)
+            st.set_option("profile", 1)
+            st.upload(x)
+            st.apply_ops(ops)
+            got = st.download()
+            sweeps = sum(v["launches"] for v in st.profile().values())
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        scale = max(1.0, float(np.max(np.abs(want))))
+        assert np.max(np.abs(got - want)) <= TOL64 * scale * 10, (name, K)
+        if name in ("c2", "c4"):
+            assert sweeps < len(ops) / 1.5, (name, K, sweeps, len(ops))  # fusion really merged gates
+
+
 def test_qft_matches_dft(O):
     """Size-independent property: the QFT circuit is the DFT matrix (bit-reversal included)."""
     n = 8
