@@ -28,7 +28,7 @@ def main():
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g = int(math.log2(world))
-    for n in (10, 14):
+    for n in (12,):
         x = circuits.random_state(n, n)
         for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 96, seed=28)),
                           ("c4", circuits.c4_clifford_t(n, 96, seed=32)),
