@@ -127,12 +127,20 @@ def main():
 
     if not torch.cuda.is_available() or q.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: rustqip_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # QIP_BENCH_DIST_BACKEND=gloo is a TEST hook: several ranks share one GPU and the remap all-to-all is
+    # staged through host memory, so the N > 1 code path can be exercised where only one GPU exists.
+    # Real multi-GPU runs use nccl (= RCCL) on device buffers.
+    dist_backend = os.environ.get("QIP_BENCH_DIST_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=dist_backend)
 
     n = args.n_local + g
     ops = circuits.c2_random_circuit(n, args.gates, seed=28)
@@ -144,7 +152,7 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1:
-        st = q.HipState(n, np.complex128, device=local_rank)
+        st = q.HipState(n, np.complex128, device=device)
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))  # dense state, every amplitude 2^(-n/2)
         compiled = st.compile_ops(ops)
@@ -153,9 +161,9 @@ def main():
         set_profile = lambda v: st.set_option("profile", v)
         get_profile = lambda: (st.profile(), st.profile_reset())[0]
     else:
-        from rustqip_amd.sharded import ShardedState
+        from rustqip_amd.sharded import HipBackend, ShardedState
 
-        st = ShardedState(n, dist, device=local_rank)
+        st = ShardedState(n, dist, backend=HipBackend(args.n_local, device, host_staged_exchange=dist_backend != "nccl"))
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
         plan = st.plan(ops)
@@ -177,7 +185,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     profile = get_profile()
@@ -250,6 +258,20 @@ def main():
                               "note": "per-sweep bytes (32*2^n per fused dense gate), never per-gate bytes over sweep time"}
         st.set_option("fuse", 0)
         st.set_option("profile", 0)
+        # the other single-GPU configs of BASELINE.json on the same resident state size
+        for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
+                            ("configs4_grover_iteration_n%d" % n, circuits.c5_grover_iteration(n)),
+                            ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True))):
+            cc = st.compile_ops(cops)
+            st.apply_compiled(cc)
+            st.sync()
+            t = time.perf_counter()
+            st.apply_compiled(cc)
+            st.sync()
+            dt = time.perf_counter() - t
+            by = sum(circuit_bytes(q, n, cops))
+            extras[cname] = {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": by / dt / 1e9}
+        extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28
         n28 = 28

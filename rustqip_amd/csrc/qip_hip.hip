@@ -368,7 +368,8 @@ struct qip_hip_state {
   int64_t profile = 0;
   int64_t lowbit_shuffle = 1;
   int64_t mfma = 1;
-  int64_t fuse = 0;  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
+  int64_t fuse = 0;
+  int64_t packed_f32 = 1;  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
   std::vector<ProfRec> pending;
@@ -579,6 +580,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
   else if (!strcmp(key, "mfma")) s->mfma = value;
   else if (!strcmp(key, "fuse")) s->fuse = value;
+  else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
@@ -696,6 +698,7 @@ template <typename F> static void dispatch_np(uint32_t npos, F&& f) {
 // States that cannot stay in the 256-MiB Infinity Cache stream with non-temporal accesses.
 static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_bytes >= (1ull << 30); }
 
+// (E, the 16-B element type, must be in scope: amp_t<T>, or f32x4 for the packed f32 view.)
 // LAUNCH_STREAMING(kernel, T, U, count, ins, args...): the unguarded <U> shape with the 32-KiB lane
 // spacing when the power-of-two work-item count allows it, else the guarded single-item shape.
 #define LAUNCH_STREAMING(KERNEL, T, UU, COUNT, INS, ...)                                           \
@@ -703,13 +706,13 @@ static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_byt
     constexpr int NP = decltype(np_)::value;                                                       \
     if ((COUNT) >= ((uint64_t)(UU) << kStrideShift)) {                                             \
       if (use_nt(s))                                                                               \
-        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP>), dim3(grid_for((COUNT), kBlock * (UU))), \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP, E>), dim3(grid_for((COUNT), kBlock * (UU))), \
                            dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
       else                                                                                         \
-        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP>), dim3(grid_for((COUNT), kBlock * (UU))), \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP, E>), dim3(grid_for((COUNT), kBlock * (UU))), \
                            dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
     } else {                                                                                       \
-      hipLaunchKernelGGL((KERNEL<T, 1, true, false, NP>), dim3(grid_for((COUNT), kBlock)),        \
+      hipLaunchKernelGGL((KERNEL<T, 1, true, false, NP, E>), dim3(grid_for((COUNT), kBlock)),     \
                          dim3(kBlock), 0, s->stream, __VA_ARGS__);                                 \
     }                                                                                              \
   })
@@ -749,9 +752,8 @@ static uint32_t work_bit(uint32_t pos, const std::vector<uint32_t>& opened) {
   return pos - below;
 }
 
-template <typename T>
-static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
-  const uint32_t n = s->n;
+template <typename T, typename E>
+static int launch_gate1q(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* actual_cls) {
   const uint32_t tpos = p.opos[0];
   Mat2<T> g;
   for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(p.m[2 * e], p.m[2 * e + 1]);
@@ -775,8 +777,8 @@ static int launch_gate1q(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* act
   return QIP_OK;
 }
 
-template <typename T>
-static int launch_phase(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+template <typename T, typename E>
+static int launch_phase(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
   const uint32_t k = (uint32_t)p.opos.size();
   std::vector<uint32_t> pos = p.cpos;
   uint64_t ones = mask_of(p.cpos);
@@ -786,7 +788,7 @@ static int launch_phase(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   }
   const Split sp = split_selectors(pos, ones);
   Ins ins = make_ins(sp.hi, sp.hi_ones);
-  const uint64_t count = 1ull << (s->n - (uint32_t)sp.hi.size());
+  const uint64_t count = 1ull << (n - (uint32_t)sp.hi.size());
   const amp_t<T> value = mk<T>(p.phase[0], p.phase[1]);
   LAUNCH_STREAMING(k_phase, T, kUPhase, count, ins, st, count, ins, sp.low, value);
   HIPCHK(hipGetLastError());
@@ -801,11 +803,11 @@ static DiagDesc make_diagdesc(const Plan& p) {
   return d;
 }
 
-template <typename T>
-static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls) {
+template <typename T, typename E>
+static int launch_diag(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* actual_cls) {
   const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
   Ins ins = make_ins(sp.hi, sp.hi_ones);
-  const uint64_t count = 1ull << (s->n - (uint32_t)sp.hi.size());
+  const uint64_t count = 1ull << (n - (uint32_t)sp.hi.size());
   if (p.opos.size() == 1) {  // Rz-like: no table, factor picked by the target bit
     *actual_cls = KC_DIAG1Q;
     const uint64_t tmask = 1ull << p.opos[0];
@@ -822,8 +824,8 @@ static int launch_diag(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actua
   return QIP_OK;
 }
 
-template <typename T>
-static int launch_swap(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+template <typename T, typename E>
+static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
   // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact,
   // so applying them one after another is bit-identical to the single permutation.
   const uint32_t h = (uint32_t)p.opos.size() / 2;
@@ -832,7 +834,7 @@ static int launch_swap(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
     uint32_t pa = p.opos[j], pb = p.opos[h + j];
     if (pa > pb) std::swap(pa, pb);  // pa < pb
     const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
-    const uint64_t nsub = 1ull << (s->n - (uint32_t)sp.hi.size());
+    const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
     if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
       Ins ins = make_ins(sp.hi, sp.hi_ones);
       LAUNCH_STREAMING(k_swap_xlane1, T, kUXlane, nsub, ins, st, nsub, ins, wa, wb, sp.low);
@@ -1046,11 +1048,61 @@ static int apply_op_t(qip_hip_state* s, const qip_op* op) {
   if (s->profile) QCHK(prof_begin(s, p.cls, p.alg_bytes, &rec));
   amp_t<T>* st = (amp_t<T>*)s->cur;
   int rc = QIP_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    // packed f32 view: 2^(n-1) elements of two amplitudes each, bit positions shifted down by one
+    const bool streaming = p.cls == KC_GATE1Q_PAIR || p.cls == KC_PHASE || p.cls == KC_DIAG || p.cls == KC_SWAP_BITS;
+    bool bit0_selector = false, bit0_target = false;
+    for (uint32_t c : p.cpos) bit0_selector |= c == 0;
+    for (uint32_t t : p.opos) bit0_target |= t == 0;
+    if (streaming && s->packed_f32 && s->n >= 2 && !bit0_selector &&
+        (!bit0_target || p.cls == KC_GATE1Q_PAIR)) {
+      Plan q = p;
+      for (auto& c : q.cpos) c -= 1;
+      f32x4* pst = (f32x4*)s->cur;
+      const uint32_t ne = s->n - 1;
+      using E = f32x4;
+      if (bit0_target) {  // the pair is the two halves of one element
+        Mat2<float> g;
+        for (int e = 0; e < 4; ++e) g.m[e] = mk<float>(p.m[2 * e], p.m[2 * e + 1]);
+        g.nz = p.nz;
+        const Split sp = split_selectors(q.cpos, mask_of(q.cpos));
+        Ins ins = make_ins(sp.hi, sp.hi_ones);
+        const uint64_t count = 1ull << (ne - (uint32_t)sp.hi.size());
+        rec.cls = KC_GATE1Q_XLANE;
+        dispatch_np(ins.npos, [&](auto np_) {
+          constexpr int NP = decltype(np_)::value;
+          if (count >= ((uint64_t)kUXlane << kStrideShift)) {
+            if (use_nt(s))
+              hipLaunchKernelGGL((k_gate1q_inelem<kUXlane, false, true, NP>), dim3(grid_for(count, kBlock * kUXlane)),
+                                 dim3(kBlock), 0, s->stream, pst, count, ins, sp.low, g);
+            else
+              hipLaunchKernelGGL((k_gate1q_inelem<kUXlane, false, false, NP>), dim3(grid_for(count, kBlock * kUXlane)),
+                                 dim3(kBlock), 0, s->stream, pst, count, ins, sp.low, g);
+          } else {
+            hipLaunchKernelGGL((k_gate1q_inelem<1, true, false, NP>), dim3(grid_for(count, kBlock)), dim3(kBlock), 0,
+                               s->stream, pst, count, ins, sp.low, g);
+          }
+        });
+        HIPCHK(hipGetLastError());
+      } else {
+        for (auto& t : q.opos) t -= 1;
+        switch (p.cls) {
+          case KC_GATE1Q_PAIR: rc = launch_gate1q<float, E>(s, ne, q, pst, &rec.cls); break;
+          case KC_PHASE: rc = launch_phase<float, E>(s, ne, q, pst); break;
+          case KC_DIAG: rc = launch_diag<float, E>(s, ne, q, pst, &rec.cls); break;
+          default: rc = launch_swap<float, E>(s, ne, q, pst); break;
+        }
+      }
+      if (rc != QIP_OK) return rc;
+      if (s->profile) QCHK(prof_end(s, &rec));
+      return QIP_OK;
+    }
+  }
   switch (p.cls) {
-    case KC_GATE1Q_PAIR: rc = launch_gate1q<T>(s, p, st, &rec.cls); break;
-    case KC_PHASE: rc = launch_phase<T>(s, p, st); break;
-    case KC_DIAG: rc = launch_diag<T>(s, p, st, &rec.cls); break;
-    case KC_SWAP_BITS: rc = launch_swap<T>(s, p, st); break;
+    case KC_GATE1Q_PAIR: rc = launch_gate1q<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
+    case KC_PHASE: rc = launch_phase<T, amp_t<T>>(s, s->n, p, st); break;
+    case KC_DIAG: rc = launch_diag<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
+    case KC_SWAP_BITS: rc = launch_swap<T, amp_t<T>>(s, s->n, p, st); break;
     case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
     default: {
       QCHK(ensure_alt(s));

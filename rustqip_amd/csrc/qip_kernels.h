@@ -78,9 +78,64 @@ template <typename A> __device__ __forceinline__ A cadd(A a, A b) {
   return r;
 }
 template <typename A> __device__ __forceinline__ A czero() {
-  A r;
-  r.x = 0;
-  r.y = 0;
+  A r = {};
+  return r;
+}
+
+// Packed single precision: one 16-B element = TWO adjacent Complex<f32> amplitudes (index bit 0 lives
+// inside the element).  Any op that does not involve bit 0 acts on both halves alike, so the f32 state
+// is swept with the same 16-B per-lane accesses as f64: an (n-1)-"qubit" vector of float4 elements.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 cmul(amp_t<float> m, f32x4 x) {
+  f32x4 r;
+  r.x = m.x * x.x - m.y * x.y;
+  r.y = m.x * x.y + m.y * x.x;
+  r.z = m.x * x.z - m.y * x.w;
+  r.w = m.x * x.w + m.y * x.z;
+  return r;
+}
+__device__ __forceinline__ f32x4 cadd(f32x4 a, f32x4 b) { return a + b; }
+
+template <typename E> __device__ __forceinline__ E shfl_xor_e(E v, int lane_mask);
+template <> __device__ __forceinline__ amp_t<double> shfl_xor_e(amp_t<double> v, int m) {
+  amp_t<double> r;
+  r.x = __shfl_xor(v.x, m, 64);
+  r.y = __shfl_xor(v.y, m, 64);
+  return r;
+}
+template <> __device__ __forceinline__ amp_t<float> shfl_xor_e(amp_t<float> v, int m) {
+  amp_t<float> r;
+  r.x = __shfl_xor(v.x, m, 64);
+  r.y = __shfl_xor(v.y, m, 64);
+  return r;
+}
+template <> __device__ __forceinline__ f32x4 shfl_xor_e(f32x4 v, int m) {
+  f32x4 r;
+  r.x = __shfl_xor(v.x, m, 64);
+  r.y = __shfl_xor(v.y, m, 64);
+  r.z = __shfl_xor(v.z, m, 64);
+  r.w = __shfl_xor(v.w, m, 64);
+  return r;
+}
+template <typename E> __device__ __forceinline__ E shfl_e(E v, int src);
+template <> __device__ __forceinline__ amp_t<double> shfl_e(amp_t<double> v, int src) {
+  amp_t<double> r;
+  r.x = __shfl(v.x, src, 64);
+  r.y = __shfl(v.y, src, 64);
+  return r;
+}
+template <> __device__ __forceinline__ amp_t<float> shfl_e(amp_t<float> v, int src) {
+  amp_t<float> r;
+  r.x = __shfl(v.x, src, 64);
+  r.y = __shfl(v.y, src, 64);
+  return r;
+}
+template <> __device__ __forceinline__ f32x4 shfl_e(f32x4 v, int src) {
+  f32x4 r;
+  r.x = __shfl(v.x, src, 64);
+  r.y = __shfl(v.y, src, 64);
+  r.z = __shfl(v.z, src, 64);
+  r.w = __shfl(v.w, src, 64);
   return r;
 }
 
@@ -142,10 +197,11 @@ __device__ __forceinline__ bool sel_hit(uint64_t idx, const Sel& s) { return (id
 // `low` carries the controls below kLineBits.
 // out0 = m00*a0 + m01*a1 ; out1 = m10*a0 + m11*a1, folded from 0 in column order
 // (matrix_ops.rs:78-93, ops.rs:104-110).
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ st, uint64_t npairs,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_gate1q_pair(E* __restrict__ st, uint64_t npairs,
                                                         Ins ins, uint64_t tmask, Sel low, Mat2<T> g) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A a0[U], a1[U];
@@ -173,15 +229,16 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_pair(amp_t<T>* __restrict__ s
 // keeps fully contiguous 1-KiB rows: each lane loads ONE amplitude, fetches its partner
 // from lane ^ (1<<tb) and computes only its own output row.  `ins` opens only the
 // control bits >= kLineBits.  Requires the work-item count to be a multiple of 64.
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ st, uint64_t namps,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_gate1q_xlane(E* __restrict__ st, uint64_t namps,
                                                          Ins ins, uint32_t tb, Sel low, Mat2<T> g) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= namps) return;  // whole waves leave together (namps % 64 == 0)
   const bool hi = (threadIdx.x >> tb) & 1u;  // this lane holds the |1> member
   // row of the gate this lane evaluates: (m_lo, m_hi) multiply (|0> member, |1> member)
-  const A m_lo = hi ? g.m[2] : g.m[0];
-  const A m_hi = hi ? g.m[3] : g.m[1];
+  const M m_lo = hi ? g.m[2] : g.m[0];
+  const M m_hi = hi ? g.m[3] : g.m[1];
   const bool nz_lo = hi ? (g.nz & 4u) : (g.nz & 1u);
   const bool nz_hi = hi ? (g.nz & 8u) : (g.nz & 2u);
   uint64_t idx[U];
@@ -193,9 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    A other;
-    other.x = __shfl_xor(own[u].x, 1 << tb, 64);
-    other.y = __shfl_xor(own[u].y, 1 << tb, 64);
+    const A other = shfl_xor_e<A>(own[u], 1 << tb);
     const A lo = hi ? other : own[u];
     const A hv = hi ? own[u] : other;
     A r = czero<A>();
@@ -205,15 +260,51 @@ __global__ __launch_bounds__(kBlock) void k_gate1q_xlane(amp_t<T>* __restrict__ 
   }
 }
 
+// ---- packed f32, target = index bit 0: the pair is the two halves of one element ------------------
+// `ins` / `low` are in element-index space (controls are at bit >= 1 of the amplitude index).
+template <int U, bool GUARD, bool NT, int NP>
+__global__ __launch_bounds__(kBlock) void k_gate1q_inelem(f32x4* __restrict__ st, uint64_t count, Ins ins,
+                                                          Sel low, Mat2<float> g) {
+  using M = amp_t<float>;
+  if (GUARD && work_index<0>(0) >= count) return;
+  uint64_t idx[U];
+  f32x4 x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    idx[u] = insert_bits<NP>(work_index<Log2<U>::v>(u), ins);
+    x[u] = ldg<NT>(st + idx[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    M a0, a1;
+    a0.x = x[u].x;
+    a0.y = x[u].y;
+    a1.x = x[u].z;
+    a1.y = x[u].w;
+    M r0 = czero<M>(), r1 = czero<M>();
+    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+    f32x4 r;
+    r.x = r0.x;
+    r.y = r0.y;
+    r.z = r1.x;
+    r.w = r1.y;
+    stg<NT>(st + idx[u], sel_hit(idx[u], low) ? r : x[u]);
+  }
+}
+
 // ---- scalar phase on a subspace ----------------------------------------------------
 // Every amplitude whose involved bits match is multiplied by `value`: Z/S/T, controlled-phase,
 // multi-controlled Z...  A diagonal gate whose other diagonal entries are exactly 1 leaves those
 // amplitudes untouched (1*x == x), so whole lines outside the subspace are neither read nor
 // written.  `ins` opens the involved bits >= kLineBits; `low` carries the ones inside a line.
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_phase(E* __restrict__ st, uint64_t count, Ins ins,
                                                   Sel low, amp_t<T> value) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
@@ -228,10 +319,11 @@ __global__ __launch_bounds__(kBlock) void k_phase(amp_t<T>* __restrict__ st, uin
 
 // ---- diagonal 1-qubit gate with both entries != 1 (Rz), optionally controlled ----------
 // Amplitude per lane inside the control subspace; the factor is picked by the target bit.
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_diag1q(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_diag1q(E* __restrict__ st, uint64_t count, Ins ins,
                                                    uint64_t tmask, Sel low, amp_t<T> d0, amp_t<T> d1) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
@@ -250,10 +342,11 @@ __global__ __launch_bounds__(kBlock) void k_diag1q(amp_t<T>* __restrict__ st, ui
 // halves are exchanged, with value 1: a pure move.  Only amplitudes whose two bits differ
 // change, so a work item is one (01,10) pair and the other half of the vector is untouched.
 // Used when both bits are >= 6 (whole 1-KiB wave rows move).
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st, uint64_t npairs,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_swap_bits(E* __restrict__ st, uint64_t npairs,
                                                       Ins ins, uint64_t amask, uint64_t bmask, Sel low) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A xa[U], xb[U];
@@ -278,10 +371,11 @@ __global__ __launch_bounds__(kBlock) void k_swap_bits(amp_t<T>* __restrict__ st,
 //     and r1 (hb = 1) at the same low index; slot (lb=1, hb=0) <-> slot (lb=0, hb=1).
 //   one-row form (both < 6): work-index bits la, lb (after control removal) are both lane bits:
 //     the lane reads from the lane whose two bits are exchanged.
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_swap_xlane2(amp_t<T>* __restrict__ st, uint64_t nitems,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_swap_xlane2(E* __restrict__ st, uint64_t nitems,
                                                         Ins ins, uint32_t lb_w, uint64_t hmask, Sel low) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= nitems) return;
   const bool lbit = (threadIdx.x >> lb_w) & 1u;
   uint64_t i0[U];
@@ -296,9 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_swap_xlane2(amp_t<T>* __restrict__ s
   for (int u = 0; u < U; ++u) {
     // lanes with lb = 1 give away their r0 (slot lb=1,hb=0); lanes with lb = 0 give away their r1
     const A give = lbit ? r0[u] : r1[u];
-    A got;
-    got.x = __shfl_xor(give.x, 1 << lb_w, 64);
-    got.y = __shfl_xor(give.y, 1 << lb_w, 64);
+    const A got = shfl_xor_e<A>(give, 1 << lb_w);
     // the partner lane has the same control bits (they are not lb), so one predicate serves both
     const bool hit = sel_hit(i0[u], low);
     const A n0 = (hit && lbit) ? got : r0[u];
@@ -308,10 +400,11 @@ __global__ __launch_bounds__(kBlock) void k_swap_xlane2(amp_t<T>* __restrict__ s
   }
 }
 
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_swap_xlane1(amp_t<T>* __restrict__ st, uint64_t nitems,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_swap_xlane1(E* __restrict__ st, uint64_t nitems,
                                                         Ins ins, uint32_t la_w, uint32_t lb_w, Sel low) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= nitems) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t ba = (lane >> la_w) & 1u, bb = (lane >> lb_w) & 1u;
@@ -325,9 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_swap_xlane1(amp_t<T>* __restrict__ s
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    A got;
-    got.x = __shfl(x[u].x, (int)src, 64);
-    got.y = __shfl(x[u].y, (int)src, 64);
+    const A got = shfl_e<A>(x[u], (int)src);
     stg<NT>(st + idx[u], sel_hit(idx[u], low) ? got : x[u]);
   }
 }
@@ -342,10 +433,11 @@ struct DiagDesc {
   uint32_t tpos[32];
 };
 
-template <typename T, int U, bool GUARD, bool NT, int NP>
-__global__ __launch_bounds__(kBlock) void k_diag(amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_diag(E* __restrict__ st, uint64_t count, Ins ins,
                                                  Sel low, DiagDesc d, const amp_t<T>* __restrict__ diag) {
-  using A = amp_t<T>;
+  using A = E;
+  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
@@ -358,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_diag(amp_t<T>* __restrict__ st, uint
   for (int u = 0; u < U; ++u) {
     uint32_t sub = 0;
     for (uint32_t j = 0; j < d.k; ++j) sub = (sub << 1) | (uint32_t)((idx[u] >> d.tpos[j]) & 1ull);
-    const A f = diag[sub];
+    const M f = diag[sub];
     const bool unit = f.x == (T)1 && f.y == (T)0;
     stg<NT>(st + idx[u], (sel_hit(idx[u], low) && !unit) ? cmul(f, x[u]) : x[u]);
   }

@@ -189,6 +189,9 @@ class HipBackend:
     def measure_probs(self, local_qubits: Sequence[int]) -> np.ndarray:
         return self.state.measure_probs(local_qubits)
 
+    def measure_state(self, local_qubits: Sequence[int], measured: int, prob: float) -> None:
+        self.state.measure_state(local_qubits, measured, prob)
+
     def sync(self) -> None:
         self.state.sync()
         self.torch.cuda.synchronize(self.dev)
@@ -410,6 +413,39 @@ class ShardedState:
         else:
             out[fixed] = self.backend.norm_sqr()
         return self._allreduce_sum(out)
+
+    def measure(self, indices: Sequence[int], measured: Optional[int] = None, rand_u01: float = 0.0):
+        """measure (measurement_ops.rs:190-214) on the sharded state.  With `measured` given it plays
+        MeasuredCondition; otherwise the outcome is drawn from the marginal distribution of the measured
+        qubits with the caller's uniform sample (walking outcomes in increasing order) — statistically the
+        reference's soft_measure (:153-176), though not the same sample-to-outcome map, which would need
+        the full vector in logical index order.  Collapse: every shard zeroes / rescales with the GLOBAL
+        probability (measure_state :220-269; no-op when it is 0)."""
+        k = len(indices)
+        probs = self.measure_probs(indices)
+        if measured is None:
+            r, m = float(rand_u01) * float(probs.sum()), 0
+            for m, pm in enumerate(probs):
+                r -= pm
+                if r <= 0:
+                    break
+        else:
+            m = int(measured)
+        p = float(probs[m])
+        if p == 0.0:
+            return m, p
+        pps = [self.phys[self.n - 1 - qb] for qb in indices]
+        loc = [i for i in range(k) if pps[i] < self.L]
+        agrees = all(self._rank_bit(pps[i]) == ((m >> i) & 1) for i in range(k) if pps[i] >= self.L)
+        if not agrees:
+            # this rank's bits contradict the outcome: the whole shard goes to zero
+            self.backend.apply_op(make_matrix_op([0], [0, 0, 0, 0]))
+        else:
+            lm = 0
+            for b, i in enumerate(loc):
+                lm |= ((m >> i) & 1) << b
+            self.backend.measure_state([self._local_qubit(pps[i]) for i in loc], lm, p)
+        return m, p
 
     # -- misc ---------------------------------------------------------------------------------------------------------
     def sync(self) -> None:

@@ -57,6 +57,12 @@ class OracleBackend:
     def measure_probs(self, local_qubits):
         return O.measure_probs(self.n_local, list(local_qubits), self._np(self.cur))
 
+    def measure_state(self, local_qubits, measured, prob):
+        cur = self._np(self.cur)
+        out = self._np(1 - self.cur)
+        if O.measure_state(self.n_local, list(local_qubits), (int(measured), float(prob)), cur, out):
+            self.cur = 1 - self.cur
+
     def sync(self):
         pass
 

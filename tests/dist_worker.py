@@ -76,6 +76,22 @@ def main():
                 assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(n, idx, want))) < 1e-12, (name, idx)
             if name in ("c4", "qft"):
                 assert st.stats["remaps"] >= 1, "circuit was expected to touch a global qubit"
+            # collapsing measurement, forced outcomes: every shard rescales with the global probability
+            for idx, forced in (([0], 1), ([n - 1, 1], 2), ([2, 0, n - 1], 5)):
+                st2 = ShardedState(n, dist, backend=OracleBackend(n - g))
+                st2.upload_global(x)
+                st2.apply_ops(ops[: len(ops) // 2])
+                ref = O.apply_ops_in_place(n, ops[: len(ops) // 2], x.copy())
+                m, p = st2.measure(idx, measured=forced)
+                out = np.zeros_like(ref)
+                wm, wp = O.measure(n, idx, ref, out, forced=forced)
+                if wp == 0:
+                    out = ref
+                assert m == wm and abs(p - wp) < 1e-12, (name, idx)
+                assert np.max(np.abs(st2.download_global() - out)) < 1e-12, (name, idx)
+                ms, ps = st2.measure(idx, rand_u01=0.37)  # sampled: already collapsed, so it repeats
+                if wp > 0:
+                    assert ms == forced and abs(ps - 1) < 1e-12
             # a basis state finds its owner through the permuted layout
             st.init_basis(5 % (1 << n))
             e = np.zeros(1 << n, dtype=np.complex128)

@@ -448,6 +448,52 @@ def test_complex64_path(O):
             assert np.max(np.abs(got - want)) <= TOL32
 
 
+def test_complex64_packed_view(O):
+    """f32 states are swept as 2^(n-1) 16-B elements of two amplitudes whenever index bit 0 is not a
+    selector; bit 0 as a 1-qubit target is handled inside the element.  Same arithmetic as the unpacked
+    8-B path, so the two must be bit-identical, and both match the f32 oracle."""
+    n = 9
+    rng = np.random.default_rng(12)
+    x = rand_state(n, 13, np.complex64)
+    ops = []
+    for t in range(n):
+        for g in ("H", "X", "Rz", "T", "Z", "dense", "upper"):
+            ops.append(q.make_matrix_op([t], GATES_1Q[g]))
+    for c, t in ((0, 8), (8, 0), (7, 8), (8, 7), (3, 6), (6, 3), (7, 1)):
+        for g in ("X", "H", "Rz", "T"):
+            ops.append(q.make_control_op([c], q.make_matrix_op([t], GATES_1Q[g])))
+    ops.append(q.make_control_op([0, 7, 2], q.make_matrix_op([8], GATES_1Q["X"])))
+    for a, b in ((0, 8), (8, 7), (7, 6), (2, 5), (1, 7), (0, 1)):
+        ops.append(q.make_swap_op([a], [b]))
+        ops.append(q.make_control_op([4], q.make_swap_op([a], [b])))
+    d = np.exp(1j * rng.uniform(0, 6, 4))
+    for idx in ([0, 1], [7, 8], [3, 8], [7, 2]):
+        ops.append(q.make_matrix_op(idx, np.diag(d).ravel()))
+    for op in ops:
+        want = oracle_apply(O, n, op, x)
+        packed = hip_apply(n, op, x)
+        plain = hip_apply(n, op, x, packed_f32=0)
+        assert packed.dtype == np.complex64
+        assert np.array_equal(packed, plain), repr(op)
+        assert np.max(np.abs(packed - want)) <= TOL32, repr(op)
+    # a whole circuit in f32, n large enough for the unguarded kernel shapes
+    n = 16
+    circ = circuits.h_layer(n) + circuits.c2_random_circuit(n, 128, seed=5) + circuits.c3_qft(n)[:60]
+    x = circuits.random_state(n, 3, np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.upload(x)
+        st.apply_ops(circ)
+        got = st.download()
+    with q.HipState(n, np.complex64) as st:
+        st.set_option("packed_f32", 0)
+        st.upload(x)
+        st.apply_ops(circ)
+        plain = st.download()
+    assert np.array_equal(got, plain)
+    want = O.apply_ops_in_place(n, circ, x.copy())
+    assert np.max(np.abs(got - want)) <= 1e-4
+
+
 # ---- whole circuits (BASELINE configs at reduced n) -------------------------------------------------------
 @pytest.mark.parametrize("name,n", [("c2", 16), ("c3", 12), ("c4", 14), ("c5", 10), ("c5k3", 10)])
 def test_config_circuits_reduced_n(O, name, n):
@@ -745,3 +791,28 @@ def test_sharded_virtual_shards_on_one_gpu():
 def test_sharded_rccl_plumbing_world1():
     out = _run_dist(1, ["--nccl"])
     assert out.count("ok n=") == 4
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 end to end (sharded state, plan/run_plan, remap, max-over-ranks timing, JSON line)
+    with two ranks sharing the one GPU through the gloo / host-staged test hook."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--n-local", "20", "--gates", "64"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, QIP_BENCH_DIST_BACKEND="gloo"))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
+    assert abs(line["norm_sqr_after"] - 1) < 1e-10
+    assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 1
