@@ -170,7 +170,7 @@ int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count)
  *                    <= K qubits (K <= 5 for f64, 4 for f32) and applies each in one sweep; results
  *                    then match the gate-by-gate path to rounding (1e-12 bar), not bit for bit.
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
- *   "unroll"         reserved
+ *   "unroll"         1 = one item per iteration in the matrix-core kernel (tuning aid)
  */
 int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);
 

@@ -917,9 +917,9 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   } while (0)
   // WU items per iteration so that WU * 2^k / 4 = 8 loads are in flight per lane (nitems is a power of two)
   switch (k) {
-    case 3: if (nitems >= 4) MF(3, 4); else MF(3, 1); break;
-    case 4: MF(4, 1); break;
-    case 5: MF(5, 1); break;
+    case 3: if (nitems >= 4 && s->unroll != 1) MF(3, 4); else MF(3, 1); break;
+    case 4: if (nitems >= 2 && s->unroll == 2) MF(4, 2); else MF(4, 1); break;
+    case 5: if (nitems >= 2 && s->unroll == 2) MF(5, 2); else MF(5, 1); break;
     default: return fail(QIP_ERR_UNSUPPORTED, "matrix-core kernel for k = %u", k);
   }
 #undef MF
@@ -942,7 +942,7 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
     // matrix cores: always for k = 5 (no register form), and for k = 3, 4 when two or more targets are
     // low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
     // register form does not (measured at n = 30: profiles/r01_ops_table*.md)
-    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2);
+    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2;  // 2 = force (tuning aid)
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
       return launch_kq_mfma(s, p, st);

@@ -529,6 +529,9 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
   constexpr int NA = S / 4;   // amplitudes per lane per item
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t j = lane & 15u, q = lane >> 4;
+  // A operand in registers for the whole wave lifetime.  (Measured alternative, k = 5 at n = 30: A in
+  // LDS with the row-block loop rolled up frees 128 VGPRs but leaves only WU accumulator chains in
+  // flight and ran 4.9 vs 5.3 TB/s: the f64 MFMA chain latency, not occupancy, is what has to be hidden.)
   double a[TT][KS];
 #pragma unroll
   for (int rb = 0; rb < TT; ++rb)
@@ -544,18 +547,15 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
       if ((m >> b) & 1) o |= 1ull << d.tau[b + 2];
     offm[m] = o;
   }
-  // WU items (16 groups each) per iteration keep WU*NA = 8 independent 16-B loads in flight per lane
-  const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / 64);
-  for (uint64_t w = ((uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * WU; w < nitems;
-       w += nwaves * WU) {
-    uint64_t base[WU];
-    A x[WU][NA];
+  auto load = [&](uint64_t w, A (&x)[WU][NA], uint64_t (&base)[WU]) {
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
       base[i] = insert_bits<-1>(((w + i) << 4) | j, ins) | offq;
 #pragma unroll
       for (int m = 0; m < NA; ++m) x[i][m] = ldg<NT>(st + (base[i] | offm[m]));
     }
+  };
+  auto compute_store = [&](const A (&x)[WU][NA], const uint64_t (&base)[WU]) {
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
 #pragma unroll
@@ -570,12 +570,20 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
         y0.y = acc[1];
         y1.x = acc[2];
         y1.y = acc[3];
-        // every load of this iteration was issued before its first store, and no other wave touches
-        // these amplitudes, so the update is in place
         stg<NT>(st + (base[i] | offm[2 * rb]), y0);
         stg<NT>(st + (base[i] | offm[2 * rb + 1]), y1);
       }
     }
+  };
+  // Grid-stride over the wave's items.  Measured alternatives at n = 30 (tools/bench_ops.py): prefetching
+  // the next item's loads ahead of the MFMA chains (software pipeline) ran 5.08 vs 5.27 TB/s at k = 5 and
+  // 4.07 vs 4.65 at k = 3 on bits 0-2, so the plain loop stays.
+  const uint64_t step = (uint64_t)gridDim.x * (kBlock / 64) * WU;
+  for (uint64_t w = ((uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * WU; w < nitems; w += step) {
+    A x[WU][NA];
+    uint64_t base[WU];
+    load(w, x, base);
+    compute_store(x, base);
   }
 }
 

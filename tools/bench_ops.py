@@ -25,6 +25,7 @@ def rand_unitary(k, rng):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     reps = 6
     rng = np.random.default_rng(0)
     hi, mid, lo = 0, n // 2, n - 1  # qubit indices: bit positions n-1, ~n/2, 0
@@ -53,6 +54,11 @@ def main():
         ("dense k=4 (MFMA f64)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {}),
         ("dense k=4 (VALU regs)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {"mfma": 0}),
         ("dense k=5 (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {}),
+        ("dense k=5 (MFMA f64, 2 items/iter)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"unroll": 2}),
+        ("dense k=4 high bits (MFMA f64, 1 item/iter)", q.make_matrix_op([hi, mid, 5, 7], rand_unitary(4, rng).ravel()), {"mfma": 2, "unroll": 1}),
+        ("dense k=5 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, 9], rand_unitary(5, rng).ravel()), {}),
+        ("dense k=4 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7], rand_unitary(4, rng).ravel()), {"mfma": 2}),
+        ("dense k=3 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 2}),
         ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
         ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
         ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
@@ -63,8 +69,10 @@ def main():
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
         for name, op, opts in cases:
-            for k in ("lowbit_shuffle", "mfma", "force_generic"):
-                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0}[k])
+            if only and only not in name:
+                continue
+            for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll"):
+                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0}[k])
             for k, v in opts.items():
                 st.set_option(k, v)
             comp = st.compile_ops([op] * reps)
