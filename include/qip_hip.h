@@ -161,6 +161,18 @@ int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op);
 /* Apply `count` ops in order (one FFI crossing per circuit instead of per gate). */
 int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count);
 
+/* A circuit recorded once and replayed as ONE hipGraph launch (launch-bound regime: for small states a
+ * kernel takes less time than its launch, ~3.7 us per gate eagerly on MI355X).  The graph is captured from
+ * the same kernel launches qip_hip_state_apply_ops issues, bound to the state's current buffer; `ops` must
+ * stay valid for the program's lifetime.  Programs containing ops that take the out-of-place path, or whose
+ * state buffer has changed since capture, transparently fall back to eager application. */
+typedef struct qip_hip_program qip_hip_program;
+int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint64_t count, qip_hip_program** out);
+int qip_hip_program_run(qip_hip_program* p);
+/* 1 if the last run replayed a hipGraph, 0 if it applied the ops eagerly */
+int qip_hip_program_is_graph(const qip_hip_program* p);
+int qip_hip_program_destroy(qip_hip_program* p);
+
 /* Options: key is one of
  *   "force_generic"  1 = route every op through the literal gather kernel
  *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)

@@ -60,6 +60,10 @@ SIGNATURES = {
     "qip_hip_state_sync": (_int, [_statep]),
     "qip_hip_state_apply_op": (_int, [_statep, _opp]),
     "qip_hip_state_apply_ops": (_int, [_statep, _opp, _u64]),
+    "qip_hip_program_create": (_int, [_statep, _opp, _u64, C.POINTER(C.c_void_p)]),
+    "qip_hip_program_run": (_int, [C.c_void_p]),
+    "qip_hip_program_is_graph": (_int, [C.c_void_p]),
+    "qip_hip_program_destroy": (_int, [C.c_void_p]),
     "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
     "qip_hip_kernel_class_count": (_int, []),
     "qip_hip_kernel_class_name": (_cp, [_int]),

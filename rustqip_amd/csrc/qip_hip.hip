@@ -15,6 +15,7 @@
 #include <functional>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -369,7 +370,10 @@ struct qip_hip_state {
   int64_t lowbit_shuffle = 1;
   int64_t mfma = 1;
   int64_t fuse = 0;
-  int64_t packed_f32 = 1;  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
+  int64_t packed_f32 = 1;
+  // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
+  std::deque<std::vector<char>>* capture_staging = nullptr;
+  size_t capture_arena_need = 0;  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
   std::vector<ProfRec> pending;
@@ -381,6 +385,10 @@ struct qip_hip_state {
 
 static int ensure_arena(qip_hip_state* s, size_t bytes) {
   if (bytes <= s->arena_cap) return QIP_OK;
+  if (s->capture_staging) {  // no malloc / sync inside a stream capture: ask the caller to grow and retry
+    s->capture_arena_need = std::max(s->capture_arena_need, bytes);
+    return fail(QIP_ERR_UNSUPPORTED, "arena too small during graph capture");
+  }
   if (s->arena) {
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipFree(s->arena));
@@ -669,17 +677,27 @@ template <typename T> static amp_t<T> mk(double re, double im) {
   return a;
 }
 
+// Stream-ordered copy of an op payload into the device arena.  Eagerly the (pageable) source is staged by
+// the runtime before the call returns; under graph capture the source must live as long as the graph, so
+// it is first copied into storage owned by the program.
+static int arena_upload(qip_hip_state* s, const void* src, size_t bytes, size_t arena_off) {
+  if (bytes == 0) return QIP_OK;
+  QCHK(ensure_arena(s, arena_off + bytes));
+  if (s->capture_staging) {
+    s->capture_staging->emplace_back((const char*)src, (const char*)src + bytes);
+    src = s->capture_staging->back().data();
+  }
+  HIPCHK(hipMemcpyAsync((char*)s->arena + arena_off, src, bytes, hipMemcpyHostToDevice, s->stream));
+  return QIP_OK;
+}
+
 // upload `count` complex values (host doubles re,im) to the device arena as amp_t<T>
 template <typename T>
 static int upload_table(qip_hip_state* s, const std::vector<double>& tab, size_t arena_off = 0) {
   const size_t count = tab.size() / 2;
-  QCHK(ensure_arena(s, arena_off + count * sizeof(amp_t<T>)));
   std::vector<amp_t<T>> tmp(count);
   for (size_t i = 0; i < count; ++i) tmp[i] = mk<T>(tab[2 * i], tab[2 * i + 1]);
-  // pageable source: the runtime stages it before returning, so `tmp` may die afterwards
-  HIPCHK(hipMemcpyAsync((char*)s->arena + arena_off, tmp.data(), count * sizeof(amp_t<T>),
-                        hipMemcpyHostToDevice, s->stream));
-  return QIP_OK;
+  return arena_upload(s, tmp.data(), count * sizeof(amp_t<T>), arena_off);
 }
 
 // Compile-time position counts 0..4 cover every 1- and 2-qubit gate with up to two extra
@@ -897,8 +915,7 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   std::sort(tau.begin(), tau.end());
   std::vector<double> afrag;
   build_afrag(p, tau, &afrag);
-  QCHK(ensure_arena(s, afrag.size() * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(s->arena, afrag.data(), afrag.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  QCHK(arena_upload(s, afrag.data(), afrag.size() * sizeof(double), 0));
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
   Ins ins = make_ins(pos, mask_of(p.cpos));
@@ -1007,8 +1024,7 @@ static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, 
   const amp_t<T>* vals = nullptr;
   if (f.inner->kind == QIP_OP_MATRIX) {
     const size_t bytes = (sizeof(amp_t<T>) << (2 * f.n_op));
-    QCHK(ensure_arena(s, bytes));
-    HIPCHK(hipMemcpyAsync(s->arena, f.inner->dense, bytes, hipMemcpyHostToDevice, s->stream));
+    QCHK(arena_upload(s, f.inner->dense, bytes, 0));
     dense = (const amp_t<T>*)s->arena;
   } else if (f.inner->kind == QIP_OP_SPARSE) {
     const uint64_t rows = 1ull << f.n_op;
@@ -1016,12 +1032,10 @@ static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, 
     const size_t b_rp = (rows + 1) * 8, b_cols = nnz * 8, b_vals = nnz * sizeof(amp_t<T>);
     const size_t o_cols = (b_rp + 15) & ~(size_t)15, o_vals = (o_cols + b_cols + 15) & ~(size_t)15;
     QCHK(ensure_arena(s, o_vals + b_vals + 16));
-    HIPCHK(hipMemcpyAsync(s->arena, f.inner->sparse_rowptr, b_rp, hipMemcpyHostToDevice, s->stream));
+    QCHK(arena_upload(s, f.inner->sparse_rowptr, b_rp, 0));
     if (nnz) {
-      HIPCHK(hipMemcpyAsync((char*)s->arena + o_cols, f.inner->sparse_cols, b_cols,
-                            hipMemcpyHostToDevice, s->stream));
-      HIPCHK(hipMemcpyAsync((char*)s->arena + o_vals, f.inner->sparse_vals, b_vals,
-                            hipMemcpyHostToDevice, s->stream));
+      QCHK(arena_upload(s, f.inner->sparse_cols, b_cols, o_cols));
+      QCHK(arena_upload(s, f.inner->sparse_vals, b_vals, o_vals));
     }
     rowptr = (const uint64_t*)s->arena;
     cols = (const uint64_t*)((char*)s->arena + o_cols);
@@ -1327,6 +1341,139 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
     }
   }
+  return QIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// programs: a circuit captured once into a hipGraph and replayed with one launch
+// ---------------------------------------------------------------------------------------
+struct qip_hip_program {
+  qip_hip_state* s = nullptr;
+  const qip_op* ops = nullptr;
+  uint64_t count = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  void* captured_cur = nullptr;
+  std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
+  int last_was_graph = 0;
+};
+
+static void program_drop_graph(qip_hip_program* p) {
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  p->exec = nullptr;
+  p->graph = nullptr;
+  p->staging.clear();
+}
+
+// Try to capture; on any obstacle leave the program in eager mode (exec == nullptr) and report success.
+static int program_capture(qip_hip_program* p) {
+  qip_hip_state* s = p->s;
+  program_drop_graph(p);
+  if (s->force_generic || g_force_generic || s->profile) return QIP_OK;
+  // an op on the out-of-place path would swap the buffers under the graph: stay eager
+  for (uint64_t i = 0; i < p->count; ++i) {
+    FlatOp f;
+    QCHK(flatten_op(s->n, &p->ops[i], false, &f));
+    Plan pl;
+    QCHK(make_plan(s->dtype, s->n, f, false, &pl));
+    const bool f64 = s->dtype == QIP_C64;
+    const uint32_t k = f.n_op;
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (f64 && s->mfma && k <= kMaxMfmaK && s->n >= f.k_all + 4));
+    if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
+  }
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    s->capture_arena_need = 0;
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      (void)hipGetLastError();
+      return QIP_OK;
+    }
+    s->capture_staging = &p->staging;
+    const int64_t fuse = s->fuse;
+    int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
+    (void)fuse;
+    s->capture_staging = nullptr;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (rc == QIP_OK && e == hipSuccess && g) {
+      if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+        p->graph = g;
+        p->captured_cur = s->cur;
+        return QIP_OK;
+      }
+      (void)hipGetLastError();
+      (void)hipGraphDestroy(g);
+      p->exec = nullptr;
+      p->staging.clear();
+      return QIP_OK;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    p->staging.clear();
+    if (s->capture_arena_need > s->arena_cap) {  // grow outside the capture, then retry
+      const size_t need = s->capture_arena_need;
+      s->capture_arena_need = 0;
+      QCHK(ensure_arena(s, need));
+      continue;
+    }
+    if (rc != QIP_OK && rc != QIP_ERR_UNSUPPORTED) return rc;  // a real descriptor error
+    return QIP_OK;
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint64_t count,
+                                      qip_hip_program** out) {
+  STATE_ENTER(s);
+  if (!out || (count && !ops)) return fail(QIP_ERR_INVALID, "null argument");
+  for (uint64_t i = 0; i < count; ++i) {
+    FlatOp f;
+    int rc = flatten_op(s->n, &ops[i], false, &f);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+  }
+  qip_hip_program* p = new qip_hip_program();
+  p->s = s;
+  p->ops = ops;
+  p->count = count;
+  int rc = program_capture(p);
+  if (rc != QIP_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_program_run(qip_hip_program* p) {
+  if (!p) return fail(QIP_ERR_INVALID, "null program");
+  qip_hip_state* s = p->s;
+  STATE_ENTER(s);
+  if (p->exec && (p->captured_cur != s->cur || s->profile || s->force_generic || g_force_generic)) {
+    if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
+    else QCHK(program_capture(p));  // the state moved to its other buffer: re-record against it
+  }
+  if (p->exec) {
+    HIPCHK(hipGraphLaunch(p->exec, s->stream));
+    p->last_was_graph = 1;
+    return QIP_OK;
+  }
+  p->last_was_graph = 0;
+  return qip_hip_state_apply_ops(s, p->ops, p->count);
+}
+
+extern "C" int qip_hip_program_is_graph(const qip_hip_program* p) { return p ? p->last_was_graph : 0; }
+
+extern "C" int qip_hip_program_destroy(qip_hip_program* p) {
+  if (!p) return QIP_OK;
+  if (p->s) {
+    (void)hipSetDevice(p->s->device);
+    if (p->s->stream || true) (void)hipStreamSynchronize(p->s->stream);
+  }
+  program_drop_graph(p);
+  delete p;
   return QIP_OK;
 }
 

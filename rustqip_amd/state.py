@@ -193,6 +193,11 @@ class HipState:
     def apply_ops(self, ops: Iterable[MatrixOp]) -> None:
         self.apply_compiled(self.compile_ops(list(ops)))
 
+    def compile_program(self, ops: Iterable[MatrixOp]) -> "HipProgram":
+        """Record a circuit once; HipProgram.run() replays it as ONE hipGraph launch (launch-bound small
+        states), falling back to eager application when a graph is not possible."""
+        return HipProgram(self, list(ops))
+
     # -- measurement (measurement_ops.rs) ------------------------------------------------
     def norm_sqr(self) -> float:
         out = C.c_double()
@@ -248,3 +253,32 @@ class HipState:
 
     def profile_reset(self) -> None:
         _check(_ffi.lib.qip_hip_state_profile_reset(self._h))
+
+
+class HipProgram:
+    """qip_hip_program: a circuit captured into a hipGraph bound to a HipState."""
+
+    def __init__(self, state: HipState, ops: List[MatrixOp]):
+        self.state = state
+        self._compiled = state.compile_ops(ops)  # keeps the descriptors alive for the program's lifetime
+        self._p = C.c_void_p()
+        arr, _ = self._compiled
+        _check(_ffi.lib.qip_hip_program_create(state._h, arr, len(arr), C.byref(self._p)))
+
+    def run(self) -> None:
+        _check(_ffi.lib.qip_hip_program_run(self._p))
+
+    @property
+    def is_graph(self) -> bool:
+        return bool(_ffi.lib.qip_hip_program_is_graph(self._p))
+
+    def close(self) -> None:
+        if self._p.value:
+            _ffi.lib.qip_hip_program_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

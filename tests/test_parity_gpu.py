@@ -566,6 +566,50 @@ def test_gate_fusion_matches_gate_by_gate(O, K):
             assert sweeps < len(ops) / 1.5, (name, K, sweeps, len(ops))  # fusion really merged gates
 
 
+def test_hipgraph_program_replay(O):
+    """A circuit captured into a hipGraph replays bit-identically to eager application (same kernels),
+    repeatedly; circuits with an out-of-place op fall back to eager transparently."""
+    rng = np.random.default_rng(2)
+    for n in (7, 12, 16):
+        perm = [int(v) for v in rng.permutation(n)]
+        circ = (circuits.h_layer(n) + circuits.c2_random_circuit(n, 100, seed=n) + circuits.c3_qft(n)[:50]
+                + circuits.c5_grover_iteration(n)
+                + [q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel()),
+                   q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()),
+                   q.make_matrix_op(perm[2:5], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()),
+                   q.make_swap_op(perm[:2], perm[2:4])])
+        if n >= 12:
+            circ.append(q.make_matrix_op(perm[:5], rand_unitary(5, rng).ravel()))
+        x = circuits.random_state(n, seed=n)
+        with q.HipState(n) as st:
+            st.upload(x)
+            st.apply_ops(circ)
+            once = st.download()
+            st.apply_ops(circ)
+            twice = st.download()
+        with q.HipState(n) as st:
+            st.upload(x)
+            prog = st.compile_program(circ)
+            prog.run()
+            assert prog.is_graph
+            assert np.array_equal(st.download(), once)
+            prog.run()
+            assert np.array_equal(st.download(), twice)
+            prog.close()
+        assert np.max(np.abs(once - O.apply_ops_in_place(n, circ, x.copy()))) <= TOL64
+        # a sparse op takes the out-of-place literal kernel: the program must stay correct (eager fallback)
+        sp = circ[:20] + [q.make_sparse_matrix_op(perm[:2], [[(1, 0.5j)], [(0, 2.0)], [(3, 1.0)], [(2, -1.0)]])] + circ[20:40]
+        with q.HipState(n) as st:
+            st.upload(x)
+            prog = st.compile_program(sp)
+            prog.run()
+            prog.run()
+            assert not prog.is_graph
+            got = st.download()
+        want = O.apply_ops_in_place(n, sp + sp, x.copy())
+        assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want))))
+
+
 def test_qft_matches_dft(O):
     """Size-independent property: the QFT circuit is the DFT matrix (bit-reversal included)."""
     n = 8

@@ -25,7 +25,10 @@ def rand_unitary(k, rng):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    only = sys.argv[2] if len(sys.argv) > 2 else None
+    only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+    f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
+    dtype = np.complex64 if f32 else np.complex128
+    amp = 8.0 if f32 else 16.0
     reps = 6
     rng = np.random.default_rng(0)
     hi, mid, lo = 0, n // 2, n - 1  # qubit indices: bit positions n-1, ~n/2, 0
@@ -64,15 +67,19 @@ def main():
         ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
         ("H via literal gather", q.make_matrix_op([mid], circuits.H), {"force_generic": 1}),
     ]
-    print(f"| op (n={n}, Complex<f64>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
-    with q.HipState(n) as st:
+    if f32:
+        cases = [c for c in cases if "MFMA" not in c[0] and "literal" not in c[0]]
+        cases += [("H, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.H), {"packed_f32": 0}),
+                  ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
+    print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
+    with q.HipState(n, dtype) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
         for name, op, opts in cases:
             if only and only not in name:
                 continue
-            for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll"):
-                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0}[k])
+            for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32"):
+                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1}[k])
             for k, v in opts.items():
                 st.set_option(k, v)
             comp = st.compile_ops([op] * reps)
@@ -88,12 +95,12 @@ def main():
             prof = st.profile()
             st.profile_reset()
             kern = "+".join(prof) or "-"
-            by = q.algorithmic_bytes(n, op)
+            by = q.algorithmic_bytes(n, op, 1 if f32 else 0)
             print(f"| {name} | `{kern}` | {dt*1e3:.3f} | {by/dt/1e9:.0f} | {100*by/dt/1e9/8000:.1f} |")
         st.set_option("profile", 0)
-        for name, fn, by in (("norm_sqr", st.norm_sqr, 16.0 * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), 16.0 * 2**n),
-                             ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), 16.0 * 2**n),
-                             ("measure_probs k=12 (scatter)", lambda: st.measure_probs(list(range(12))), 16.0 * 2**n)):
+        for name, fn, by in (("norm_sqr", st.norm_sqr, amp * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), amp * 2**n),
+                             ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), amp * 2**n),
+                             ("measure_probs k=12 (LDS histogram)", lambda: st.measure_probs(list(range(12))), amp * 2**n)):
             fn()
             t0 = time.perf_counter()
             for _ in range(3):
