@@ -570,7 +570,7 @@ def test_hipgraph_program_replay(O):
     """A circuit captured into a hipGraph replays bit-identically to eager application (same kernels),
     repeatedly; circuits with an out-of-place op fall back to eager transparently."""
     rng = np.random.default_rng(2)
-    for n in (7, 12, 16):
+    for n in (7, 12, 15):
         perm = [int(v) for v in rng.permutation(n)]
         circ = (circuits.h_layer(n) + circuits.c2_random_circuit(n, 100, seed=n) + circuits.c3_qft(n)[:50]
                 + circuits.c5_grover_iteration(n)
