@@ -212,7 +212,7 @@ extern "C" const char* qip_hip_kernel_class_name(int cls) {
 // ---------------------------------------------------------------------------------------
 // planning: which kernel applies an op
 // ---------------------------------------------------------------------------------------
-template <typename T> struct HostAmp { T re, im; };
+template <typename T> struct HostAmp { T re, im; };  // host view of one downloaded amplitude
 
 struct Plan {
   int cls = KC_GATHER_GENERIC;
@@ -508,12 +508,6 @@ static inline unsigned grid_for(uint64_t items, uint64_t per_block) {
 static inline unsigned grid_stride(uint64_t items) {
   // memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8
   return (unsigned)std::min<uint64_t>(std::max<uint64_t>((items + kBlock - 1) / kBlock, 1), 256 * 16);
-}
-
-template <typename T>
-static int fill_zero_async(qip_hip_state* s, void* buf) {
-  HIPCHK(hipMemsetAsync(buf, 0, s->namps * s->amp_bytes, s->stream));
-  return QIP_OK;
 }
 
 extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) {
@@ -1389,9 +1383,7 @@ static int program_capture(qip_hip_program* p) {
       return QIP_OK;
     }
     s->capture_staging = &p->staging;
-    const int64_t fuse = s->fuse;
     int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
-    (void)fuse;
     s->capture_staging = nullptr;
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s->stream, &g);
@@ -1470,7 +1462,7 @@ extern "C" int qip_hip_program_destroy(qip_hip_program* p) {
   if (!p) return QIP_OK;
   if (p->s) {
     (void)hipSetDevice(p->s->device);
-    if (p->s->stream || true) (void)hipStreamSynchronize(p->s->stream);
+    (void)hipStreamSynchronize(p->s->stream);
   }
   program_drop_graph(p);
   delete p;

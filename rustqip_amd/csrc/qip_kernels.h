@@ -841,11 +841,4 @@ __global__ __launch_bounds__(kBlock) void k_collapse(amp_t<T>* __restrict__ st, 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_fill_zero(amp_t<T>* __restrict__ st, uint64_t namps) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride)
-    st[i] = czero<amp_t<T>>();
-}
-
 }  // namespace qipk
