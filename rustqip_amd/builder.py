@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import cmath
 import math
+from fractions import Fraction
 from dataclasses import dataclass
 from typing import Iterable, List, Optional, Sequence, Tuple
 
@@ -91,7 +92,12 @@ def lower_to_matrix_op(entry: PipelineEntry) -> Optional[MatrixOp]:
         x = len(idx) // 2
         return make_swap_op(idx[:x], idx[x:])  # :471-478
     if k == "Rz":
-        h_theta = float(entry.param) * 0.5  # :486-495
+        theta = entry.param
+        if isinstance(theta, Fraction):
+            # RotationObject::PiRational(r) is lowered as r radians — WITHOUT pi — by the reference
+            # (builder.rs:480-486).  Mirrored as written, so results match LocalBuilder.
+            theta = float(theta)
+        h_theta = float(theta) * 0.5  # :486-495
         return make_matrix_op(idx, [cmath.rect(1.0, -h_theta), o, o, cmath.rect(1.0, h_theta)])
     if k == "GlobalPhase":
         return None  # :431-432
@@ -183,6 +189,21 @@ class HipBuilder:
     # RotationsBuilder / UnitaryBuilder
     def rz(self, r: Register, theta: float):
         return self._apply(r, "Rz", 1, float(theta))
+
+    def rz_ratio(self, r: Register, theta: Fraction):
+        """RotationsBuilder::rz_ratio: Rz with a PiRational angle (exported to QASM as k*pi/m)."""
+        return self._apply(r, "Rz", 1, Fraction(theta))
+
+    def rz_pi_by(self, r: Register, m: int):
+        """RotationsBuilder::rz_pi_by: Rz(pi/m) as PiRational(1/m) (see the Q1 note in lower_to_matrix_op)."""
+        if m == 0:
+            raise CircuitError("rz_pi_by: denominator must be non-zero")
+        return self.rz_ratio(r, Fraction(1, m))
+
+    def apply_global_phase(self, r: Register, theta: float):
+        """builder.rs:32-56: recorded, no effect on the state (builder.rs:431-432)."""
+        self.pipeline.append(PipelineEntry(list(r.indices), "GlobalPhase", float(theta)))
+        return r
 
     def apply_matrix(self, r: Register, data):  # UnitaryBuilder::apply_vec_matrix
         data = np.asarray(data, dtype=np.complex128).ravel()

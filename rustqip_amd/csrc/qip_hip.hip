@@ -242,7 +242,7 @@ static void read_dense(const void* dense, uint64_t count, std::vector<double>* o
 
 static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
 static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5
-static constexpr uint32_t kMaxDiagK = 20;   // diagonal tables shipped to the device
+static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
 
 static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p) {
   const double amp_bytes = dtype == QIP_C64 ? 16.0 : 8.0;
