@@ -373,7 +373,8 @@ struct qip_hip_state {
   int64_t packed_f32 = 1;
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
-  size_t capture_arena_need = 0;  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
+  size_t capture_arena_need = 0;
+  std::vector<struct qip_hip_program*> programs;  // graphs recorded against this state's buffers  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
   std::vector<ProfRec> pending;
@@ -478,10 +479,13 @@ extern "C" int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps,
   return QIP_OK;
 }
 
+static void programs_orphan(qip_hip_state* s);
+
 extern "C" int qip_hip_state_destroy(qip_hip_state* s) {
   if (!s) return QIP_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  programs_orphan(s);  // programs outliving their state become inert instead of dangling
   for (auto& r : s->pending) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
@@ -973,23 +977,28 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   Ins ins = make_ins(pos, mask_of(p.cpos));
   const uint64_t groups = 1ull << (s->n - (uint32_t)pos.size());
   const DiagDesc d = make_diagdesc(p);
-  const dim3 grid(grid_for(groups, kBlock)), block(kBlock);
   const amp_t<T>* mat = (const amp_t<T>*)s->arena;
+  const bool nt = use_nt(s) && min_target >= 6;
+  // groups per lane: 16 / 16 / 16 amplitudes in flight for k = 2 / 3 / 4 (option unroll = 1: one group)
+#define KQ(K, UU)                                                                                       \
+  do {                                                                                                  \
+    if (groups >= ((uint64_t)(UU) << kStrideShift) && s->unroll != 1) {                                 \
+      const dim3 grid(grid_for(groups, kBlock * (UU)));                                                 \
+      if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);  \
+      else hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
+    } else {                                                                                            \
+      const dim3 grid(grid_for(groups, kBlock));                                                        \
+      if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
+      else hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);      \
+    }                                                                                                   \
+  } while (0)
   switch (k) {
-    case 2:
-      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 2, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      else hipLaunchKernelGGL((k_gate_kq<T, 2, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      break;
-    case 3:
-      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 3, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      else hipLaunchKernelGGL((k_gate_kq<T, 3, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      break;
-    case 4:
-      if (use_nt(s) && min_target >= 6) hipLaunchKernelGGL((k_gate_kq<T, 4, true>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      else hipLaunchKernelGGL((k_gate_kq<T, 4, false>), grid, block, 0, s->stream, st, groups, ins, d, mat);
-      break;
+    case 2: KQ(2, 4); break;
+    case 3: KQ(3, 2); break;
+    case 4: KQ(4, 1); break;
     default: return fail(QIP_ERR_UNSUPPORTED, "register kernel for k = %u", k);
   }
+#undef KQ
   HIPCHK(hipGetLastError());
   return QIP_OK;
 }
@@ -1043,6 +1052,7 @@ static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, 
 
 template <typename T>
 static int apply_op_t(qip_hip_state* s, const qip_op* op) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   FlatOp f;
   QCHK(flatten_op(s->n, op, false, &f));
   Plan p;
@@ -1352,6 +1362,15 @@ struct qip_hip_program {
   int last_was_graph = 0;
 };
 
+static void program_drop_graph(qip_hip_program* p);
+static void programs_orphan(qip_hip_state* s) {
+  for (qip_hip_program* p : s->programs) {
+    program_drop_graph(p);
+    p->s = nullptr;
+  }
+  s->programs.clear();
+}
+
 static void program_drop_graph(qip_hip_program* p) {
   if (p->exec) (void)hipGraphExecDestroy(p->exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
@@ -1435,6 +1454,7 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
     delete p;
     return rc;
   }
+  s->programs.push_back(p);
   *out = p;
   return QIP_OK;
 }
@@ -1442,6 +1462,7 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
 extern "C" int qip_hip_program_run(qip_hip_program* p) {
   if (!p) return fail(QIP_ERR_INVALID, "null program");
   qip_hip_state* s = p->s;
+  if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
   STATE_ENTER(s);
   if (p->exec && (p->captured_cur != s->cur || s->profile || s->force_generic || g_force_generic)) {
     if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
@@ -1463,6 +1484,8 @@ extern "C" int qip_hip_program_destroy(qip_hip_program* p) {
   if (p->s) {
     (void)hipSetDevice(p->s->device);
     (void)hipStreamSynchronize(p->s->stream);
+    auto& v = p->s->programs;
+    v.erase(std::remove(v.begin(), v.end(), p), v.end());
   }
   program_drop_graph(p);
   delete p;

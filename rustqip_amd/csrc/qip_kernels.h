@@ -461,15 +461,13 @@ __global__ __launch_bounds__(kBlock) void k_diag(E* __restrict__ st, uint64_t co
 // controls.  off[c] is the amplitude-index offset of sub-index c.  The matrix is read
 // through wave-uniform (scalar) loads.  Zero entries are multiplied, not skipped: for
 // finite amplitudes 0*x adds +-0, which leaves every sum IEEE-equal to the reference's.
-template <typename T, int K, bool NT>
+template <typename T, int K, int U, bool GUARD, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, uint64_t ngroups,
                                                     Ins ins, DiagDesc d,
                                                     const amp_t<T>* __restrict__ mat) {
   using A = amp_t<T>;
   constexpr int S = 1 << K;
-  const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (w >= ngroups) return;
-  const uint64_t i0 = insert_bits<-1>(w, ins);
+  if (GUARD && work_index<0>(0) >= ngroups) return;
   uint64_t off[S];
 #pragma unroll
   for (int c = 0; c < S; ++c) {
@@ -479,15 +477,24 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq(amp_t<T>* __restrict__ st, u
       if ((c >> (K - 1 - j)) & 1) o |= 1ull << d.tpos[j];
     off[c] = o;
   }
-  A x[S];
+  // U groups per lane, 32 KiB apart in the work index, all U * 2^K loads issued before the first store
+  uint64_t i0[U];
+  A x[U][S];
 #pragma unroll
-  for (int c = 0; c < S; ++c) x[c] = ldg<NT>(st + (i0 | off[c]));
+  for (int u = 0; u < U; ++u) {
+    i0[u] = insert_bits<-1>(work_index<Log2<U>::v>(u), ins);
 #pragma unroll
-  for (int r = 0; r < S; ++r) {
-    A acc = czero<A>();
+    for (int c = 0; c < S; ++c) x[u][c] = ldg<NT>(st + (i0[u] | off[c]));
+  }
 #pragma unroll
-    for (int c = 0; c < S; ++c) acc = cadd(acc, cmul(mat[r * S + c], x[c]));
-    stg<NT>(st + (i0 | off[r]), acc);
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      A acc = czero<A>();
+#pragma unroll
+      for (int c = 0; c < S; ++c) acc = cadd(acc, cmul(mat[r * S + c], x[u][c]));
+      stg<NT>(st + (i0[u] | off[r]), acc);
+    }
   }
 }
 

@@ -610,6 +610,22 @@ def test_hipgraph_program_replay(O):
         assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want))))
 
 
+def test_program_outliving_its_state_is_inert():
+    st = q.HipState(6)
+    st.init_basis(0)
+    prog = st.compile_program(circuits.h_layer(6))
+    prog.run()
+    st.close()
+    with pytest.raises(q.CircuitError, match="destroyed"):
+        prog.run()
+    prog.close()  # must not touch the dead state
+    # and the next state works normally
+    with q.HipState(6) as st2:
+        st2.init_basis(0)
+        st2.apply_ops(circuits.h_layer(6))
+        assert abs(st2.norm_sqr() - 1) < 1e-12
+
+
 def test_qft_matches_dft(O):
     """Size-independent property: the QFT circuit is the DFT matrix (bit-reversal included)."""
     n = 8
