@@ -979,10 +979,12 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   const DiagDesc d = make_diagdesc(p);
   const amp_t<T>* mat = (const amp_t<T>*)s->arena;
   const bool nt = use_nt(s) && min_target >= 6;
-  // groups per lane: 16 / 16 / 16 amplitudes in flight for k = 2 / 3 / 4 (option unroll = 1: one group)
+  // One group (2^k amplitudes) per lane.  Several groups per lane with the 32-KiB spacing that pays off
+  // for the 1-qubit kernels were measured at n = 30 and do NOT help here (k = 2: 5.82 vs 5.85 TB/s, k = 3:
+  // 5.52 vs 5.61): option unroll = 2 still selects them for experiments.
 #define KQ(K, UU)                                                                                       \
   do {                                                                                                  \
-    if (groups >= ((uint64_t)(UU) << kStrideShift) && s->unroll != 1) {                                 \
+    if (groups >= ((uint64_t)(UU) << kStrideShift) && s->unroll == 2 && (UU) > 1) {                     \
       const dim3 grid(grid_for(groups, kBlock * (UU)));                                                 \
       if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);  \
       else hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
