@@ -257,6 +257,22 @@ def main():
                               "sweep_GBps": sweep_bytes / dt / 1e9,
                               "note": "per-sweep bytes (32*2^n per fused dense gate), never per-gate bytes over sweep time"}
         st.set_option("fuse", 0)
+        # LDS-resident multi-gate sweeps: tile = 1 (circuit order, bit-identical) and tile = 2 (commuting reorder)
+        for mode in (1, 2):
+            st.set_option("tile", mode)
+            ct = st.compile_ops(ops)
+            st.apply_compiled(ct)
+            st.sync()
+            st.profile_reset()
+            t = time.perf_counter()
+            st.apply_compiled(ct)
+            st.sync()
+            dt = time.perf_counter() - t
+            prof_t = st.profile()
+            sweeps = sum(v["launches"] for v in prof_t.values())
+            extras["tiled_mode%d" % mode] = {"gates": len(ops), "sweeps": sweeps, "gates_per_s": len(ops) / dt, "ms_per_step": 1e3 * dt,
+                                             "sweep_GBps": sum(v["algorithmic_bytes"] for v in prof_t.values()) / dt / 1e9}
+        st.set_option("tile", 0)
         st.set_option("profile", 0)
         # the other single-GPU configs of BASELINE.json on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),

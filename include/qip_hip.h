@@ -182,6 +182,11 @@ int qip_hip_program_destroy(qip_hip_program* p);
  *                    <= K qubits (K <= 5 for f64, 4 for f32) and applies each in one sweep; results
  *                    then match the gate-by-gate path to rounding (1e-12 bar), not bit for bit.
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
+ *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into consecutive segments of gates that live
+ *                    on index bits 0..5 plus five free higher bits and applies each segment in ONE sweep
+ *                    through an LDS-resident tile (bit-identical to the gate-by-gate path);
+ *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
+ *   "packed_f32"     1 (default): f32 states are swept as 16-B elements of two amplitudes where possible
  *   "unroll"         1 = one item per iteration in the matrix-core kernel (tuning aid)
  */
 int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);

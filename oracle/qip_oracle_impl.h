@@ -134,7 +134,7 @@ void FN(qip_oracle_apply_op)(uint32_t n, const qip_op* op, const CPLX* input, ui
                              int accumulate, int nthreads) {
   int64_t rows = (int64_t)out_len;
   /* tiny vectors: forking a team on a many-core host costs far more than the loop */
-  if (nthreads <= 0) nthreads = rows < 65536 ? 1 : omp_get_max_threads();
+  if (nthreads <= 0) nthreads = rows < (1 << 20) ? 1 : omp_get_max_threads();
 #pragma omp parallel for schedule(static) num_threads(nthreads)
   for (int64_t r = 0; r < rows; ++r) {
     CPLX y = FN(qip_oracle_apply_op_row)(n, op, input, in_len, (uint64_t)r, in_off, out_off);

@@ -195,13 +195,14 @@ enum KernelClass {
   KC_SWAP_BITS,
   KC_GATE_KQ,
   KC_GATE_KQ_MFMA,
+  KC_TILE_GATES,
   KC_GATHER_GENERIC,
   KC_NOOP,
   KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
-    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_gather_generic",
+    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_gates",     "k_gather_generic",
     "noop_identity"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
@@ -370,6 +371,7 @@ struct qip_hip_state {
   int64_t lowbit_shuffle = 1;
   int64_t mfma = 1;
   int64_t fuse = 0;
+  int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
@@ -587,6 +589,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "mfma")) s->mfma = value;
   else if (!strcmp(key, "fuse")) s->fuse = value;
   else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
+  else if (!strcmp(key, "tile")) s->tile = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
@@ -1332,9 +1335,189 @@ static int apply_ops_fused(qip_hip_state* s, const qip_op* ops, uint64_t count, 
   return QIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-resident multi-gate sweeps (option "tile"): the scheduler cuts the circuit into segments whose
+// gates all live on index bits 0..5 plus five freely chosen higher bits, and k_tile_gates applies a whole
+// segment with one read and one write of the vector.
+//   tile = 1  segments are consecutive runs of the circuit: same per-amplitude operation order as the
+//             gate-by-gate path, hence bit-identical results;
+//   tile = 2  a gate may also be hoisted over skipped gates it shares no qubit with (they commute), which
+//             packs segments better; equal to the reference up to rounding (1e-12 bar).
+// ---------------------------------------------------------------------------------------
+struct TileItem {
+  bool tileable = false;
+  int kind = 0;                 // TileGate kind
+  std::vector<uint32_t> pos;    // every involved bit position
+  uint32_t t0 = 0, t1 = 0;      // target position(s)
+  std::vector<uint32_t> cpos;
+  double m[8] = {0};
+  uint32_t nz = 0;
+};
+
+template <typename T>
+static int classify_tile_item(qip_hip_state* s, const qip_op* op, TileItem* it) {
+  FlatOp f;
+  QCHK(flatten_op(s->n, op, false, &f));
+  Plan p;
+  QCHK(make_plan(s->dtype, s->n, f, false, &p));
+  it->tileable = false;
+  it->pos.clear();
+  for (uint32_t c : p.cpos) it->pos.push_back(c);
+  for (uint32_t t : p.opos) it->pos.push_back(t);
+  it->cpos = p.cpos;
+  if (!f.distinct) return QIP_OK;
+  const uint32_t k = (uint32_t)p.opos.size();
+  if (p.cls == KC_GATE1Q_PAIR) {
+    it->kind = 0;
+    it->t0 = p.opos[0];
+    memcpy(it->m, p.m, sizeof it->m);
+    it->nz = p.nz;
+    it->tileable = true;
+  } else if (p.cls == KC_PHASE && k == 1) {
+    it->kind = 1;
+    it->t0 = p.opos[0];
+    const bool on_one = p.phase_ones & 1ull;
+    it->m[0] = on_one ? 1.0 : p.phase[0];
+    it->m[1] = on_one ? 0.0 : p.phase[1];
+    it->m[2] = on_one ? p.phase[0] : 1.0;
+    it->m[3] = on_one ? p.phase[1] : 0.0;
+    it->tileable = true;
+  } else if (p.cls == KC_DIAG && k == 1) {
+    it->kind = 1;
+    it->t0 = p.opos[0];
+    for (int e = 0; e < 4; ++e) it->m[e] = p.table[e];
+    it->tileable = true;
+  } else if (p.cls == KC_SWAP_BITS && k == 2) {
+    it->kind = 2;
+    it->t0 = std::min(p.opos[0], p.opos[1]);
+    it->t1 = std::max(p.opos[0], p.opos[1]);
+    it->tileable = true;
+  }
+  if (it->pos.size() > (size_t)kTileBits) it->tileable = false;
+  return QIP_OK;
+}
+
+template <typename T>
+static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
+                               std::vector<uint32_t> high) {
+  // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
+  for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < s->n; ++p)
+    if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+  std::sort(high.begin(), high.end());
+  auto tile_bit = [&](uint32_t pos) -> uint32_t {
+    if (pos < (uint32_t)kTileLow) return pos;
+    return kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin());
+  };
+  std::vector<TileGate<T>> gates(seg.size());
+  for (size_t i = 0; i < seg.size(); ++i) {
+    const TileItem& it = *seg[i];
+    TileGate<T>& g = gates[i];
+    memset(&g, 0, sizeof g);
+    g.kind = (uint32_t)it.kind;
+    g.b0 = tile_bit(it.t0);
+    g.b1 = it.kind == 2 ? tile_bit(it.t1) : 0;
+    if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);
+    for (uint32_t c : it.cpos) g.cmask |= 1u << tile_bit(c);
+    g.nz = it.nz;
+    if (it.kind == 0) {
+      for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
+    } else if (it.kind == 1) {
+      g.m[0] = mk<T>(it.m[0], it.m[1]);
+      g.m[1] = mk<T>(it.m[2], it.m[3]);
+    }
+  }
+  QCHK(arena_upload(s, gates.data(), gates.size() * sizeof(TileGate<T>), 0));
+  TileDesc d;
+  memset(&d, 0, sizeof d);
+  d.ngates = (uint32_t)gates.size();
+  for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
+  Ins ins = make_ins(high, 0);
+  const uint64_t ntiles = 1ull << (s->n - kTileBits);
+  const size_t lds = sizeof(amp_t<T>) << kTileBits;
+  const TileGate<T>* dg = (const TileGate<T>*)s->arena;
+  ProfRec rec;
+  rec.cls = KC_TILE_GATES;
+  if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+  if (use_nt(s))
+    hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                       (amp_t<T>*)s->cur, ins, d, dg);
+  else
+    hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                       (amp_t<T>*)s->cur, ins, d, dg);
+  HIPCHK(hipGetLastError());
+  if (s->profile) QCHK(prof_end(s, &rec));
+  return QIP_OK;
+}
+
+template <typename T>
+static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
+  std::vector<TileItem> items(count);
+  for (uint64_t i = 0; i < count; ++i) {
+    int rc = classify_tile_item<T>(s, &ops[i], &items[i]);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+  }
+  std::vector<char> done(count, 0);
+  uint64_t head = 0;
+  const uint64_t window = reorder ? 256 : 0;
+  while (head < count) {
+    if (done[head]) {
+      ++head;
+      continue;
+    }
+    if (!items[head].tileable) {
+      QCHK(apply_op_t<T>(s, &ops[head]));
+      done[head++] = 1;
+      continue;
+    }
+    // grow a segment from `head`
+    std::vector<const TileItem*> seg;
+    std::vector<uint32_t> high;
+    uint64_t blocked = 0;  // bit positions of gates skipped so far (later gates must not touch them)
+    bool any_skipped = false;
+    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && seg.size() < (size_t)kTileMaxGates; ++i) {
+      if (done[i]) continue;
+      const TileItem& it = items[i];
+      uint64_t mask = 0;
+      for (uint32_t p : it.pos) mask |= 1ull << p;
+      bool fits = it.tileable && !(mask & blocked);
+      std::vector<uint32_t> need;
+      if (fits) {
+        for (uint32_t p : it.pos)
+          if (p >= (uint32_t)kTileLow && std::find(high.begin(), high.end(), p) == high.end() &&
+              std::find(need.begin(), need.end(), p) == need.end())
+            need.push_back(p);
+        fits = high.size() + need.size() <= (size_t)kTileHigh;
+      }
+      if (fits) {
+        for (uint32_t p : need) high.push_back(p);
+        seg.push_back(&it);
+        done[i] = 1;
+      } else {
+        if (!reorder) break;  // strict: segments are consecutive runs of the circuit
+        blocked |= mask;
+        any_skipped = true;
+      }
+    }
+    if (seg.size() == 1) {
+      // a lone gate gains nothing from the tile: its own kernel touches only what can change
+      const uint64_t i = (uint64_t)(seg[0] - items.data());
+      QCHK(apply_op_t<T>(s, &ops[i]));
+    } else {
+      QCHK(launch_tile_segment<T>(s, seg, high));
+    }
+  }
+  return QIP_OK;
+}
+
 extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) {
   STATE_ENTER(s);
   if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
+  if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
+    return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
+                               : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
   if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
     const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, s->dtype == QIP_C64 ? kMaxMfmaK : kMaxRegK);
     if (s->n >= K + 4)

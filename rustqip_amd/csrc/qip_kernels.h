@@ -594,6 +594,110 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
   }
 }
 
+// ---- LDS-resident multi-gate sweep ------------------------------------------
+// One sweep applies a whole LIST of gates: a 256-lane block stages a tile of 2^11 amplitudes in LDS
+// (32 KiB for f64) — index bits 0..5 (one contiguous 1-KiB wave row) plus kTileHigh = 5 arbitrary
+// higher bit positions chosen by the host scheduler — applies every gate of the segment to the tile
+// (1-qubit dense / diagonal gates with any controls, bit swaps; all qubits inside the tile's 11 bits),
+// and writes the tile back.  HBM traffic is ONE read + ONE write of the vector for the whole segment.
+// Per gate the arithmetic is exactly that of k_gate1q_pair / k_phase / k_diag1q / k_swap_bits (same
+// formulas, same zero-skipping, no FMA), so a segment that keeps the circuit's gate order is bit-identical
+// to applying its gates one sweep at a time.
+// LDS cost per gate per tile is ~550 LDS cycles against ~6500 cycles of HBM time per tile per CU, so
+// about a dozen gates ride along for free; the scheduler caps a segment at kTileMaxGates.
+constexpr int kTileLow = 6;                        // contiguous low bits (one wave row)
+constexpr int kTileHigh = 5;                       // free bit positions per segment
+constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile
+constexpr int kTileMaxGates = 24;
+
+template <typename T> struct TileGate {
+  uint32_t kind;    // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap
+  uint32_t b0, b1;  // tile-index bit(s): target (kinds 0, 1) or the two swapped bits (kind 2, b0 < b1)
+  uint32_t cmask;   // tile-index bits that must all be 1 (controls)
+  uint32_t nz;      // kind 0: non-zero mask of the 2x2 entries
+  amp_t<T> m[4];    // kind 0: 2x2 row-major; kind 1: m[0] = d0, m[1] = d1
+};
+
+struct TileDesc {
+  uint32_t ngates;
+  uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
+};
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, Ins ins, TileDesc d,
+                                                       const TileGate<T>* __restrict__ gates) {
+  using A = amp_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  A* tile = reinterpret_cast<A*>(tile_raw);
+  constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
+  // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
+  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  uint64_t idx[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t t = u * kBlock + threadIdx.x;
+    const uint32_t h = t >> kTileLow;
+    uint64_t off = t & ((1u << kTileLow) - 1u);
+#pragma unroll
+    for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
+    idx[u] = base | off;
+  }
+  A x[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + idx[u]);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) tile[u * kBlock + threadIdx.x] = x[u];
+  __syncthreads();
+  for (uint32_t gi = 0; gi < d.ngates; ++gi) {
+    const TileGate<T> g = gates[gi];  // wave-uniform
+    if (g.kind == 0) {
+      const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
+#pragma unroll
+      for (int k = 0; k < PER / 2; ++k) {
+        const uint32_t p = k * kBlock + threadIdx.x;
+        const uint32_t t0 = ((p >> g.b0) << (g.b0 + 1)) | (p & low);
+        if ((t0 & g.cmask) != g.cmask) continue;
+        const A a0 = tile[t0], a1 = tile[t0 | bit];
+        A r0 = czero<A>(), r1 = czero<A>();
+        if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+        if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+        if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+        if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+        tile[t0] = r0;
+        tile[t0 | bit] = r1;
+      }
+    } else if (g.kind == 1) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t t = u * kBlock + threadIdx.x;
+        if ((t & g.cmask) != g.cmask) continue;
+        const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
+        if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
+        tile[t] = cmul(f, tile[t]);
+      }
+    } else {
+      const uint32_t lowa = (1u << g.b0) - 1u;
+#pragma unroll
+      for (int k = 0; k < PER / 4; ++k) {
+        uint32_t p = k * kBlock + threadIdx.x;         // index over the tile with bits b0 < b1 removed
+        p = ((p >> g.b0) << (g.b0 + 1)) | (p & lowa);  // open b0
+        const uint32_t hi_part = p >> g.b1;            // open b1 (p already has b0 opened, so b1 is final)
+        p = (hi_part << (g.b1 + 1)) | (p & ((1u << g.b1) - 1u));
+        if ((p & g.cmask) != g.cmask) continue;
+        const uint32_t ta = p | (1u << g.b0), tb = p | (1u << g.b1);
+        const A va = tile[ta], vb = tile[tb];
+        tile[ta] = vb;
+        tile[tb] = va;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) x[u] = tile[u * kBlock + threadIdx.x];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) stg<NT>(st + idx[u], x[u]);
+}
+
 // ---- literal fallback: one output row per lane, out of place ------------------------------
 // The gather formulation of the reference, variant by variant (matrix_ops.rs:62-94,
 // ops.rs:100-156, qubit_iterators.rs).  Correct for every descriptor the reference accepts,

@@ -566,6 +566,60 @@ def test_gate_fusion_matches_gate_by_gate(O, K):
             assert sweeps < len(ops) / 1.5, (name, K, sweeps, len(ops))  # fusion really merged gates
 
 
+@pytest.mark.parametrize("n", [11, 13, 16])
+def test_lds_tile_multi_gate_sweeps(O, n):
+    """option tile: whole segments of gates applied in one LDS-resident sweep.  tile = 1 keeps the circuit's
+    gate order and must be BIT-IDENTICAL to the gate-by-gate path; tile = 2 (commuting reorder) meets 1e-12."""
+    rng = np.random.default_rng(n)
+    mixed = []
+    for _ in range(120):
+        perm = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 9))
+        if kind == 0:
+            mixed.append(q.make_swap_op([perm[0]], [perm[1]]))
+        elif kind == 1:
+            mixed.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], GATES_1Q["dense"])))
+        elif kind == 2:
+            mixed.append(q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel()))  # not tileable
+        elif kind == 3:
+            mixed.append(q.make_control_op([perm[0]], q.make_swap_op([perm[1]], [perm[2]])))
+        elif kind == 4:
+            mixed.append(q.make_control_op(perm[:1], q.make_matrix_op([perm[1]], [1, 0, 0, cmath.rect(1, 0.7)])))
+        else:
+            mixed.append(q.make_matrix_op([perm[0]], GATES_1Q[["H", "T", "Rz", "X", "Y", "upper", "S"][int(rng.integers(0, 7))]]))
+    for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 200, seed=28)),
+                      ("qft", circuits.c3_qft(n)),
+                      ("c4", circuits.c4_clifford_t(n, 200, seed=32)),
+                      ("grover", circuits.h_layer(n) + circuits.c5_grover_iteration(n)),
+                      ("mixed", mixed)):
+        x = circuits.random_state(n, seed=n)
+        with q.HipState(n) as st:
+            st.upload(x)
+            st.apply_ops(ops)
+            eager = st.download()
+        sweeps = {}
+        for mode in (1, 2):
+            with q.HipState(n) as st:
+                st.set_option("tile", mode)
+                st.set_option("profile", 1)
+                st.upload(x)
+                st.apply_ops(ops)
+                got = st.download()
+                sweeps[mode] = sum(v["launches"] for v in st.profile().values())
+            if mode == 1:
+                assert np.array_equal(got, eager), (name, n)
+            else:
+                assert np.max(np.abs(got - eager)) <= TOL64 * max(1.0, float(np.max(np.abs(eager)))), (name, n)
+        if name in ("c2", "c4", "qft"):
+            assert sweeps[1] < len(ops) / 2 and sweeps[2] <= sweeps[1], (name, sweeps, len(ops))
+    want = O.apply_ops_in_place(n, mixed, x.copy())
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.upload(x)
+        st.apply_ops(mixed)
+        assert np.array_equal(st.download(), want)  # and bit-equal to the oracle itself
+
+
 def test_hipgraph_program_replay(O):
     """A circuit captured into a hipGraph replays bit-identically to eager application (same kernels),
     repeatedly; circuits with an out-of-place op fall back to eager transparently."""
