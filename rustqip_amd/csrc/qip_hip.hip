@@ -1403,7 +1403,17 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
   for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < s->n; ++p)
     if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
-  std::sort(high.begin(), high.end());
+  // tile bits 6, 7 are wave bits (exchange through LDS), 8..10 register bits (free): give the free positions
+  // that are exchange targets least often to the wave bits
+  std::vector<uint32_t> uses(64, 0);
+  for (const TileItem* it : seg) {
+    if (it->kind == 0) uses[it->t0] += 1;
+    if (it->kind == 2) {
+      uses[it->t0] += 1;
+      uses[it->t1] += 1;
+    }
+  }
+  std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
   auto tile_bit = [&](uint32_t pos) -> uint32_t {
     if (pos < (uint32_t)kTileLow) return pos;
     return kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin());
@@ -1431,7 +1441,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   memset(&d, 0, sizeof d);
   d.ngates = (uint32_t)gates.size();
   for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
-  Ins ins = make_ins(high, 0);
+  Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
   const uint64_t ntiles = 1ull << (s->n - kTileBits);
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const TileGate<T>* dg = (const TileGate<T>*)s->arena;

@@ -623,6 +623,51 @@ struct TileDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
 };
 
+// The tile lives in REGISTERS: lane `tid` of the block owns elements t = u*256 + tid, u = 0..7, so
+//   tile bits 0..5  = lane index      -> partner by cross-lane exchange (ds_bpermute, no LDS memory, no barrier)
+//   tile bits 6..7  = wave index      -> partner through LDS (write, barrier, read, barrier)
+//   tile bits 8..10 = register index  -> partner is another register of the same lane (nothing to exchange)
+// Diagonal gates never exchange anything.  The host assigns a segment's most used free bits to the
+// register bits and the least used to the wave bits.  (First version: every gate through LDS memory —
+// 22 sweeps of 9.3 ms for the 256-gate circuit at n = 30; LDS-bound.)
+template <typename T>
+__device__ __forceinline__ amp_t<T> tile_row(const TileGate<T>& g, bool hi, amp_t<T> own, amp_t<T> other) {
+  // the 2x2 row this element evaluates, folded from 0 in column order exactly like k_gate1q_pair
+  using A = amp_t<T>;
+  const A lo = hi ? other : own, hv = hi ? own : other;
+  A r = czero<A>();
+  if (hi) {
+    if (g.nz & 4u) r = cadd(r, cmul(g.m[2], lo));
+    if (g.nz & 8u) r = cadd(r, cmul(g.m[3], hv));
+  } else {
+    if (g.nz & 1u) r = cadd(r, cmul(g.m[0], lo));
+    if (g.nz & 2u) r = cadd(r, cmul(g.m[1], hv));
+  }
+  return r;
+}
+
+template <typename T, int RB>
+__device__ __forceinline__ void tile_register_gate(const TileGate<T>& g, amp_t<T> (&x)[8], uint32_t tid) {
+  using A = amp_t<T>;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if ((u >> RB) & 1) continue;
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int v = u | (1 << RB);
+    const uint32_t t0 = u * kBlock + tid;
+    if ((t0 & g.cmask) != g.cmask) continue;
+    const A a0 = x[u], a1 = x[v];
+    A r0 = czero<A>(), r1 = czero<A>();
+    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+    x[u] = r0;
+    x[v] = r1;
+  }
+}
+
 template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, Ins ins, TileDesc d,
                                                        const TileGate<T>* __restrict__ gates) {
@@ -630,12 +675,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
+  static_assert(PER == 8, "tile layout assumes 8 elements per lane");
+  const uint32_t tid = threadIdx.x;
   // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
   const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
   uint64_t idx[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const uint32_t t = u * kBlock + threadIdx.x;
+    const uint32_t t = u * kBlock + tid;
     const uint32_t h = t >> kTileLow;
     uint64_t off = t & ((1u << kTileLow) - 1u);
 #pragma unroll
@@ -645,55 +692,54 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   A x[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + idx[u]);
-#pragma unroll
-  for (int u = 0; u < PER; ++u) tile[u * kBlock + threadIdx.x] = x[u];
-  __syncthreads();
   for (uint32_t gi = 0; gi < d.ngates; ++gi) {
     const TileGate<T> g = gates[gi];  // wave-uniform
-    if (g.kind == 0) {
-      const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
-#pragma unroll
-      for (int k = 0; k < PER / 2; ++k) {
-        const uint32_t p = k * kBlock + threadIdx.x;
-        const uint32_t t0 = ((p >> g.b0) << (g.b0 + 1)) | (p & low);
-        if ((t0 & g.cmask) != g.cmask) continue;
-        const A a0 = tile[t0], a1 = tile[t0 | bit];
-        A r0 = czero<A>(), r1 = czero<A>();
-        if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
-        if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
-        if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
-        if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
-        tile[t0] = r0;
-        tile[t0 | bit] = r1;
-      }
-    } else if (g.kind == 1) {
+    if (g.kind == 1) {  // diagonal: element-wise, nothing to exchange
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const uint32_t t = u * kBlock + threadIdx.x;
-        if ((t & g.cmask) != g.cmask) continue;
+        const uint32_t t = u * kBlock + tid;
         const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
-        if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
-        tile[t] = cmul(f, tile[t]);
+        const bool unit = f.x == (T)1 && f.y == (T)0;  // unit entries leave the amplitude untouched
+        if ((t & g.cmask) == g.cmask && !unit) x[u] = cmul(f, x[u]);
       }
-    } else {
-      const uint32_t lowa = (1u << g.b0) - 1u;
+    } else if (g.kind == 0 && g.b0 >= 8) {  // partner in another register of this lane
+      if (g.b0 == 8) tile_register_gate<T, 0>(g, x, tid);
+      else if (g.b0 == 9) tile_register_gate<T, 1>(g, x, tid);
+      else tile_register_gate<T, 2>(g, x, tid);
+    } else if (g.kind == 0 && g.b0 < 6) {  // partner in another lane of this wave
+      const bool hi = (tid >> g.b0) & 1u;
 #pragma unroll
-      for (int k = 0; k < PER / 4; ++k) {
-        uint32_t p = k * kBlock + threadIdx.x;         // index over the tile with bits b0 < b1 removed
-        p = ((p >> g.b0) << (g.b0 + 1)) | (p & lowa);  // open b0
-        const uint32_t hi_part = p >> g.b1;            // open b1 (p already has b0 opened, so b1 is final)
-        p = (hi_part << (g.b1 + 1)) | (p & ((1u << g.b1) - 1u));
-        if ((p & g.cmask) != g.cmask) continue;
-        const uint32_t ta = p | (1u << g.b0), tb = p | (1u << g.b1);
-        const A va = tile[ta], vb = tile[tb];
-        tile[ta] = vb;
-        tile[tb] = va;
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t t = u * kBlock + tid;
+        const A other = shfl_xor_e<A>(x[u], 1 << g.b0);
+        const A r = tile_row<T>(g, hi, x[u], other);
+        if ((t & g.cmask) == g.cmask) x[u] = r;
       }
+    } else {  // partner in another wave (dense gate on tile bit 6 or 7) or a bit swap: through LDS
+#pragma unroll
+      for (int u = 0; u < PER; ++u) tile[u * kBlock + tid] = x[u];
+      __syncthreads();
+      if (g.kind == 0) {
+        const uint32_t bit = 1u << g.b0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const uint32_t t = u * kBlock + tid;
+          const A other = tile[t ^ bit];
+          const A r = tile_row<T>(g, (t & bit) != 0, x[u], other);
+          if ((t & g.cmask) == g.cmask) x[u] = r;
+        }
+      } else {  // swap of tile bits b0 < b1: element t takes the value of the element with the two bits exchanged
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const uint32_t t = u * kBlock + tid;
+          const uint32_t ba = (t >> g.b0) & 1u, bb = (t >> g.b1) & 1u;
+          const uint32_t src = (t & ~((1u << g.b0) | (1u << g.b1))) | (bb << g.b0) | (ba << g.b1);
+          if ((t & g.cmask) == g.cmask) x[u] = tile[src];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-#pragma unroll
-  for (int u = 0; u < PER; ++u) x[u] = tile[u * kBlock + threadIdx.x];
 #pragma unroll
   for (int u = 0; u < PER; ++u) stg<NT>(st + idx[u], x[u]);
 }
