@@ -623,13 +623,13 @@ struct TileDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
 };
 
-// The tile lives in REGISTERS: lane `tid` of the block owns elements t = u*256 + tid, u = 0..7, so
-//   tile bits 0..5  = lane index      -> partner by cross-lane exchange (ds_bpermute, no LDS memory, no barrier)
-//   tile bits 6..7  = wave index      -> partner through LDS (write, barrier, read, barrier)
-//   tile bits 8..10 = register index  -> partner is another register of the same lane (nothing to exchange)
-// Diagonal gates never exchange anything.  The host assigns a segment's most used free bits to the
-// register bits and the least used to the wave bits.  (First version: every gate through LDS memory —
-// 22 sweeps of 9.3 ms for the 256-gate circuit at n = 30; LDS-bound.)
+// The tile lives in REGISTERS: lane `tid` of the block owns elements t = u*256 + tid, u = 0..7.
+//   diagonal gates          -> element-wise, no exchange at all
+//   dense gate, tile bit<6  -> partner by cross-lane exchange (ds_bpermute: no LDS memory, no barrier)
+//   dense gate, tile bit>=6 -> partner through LDS (write, barrier, read, barrier); bit swaps likewise
+// (First version: tile resident in LDS memory, every gate a read-modify-write of LDS — 22 sweeps of 9.3 ms
+// for the 256-gate circuit at n = 30, LDS-bound.  A variant with a third, register-to-register class for
+// tile bits 8..10 compiled to 344 VGPRs and ran 3.6x slower.)
 template <typename T>
 __device__ __forceinline__ amp_t<T> tile_row(const TileGate<T>& g, bool hi, amp_t<T> own, amp_t<T> other) {
   // the 2x2 row this element evaluates, folded from 0 in column order exactly like k_gate1q_pair
@@ -644,28 +644,6 @@ __device__ __forceinline__ amp_t<T> tile_row(const TileGate<T>& g, bool hi, amp_
     if (g.nz & 2u) r = cadd(r, cmul(g.m[1], hv));
   }
   return r;
-}
-
-template <typename T, int RB>
-__device__ __forceinline__ void tile_register_gate(const TileGate<T>& g, amp_t<T> (&x)[8], uint32_t tid) {
-  using A = amp_t<T>;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    if ((u >> RB) & 1) continue;
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int v = u | (1 << RB);
-    const uint32_t t0 = u * kBlock + tid;
-    if ((t0 & g.cmask) != g.cmask) continue;
-    const A a0 = x[u], a1 = x[v];
-    A r0 = czero<A>(), r1 = czero<A>();
-    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
-    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
-    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
-    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
-    x[u] = r0;
-    x[v] = r1;
-  }
 }
 
 template <typename T, bool NT>
@@ -702,42 +680,34 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
         const bool unit = f.x == (T)1 && f.y == (T)0;  // unit entries leave the amplitude untouched
         if ((t & g.cmask) == g.cmask && !unit) x[u] = cmul(f, x[u]);
       }
-    } else if (g.kind == 0 && g.b0 >= 8) {  // partner in another register of this lane
-      if (g.b0 == 8) tile_register_gate<T, 0>(g, x, tid);
-      else if (g.b0 == 9) tile_register_gate<T, 1>(g, x, tid);
-      else tile_register_gate<T, 2>(g, x, tid);
-    } else if (g.kind == 0 && g.b0 < 6) {  // partner in another lane of this wave
-      const bool hi = (tid >> g.b0) & 1u;
+      continue;
+    }
+    // dense 1-qubit gate or bit swap: every element needs ONE other element of the tile
+    A other[PER];
+    if (g.kind == 0 && g.b0 < 6) {  // partner in another lane of this wave
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const uint32_t t = u * kBlock + tid;
-        const A other = shfl_xor_e<A>(x[u], 1 << g.b0);
-        const A r = tile_row<T>(g, hi, x[u], other);
-        if ((t & g.cmask) == g.cmask) x[u] = r;
-      }
-    } else {  // partner in another wave (dense gate on tile bit 6 or 7) or a bit swap: through LDS
+      for (int u = 0; u < PER; ++u) other[u] = shfl_xor_e<A>(x[u], 1 << g.b0);
+    } else {  // partner elsewhere in the block: through LDS
 #pragma unroll
       for (int u = 0; u < PER; ++u) tile[u * kBlock + tid] = x[u];
       __syncthreads();
-      if (g.kind == 0) {
-        const uint32_t bit = 1u << g.b0;
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-          const uint32_t t = u * kBlock + tid;
-          const A other = tile[t ^ bit];
-          const A r = tile_row<T>(g, (t & bit) != 0, x[u], other);
-          if ((t & g.cmask) == g.cmask) x[u] = r;
-        }
-      } else {  // swap of tile bits b0 < b1: element t takes the value of the element with the two bits exchanged
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-          const uint32_t t = u * kBlock + tid;
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t t = u * kBlock + tid;
+        uint32_t src = t ^ (1u << g.b0);
+        if (g.kind == 2) {  // swap of tile bits b0 < b1: take the element with the two bits exchanged
           const uint32_t ba = (t >> g.b0) & 1u, bb = (t >> g.b1) & 1u;
-          const uint32_t src = (t & ~((1u << g.b0) | (1u << g.b1))) | (bb << g.b0) | (ba << g.b1);
-          if ((t & g.cmask) == g.cmask) x[u] = tile[src];
+          src = (t & ~((1u << g.b0) | (1u << g.b1))) | (bb << g.b0) | (ba << g.b1);
         }
+        other[u] = tile[src];
       }
       __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const uint32_t t = u * kBlock + tid;
+      const A r = g.kind == 2 ? other[u] : tile_row<T>(g, ((t >> g.b0) & 1u) != 0, x[u], other[u]);
+      if ((t & g.cmask) == g.cmask) x[u] = r;
     }
   }
 #pragma unroll
