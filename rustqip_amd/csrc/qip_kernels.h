@@ -623,95 +623,104 @@ struct TileDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
 };
 
-// The tile lives in REGISTERS: lane `tid` of the block owns elements t = u*256 + tid, u = 0..7.
-//   diagonal gates          -> element-wise, no exchange at all
-//   dense gate, tile bit<6  -> partner by cross-lane exchange (ds_bpermute: no LDS memory, no barrier)
-//   dense gate, tile bit>=6 -> partner through LDS (write, barrier, read, barrier); bit swaps likewise
-// (First version: tile resident in LDS memory, every gate a read-modify-write of LDS — 22 sweeps of 9.3 ms
-// for the 256-gate circuit at n = 30, LDS-bound.  A variant with a third, register-to-register class for
-// tile bits 8..10 compiled to 344 VGPRs and ran 3.6x slower.)
-template <typename T>
-__device__ __forceinline__ amp_t<T> tile_row(const TileGate<T>& g, bool hi, amp_t<T> own, amp_t<T> other) {
-  // the 2x2 row this element evaluates, folded from 0 in column order exactly like k_gate1q_pair
-  using A = amp_t<T>;
-  const A lo = hi ? other : own, hv = hi ? own : other;
-  A r = czero<A>();
-  if (hi) {
-    if (g.nz & 4u) r = cadd(r, cmul(g.m[2], lo));
-    if (g.nz & 8u) r = cadd(r, cmul(g.m[3], hv));
-  } else {
-    if (g.nz & 1u) r = cadd(r, cmul(g.m[0], lo));
-    if (g.nz & 2u) r = cadd(r, cmul(g.m[1], hv));
-  }
-  return r;
-}
-
+// The tile is resident in LDS memory and every gate is a read-modify-write of LDS by the whole block.
+// Measured alternatives for the 256-gate circuit at n = 30 (22 segments): this form 9.3 ms per sweep
+// (1256 gates/s); tile in registers with lane-shuffle / LDS exchange classes 14 ms (each element then evaluates
+// its own row: twice the f64 multiplies, which run at quarter rate) ; with a third register-to-register
+// class 344 VGPRs and 3.6x slower.
 template <typename T, bool NT>
-__global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, Ins ins, TileDesc d,
-                                                       const TileGate<T>* __restrict__ gates) {
+__global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, uint64_t ntiles, Ins ins,
+                                                       TileDesc d, const TileGate<T>* __restrict__ gates) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
-  static_assert(PER == 8, "tile layout assumes 8 elements per lane");
-  const uint32_t tid = threadIdx.x;
-  // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
-  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
-  uint64_t idx[PER];
+  // per-lane offsets of its 8 tile elements (independent of the tile)
+  uint64_t off[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const uint32_t t = u * kBlock + tid;
+    const uint32_t t = u * kBlock + threadIdx.x;
     const uint32_t h = t >> kTileLow;
-    uint64_t off = t & ((1u << kTileLow) - 1u);
+    uint64_t o = t & ((1u << kTileLow) - 1u);
 #pragma unroll
-    for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
-    idx[u] = base | off;
+    for (int j = 0; j < kTileHigh; ++j) o |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
+    off[u] = o;
   }
+  // Persistent blocks, software-pipelined over their tiles: the NEXT tile's 8 loads per lane are in flight
+  // while the current tile's gates run in LDS, so HBM latency hides behind the LDS phase inside one block
+  // (tiles are disjoint sets of amplitudes, so prefetching ahead of the stores is safe in place).
+  // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero.
+  uint64_t tile_id = blockIdx.x;
   A x[PER];
+  uint64_t base = 0;
+  if (tile_id < ntiles) {
+    base = insert_bits<-1>(tile_id << kTileLow, ins);
 #pragma unroll
-  for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + idx[u]);
-  for (uint32_t gi = 0; gi < d.ngates; ++gi) {
-    const TileGate<T> g = gates[gi];  // wave-uniform
-    if (g.kind == 1) {  // diagonal: element-wise, nothing to exchange
+    for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + (base | off[u]));
+  }
+  while (tile_id < ntiles) {
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const uint32_t t = u * kBlock + tid;
-        const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
-        const bool unit = f.x == (T)1 && f.y == (T)0;  // unit entries leave the amplitude untouched
-        if ((t & g.cmask) == g.cmask && !unit) x[u] = cmul(f, x[u]);
-      }
-      continue;
+    for (int u = 0; u < PER; ++u) tile[u * kBlock + threadIdx.x] = x[u];
+    __syncthreads();
+    const uint64_t cur_base = base;
+    const uint64_t next_id = tile_id + gridDim.x;
+    if (next_id < ntiles) {
+      base = insert_bits<-1>(next_id << kTileLow, ins);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + (base | off[u]));
     }
-    // dense 1-qubit gate or bit swap: every element needs ONE other element of the tile
-    A other[PER];
-    if (g.kind == 0 && g.b0 < 6) {  // partner in another lane of this wave
+    for (uint32_t gi = 0; gi < d.ngates; ++gi) {
+      const TileGate<T> g = gates[gi];  // wave-uniform
+      if (g.kind == 0) {
+        const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
 #pragma unroll
-      for (int u = 0; u < PER; ++u) other[u] = shfl_xor_e<A>(x[u], 1 << g.b0);
-    } else {  // partner elsewhere in the block: through LDS
-#pragma unroll
-      for (int u = 0; u < PER; ++u) tile[u * kBlock + tid] = x[u];
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const uint32_t t = u * kBlock + tid;
-        uint32_t src = t ^ (1u << g.b0);
-        if (g.kind == 2) {  // swap of tile bits b0 < b1: take the element with the two bits exchanged
-          const uint32_t ba = (t >> g.b0) & 1u, bb = (t >> g.b1) & 1u;
-          src = (t & ~((1u << g.b0) | (1u << g.b1))) | (bb << g.b0) | (ba << g.b1);
+        for (int k = 0; k < PER / 2; ++k) {
+          const uint32_t p = k * kBlock + threadIdx.x;
+          const uint32_t t0 = ((p >> g.b0) << (g.b0 + 1)) | (p & low);
+          if ((t0 & g.cmask) != g.cmask) continue;
+          const A a0 = tile[t0], a1 = tile[t0 | bit];
+          A r0 = czero<A>(), r1 = czero<A>();
+          if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+          if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+          if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+          if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+          tile[t0] = r0;
+          tile[t0 | bit] = r1;
         }
-        other[u] = tile[src];
+      } else if (g.kind == 1) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const uint32_t t = u * kBlock + threadIdx.x;
+          if ((t & g.cmask) != g.cmask) continue;
+          const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
+          if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
+          tile[t] = cmul(f, tile[t]);
+        }
+      } else {
+        const uint32_t lowa = (1u << g.b0) - 1u;
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) {
+          uint32_t p = k * kBlock + threadIdx.x;         // index over the tile with bits b0 < b1 removed
+          p = ((p >> g.b0) << (g.b0 + 1)) | (p & lowa);  // open b0
+          const uint32_t hi_part = p >> g.b1;            // open b1 (p already has b0 opened, so b1 is final)
+          p = (hi_part << (g.b1 + 1)) | (p & ((1u << g.b1) - 1u));
+          if ((p & g.cmask) != g.cmask) continue;
+          const uint32_t ta = p | (1u << g.b0), tb = p | (1u << g.b1);
+          const A va = tile[ta], vb = tile[tb];
+          tile[ta] = vb;
+          tile[tb] = va;
+        }
       }
       __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const uint32_t t = u * kBlock + tid;
-      const A r = g.kind == 2 ? other[u] : tile_row<T>(g, ((t >> g.b0) & 1u) != 0, x[u], other[u]);
-      if ((t & g.cmask) == g.cmask) x[u] = r;
+      const A y = tile[u * kBlock + threadIdx.x];
+      stg<NT>(st + (cur_base | off[u]), y);
     }
+    __syncthreads();  // the tile buffer is rewritten by the next iteration
+    tile_id = next_id;
   }
-#pragma unroll
-  for (int u = 0; u < PER; ++u) stg<NT>(st + idx[u], x[u]);
 }
 
 // ---- literal fallback: one output row per lane, out of place ------------------------------
