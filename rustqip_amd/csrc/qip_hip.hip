@@ -1448,14 +1448,12 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   ProfRec rec;
   rec.cls = KC_TILE_GATES;
   if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
-  // persistent blocks: 4 per CU (LDS would admit 5 at f64) loop over the tiles
-  const unsigned blocks = (unsigned)std::min<uint64_t>(ntiles, 256ull * 4);
   if (use_nt(s))
-    hipLaunchKernelGGL((k_tile_gates<T, true>), dim3(blocks), dim3(kBlock), lds, s->stream,
-                       (amp_t<T>*)s->cur, ntiles, ins, d, dg);
+    hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                       (amp_t<T>*)s->cur, ins, d, dg);
   else
-    hipLaunchKernelGGL((k_tile_gates<T, false>), dim3(blocks), dim3(kBlock), lds, s->stream,
-                       (amp_t<T>*)s->cur, ntiles, ins, d, dg);
+    hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                       (amp_t<T>*)s->cur, ins, d, dg);
   HIPCHK(hipGetLastError());
   if (s->profile) QCHK(prof_end(s, &rec));
   return QIP_OK;

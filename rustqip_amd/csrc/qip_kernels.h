@@ -623,104 +623,86 @@ struct TileDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
 };
 
-// The tile is resident in LDS memory and every gate is a read-modify-write of LDS by the whole block.
-// Measured alternatives for the 256-gate circuit at n = 30 (22 segments): this form 9.3 ms per sweep
-// (1256 gates/s); tile in registers with lane-shuffle / LDS exchange classes 14 ms (each element then evaluates
-// its own row: twice the f64 multiplies, which run at quarter rate) ; with a third register-to-register
-// class 344 VGPRs and 3.6x slower.
+// The tile is resident in LDS memory and every gate is a read-modify-write of LDS by the whole block; one
+// block per tile, and the hardware overlaps the blocks' load / LDS / store phases.  Measured alternatives for
+// the 256-gate circuit at n = 30 (22 segments, ~11.6 gates per sweep): this form 9.3 ms per sweep = 1256
+// gates/s; persistent blocks software-pipelined over tiles (next tile's loads in flight during the LDS phase)
+// 11.1 ms; tile held in registers with lane-shuffle / LDS exchange classes 14 ms (each element then evaluates
+// its own matrix row: twice the quarter-rate f64 multiplies); a third register-to-register class: 344 VGPRs,
+// 3.6x slower.
 template <typename T, bool NT>
-__global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, uint64_t ntiles, Ins ins,
-                                                       TileDesc d, const TileGate<T>* __restrict__ gates) {
+__global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, Ins ins, TileDesc d,
+                                                       const TileGate<T>* __restrict__ gates) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
-  // per-lane offsets of its 8 tile elements (independent of the tile)
-  uint64_t off[PER];
+  // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
+  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  uint64_t idx[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const uint32_t t = u * kBlock + threadIdx.x;
     const uint32_t h = t >> kTileLow;
-    uint64_t o = t & ((1u << kTileLow) - 1u);
+    uint64_t off = t & ((1u << kTileLow) - 1u);
 #pragma unroll
-    for (int j = 0; j < kTileHigh; ++j) o |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
-    off[u] = o;
+    for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
+    idx[u] = base | off;
   }
-  // Persistent blocks, software-pipelined over their tiles: the NEXT tile's 8 loads per lane are in flight
-  // while the current tile's gates run in LDS, so HBM latency hides behind the LDS phase inside one block
-  // (tiles are disjoint sets of amplitudes, so prefetching ahead of the stores is safe in place).
-  // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero.
-  uint64_t tile_id = blockIdx.x;
   A x[PER];
-  uint64_t base = 0;
-  if (tile_id < ntiles) {
-    base = insert_bits<-1>(tile_id << kTileLow, ins);
 #pragma unroll
-    for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + (base | off[u]));
-  }
-  while (tile_id < ntiles) {
+  for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + idx[u]);
 #pragma unroll
-    for (int u = 0; u < PER; ++u) tile[u * kBlock + threadIdx.x] = x[u];
-    __syncthreads();
-    const uint64_t cur_base = base;
-    const uint64_t next_id = tile_id + gridDim.x;
-    if (next_id < ntiles) {
-      base = insert_bits<-1>(next_id << kTileLow, ins);
+  for (int u = 0; u < PER; ++u) tile[u * kBlock + threadIdx.x] = x[u];
+  __syncthreads();
+  for (uint32_t gi = 0; gi < d.ngates; ++gi) {
+    const TileGate<T> g = gates[gi];  // wave-uniform
+    if (g.kind == 0) {
+      const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
 #pragma unroll
-      for (int u = 0; u < PER; ++u) x[u] = ldg<NT>(st + (base | off[u]));
-    }
-    for (uint32_t gi = 0; gi < d.ngates; ++gi) {
-      const TileGate<T> g = gates[gi];  // wave-uniform
-      if (g.kind == 0) {
-        const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
-#pragma unroll
-        for (int k = 0; k < PER / 2; ++k) {
-          const uint32_t p = k * kBlock + threadIdx.x;
-          const uint32_t t0 = ((p >> g.b0) << (g.b0 + 1)) | (p & low);
-          if ((t0 & g.cmask) != g.cmask) continue;
-          const A a0 = tile[t0], a1 = tile[t0 | bit];
-          A r0 = czero<A>(), r1 = czero<A>();
-          if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
-          if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
-          if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
-          if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
-          tile[t0] = r0;
-          tile[t0 | bit] = r1;
-        }
-      } else if (g.kind == 1) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-          const uint32_t t = u * kBlock + threadIdx.x;
-          if ((t & g.cmask) != g.cmask) continue;
-          const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
-          if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
-          tile[t] = cmul(f, tile[t]);
-        }
-      } else {
-        const uint32_t lowa = (1u << g.b0) - 1u;
-#pragma unroll
-        for (int k = 0; k < PER / 4; ++k) {
-          uint32_t p = k * kBlock + threadIdx.x;         // index over the tile with bits b0 < b1 removed
-          p = ((p >> g.b0) << (g.b0 + 1)) | (p & lowa);  // open b0
-          const uint32_t hi_part = p >> g.b1;            // open b1 (p already has b0 opened, so b1 is final)
-          p = (hi_part << (g.b1 + 1)) | (p & ((1u << g.b1) - 1u));
-          if ((p & g.cmask) != g.cmask) continue;
-          const uint32_t ta = p | (1u << g.b0), tb = p | (1u << g.b1);
-          const A va = tile[ta], vb = tile[tb];
-          tile[ta] = vb;
-          tile[tb] = va;
-        }
+      for (int k = 0; k < PER / 2; ++k) {
+        const uint32_t p = k * kBlock + threadIdx.x;
+        const uint32_t t0 = ((p >> g.b0) << (g.b0 + 1)) | (p & low);
+        if ((t0 & g.cmask) != g.cmask) continue;
+        const A a0 = tile[t0], a1 = tile[t0 | bit];
+        A r0 = czero<A>(), r1 = czero<A>();
+        if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+        if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+        if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+        if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+        tile[t0] = r0;
+        tile[t0 | bit] = r1;
       }
-      __syncthreads();
-    }
+    } else if (g.kind == 1) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const A y = tile[u * kBlock + threadIdx.x];
-      stg<NT>(st + (cur_base | off[u]), y);
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t t = u * kBlock + threadIdx.x;
+        if ((t & g.cmask) != g.cmask) continue;
+        const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
+        if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
+        tile[t] = cmul(f, tile[t]);
+      }
+    } else {
+      const uint32_t lowa = (1u << g.b0) - 1u;
+#pragma unroll
+      for (int k = 0; k < PER / 4; ++k) {
+        uint32_t p = k * kBlock + threadIdx.x;         // index over the tile with bits b0 < b1 removed
+        p = ((p >> g.b0) << (g.b0 + 1)) | (p & lowa);  // open b0
+        const uint32_t hi_part = p >> g.b1;            // open b1 (p already has b0 opened, so b1 is final)
+        p = (hi_part << (g.b1 + 1)) | (p & ((1u << g.b1) - 1u));
+        if ((p & g.cmask) != g.cmask) continue;
+        const uint32_t ta = p | (1u << g.b0), tb = p | (1u << g.b1);
+        const A va = tile[ta], vb = tile[tb];
+        tile[ta] = vb;
+        tile[tb] = va;
+      }
     }
-    __syncthreads();  // the tile buffer is rewritten by the next iteration
-    tile_id = next_id;
+    __syncthreads();
   }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) x[u] = tile[u * kBlock + threadIdx.x];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) stg<NT>(st + idx[u], x[u]);
 }
 
 // ---- literal fallback: one output row per lane, out of place ------------------------------
