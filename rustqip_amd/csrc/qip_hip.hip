@@ -1393,7 +1393,6 @@ static int classify_tile_item(qip_hip_state* s, const qip_op* op, TileItem* it) 
     it->t1 = std::max(p.opos[0], p.opos[1]);
     it->tileable = true;
   }
-  if (it->pos.size() > (size_t)kTileBits) it->tileable = false;
   return QIP_OK;
 }
 
@@ -1414,9 +1413,10 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     }
   }
   std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
-  auto tile_bit = [&](uint32_t pos) -> uint32_t {
+  auto tile_bit = [&](uint32_t pos) -> uint32_t {  // kTileOutside when the position is not part of the tile
     if (pos < (uint32_t)kTileLow) return pos;
-    return kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin());
+    const auto f = std::find(high.begin(), high.end(), pos);
+    return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
   std::vector<TileGate<T>> gates(seg.size());
   for (size_t i = 0; i < seg.size(); ++i) {
@@ -1427,7 +1427,12 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     g.b0 = tile_bit(it.t0);
     g.b1 = it.kind == 2 ? tile_bit(it.t1) : 0;
     if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);
-    for (uint32_t c : it.cpos) g.cmask |= 1u << tile_bit(c);
+    if (it.kind == 1 && g.b0 == kTileOutside) g.tpos_out = it.t0;
+    for (uint32_t c : it.cpos) {
+      const uint32_t tb = tile_bit(c);
+      if (tb == kTileOutside) g.omask |= 1ull << c;
+      else g.cmask |= 1u << tb;
+    }
     g.nz = it.nz;
     if (it.kind == 0) {
       for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
@@ -1495,7 +1500,12 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
       bool fits = it.tileable && !(mask & blocked);
       std::vector<uint32_t> need;
       if (fits) {
-        for (uint32_t p : it.pos)
+        // only bits the gate exchanges amplitudes across must be tile bits: a dense target, both swap bits;
+        // controls and diagonal targets may stay outside (block-uniform predicates)
+        std::vector<uint32_t> exch;
+        if (it.kind == 0) exch = {it.t0};
+        if (it.kind == 2) exch = {it.t0, it.t1};
+        for (uint32_t p : exch)
           if (p >= (uint32_t)kTileLow && std::find(high.begin(), high.end(), p) == high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
             need.push_back(p);

@@ -610,12 +610,20 @@ constexpr int kTileHigh = 5;                       // free bit positions per seg
 constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile
 constexpr int kTileMaxGates = 24;
 
+// Only the bits a gate EXCHANGES amplitudes across must lie inside the tile: the target of a dense gate, the
+// two bits of a swap.  Controls, and the target of a diagonal gate, may sit on any index bit: outside the tile
+// such a bit is constant for the whole block, so it is tested once against the block's base index
+// (`omask` / `tpos_out`, amplitude-index space) instead of per element (`cmask` / `b0`, tile-index space).
+constexpr uint32_t kTileOutside = 0xffffffffu;
 template <typename T> struct TileGate {
-  uint32_t kind;    // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap
-  uint32_t b0, b1;  // tile-index bit(s): target (kinds 0, 1) or the two swapped bits (kind 2, b0 < b1)
-  uint32_t cmask;   // tile-index bits that must all be 1 (controls)
-  uint32_t nz;      // kind 0: non-zero mask of the 2x2 entries
-  amp_t<T> m[4];    // kind 0: 2x2 row-major; kind 1: m[0] = d0, m[1] = d1
+  uint32_t kind;      // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap
+  uint32_t b0, b1;    // tile-index bit(s): target (kinds 0, 1; kTileOutside for a diagonal target outside the tile)
+                      // or the two swapped bits (kind 2, b0 < b1)
+  uint32_t cmask;     // tile-index bits that must all be 1 (controls inside the tile)
+  uint32_t nz;        // kind 0: non-zero mask of the 2x2 entries
+  uint32_t tpos_out;  // kind 1 with b0 == kTileOutside: amplitude-index position of the target
+  uint64_t omask;     // amplitude-index bits outside the tile that must all be 1 (controls outside the tile)
+  amp_t<T> m[4];      // kind 0: 2x2 row-major; kind 1: m[0] = d0, m[1] = d1
 };
 
 struct TileDesc {
@@ -657,6 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   __syncthreads();
   for (uint32_t gi = 0; gi < d.ngates; ++gi) {
     const TileGate<T> g = gates[gi];  // wave-uniform
+    if ((base & g.omask) != g.omask) continue;  // block-uniform: an outside control is 0 for this whole tile
     if (g.kind == 0) {
       const uint32_t low = (1u << g.b0) - 1u, bit = 1u << g.b0;
 #pragma unroll
@@ -674,11 +683,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
         tile[t0 | bit] = r1;
       }
     } else if (g.kind == 1) {
+      const bool out = g.b0 == kTileOutside;
+      const bool out_bit = out && ((base >> g.tpos_out) & 1ull);
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const uint32_t t = u * kBlock + threadIdx.x;
         if ((t & g.cmask) != g.cmask) continue;
-        const A f = ((t >> g.b0) & 1u) ? g.m[1] : g.m[0];
+        const bool one = out ? out_bit : (((t >> g.b0) & 1u) != 0);
+        const A f = one ? g.m[1] : g.m[0];
         if (f.x == (T)1 && f.y == (T)0) continue;  // unit entries leave the amplitude untouched
         tile[t] = cmul(f, tile[t]);
       }
