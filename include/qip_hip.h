@@ -186,6 +186,8 @@ int qip_hip_program_destroy(qip_hip_program* p);
  *                    on index bits 0..5 plus five free higher bits and applies each segment in ONE sweep
  *                    through an LDS-resident tile (bit-identical to the gate-by-gate path);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
+ *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
+ *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)
  *   "packed_f32"     1 (default): f32 states are swept as 16-B elements of two amplitudes where possible
  *   "unroll"         1 = one item per iteration in the matrix-core kernel (tuning aid)
  */

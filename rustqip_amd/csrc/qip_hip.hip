@@ -371,6 +371,7 @@ struct qip_hip_state {
   int64_t lowbit_shuffle = 1;
   int64_t mfma = 1;
   int64_t fuse = 0;
+  int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
   int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
@@ -590,6 +591,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "fuse")) s->fuse = value;
   else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
   else if (!strcmp(key, "tile")) s->tile = value;
+  else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
@@ -1453,12 +1455,52 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   ProfRec rec;
   rec.cls = KC_TILE_GATES;
   if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
-  if (use_nt(s))
+  if (s->tile_passes) {
+    // group consecutive gates into passes of at most three distinct exchange bits (see k_tile_passes)
+    TilePassDesc pd;
+    memset(&pd, 0, sizeof pd);
+    for (int j = 0; j < kTileHigh; ++j) pd.hpos[j] = high[j];
+    std::vector<uint32_t> bits;
+    uint32_t first = 0;
+    auto close_pass = [&](uint32_t end) {
+      std::vector<uint32_t> b = bits;
+      for (uint32_t t = 0; b.size() < 3 && t < (uint32_t)kTileBits; ++t)
+        if (std::find(b.begin(), b.end(), t) == b.end()) b.push_back(t);
+      std::sort(b.begin(), b.end());
+      TilePass& ps = pd.pass[pd.npasses++];
+      ps.first = first;
+      ps.count = end - first;
+      for (int j = 0; j < 3; ++j) ps.pb[j] = b[j];
+      first = end;
+      bits.clear();
+    };
+    for (uint32_t i = 0; i < (uint32_t)gates.size(); ++i) {
+      std::vector<uint32_t> add;
+      if (gates[i].kind == 0) add = {gates[i].b0};
+      if (gates[i].kind == 2) add = {gates[i].b0, gates[i].b1};
+      std::vector<uint32_t> merged = bits;
+      for (uint32_t b : add)
+        if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
+      if (merged.size() > 3) {
+        close_pass(i);
+        merged = add;
+      }
+      bits = merged;
+    }
+    close_pass((uint32_t)gates.size());
+    if (use_nt(s))
+      hipLaunchKernelGGL((k_tile_passes<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, pd, dg);
+    else
+      hipLaunchKernelGGL((k_tile_passes<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, pd, dg);
+  } else if (use_nt(s)) {
     hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
                        (amp_t<T>*)s->cur, ins, d, dg);
-  else
+  } else {
     hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
                        (amp_t<T>*)s->cur, ins, d, dg);
+  }
   HIPCHK(hipGetLastError());
   if (s->profile) QCHK(prof_end(s, &rec));
   return QIP_OK;

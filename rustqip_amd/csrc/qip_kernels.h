@@ -717,6 +717,144 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   for (int u = 0; u < PER; ++u) stg<NT>(st + idx[u], x[u]);
 }
 
+// ---- the same segment, LDS traffic cut by "passes" ------------------------------------------------------
+// k_tile_gates above is LDS-bandwidth bound (64 KiB of LDS traffic per gate per tile; ~17 gates per sweep cost
+// twice the HBM time).  Here consecutive gates are grouped into PASSES of at most three distinct exchange
+// bits: each lane pulls the 8 tile elements that are closed under those bits into registers (one LDS read +
+// one LDS write per element per PASS), applies every gate of the pass to them in circuit order — register
+// butterflies for dense gates, element-wise factors for diagonal gates, register permutations for swaps —
+// and barriers only at pass boundaries.  Per element the operations and their order are those of the
+// gate-by-gate path, so circuit-order segments stay bit-identical.
+struct TilePass {
+  uint32_t first, count;  // gates[first .. first+count)
+  uint32_t pb[3];         // the pass's three exchange bits (tile-index space, distinct, ascending)
+};
+constexpr int kTileMaxPasses = 24;
+struct TilePassDesc {
+  uint32_t npasses;
+  uint32_t hpos[kTileHigh];
+  TilePass pass[kTileMaxPasses];
+};
+
+template <typename T, int J>
+__device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
+  using A = amp_t<T>;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if ((i >> J) & 1) continue;
+    const int k = i | (1 << J);
+    const A a0 = e[i], a1 = e[k];
+    A r0 = czero<A>(), r1 = czero<A>();
+    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
+    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
+    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
+    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+    const bool hit = (te[i] & g.cmask) == g.cmask;
+    e[i] = hit ? r0 : a0;
+    e[k] = hit ? r1 : a1;
+  }
+}
+
+template <typename T, int J0, int J1>
+__device__ __forceinline__ void pass_swap(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
+  using A = amp_t<T>;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (!(((i >> J0) & 1) == 1 && ((i >> J1) & 1) == 0)) continue;  // i has (J0,J1) = (1,0); partner (0,1)
+    const int k = (i & ~(1 << J0)) | (1 << J1);
+    const bool hit = (te[i] & g.cmask) == g.cmask;  // controls are not J0/J1, so both elements agree
+    const A a = e[i], b = e[k];
+    e[i] = hit ? b : a;
+    e[k] = hit ? a : b;
+  }
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kBlock) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
+                                                        const TileGate<T>* __restrict__ gates) {
+  using A = amp_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  A* tile = reinterpret_cast<A*>(tile_raw);
+  constexpr int PER = (1 << kTileBits) / kBlock;
+  static_assert(PER == 8, "one 8-element group per lane");
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  {
+    uint64_t idx[PER];
+    A x[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const uint32_t t = u * kBlock + tid;
+      const uint32_t h = t >> kTileLow;
+      uint64_t off = t & ((1u << kTileLow) - 1u);
+#pragma unroll
+      for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
+      idx[u] = base | off;
+      x[u] = ldg<NT>(st + idx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) tile[u * kBlock + tid] = x[u];
+  }
+  __syncthreads();
+  for (uint32_t pi = 0; pi < d.npasses; ++pi) {
+    const TilePass ps = d.pass[pi];
+    // this lane's group: tid with zeros opened at the three pass bits (ascending), then the 8 combinations
+    uint32_t tb = tid;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tb = ((tb >> ps.pb[j]) << (ps.pb[j] + 1)) | (tb & ((1u << ps.pb[j]) - 1u));
+    uint32_t te[8];
+    A e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      te[i] = tb | ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) |
+              ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+      e[i] = tile[te[i]];
+    }
+    for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+      const TileGate<T> g = gates[gi];  // wave-uniform
+      if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
+      if (g.kind == 1) {
+        const bool out = g.b0 == kTileOutside;
+        const bool out_bit = out && ((base >> g.tpos_out) & 1ull);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool one = out ? out_bit : (((te[i] >> g.b0) & 1u) != 0);
+          const A f = one ? g.m[1] : g.m[0];
+          const bool unit = f.x == (T)1 && f.y == (T)0;
+          const bool hit = (te[i] & g.cmask) == g.cmask && !unit;
+          const A y = cmul(f, e[i]);
+          e[i] = hit ? y : e[i];
+        }
+      } else if (g.kind == 0) {
+        // which of the pass's three bits is the target
+        if (g.b0 == ps.pb[0]) pass_butterflies<T, 0>(g, e, te);
+        else if (g.b0 == ps.pb[1]) pass_butterflies<T, 1>(g, e, te);
+        else pass_butterflies<T, 2>(g, e, te);
+      } else {
+        const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
+        const bool b1 = g.b1 == ps.pb[1];
+        if (a0 && b1) pass_swap<T, 0, 1>(g, e, te);
+        else if (a0) pass_swap<T, 0, 2>(g, e, te);
+        else if (a1) pass_swap<T, 1, 2>(g, e, te);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[te[i]] = e[i];
+    __syncthreads();
+  }
+  {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const uint32_t t = u * kBlock + tid;
+      const uint32_t h = t >> kTileLow;
+      uint64_t off = t & ((1u << kTileLow) - 1u);
+#pragma unroll
+      for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
+      stg<NT>(st + (base | off), tile[t]);
+    }
+  }
+}
+
 // ---- literal fallback: one output row per lane, out of place ------------------------------
 // The gather formulation of the reference, variant by variant (matrix_ops.rs:62-94,
 // ops.rs:100-156, qubit_iterators.rs).  Correct for every descriptor the reference accepts,

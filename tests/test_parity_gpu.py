@@ -597,6 +597,12 @@ def test_lds_tile_multi_gate_sweeps(O, n):
             st.upload(x)
             st.apply_ops(ops)
             eager = st.download()
+        with q.HipState(n) as st:  # one LDS round trip per gate (the simpler kernel) is bit-identical too
+            st.set_option("tile", 1)
+            st.set_option("tile_passes", 0)
+            st.upload(x)
+            st.apply_ops(ops)
+            assert np.array_equal(st.download(), eager), (name, n)
         sweeps = {}
         for mode in (1, 2):
             with q.HipState(n) as st:
