@@ -1438,6 +1438,11 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     g.nz = it.nz;
     if (it.kind == 0) {
       for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
+      if (s->tile_passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
+        const bool real = it.m[1] == 0 && it.m[3] == 0 && it.m[5] == 0 && it.m[7] == 0;
+        const bool is_x = it.nz == 6u && it.m[2] == 1 && it.m[3] == 0 && it.m[4] == 1 && it.m[5] == 0;
+        g.b1 = (real ? 1u : 0u) | (is_x ? 2u : 0u);
+      }
     } else if (it.kind == 1) {
       g.m[0] = mk<T>(it.m[0], it.m[1]);
       g.m[1] = mk<T>(it.m[2], it.m[3]);

@@ -618,7 +618,11 @@ constexpr uint32_t kTileOutside = 0xffffffffu;
 template <typename T> struct TileGate {
   uint32_t kind;      // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap
   uint32_t b0, b1;    // tile-index bit(s): target (kinds 0, 1; kTileOutside for a diagonal target outside the tile)
-                      // or the two swapped bits (kind 2, b0 < b1)
+                      // or the two swapped bits (kind 2, b0 < b1).  Kind 0 keeps flags in b1:
+                      //   bit 0: every matrix entry is real  -> 2 multiplies per product instead of 4 mul + 2 add
+                      //   bit 1: the gate is X ([0,1;1,0])   -> the pair is exchanged, no arithmetic
+                      // both give IEEE-equal results for finite amplitudes (x*1 == x, a - 0*b == a); inside a
+                      // tile sweep the f64 VALU (quarter rate), not HBM, is the limit, so flops matter here
   uint32_t cmask;     // tile-index bits that must all be 1 (controls inside the tile)
   uint32_t nz;        // kind 0: non-zero mask of the 2x2 entries
   uint32_t tpos_out;  // kind 1 with b0 == kTileOutside: amplitude-index position of the target
@@ -736,6 +740,30 @@ struct TilePassDesc {
   TilePass pass[kTileMaxPasses];
 };
 
+template <typename T>
+__device__ __forceinline__ void tile_pair(const TileGate<T>& g, amp_t<T> a0, amp_t<T> a1, amp_t<T>* r0, amp_t<T>* r1) {
+  using A = amp_t<T>;
+  if (g.b1 & 2u) {  // X: pure exchange
+    *r0 = a1;
+    *r1 = a0;
+    return;
+  }
+  A s0 = czero<A>(), s1 = czero<A>();
+  if (g.b1 & 1u) {  // real entries: (m, 0) * (x, y) = (m*x, m*y)
+    if (g.nz & 1u) { A t; t.x = g.m[0].x * a0.x; t.y = g.m[0].x * a0.y; s0 = cadd(s0, t); }
+    if (g.nz & 2u) { A t; t.x = g.m[1].x * a1.x; t.y = g.m[1].x * a1.y; s0 = cadd(s0, t); }
+    if (g.nz & 4u) { A t; t.x = g.m[2].x * a0.x; t.y = g.m[2].x * a0.y; s1 = cadd(s1, t); }
+    if (g.nz & 8u) { A t; t.x = g.m[3].x * a1.x; t.y = g.m[3].x * a1.y; s1 = cadd(s1, t); }
+  } else {
+    if (g.nz & 1u) s0 = cadd(s0, cmul(g.m[0], a0));
+    if (g.nz & 2u) s0 = cadd(s0, cmul(g.m[1], a1));
+    if (g.nz & 4u) s1 = cadd(s1, cmul(g.m[2], a0));
+    if (g.nz & 8u) s1 = cadd(s1, cmul(g.m[3], a1));
+  }
+  *r0 = s0;
+  *r1 = s1;
+}
+
 template <typename T, int J>
 __device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
   using A = amp_t<T>;
@@ -744,11 +772,8 @@ __device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> 
     if ((i >> J) & 1) continue;
     const int k = i | (1 << J);
     const A a0 = e[i], a1 = e[k];
-    A r0 = czero<A>(), r1 = czero<A>();
-    if (g.nz & 1u) r0 = cadd(r0, cmul(g.m[0], a0));
-    if (g.nz & 2u) r0 = cadd(r0, cmul(g.m[1], a1));
-    if (g.nz & 4u) r1 = cadd(r1, cmul(g.m[2], a0));
-    if (g.nz & 8u) r1 = cadd(r1, cmul(g.m[3], a1));
+    A r0, r1;
+    tile_pair<T>(g, a0, a1, &r0, &r1);
     const bool hit = (te[i] & g.cmask) == g.cmask;
     e[i] = hit ? r0 : a0;
     e[k] = hit ? r1 : a1;
