@@ -287,6 +287,19 @@ def main():
             dt = time.perf_counter() - t
             by = sum(circuit_bytes(q, n, cops))
             extras[cname] = {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": by / dt / 1e9}
+            st.set_option("tile", 1)  # bit-identical multi-gate sweeps
+            st.set_option("profile", 1)
+            st.apply_compiled(cc)
+            st.sync()
+            st.profile_reset()
+            t = time.perf_counter()
+            st.apply_compiled(cc)
+            st.sync()
+            dt = time.perf_counter() - t
+            extras[cname]["tile1"] = {"ms": 1e3 * dt, "ops_per_s": len(cops) / dt,
+                                      "sweeps": sum(v["launches"] for v in st.profile().values())}
+            st.set_option("tile", 0)
+            st.set_option("profile", 0)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28
