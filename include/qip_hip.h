@@ -173,6 +173,12 @@ int qip_hip_program_run(qip_hip_program* p);
 int qip_hip_program_is_graph(const qip_hip_program* p);
 int qip_hip_program_destroy(qip_hip_program* p);
 
+/* The schedule option "tile" would use for this circuit, without touching a device: step_of_op[i] = index of
+ * the step op i belongs to; a step holding one op is an ordinary launch, a step holding several is one
+ * LDS-resident sweep.  mode 1 = circuit order, 2 = with commuting reorder.  Pure host code. */
+int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
+                       int64_t* step_of_op, uint64_t* n_steps);
+
 /* Options: key is one of
  *   "force_generic"  1 = route every op through the literal gather kernel
  *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)

@@ -1356,12 +1356,11 @@ struct TileItem {
   uint32_t nz = 0;
 };
 
-template <typename T>
-static int classify_tile_item(qip_hip_state* s, const qip_op* op, TileItem* it) {
+static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it) {
   FlatOp f;
-  QCHK(flatten_op(s->n, op, false, &f));
+  QCHK(flatten_op(n, op, false, &f));
   Plan p;
-  QCHK(make_plan(s->dtype, s->n, f, false, &p));
+  QCHK(make_plan(dtype, n, f, false, &p));
   it->tileable = false;
   it->pos.clear();
   for (uint32_t c : p.cpos) it->pos.push_back(c);
@@ -1511,11 +1510,22 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   return QIP_OK;
 }
 
-template <typename T>
-static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
-  std::vector<TileItem> items(count);
+// One step of a tiled schedule: a segment of >= 2 gates applied in one sweep, or a single op applied by
+// its own kernel (not tileable, or alone — a lone gate's own kernel touches only what can change).
+struct TileStep {
+  std::vector<uint64_t> ops;   // indices into the circuit, in application order
+  std::vector<uint32_t> high;  // the free bit positions the segment claimed (<= kTileHigh)
+};
+
+// Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
+// qip_hip_plan_tiles: every op appears in exactly one step; without reorder the concatenation of the steps
+// is the circuit itself; with reorder an op only overtakes ops it shares no qubit with.
+static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
+                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps) {
+  std::vector<TileItem>& items = *items_out;
+  items.assign(count, TileItem());
   for (uint64_t i = 0; i < count; ++i) {
-    int rc = classify_tile_item<T>(s, &ops[i], &items[i]);
+    int rc = classify_tile_item(dtype, n, &ops[i], &items[i]);
     if (rc != QIP_OK) {
       std::string msg = g_last_error;
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
@@ -1530,16 +1540,15 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
       continue;
     }
     if (!items[head].tileable) {
-      QCHK(apply_op_t<T>(s, &ops[head]));
+      steps->push_back(TileStep{{head}, {}});
       done[head++] = 1;
       continue;
     }
     // grow a segment from `head`
-    std::vector<const TileItem*> seg;
-    std::vector<uint32_t> high;
+    TileStep st;
     uint64_t blocked = 0;  // bit positions of gates skipped so far (later gates must not touch them)
     bool any_skipped = false;
-    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && seg.size() < (size_t)kTileMaxGates; ++i) {
+    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && st.ops.size() < (size_t)kTileMaxGates; ++i) {
       if (done[i]) continue;
       const TileItem& it = items[i];
       uint64_t mask = 0;
@@ -1553,14 +1562,14 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
         if (it.kind == 0) exch = {it.t0};
         if (it.kind == 2) exch = {it.t0, it.t1};
         for (uint32_t p : exch)
-          if (p >= (uint32_t)kTileLow && std::find(high.begin(), high.end(), p) == high.end() &&
+          if (p >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
             need.push_back(p);
-        fits = high.size() + need.size() <= (size_t)kTileHigh;
+        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
       }
       if (fits) {
-        for (uint32_t p : need) high.push_back(p);
-        seg.push_back(&it);
+        for (uint32_t p : need) st.high.push_back(p);
+        st.ops.push_back(i);
         done[i] = 1;
       } else {
         if (!reorder) break;  // strict: segments are consecutive runs of the circuit
@@ -1568,13 +1577,38 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
         any_skipped = true;
       }
     }
-    if (seg.size() == 1) {
-      // a lone gate gains nothing from the tile: its own kernel touches only what can change
-      const uint64_t i = (uint64_t)(seg[0] - items.data());
-      QCHK(apply_op_t<T>(s, &ops[i]));
-    } else {
-      QCHK(launch_tile_segment<T>(s, seg, high));
+    steps->push_back(st);
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
+                                  int64_t* step_of_op, uint64_t* n_steps) {
+  if ((count && (!ops || !step_of_op)) || !n_steps) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
+  std::vector<TileItem> items;
+  std::vector<TileStep> steps;
+  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
+  for (size_t si = 0; si < steps.size(); ++si)
+    for (uint64_t i : steps[si].ops) step_of_op[i] = (int64_t)si;
+  *n_steps = steps.size();
+  return QIP_OK;
+}
+
+template <typename T>
+static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
+  std::vector<TileItem> items;
+  std::vector<TileStep> steps;
+  QCHK(schedule_tiles(s->dtype, s->n, ops, count, reorder, &items, &steps));
+  for (const TileStep& st : steps) {
+    if (st.ops.size() == 1) {
+      QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
+      continue;
     }
+    std::vector<const TileItem*> seg;
+    for (uint64_t i : st.ops) seg.push_back(&items[i]);
+    QCHK(launch_tile_segment<T>(s, seg, st.high));
   }
   return QIP_OK;
 }

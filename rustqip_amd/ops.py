@@ -217,3 +217,19 @@ def algorithmic_bytes(n: int, op: MatrixOp, dtype: int = _ffi.QIP_C64) -> float:
     if rc != _ffi.QIP_OK:
         raise CircuitError(_ffi.last_error())
     return out.value
+
+
+def plan_tiles(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64):
+    """Schedule of the LDS-resident multi-gate sweeps (option "tile") for a circuit — host code, no GPU.
+    Returns a list of steps, each a list of op indices in application order."""
+    cops = [op.to_c(dtype) for op in ops]
+    arr = (_ffi.QipOp * len(cops))(*cops)
+    step_of = (C.c_int64 * len(cops))()
+    n_steps = C.c_uint64()
+    rc = _ffi.lib.qip_hip_plan_tiles(dtype, n, arr, len(cops), mode, step_of, C.byref(n_steps))
+    if rc != _ffi.QIP_OK:
+        raise CircuitError(_ffi.last_error())
+    steps = [[] for _ in range(n_steps.value)]
+    for i in range(len(cops)):
+        steps[step_of[i]].append(i)
+    return steps

@@ -166,3 +166,51 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 hit = re.search(r"(import|from)\s+oracle|oracle[/.]|qip_oracle|libqip_oracle", text)
                 assert hit is None, f"{f} references the CPU oracle: {hit.group(0)!r}"
+
+
+def test_tile_schedule_invariants():
+    """Host-side scheduling of the LDS-resident multi-gate sweeps (qip_hip_plan_tiles): every op lands in exactly
+    one step; circuit-order mode only cuts the circuit into consecutive runs; reorder mode lets an op overtake
+    only ops it shares no qubit with; a segment claims at most 5 free bits for its exchanging gates."""
+    from rustqip_amd import circuits
+    from rustqip_amd.ops import plan_tiles
+    from rustqip_amd.sharded import flatten
+
+    n = 20
+    rng = np.random.default_rng(0)
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 300, seed=3) + circuits.c3_qft(n)[:120]
+    ops.insert(50, q.make_matrix_op([3, 9], np.eye(4).ravel() * (1 + 0j) + 0.1))      # dense k = 2: not tileable
+    ops.insert(200, q.make_control_op(list(range(12)), q.make_matrix_op([15], [1, 0, 0, -1])))  # many controls: fine
+    qubits = [set(flatten(o)[0]) | set(flatten(o)[2]) for o in ops]
+
+    def exchange_bits(o):
+        ctrl, inner, tgt = flatten(o)
+        if inner.kind == "Swap":
+            return {n - 1 - t for t in tgt}
+        d = np.asarray(inner.data).reshape(2 ** len(tgt), -1)
+        return set() if np.count_nonzero(d - np.diag(np.diagonal(d))) == 0 else {n - 1 - t for t in tgt}
+
+    for mode in (1, 2):
+        steps = plan_tiles(n, ops, mode)
+        flat = [i for st in steps for i in st]
+        assert sorted(flat) == list(range(len(ops)))
+        if mode == 1:
+            assert flat == list(range(len(ops)))
+        else:
+            pos = {i: k for k, i in enumerate(flat)}
+            for a in range(len(ops)):
+                for b in range(a + 1, len(ops)):
+                    if pos[b] < pos[a]:
+                        assert not (qubits[a] & qubits[b]), (a, b)
+        for st in steps:
+            assert all(st[k] < st[k + 1] for k in range(len(st) - 1))  # circuit order inside a step
+            if len(st) > 1:
+                free = set()
+                for i in st:
+                    free |= {p for p in exchange_bits(ops[i]) if p >= 6}
+                assert len(free) <= 5 and len(st) <= 24
+                assert all(len(flatten(ops[i])[2]) == 1 or flatten(ops[i])[1].kind == "Swap" for i in st)
+        assert [50] in steps  # the dense 2-qubit gate is launched on its own
+    assert len(plan_tiles(n, ops, 2)) <= len(plan_tiles(n, ops, 1)) < len(ops) / 4
+    with pytest.raises(q.CircuitError):
+        plan_tiles(8, ops[:3], 1)  # n below the tile size
