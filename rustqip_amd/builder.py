@@ -107,9 +107,13 @@ def lower_to_matrix_op(entry: PipelineEntry) -> Optional[MatrixOp]:
 class HipBuilder:
     """Drop-in for the LocalBuilder<P> call sequence of the reference, GPU-backed."""
 
-    def __init__(self, dtype=np.complex128, device: int = 0):
+    def __init__(self, dtype=np.complex128, device: int = 0, tile: int = 1):
         self.dtype = np.dtype(dtype)
         self.device = device
+        # tile = 1: runs of gates between measurements are applied as LDS-resident multi-gate sweeps in circuit
+        # order — bit-identical to one sweep per gate, several times fewer passes over HBM.  0 = one sweep per
+        # gate, 2 = also hoist gates over gates they commute with (1e-12 instead of bit equality).
+        self.tile = tile
         self._n = 0
         self.pipeline: List[PipelineEntry] = []
 
@@ -300,6 +304,7 @@ class HipBuilder:
         rng = rng or np.random.default_rng()
         forced = list(forced_measurements or [])
         state = HipState(n, self.dtype, self.device)
+        state.set_option("tile", self.tile)
         state.init_basis(self.initial_index(init))
         results: List[tuple] = []
         batch: List[MatrixOp] = []
