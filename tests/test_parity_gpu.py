@@ -733,6 +733,40 @@ def test_cswap_readme_example(O):
     assert m in (0, 1) and abs(p - 0.5) < 1e-12
 
 
+def test_builder_run_loop_uses_tile_sweeps_bit_identically(O):
+    """HipBuilder (default tile = 1) on a 12-qubit circuit: same amplitudes, bit for bit, as the oracle's
+    restatement of the reference run loop and as the one-sweep-per-gate builder."""
+    from rustqip_amd.builder import Register
+
+    def build(tile):
+        b = q.HipBuilder(tile=tile)
+        ra, rb = b.register(6), b.register(6)
+        b.h(ra)
+        b.cnot(Register((0,)), rb)
+        b.t(rb)
+        b.rz(ra, 0.37)
+        b.swap_op(Register((1, 2)), Register((10, 11)))
+        b.y(Register((4,)))
+        b.s_dagger(Register((7,)))
+        b.toffoli(Register((3, 8)), Register((5,)))
+        b.h(rb)
+        b.measure_stochastic(Register((2, 9)))
+        _, h = b.measure(Register((6,)))
+        return b, (ra, rb), h
+
+    b1, (ra, rb), h = build(1)
+    b0, _, _ = build(0)
+    init = [(ra, 0b010101), (rb, 0b100001)]
+    s1, m1 = b1.calculate_state_with_init(init, forced_measurements=[1])
+    s0, m0 = b0.calculate_state_with_init(init, forced_measurements=[1])
+    assert np.array_equal(s1, s0)
+    pipe = [(e.indices, e.kind, e.param) for e in b1.pipeline]
+    want, res = O.run_pipeline(12, pipe, b1.initial_index(init), forced_measurements=[1])
+    assert np.max(np.abs(s1 - want)) < 1e-12
+    assert np.max(np.abs(m1.get_stochastic_measurement(0) - res[0][1])) < 1e-12
+    assert m1.get_measurement(h)[0] == 1 and abs(m1.get_measurement(h)[1] - res[1][2]) < 1e-12
+
+
 # ---- measurement -----------------------------------------------------------------------------------------------
 def test_measurement_golden_vectors():
     with q.HipState(2) as st:
