@@ -64,18 +64,70 @@ def write_openqasm_file(b: HipBuilder, path) -> None:
         f.write(to_openqasm(b))
 
 
-_ANGLE = re.compile(r"^\s*(-?\d+)\s*\*\s*pi\s*(?:/\s*(-?\d+))?\s*$")
+_TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?)|(pi)|([-+*/()]))")
 
 
 def _parse_angle(text: str) -> float:
-    """OpenQASM semantics: `k*pi/m` means k*pi/m radians (the reference's *simulation* of PiRational drops
-    the pi — App. C Q1 — but its exported text means what it says, and that is what an ingester must honour)."""
-    m = _ANGLE.match(text)
-    if m:
-        return int(m.group(1)) * math.pi / int(m.group(2) or 1)
-    if not re.fullmatch(r"[\d\s.eE+\-*/()pi]+", text):
+    """Arithmetic over numbers and `pi` with + - * / and parentheses (what OpenQASM 2 angle expressions of the
+    exporter's gate set use).  OpenQASM semantics: `k*pi/m` means k*pi/m radians — the reference's *simulation*
+    of PiRational drops the pi, but its exported text means what it says, and that is what
+    an ingester must honour."""
+    tokens = []
+    pos = 0
+    while pos < len(text):
+        if text[pos:].strip() == "":
+            break
+        m = _TOKEN.match(text, pos)
+        if not m:
+            raise CircuitError(f"unsupported angle expression {text!r}")
+        tokens.append(float(m.group(1)) if m.group(1) else math.pi if m.group(2) else m.group(3))
+        pos = m.end()
+    it = iter(tokens + [None])
+    cur = [next(it)]
+
+    def advance():
+        cur[0] = next(it)
+
+    def atom():
+        t = cur[0]
+        if isinstance(t, float):
+            advance()
+            return t
+        if t == "(":
+            advance()
+            v = expr()
+            if cur[0] != ")":
+                raise CircuitError(f"unbalanced parentheses in {text!r}")
+            advance()
+            return v
+        if t in ("-", "+"):
+            advance()
+            v = atom()
+            return -v if t == "-" else v
         raise CircuitError(f"unsupported angle expression {text!r}")
-    return float(eval(text, {"__builtins__": {}}, {"pi": math.pi}))  # arithmetic on numbers and pi only
+
+    def term():
+        v = atom()
+        while cur[0] in ("*", "/"):
+            op = cur[0]
+            advance()
+            w = atom()
+            v = v * w if op == "*" else v / w
+        return v
+
+    def expr():
+        v = term()
+        while cur[0] in ("+", "-"):
+            op = cur[0]
+            advance()
+            w = term()
+            v = v + w if op == "+" else v - w
+        return v
+
+    value = expr()
+    if cur[0] is not None:
+        raise CircuitError(f"unsupported angle expression {text!r}")
+    return value
 
 
 def from_openqasm(text: str, dtype=None) -> HipBuilder:
