@@ -512,6 +512,13 @@ static inline unsigned grid_for(uint64_t items, uint64_t per_block) {
   if (g == 0) g = 1;
   return (unsigned)std::min<uint64_t>(g, 0x7fffffffull);
 }
+// block count -> grid; a second dimension keeps every launch under HIP's 2^32-thread limit
+static inline dim3 grid2d(uint64_t items, uint64_t per_block) {
+  uint64_t g = (items + per_block - 1) / per_block;
+  if (g == 0) g = 1;
+  const uint64_t gx = std::min<uint64_t>(g, 1ull << 22);
+  return dim3((unsigned)gx, (unsigned)((g + gx - 1) / gx));
+}
 static inline unsigned grid_stride(uint64_t items) {
   // memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8
   return (unsigned)std::min<uint64_t>(std::max<uint64_t>((items + kBlock - 1) / kBlock, 1), 256 * 16);
@@ -727,10 +734,10 @@ static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_byt
     constexpr int NP = decltype(np_)::value;                                                       \
     if ((COUNT) >= ((uint64_t)(UU) << kStrideShift)) {                                             \
       if (use_nt(s))                                                                               \
-        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP, E>), dim3(grid_for((COUNT), kBlock * (UU))), \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP, E>), grid2d((COUNT), kBlock * (UU)),       \
                            dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
       else                                                                                         \
-        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP, E>), dim3(grid_for((COUNT), kBlock * (UU))), \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP, E>), grid2d((COUNT), kBlock * (UU)),      \
                            dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
     } else {                                                                                       \
       hipLaunchKernelGGL((KERNEL<T, 1, true, false, NP, E>), dim3(grid_for((COUNT), kBlock)),     \

@@ -160,7 +160,8 @@ constexpr int kStrideShift = 11;  // 2^11 work items x 16 B = 32 KiB between a l
 
 template <int LOGU> __device__ __forceinline__ uint64_t work_index(uint32_t u) {
   constexpr int S = kStrideShift - 8;  // kBlock = 2^8
-  const uint64_t blk = blockIdx.x;
+  // 2-D grids only exist because HIP caps a launch at 2^32 threads (n = 33 with U = 2 would need exactly that)
+  const uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   return ((blk >> S) << (kStrideShift + LOGU)) | ((uint64_t)u << kStrideShift) |
          ((blk & ((1u << S) - 1u)) << 8) | threadIdx.x;
 }
