@@ -626,6 +626,37 @@ def test_lds_tile_multi_gate_sweeps(O, n):
         assert np.array_equal(st.download(), want)  # and bit-equal to the oracle itself
 
 
+def test_lds_tile_sweeps_complex64_and_programs(O):
+    """tile sweeps in f32 (16-KiB tiles) are bit-identical to the f32 gate-by-gate path, and a hipGraph
+    program recorded with tile = 1 replays the same result."""
+    n = 14
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 150, seed=9) + circuits.c3_qft(n)[:60]
+    x = circuits.random_state(n, seed=2, dtype=np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        eager = st.download()
+    with q.HipState(n, np.complex64) as st:
+        st.set_option("tile", 1)
+        st.upload(x)
+        st.apply_ops(ops)
+        assert np.array_equal(st.download(), eager)
+    assert np.max(np.abs(eager - O.apply_ops_in_place(n, ops, x.copy()))) < 1e-4
+    x64 = circuits.random_state(n, seed=2)
+    with q.HipState(n) as st:
+        st.upload(x64)
+        st.apply_ops(ops)
+        eager64 = st.download()
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.upload(x64)
+        prog = st.compile_program(ops)
+        prog.run()
+        assert prog.is_graph
+        assert np.array_equal(st.download(), eager64)
+        prog.close()
+
+
 def test_hipgraph_program_replay(O):
     """A circuit captured into a hipGraph replays bit-identically to eager application (same kernels),
     repeatedly; circuits with an out-of-place op fall back to eager transparently."""

@@ -39,8 +39,28 @@ def main():
                 st.sync()
                 dg = time.perf_counter() - t
                 tag = "" if prog.is_graph else " (eager fallback)"
-                print(f"| {n} | {name} | {1e6*dt/reps:.2f} | {reps/dt:.0f} | {1e6*dg/reps:.2f}{tag} | {reps/dg:.0f} | {by/dg/1e9:.1f} |")
                 prog.close()
+                extra = ""
+                if n >= 11 and op is None:
+                    st.set_option("tile", 1)  # bit-identical multi-gate sweeps, then the same inside a graph
+                    ct = st.compile_ops(ops)
+                    st.apply_compiled(ct)
+                    st.sync()
+                    t = time.perf_counter()
+                    st.apply_compiled(ct)
+                    st.sync()
+                    dtile = time.perf_counter() - t
+                    prog = st.compile_program(ops)
+                    prog.run()
+                    st.sync()
+                    t = time.perf_counter()
+                    prog.run()
+                    st.sync()
+                    dtg = time.perf_counter() - t
+                    extra = f" tile=1: {reps/dtile:.0f} gates/s eager, {reps/dtg:.0f} gates/s as a hipGraph"
+                    prog.close()
+                    st.set_option("tile", 0)
+                print(f"| {n} | {name} | {1e6*dt/reps:.2f} | {reps/dt:.0f} | {1e6*dg/reps:.2f}{tag} | {reps/dg:.0f} | {by/dg/1e9:.1f} |{extra}")
 
 
 if __name__ == "__main__":
