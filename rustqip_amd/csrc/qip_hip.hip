@@ -2009,32 +2009,33 @@ static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p);
 // reference's sequential loop inside the one chunk that crosses zero.
 template <typename T>
 static int soft_measure_t(qip_hip_state* s, const MeasDesc& md, double rand_u01, uint64_t* measured) {
+  // Two device passes: per-chunk sums of |amp|^2, then k_find_crossing inside the chunk(s) that may bring the
+  // running remainder to <= 0.  The host only walks the few thousand chunk sums; no amplitude leaves HBM.
   std::vector<double> sums;
   uint64_t chunk = 0;
   QCHK(chunk_norms<T>(s, &chunk, &sums));
-  T r = (T)rand_u01;
+  QCHK(ensure_partial(s, 2));
+  double r = (double)(T)rand_u01;
   uint64_t measured_indx = 0;
-  bool found = false;
-  for (size_t c = 0; c < sums.size() && !found; ++c) {
-    if ((double)r - sums[c] > 1e-9 * (1.0 + sums[c])) {  // clearly past this chunk
-      r = (T)((double)r - sums[c]);
+  for (size_t c = 0; c < sums.size(); ++c) {
+    if (r - sums[c] > 1e-9 * (1.0 + sums[c])) {  // clearly past this chunk
+      r -= sums[c];
       continue;
     }
     const uint64_t lo = (uint64_t)c * chunk, len = std::min<uint64_t>(chunk, s->namps - lo);
-    std::vector<HostAmp<T>> amps(len);
-    HIPCHK(hipMemcpyAsync(amps.data(), (const char*)s->cur + lo * s->amp_bytes, len * s->amp_bytes,
-                          hipMemcpyDeviceToHost, s->stream));
+    hipLaunchKernelGGL((k_find_crossing<T>), dim3(1), dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur, lo,
+                       len, r, (uint64_t*)s->d_partial);
+    HIPCHK(hipGetLastError());
+    uint64_t res[2];
+    HIPCHK(hipMemcpyAsync(res, s->d_partial, sizeof res, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (uint64_t i = 0; i < len; ++i) {
-      r -= amps[i].re * amps[i].re + amps[i].im * amps[i].im;
-      if (r <= (T)0) {
-        measured_indx = lo + i;
-        found = true;
-        break;
-      }
+    if (res[0] != ~0ull) {
+      measured_indx = res[0];
+      break;
     }
+    memcpy(&r, &res[1], sizeof r);  // the chunk was scanned without crossing: carry its exact remainder on
   }
-  // not found: the reference leaves measured_indx = 0 (:166)
+  // never crossing: the reference leaves measured_indx = 0 (:166)
   uint64_t m = 0;
   for (uint32_t i = 0; i < md.k; ++i) m |= ((measured_indx >> md.mpos[i]) & 1ull) << i;
   *measured = m;

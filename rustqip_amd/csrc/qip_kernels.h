@@ -1114,6 +1114,74 @@ __global__ __launch_bounds__(kBlock) void k_chunk_norms(const amp_t<T>* __restri
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// soft_measure's sequential scan (measurement_ops.rs:167-173) inside ONE chunk: find the first index at
+// which r - sum_{j<=i} |amp_j|^2 <= 0.  One block: every lane sums its contiguous segment, lane 0 walks the
+// 256 segment sums to the segment that crosses zero, that lane replays the sequential subtraction.
+// result[0] = index (or ~0 when the chunk never crosses), result[1] = bits of the remaining r (double).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_find_crossing(const amp_t<T>* __restrict__ st, uint64_t lo,
+                                                          uint64_t len, double r0, uint64_t* __restrict__ result) {
+  __shared__ double seg_sum[kBlock];
+  __shared__ int owner;
+  const uint64_t seg = (len + kBlock - 1) / kBlock;
+  const uint64_t a = lo + (uint64_t)threadIdx.x * seg;
+  const uint64_t b = a + seg < lo + len ? a + seg : lo + len;
+  T acc = 0;
+  for (uint64_t i = a; i < b; ++i) {
+    const amp_t<T> x = st[i];
+    acc += x.x * x.x + x.y * x.y;
+  }
+  seg_sum[threadIdx.x] = (double)acc;
+  __shared__ double r_cur;
+  __shared__ unsigned long long found_at;
+  if (threadIdx.x == 0) {
+    r_cur = r0;
+    found_at = ~0ull;
+    owner = -1;
+  }
+  __syncthreads();
+  int start = 0;
+  while (true) {
+    if (threadIdx.x == 0) {
+      // walk the segment sums from `start`; a segment that may bring r to <= 0 (with a rounding margin)
+      // is scanned element by element by the lane that owns it
+      double r = r_cur;
+      owner = -1;
+      for (int t = start; t < kBlock; ++t) {
+        if (r - seg_sum[t] <= 1e-9 * (1.0 + seg_sum[t])) {
+          owner = t;
+          break;
+        }
+        r -= seg_sum[t];
+      }
+      r_cur = r;
+    }
+    __syncthreads();
+    const int own = owner;
+    if (own < 0) break;
+    if ((int)threadIdx.x == own) {
+      T r = (T)r_cur;
+      for (uint64_t i = a; i < b; ++i) {
+        const amp_t<T> x = st[i];
+        r -= x.x * x.x + x.y * x.y;  // same running subtraction, same precision as the reference
+        if (r <= (T)0) {
+          found_at = i;
+          break;
+        }
+      }
+      r_cur = (double)r;
+    }
+    __syncthreads();
+    if (found_at != ~0ull) break;
+    start = own + 1;  // the margin case: the segment came close but did not cross; carry on after it
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    result[0] = found_at;
+    result[1] = (uint64_t)__double_as_longlong(r_cur);
+  }
+}
+
 // measure_state (measurement_ops.rs:220-269): zero what disagrees with the outcome,
 // scale the rest by 1/sqrt(p) (Complex * real = (re*p, im*p)).
 template <typename T>
