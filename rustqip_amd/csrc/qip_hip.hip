@@ -1499,12 +1499,15 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       bits = merged;
     }
     close_pass((uint32_t)gates.size());
-    if (use_nt(s))
-      hipLaunchKernelGGL((k_tile_passes<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
-                         (amp_t<T>*)s->cur, ins, pd, dg);
-    else
-      hipLaunchKernelGGL((k_tile_passes<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
-                         (amp_t<T>*)s->cur, ins, pd, dg);
+    const bool fma = s->tile >= 2;  // only the reordering mode, which is not held to IEEE equality anyway
+#define TP(NTV, FMAV) hipLaunchKernelGGL((k_tile_passes<T, NTV, FMAV>), dim3((unsigned)ntiles), dim3(kBlock), lds, \
+                                         s->stream, (amp_t<T>*)s->cur, ins, pd, dg)
+    if (use_nt(s)) {
+      if (fma) TP(true, true); else TP(true, false);
+    } else {
+      if (fma) TP(false, true); else TP(false, false);
+    }
+#undef TP
   } else if (use_nt(s)) {
     hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
                        (amp_t<T>*)s->cur, ins, d, dg);

@@ -741,12 +741,45 @@ struct TilePassDesc {
   TilePass pass[kTileMaxPasses];
 };
 
-template <typename T>
+// FMA = false: the unfused arithmetic of the gate-by-gate kernels (products and sums rounded separately, zero
+// entries skipped) — what keeps circuit-order tile sweeps IEEE-equal to them.  FMA = true (tile = 2 only, which
+// is held to the 1e-12 bar anyway): explicit fused multiply-adds, about half the f64 instructions; inside a tile
+// sweep the quarter-rate f64 VALU is the limit, so this is where the time goes.
+template <typename T, bool FMA>
+__device__ __forceinline__ amp_t<T> tile_cmul(amp_t<T> m, amp_t<T> x) {
+  if constexpr (FMA) {
+    amp_t<T> r;
+    r.x = __builtin_fma(-m.y, x.y, m.x * x.x);
+    r.y = __builtin_fma(m.y, x.x, m.x * x.y);
+    return r;
+  } else {
+    return cmul(m, x);
+  }
+}
+
+template <typename T, bool FMA>
 __device__ __forceinline__ void tile_pair(const TileGate<T>& g, amp_t<T> a0, amp_t<T> a1, amp_t<T>* r0, amp_t<T>* r1) {
   using A = amp_t<T>;
   if (g.b1 & 2u) {  // X: pure exchange
     *r0 = a1;
     *r1 = a0;
+    return;
+  }
+  if constexpr (FMA) {
+    A s0, s1;
+    if (g.b1 & 1u) {  // real entries
+      s0.x = __builtin_fma(g.m[1].x, a1.x, g.m[0].x * a0.x);
+      s0.y = __builtin_fma(g.m[1].x, a1.y, g.m[0].x * a0.y);
+      s1.x = __builtin_fma(g.m[3].x, a1.x, g.m[2].x * a0.x);
+      s1.y = __builtin_fma(g.m[3].x, a1.y, g.m[2].x * a0.y);
+    } else {
+      s0.x = __builtin_fma(-g.m[1].y, a1.y, __builtin_fma(g.m[1].x, a1.x, __builtin_fma(-g.m[0].y, a0.y, g.m[0].x * a0.x)));
+      s0.y = __builtin_fma(g.m[1].y, a1.x, __builtin_fma(g.m[1].x, a1.y, __builtin_fma(g.m[0].y, a0.x, g.m[0].x * a0.y)));
+      s1.x = __builtin_fma(-g.m[3].y, a1.y, __builtin_fma(g.m[3].x, a1.x, __builtin_fma(-g.m[2].y, a0.y, g.m[2].x * a0.x)));
+      s1.y = __builtin_fma(g.m[3].y, a1.x, __builtin_fma(g.m[3].x, a1.y, __builtin_fma(g.m[2].y, a0.x, g.m[2].x * a0.y)));
+    }
+    *r0 = s0;
+    *r1 = s1;
     return;
   }
   A s0 = czero<A>(), s1 = czero<A>();
@@ -765,7 +798,7 @@ __device__ __forceinline__ void tile_pair(const TileGate<T>& g, amp_t<T> a0, amp
   *r1 = s1;
 }
 
-template <typename T, int J>
+template <typename T, int J, bool FMA>
 __device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
   using A = amp_t<T>;
 #pragma unroll
@@ -774,7 +807,7 @@ __device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> 
     const int k = i | (1 << J);
     const A a0 = e[i], a1 = e[k];
     A r0, r1;
-    tile_pair<T>(g, a0, a1, &r0, &r1);
+    tile_pair<T, FMA>(g, a0, a1, &r0, &r1);
     const bool hit = (te[i] & g.cmask) == g.cmask;
     e[i] = hit ? r0 : a0;
     e[k] = hit ? r1 : a1;
@@ -795,7 +828,7 @@ __device__ __forceinline__ void pass_swap(const TileGate<T>& g, amp_t<T> (&e)[8]
   }
 }
 
-template <typename T, bool NT>
+template <typename T, bool NT, bool FMA>
 __global__ __launch_bounds__(kBlock) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
                                                         const TileGate<T>* __restrict__ gates) {
   using A = amp_t<T>;
@@ -848,14 +881,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_passes(amp_t<T>* __restrict__ s
           const A f = one ? g.m[1] : g.m[0];
           const bool unit = f.x == (T)1 && f.y == (T)0;
           const bool hit = (te[i] & g.cmask) == g.cmask && !unit;
-          const A y = cmul(f, e[i]);
+          const A y = tile_cmul<T, FMA>(f, e[i]);
           e[i] = hit ? y : e[i];
         }
       } else if (g.kind == 0) {
         // which of the pass's three bits is the target
-        if (g.b0 == ps.pb[0]) pass_butterflies<T, 0>(g, e, te);
-        else if (g.b0 == ps.pb[1]) pass_butterflies<T, 1>(g, e, te);
-        else pass_butterflies<T, 2>(g, e, te);
+        if (g.b0 == ps.pb[0]) pass_butterflies<T, 0, FMA>(g, e, te);
+        else if (g.b0 == ps.pb[1]) pass_butterflies<T, 1, FMA>(g, e, te);
+        else pass_butterflies<T, 2, FMA>(g, e, te);
       } else {
         const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
         const bool b1 = g.b1 == ps.pb[1];
