@@ -1348,13 +1348,17 @@ static int apply_ops_fused(qip_hip_state* s, const qip_op* ops, uint64_t count, 
 // LDS-resident multi-gate sweeps (option "tile"): the scheduler cuts the circuit into segments whose
 // gates all live on index bits 0..5 plus five freely chosen higher bits, and k_tile_gates applies a whole
 // segment with one read and one write of the vector.
-//   tile = 1  segments are consecutive runs of the circuit: same per-amplitude operation order as the
-//             gate-by-gate path, hence bit-identical results;
-//   tile = 2  a gate may also be hoisted over skipped gates it shares no qubit with (they commute), which
-//             packs segments better; equal to the reference up to rounding (1e-12 bar).
+//   tile = 1  circuit order up to EXACT commutations (a rounding-free gate — X, CNOT, SWAP, Z, S ... — may pass
+//             gates on other qubits and vice versa): every amplitude sees the same rounded operations in the
+//             same order as in the gate-by-gate path, hence IEEE-equal results;
+//   tile = 2  any gate may be hoisted over skipped gates it shares no qubit with, and the kernel uses explicit
+//             FMAs; equal to the reference up to rounding (1e-12 bar).
 // ---------------------------------------------------------------------------------------
 struct TileItem {
   bool tileable = false;
+  // every matrix entry is in {0, +-1, +-i}: the gate moves / negates / rotates amplitudes by 90 degrees without
+  // any rounding, so it commutes with gates on other qubits EXACTLY (IEEE ==), not just mathematically
+  bool exact = false;
   int kind = 0;                 // TileGate kind
   std::vector<uint32_t> pos;    // every involved bit position
   uint32_t t0 = 0, t1 = 0;      // target position(s)
@@ -1375,12 +1379,19 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
   it->cpos = p.cpos;
   if (!f.distinct) return QIP_OK;
   const uint32_t k = (uint32_t)p.opos.size();
+  auto unit_axis = [](double re, double im) {  // 0, +-1 or +-i
+    return (re == 0.0 && (im == 0.0 || im == 1.0 || im == -1.0)) || (im == 0.0 && (re == 1.0 || re == -1.0));
+  };
   if (p.cls == KC_GATE1Q_PAIR) {
     it->kind = 0;
     it->t0 = p.opos[0];
     memcpy(it->m, p.m, sizeof it->m);
     it->nz = p.nz;
     it->tileable = true;
+    it->exact = true;
+    for (int e = 0; e < 4; ++e) it->exact = it->exact && unit_axis(p.m[2 * e], p.m[2 * e + 1]);
+    // at most one non-zero entry per row, else the row is a sum of two terms (rounded)
+    it->exact = it->exact && !((p.nz & 1u) && (p.nz & 2u)) && !((p.nz & 4u) && (p.nz & 8u));
   } else if (p.cls == KC_PHASE && k == 1) {
     it->kind = 1;
     it->t0 = p.opos[0];
@@ -1390,16 +1401,21 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
     it->m[2] = on_one ? p.phase[0] : 1.0;
     it->m[3] = on_one ? p.phase[1] : 0.0;
     it->tileable = true;
+    it->exact = unit_axis(p.phase[0], p.phase[1]);
   } else if (p.cls == KC_DIAG && k == 1) {
     it->kind = 1;
     it->t0 = p.opos[0];
     for (int e = 0; e < 4; ++e) it->m[e] = p.table[e];
     it->tileable = true;
+    it->exact = unit_axis(p.table[0], p.table[1]) && unit_axis(p.table[2], p.table[3]);
   } else if (p.cls == KC_SWAP_BITS && k == 2) {
     it->kind = 2;
     it->t0 = std::min(p.opos[0], p.opos[1]);
     it->t1 = std::max(p.opos[0], p.opos[1]);
     it->tileable = true;
+    it->exact = true;
+  } else if (p.cls == KC_NOOP) {
+    it->exact = true;  // identity: nothing happens (not tileable, launches nothing)
   }
   return QIP_OK;
 }
@@ -1473,15 +1489,68 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     for (int j = 0; j < kTileHigh; ++j) pd.hpos[j] = high[j];
     std::vector<uint32_t> bits;
     uint32_t first = 0;
+    constexpr uint32_t S = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // swizzle fold width, see TilePass
+    bool pass_layout_ok = true;
     auto close_pass = [&](uint32_t end) {
       std::vector<uint32_t> b = bits;
-      for (uint32_t t = 0; b.size() < 3 && t < (uint32_t)kTileBits; ++t)
-        if (std::find(b.begin(), b.end(), t) == b.end()) b.push_back(t);
+      auto has = [&](uint32_t t) { return std::find(b.begin(), b.end(), t) != b.end(); };
+      // pad to three bits from the top, never completing a pair (t, t +- S): such a pass would be 2-way
+      // bank-conflicted, and low pad bits are what made the linear layout 8-way
+      for (int relax = 0; relax < 2 && b.size() < 3; ++relax)
+        for (int t = kTileBits - 1; t >= 0 && b.size() < 3; --t) {
+          if (has((uint32_t)t)) continue;
+          const bool pairs = has((uint32_t)t + S) || (t >= (int)S && has((uint32_t)t - S));
+          if (pairs && relax == 0) continue;
+          b.push_back((uint32_t)t);
+        }
       std::sort(b.begin(), b.end());
       TilePass& ps = pd.pass[pd.npasses++];
       ps.first = first;
       ps.count = end - first;
       for (int j = 0; j < 3; ++j) ps.pb[j] = b[j];
+      // lane-id bit -> tile bit: lane bit j < S goes on bit j or j + S (whichever is not a pass bit), so the S
+      // swizzled slot bits enumerate the lanes of a bank group; the other lane bits fill what is left, bits
+      // that are not folded (>= 2S) first, then partners of the pairs that hold lane bits 0 and 1 (lane bit 4
+      // varies inside a ds_read_b128 group in a pattern that is closed under flipping lane bits 0 / 1 only)
+      int pos_of[8];
+      for (int k = 0; k < 8; ++k) pos_of[k] = -1;
+      bool used[kTileBits] = {false};
+      std::vector<int> rest_bits;
+      for (uint32_t j = 0; j < S; ++j) {
+        int where = -1;
+        for (uint32_t c : {j, j + S})
+          if (c < (uint32_t)kTileBits && !has(c) && !used[c]) {
+            where = (int)c;
+            break;
+          }
+        if (where >= 0) {
+          pos_of[j] = where;
+          used[where] = true;
+        } else {
+          rest_bits.push_back((int)j);
+        }
+      }
+      for (int k = (int)S; k < 8; ++k) rest_bits.push_back(k);
+      std::vector<int> rest_pos;
+      for (int t = 0; t < kTileBits; ++t)
+        if (!has((uint32_t)t) && !used[t]) rest_pos.push_back(t);
+      auto rank = [&](int t) {
+        if (t >= (int)(2 * S)) return 0;
+        const int j = t >= (int)S ? t - (int)S : t;
+        for (int k = 0; k < 2; ++k)
+          if (pos_of[k] == j || pos_of[k] == j + (int)S) return 1;
+        return 2;
+      };
+      std::stable_sort(rest_pos.begin(), rest_pos.end(), [&](int x, int y) { return rank(x) < rank(y); });
+      for (size_t q = 0; q < rest_bits.size(); ++q) pos_of[rest_bits[q]] = rest_pos[q];
+      ps.lanepos = 0;
+      uint32_t covered = 0;
+      for (int k = 0; k < 8; ++k) {
+        ps.lanepos |= (uint32_t)pos_of[k] << (4 * k);
+        covered |= 1u << pos_of[k];
+      }
+      for (int j = 0; j < 3; ++j) covered |= 1u << b[j];
+      if (covered != (1u << kTileBits) - 1u) pass_layout_ok = false;  // not a bijection: refuse to launch
       first = end;
       bits.clear();
     };
@@ -1499,6 +1568,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       bits = merged;
     }
     close_pass((uint32_t)gates.size());
+    if (!pass_layout_ok) return fail(QIP_ERR_UNSUPPORTED, "tile pass: lane-bit assignment is not a bijection (internal error)");
     const bool fma = s->tile >= 2;  // only the reordering mode, which is not held to IEEE equality anyway
 #define TP(NTV, FMAV) hipLaunchKernelGGL((k_tile_passes<T, NTV, FMAV>), dim3((unsigned)ntiles), dim3(kBlock), lds, \
                                          s->stream, (amp_t<T>*)s->cur, ins, pd, dg)
@@ -1528,8 +1598,8 @@ struct TileStep {
 };
 
 // Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
-// qip_hip_plan_tiles: every op appears in exactly one step; without reorder the concatenation of the steps
-// is the circuit itself; with reorder an op only overtakes ops it shares no qubit with.
+// qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it shares no qubit with;
+// without `reorder` it does so only when it, or every op it overtakes, is rounding-free.
 static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
                           std::vector<TileItem>* items_out, std::vector<TileStep>* steps) {
   std::vector<TileItem>& items = *items_out;
@@ -1543,7 +1613,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
   }
   std::vector<char> done(count, 0);
   uint64_t head = 0;
-  const uint64_t window = reorder ? 256 : 0;
+  const uint64_t window = 256;
   while (head < count) {
     if (done[head]) {
       ++head;
@@ -1554,16 +1624,21 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       done[head++] = 1;
       continue;
     }
-    // grow a segment from `head`
+    // Grow a segment from `head`, scanning ahead.  A later gate may join over the gates skipped so far only if
+    // it shares no qubit with any of them (they commute) and, unless `reorder` (which accepts rounding-level
+    // differences), the commutation is EXACT: the gate itself, or every skipped gate, is rounding-free
+    // (entries in {0, +-1, +-i}: X, Y, Z, S, CNOT, CZ, Toffoli, SWAP ...).  Exact commutations leave every
+    // amplitude's sequence of rounded operations unchanged, so the result stays IEEE-equal to circuit order.
     TileStep st;
-    uint64_t blocked = 0;  // bit positions of gates skipped so far (later gates must not touch them)
+    uint64_t blocked = 0;          // bit positions of gates skipped so far
+    bool skipped_inexact = false;  // some skipped gate rounds
     bool any_skipped = false;
     for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && st.ops.size() < (size_t)kTileMaxGates; ++i) {
       if (done[i]) continue;
       const TileItem& it = items[i];
       uint64_t mask = 0;
       for (uint32_t p : it.pos) mask |= 1ull << p;
-      bool fits = it.tileable && !(mask & blocked);
+      bool fits = it.tileable && !(mask & blocked) && (reorder || it.exact || !skipped_inexact);
       std::vector<uint32_t> need;
       if (fits) {
         // only bits the gate exchanges amplitudes across must be tile bits: a dense target, both swap bits;
@@ -1582,8 +1657,8 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         st.ops.push_back(i);
         done[i] = 1;
       } else {
-        if (!reorder) break;  // strict: segments are consecutive runs of the circuit
         blocked |= mask;
+        skipped_inexact = skipped_inexact || !it.exact;
         any_skipped = true;
       }
     }

@@ -623,7 +623,7 @@ template <typename T> struct TileGate {
                       //   bit 0: every matrix entry is real  -> 2 multiplies per product instead of 4 mul + 2 add
                       //   bit 1: the gate is X ([0,1;1,0])   -> the pair is exchanged, no arithmetic
                       // both give IEEE-equal results for finite amplitudes (x*1 == x, a - 0*b == a); inside a
-                      // tile sweep the f64 VALU (quarter rate), not HBM, is the limit, so flops matter here
+                      // tile sweep VALU issue, not HBM, is the limit, so instructions matter here
   uint32_t cmask;     // tile-index bits that must all be 1 (controls inside the tile)
   uint32_t nz;        // kind 0: non-zero mask of the 2x2 entries
   uint32_t tpos_out;  // kind 1 with b0 == kTileOutside: amplitude-index position of the target
@@ -641,7 +641,7 @@ struct TileDesc {
 // the 256-gate circuit at n = 30 (22 segments, ~11.6 gates per sweep): this form 9.3 ms per sweep = 1256
 // gates/s; persistent blocks software-pipelined over tiles (next tile's loads in flight during the LDS phase)
 // 11.1 ms; tile held in registers with lane-shuffle / LDS exchange classes 14 ms (each element then evaluates
-// its own matrix row: twice the quarter-rate f64 multiplies); a third register-to-register class: 344 VGPRs,
+// its own matrix row: twice the f64 multiplies); a third register-to-register class: 344 VGPRs,
 // 3.6x slower.
 template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st, Ins ins, TileDesc d,
@@ -730,10 +730,25 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
 // butterflies for dense gates, element-wise factors for diagonal gates, register permutations for swaps —
 // and barriers only at pass boundaries.  Per element the operations and their order are those of the
 // gate-by-gate path, so circuit-order segments stay bit-identical.
+//
+// LDS banking (MI355X_MICROARCH.md §LDS): a 16-byte ds_read_b128 is served in four 16-lane groups over 16 slots
+// of 16 B, a ds_write_b128 in eight 8-lane groups over 8 slots; lanes of a group that hit one slot at different
+// addresses serialise.  With the tile stored linearly a pass on the low bits {0,1,2} makes every lane of a group
+// hit the same slot (8-way: the LDS phase then costs more than the HBM phase).  Two measures make every pass
+// conflict-free unless it holds both bits of a pair (j, j+S) (then 2-way):
+//   * the tile is stored swizzled, slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 for 16-byte amplitudes (5 for
+//     8-byte ones, whose reads are served in 32-lane groups over 32 slots);
+//   * the host chooses, per pass, which lane-id bit fills which non-pass tile bit (`lanepos`), putting lane bit
+//     j < S on bit j or j+S so the low S slot bits enumerate the lanes of a group.
 struct TilePass {
   uint32_t first, count;  // gates[first .. first+count)
   uint32_t pb[3];         // the pass's three exchange bits (tile-index space, distinct, ascending)
+  uint32_t lanepos;       // nibble k = tile-index bit filled by bit k of the lane id (the 8 non-pass bits)
 };
+template <typename A> __device__ __forceinline__ uint32_t tile_slot(uint32_t t) {
+  constexpr uint32_t S = sizeof(A) == 16 ? 4u : 5u;
+  return t ^ ((t >> S) & ((1u << S) - 1u));
+}
 constexpr int kTileMaxPasses = 24;
 struct TilePassDesc {
   uint32_t npasses;
@@ -743,8 +758,25 @@ struct TilePassDesc {
 
 // FMA = false: the unfused arithmetic of the gate-by-gate kernels (products and sums rounded separately, zero
 // entries skipped) — what keeps circuit-order tile sweeps IEEE-equal to them.  FMA = true (tile = 2 only, which
-// is held to the 1e-12 bar anyway): explicit fused multiply-adds, about half the f64 instructions; inside a tile
-// sweep the quarter-rate f64 VALU is the limit, so this is where the time goes.
+// is held to the 1e-12 bar anyway): explicit fused multiply-adds, about half the f64 instructions.
+//
+// The sweep is VALU-issue bound, not LDS or HBM bound (rocprofv3 PMC, profiles/r01_tile_pmc.md: SQ_INSTS_VALU x 4
+// cycles / 1024 SIMDs = 83 % of the kernel's cycles, LDS array 4 %), so the gate loop is written to issue as
+// few vector instructions as possible:
+//   * a control on a pass bit is wave-uniform per register element (scalar branch), a control on a lane bit is
+//     one predicate per gate and the update runs under the EXEC mask — no per-element v_cndmask selects;
+//   * a diagonal gate whose target is a pass bit has a wave-uniform factor per element (unit factors skipped by
+//     a scalar branch); on a lane bit the factor is selected once per gate, not per element;
+//   * X is a register exchange; gates with real entries multiply two reals per product;
+//   * the reference's leading "0 +" of every row sum is dropped: 0 + p == p under IEEE == (it only turns a -0
+//     into +0), the same equality the X and real-entry forms rely on;
+//   * global addresses are a wave-uniform base plus the lane id.
+// Wave-uniform conditions in the gate loop must stay BRANCHES.  Left alone the compiler if-converts the small
+// conditional bodies: it computes every element's update speculatively and blends with v_cndmask on the scalar
+// condition — more vector instructions and ~100 more live registers (spills at five waves per SIMD).  An empty
+// volatile asm cannot be speculated, so a block that contains one keeps its branch.
+#define QIP_KEEP_BRANCH() asm volatile("")
+
 template <typename T, bool FMA>
 __device__ __forceinline__ amp_t<T> tile_cmul(amp_t<T> m, amp_t<T> x) {
   if constexpr (FMA) {
@@ -757,159 +789,234 @@ __device__ __forceinline__ amp_t<T> tile_cmul(amp_t<T> m, amp_t<T> x) {
   }
 }
 
-template <typename T, bool FMA>
-__device__ __forceinline__ void tile_pair(const TileGate<T>& g, amp_t<T> a0, amp_t<T> a1, amp_t<T>* r0, amp_t<T>* r1) {
-  using A = amp_t<T>;
-  if (g.b1 & 2u) {  // X: pure exchange
-    *r0 = a1;
-    *r1 = a0;
-    return;
-  }
-  if constexpr (FMA) {
-    A s0, s1;
-    if (g.b1 & 1u) {  // real entries
-      s0.x = __builtin_fma(g.m[1].x, a1.x, g.m[0].x * a0.x);
-      s0.y = __builtin_fma(g.m[1].x, a1.y, g.m[0].x * a0.y);
-      s1.x = __builtin_fma(g.m[3].x, a1.x, g.m[2].x * a0.x);
-      s1.y = __builtin_fma(g.m[3].x, a1.y, g.m[2].x * a0.y);
-    } else {
-      s0.x = __builtin_fma(-g.m[1].y, a1.y, __builtin_fma(g.m[1].x, a1.x, __builtin_fma(-g.m[0].y, a0.y, g.m[0].x * a0.x)));
-      s0.y = __builtin_fma(g.m[1].y, a1.x, __builtin_fma(g.m[1].x, a1.y, __builtin_fma(g.m[0].y, a0.x, g.m[0].x * a0.y)));
-      s1.x = __builtin_fma(-g.m[3].y, a1.y, __builtin_fma(g.m[3].x, a1.x, __builtin_fma(-g.m[2].y, a0.y, g.m[2].x * a0.x)));
-      s1.y = __builtin_fma(g.m[3].y, a1.x, __builtin_fma(g.m[3].x, a1.y, __builtin_fma(g.m[2].y, a0.x, g.m[2].x * a0.y)));
-    }
-    *r0 = s0;
-    *r1 = s1;
-    return;
-  }
-  A s0 = czero<A>(), s1 = czero<A>();
-  if (g.b1 & 1u) {  // real entries: (m, 0) * (x, y) = (m*x, m*y)
-    if (g.nz & 1u) { A t; t.x = g.m[0].x * a0.x; t.y = g.m[0].x * a0.y; s0 = cadd(s0, t); }
-    if (g.nz & 2u) { A t; t.x = g.m[1].x * a1.x; t.y = g.m[1].x * a1.y; s0 = cadd(s0, t); }
-    if (g.nz & 4u) { A t; t.x = g.m[2].x * a0.x; t.y = g.m[2].x * a0.y; s1 = cadd(s1, t); }
-    if (g.nz & 8u) { A t; t.x = g.m[3].x * a1.x; t.y = g.m[3].x * a1.y; s1 = cadd(s1, t); }
-  } else {
-    if (g.nz & 1u) s0 = cadd(s0, cmul(g.m[0], a0));
-    if (g.nz & 2u) s0 = cadd(s0, cmul(g.m[1], a1));
-    if (g.nz & 4u) s1 = cadd(s1, cmul(g.m[2], a0));
-    if (g.nz & 8u) s1 = cadd(s1, cmul(g.m[3], a1));
-  }
-  *r0 = s0;
-  *r1 = s1;
+// (re, 0) * x
+template <typename T> __device__ __forceinline__ amp_t<T> tile_rmul(T m, amp_t<T> x) {
+  amp_t<T> r;
+  r.x = m * x.x;
+  r.y = m * x.y;
+  return r;
 }
 
-template <typename T, int J, bool FMA>
-__device__ __forceinline__ void pass_butterflies(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
+// one row of a 2x2 gate applied to the pair (a0, a1); `REAL`: every entry has a zero imaginary part
+template <typename T, bool FMA, bool REAL>
+__device__ __forceinline__ amp_t<T> tile_row(amp_t<T> ma, amp_t<T> mb, bool has_a, bool has_b, amp_t<T> a0, amp_t<T> a1) {
   using A = amp_t<T>;
+  if constexpr (FMA) {  // zero entries ride along: exact for finite amplitudes, and this mode is held to 1e-12
+    A r;
+    if constexpr (REAL) {
+      r.x = __builtin_fma(mb.x, a1.x, ma.x * a0.x);
+      r.y = __builtin_fma(mb.x, a1.y, ma.x * a0.y);
+    } else {
+      r.x = __builtin_fma(-mb.y, a1.y, __builtin_fma(mb.x, a1.x, __builtin_fma(-ma.y, a0.y, ma.x * a0.x)));
+      r.y = __builtin_fma(mb.y, a1.x, __builtin_fma(mb.x, a1.y, __builtin_fma(ma.y, a0.x, ma.x * a0.y)));
+    }
+    return r;
+  } else {
+    auto prod = [](A m, A x) {
+      if constexpr (REAL) return tile_rmul<T>(m.x, x);
+      else return cmul(m, x);
+    };
+    if (has_a && has_b) return cadd(prod(ma, a0), prod(mb, a1));
+    if (has_a) return prod(ma, a0);
+    if (has_b) return prod(mb, a1);
+    return czero<A>();
+  }
+}
+
+// dense 1-qubit gate on pass bit J: four register butterflies.  c[i] = the pass-bit part of element i's tile
+// index (wave-uniform), cm = the gate's controls that sit on pass bits.  The common shapes (no control on a pass
+// bit, all four entries non-zero) run as straight-line code; every test below is wave-uniform.
+template <typename T, int J, bool FMA, bool REAL, bool CHECKED>
+__device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+  using A = amp_t<T>;
+  const bool h0 = CHECKED ? (g.nz & 1u) != 0 : true, h1 = CHECKED ? (g.nz & 2u) != 0 : true;
+  const bool h2 = CHECKED ? (g.nz & 4u) != 0 : true, h3 = CHECKED ? (g.nz & 8u) != 0 : true;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if ((i >> J) & 1) continue;
     const int k = i | (1 << J);
+    if constexpr (CHECKED) {
+      if ((c[i] & cm) != cm) continue;  // a control on another pass bit is 0 for this pair
+      QIP_KEEP_BRANCH();
+    }
     const A a0 = e[i], a1 = e[k];
-    A r0, r1;
-    tile_pair<T, FMA>(g, a0, a1, &r0, &r1);
-    const bool hit = (te[i] & g.cmask) == g.cmask;
-    e[i] = hit ? r0 : a0;
-    e[k] = hit ? r1 : a1;
+    e[i] = tile_row<T, FMA, REAL>(g.m[0], g.m[1], h0, h1, a0, a1);
+    e[k] = tile_row<T, FMA, REAL>(g.m[2], g.m[3], h2, h3, a0, a1);
+    __builtin_amdgcn_sched_barrier(0);  // one butterfly at a time: interleaving them only costs registers
+  }
+}
+
+template <typename T, int J, bool FMA>
+__device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+  using A = amp_t<T>;
+  const bool is_x = (g.b1 & 2u) != 0, real = (g.b1 & 1u) != 0;
+  if (is_x) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((i >> J) & 1) continue;
+      const int k = i | (1 << J);
+      if ((c[i] & cm) != cm) continue;
+      QIP_KEEP_BRANCH();
+      const A a0 = e[i];
+      e[i] = e[k];
+      e[k] = a0;
+    }
+    return;
+  }
+  const bool plain = cm == 0u && (FMA || g.nz == 15u);
+  if (plain) {
+    if (real) pass_dense_body<T, J, FMA, true, false>(g, e, c, cm);
+    else pass_dense_body<T, J, FMA, false, false>(g, e, c, cm);
+  } else {
+    if (real) pass_dense_body<T, J, FMA, true, true>(g, e, c, cm);
+    else pass_dense_body<T, J, FMA, false, true>(g, e, c, cm);
+  }
+}
+
+// diagonal 1-qubit gate whose target is pass bit J: the factor of element i is m[(i >> J) & 1], known at
+// compile time; unit factors (wave-uniform test) leave their four elements untouched
+template <typename T, int J, bool FMA>
+__device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const amp_t<T> f = g.m[half];
+    if (f.x == (T)1 && f.y == (T)0) continue;
+    QIP_KEEP_BRANCH();
+    if (cm == 0u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (((i >> J) & 1) == half) e[i] = tile_cmul<T, FMA>(f, e[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (((i >> J) & 1) == half && (c[i] & cm) == cm) {
+          QIP_KEEP_BRANCH();
+          e[i] = tile_cmul<T, FMA>(f, e[i]);
+        }
+    }
   }
 }
 
 template <typename T, int J0, int J1>
-__device__ __forceinline__ void pass_swap(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&te)[8]) {
+__device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
   using A = amp_t<T>;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (!(((i >> J0) & 1) == 1 && ((i >> J1) & 1) == 0)) continue;  // i has (J0,J1) = (1,0); partner (0,1)
     const int k = (i & ~(1 << J0)) | (1 << J1);
-    const bool hit = (te[i] & g.cmask) == g.cmask;  // controls are not J0/J1, so both elements agree
-    const A a = e[i], b = e[k];
-    e[i] = hit ? b : a;
-    e[k] = hit ? a : b;
+    if ((c[i] & cm) != cm) continue;  // controls are never J0/J1, so both elements agree
+    QIP_KEEP_BRANCH();
+    const A a = e[i];
+    e[i] = e[k];
+    e[k] = a;
   }
 }
 
+// __launch_bounds__(kBlock, 5): five waves per SIMD = the five 32-KiB tiles that fit a CU's LDS.  The sweep is
+// latency-bound per wave (scalar gate fetch -> branch -> short VALU body, per gate), so resident blocks are what
+// hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
+// (f32 keeps the default: its 16-KiB tiles already allow more, and under the bound hipcc 7.2 spills its tile.)
 template <typename T, bool NT, bool FMA>
-__global__ __launch_bounds__(kBlock) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
                                                         const TileGate<T>* __restrict__ gates) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;
-  static_assert(PER == 8, "one 8-element group per lane");
+  static_assert(PER == 8 && kTileLow == 6 && kBlock == 256, "tile index = (u << 8) | (wave << 6) | lane");
   const uint32_t tid = threadIdx.x;
-  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // everything but the lane id is wave-uniform: tile bits 6, 7 = wave id, bits 8..10 = u
+  uint64_t wbase = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  const uint64_t base = wbase;
+  wbase |= (uint64_t)(wave & 1u) << d.hpos[0];
+  wbase |= (uint64_t)((wave >> 1) & 1u) << d.hpos[1];
+  const uint32_t slot_tid = tile_slot<A>(tid);
   {
-    uint64_t idx[PER];
     A x[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const uint32_t t = u * kBlock + tid;
-      const uint32_t h = t >> kTileLow;
-      uint64_t off = t & ((1u << kTileLow) - 1u);
-#pragma unroll
-      for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
-      idx[u] = base | off;
-      x[u] = ldg<NT>(st + idx[u]);
+      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[2]) | ((uint64_t)((u >> 1) & 1) << d.hpos[3]) |
+                          ((uint64_t)((u >> 2) & 1) << d.hpos[4]);
+      x[u] = ldg<NT>(st + ub + lane);
     }
 #pragma unroll
-    for (int u = 0; u < PER; ++u) tile[u * kBlock + tid] = x[u];
+    for (int u = 0; u < PER; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
   }
   __syncthreads();
   for (uint32_t pi = 0; pi < d.npasses; ++pi) {
     const TilePass ps = d.pass[pi];
-    // this lane's group: tid with zeros opened at the three pass bits (ascending), then the 8 combinations
-    uint32_t tb = tid;
+    // this lane's group: the lane id's bits spread over the 8 non-pass tile bits (tb), and the 8 combinations
+    // of the pass bits (c[i], wave-uniform); tb and c[i] have no bit in common, so slot(tb | c) = slot(tb) ^ slot(c)
+    uint32_t tb = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) tb = ((tb >> ps.pb[j]) << (ps.pb[j] + 1)) | (tb & ((1u << ps.pb[j]) - 1u));
-    uint32_t te[8];
+    for (int k = 0; k < 8; ++k) tb |= ((tid >> k) & 1u) << ((ps.lanepos >> (4 * k)) & 15u);
+    const uint32_t slot_tb = tile_slot<A>(tb);
+    const uint32_t passmask = (1u << ps.pb[0]) | (1u << ps.pb[1]) | (1u << ps.pb[2]);
+    uint32_t c[8];
     A e[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      te[i] = tb | ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) |
-              ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
-      e[i] = tile[te[i]];
+      c[i] = ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) |
+             ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+      e[i] = tile[slot_tb ^ tile_slot<A>(c[i])];
     }
     for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
       const TileGate<T> g = gates[gi];  // wave-uniform
       if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
+      const uint32_t cm_reg = g.cmask & passmask;   // controls on pass bits: wave-uniform per element
+      const uint32_t cm_lane = g.cmask & ~passmask;  // controls on lane bits: one predicate per gate
+      const bool lane_ok = (tb & cm_lane) == cm_lane;
       if (g.kind == 1) {
-        const bool out = g.b0 == kTileOutside;
-        const bool out_bit = out && ((base >> g.tpos_out) & 1ull);
+        const bool outside = g.b0 == kTileOutside;
+        if (outside || !((passmask >> g.b0) & 1u)) {
+          // the target bit is the same for the lane's 8 elements: one factor per gate
+          A f;
+          if (outside) f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];
+          else f = ((tb >> g.b0) & 1u) ? g.m[1] : g.m[0];
+          if (lane_ok && !(f.x == (T)1 && f.y == (T)0)) {  // unit entries leave the amplitude untouched
+            if (cm_reg == 0u) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool one = out ? out_bit : (((te[i] >> g.b0) & 1u) != 0);
-          const A f = one ? g.m[1] : g.m[0];
-          const bool unit = f.x == (T)1 && f.y == (T)0;
-          const bool hit = (te[i] & g.cmask) == g.cmask && !unit;
-          const A y = tile_cmul<T, FMA>(f, e[i]);
-          e[i] = hit ? y : e[i];
+              for (int i = 0; i < 8; ++i) e[i] = tile_cmul<T, FMA>(f, e[i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                if ((c[i] & cm_reg) == cm_reg) {
+                  QIP_KEEP_BRANCH();
+                  e[i] = tile_cmul<T, FMA>(f, e[i]);
+                }
+            }
+          }
+        } else if (lane_ok) {
+          if (g.b0 == ps.pb[0]) pass_diag<T, 0, FMA>(g, e, c, cm_reg);
+          else if (g.b0 == ps.pb[1]) pass_diag<T, 1, FMA>(g, e, c, cm_reg);
+          else pass_diag<T, 2, FMA>(g, e, c, cm_reg);
         }
       } else if (g.kind == 0) {
-        // which of the pass's three bits is the target
-        if (g.b0 == ps.pb[0]) pass_butterflies<T, 0, FMA>(g, e, te);
-        else if (g.b0 == ps.pb[1]) pass_butterflies<T, 1, FMA>(g, e, te);
-        else pass_butterflies<T, 2, FMA>(g, e, te);
-      } else {
+        if (lane_ok) {
+          if (g.b0 == ps.pb[0]) pass_dense<T, 0, FMA>(g, e, c, cm_reg);
+          else if (g.b0 == ps.pb[1]) pass_dense<T, 1, FMA>(g, e, c, cm_reg);
+          else pass_dense<T, 2, FMA>(g, e, c, cm_reg);
+        }
+      } else if (lane_ok) {
         const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
         const bool b1 = g.b1 == ps.pb[1];
-        if (a0 && b1) pass_swap<T, 0, 1>(g, e, te);
-        else if (a0) pass_swap<T, 0, 2>(g, e, te);
-        else if (a1) pass_swap<T, 1, 2>(g, e, te);
+        if (a0 && b1) pass_swap<T, 0, 1>(e, c, cm_reg);
+        else if (a0) pass_swap<T, 0, 2>(e, c, cm_reg);
+        else if (a1) pass_swap<T, 1, 2>(e, c, cm_reg);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tile[te[i]] = e[i];
+    for (int i = 0; i < 8; ++i) tile[slot_tb ^ tile_slot<A>(c[i])] = e[i];
     __syncthreads();
   }
   {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const uint32_t t = u * kBlock + tid;
-      const uint32_t h = t >> kTileLow;
-      uint64_t off = t & ((1u << kTileLow) - 1u);
-#pragma unroll
-      for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
-      stg<NT>(st + (base | off), tile[t]);
+      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[2]) | ((uint64_t)((u >> 1) & 1) << d.hpos[3]) |
+                          ((uint64_t)((u >> 2) & 1) << d.hpos[4]);
+      stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)]);
     }
   }
 }

@@ -1,0 +1,58 @@
+"""Time the LDS-resident multi-gate sweeps (option "tile") on the configured circuits.
+
+    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2]
+
+Prints one JSON line per (circuit, mode): sweeps launched, ms per run of the circuit, gates/s, and the
+per-sweep HBM rate (each sweep reads and writes the vector once: 32 * 2^n bytes)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import rustqip_amd as q  # noqa: E402
+from rustqip_amd import circuits  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    cases = {
+        "c2": circuits.c2_random_circuit(n, 256, seed=28),
+        "c4": circuits.c4_clifford_t(n, 256, seed=32),
+        "qft": circuits.c3_qft(n),
+        "grover": circuits.c5_grover_iteration(n),
+    }
+    if len(sys.argv) > 3:
+        cases = {k: v for k, v in cases.items() if k in sys.argv[3].split(",")}
+    modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2]
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(circuits.h_layer(n))
+        for name, ops in cases.items():
+            for mode, passes in [(m, 1) for m in modes]:
+                st.set_option("tile", mode)
+                st.set_option("tile_passes", passes)
+                cops = st.compile_ops(ops)
+                st.set_option("profile", 1)
+                st.profile_reset()
+                st.apply_compiled(cops)
+                st.sync()
+                sweeps = sum(v["launches"] for v in st.profile().values())
+                st.set_option("profile", 0)
+                best = 1e9
+                for _ in range(reps):
+                    st.sync()
+                    t0 = time.perf_counter()
+                    st.apply_compiled(cops)
+                    st.sync()
+                    best = min(best, time.perf_counter() - t0)
+                print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
+                                  "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
+                                  "ms_per_sweep": round(1e3 * best / sweeps, 3),
+                                  "norm": st.norm_sqr()}), flush=True)
+        st.set_option("tile", 0)
+
+
+if __name__ == "__main__":
+    main()
