@@ -1351,8 +1351,8 @@ static int apply_ops_fused(qip_hip_state* s, const qip_op* ops, uint64_t count, 
 //   tile = 1  circuit order up to EXACT commutations (a rounding-free gate — X, CNOT, SWAP, Z, S ... — may pass
 //             gates on other qubits and vice versa): every amplitude sees the same rounded operations in the
 //             same order as in the gate-by-gate path, hence IEEE-equal results;
-//   tile = 2  any gate may be hoisted over skipped gates it shares no qubit with, and the kernel uses explicit
-//             FMAs; equal to the reference up to rounding (1e-12 bar).
+//   tile = 2  any gate may be hoisted over skipped gates it shares no qubit with (they commute mathematically,
+//             not in floating point); equal to the reference up to rounding (1e-12 bar).
 // ---------------------------------------------------------------------------------------
 struct TileItem {
   bool tileable = false;
@@ -1558,9 +1558,21 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       std::vector<uint32_t> add;
       if (gates[i].kind == 0) add = {gates[i].b0};
       if (gates[i].kind == 2) add = {gates[i].b0, gates[i].b1};
-      std::vector<uint32_t> merged = bits;
-      for (uint32_t b : add)
-        if (std::find(merged.begin(), merged.end(), b) == merged.end()) merged.push_back(b);
+      if (!add.empty()) {
+        // a control of a dense gate / swap is a scalar branch on a pass bit but a per-lane select on a lane
+        // bit (k_tile_passes): make the in-tile controls pass bits too whenever the three slots allow
+        std::vector<uint32_t> with_ctl = add;
+        for (uint32_t t = 0; t < (uint32_t)kTileBits; ++t)
+          if ((gates[i].cmask >> t) & 1u) with_ctl.push_back(t);
+        if (with_ctl.size() <= 3) add = with_ctl;
+      }
+      auto merge = [&](const std::vector<uint32_t>& extra) {
+        std::vector<uint32_t> m = bits;
+        for (uint32_t b : extra)
+          if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
+        return m;
+      };
+      std::vector<uint32_t> merged = merge(add);
       if (merged.size() > 3) {
         close_pass(i);
         merged = add;
@@ -1569,14 +1581,10 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     }
     close_pass((uint32_t)gates.size());
     if (!pass_layout_ok) return fail(QIP_ERR_UNSUPPORTED, "tile pass: lane-bit assignment is not a bijection (internal error)");
-    const bool fma = s->tile >= 2;  // only the reordering mode, which is not held to IEEE equality anyway
-#define TP(NTV, FMAV) hipLaunchKernelGGL((k_tile_passes<T, NTV, FMAV>), dim3((unsigned)ntiles), dim3(kBlock), lds, \
-                                         s->stream, (amp_t<T>*)s->cur, ins, pd, dg)
-    if (use_nt(s)) {
-      if (fma) TP(true, true); else TP(true, false);
-    } else {
-      if (fma) TP(false, true); else TP(false, false);
-    }
+#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream, \
+                                   (amp_t<T>*)s->cur, ins, pd, dg)
+    if (use_nt(s)) TP(true);
+    else TP(false);
 #undef TP
   } else if (use_nt(s)) {
     hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,

@@ -756,77 +756,63 @@ struct TilePassDesc {
   TilePass pass[kTileMaxPasses];
 };
 
-// FMA = false: the unfused arithmetic of the gate-by-gate kernels (products and sums rounded separately, zero
-// entries skipped) — what keeps circuit-order tile sweeps IEEE-equal to them.  FMA = true (tile = 2 only, which
-// is held to the 1e-12 bar anyway): explicit fused multiply-adds, about half the f64 instructions.
+// Arithmetic: exactly the unfused products and sums of the gate-by-gate kernels (zero entries skipped), so that
+// circuit-order tile sweeps stay IEEE-equal to them.
 //
-// The sweep is VALU-issue bound, not LDS or HBM bound (rocprofv3 PMC, profiles/r01_tile_pmc.md: SQ_INSTS_VALU x 4
-// cycles / 1024 SIMDs = 83 % of the kernel's cycles, LDS array 4 %), so the gate loop is written to issue as
-// few vector instructions as possible:
-//   * a control on a pass bit is wave-uniform per register element (scalar branch), a control on a lane bit is
-//     one predicate per gate and the update runs under the EXEC mask — no per-element v_cndmask selects;
+// The sweep is bound by vector-instruction issue and per-wave latency, not by LDS or HBM (rocprofv3 PMC,
+// profiles/r01_tile_pmc.md), so the gate loop is written to issue as few vector instructions as possible and to
+// keep five blocks resident per CU:
+//   * a control on a pass bit is wave-uniform per register element (scalar branch); the host makes the controls
+//     of dense gates and swaps pass bits whenever the pass has room, so the dense code has no per-lane predicate
+//     (a divergent `if` around the update makes the compiler keep, and move, two copies of the lane's eight
+//     amplitudes per gate).  What is left — a diagonal gate's lane-bit controls, the rare dense gate with more
+//     controls than a pass holds — folds the predicate into the factor / selects per lane;
 //   * a diagonal gate whose target is a pass bit has a wave-uniform factor per element (unit factors skipped by
 //     a scalar branch); on a lane bit the factor is selected once per gate, not per element;
 //   * X is a register exchange; gates with real entries multiply two reals per product;
 //   * the reference's leading "0 +" of every row sum is dropped: 0 + p == p under IEEE == (it only turns a -0
 //     into +0), the same equality the X and real-entry forms rely on;
+//   * what remains above the arithmetic is hipcc ping-ponging the lane's eight amplitudes between two register
+//     sets across the gate loop (about 16 v_mov_b64 per gate).  Tried and measured worse: the updates as in-place
+//     gfx950 inline assembly with "+v" operands (operands copied in and out: 2186 vs 1602 vector instructions
+//     per wave for 20 Hadamards), scalar re[8]/im[8] registers with products-before-sums ordering (1825, and the
+//     X exchange if-converted into selects: 2959 vs 1256);
+//   * wave-uniform conditions stay BRANCHES (QIP_KEEP_BRANCH): if-converted they become speculative arithmetic
+//     blended by v_cndmask — more instructions and ~100 more live registers;
 //   * global addresses are a wave-uniform base plus the lane id.
-// Wave-uniform conditions in the gate loop must stay BRANCHES.  Left alone the compiler if-converts the small
-// conditional bodies: it computes every element's update speculatively and blends with v_cndmask on the scalar
-// condition — more vector instructions and ~100 more live registers (spills at five waves per SIMD).  An empty
-// volatile asm cannot be speculated, so a block that contains one keeps its branch.
 #define QIP_KEEP_BRANCH() asm volatile("")
 
-template <typename T, bool FMA>
-__device__ __forceinline__ amp_t<T> tile_cmul(amp_t<T> m, amp_t<T> x) {
-  if constexpr (FMA) {
-    amp_t<T> r;
-    r.x = __builtin_fma(-m.y, x.y, m.x * x.x);
-    r.y = __builtin_fma(m.y, x.x, m.x * x.y);
-    return r;
-  } else {
-    return cmul(m, x);
-  }
-}
-
-// (re, 0) * x
-template <typename T> __device__ __forceinline__ amp_t<T> tile_rmul(T m, amp_t<T> x) {
-  amp_t<T> r;
-  r.x = m * x.x;
-  r.y = m * x.y;
+template <typename A> __device__ __forceinline__ A tile_sel(bool take, A yes, A no) {
+  A r;
+  r.x = take ? yes.x : no.x;
+  r.y = take ? yes.y : no.y;
   return r;
 }
 
-// one row of a 2x2 gate applied to the pair (a0, a1); `REAL`: every entry has a zero imaginary part
-template <typename T, bool FMA, bool REAL>
+// one row of a 2x2 gate applied to the pair (a0, a1), zero entries skipped; REAL: every entry is (re, 0)
+template <typename T, bool REAL>
 __device__ __forceinline__ amp_t<T> tile_row(amp_t<T> ma, amp_t<T> mb, bool has_a, bool has_b, amp_t<T> a0, amp_t<T> a1) {
   using A = amp_t<T>;
-  if constexpr (FMA) {  // zero entries ride along: exact for finite amplitudes, and this mode is held to 1e-12
-    A r;
+  auto prod = [](A m, A x) {
     if constexpr (REAL) {
-      r.x = __builtin_fma(mb.x, a1.x, ma.x * a0.x);
-      r.y = __builtin_fma(mb.x, a1.y, ma.x * a0.y);
+      A r;
+      r.x = m.x * x.x;
+      r.y = m.x * x.y;
+      return r;
     } else {
-      r.x = __builtin_fma(-mb.y, a1.y, __builtin_fma(mb.x, a1.x, __builtin_fma(-ma.y, a0.y, ma.x * a0.x)));
-      r.y = __builtin_fma(mb.y, a1.x, __builtin_fma(mb.x, a1.y, __builtin_fma(ma.y, a0.x, ma.x * a0.y)));
+      return cmul(m, x);
     }
-    return r;
-  } else {
-    auto prod = [](A m, A x) {
-      if constexpr (REAL) return tile_rmul<T>(m.x, x);
-      else return cmul(m, x);
-    };
-    if (has_a && has_b) return cadd(prod(ma, a0), prod(mb, a1));
-    if (has_a) return prod(ma, a0);
-    if (has_b) return prod(mb, a1);
-    return czero<A>();
-  }
+  };
+  if (has_a && has_b) return cadd(prod(ma, a0), prod(mb, a1));
+  if (has_a) return prod(ma, a0);
+  if (has_b) return prod(mb, a1);
+  return czero<A>();
 }
 
 // dense 1-qubit gate on pass bit J: four register butterflies.  c[i] = the pass-bit part of element i's tile
 // index (wave-uniform), cm = the gate's controls that sit on pass bits.  The common shapes (no control on a pass
 // bit, all four entries non-zero) run as straight-line code; every test below is wave-uniform.
-template <typename T, int J, bool FMA, bool REAL, bool CHECKED>
+template <typename T, int J, bool REAL, bool CHECKED>
 __device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
   using A = amp_t<T>;
   const bool h0 = CHECKED ? (g.nz & 1u) != 0 : true, h1 = CHECKED ? (g.nz & 2u) != 0 : true;
@@ -840,13 +826,13 @@ __device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (
       QIP_KEEP_BRANCH();
     }
     const A a0 = e[i], a1 = e[k];
-    e[i] = tile_row<T, FMA, REAL>(g.m[0], g.m[1], h0, h1, a0, a1);
-    e[k] = tile_row<T, FMA, REAL>(g.m[2], g.m[3], h2, h3, a0, a1);
+    e[i] = tile_row<T, REAL>(g.m[0], g.m[1], h0, h1, a0, a1);
+    e[k] = tile_row<T, REAL>(g.m[2], g.m[3], h2, h3, a0, a1);
     __builtin_amdgcn_sched_barrier(0);  // one butterfly at a time: interleaving them only costs registers
   }
 }
 
-template <typename T, int J, bool FMA>
+template <typename T, int J>
 __device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
   using A = amp_t<T>;
   const bool is_x = (g.b1 & 2u) != 0, real = (g.b1 & 1u) != 0;
@@ -863,42 +849,79 @@ __device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[8
     }
     return;
   }
-  const bool plain = cm == 0u && (FMA || g.nz == 15u);
-  if (plain) {
-    if (real) pass_dense_body<T, J, FMA, true, false>(g, e, c, cm);
-    else pass_dense_body<T, J, FMA, false, false>(g, e, c, cm);
+  if (cm == 0u && g.nz == 15u) {
+    if (real) pass_dense_body<T, J, true, false>(g, e, c, cm);
+    else pass_dense_body<T, J, false, false>(g, e, c, cm);
   } else {
-    if (real) pass_dense_body<T, J, FMA, true, true>(g, e, c, cm);
-    else pass_dense_body<T, J, FMA, false, true>(g, e, c, cm);
+    if (real) pass_dense_body<T, J, true, true>(g, e, c, cm);
+    else pass_dense_body<T, J, false, true>(g, e, c, cm);
+  }
+}
+
+// Rare shape: a dense gate that still has controls on LANE bits (more controls than a pass holds).  One generic
+// form, selected per lane — compactness over speed.
+template <typename T, int J>
+__device__ __forceinline__ void pass_dense_lane(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+                                                bool lane_ok) {
+  using A = amp_t<T>;
+  const bool h0 = (g.nz & 1u) != 0, h1 = (g.nz & 2u) != 0, h2 = (g.nz & 4u) != 0, h3 = (g.nz & 8u) != 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if ((i >> J) & 1) continue;
+    const int k = i | (1 << J);
+    if ((c[i] & cm) != cm) continue;
+    QIP_KEEP_BRANCH();
+    const A a0 = e[i], a1 = e[k];
+    const A r0 = tile_row<T, false>(g.m[0], g.m[1], h0, h1, a0, a1);
+    const A r1 = tile_row<T, false>(g.m[2], g.m[3], h2, h3, a0, a1);
+    e[i] = tile_sel(lane_ok, r0, a0);
+    e[k] = tile_sel(lane_ok, r1, a1);
+  }
+}
+
+// e[i] <- f * e[i] for the elements whose pass-bit controls are 1 (HALF >= 0: only elements with pass bit J equal
+// to HALF); straight-line when the gate has no control on a pass bit
+template <typename T, int J, int HALF>
+__device__ __forceinline__ void pass_scale(amp_t<T> f, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+  if (cm == 0u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (HALF < 0 || ((i >> J) & 1) == HALF) e[i] = cmul(f, e[i]);
+  } else {
+    QIP_KEEP_BRANCH();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if ((HALF < 0 || ((i >> J) & 1) == HALF) && (c[i] & cm) == cm) {
+        QIP_KEEP_BRANCH();
+        e[i] = cmul(f, e[i]);
+      }
   }
 }
 
 // diagonal 1-qubit gate whose target is pass bit J: the factor of element i is m[(i >> J) & 1], known at
-// compile time; unit factors (wave-uniform test) leave their four elements untouched
-template <typename T, int J, bool FMA>
-__device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+// compile time; unit factors (wave-uniform test) leave their four elements untouched.  With lane-bit controls
+// the lanes whose controls are 0 multiply by (1, 0) instead: x*1 - y*0 == x for finite amplitudes.
+template <typename T, int J>
+__device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+                                          bool lane_ctl, bool lane_ok) {
+  using A = amp_t<T>;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const amp_t<T> f = g.m[half];
+    A f = g.m[half];
     if (f.x == (T)1 && f.y == (T)0) continue;
     QIP_KEEP_BRANCH();
-    if (cm == 0u) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (((i >> J) & 1) == half) e[i] = tile_cmul<T, FMA>(f, e[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (((i >> J) & 1) == half && (c[i] & cm) == cm) {
-          QIP_KEEP_BRANCH();
-          e[i] = tile_cmul<T, FMA>(f, e[i]);
-        }
+    if (lane_ctl) {
+      QIP_KEEP_BRANCH();
+      f.x = lane_ok ? f.x : (T)1;
+      f.y = lane_ok ? f.y : (T)0;
     }
+    if (half == 0) pass_scale<T, J, 0>(f, e, c, cm);
+    else pass_scale<T, J, 1>(f, e, c, cm);
   }
 }
 
 template <typename T, int J0, int J1>
-__device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+__device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm, bool lane_ctl, bool lane_ok) {
   using A = amp_t<T>;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -906,9 +929,15 @@ __device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[
     const int k = (i & ~(1 << J0)) | (1 << J1);
     if ((c[i] & cm) != cm) continue;  // controls are never J0/J1, so both elements agree
     QIP_KEEP_BRANCH();
-    const A a = e[i];
-    e[i] = e[k];
-    e[k] = a;
+    const A a = e[i], b = e[k];
+    if (lane_ctl) {
+      QIP_KEEP_BRANCH();
+      e[i] = tile_sel(lane_ok, b, a);
+      e[k] = tile_sel(lane_ok, a, b);
+    } else {
+      e[i] = b;
+      e[k] = a;
+    }
   }
 }
 
@@ -916,9 +945,9 @@ __device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[
 // latency-bound per wave (scalar gate fetch -> branch -> short VALU body, per gate), so resident blocks are what
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
 // (f32 keeps the default: its 16-KiB tiles already allow more, and under the bound hipcc 7.2 spills its tile.)
-template <typename T, bool NT, bool FMA>
+template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
-                                                        const TileGate<T>* __restrict__ gates) {
+                                                                              const TileGate<T>* __restrict__ gates) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
@@ -967,44 +996,49 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
       if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
       const uint32_t cm_reg = g.cmask & passmask;   // controls on pass bits: wave-uniform per element
       const uint32_t cm_lane = g.cmask & ~passmask;  // controls on lane bits: one predicate per gate
+      const bool lane_ctl = cm_lane != 0u;
       const bool lane_ok = (tb & cm_lane) == cm_lane;
       if (g.kind == 1) {
         const bool outside = g.b0 == kTileOutside;
         if (outside || !((passmask >> g.b0) & 1u)) {
           // the target bit is the same for the lane's 8 elements: one factor per gate
-          A f;
-          if (outside) f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];
-          else f = ((tb >> g.b0) & 1u) ? g.m[1] : g.m[0];
-          if (lane_ok && !(f.x == (T)1 && f.y == (T)0)) {  // unit entries leave the amplitude untouched
-            if (cm_reg == 0u) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) e[i] = tile_cmul<T, FMA>(f, e[i]);
-            } else {
-#pragma unroll
-              for (int i = 0; i < 8; ++i)
-                if ((c[i] & cm_reg) == cm_reg) {
-                  QIP_KEEP_BRANCH();
-                  e[i] = tile_cmul<T, FMA>(f, e[i]);
-                }
-            }
+          if (outside && !lane_ctl) {
+            const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];  // wave-uniform
+            if (f.x == (T)1 && f.y == (T)0) continue;                       // unit entries leave the amplitude untouched
+            QIP_KEEP_BRANCH();
+            pass_scale<T, 0, -1>(f, e, c, cm_reg);
+          } else {
+            QIP_KEEP_BRANCH();
+            // per-lane factor: the target bit's entry (a unit entry multiplies exactly), (1, 0) where a
+            // lane-bit control is 0
+            const bool one = outside ? ((base >> g.tpos_out) & 1ull) != 0 : ((tb >> g.b0) & 1u) != 0;
+            A f = tile_sel(one, g.m[1], g.m[0]);
+            f.x = lane_ok ? f.x : (T)1;
+            f.y = lane_ok ? f.y : (T)0;
+            pass_scale<T, 0, -1>(f, e, c, cm_reg);
           }
-        } else if (lane_ok) {
-          if (g.b0 == ps.pb[0]) pass_diag<T, 0, FMA>(g, e, c, cm_reg);
-          else if (g.b0 == ps.pb[1]) pass_diag<T, 1, FMA>(g, e, c, cm_reg);
-          else pass_diag<T, 2, FMA>(g, e, c, cm_reg);
+        } else {
+          if (g.b0 == ps.pb[0]) pass_diag<T, 0>(g, e, c, cm_reg, lane_ctl, lane_ok);
+          else if (g.b0 == ps.pb[1]) pass_diag<T, 1>(g, e, c, cm_reg, lane_ctl, lane_ok);
+          else pass_diag<T, 2>(g, e, c, cm_reg, lane_ctl, lane_ok);
         }
       } else if (g.kind == 0) {
-        if (lane_ok) {
-          if (g.b0 == ps.pb[0]) pass_dense<T, 0, FMA>(g, e, c, cm_reg);
-          else if (g.b0 == ps.pb[1]) pass_dense<T, 1, FMA>(g, e, c, cm_reg);
-          else pass_dense<T, 2, FMA>(g, e, c, cm_reg);
+        if (!lane_ctl) {
+          if (g.b0 == ps.pb[0]) pass_dense<T, 0>(g, e, c, cm_reg);
+          else if (g.b0 == ps.pb[1]) pass_dense<T, 1>(g, e, c, cm_reg);
+          else pass_dense<T, 2>(g, e, c, cm_reg);
+        } else {
+          QIP_KEEP_BRANCH();
+          if (g.b0 == ps.pb[0]) pass_dense_lane<T, 0>(g, e, c, cm_reg, lane_ok);
+          else if (g.b0 == ps.pb[1]) pass_dense_lane<T, 1>(g, e, c, cm_reg, lane_ok);
+          else pass_dense_lane<T, 2>(g, e, c, cm_reg, lane_ok);
         }
-      } else if (lane_ok) {
+      } else {
         const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
         const bool b1 = g.b1 == ps.pb[1];
-        if (a0 && b1) pass_swap<T, 0, 1>(e, c, cm_reg);
-        else if (a0) pass_swap<T, 0, 2>(e, c, cm_reg);
-        else if (a1) pass_swap<T, 1, 2>(e, c, cm_reg);
+        if (a0 && b1) pass_swap<T, 0, 1>(e, c, cm_reg, lane_ctl, lane_ok);
+        else if (a0) pass_swap<T, 0, 2>(e, c, cm_reg, lane_ctl, lane_ok);
+        else if (a1) pass_swap<T, 1, 2>(e, c, cm_reg, lane_ctl, lane_ok);
       }
     }
 #pragma unroll

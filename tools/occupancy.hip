@@ -18,10 +18,8 @@ int main() {
   printf("%s CUs=%d ldsPerBlock=%zu ldsPerCU=%zu regsPerBlock=%d regsPerCU=%d maxThreadsPerCU=%d clock=%d kHz\n", p.gcnArchName,
          p.multiProcessorCount, p.sharedMemPerBlock, p.maxSharedMemoryPerMultiProcessor, p.regsPerBlock,
          p.regsPerMultiprocessor, p.maxThreadsPerMultiProcessor, p.clockRate);
-  show("k_tile_passes<double,NT,noFMA>", k_tile_passes<double, true, false>, 32768);
-  show("k_tile_passes<double,NT,FMA>", k_tile_passes<double, true, true>, 32768);
-  show("k_tile_passes<float,NT,noFMA>", k_tile_passes<float, true, false>, 16384);
+  show("k_tile_passes<double,NT>", k_tile_passes<double, true>, 32768);
+  show("k_tile_passes<float,NT>", k_tile_passes<float, true>, 16384);
   show("k_tile_gates<double,NT>", k_tile_gates<double, true>, 32768);
-  show("k_tile_passes<double,NT,noFMA> lds16k", k_tile_passes<double, true, false>, 16384);
   return 0;
 }

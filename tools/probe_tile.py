@@ -25,6 +25,42 @@ def main():
         "20H bits top5 x4": list(range(n - 5, n)) * 4,
         "20H bits 0..4 x4": [0, 1, 2, 3, 4] * 4,
     }
+    if len(sys.argv) > 2 and sys.argv[2] == "kinds":
+        # one gate kind per sweep, targets spread over lane / wave / register bits (PMC: instructions per gate)
+        import cmath
+        bits20 = [0, 3, 6, 7, 8, 9, 10, 2, 5, 8] * 2
+        X = [0, 1, 1, 0]
+        rz = [cmath.rect(1, -0.3), 0, 0, cmath.rect(1, 0.3)]
+        tg = [1, 0, 0, cmath.rect(1, 0.785398)]
+        yy = [0, -1j, 1j, 0]
+        dense = [0.6, 0.8j, 0.8j, 0.6]
+        kinds = {
+            "20H": [q.make_matrix_op([bit(b)], H) for b in bits20],
+            "20X": [q.make_matrix_op([bit(b)], X) for b in bits20],
+            "20Rz": [q.make_matrix_op([bit(b)], rz) for b in bits20],
+            "20T": [q.make_matrix_op([bit(b)], tg) for b in bits20],
+            "20Y": [q.make_matrix_op([bit(b)], yy) for b in bits20],
+            "20dense": [q.make_matrix_op([bit(b)], dense) for b in bits20],
+            "20CNOT": [q.make_control_op([bit(bits20[(i + 3) % 20])], q.make_matrix_op([bit(b)], X))
+                       for i, b in enumerate(bits20) if bits20[(i + 3) % 20] != b],
+            "20CP": [q.make_control_op([bit(bits20[(i + 3) % 20])], q.make_matrix_op([bit(b)], tg))
+                     for i, b in enumerate(bits20) if bits20[(i + 3) % 20] != b],
+            "2H": [q.make_matrix_op([bit(b)], H) for b in (6, 7)],
+        }
+        with q.HipState(n) as st:
+            st.init_basis(0)
+            st.apply_ops(circuits.h_layer(n))
+            for mode in (1, 2):
+                st.set_option("tile", mode)
+                for name, ops in kinds.items():
+                    cops = st.compile_ops(ops)
+                    st.apply_compiled(cops)
+                    st.sync()
+                    t0 = time.perf_counter()
+                    st.apply_compiled(cops)
+                    st.sync()
+                    print(json.dumps({"tile": mode, "case": name, "gates": len(ops), "ms": round(1e3 * (time.perf_counter() - t0), 3)}), flush=True)
+        return
     with q.HipState(n) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
