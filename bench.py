@@ -257,7 +257,7 @@ def main():
                               "sweep_GBps": sweep_bytes / dt / 1e9,
                               "note": "per-sweep bytes (32*2^n per fused dense gate), never per-gate bytes over sweep time"}
         st.set_option("fuse", 0)
-        # LDS-resident multi-gate sweeps: tile = 1 (circuit order, bit-identical) and tile = 2 (commuting reorder)
+        # LDS-resident multi-gate sweeps: tile = 1 (circuit order up to exact commutations, IEEE-equal) and tile = 2 (commuting reorder)
         for mode in (1, 2):
             st.set_option("tile", mode)
             ct = st.compile_ops(ops)
@@ -287,7 +287,7 @@ def main():
             dt = time.perf_counter() - t
             by = sum(circuit_bytes(q, n, cops))
             extras[cname] = {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": by / dt / 1e9}
-            st.set_option("tile", 1)  # bit-identical multi-gate sweeps
+            st.set_option("tile", 1)  # IEEE-equal multi-gate sweeps
             st.set_option("profile", 1)
             st.apply_compiled(cc)
             st.sync()

@@ -190,7 +190,8 @@ int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
  *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into consecutive segments of gates that live
  *                    on index bits 0..5 plus five free higher bits and applies each segment in ONE sweep
- *                    through an LDS-resident tile (bit-identical to the gate-by-gate path);
+ *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
+ *                    (IEEE-equal to the gate-by-gate path);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

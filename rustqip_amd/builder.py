@@ -111,7 +111,7 @@ class HipBuilder:
         self.dtype = np.dtype(dtype)
         self.device = device
         # tile = 1: runs of gates between measurements are applied as LDS-resident multi-gate sweeps in circuit
-        # order — bit-identical to one sweep per gate, several times fewer passes over HBM.  0 = one sweep per
+        # order — IEEE-equal to one sweep per gate, several times fewer passes over HBM.  0 = one sweep per
         # gate, 2 = also hoist gates over gates they commute with (1e-12 instead of bit equality).
         self.tile = tile
         self._n = 0
