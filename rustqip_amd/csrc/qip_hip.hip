@@ -1494,10 +1494,26 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     auto close_pass = [&](uint32_t end) {
       std::vector<uint32_t> b = bits;
       auto has = [&](uint32_t t) { return std::find(b.begin(), b.end(), t) != b.end(); };
-      // pad to three bits from the top, never completing a pair (t, t +- S): such a pass would be 2-way
-      // bank-conflicted, and low pad bits are what made the linear layout 8-way
+      // Pad to three bits.  A free slot is best spent on a bit the pass's DIAGONAL gates test: a control on a
+      // pass bit, or the target of a gate with one unit entry (phase, T, S, Z, controlled-phase), turns "multiply
+      // all eight elements" into "multiply the four (two) that can change" by a scalar branch.  Otherwise from the
+      // top; never completing a pair (t, t +- S) unless nothing else is left: such a pass is 2-way
+      // bank-conflicted (and low pad bits are what made the linear layout 8-way).
+      int score[kTileBits] = {0};
+      for (uint32_t gi = first; gi < end; ++gi) {
+        const TileGate<T>& g = gates[gi];
+        if (g.kind != 1) continue;
+        for (int t = 0; t < kTileBits; ++t)
+          if ((g.cmask >> t) & 1u) score[t] += 1;
+        const bool unit0 = g.m[0].x == (T)1 && g.m[0].y == (T)0, unit1 = g.m[1].x == (T)1 && g.m[1].y == (T)0;
+        if (g.b0 != kTileOutside && (unit0 || unit1)) score[g.b0] += 1;
+      }
+      std::vector<int> order;
+      for (int t = kTileBits - 1; t >= 0; --t) order.push_back(t);
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return score[x] > score[y]; });
       for (int relax = 0; relax < 2 && b.size() < 3; ++relax)
-        for (int t = kTileBits - 1; t >= 0 && b.size() < 3; --t) {
+        for (size_t q = 0; q < order.size() && b.size() < 3; ++q) {
+          const int t = order[q];
           if (has((uint32_t)t)) continue;
           const bool pairs = has((uint32_t)t + S) || (t >= (int)S && has((uint32_t)t - S));
           if (pairs && relax == 0) continue;

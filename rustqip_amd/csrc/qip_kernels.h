@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
 constexpr int kTileLow = 6;                        // contiguous low bits (one wave row)
 constexpr int kTileHigh = 5;                       // free bit positions per segment
 constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile
-constexpr int kTileMaxGates = 24;
+constexpr int kTileMaxGates = 64;  // a gate riding along costs ~0.2 ms at n = 30, a new sweep 6.4 ms
 
 // Only the bits a gate EXCHANGES amplitudes across must lie inside the tile: the target of a dense gate, the
 // two bits of a swap.  Controls, and the target of a diagonal gate, may sit on any index bit: outside the tile
@@ -749,7 +749,7 @@ template <typename A> __device__ __forceinline__ uint32_t tile_slot(uint32_t t) 
   constexpr uint32_t S = sizeof(A) == 16 ? 4u : 5u;
   return t ^ ((t >> S) & ((1u << S) - 1u));
 }
-constexpr int kTileMaxPasses = 24;
+constexpr int kTileMaxPasses = kTileMaxGates;  // every gate closes at most one pass
 struct TilePassDesc {
   uint32_t npasses;
   uint32_t hpos[kTileHigh];
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
       e[i] = tile[slot_tb ^ tile_slot<A>(c[i])];
     }
     for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
-      const TileGate<T> g = gates[gi];  // wave-uniform
+      const TileGate<T> g = gates[gi];  // wave-uniform (prefetching the next descriptor was measured: no gain)
       if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
       const uint32_t cm_reg = g.cmask & passmask;   // controls on pass bits: wave-uniform per element
       const uint32_t cm_lane = g.cmask & ~passmask;  // controls on lane bits: one predicate per gate

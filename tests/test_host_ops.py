@@ -222,7 +222,7 @@ def test_tile_schedule_invariants():
                 free = set()
                 for i in st:
                     free |= {p for p in exchange_bits(ops[i]) if p >= 6}
-                assert len(free) <= 5 and len(st) <= 24
+                assert len(free) <= 5 and len(st) <= 64
                 assert all(len(flatten(ops[i])[2]) == 1 or flatten(ops[i])[1].kind == "Swap" for i in st)
         assert [50] in steps  # the dense 2-qubit gate is launched on its own
     assert len(plan_tiles(n, ops, 2)) <= len(plan_tiles(n, ops, 1)) < len(ops) / 4
