@@ -1,0 +1,23 @@
+//! `qip-hip` — run circuits built with `qip` on an AMD MI355X.
+//!
+//! The reference has no FFI seam and forbids `unsafe` in both library crates (`qip/src/lib.rs:1`,
+//! `qip-iterators/src/lib.rs:1`), so the binding is this separate crate:
+//!
+//! * [`sys`]     raw `extern "C"` declarations, one per entry of `include/qip_hip.h`;
+//! * [`op`]      `MatrixOp<Complex<f64>>` -> `struct qip_op` (borrowing the op's own buffers);
+//! * [`state`]   `HipState`: the device-resident amplitude vector (RAII over `qip_hip_state_*`);
+//! * [`builder`] `HipBuilder`: owns a `LocalBuilder<f64>` for all circuit bookkeeping and replaces only
+//!               `calculate_state_with_init` (`qip/src/builder.rs:400-519`) with device launches;
+//! * [`replay`]  writer for the flat circuit-replay text format (`rustqip_amd/replay.py`), for setups
+//!               where the Rust program and the GPU are not in the same process.
+//!
+//! Status: **uncompiled** (no Rust toolchain in the build image).  The C ABI underneath is built and tested
+//! through the same entry points from Python (`tests/`) and C++ (`rustqip_amd/host/qip_hip.hpp`).
+pub mod builder;
+pub mod op;
+pub mod replay;
+pub mod state;
+pub mod sys;
+
+pub use builder::{HipBuilder, HipMeasurements};
+pub use state::{HipError, HipState};

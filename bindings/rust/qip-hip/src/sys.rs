@@ -1,0 +1,117 @@
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 1).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_double, c_int, c_void};
+
+pub const QIP_C64: c_int = 0; // Complex<f64>
+pub const QIP_C32: c_int = 1; // Complex<f32>
+
+pub const QIP_OP_MATRIX: i32 = 0;
+pub const QIP_OP_SPARSE: i32 = 1;
+pub const QIP_OP_SWAP: i32 = 2;
+pub const QIP_OP_CONTROL: i32 = 3;
+
+pub const QIP_OK: c_int = 0;
+pub const QIP_ERR_INVALID: c_int = 1;
+pub const QIP_ERR_DEVICE: c_int = 2;
+pub const QIP_ERR_NO_DEVICE: c_int = 3;
+pub const QIP_ERR_UNSUPPORTED: c_int = 4;
+
+/// `struct qip_op`: the flat image of `MatrixOp<P>` (`qip-iterators/src/iterators/ops.rs:11-20`).
+#[repr(C)]
+pub struct qip_op {
+    pub kind: i32,
+    pub n_indices: u32,
+    /// Control: control indices then op indices.  Swap: A half then B half.
+    pub indices: *const u64,
+    pub n_controls: u32,
+    /// Matrix: 4^k `Complex<P>`, row-major.
+    pub dense: *const c_void,
+    /// SparseMatrix as CSR: `Vec<Vec<(usize, P)>>` flattened, order preserved.
+    pub sparse_rowptr: *const u64,
+    pub sparse_cols: *const u64,
+    pub sparse_vals: *const c_void,
+    pub inner: *const qip_op,
+}
+
+#[repr(C)]
+pub struct qip_hip_state {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct qip_hip_program {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn qip_hip_last_error() -> *const c_char;
+    pub fn qip_hip_device_count() -> c_int;
+    pub fn qip_hip_abi_version() -> c_int;
+    pub fn qip_hip_set_global_option(key: *const c_char, value: i64) -> c_int;
+
+    pub fn qip_hip_validate_op(n: u32, op: *const qip_op) -> c_int;
+    pub fn qip_hip_op_algorithmic_bytes(dtype: c_int, n: u32, op: *const qip_op, bytes: *mut c_double) -> c_int;
+
+    /// Twin of `apply_op` (`accumulate = 1`, matrix_ops.rs:98-123) and `apply_op_overwrite`
+    /// (`accumulate = 0`, :127-152) on host buffers, windows included.
+    pub fn qip_hip_apply_op_host(
+        dtype: c_int, n: u32, op: *const qip_op,
+        input: *const c_void, in_len: u64, output: *mut c_void, out_len: u64,
+        in_off: u64, out_off: u64, accumulate: c_int,
+    ) -> c_int;
+
+    pub fn qip_hip_state_create(n: u32, dtype: c_int, device: c_int, out: *mut *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_state_wrap(
+        n: u32, dtype: c_int, device: c_int, amps: *mut c_void, scratch: *mut c_void,
+        stream: *mut c_void, out: *mut *mut qip_hip_state,
+    ) -> c_int;
+    pub fn qip_hip_state_destroy(s: *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_state_init_basis(s: *mut qip_hip_state, index: u64) -> c_int;
+    pub fn qip_hip_state_upload(s: *mut qip_hip_state, src: *const c_void, offset: u64, len: u64) -> c_int;
+    pub fn qip_hip_state_download(s: *mut qip_hip_state, dst: *mut c_void, offset: u64, len: u64) -> c_int;
+    pub fn qip_hip_state_device_ptr(s: *mut qip_hip_state, amps: *mut *mut c_void) -> c_int;
+    pub fn qip_hip_state_scratch_ptr(s: *mut qip_hip_state, scratch: *mut *mut c_void) -> c_int;
+    pub fn qip_hip_state_swap_buffers(s: *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_state_sync(s: *mut qip_hip_state) -> c_int;
+
+    pub fn qip_hip_state_apply_op(s: *mut qip_hip_state, op: *const qip_op) -> c_int;
+    pub fn qip_hip_state_apply_ops(s: *mut qip_hip_state, ops: *const qip_op, count: u64) -> c_int;
+
+    pub fn qip_hip_program_create(
+        s: *mut qip_hip_state, ops: *const qip_op, count: u64, out: *mut *mut qip_hip_program,
+    ) -> c_int;
+    pub fn qip_hip_program_run(p: *mut qip_hip_program) -> c_int;
+    pub fn qip_hip_program_is_graph(p: *const qip_hip_program) -> c_int;
+    pub fn qip_hip_program_destroy(p: *mut qip_hip_program) -> c_int;
+
+    pub fn qip_hip_plan_tiles(
+        dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int,
+        step_of_op: *mut i64, n_steps: *mut u64,
+    ) -> c_int;
+
+    pub fn qip_hip_state_set_option(s: *mut qip_hip_state, key: *const c_char, value: i64) -> c_int;
+    pub fn qip_hip_kernel_class_count() -> c_int;
+    pub fn qip_hip_kernel_class_name(cls: c_int) -> *const c_char;
+    pub fn qip_hip_state_profile_get(
+        s: *mut qip_hip_state, cls: c_int, launches: *mut u64, total_ms: *mut c_double,
+        algorithmic_bytes: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_state_profile_reset(s: *mut qip_hip_state) -> c_int;
+
+    pub fn qip_hip_state_norm_sqr(s: *mut qip_hip_state, out: *mut c_double) -> c_int;
+    pub fn qip_hip_state_measure_probs(
+        s: *mut qip_hip_state, indices: *const u64, k: u32, out: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_state_measure_prob(
+        s: *mut qip_hip_state, measured: u64, indices: *const u64, k: u32, out: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_state_soft_measure(
+        s: *mut qip_hip_state, indices: *const u64, k: u32, rand_u01: c_double, measured: *mut u64,
+    ) -> c_int;
+    pub fn qip_hip_state_measure(
+        s: *mut qip_hip_state, indices: *const u64, k: u32, forced: i64, rand_u01: c_double,
+        measured: *mut u64, prob: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_state_measure_state(
+        s: *mut qip_hip_state, indices: *const u64, k: u32, measured: u64, prob: c_double,
+    ) -> c_int;
+}

@@ -15,10 +15,11 @@ from .state import (HipState, QipHipError, apply_op, apply_op_overwrite, device_
 from .builder import Conditioned, HipBuilder, Measurements, Register, lower_to_matrix_op
 from .state import HipProgram
 from . import circuits  # noqa: F401  (workload generators: rustqip_amd.circuits)
+from . import replay  # noqa: F401  (flat circuit-replay format)
 
 __all__ = [
     "CircuitError", "MatrixOp", "Representation", "algorithmic_bytes", "flip_bits", "make_control_op",
     "make_matrix_op", "make_sparse_matrix_op", "make_swap_op", "validate_op", "HipState", "QipHipError",
     "apply_op", "apply_op_overwrite", "device_count", "make_op_matrix", "set_global_option", "Conditioned",
-    "HipBuilder", "Measurements", "Register", "lower_to_matrix_op", "HipProgram", "circuits",
+    "HipBuilder", "Measurements", "Register", "lower_to_matrix_op", "HipProgram", "circuits", "replay",
 ]

@@ -9,6 +9,7 @@ Everything goes through the C ABI (ctypes -> libqip_hip.so -> HIP kernels).  Bar
 """
 import cmath
 import math
+import os
 
 import numpy as np
 import pytest
@@ -18,6 +19,8 @@ from rustqip_amd import circuits
 from rustqip_amd.ops import MatrixOp
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL64 = 1e-12
 TOL32 = 1e-5
@@ -1001,3 +1004,41 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
     assert abs(line["norm_sqr_after"] - 1) < 1e-10
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 1
+
+
+def test_circuit_replay_python_and_cpp_cli(O, tmp_path):
+    """a "qipc 1" file replayed by rustqip_amd.replay and by tools/qip_replay (C++ host
+    mirror) gives the oracle's amplitudes / probabilities; the two replays print identical numbers."""
+    import subprocess
+
+    from rustqip_amd import replay
+
+    n = 9
+    rng = np.random.default_rng(5)
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 60, seed=3) + circuits.c3_qft(n)[:30]
+    ops.append(q.make_sparse_matrix_op([1, 4], [[(0, 1)], [(2, 1j)], [(1, -1)], [(3, cmath.rect(1, 0.4))]]))
+    ops.append(q.make_matrix_op([2, 7, 0], rand_unitary(3, rng).ravel()))
+    circ = replay.Circuit(n, 5, ops[:50] + [replay.Probs([0, 3, 8])] + ops[50:] + [replay.Probs([1, 2])])
+    path = tmp_path / "c.qipc"
+    replay.dump(str(path), circ)
+    x = np.zeros(1 << n, dtype=np.complex128)
+    x[5] = 1
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    mid = O.apply_ops_in_place(n, ops[:50], x.copy())
+    results, st = replay.run(replay.load(str(path)), tile=1)
+    try:
+        got = st.download()
+    finally:
+        st.close()
+    assert np.max(np.abs(got - want)) <= TOL64
+    assert np.max(np.abs(results[0] - O.measure_probs(n, [0, 3, 8], mid))) <= TOL64
+    assert np.max(np.abs(results[1] - O.measure_probs(n, [1, 2], want))) <= TOL64
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "qip_replay"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(ROOT, "tools", "qip_replay"), "--tile", "1", "--amps", "16", str(path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    probs = [np.array([float(t) for t in ln.split()[1:]]) for ln in lines if ln.startswith("probs")]
+    assert len(probs) == 2 and np.array_equal(probs[0], results[0]) and np.array_equal(probs[1], results[1])
+    amps = np.array([complex(float(ln.split()[2]), float(ln.split()[3])) for ln in lines if ln.startswith("amp ")])
+    assert np.array_equal(amps, got[:16])  # same library, same launches: identical to the last bit
