@@ -1042,3 +1042,68 @@ def test_circuit_replay_python_and_cpp_cli(O, tmp_path):
     assert len(probs) == 2 and np.array_equal(probs[0], results[0]) and np.array_equal(probs[1], results[1])
     amps = np.array([complex(float(ln.split()[2]), float(ln.split()[3])) for ln in lines if ln.startswith("amp ")])
     assert np.array_equal(amps, got[:16])  # same library, same launches: identical to the last bit
+
+
+@pytest.mark.parametrize("n, seed", [(8, 1), (12, 2), (14, 3), (15, 4)])
+def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
+    """Seeded fuzz over the shapes a tile segment can hold — 1-qubit gates of every zero pattern with 0..4
+    controls, (multi-)controlled diagonal gates, (controlled) swaps — mixed with ops that are not tileable.
+    tile = 1 must equal the gate-by-gate path under IEEE ==, both must equal the oracle (gate by gate: bit for
+    bit on f64), tile = 2 / programs to 1e-12.  n > 11 puts targets and controls outside the tile as well."""
+    rng = np.random.default_rng(seed)
+    names = list(GATES_1Q)
+    ops = []
+    for _ in range(160):
+        perm = [int(v) for v in rng.permutation(n)]
+        shape = int(rng.integers(0, 8))
+        nc = int(rng.integers(0, min(5, n - 2)))
+        if shape <= 3:  # dense / diagonal 1-qubit gate, any number of controls
+            g = q.make_matrix_op([perm[0]], GATES_1Q[names[int(rng.integers(0, len(names)))]])
+            ops.append(q.make_control_op(perm[1:1 + nc], g) if nc else g)
+        elif shape == 4:  # controlled phase with a random angle
+            g = q.make_matrix_op([perm[0]], [1, 0, 0, cmath.rect(1, float(rng.uniform(0, 6.28)))])
+            ops.append(q.make_control_op(perm[1:2 + nc], g))
+        elif shape == 5:  # (controlled) swap
+            g = q.make_swap_op([perm[0]], [perm[1]])
+            ops.append(q.make_control_op(perm[2:2 + nc], g) if nc else g)
+        elif shape == 6:  # not tileable: dense 2-qubit gate / 2+2 swap
+            if rng.integers(0, 2):
+                ops.append(q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel()))
+            else:
+                ops.append(q.make_swap_op(perm[:2], perm[2:4]))
+        else:  # sparse (generic gather path)
+            ops.append(q.make_sparse_matrix_op([perm[0]], [[(1, 1j)], [(0, -1j)]]))
+    x = circuits.random_state(n, seed=seed)
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        eager = st.download()
+    assert np.array_equal(eager, want)
+    for mode in (1, 2):
+        with q.HipState(n) as st:
+            st.set_option("tile", mode)
+            st.upload(x)
+            st.apply_ops(ops)
+            got = st.download()
+        if mode == 1:
+            assert np.array_equal(got, eager), (n, seed)
+        else:
+            assert np.max(np.abs(got - eager)) <= TOL64 * max(1.0, float(np.max(np.abs(eager)))), (n, seed)
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.upload(x)
+        prog = st.compile_program(ops)
+        prog.run()
+        assert np.array_equal(st.download(), eager)
+        prog.close()
+    x32 = x.astype(np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.upload(x32)
+        st.apply_ops(ops)
+        e32 = st.download()
+    with q.HipState(n, np.complex64) as st:
+        st.set_option("tile", 1)
+        st.upload(x32)
+        st.apply_ops(ops)
+        assert np.array_equal(st.download(), e32), (n, seed)
