@@ -1,6 +1,6 @@
 """Time the LDS-resident multi-gate sweeps (option "tile") on the configured circuits.
 
-    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2]
+    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2] [f32]
 
 Prints one JSON line per (circuit, mode): sweeps launched, ms per run of the circuit, gates/s, and the
 per-sweep HBM rate (each sweep reads and writes the vector once: 32 * 2^n bytes)."""
@@ -26,7 +26,10 @@ def main():
     if len(sys.argv) > 3:
         cases = {k: v for k, v in cases.items() if k in sys.argv[3].split(",")}
     modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2]
-    with q.HipState(n) as st:
+    import numpy as np
+
+    f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
+    with q.HipState(n, np.complex64 if f32 else np.complex128) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
         for name, ops in cases.items():
@@ -49,7 +52,7 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
                                   "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
-                                  "ms_per_sweep": round(1e3 * best / sweeps, 3),
+                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64",
                                   "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
 
