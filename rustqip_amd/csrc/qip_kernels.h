@@ -772,6 +772,8 @@ struct TilePassDesc {
 //   * X is a register exchange; gates with real entries multiply two reals per product;
 //   * the reference's leading "0 +" of every row sum is dropped: 0 + p == p under IEEE == (it only turns a -0
 //     into +0), the same equality the X and real-entry forms rely on;
+//   * explicit FMAs for tile = 2 (which is held to 1e-12 anyway) would halve the arithmetic, but every FMA
+//     variant of this kernel spilled under the occupancy bound (430 VGPRs at 96, 48 at 128): 30 ms per sweep;
 //   * what remains above the arithmetic is hipcc ping-ponging the lane's eight amplitudes between two register
 //     sets across the gate loop (about 16 v_mov_b64 per gate).  Tried and measured worse: the updates as in-place
 //     gfx950 inline assembly with "+v" operands (operands copied in and out: 2186 vs 1602 vector instructions
