@@ -1107,3 +1107,25 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
         st.upload(x32)
         st.apply_ops(ops)
         assert np.array_equal(st.download(), e32), (n, seed)
+
+
+def test_resource_and_option_errors_are_reported_not_fatal():
+    """A state that cannot fit in HBM, an unknown option, an op on more qubits than the state has: each is a
+    status + message (QipHipError / CircuitError), and the library keeps working afterwards."""
+    with pytest.raises(q.QipHipError) as e:
+        q.HipState(40)  # 16 TiB: hipMalloc fails cleanly
+    assert "40-qubit" in str(e.value)
+    with pytest.raises((q.QipHipError, q.CircuitError)):
+        q.HipState(41)
+    with q.HipState(6) as st:
+        with pytest.raises((q.QipHipError, q.CircuitError)) as e:
+            st.set_option("no_such_option", 1)
+        assert "no_such_option" in str(e.value)
+        with pytest.raises((q.QipHipError, q.CircuitError)):
+            st.apply_op(q.make_matrix_op([6], GATES_1Q["H"]))  # qubit 6 of a 6-qubit state
+        with pytest.raises((q.QipHipError, q.CircuitError)):
+            st.measure_probs([0, 0])
+        st.init_basis(0)
+        st.apply_ops(circuits.h_layer(6))  # still usable
+        assert abs(st.norm_sqr() - 1.0) < 1e-12
+        assert np.allclose(st.measure_probs([1, 4]), 0.25)
