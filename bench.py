@@ -319,6 +319,28 @@ def main():
             extras["configs1_n28"] = {"GBps": sum(circuit_bytes(q, n28, ops28)) / dt / 1e9, "gates_per_s": len(ops28) / dt,
                                       "ms_per_step": 1e3 * dt, "norm_sqr": s28.norm_sqr()}
 
+    if world > 1 and not args.no_extras:
+        # the same step with the runs of local gates between remaps applied as LDS-resident tile sweeps on every
+        # shard (tile = 1: IEEE-equal to gate by gate).  Reported beside the headline, never as `value`; guarded so
+        # that nothing here can take the bench line down.
+        try:
+            st.backend.state.set_option("tile", 1)
+            st.run_plan(plan, batched=True)
+            sync()
+            barrier()
+            t = time.perf_counter()
+            st.run_plan(plan, batched=True)
+            sync()
+            barrier()
+            dt = time.perf_counter() - t
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            extras["tiled_mode1"] = {"gates": len(ops), "ms_per_step": 1e3 * float(tt.item()),
+                                     "gates_per_s": len(ops) / float(tt.item())}
+            st.backend.state.set_option("tile", 0)
+        except Exception as exc:  # noqa: BLE001
+            extras["tiled_mode1"] = {"error": repr(exc)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(q, circuits, args)

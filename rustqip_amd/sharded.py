@@ -107,7 +107,7 @@ class HipBackend:
     """2^L amplitudes in HBM allocated by torch (two buffers: current + exchange target), driven by
     HipState on torch's current stream."""
 
-    def __init__(self, n_local: int, device: int, host_staged_exchange: bool = False):
+    def __init__(self, n_local: int, device: int, host_staged_exchange: bool = False, tile: int = 0):
         import torch
 
         from .state import HipState
@@ -124,6 +124,8 @@ class HipBackend:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.state = HipState(n_local, np.complex128, device, wrap_ptr=self.bufs[0].data_ptr(),
                               scratch_ptr=self.bufs[1].data_ptr(), stream=stream)
+        if tile:
+            self.state.set_option("tile", tile)  # applies to apply_ops batches (ShardedState.run_plan(batched=True))
         self._events: List[tuple] = []
 
     def _cur(self) -> int:
@@ -131,6 +133,9 @@ class HipBackend:
 
     def apply_op(self, op: MatrixOp) -> None:
         self.state.apply_op(op)
+
+    def apply_ops(self, ops: Sequence[MatrixOp]) -> None:
+        self.state.apply_ops(ops)
 
     def exchange_buffers(self):
         """(send, recv) as real views; after the collective call adopt_recv()."""
@@ -351,15 +356,25 @@ class ShardedState:
                     loc = make_matrix_op([0], [d, 0, 0, d])
         return make_control_op(local_ctrl, loc) if local_ctrl else loc
 
-    def _apply_info(self, info: OpInfo, next_use: Optional[Dict[int, int]] = None) -> None:
+    def _apply_info(self, info: OpInfo, next_use: Optional[Dict[int, int]] = None,
+                    batch: Optional[List[MatrixOp]] = None) -> None:
+        """One op.  With `batch`, the localized op is appended instead of applied and the caller flushes the
+        list through backend.apply_ops: the runs of local gates between two remaps, so the shard's own
+        scheduler (option "tile") sees them together.  The batch is flushed before any remap."""
         self.clock += 1
         if any(self.phys[p] >= self.L for p in info.nondiag_bits):
+            if batch:
+                self.backend.apply_ops(batch)
+                batch.clear()
             self._remap(info.nondiag_bits, next_use)
         for qb in info.ctrl + info.tgt:
             self.last_use[self.n - 1 - qb] = self.clock
         loc = self._localize(info)
         if loc is not None:
-            self.backend.apply_op(loc)
+            if batch is not None:
+                batch.append(loc)
+            else:
+                self.backend.apply_op(loc)
 
     def apply_op(self, op: MatrixOp) -> None:
         self._apply_info(OpInfo(self.n, op))
@@ -379,10 +394,16 @@ class ShardedState:
             nxt[i] = dict(cur)
         return infos, nxt
 
-    def run_plan(self, plan) -> None:
+    def run_plan(self, plan, batched: bool = False) -> None:
+        """batched = False: one launch per gate.  True: the gates between two remaps go to the shard backend in
+        one apply_ops call each, so a backend created with tile > 0 applies them as LDS-resident multi-gate
+        sweeps (IEEE-equal to gate by gate for tile = 1)."""
         infos, nxt = plan
+        batch: Optional[List[MatrixOp]] = [] if batched and hasattr(self.backend, "apply_ops") else None
         for info, nu in zip(infos, nxt):
-            self._apply_info(info, nu)
+            self._apply_info(info, nu, batch)
+        if batch:
+            self.backend.apply_ops(batch)
 
     # -- reductions ------------------------------------------------------------------------------------------------
     def _allreduce_sum(self, arr: np.ndarray) -> np.ndarray:

@@ -25,6 +25,11 @@ class OracleBackend:
         O.apply_op_overwrite(self.n_local, op, self._np(self.cur), self._np(1 - self.cur))
         self.cur = 1 - self.cur
 
+    def apply_ops(self, ops):
+        self.batches = getattr(self, "batches", []) + [len(ops)]
+        for op in ops:
+            self.apply_op(op)
+
     def exchange_buffers(self):
         return torch.view_as_real(self.bufs[self.cur]), torch.view_as_real(self.bufs[1 - self.cur])
 

@@ -76,6 +76,14 @@ def main():
                 assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(n, idx, want))) < 1e-12, (name, idx)
             if name in ("c4", "qft"):
                 assert st.stats["remaps"] >= 1, "circuit was expected to touch a global qubit"
+                # batched replay: the runs of local gates between remaps reach the backend as lists (what lets a
+                # HIP shard apply them as tile sweeps); same ops in the same order, so the result is identical
+                stb = ShardedState(n, dist, backend=OracleBackend(n - g))
+                stb.upload_global(x)
+                stb.run_plan(stb.plan(ops), batched=True)
+                assert np.array_equal(stb.download_global(), got), (name, n)
+                assert 1 <= len(stb.backend.batches) <= stb.stats["remaps"] + 1
+                assert (stb.stats["remaps"], stb.stats["local_swaps"]) == (st.stats["remaps"], st.stats["local_swaps"])
             # collapsing measurement, forced outcomes: every shard rescales with the global probability
             for idx, forced in (([0], 1), ([n - 1, 1], 2), ([2, 0, n - 1], 5)):
                 st2 = ShardedState(n, dist, backend=OracleBackend(n - g))

@@ -46,6 +46,12 @@ def main():
                 assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(n, idx, want))) < 1e-12
             if world > 1 and name != "grover_k3":
                 assert st.stats["remaps"] >= 1
+            # the runs of local gates between remaps as LDS-resident tile sweeps on every shard (tile = 1):
+            # IEEE-equal to the gate-by-gate shards
+            stt = ShardedState(n, dist, backend=HipBackend(n - g, 0, host_staged_exchange=not use_nccl, tile=1))
+            stt.upload_global(x)
+            stt.run_plan(stt.plan(ops), batched=True)
+            assert np.array_equal(stt.download_global(), got), (name, n, world)
             if rank == 0:
                 print(f"ok n={n} world={world} {name}: err={err:.2e} stats={st.comm_stats()}")
     dist.barrier()

@@ -1004,6 +1004,8 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
     assert abs(line["norm_sqr_after"] - 1) < 1e-10
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 1
+    tiled = line["extras"]["tiled_mode1"]  # tile sweeps on the shards, guarded extra
+    assert "error" not in tiled and tiled["gates_per_s"] > 0, tiled
 
 
 def test_circuit_replay_python_and_cpp_cli(O, tmp_path):
