@@ -188,8 +188,9 @@ int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
  *                    <= K qubits (K <= 5 for f64, 4 for f32) and applies each in one sweep; results
  *                    then match the gate-by-gate path to rounding (1e-12 bar), not bit for bit.
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
- *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into consecutive segments of gates that live
- *                    on index bits 0..5 plus five free higher bits and applies each segment in ONE sweep
+ *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into segments of gates (1-qubit gates with any
+ *                    controls, dense 2-qubit gates, bit swaps) whose exchanging bits live on index bits 0..5
+ *                    plus five free higher bits and applies each segment in ONE sweep
  *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
  *                    (IEEE-equal to the gate-by-gate path);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.

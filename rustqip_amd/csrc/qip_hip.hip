@@ -1365,6 +1365,7 @@ struct TileItem {
   std::vector<uint32_t> cpos;
   double m[8] = {0};
   uint32_t nz = 0;
+  std::vector<double> mat;  // kind 3: 4x4 row-major as re,im pairs, sub-index MSB = t0
 };
 
 static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it) {
@@ -1414,6 +1415,12 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
     it->t1 = std::max(p.opos[0], p.opos[1]);
     it->tileable = true;
     it->exact = true;
+  } else if (p.cls == KC_GATE_KQ && k == 2 && p.table.size() == 32) {
+    it->kind = 3;  // dense 2-qubit gate: both targets exchange amplitudes
+    it->t0 = p.opos[0];
+    it->t1 = p.opos[1];
+    it->mat = p.table;
+    it->tileable = true;
   } else if (p.cls == KC_NOOP) {
     it->exact = true;  // identity: nothing happens (not tileable, launches nothing)
   }
@@ -1431,7 +1438,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   std::vector<uint32_t> uses(64, 0);
   for (const TileItem* it : seg) {
     if (it->kind == 0) uses[it->t0] += 1;
-    if (it->kind == 2) {
+    if (it->kind == 2 || it->kind == 3) {
       uses[it->t0] += 1;
       uses[it->t1] += 1;
     }
@@ -1443,21 +1450,26 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
   std::vector<TileGate<T>> gates(seg.size());
+  std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
   for (size_t i = 0; i < seg.size(); ++i) {
     const TileItem& it = *seg[i];
     TileGate<T>& g = gates[i];
     memset(&g, 0, sizeof g);
     g.kind = (uint32_t)it.kind;
     g.b0 = tile_bit(it.t0);
-    g.b1 = it.kind == 2 ? tile_bit(it.t1) : 0;
-    if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);
+    g.b1 = it.kind >= 2 ? tile_bit(it.t1) : 0;
+    if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);  // (kind 3 keeps b0 = the sub-index MSB)
+    if (it.kind == 3) {
+      g.nz = (uint32_t)(mats.size() / 16);  // index of its 4x4 in the matrix block behind the gate list
+      for (int e = 0; e < 16; ++e) mats.push_back(mk<T>(it.mat[2 * e], it.mat[2 * e + 1]));
+    }
     if (it.kind == 1 && g.b0 == kTileOutside) g.tpos_out = it.t0;
     for (uint32_t c : it.cpos) {
       const uint32_t tb = tile_bit(c);
       if (tb == kTileOutside) g.omask |= 1ull << c;
       else g.cmask |= 1u << tb;
     }
-    g.nz = it.nz;
+    if (it.kind != 3) g.nz = it.nz;
     if (it.kind == 0) {
       for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
       if (s->tile_passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
@@ -1470,7 +1482,11 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       g.m[1] = mk<T>(it.m[2], it.m[3]);
     }
   }
-  QCHK(arena_upload(s, gates.data(), gates.size() * sizeof(TileGate<T>), 0));
+  const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
+  static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
+  QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
+  if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
+  const amp_t<T>* dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
   TileDesc d;
   memset(&d, 0, sizeof d);
   d.ngates = (uint32_t)gates.size();
@@ -1573,7 +1589,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     for (uint32_t i = 0; i < (uint32_t)gates.size(); ++i) {
       std::vector<uint32_t> add;
       if (gates[i].kind == 0) add = {gates[i].b0};
-      if (gates[i].kind == 2) add = {gates[i].b0, gates[i].b1};
+      if (gates[i].kind == 2 || gates[i].kind == 3) add = {gates[i].b0, gates[i].b1};
       if (!add.empty()) {
         // a control of a dense gate / swap is a scalar branch on a pass bit but a per-lane select on a lane
         // bit (k_tile_passes): make the in-tile controls pass bits too whenever the three slots allow
@@ -1598,7 +1614,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     close_pass((uint32_t)gates.size());
     if (!pass_layout_ok) return fail(QIP_ERR_UNSUPPORTED, "tile pass: lane-bit assignment is not a bijection (internal error)");
 #define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream, \
-                                   (amp_t<T>*)s->cur, ins, pd, dg)
+                                   (amp_t<T>*)s->cur, ins, pd, dg, dmats)
     if (use_nt(s)) TP(true);
     else TP(false);
 #undef TP
@@ -1625,7 +1641,7 @@ struct TileStep {
 // qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it shares no qubit with;
 // without `reorder` it does so only when it, or every op it overtakes, is rounding-free.
 static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
-                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps) {
+                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps, bool allow_2q = true) {
   std::vector<TileItem>& items = *items_out;
   items.assign(count, TileItem());
   for (uint64_t i = 0; i < count; ++i) {
@@ -1634,6 +1650,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       std::string msg = g_last_error;
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
     }
+    if (items[i].kind == 3 && !allow_2q) items[i].tileable = false;  // k_tile_gates has no 2-qubit form
   }
   std::vector<char> done(count, 0);
   uint64_t head = 0;
@@ -1669,7 +1686,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         // controls and diagonal targets may stay outside (block-uniform predicates)
         std::vector<uint32_t> exch;
         if (it.kind == 0) exch = {it.t0};
-        if (it.kind == 2) exch = {it.t0, it.t1};
+        if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
         for (uint32_t p : exch)
           if (p >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
@@ -1709,7 +1726,7 @@ template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
   std::vector<TileItem> items;
   std::vector<TileStep> steps;
-  QCHK(schedule_tiles(s->dtype, s->n, ops, count, reorder, &items, &steps));
+  QCHK(schedule_tiles(s->dtype, s->n, ops, count, reorder, &items, &steps, s->tile_passes != 0));
   for (const TileStep& st : steps) {
     if (st.ops.size() == 1) {
       QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));

@@ -619,7 +619,8 @@ constexpr int kTileMaxGates = 64;  // a gate riding along costs ~0.2 ms at n = 3
 // (`omask` / `tpos_out`, amplitude-index space) instead of per element (`cmask` / `b0`, tile-index space).
 constexpr uint32_t kTileOutside = 0xffffffffu;
 template <typename T> struct TileGate {
-  uint32_t kind;      // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap
+  uint32_t kind;      // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap,
+                      // 3 = dense 2-qubit (b0 = bit of the sub-index MSB, b1 = LSB; nz = index of its 4x4 matrix)
   uint32_t b0, b1;    // tile-index bit(s): target (kinds 0, 1; kTileOutside for a diagonal target outside the tile)
                       // or the two swapped bits (kind 2, b0 < b1).  Kind 0 keeps flags in b1:
                       //   bit 0: every matrix entry is real  -> 2 multiplies per product instead of 4 mul + 2 add
@@ -945,13 +946,41 @@ __device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[
   }
 }
 
+// dense 2-qubit gate on pass bits JA (sub-index MSB) and JB: the lane's eight elements are two quads (the third
+// pass bit JC = 0 / 1); out[r] = sum_c M[r][c] * in[c] with the fold order of k_gate_kq (all 16 products, columns
+// ascending), so circuit-order sweeps stay IEEE-equal to the gate-by-gate path.
+template <typename T, int JA, int JB>
+__device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+                                            bool lane_ctl, bool lane_ok) {
+  using A = amp_t<T>;
+  constexpr int JC = 3 - JA - JB;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int base = q << JC;
+    if ((c[base] & cm) != cm) continue;  // controls never sit on JA / JB: one test per quad
+    QIP_KEEP_BRANCH();
+    A x[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = e[base | ((s >> 1) << JA) | ((s & 1) << JB)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      A acc = cmul(M[r * 4], x[0]);
+#pragma unroll
+      for (int s = 1; s < 4; ++s) acc = cadd(acc, cmul(M[r * 4 + s], x[s]));
+      const int i = base | ((r >> 1) << JA) | ((r & 1) << JB);
+      e[i] = lane_ctl ? tile_sel(lane_ok, acc, x[r]) : acc;
+    }
+  }
+}
+
 // __launch_bounds__(kBlock, 5): five waves per SIMD = the five 32-KiB tiles that fit a CU's LDS.  The sweep is
 // latency-bound per wave (scalar gate fetch -> branch -> short VALU body, per gate), so resident blocks are what
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
 // (f32 keeps the default: its 16-KiB tiles already allow more, and under the bound hipcc 7.2 spills its tile.)
 template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
-                                                                              const TileGate<T>* __restrict__ gates) {
+                                                                              const TileGate<T>* __restrict__ gates,
+                                                                              const amp_t<T>* __restrict__ mats) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
@@ -1037,6 +1066,16 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
           else if (g.b0 == ps.pb[1]) pass_dense_lane<T, 1>(g, e, c, cm_reg, lane_ok);
           else pass_dense_lane<T, 2>(g, e, c, cm_reg, lane_ok);
         }
+      } else if (g.kind == 3) {
+        const amp_t<T>* M = mats + 16u * g.nz;
+        const int ja = g.b0 == ps.pb[0] ? 0 : g.b0 == ps.pb[1] ? 1 : 2;
+        const int jb = g.b1 == ps.pb[0] ? 0 : g.b1 == ps.pb[1] ? 1 : 2;
+        if (ja == 0 && jb == 1) pass_dense2<T, 0, 1>(M, e, c, cm_reg, lane_ctl, lane_ok);
+        else if (ja == 0 && jb == 2) pass_dense2<T, 0, 2>(M, e, c, cm_reg, lane_ctl, lane_ok);
+        else if (ja == 1 && jb == 0) pass_dense2<T, 1, 0>(M, e, c, cm_reg, lane_ctl, lane_ok);
+        else if (ja == 1 && jb == 2) pass_dense2<T, 1, 2>(M, e, c, cm_reg, lane_ctl, lane_ok);
+        else if (ja == 2 && jb == 0) pass_dense2<T, 2, 0>(M, e, c, cm_reg, lane_ctl, lane_ok);
+        else pass_dense2<T, 2, 1>(M, e, c, cm_reg, lane_ctl, lane_ok);
       } else {
         const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
         const bool b1 = g.b1 == ps.pb[1];

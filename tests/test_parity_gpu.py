@@ -1068,9 +1068,13 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
         elif shape == 5:  # (controlled) swap
             g = q.make_swap_op([perm[0]], [perm[1]])
             ops.append(q.make_control_op(perm[2:2 + nc], g) if nc else g)
-        elif shape == 6:  # not tileable: dense 2-qubit gate / 2+2 swap
-            if rng.integers(0, 2):
-                ops.append(q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel()))
+        elif shape == 6:  # dense 2-qubit gate with 0..2 controls (tileable) / 3-qubit gate, 2+2 swap (not)
+            pick = int(rng.integers(0, 4))
+            if pick <= 1:
+                g = q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel())
+                ops.append(q.make_control_op(perm[2:2 + min(nc, 2)], g) if nc and pick else g)
+            elif pick == 2:
+                ops.append(q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()))
             else:
                 ops.append(q.make_swap_op(perm[:2], perm[2:4]))
         else:  # sparse (generic gather path)
@@ -1078,12 +1082,14 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
     x = circuits.random_state(n, seed=seed)
     want = O.apply_ops_in_place(n, ops, x.copy())
     with q.HipState(n) as st:
+        st.set_option("mfma", 0)  # dense k = 3 on the VALU: bit-equal to the oracle (the matrix cores are an fma chain)
         st.upload(x)
         st.apply_ops(ops)
         eager = st.download()
     assert np.array_equal(eager, want)
     for mode in (1, 2):
         with q.HipState(n) as st:
+            st.set_option("mfma", 0)
             st.set_option("tile", mode)
             st.upload(x)
             st.apply_ops(ops)
@@ -1093,6 +1099,7 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
         else:
             assert np.max(np.abs(got - eager)) <= TOL64 * max(1.0, float(np.max(np.abs(eager)))), (n, seed)
     with q.HipState(n) as st:
+        st.set_option("mfma", 0)
         st.set_option("tile", 1)
         st.upload(x)
         prog = st.compile_program(ops)

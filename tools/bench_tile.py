@@ -14,6 +14,20 @@ import rustqip_amd as q  # noqa: E402
 from rustqip_amd import circuits  # noqa: E402
 
 
+def brickwork(n, layers, seed=7):
+    """layers of random dense 2-qubit unitaries on neighbouring qubits (even / odd bonds alternate)"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    ops = []
+    for layer in range(layers):
+        for a in range(layer % 2, n - 1, 2):
+            m = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+            u, _ = np.linalg.qr(m)
+            ops.append(q.make_matrix_op([a, a + 1], u.ravel()))
+    return ops
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -22,6 +36,7 @@ def main():
         "c4": circuits.c4_clifford_t(n, 256, seed=32),
         "qft": circuits.c3_qft(n),
         "grover": circuits.c5_grover_iteration(n),
+        "brick2q": brickwork(n, 4),
     }
     if len(sys.argv) > 3:
         cases = {k: v for k, v in cases.items() if k in sys.argv[3].split(",")}
