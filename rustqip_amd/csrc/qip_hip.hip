@@ -17,6 +17,8 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <exception>
+#include <new>
 #include <type_traits>
 #include <vector>
 
@@ -54,25 +56,33 @@ static int fail(int code, const char* fmt, ...) {
     if (rc_ != QIP_OK) return rc_; \
   } while (0)
 
+// No C++ exception may cross the C ABI (include/qip_hip.h: "never aborts or throws"): every entry point that can
+// allocate is a function-try-block ending in this handler, which turns std::bad_alloc / std::length_error / ...
+// into a status + message like any other failure.
+#define QIP_CATCH_ALL                                                                       \
+  catch (const std::bad_alloc&) { return fail(QIP_ERR_DEVICE, "out of host memory"); }      \
+  catch (const std::exception& e) { return fail(QIP_ERR_INVALID, "internal error: %s", e.what()); } \
+  catch (...) { return fail(QIP_ERR_INVALID, "internal error: unknown C++ exception"); }
+
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
 extern "C" int qip_hip_abi_version(void) { return 1; }
-extern "C" int qip_hip_device_count(void) {
+extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return c;
-}
+} QIP_CATCH_ALL
 
 static int64_t g_force_generic = 0;
-extern "C" int qip_hip_set_global_option(const char* key, int64_t value) {
+extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
     return QIP_OK;
   }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // op flattening + validation
@@ -178,10 +188,10 @@ static int flatten_op(uint32_t n, const qip_op* op, bool strict, FlatOp* f) {
   return QIP_OK;
 }
 
-extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) {
+extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) try {
   FlatOp f;
   return flatten_op(n, op, /*strict=*/true, &f);
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // kernel classes (profiling + algorithmic bytes)
@@ -326,7 +336,7 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
   return QIP_OK;
 }
 
-extern "C" int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op* op, double* bytes) {
+extern "C" int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op* op, double* bytes) try {
   if (!bytes) return fail(QIP_ERR_INVALID, "null output");
   if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   FlatOp f;
@@ -337,7 +347,7 @@ extern "C" int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op*
   // prices Swap at the full vector; keep that convention for the reported figure.
   *bytes = p.alg_bytes;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // state handle
@@ -448,7 +458,7 @@ static int state_new(uint32_t n, int dtype, int device, qip_hip_state** out) {
   return QIP_OK;
 }
 
-extern "C" int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_state** out) {
+extern "C" int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_state** out) try {
   QCHK(state_new(n, dtype, device, out));
   qip_hip_state* s = *out;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -466,10 +476,10 @@ extern "C" int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_s
     return fail(QIP_ERR_DEVICE, "allocating a %u-qubit state failed: %s", n, hipGetErrorString(e));
   }
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps, void* scratch,
-                                  void* stream, qip_hip_state** out) {
+                                  void* stream, qip_hip_state** out) try {
   if (!amps) return fail(QIP_ERR_INVALID, "null amplitude buffer");
   QCHK(state_new(n, dtype, device, out));
   qip_hip_state* s = *out;
@@ -480,11 +490,11 @@ extern "C" int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps,
   s->stream = (hipStream_t)stream;
   s->owns_stream = false;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 static void programs_orphan(qip_hip_state* s);
 
-extern "C" int qip_hip_state_destroy(qip_hip_state* s) {
+extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
   if (!s) return QIP_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -501,7 +511,7 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) {
   if (s->owns_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 #define STATE_ENTER(s)                                        \
   if (!(s)) return fail(QIP_ERR_INVALID, "null state handle"); \
@@ -524,7 +534,7 @@ static inline unsigned grid_stride(uint64_t items) {
   return (unsigned)std::min<uint64_t>(std::max<uint64_t>((items + kBlock - 1) / kBlock, 1), 256 * 16);
 }
 
-extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) {
+extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
   STATE_ENTER(s);
   if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
@@ -537,9 +547,9 @@ extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) {
   }
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len) {
+extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len) try {
   STATE_ENTER(s);
   if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "upload range out of bounds");
   if (len == 0) return QIP_OK;
@@ -548,9 +558,9 @@ extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t 
                         hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offset, uint64_t len) {
+extern "C" int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offset, uint64_t len) try {
   STATE_ENTER(s);
   if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "download range out of bounds");
   if (len == 0) return QIP_OK;
@@ -559,37 +569,37 @@ extern "C" int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offs
                         hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_device_ptr(qip_hip_state* s, void** amps) {
+extern "C" int qip_hip_state_device_ptr(qip_hip_state* s, void** amps) try {
   if (!s || !amps) return fail(QIP_ERR_INVALID, "null argument");
   *amps = s->cur;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch) {
+extern "C" int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch) try {
   STATE_ENTER(s);
   if (!scratch) return fail(QIP_ERR_INVALID, "null argument");
   QCHK(ensure_alt(s));
   *scratch = s->alt;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) {
+extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) try {
   STATE_ENTER(s);
   QCHK(ensure_alt(s));
   std::swap(s->cur, s->alt);
   std::swap(s->owns_cur, s->owns_alt);
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_sync(qip_hip_state* s) {
+extern "C" int qip_hip_state_sync(qip_hip_state* s) try {
   STATE_ENTER(s);
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value) {
+extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value) try {
   if (!s || !key) return fail(QIP_ERR_INVALID, "null argument");
   if (!strcmp(key, "force_generic")) s->force_generic = value;
   else if (!strcmp(key, "profile")) s->profile = value;
@@ -602,7 +612,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 // ---- profiling ---------------------------------------------------------------------------
 static int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r) {
@@ -641,7 +651,7 @@ static int prof_drain(qip_hip_state* s) {
 }
 
 extern "C" int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
-                                         double* total_ms, double* algorithmic_bytes) {
+                                         double* total_ms, double* algorithmic_bytes) try {
   STATE_ENTER(s);
   if (cls < 0 || cls >= KC_COUNT) return fail(QIP_ERR_INVALID, "bad kernel class %d", cls);
   QCHK(prof_drain(s));
@@ -649,8 +659,8 @@ extern "C" int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* la
   if (total_ms) *total_ms = s->prof_ms[cls];
   if (algorithmic_bytes) *algorithmic_bytes = s->prof_bytes[cls];
   return QIP_OK;
-}
-extern "C" int qip_hip_state_profile_reset(qip_hip_state* s) {
+} QIP_CATCH_ALL
+extern "C" int qip_hip_state_profile_reset(qip_hip_state* s) try {
   STATE_ENTER(s);
   QCHK(prof_drain(s));
   for (int c = 0; c < KC_COUNT; ++c) {
@@ -659,7 +669,7 @@ extern "C" int qip_hip_state_profile_reset(qip_hip_state* s) {
     s->prof_bytes[c] = 0;
   }
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // launchers
@@ -1152,10 +1162,10 @@ static int apply_op_t(qip_hip_state* s, const qip_op* op) {
   return QIP_OK;
 }
 
-extern "C" int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op) {
+extern "C" int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op) try {
   STATE_ENTER(s);
   return s->dtype == QIP_C64 ? apply_op_t<double>(s, op) : apply_op_t<float>(s, op);
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // gate fusion: option "fuse" = K merges consecutive small gates into dense
@@ -1709,7 +1719,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
 }
 
 extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
-                                  int64_t* step_of_op, uint64_t* n_steps) {
+                                  int64_t* step_of_op, uint64_t* n_steps) try {
   if ((count && (!ops || !step_of_op)) || !n_steps) return fail(QIP_ERR_INVALID, "null argument");
   if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
@@ -1720,7 +1730,7 @@ extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint
     for (uint64_t i : steps[si].ops) step_of_op[i] = (int64_t)si;
   *n_steps = steps.size();
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
@@ -1739,7 +1749,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
   return QIP_OK;
 }
 
-extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) {
+extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) try {
   STATE_ENTER(s);
   if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
   if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
@@ -1758,7 +1768,7 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     }
   }
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // programs: a circuit captured once into a hipGraph and replayed with one launch
@@ -1846,7 +1856,7 @@ static int program_capture(qip_hip_program* p) {
 }
 
 extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint64_t count,
-                                      qip_hip_program** out) {
+                                      qip_hip_program** out) try {
   STATE_ENTER(s);
   if (!out || (count && !ops)) return fail(QIP_ERR_INVALID, "null argument");
   for (uint64_t i = 0; i < count; ++i) {
@@ -1869,9 +1879,9 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
   s->programs.push_back(p);
   *out = p;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_program_run(qip_hip_program* p) {
+extern "C" int qip_hip_program_run(qip_hip_program* p) try {
   if (!p) return fail(QIP_ERR_INVALID, "null program");
   qip_hip_state* s = p->s;
   if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
@@ -1887,11 +1897,11 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) {
   }
   p->last_was_graph = 0;
   return qip_hip_state_apply_ops(s, p->ops, p->count);
-}
+} QIP_CATCH_ALL
 
-extern "C" int qip_hip_program_is_graph(const qip_hip_program* p) { return p ? p->last_was_graph : 0; }
+extern "C" int qip_hip_program_is_graph(const qip_hip_program* p) try { return p ? p->last_was_graph : 0; } QIP_CATCH_ALL
 
-extern "C" int qip_hip_program_destroy(qip_hip_program* p) {
+extern "C" int qip_hip_program_destroy(qip_hip_program* p) try {
   if (!p) return QIP_OK;
   if (p->s) {
     (void)hipSetDevice(p->s->device);
@@ -1902,7 +1912,7 @@ extern "C" int qip_hip_program_destroy(qip_hip_program* p) {
   program_drop_graph(p);
   delete p;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // host-pointer twin of apply_op / apply_op_overwrite
@@ -1969,14 +1979,14 @@ static int apply_op_host_t(int dtype, uint32_t n, const qip_op* op, const void* 
 
 extern "C" int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op, const void* in,
                                      uint64_t in_len, void* out, uint64_t out_len, uint64_t in_off,
-                                     uint64_t out_off, int accumulate) {
+                                     uint64_t out_off, int accumulate) try {
   if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   if ((in_len && !in) || (out_len && !out)) return fail(QIP_ERR_INVALID, "null buffer");
   if (n == 0 || n > 40) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 40]", n);
   return dtype == QIP_C64
              ? apply_op_host_t<double>(dtype, n, op, in, in_len, out, out_len, in_off, out_off, accumulate)
              : apply_op_host_t<float>(dtype, n, op, in, in_len, out, out_len, in_off, out_off, accumulate);
-}
+} QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
 // measurement
@@ -2014,7 +2024,7 @@ static int chunk_norms(qip_hip_state* s, uint64_t* chunk_out, std::vector<double
   return QIP_OK;
 }
 
-extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) {
+extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) try {
   STATE_ENTER(s);
   if (!out) return fail(QIP_ERR_INVALID, "null output");
   std::vector<double> sums;
@@ -2024,7 +2034,7 @@ extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) {
   for (double v : sums) t += v;
   *out = t;
   return QIP_OK;
-}
+} QIP_CATCH_ALL
 
 template <typename T>
 static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vector<uint32_t>& pos,
@@ -2098,7 +2108,7 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
 }
 
 extern "C" int qip_hip_state_measure_probs(qip_hip_state* s, const uint64_t* indices, uint32_t k,
-                                           double* out) {
+                                           double* out) try {
   STATE_ENTER(s);
   if (!out) return fail(QIP_ERR_INVALID, "null output");
   MeasDesc md;
@@ -2107,10 +2117,10 @@ extern "C" int qip_hip_state_measure_probs(qip_hip_state* s, const uint64_t* ind
   if (k > 30) return fail(QIP_ERR_UNSUPPORTED, "measure_probs over %u qubits", k);
   return s->dtype == QIP_C64 ? measure_probs_t<double>(s, md, pos, 0, 1ull << k, out)
                              : measure_probs_t<float>(s, md, pos, 0, 1ull << k, out);
-}
+} QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, const uint64_t* indices,
-                                          uint32_t k, double* out) {
+                                          uint32_t k, double* out) try {
   STATE_ENTER(s);
   if (!out) return fail(QIP_ERR_INVALID, "null output");
   MeasDesc md;
@@ -2119,7 +2129,7 @@ extern "C" int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, c
   if (k < 64 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
   return s->dtype == QIP_C64 ? measure_probs_t<double>(s, md, pos, measured, 1, out)
                              : measure_probs_t<float>(s, md, pos, measured, 1, out);
-}
+} QIP_CATCH_ALL
 
 static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p);
 
@@ -2162,7 +2172,7 @@ static int soft_measure_t(qip_hip_state* s, const MeasDesc& md, double rand_u01,
 }
 
 extern "C" int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
-                                          double rand_u01, uint64_t* measured) {
+                                          double rand_u01, uint64_t* measured) try {
   STATE_ENTER(s);
   if (!measured) return fail(QIP_ERR_INVALID, "null output");
   MeasDesc md;
@@ -2170,10 +2180,10 @@ extern "C" int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indi
   QCHK(check_measure_indices(s, indices, k, &md, &pos));
   return s->dtype == QIP_C64 ? soft_measure_t<double>(s, md, rand_u01, measured)
                              : soft_measure_t<float>(s, md, rand_u01, measured);
-}
+} QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
-                                     int64_t forced, double rand_u01, uint64_t* measured, double* prob) {
+                                     int64_t forced, double rand_u01, uint64_t* measured, double* prob) try {
   STATE_ENTER(s);
   if (!measured || !prob) return fail(QIP_ERR_INVALID, "null output");
   MeasDesc md;
@@ -2193,7 +2203,7 @@ extern "C" int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, 
   *measured = m;
   *prob = p;
   return collapse(s, md, m, p);
-}
+} QIP_CATCH_ALL
 
 static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p) {
   if (p == 0.0) return QIP_OK;  // measure_state is a no-op (:230)
@@ -2216,7 +2226,7 @@ static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p) 
 }
 
 extern "C" int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* indices, uint32_t k,
-                                           uint64_t measured, double prob) {
+                                           uint64_t measured, double prob) try {
   STATE_ENTER(s);
   MeasDesc md;
   memset(&md, 0, sizeof md);
@@ -2225,4 +2235,4 @@ extern "C" int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* ind
   if (k < 64 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
   if (!(prob >= 0.0)) return fail(QIP_ERR_INVALID, "probability must be >= 0");
   return collapse(s, md, measured, prob);
-}
+} QIP_CATCH_ALL
