@@ -255,10 +255,38 @@ template <typename P> class HipState {
     auto c = op.to_c();
     check(qip_hip_state_apply_op(h_, &c->op));
   }
+  /// A run of gates in one call, so the library may schedule them (options "tile", "fuse").
+  void apply_ops(const std::vector<MatrixOp<P>>& ops) {
+    std::vector<std::unique_ptr<typename MatrixOp<P>::CView>> views;
+    std::vector<qip_op> flat;
+    views.reserve(ops.size());
+    flat.reserve(ops.size());
+    for (const auto& op : ops) {
+      views.push_back(op.to_c());
+      flat.push_back(views.back()->op);
+    }
+    check(qip_hip_state_apply_ops(h_, flat.data(), flat.size()));
+  }
+  void set_option(const char* key, int64_t value) { check(qip_hip_state_set_option(h_, key, value)); }
+  void sync() { check(qip_hip_state_sync(h_)); }
   double norm_sqr() const {
     double v = 0;
     check(qip_hip_state_norm_sqr(h_, &v));
     return v;
+  }
+  /// measure_prob (measurement_ops.rs:44-112): probability of outcome `measured` on `indices`.
+  double measure_prob(size_t measured, const std::vector<size_t>& indices) const {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    double v = 0;
+    check(qip_hip_state_measure_prob(h_, measured, idx.data(), (uint32_t)idx.size(), &v));
+    return v;
+  }
+  /// soft_measure (measurement_ops.rs:153-176) with the caller's uniform sample.
+  size_t soft_measure(const std::vector<size_t>& indices, double rand_u01) const {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    uint64_t m = 0;
+    check(qip_hip_state_soft_measure(h_, idx.data(), (uint32_t)idx.size(), rand_u01, &m));
+    return size_t(m);
   }
   std::vector<double> measure_probs(const std::vector<size_t>& indices) const {
     std::vector<uint64_t> idx(indices.begin(), indices.end());

@@ -30,10 +30,10 @@ int main(int argc, char** argv) {
     if (!in) throw qip::CircuitError(std::string("cannot open ") + path);
     const auto circ = qip::replay::load<double>(in);
     qip::HipState<double> st(circ.n);
-    qip::check(qip_hip_state_set_option(st.handle(), "tile", tile));
+    st.set_option("tile", tile);
     const auto t0 = std::chrono::steady_clock::now();
     const auto results = qip::replay::run(circ, st);
-    qip::check(qip_hip_state_sync(st.handle()));
+    st.sync();
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (const auto& r : results) {
       if (r.stochastic) {
