@@ -1376,6 +1376,10 @@ struct TileItem {
   double m[8] = {0};
   uint32_t nz = 0;
   std::vector<double> mat;  // kind 3: 4x4 row-major as re,im pairs, sub-index MSB = t0
+  // how the gate acts on each of its bits: `nd_mask` = it exchanges amplitudes across the bit (dense target, swap
+  // bits), `d_mask` = it only tests the bit (controls, diagonal targets).  Two gates commute when on every bit
+  // they share both only test it.  Ops that are not tileable count every bit as exchanged.
+  uint64_t nd_mask = 0, d_mask = 0;
 };
 
 static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it) {
@@ -1433,6 +1437,15 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
     it->tileable = true;
   } else if (p.cls == KC_NOOP) {
     it->exact = true;  // identity: nothing happens (not tileable, launches nothing)
+  }
+  it->nd_mask = it->d_mask = 0;
+  if (it->tileable) {
+    for (uint32_t c : p.cpos) it->d_mask |= 1ull << c;
+    if (it->kind == 1) it->d_mask |= 1ull << it->t0;
+    else it->nd_mask |= 1ull << it->t0;
+    if (it->kind >= 2) it->nd_mask |= 1ull << it->t1;
+  } else {
+    for (uint32_t b : it->pos) it->nd_mask |= 1ull << b;
   }
   return QIP_OK;
 }
@@ -1648,8 +1661,8 @@ struct TileStep {
 };
 
 // Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
-// qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it shares no qubit with;
-// without `reorder` it does so only when it, or every op it overtakes, is rounding-free.
+// qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it commutes with (on every
+// shared bit both only test it); without `reorder` only when it, or every op it overtakes, is rounding-free.
 static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
                           std::vector<TileItem>* items_out, std::vector<TileStep>* steps, bool allow_2q = true) {
   std::vector<TileItem>& items = *items_out;
@@ -1676,20 +1689,20 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       continue;
     }
     // Grow a segment from `head`, scanning ahead.  A later gate may join over the gates skipped so far only if
-    // it shares no qubit with any of them (they commute) and, unless `reorder` (which accepts rounding-level
+    // it commutes with each of them — on every bit they share, both gates only TEST the bit (control or diagonal
+    // target), neither exchanges amplitudes across it — and, unless `reorder` (which accepts rounding-level
     // differences), the commutation is EXACT: the gate itself, or every skipped gate, is rounding-free
     // (entries in {0, +-1, +-i}: X, Y, Z, S, CNOT, CZ, Toffoli, SWAP ...).  Exact commutations leave every
     // amplitude's sequence of rounded operations unchanged, so the result stays IEEE-equal to circuit order.
     TileStep st;
-    uint64_t blocked = 0;          // bit positions of gates skipped so far
-    bool skipped_inexact = false;  // some skipped gate rounds
+    uint64_t blocked_nd = 0, blocked_d = 0;  // bits the skipped gates exchange across / only test
+    bool skipped_inexact = false;            // some skipped gate rounds
     bool any_skipped = false;
     for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && st.ops.size() < (size_t)kTileMaxGates; ++i) {
       if (done[i]) continue;
       const TileItem& it = items[i];
-      uint64_t mask = 0;
-      for (uint32_t p : it.pos) mask |= 1ull << p;
-      bool fits = it.tileable && !(mask & blocked) && (reorder || it.exact || !skipped_inexact);
+      const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact);
       std::vector<uint32_t> need;
       if (fits) {
         // only bits the gate exchanges amplitudes across must be tile bits: a dense target, both swap bits;
@@ -1708,7 +1721,8 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         st.ops.push_back(i);
         done[i] = 1;
       } else {
-        blocked |= mask;
+        blocked_nd |= it.nd_mask;
+        blocked_d |= it.d_mask;
         skipped_inexact = skipped_inexact || !it.exact;
         any_skipped = true;
       }
