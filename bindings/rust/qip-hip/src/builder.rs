@@ -103,18 +103,16 @@ pub fn lower(indices: &[usize], obj: &UnitaryMatrixObject<f64>) -> CircuitResult
     Ok(Some(op))
 }
 
-/// Basis index of the initial state (`builder.rs:409-421`): bit `n-1-q` of the index is the value bit of
-/// qubit `q`, registers given most-significant qubit first.
+/// Basis index of the initial state (`builder.rs:409-421`): bit `k` of a register's value belongs to the
+/// register's `k`-th qubit `q = indices[k]`, which is bit `n-1-q` of the state index.
 pub fn initial_index<'a, It>(n: usize, it: It) -> usize
 where
     It: IntoIterator<Item = (&'a Qudit, usize)>,
 {
     let mut index = 0usize;
     for (reg, value) in it {
-        let width = reg.n();
-        for (pos, &q) in reg.indices().iter().enumerate() {
-            let bit = (value >> (width - 1 - pos)) & 1;
-            index |= bit << (n - 1 - q);
+        for (k, &q) in reg.indices().iter().enumerate() {
+            index |= ((value >> k) & 1) << (n - 1 - q);
         }
     }
     index
