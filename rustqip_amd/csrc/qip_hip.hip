@@ -1507,9 +1507,12 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   }
   const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
   static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
-  QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
-  if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
-  const amp_t<T>* dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
+  auto upload_gates = [&]() -> int {  // after the gates are final (k_tile_passes resolves them per pass first)
+    QCHK(ensure_arena(s, gates_bytes + mats.size() * sizeof(amp_t<T>)));  // one allocation: growing frees the old arena
+    QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
+    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
+    return QIP_OK;
+  };
   TileDesc d;
   memset(&d, 0, sizeof d);
   d.ngates = (uint32_t)gates.size();
@@ -1517,10 +1520,17 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
   const uint64_t ntiles = 1ull << (s->n - kTileBits);
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
-  const TileGate<T>* dg = (const TileGate<T>*)s->arena;
+  const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
+  const amp_t<T>* dmats = nullptr;
   ProfRec rec;
   rec.cls = KC_TILE_GATES;
-  if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+  auto begin = [&]() -> int {  // descriptors up, then the timed region starts
+    QCHK(upload_gates());
+    dg = (const TileGate<T>*)s->arena;
+    dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    return QIP_OK;
+  };
   if (s->tile_passes) {
     // group consecutive gates into passes of at most three distinct exchange bits (see k_tile_passes)
     TilePassDesc pd;
@@ -1636,17 +1646,50 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     }
     close_pass((uint32_t)gates.size());
     if (!pass_layout_ok) return fail(QIP_ERR_UNSUPPORTED, "tile pass: lane-bit assignment is not a bijection (internal error)");
+    // resolve every gate against its pass: code path, pass-bit index of its bit(s), controls split into pass-bit
+    // and lane-bit parts (see TileGate::op)
+    for (uint32_t pi = 0; pi < pd.npasses; ++pi) {
+      const TilePass& ps = pd.pass[pi];
+      const uint32_t passmask = (1u << ps.pb[0]) | (1u << ps.pb[1]) | (1u << ps.pb[2]);
+      auto jof = [&](uint32_t bit) { return bit == ps.pb[0] ? 0u : bit == ps.pb[1] ? 1u : 2u; };
+      for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+        TileGate<T>& g = gates[gi];
+        g.cm_reg = g.cmask & passmask;
+        g.cm_lane = g.cmask & ~passmask;
+        const bool lane_ctl = g.cm_lane != 0u;
+        if (g.kind == 1) {
+          const bool outside = g.b0 == kTileOutside;
+          if (outside && !lane_ctl) g.op = TOP_DIAG_UNIFORM;
+          else if (outside || !((passmask >> g.b0) & 1u)) g.op = lane_ctl ? TOP_DIAG_LANE_CTL : TOP_DIAG_LANE;
+          else g.op = TOP_DIAG_REG0 + jof(g.b0);
+        } else if (g.kind == 0) {
+          g.op = (lane_ctl ? TOP_DENSE_LANE0 : TOP_DENSE0) + jof(g.b0);
+        } else if (g.kind == 3) {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1);
+          static const uint32_t table[3][3] = {{0, TOP_DENSE2Q_01, TOP_DENSE2Q_02},
+                                               {TOP_DENSE2Q_10, 0, TOP_DENSE2Q_12},
+                                               {TOP_DENSE2Q_20, TOP_DENSE2Q_21, 0}};
+          g.op = table[ja][jb];
+        } else {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1);  // b0 < b1 and pass bits ascend, so ja < jb
+          g.op = ja == 0 ? (jb == 1 ? TOP_SWAP_01 : TOP_SWAP_02) : TOP_SWAP_12;
+        }
+      }
+    }
+    QCHK(begin());
 #define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream, \
                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats)
     if (use_nt(s)) TP(true);
     else TP(false);
 #undef TP
-  } else if (use_nt(s)) {
-    hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
-                       (amp_t<T>*)s->cur, ins, d, dg);
   } else {
-    hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
-                       (amp_t<T>*)s->cur, ins, d, dg);
+    QCHK(begin());
+    if (use_nt(s))
+      hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, d, dg);
+    else
+      hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, d, dg);
   }
   HIPCHK(hipGetLastError());
   if (s->profile) QCHK(prof_end(s, &rec));

@@ -631,7 +631,24 @@ template <typename T> struct TileGate {
   uint32_t nz;        // kind 0: non-zero mask of the 2x2 entries
   uint32_t tpos_out;  // kind 1 with b0 == kTileOutside: amplitude-index position of the target
   uint64_t omask;     // amplitude-index bits outside the tile that must all be 1 (controls outside the tile)
+  // k_tile_passes only, resolved by the host against the pass the gate belongs to — the kernel is bound by
+  // instruction issue, scalar instructions included, so nothing that depends only on (gate, pass) is recomputed
+  // per wave: `op` selects the code path (TileOp), `cm_reg` / `cm_lane` are cmask split into the controls on pass
+  // bits (wave-uniform per element) and on lane bits (one predicate per gate)
+  uint32_t op, cm_reg, cm_lane, pad_;
   amp_t<T> m[4];      // kind 0: 2x2 row-major; kind 1: m[0] = d0, m[1] = d1
+};
+
+// Code paths of k_tile_passes.  J* = index (0..2) of the pass bit the gate exchanges across / tests.
+enum TileOp : uint32_t {
+  TOP_DIAG_UNIFORM = 0,  // diagonal, target outside the tile, no lane-bit control: one wave-uniform factor
+  TOP_DIAG_LANE,         // diagonal, target on a lane bit (or outside), no lane-bit control: per-lane factor
+  TOP_DIAG_LANE_CTL,     // ... with lane-bit controls folded into the factor
+  TOP_DIAG_REG0, TOP_DIAG_REG1, TOP_DIAG_REG2,  // diagonal, target = pass bit J
+  TOP_DENSE0, TOP_DENSE1, TOP_DENSE2,           // dense 1-qubit on pass bit J, controls (if any) on pass bits
+  TOP_DENSE_LANE0, TOP_DENSE_LANE1, TOP_DENSE_LANE2,  // ... with lane-bit controls (select per lane)
+  TOP_DENSE2Q_01, TOP_DENSE2Q_02, TOP_DENSE2Q_10, TOP_DENSE2Q_12, TOP_DENSE2Q_20, TOP_DENSE2Q_21,  // JA (MSB), JB
+  TOP_SWAP_01, TOP_SWAP_02, TOP_SWAP_12,
 };
 
 struct TileDesc {
@@ -1015,7 +1032,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
 #pragma unroll
     for (int k = 0; k < 8; ++k) tb |= ((tid >> k) & 1u) << ((ps.lanepos >> (4 * k)) & 15u);
     const uint32_t slot_tb = tile_slot<A>(tb);
-    const uint32_t passmask = (1u << ps.pb[0]) | (1u << ps.pb[1]) | (1u << ps.pb[2]);
     uint32_t c[8];
     A e[8];
 #pragma unroll
@@ -1024,64 +1040,58 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
              ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
       e[i] = tile[slot_tb ^ tile_slot<A>(c[i])];
     }
-    for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
-      const TileGate<T> g = gates[gi];  // wave-uniform (prefetching the next descriptor was measured: no gain)
+    const TileGate<T>* gp = gates + ps.first;
+    const TileGate<T>* const gend = gp + ps.count;
+    for (; gp != gend; ++gp) {
+      const TileGate<T> g = *gp;  // wave-uniform (prefetching the next descriptor was measured: no gain)
       if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
-      const uint32_t cm_reg = g.cmask & passmask;   // controls on pass bits: wave-uniform per element
-      const uint32_t cm_lane = g.cmask & ~passmask;  // controls on lane bits: one predicate per gate
-      const bool lane_ctl = cm_lane != 0u;
-      const bool lane_ok = (tb & cm_lane) == cm_lane;
-      if (g.kind == 1) {
-        const bool outside = g.b0 == kTileOutside;
-        if (outside || !((passmask >> g.b0) & 1u)) {
-          // the target bit is the same for the lane's 8 elements: one factor per gate
-          if (outside && !lane_ctl) {
-            const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];  // wave-uniform
-            if (f.x == (T)1 && f.y == (T)0) continue;                       // unit entries leave the amplitude untouched
+      const uint32_t cm_reg = g.cm_reg;
+      switch (g.op) {
+        case TOP_DIAG_UNIFORM: {
+          const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];
+          if (f.x == (T)1 && f.y == (T)0) break;  // unit entries leave the amplitude untouched
+          QIP_KEEP_BRANCH();
+          pass_scale<T, 0, -1>(f, e, c, cm_reg);
+          break;
+        }
+        case TOP_DIAG_LANE:
+        case TOP_DIAG_LANE_CTL: {
+          // per-lane factor: the target bit's entry (a unit entry multiplies exactly), (1, 0) where a lane-bit
+          // control is 0
+          const bool outside = g.b0 == kTileOutside;
+          const bool one = outside ? ((base >> g.tpos_out) & 1ull) != 0 : ((tb >> g.b0) & 1u) != 0;
+          A f = tile_sel(one, g.m[1], g.m[0]);
+          if (g.op == TOP_DIAG_LANE_CTL) {
             QIP_KEEP_BRANCH();
-            pass_scale<T, 0, -1>(f, e, c, cm_reg);
-          } else {
-            QIP_KEEP_BRANCH();
-            // per-lane factor: the target bit's entry (a unit entry multiplies exactly), (1, 0) where a
-            // lane-bit control is 0
-            const bool one = outside ? ((base >> g.tpos_out) & 1ull) != 0 : ((tb >> g.b0) & 1u) != 0;
-            A f = tile_sel(one, g.m[1], g.m[0]);
+            const bool lane_ok = (tb & g.cm_lane) == g.cm_lane;
             f.x = lane_ok ? f.x : (T)1;
             f.y = lane_ok ? f.y : (T)0;
-            pass_scale<T, 0, -1>(f, e, c, cm_reg);
           }
-        } else {
-          if (g.b0 == ps.pb[0]) pass_diag<T, 0>(g, e, c, cm_reg, lane_ctl, lane_ok);
-          else if (g.b0 == ps.pb[1]) pass_diag<T, 1>(g, e, c, cm_reg, lane_ctl, lane_ok);
-          else pass_diag<T, 2>(g, e, c, cm_reg, lane_ctl, lane_ok);
+          pass_scale<T, 0, -1>(f, e, c, cm_reg);
+          break;
         }
-      } else if (g.kind == 0) {
-        if (!lane_ctl) {
-          if (g.b0 == ps.pb[0]) pass_dense<T, 0>(g, e, c, cm_reg);
-          else if (g.b0 == ps.pb[1]) pass_dense<T, 1>(g, e, c, cm_reg);
-          else pass_dense<T, 2>(g, e, c, cm_reg);
-        } else {
-          QIP_KEEP_BRANCH();
-          if (g.b0 == ps.pb[0]) pass_dense_lane<T, 0>(g, e, c, cm_reg, lane_ok);
-          else if (g.b0 == ps.pb[1]) pass_dense_lane<T, 1>(g, e, c, cm_reg, lane_ok);
-          else pass_dense_lane<T, 2>(g, e, c, cm_reg, lane_ok);
-        }
-      } else if (g.kind == 3) {
-        const amp_t<T>* M = mats + 16u * g.nz;
-        const int ja = g.b0 == ps.pb[0] ? 0 : g.b0 == ps.pb[1] ? 1 : 2;
-        const int jb = g.b1 == ps.pb[0] ? 0 : g.b1 == ps.pb[1] ? 1 : 2;
-        if (ja == 0 && jb == 1) pass_dense2<T, 0, 1>(M, e, c, cm_reg, lane_ctl, lane_ok);
-        else if (ja == 0 && jb == 2) pass_dense2<T, 0, 2>(M, e, c, cm_reg, lane_ctl, lane_ok);
-        else if (ja == 1 && jb == 0) pass_dense2<T, 1, 0>(M, e, c, cm_reg, lane_ctl, lane_ok);
-        else if (ja == 1 && jb == 2) pass_dense2<T, 1, 2>(M, e, c, cm_reg, lane_ctl, lane_ok);
-        else if (ja == 2 && jb == 0) pass_dense2<T, 2, 0>(M, e, c, cm_reg, lane_ctl, lane_ok);
-        else pass_dense2<T, 2, 1>(M, e, c, cm_reg, lane_ctl, lane_ok);
-      } else {
-        const bool a0 = g.b0 == ps.pb[0], a1 = g.b0 == ps.pb[1];
-        const bool b1 = g.b1 == ps.pb[1];
-        if (a0 && b1) pass_swap<T, 0, 1>(e, c, cm_reg, lane_ctl, lane_ok);
-        else if (a0) pass_swap<T, 0, 2>(e, c, cm_reg, lane_ctl, lane_ok);
-        else if (a1) pass_swap<T, 1, 2>(e, c, cm_reg, lane_ctl, lane_ok);
+        case TOP_DIAG_REG0: pass_diag<T, 0>(g, e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_DIAG_REG1: pass_diag<T, 1>(g, e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_DIAG_REG2: pass_diag<T, 2>(g, e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_DENSE0: pass_dense<T, 0>(g, e, c, cm_reg); break;
+        case TOP_DENSE1: pass_dense<T, 1>(g, e, c, cm_reg); break;
+        case TOP_DENSE2: pass_dense<T, 2>(g, e, c, cm_reg); break;
+        case TOP_DENSE_LANE0: pass_dense_lane<T, 0>(g, e, c, cm_reg, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_DENSE_LANE1: pass_dense_lane<T, 1>(g, e, c, cm_reg, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_DENSE_LANE2: pass_dense_lane<T, 2>(g, e, c, cm_reg, (tb & g.cm_lane) == g.cm_lane); break;
+#define QIP_D2Q(JA, JB) \
+  pass_dense2<T, JA, JB>(mats + 16u * g.nz, e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane)
+        case TOP_DENSE2Q_01: QIP_D2Q(0, 1); break;
+        case TOP_DENSE2Q_02: QIP_D2Q(0, 2); break;
+        case TOP_DENSE2Q_10: QIP_D2Q(1, 0); break;
+        case TOP_DENSE2Q_12: QIP_D2Q(1, 2); break;
+        case TOP_DENSE2Q_20: QIP_D2Q(2, 0); break;
+        case TOP_DENSE2Q_21: QIP_D2Q(2, 1); break;
+#undef QIP_D2Q
+        case TOP_SWAP_01: pass_swap<T, 0, 1>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_SWAP_02: pass_swap<T, 0, 2>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        case TOP_SWAP_12: pass_swap<T, 1, 2>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+        default: break;
       }
     }
 #pragma unroll
