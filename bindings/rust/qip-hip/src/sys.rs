@@ -88,6 +88,8 @@ extern "C" {
         step_of_op: *mut i64, n_steps: *mut u64,
     ) -> c_int;
 
+    pub fn qip_hip_tile_lane_assignment(dtype: c_int, pass_bits: *const u32, lanepos: *mut u32) -> c_int;
+
     pub fn qip_hip_state_set_option(s: *mut qip_hip_state, key: *const c_char, value: i64) -> c_int;
     pub fn qip_hip_kernel_class_count() -> c_int;
     pub fn qip_hip_kernel_class_name(cls: c_int) -> *const c_char;

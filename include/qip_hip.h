@@ -179,6 +179,13 @@ int qip_hip_program_destroy(qip_hip_program* p);
 int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
                        int64_t* step_of_op, uint64_t* n_steps);
 
+/* Host-only: how one pass of a tile sweep lays the lane id over the tile.  pass_bits = the pass's three exchange
+ * bits (tile-index space 0..10, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the lane id.
+ * The tile is stored in LDS at slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 (QIP_C64) / 5 (QIP_C32); together the two
+ * make every pass free of LDS bank conflicts unless it holds both bits of a pair (j, j+S).  Exposed so the claim
+ * can be checked without a GPU (tests/test_host_ops.py). */
+int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t* lanepos);
+
 /* Options: key is one of
  *   "force_generic"  1 = route every op through the literal gather kernel
  *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)

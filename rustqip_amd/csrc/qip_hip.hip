@@ -1450,6 +1450,67 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
   return QIP_OK;
 }
 
+// Lane-id bit -> tile bit for one pass of k_tile_passes (TilePass::lanepos): lane bit j < S goes on tile bit j or
+// j + S (whichever is not a pass bit), so the S swizzled slot bits enumerate the lanes of an LDS bank group; the
+// other lane bits fill what is left, bits that are not folded (>= 2S) first, then partners of the pairs that hold
+// lane bits 0 and 1 (lane bit 4 varies inside a ds_read_b128 group in a pattern that is closed under flipping lane
+// bits 0 / 1 only).  S = 4 for 16-byte amplitudes, 5 for 8-byte ones.  `pb` ascending and distinct.  Returns 0 if
+// the result is not a bijection onto the non-pass bits (cannot happen; the caller refuses to launch).
+// Checked against the LDS banking model of MI355X_MICROARCH.md in tests/test_host_ops.py.
+static uint32_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
+  auto has = [&](uint32_t t) { return t == pb[0] || t == pb[1] || t == pb[2]; };
+  int pos_of[8];
+  for (int k = 0; k < 8; ++k) pos_of[k] = -1;
+  bool used[kTileBits] = {false};
+  std::vector<int> rest_bits;
+  for (uint32_t j = 0; j < S; ++j) {
+    int where = -1;
+    for (uint32_t c : {j, j + S})
+      if (c < (uint32_t)kTileBits && !has(c) && !used[c]) {
+        where = (int)c;
+        break;
+      }
+    if (where >= 0) {
+      pos_of[j] = where;
+      used[where] = true;
+    } else {
+      rest_bits.push_back((int)j);
+    }
+  }
+  for (int k = (int)S; k < 8; ++k) rest_bits.push_back(k);
+  std::vector<int> rest_pos;
+  for (int t = 0; t < kTileBits; ++t)
+    if (!has((uint32_t)t) && !used[t]) rest_pos.push_back(t);
+  auto rank = [&](int t) {
+    if (t >= (int)(2 * S)) return 0;
+    const int j = t >= (int)S ? t - (int)S : t;
+    for (int k = 0; k < 2; ++k)
+      if (pos_of[k] == j || pos_of[k] == j + (int)S) return 1;
+    return 2;
+  };
+  std::stable_sort(rest_pos.begin(), rest_pos.end(), [&](int x, int y) { return rank(x) < rank(y); });
+  if (rest_bits.size() != rest_pos.size()) return 0;
+  for (size_t q = 0; q < rest_bits.size(); ++q) pos_of[rest_bits[q]] = rest_pos[q];
+  uint32_t lanepos = 0, covered = 0;
+  for (int k = 0; k < 8; ++k) {
+    lanepos |= (uint32_t)pos_of[k] << (4 * k);
+    covered |= 1u << pos_of[k];
+  }
+  for (int j = 0; j < 3; ++j) covered |= 1u << pb[j];
+  return covered == (1u << kTileBits) - 1u ? lanepos : 0u;
+}
+
+extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t* lanepos) try {
+  if (!pass_bits || !lanepos) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  uint32_t pb[3] = {pass_bits[0], pass_bits[1], pass_bits[2]};
+  if (!(pb[0] < pb[1] && pb[1] < pb[2] && pb[2] < (uint32_t)kTileBits))
+    return fail(QIP_ERR_INVALID, "pass bits must be ascending, distinct and below %d", kTileBits);
+  *lanepos = tile_lane_assignment(pb, dtype == QIP_C64 ? 4u : 5u);
+  if (*lanepos == 0u) return fail(QIP_ERR_UNSUPPORTED, "lane-bit assignment is not a bijection (internal error)");
+  return QIP_OK;
+} QIP_CATCH_ALL
+
 template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
                                std::vector<uint32_t> high) {
@@ -1573,49 +1634,8 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       ps.first = first;
       ps.count = end - first;
       for (int j = 0; j < 3; ++j) ps.pb[j] = b[j];
-      // lane-id bit -> tile bit: lane bit j < S goes on bit j or j + S (whichever is not a pass bit), so the S
-      // swizzled slot bits enumerate the lanes of a bank group; the other lane bits fill what is left, bits
-      // that are not folded (>= 2S) first, then partners of the pairs that hold lane bits 0 and 1 (lane bit 4
-      // varies inside a ds_read_b128 group in a pattern that is closed under flipping lane bits 0 / 1 only)
-      int pos_of[8];
-      for (int k = 0; k < 8; ++k) pos_of[k] = -1;
-      bool used[kTileBits] = {false};
-      std::vector<int> rest_bits;
-      for (uint32_t j = 0; j < S; ++j) {
-        int where = -1;
-        for (uint32_t c : {j, j + S})
-          if (c < (uint32_t)kTileBits && !has(c) && !used[c]) {
-            where = (int)c;
-            break;
-          }
-        if (where >= 0) {
-          pos_of[j] = where;
-          used[where] = true;
-        } else {
-          rest_bits.push_back((int)j);
-        }
-      }
-      for (int k = (int)S; k < 8; ++k) rest_bits.push_back(k);
-      std::vector<int> rest_pos;
-      for (int t = 0; t < kTileBits; ++t)
-        if (!has((uint32_t)t) && !used[t]) rest_pos.push_back(t);
-      auto rank = [&](int t) {
-        if (t >= (int)(2 * S)) return 0;
-        const int j = t >= (int)S ? t - (int)S : t;
-        for (int k = 0; k < 2; ++k)
-          if (pos_of[k] == j || pos_of[k] == j + (int)S) return 1;
-        return 2;
-      };
-      std::stable_sort(rest_pos.begin(), rest_pos.end(), [&](int x, int y) { return rank(x) < rank(y); });
-      for (size_t q = 0; q < rest_bits.size(); ++q) pos_of[rest_bits[q]] = rest_pos[q];
-      ps.lanepos = 0;
-      uint32_t covered = 0;
-      for (int k = 0; k < 8; ++k) {
-        ps.lanepos |= (uint32_t)pos_of[k] << (4 * k);
-        covered |= 1u << pos_of[k];
-      }
-      for (int j = 0; j < 3; ++j) covered |= 1u << b[j];
-      if (covered != (1u << kTileBits) - 1u) pass_layout_ok = false;  // not a bijection: refuse to launch
+      ps.lanepos = tile_lane_assignment(ps.pb, S);
+      if (ps.lanepos == 0u) pass_layout_ok = false;  // not a bijection: refuse to launch
       first = end;
       bits.clear();
     };

@@ -233,3 +233,14 @@ def plan_tiles(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64):
     for i in range(len(cops)):
         steps[step_of[i]].append(i)
     return steps
+
+
+def tile_lane_assignment(pass_bits, dtype: int = _ffi.QIP_C64):
+    """Host-only: for one pass of a tile sweep (its three exchange bits, tile-index space, ascending), the
+    tile-index bit each of the 8 lane-id bits fills (qip_hip_tile_lane_assignment)."""
+    pb = (C.c_uint32 * 3)(*pass_bits)
+    out = C.c_uint32()
+    rc = _ffi.lib.qip_hip_tile_lane_assignment(dtype, pb, C.byref(out))
+    if rc != _ffi.QIP_OK:
+        raise CircuitError(_ffi.last_error())
+    return [(out.value >> (4 * k)) & 15 for k in range(8)]

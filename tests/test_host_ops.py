@@ -248,3 +248,59 @@ def test_tile_schedule_invariants():
     print('steps', len(plan_tiles(n, ops, 1)), len(plan_tiles(n, ops, 2)), 'of', len(ops))
     with pytest.raises(q.CircuitError):
         plan_tiles(8, ops[:3], 1)  # n below the tile size
+
+
+@pytest.mark.parametrize("dtype_name", ["c64", "c32"])
+def test_tile_pass_layout_is_a_bijection_and_bank_conflict_free(dtype_name):
+    """The LDS layout of the tile sweeps, checked against the banking model of MI355X_MICROARCH.md (section LDS)
+    without a GPU: for every choice of three pass bits the lane-bit assignment is a bijection onto the other
+    eight tile bits, and with the XOR-swizzled slot function the pass's reads (ds_read_b128: four 16-lane groups
+    over 16 slots of 16 B; 8-byte amplitudes: ds_read_b64, two 32-lane groups over 32 slots) and writes
+    (ds_write_b128: eight 8-lane groups over 8 slots; ds_write_b64: four 16-lane groups over 16 slots) are
+    conflict-free unless the pass holds both bits of a pair (j, j + S) — then exactly 2-way."""
+    import itertools
+
+    from rustqip_amd import _ffi
+    from rustqip_amd.ops import tile_lane_assignment
+
+    if dtype_name == "c64":
+        dtype, S = _ffi.QIP_C64, 4
+        half = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+        read_groups = half + [[lane + 32 for lane in g] for g in half]
+        write_groups = [list(range(8 * k, 8 * k + 8)) for k in range(8)]
+        read_slots, write_slots = 16, 8
+    else:
+        dtype, S = _ffi.QIP_C32, 5
+        read_groups = [list(range(32)), list(range(32, 64))]
+        write_groups = [list(range(16 * k, 16 * k + 16)) for k in range(4)]
+        read_slots, write_slots = 32, 16
+
+    def slot(t):
+        return t ^ ((t >> S) & ((1 << S) - 1))
+
+    def worst(groups, nslots, pos, P):
+        w = 1
+        for wave in range(4):
+            for i in range(8):
+                ibits = sum(((i >> j) & 1) << P[j] for j in range(3))
+                for g in groups:
+                    hit = {}
+                    for lane in g:
+                        tid = wave * 64 + lane
+                        t = ibits | sum(((tid >> k) & 1) << pos[k] for k in range(8))
+                        hit.setdefault(slot(t) % nslots, set()).add(slot(t))
+                    w = max(w, max(len(v) for v in hit.values()))
+        return w
+
+    for P in itertools.combinations(range(11), 3):
+        pos = tile_lane_assignment(P, dtype)
+        assert sorted(pos + list(P)) == list(range(11)), (P, pos)
+        has_pair = any(b + S in P for b in P)
+        r, w = worst(read_groups, read_slots, pos, P), worst(write_groups, write_slots, pos, P)
+        if has_pair:
+            assert r <= 2 and w <= 2, (P, r, w)
+        else:
+            assert (r, w) == (1, 1), (P, r, w)
+    with pytest.raises(q.CircuitError):
+        tile_lane_assignment((3, 3, 5), dtype)
