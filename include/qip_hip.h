@@ -186,6 +186,13 @@ int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
  * can be checked without a GPU (tests/test_host_ops.py). */
 int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t* lanepos);
 
+/* Host-only test hook: the complete tile plan of a circuit as a JSON string (owned by the library, valid until
+ * the calling thread's next call; NULL on error): the schedule of qip_hip_plan_tiles and, for every multi-gate
+ * step, the free bit positions, the passes (exchange bits, lane-bit assignment) and the gate descriptors exactly
+ * as they are shipped to k_tile_passes.  tests/test_tile_plan_cpu.py replays it with a numpy model of the kernel
+ * and checks the result against the CPU oracle, so the host half of the tile path is covered without a GPU. */
+const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode);
+
 /* Options: key is one of
  *   "force_generic"  1 = route every op through the literal gather kernel
  *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)

@@ -1511,11 +1511,22 @@ extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits
   return QIP_OK;
 } QIP_CATCH_ALL
 
+// Everything the host decides about one segment before anything touches the device: which amplitude-index
+// positions the tile's free bits 6..10 stand for, the gate descriptors, the passes and each gate's resolution
+// against its pass.  Pure host code: qip_hip_debug_tile_plan serialises it so that tests can replay a plan on
+// the CPU (tests/test_tile_plan_cpu.py) and check it against the oracle without a GPU.
+template <typename T> struct TileSegmentPlan {
+  std::vector<uint32_t> high;  // amplitude-index position of tile bit 6 + j
+  std::vector<TileGate<T>> gates;
+  std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
+  TilePassDesc pd;             // passes (only when `passes`)
+};
+
 template <typename T>
-static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
-                               std::vector<uint32_t> high) {
+static int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg,
+                              std::vector<uint32_t> high, TileSegmentPlan<T>* out) {
   // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
-  for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < s->n; ++p)
+  for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < n; ++p)
     if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
   // tile bits 6, 7 are wave bits (exchange through LDS), 8..10 register bits (free): give the free positions
   // that are exchange targets least often to the wave bits
@@ -1533,8 +1544,10 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     const auto f = std::find(high.begin(), high.end(), pos);
     return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
-  std::vector<TileGate<T>> gates(seg.size());
-  std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
+  std::vector<TileGate<T>>& gates = out->gates;
+  std::vector<amp_t<T>>& mats = out->mats;
+  gates.assign(seg.size(), TileGate<T>());
+  mats.clear();
   for (size_t i = 0; i < seg.size(); ++i) {
     const TileItem& it = *seg[i];
     TileGate<T>& g = gates[i];
@@ -1556,7 +1569,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     if (it.kind != 3) g.nz = it.nz;
     if (it.kind == 0) {
       for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
-      if (s->tile_passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
+      if (passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
         const bool real = it.m[1] == 0 && it.m[3] == 0 && it.m[5] == 0 && it.m[7] == 0;
         const bool is_x = it.nz == 6u && it.m[2] == 1 && it.m[3] == 0 && it.m[4] == 1 && it.m[5] == 0;
         g.b1 = (real ? 1u : 0u) | (is_x ? 2u : 0u);
@@ -1566,35 +1579,11 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       g.m[1] = mk<T>(it.m[2], it.m[3]);
     }
   }
-  const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
-  static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
-  auto upload_gates = [&]() -> int {  // after the gates are final (k_tile_passes resolves them per pass first)
-    QCHK(ensure_arena(s, gates_bytes + mats.size() * sizeof(amp_t<T>)));  // one allocation: growing frees the old arena
-    QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
-    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
-    return QIP_OK;
-  };
-  TileDesc d;
-  memset(&d, 0, sizeof d);
-  d.ngates = (uint32_t)gates.size();
-  for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
-  Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
-  const uint64_t ntiles = 1ull << (s->n - kTileBits);
-  const size_t lds = sizeof(amp_t<T>) << kTileBits;
-  const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
-  const amp_t<T>* dmats = nullptr;
-  ProfRec rec;
-  rec.cls = KC_TILE_GATES;
-  auto begin = [&]() -> int {  // descriptors up, then the timed region starts
-    QCHK(upload_gates());
-    dg = (const TileGate<T>*)s->arena;
-    dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
-    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
-    return QIP_OK;
-  };
-  if (s->tile_passes) {
+  out->high = high;
+  memset(&out->pd, 0, sizeof out->pd);
+  if (passes) {
     // group consecutive gates into passes of at most three distinct exchange bits (see k_tile_passes)
-    TilePassDesc pd;
+    TilePassDesc& pd = out->pd;
     memset(&pd, 0, sizeof pd);
     for (int j = 0; j < kTileHigh; ++j) pd.hpos[j] = high[j];
     std::vector<uint32_t> bits;
@@ -1696,6 +1685,46 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
         }
       }
     }
+  }
+  return QIP_OK;
+}
+
+template <typename T>
+static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
+                               std::vector<uint32_t> high_in) {
+  TileSegmentPlan<T> plan;
+  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan));
+  const std::vector<uint32_t>& high = plan.high;
+  std::vector<TileGate<T>>& gates = plan.gates;
+  std::vector<amp_t<T>>& mats = plan.mats;
+  TilePassDesc& pd = plan.pd;
+  const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
+  static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
+  auto upload_gates = [&]() -> int {  // after the gates are final (k_tile_passes resolves them per pass first)
+    QCHK(ensure_arena(s, gates_bytes + mats.size() * sizeof(amp_t<T>)));  // one allocation: growing frees the old arena
+    QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
+    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
+    return QIP_OK;
+  };
+  TileDesc d;
+  memset(&d, 0, sizeof d);
+  d.ngates = (uint32_t)gates.size();
+  for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
+  Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
+  const uint64_t ntiles = 1ull << (s->n - kTileBits);
+  const size_t lds = sizeof(amp_t<T>) << kTileBits;
+  const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
+  const amp_t<T>* dmats = nullptr;
+  ProfRec rec;
+  rec.cls = KC_TILE_GATES;
+  auto begin = [&]() -> int {  // descriptors up, then the timed region starts
+    QCHK(upload_gates());
+    dg = (const TileGate<T>*)s->arena;
+    dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    return QIP_OK;
+  };
+  if (s->tile_passes) {
     QCHK(begin());
 #define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream, \
                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats)
@@ -1808,6 +1837,83 @@ extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint
   *n_steps = steps.size();
   return QIP_OK;
 } QIP_CATCH_ALL
+
+// Host-only: the complete tile plan of a circuit as JSON (schedule, and for every multi-gate step the segment
+// plan of build_tile_segment).  Test infrastructure for the host half of the tile path: tests replay the plan
+// on the CPU with a numpy model of k_tile_passes and compare with the oracle, no GPU involved.
+template <typename T>
+static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, std::string* out) {
+  std::vector<TileItem> items;
+  std::vector<TileStep> steps;
+  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
+  char buf[256];
+  auto num = [&](double v) {
+    snprintf(buf, sizeof buf, "%.17g", v);
+    return std::string(buf);
+  };
+  std::string& js = *out;
+  js = "{\"n\":" + std::to_string(n) + ",\"steps\":[";
+  for (size_t si = 0; si < steps.size(); ++si) {
+    const TileStep& st = steps[si];
+    if (si) js += ",";
+    js += "{\"ops\":[";
+    for (size_t k = 0; k < st.ops.size(); ++k) js += (k ? "," : "") + std::to_string(st.ops[k]);
+    js += "]";
+    if (st.ops.size() > 1) {
+      std::vector<const TileItem*> seg;
+      for (uint64_t i : st.ops) seg.push_back(&items[i]);
+      TileSegmentPlan<T> plan;
+      QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+      js += ",\"high\":[";
+      for (size_t k = 0; k < plan.high.size(); ++k) js += (k ? "," : "") + std::to_string(plan.high[k]);
+      js += "],\"passes\":[";
+      for (uint32_t pi = 0; pi < plan.pd.npasses; ++pi) {
+        const TilePass& ps = plan.pd.pass[pi];
+        if (pi) js += ",";
+        js += "{\"first\":" + std::to_string(ps.first) + ",\"count\":" + std::to_string(ps.count) + ",\"pb\":[" +
+              std::to_string(ps.pb[0]) + "," + std::to_string(ps.pb[1]) + "," + std::to_string(ps.pb[2]) +
+              "],\"lanepos\":[";
+        for (int k = 0; k < 8; ++k) js += (k ? "," : "") + std::to_string((ps.lanepos >> (4 * k)) & 15u);
+        js += "]}";
+      }
+      js += "],\"gates\":[";
+      for (size_t gi = 0; gi < plan.gates.size(); ++gi) {
+        const TileGate<T>& g = plan.gates[gi];
+        if (gi) js += ",";
+        js += "{\"kind\":" + std::to_string(g.kind) + ",\"op\":" + std::to_string(g.op) + ",\"b0\":" +
+              std::to_string(g.b0) + ",\"b1\":" + std::to_string(g.b1) + ",\"cmask\":" + std::to_string(g.cmask) +
+              ",\"cm_reg\":" + std::to_string(g.cm_reg) + ",\"cm_lane\":" + std::to_string(g.cm_lane) +
+              ",\"omask\":" + std::to_string(g.omask) + ",\"tpos_out\":" + std::to_string(g.tpos_out) +
+              ",\"nz\":" + std::to_string(g.nz) + ",\"m\":[";
+        for (int e = 0; e < 4; ++e)
+          js += std::string(e ? "," : "") + "[" + num((double)g.m[e].x) + "," + num((double)g.m[e].y) + "]";
+        js += "]}";
+      }
+      js += "],\"mats\":[";
+      for (size_t e = 0; e < plan.mats.size(); ++e)
+        js += std::string(e ? "," : "") + "[" + num((double)plan.mats[e].x) + "," + num((double)plan.mats[e].y) + "]";
+      js += "]";
+    }
+    js += "}";
+  }
+  js += "]}";
+  return QIP_OK;
+}
+
+extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode) {
+  static thread_local std::string json;
+  try {
+    if (count && !ops) return fail(QIP_ERR_INVALID, "null op array"), nullptr;
+    if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype), nullptr;
+    if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits), nullptr;
+    const int rc = dtype == QIP_C64 ? tile_plan_json<double>(dtype, n, ops, count, mode, &json)
+                                    : tile_plan_json<float>(dtype, n, ops, count, mode, &json);
+    return rc == QIP_OK ? json.c_str() : nullptr;
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  }
+}
 
 template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {

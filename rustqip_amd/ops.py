@@ -244,3 +244,16 @@ def tile_lane_assignment(pass_bits, dtype: int = _ffi.QIP_C64):
     if rc != _ffi.QIP_OK:
         raise CircuitError(_ffi.last_error())
     return [(out.value >> (4 * k)) & 15 for k in range(8)]
+
+
+def debug_tile_plan(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64) -> dict:
+    """Host-only test hook (qip_hip_debug_tile_plan): the tile schedule plus every segment's passes and gate
+    descriptors as shipped to the kernel, parsed from JSON."""
+    import json
+
+    cops = [op.to_c(dtype) for op in ops]
+    arr = (_ffi.QipOp * len(cops))(*cops)
+    txt = _ffi.lib.qip_hip_debug_tile_plan(dtype, n, arr, len(cops), mode)
+    if not txt:
+        raise CircuitError(_ffi.last_error())
+    return json.loads(txt.decode() if isinstance(txt, bytes) else txt)

@@ -1,0 +1,184 @@
+"""The host half of the tile sweeps, without a GPU: qip_hip_debug_tile_plan gives the schedule, the passes and the
+gate descriptors exactly as they are shipped to k_tile_passes; a numpy model of that kernel (this file: the
+kernel's semantics restated, tile by tile, pass by pass, lane by lane) replays them on a CPU state vector and the
+result must match the oracle applying the circuit gate by gate.  Covers: scheduling legality (commutation rules),
+free-bit selection, pass grouping, the lane-bit assignment, the dispatch codes and pass-bit indices the host
+resolves, the split of controls into pass-bit / lane-bit / outside-the-tile parts, 2-qubit matrix order."""
+import cmath
+
+import numpy as np
+import pytest
+
+import rustqip_amd as q
+from oracle import qip_oracle as O
+from rustqip_amd import circuits
+from rustqip_amd.ops import debug_tile_plan
+
+TILE_LOW, TILE_BITS, OUTSIDE = 6, 11, 0xFFFFFFFF
+# enum TileOp (rustqip_amd/csrc/qip_kernels.h)
+DIAG_UNIFORM, DIAG_LANE, DIAG_LANE_CTL, DIAG_REG0 = 0, 1, 2, 3
+DENSE0, DENSE_LANE0, DENSE2Q_FIRST, SWAP_FIRST = 6, 9, 12, 18
+DENSE2Q = [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)]
+SWAPS = [(0, 1), (0, 2), (1, 2)]
+
+
+def emulate_segment(state, n, seg):
+    """k_tile_passes on a numpy vector: one block per tile, 256 lanes, 8 elements per lane and pass."""
+    high = seg["high"]
+    tile_pos = list(range(TILE_LOW)) + high
+    other = [p for p in range(n) if p not in tile_pos]  # the block index fills these, ascending (insert_bits)
+    ntiles = 1 << (n - TILE_BITS)
+    bid = np.arange(ntiles, dtype=np.uint64)
+    base = np.zeros(ntiles, dtype=np.uint64)
+    for k, p in enumerate(other):
+        base |= ((bid >> np.uint64(k)) & np.uint64(1)) << np.uint64(p)
+    t = np.arange(1 << TILE_BITS, dtype=np.uint64)
+    off = np.zeros_like(t)
+    for b, p in enumerate(tile_pos):
+        off |= ((t >> np.uint64(b)) & np.uint64(1)) << np.uint64(p)
+    idx = (base[:, None] | off[None, :]).astype(np.int64)
+    tile = state[idx]  # (ntiles, 2048): the LDS-resident tile, indexed by tile index
+    gates = seg["gates"]
+    mats = np.array([complex(a, b) for a, b in seg["mats"]], dtype=np.complex128)
+    tid = np.arange(256, dtype=np.int64)
+    seen = 0
+    for ps in seg["passes"]:
+        pb, lanepos = ps["pb"], ps["lanepos"]
+        assert sorted(pb + lanepos) == list(range(TILE_BITS))  # lane bits + pass bits tile the 11 bits exactly
+        tb = np.zeros(256, dtype=np.int64)
+        for k in range(8):
+            tb |= ((tid >> k) & 1) << lanepos[k]
+        c = np.array([sum(((i >> j) & 1) << pb[j] for j in range(3)) for i in range(8)], dtype=np.int64)
+        te = tb[:, None] | c[None, :]  # (256, 8): a bijection onto the 2048 tile indices
+        assert np.array_equal(np.sort(te.ravel()), np.arange(1 << TILE_BITS))
+        e = tile[:, te]  # (ntiles, 256, 8)
+        assert ps["first"] == seen
+        seen += ps["count"]
+        for g in gates[ps["first"]: ps["first"] + ps["count"]]:
+            passmask = sum(1 << b for b in pb)
+            assert g["cm_reg"] == g["cmask"] & passmask and g["cm_lane"] == g["cmask"] & ~passmask
+            m = [complex(a, b) for a, b in g["m"]]
+            tile_on = (base & np.uint64(g["omask"])) == np.uint64(g["omask"])  # outside controls: per block
+            elem_ok = (c & g["cm_reg"]) == g["cm_reg"]
+            lane_ok = (tb & g["cm_lane"]) == g["cm_lane"]
+            mask = tile_on[:, None, None] & lane_ok[None, :, None] & elem_ok[None, None, :]
+            op = g["op"]
+            if op in (DIAG_UNIFORM, DIAG_LANE, DIAG_LANE_CTL):
+                assert g["kind"] == 1 and (op != DIAG_UNIFORM or (g["b0"] == OUTSIDE and g["cm_lane"] == 0))
+                assert (op == DIAG_LANE_CTL) == (g["cm_lane"] != 0) or op == DIAG_UNIFORM
+                if g["b0"] == OUTSIDE:
+                    one = np.broadcast_to((((base >> np.uint64(g["tpos_out"])) & np.uint64(1)) != 0)[:, None], (ntiles, 256))
+                else:
+                    assert not (passmask >> g["b0"]) & 1
+                    one = np.broadcast_to((((tb >> g["b0"]) & 1) != 0)[None, :], (ntiles, 256))
+                f = np.where(one, m[1], m[0])
+                e = np.where(mask, f[:, :, None] * e, e)
+            elif DIAG_REG0 <= op < DIAG_REG0 + 3:
+                j = op - DIAG_REG0
+                assert g["kind"] == 1 and g["b0"] == pb[j]
+                for i in range(8):
+                    e[:, :, i] = np.where(mask[:, :, i], m[(i >> j) & 1] * e[:, :, i], e[:, :, i])
+            elif DENSE0 <= op < DENSE0 + 6:
+                j = (op - DENSE0) % 3
+                assert g["kind"] == 0 and g["b0"] == pb[j] and ((op >= DENSE_LANE0) == (g["cm_lane"] != 0))
+                for i in range(8):
+                    if (i >> j) & 1:
+                        continue
+                    k = i | (1 << j)
+                    a0, a1 = e[:, :, i].copy(), e[:, :, k].copy()
+                    e[:, :, i] = np.where(mask[:, :, i], m[0] * a0 + m[1] * a1, a0)
+                    e[:, :, k] = np.where(mask[:, :, i], m[2] * a0 + m[3] * a1, a1)
+            elif DENSE2Q_FIRST <= op < DENSE2Q_FIRST + 6:
+                ja, jb = DENSE2Q[op - DENSE2Q_FIRST]
+                assert g["kind"] == 3 and g["b0"] == pb[ja] and g["b1"] == pb[jb]
+                mat = mats[16 * g["nz"]: 16 * g["nz"] + 16].reshape(4, 4)
+                jc = 3 - ja - jb
+                for qd in range(2):
+                    ids = [(qd << jc) | ((s >> 1) << ja) | ((s & 1) << jb) for s in range(4)]
+                    x = np.stack([e[:, :, i] for i in ids], axis=-1)
+                    y = x @ mat.T
+                    for r, i in enumerate(ids):
+                        e[:, :, i] = np.where(mask[:, :, ids[0]], y[:, :, r], x[:, :, r])
+            elif SWAP_FIRST <= op < SWAP_FIRST + 3:
+                j0, j1 = SWAPS[op - SWAP_FIRST]
+                assert g["kind"] == 2 and g["b0"] == pb[j0] and g["b1"] == pb[j1]
+                for i in range(8):
+                    if ((i >> j0) & 1, (i >> j1) & 1) != (1, 0):
+                        continue
+                    k = (i & ~(1 << j0)) | (1 << j1)
+                    a, b = e[:, :, i].copy(), e[:, :, k].copy()
+                    e[:, :, i] = np.where(mask[:, :, i], b, a)
+                    e[:, :, k] = np.where(mask[:, :, i], a, b)
+            else:
+                raise AssertionError(f"unknown dispatch code {op}")
+        tile[:, te] = e
+    assert seen == len(gates)
+    state[idx] = tile
+
+
+def replay(n, ops, mode, x):
+    plan = debug_tile_plan(n, ops, mode)
+    assert plan["n"] == n
+    st = x.copy()
+    done = []
+    for step in plan["steps"]:
+        if len(step["ops"]) == 1:
+            st = O.apply_ops_in_place(n, [ops[step["ops"][0]]], st)
+        else:
+            assert len(step["high"]) == 5 and len(set(step["high"])) == 5 and min(step["high"]) >= TILE_LOW
+            emulate_segment(st, n, step)
+        done += step["ops"]
+    assert sorted(done) == list(range(len(ops)))
+    return st, plan
+
+
+def rand_unitary(k, rng):
+    a = rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))
+    u, _ = np.linalg.qr(a)
+    return u
+
+
+def fuzz_circuit(n, rng, gates):
+    s2 = 0.5 ** 0.5
+    g1 = [[0, 1, 1, 0], [0, -1j, 1j, 0], [1, 0, 0, -1], [s2, s2, s2, -s2], [1, 0, 0, 1j], [1, 0, 0, cmath.rect(1, 0.785)],
+          [cmath.rect(1, -0.35), 0, 0, cmath.rect(1, 0.35)], [1, 1, 0, 1], [0.3 + 0.1j, -0.7j, 0.2, 0.9 - 0.4j]]
+    ops = []
+    for _ in range(gates):
+        perm = [int(v) for v in rng.permutation(n)]
+        shape = int(rng.integers(0, 9))
+        nc = int(rng.integers(0, 5))
+        if shape <= 3:
+            g = q.make_matrix_op([perm[0]], g1[int(rng.integers(0, len(g1)))])
+            ops.append(q.make_control_op(perm[1:1 + nc], g) if nc and rng.integers(0, 2) else g)
+        elif shape == 4:
+            g = q.make_matrix_op([perm[0]], [1, 0, 0, cmath.rect(1, float(rng.uniform(0, 6.28)))])
+            ops.append(q.make_control_op(perm[1:2 + nc], g))
+        elif shape == 5:
+            g = q.make_swap_op([perm[0]], [perm[1]])
+            ops.append(q.make_control_op(perm[2:2 + nc], g) if nc else g)
+        elif shape == 6:
+            g = q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel())
+            ops.append(q.make_control_op(perm[2:2 + min(nc, 3)], g) if nc else g)
+        elif shape == 7:
+            ops.append(q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()))  # not tileable
+        else:
+            ops.append(q.make_swap_op(perm[:2], perm[2:4]))  # not tileable
+    return ops
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", ["c2", "qft", "c4", "grover", "fuzz12", "fuzz13", "fuzz14"])
+def test_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
+    n = {"fuzz13": 13, "fuzz14": 14}.get(name, 12)
+    rng = np.random.default_rng(len(name) * 7 + n)
+    ops = {
+        "c2": lambda: circuits.h_layer(n) + circuits.c2_random_circuit(n, 120, seed=28),
+        "qft": lambda: circuits.c3_qft(n),
+        "c4": lambda: circuits.c4_clifford_t(n, 120, seed=32),
+        "grover": lambda: circuits.h_layer(n) + circuits.c5_grover_iteration(n),
+    }.get(name, lambda: fuzz_circuit(n, rng, 140))()
+    x = circuits.random_state(n, seed=n)
+    got, plan = replay(n, ops, mode, x)
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.max(np.abs(want))))
+    assert len(plan["steps"]) < len(ops)  # gates really share sweeps
