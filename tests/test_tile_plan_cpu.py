@@ -116,8 +116,8 @@ def emulate_segment(state, n, seg):
     state[idx] = tile
 
 
-def replay(n, ops, mode, x):
-    plan = debug_tile_plan(n, ops, mode)
+def replay(n, ops, mode, x, dtype=None):
+    plan = debug_tile_plan(n, ops, mode) if dtype is None else debug_tile_plan(n, ops, mode, dtype)
     assert plan["n"] == n
     st = x.copy()
     done = []
@@ -182,3 +182,17 @@ def test_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.max(np.abs(want))))
     assert len(plan["steps"]) < len(ops)  # gates really share sweeps
+
+
+def test_tile_plan_for_complex64_states():
+    """The f32 plan (8-byte amplitudes: swizzle fold S = 5, matrices rounded to f32) replayed in f64: same
+    structure, agreement with the f64 oracle to f32 rounding."""
+    from rustqip_amd import _ffi
+
+    n = 12
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 100, seed=5) + circuits.c3_qft(n)[:40]
+    x = circuits.random_state(n, seed=1)
+    got, plan = replay(n, ops, 1, x, _ffi.QIP_C32)
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) < 1e-5
+    assert len(plan["steps"]) < len(ops) / 4
