@@ -1,21 +1,28 @@
 #!/usr/bin/env python
 """bench.py — gate-application throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: the configs[1] circuit
-(random single-qubit H / X / Rz + CNOT, 256 gates) applied once to a
-2^n-amplitude Complex<f64> state that is already resident in HBM.  n = n_local + log2(N) with
-n_local = 30 amplitudes-bits per GPU by default (the size BASELINE.json's target is quoted on:
-n=30 on 1 GPU, n=33 on 8); weak scaling.  value = algorithmic GB/s of the whole job
-(sum over gates of the bytes of SURVEY.md §8(d)'s table, / wall time), gates/s beside it.
+N > 1 without a torch.distributed environment re-launches itself as N ranks (one per GPU) under
+torch.distributed.run on 127.0.0.1; under an existing launcher (RANK / WORLD_SIZE set) it runs as that rank.
+
+A "step" is one pass of the hot path over one batch of synthetic input: 256 random single-qubit gates
+(uniform over H / X / Rz(theta), uniform target — the single-qubit part of the configs[1] generator,
+SURVEY.md §8(d)) applied to a 2^n-amplitude Complex<f64> state that is already resident in HBM.
+n = n_local + log2(N) with n_local = 30 (the size BASELINE.json's target is quoted on: n = 30 on 1 GPU,
+n = 33 on 8); weak scaling.  value = algorithmic GB/s of the whole job (32 * 2^n bytes per gate / wall time).
+The configs[1] mix itself (3/4 single-qubit + 1/4 CNOT) is reported beside it as `mixed_circuit`.
 
 Also on the same JSON line:
+  parity        the timed configuration checked against the CPU ORACLE before anything is timed: a seeded
+                product state with pairwise distinct amplitudes, then gate by gate >= 4 closed sub-cubes of 2^16+
+                rows (bottom and top of the index space included) downloaded before/after and compared with the
+                oracle's apply_op_overwrite / apply_op_row (oracle/window_parity.py) — the checker, never timed
   roofline      dominant kernel: algorithmic bytes per launch / mean launch duration, measured with
                 HIP events on the launching stream inside the timed region
   cpu_baseline  the CPU oracle (C restatement of qip-iterators apply_op_overwrite, OpenMP over all
                 host cores) timed on a bounded sample of the same circuit (rank 0, N = 1 only)
-  extras        configs[1] exactly (n = 28) and the per-target-qubit H sweep at n_local
+  extras        the other BASELINE configs and the optional modes, each the median of 5 repetitions
 """
 from __future__ import annotations
 
@@ -23,6 +30,7 @@ import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -31,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+REPS = 5                # repetitions of every untimed-contract leg (median reported)
 
 
 def parse_args():
@@ -42,12 +51,27 @@ def parse_args():
     ap.add_argument("--gates", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
 
 
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` as a plain command: become N ranks under torch.distributed.run."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def circuit_bytes(q, n, ops):
-    return [q.algorithmic_bytes(n, op) for op in ops]
+    return sum(q.algorithmic_bytes(n, op) for op in ops)
 
 
 def dominant_kernel(profile):
@@ -58,62 +82,116 @@ def dominant_kernel(profile):
 
 
 def load_traffic(kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/): a STATIC
+    figure from separate --pmc passes of this same command, not a per-run measurement."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get(kernel_name, {}).get("hbm_bytes_per_launch"), d.get("_source", "profiles/pmc_traffic.json")
     except Exception:
-        return None
+        return None, None
+
+
+def median_time(fn, sync, reps=REPS):
+    """fn() once untimed, then `reps` individually timed runs; returns (median seconds, all seconds)."""
+    fn()
+    sync()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        sync()
+        ts.append(time.perf_counter() - t)
+    return statistics.median(ts), ts
 
 
 def cpu_baseline(q, circuits, args):
-    """Time the oracle on a bounded sample of the same workload: the first gates of the same
-    seeded circuit at the largest n <= 28 whose predicted cost fits the budget."""
+    """Time the oracle on a bounded sample of the same workload: the first 16 gates of the same seeded single-qubit
+    circuit at the largest n <= 28 whose 5 repetitions fit the budget; median of the repetitions."""
     import numpy as np
 
     from oracle import qip_oracle as O
 
     threads = O.max_threads()
 
-    def run(n, ops):
+    def run(n, ops, reps):
         state = np.zeros(1 << n, dtype=np.complex128)
         state[0] = 1
         arena = np.zeros_like(state)  # touch both buffers before timing
         for op in circuits.h_layer(n)[:2]:
             O.apply_op_overwrite(n, op, state, arena)
             state, arena = arena, state
-        t0 = time.perf_counter()
-        for op in ops:
-            O.apply_op_overwrite(n, op, state, arena)
-            state, arena = arena, state
-        return time.perf_counter() - t0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for op in ops:
+                O.apply_op_overwrite(n, op, state, arena)
+                state, arena = arena, state
+            ts.append(time.perf_counter() - t0)
+        return ts
 
     n_cal, n_gates = 22, 16
-    ops_cal = circuits.c2_random_circuit(n_cal, n_gates, seed=28)
-    t_cal = run(n_cal, ops_cal)
+    t_cal = statistics.median(run(n_cal, circuits.c2_random_circuit(n_cal, n_gates, seed=28, single_only=True), 3))
     n_cpu = n_cal
-    while n_cpu < 28 and t_cal * (2 ** (n_cpu + 1 - n_cal)) <= args.cpu_budget_s:
+    while n_cpu < 28 and t_cal * (2 ** (n_cpu + 1 - n_cal)) * REPS <= args.cpu_budget_s:
         n_cpu += 1
-    ops = circuits.c2_random_circuit(n_cpu, n_gates, seed=28)
-    t = run(n_cpu, ops) if n_cpu != n_cal else t_cal
-    by = sum(circuit_bytes(q, n_cpu, ops))
+    ops = circuits.c2_random_circuit(n_cpu, n_gates, seed=28, single_only=True)
+    ts = run(n_cpu, ops, REPS)
+    t = statistics.median(ts)
+    by = circuit_bytes(q, n_cpu, ops)
     return {
         "value": by / t / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
-        "gates_per_s": n_gates / t, "ms_per_gate": 1e3 * t / n_gates,
-        "sample": f"first {n_gates} gates of the same seeded C2 circuit at n={n_cpu} (2 buffers x {16 * 2**n_cpu / 2**30:.2f} GiB), "
-                  f"C restatement of qip-iterators 1.5.0 apply_op_overwrite, gcc -O2 -fopenmp, {threads} threads, {t:.1f} s",
+        "gates_per_s": n_gates / t, "ms_per_gate": 1e3 * t / n_gates, "reps_s": [round(x, 3) for x in ts],
+        "sample": f"first {n_gates} gates of the same seeded single-qubit circuit at n={n_cpu} (2 buffers x {16 * 2**n_cpu / 2**30:.2f} GiB), "
+                  f"C restatement of qip-iterators 1.5.0 apply_op_overwrite, gcc -O3 -fopenmp, {threads} threads, "
+                  f"median of {REPS} repetitions ({sum(ts):.1f} s of CPU work)",
+    }
+
+
+def parity_check(q, circuits, st, n, ops_headline, ops_mixed):
+    """The timed configuration against the oracle (see module docstring).  Leaves the state in the seeded product
+    state advanced by the checked gates — a non-uniform state, which is also what gets timed."""
+    import numpy as np
+
+    from oracle import qip_oracle as O
+    from oracle import window_parity as W
+
+    t0 = time.perf_counter()
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    st.init_basis(0)
+    st.apply_ops(ops0)
+    init_err = 0.0
+    for off in (0, (1 << n) // 3, (1 << n) - (1 << 16)):
+        got = st.download(off, 1 << 16)
+        want = W.product_state_window(n, vecs, off, 1 << 16)
+        init_err = max(init_err, float(np.max(np.abs(got - want) / np.abs(want))))
+    a = W.check_circuit(st, n, ops_headline[:32], O, gate_by_gate=True, seed=11)
+    b = W.check_circuit(st, n, ops_mixed[:32], O, gate_by_gate=True, seed=12)
+    st.set_option("tile", 1)
+    c = W.check_circuit(st, n, ops_mixed[32:96], O, gate_by_gate=False, seed=13)
+    st.set_option("tile", 0)
+    return {
+        "checker": "CPU oracle (oracle/qip_oracle.c apply_op_overwrite + apply_op_row) on closed sub-cubes, oracle/window_parity.py",
+        "n": n, "state": "seeded product state, pairwise distinct amplitudes (closed form checked: max rel err %.1e)" % init_err,
+        "gates_checked": a["gates"] + b["gates"] + c["gates"], "gates_skipped": a["skipped"] + b["skipped"] + c["skipped"],
+        "rows_checked": a["rows"] + b["rows"] + c["rows"], "windows": a["windows"] + b["windows"] + c["windows"],
+        "apply_op_row_calls": a["row_calls"] + b["row_calls"],
+        "max_abs_delta": max(a["max_abs_delta"], b["max_abs_delta"], c["max_abs_delta"]),
+        "bit_equal": bool(a["bit_equal"] and b["bit_equal"] and c["bit_equal"]),
+        "legs": {"single_qubit_gate_by_gate": a, "mixed_gate_by_gate": b, "mixed_tile1_chunks": c},
+        "seconds": round(time.perf_counter() - t0, 2),
     }
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     g = int(math.log2(world))
     if 1 << g != world:
@@ -129,7 +207,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: rustqip_amd has no CPU fallback")
     # QIP_BENCH_DIST_BACKEND=gloo is a TEST hook: several ranks share one GPU and the remap all-to-all is
     # staged through host memory, so the N > 1 code path can be exercised where only one GPU exists.
-    # Real multi-GPU runs use nccl (= RCCL) on device buffers.
+    # Real multi-GPU runs use RCCL on device buffers.
     dist_backend = os.environ.get("QIP_BENCH_DIST_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
@@ -143,29 +221,41 @@ def main():
             dist.init_process_group(backend=dist_backend)
 
     n = args.n_local + g
-    ops = circuits.c2_random_circuit(n, args.gates, seed=28)
-    bytes_per_step = sum(circuit_bytes(q, n, ops))  # whole job (all ranks)
+    ops = circuits.c2_random_circuit(n, args.gates, seed=28, single_only=True)  # the headline: H / X / Rz only
+    ops_mixed = circuits.c2_random_circuit(n, args.gates, seed=28)              # configs[1]: 3/4 of those + 1/4 CNOT
+    bytes_per_step = circuit_bytes(q, n, ops)  # whole job (all ranks)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    parity = None
     if world == 1:
         st = q.HipState(n, np.complex128, device=device)
-        st.init_basis(0)
-        st.apply_ops(circuits.h_layer(n))  # dense state, every amplitude 2^(-n/2)
+        if not args.no_parity:
+            parity = parity_check(q, circuits, st, n, ops, ops_mixed)
+        else:
+            st.init_basis(0)
+            st.apply_ops(circuits.h_layer(n))
         compiled = st.compile_ops(ops)
         run_step = lambda: st.apply_compiled(compiled)
         sync = st.sync
         set_profile = lambda v: st.set_option("profile", v)
         get_profile = lambda: (st.profile(), st.profile_reset())[0]
     else:
-        from rustqip_amd.sharded import HipBackend, ShardedState
+        from rustqip_amd.sharded import make_sharded_state
 
-        st = ShardedState(n, dist, backend=HipBackend(args.n_local, device, host_staged_exchange=dist_backend != "nccl"))
+        st = make_sharded_state(n, args.n_local, dist, device, host_staged=dist_backend != "nccl")
         st.init_basis(0)
-        st.apply_ops(circuits.h_layer(n))
+        st.apply_ops(circuits.h_layer(n) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n)])
         plan = st.plan(ops)
         run_step = lambda: st.run_plan(plan)
         sync = st.sync
@@ -183,13 +273,10 @@ def main():
     sync()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(t1 - t0)
     profile = get_profile()
     set_profile(0)
+    comm_headline = st.comm_stats() if world > 1 else None
     norm = st.norm_sqr()
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -200,9 +287,11 @@ def main():
         per_launch_bytes = kstat["algorithmic_bytes"] / kstat["launches"]
         avg_ms = kstat["total_ms"] / kstat["launches"]
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic(kname)
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(kname),
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_source": f"static, from {traffic_src} (separate rocprofv3 --pmc passes of this command; not re-measured per run)",
             "avg_launch_ms": avg_ms, "launches": kstat["launches"], "algorithmic_bytes_per_launch": per_launch_bytes,
         }
     kernels = {
@@ -211,95 +300,54 @@ def main():
         for k, v in (profile or {}).items() if v["launches"] and v["total_ms"] > 0
     }
 
-    extras = {}
-    if world == 1 and not args.no_extras:
-        # per-target-qubit H sweep at n_local: GB/s by target qubit
-        sweep = []
+    def leg(cops, label_ops="gates", **options):
+        """median of REPS timed applications of a circuit with the given state options (single GPU)"""
+        for k, v in options.items():
+            st.set_option(k, v)
+        cc = st.compile_ops(cops)
+        st.set_option("profile", 1)
+        st.apply_compiled(cc)
+        st.sync()
+        st.profile_reset()
+        dt, ts = median_time(lambda: st.apply_compiled(cc), st.sync)
+        prof = st.profile()
         st.set_option("profile", 0)
+        for k in options:
+            st.set_option(k, 0)
+        sweeps = sum(v["launches"] for v in prof.values()) // (REPS + 1)
+        sweep_bytes = sum(v["algorithmic_bytes"] for v in prof.values()) / (REPS + 1)
+        by = circuit_bytes(q, n, cops)
+        return {label_ops: len(cops), "ms": 1e3 * dt, "ms_min_max": [round(1e3 * min(ts), 3), round(1e3 * max(ts), 3)],
+                "%s_per_s" % label_ops: len(cops) / dt, "algorithmic_GBps": by / dt / 1e9, "launches": sweeps,
+                "per_launch_GBps": sweep_bytes / dt / 1e9, "reps": REPS}
+
+    extras = {}
+    mixed = None
+    if world == 1:
+        mixed = leg(ops_mixed)
+        mixed["frac_of_8TBps"] = mixed["algorithmic_GBps"] / HBM_PEAK_GBPS
+        mixed["workload"] = "configs[1] generator: 3/4 H/X/Rz + 1/4 CNOT, seed 28, %d gates, n=%d" % (len(ops_mixed), n)
+    if world == 1 and not args.no_extras:
+        # per-target-qubit H sweep at n_local (SURVEY.md §8(d) S0): GB/s by target qubit, median of REPS x 2 gates
+        sweep = []
         for tq in range(n):
-            op = st.compile_ops([q.make_matrix_op([tq], circuits.H)] * 4)
-            st.apply_compiled(op)
-            st.sync()
-            t = time.perf_counter()
-            st.apply_compiled(op)
-            st.apply_compiled(op)
-            st.sync()
-            dt = (time.perf_counter() - t) / 8
-            sweep.append(round(32.0 * 2**n / dt / 1e9, 1))
+            op = st.compile_ops([q.make_matrix_op([tq], circuits.H)] * 2)
+            dt, _ = median_time(lambda: st.apply_compiled(op), st.sync)
+            sweep.append(round(32.0 * 2**n / (dt / 2) / 1e9, 1))
         extras["h_sweep_GBps_by_target_qubit"] = sweep
         extras["h_sweep_min_median_GBps"] = [min(sweep), float(np.median(sweep))]
-        single = circuits.c2_random_circuit(n, args.gates, seed=30, single_only=True)
-        cs = st.compile_ops(single)
-        st.apply_compiled(cs)
-        st.sync()
-        t = time.perf_counter()
-        st.apply_compiled(cs)
-        st.sync()
-        dt = time.perf_counter() - t
-        extras["single_qubit_only"] = {"n": n, "gates": len(single), "GBps": sum(circuit_bytes(q, n, single)) / dt / 1e9,
-                                       "gates_per_s": len(single) / dt, "frac_of_8TBps": sum(circuit_bytes(q, n, single)) / dt / 1e9 / HBM_PEAK_GBPS}
-        # gate fusion: the same circuit with option fuse = 5 — one sweep per fused gate
-        st.set_option("fuse", 5)
-        st.set_option("profile", 1)
-        st.profile_reset()
-        cf = st.compile_ops(ops)
-        st.apply_compiled(cf)
-        st.sync()
-        st.profile_reset()
-        t = time.perf_counter()
-        st.apply_compiled(cf)
-        st.sync()
-        dt = time.perf_counter() - t
-        prof_f = st.profile()
-        sweeps = sum(v["launches"] for v in prof_f.values())
-        sweep_bytes = sum(v["algorithmic_bytes"] for v in prof_f.values())
-        extras["fused_k5"] = {"gates": len(ops), "sweeps": sweeps, "gates_per_s": len(ops) / dt, "ms_per_step": 1e3 * dt,
-                              "sweep_GBps": sweep_bytes / dt / 1e9,
-                              "note": "per-sweep bytes (32*2^n per fused dense gate), never per-gate bytes over sweep time"}
-        st.set_option("fuse", 0)
-        # LDS-resident multi-gate sweeps: tile = 1 (circuit order up to exact commutations, IEEE-equal) and tile = 2 (commuting reorder)
-        for mode in (1, 2):
-            st.set_option("tile", mode)
-            ct = st.compile_ops(ops)
-            st.apply_compiled(ct)
-            st.sync()
-            st.profile_reset()
-            t = time.perf_counter()
-            st.apply_compiled(ct)
-            st.sync()
-            dt = time.perf_counter() - t
-            prof_t = st.profile()
-            sweeps = sum(v["launches"] for v in prof_t.values())
-            extras["tiled_mode%d" % mode] = {"gates": len(ops), "sweeps": sweeps, "gates_per_s": len(ops) / dt, "ms_per_step": 1e3 * dt,
-                                             "sweep_GBps": sum(v["algorithmic_bytes"] for v in prof_t.values()) / dt / 1e9}
-        st.set_option("tile", 0)
-        st.set_option("profile", 0)
-        # the other single-GPU configs of BASELINE.json on the same resident state size
+        # optional modes on the configs[1] mix: dense fusion (one sweep per fused gate: per_launch_GBps is per SWEEP
+        # bytes, never per-gate bytes over sweep time) and LDS-resident multi-gate sweeps
+        extras["fused_k5"] = leg(ops_mixed, fuse=5)
+        extras["tiled_mode1"] = leg(ops_mixed, tile=1)
+        extras["tiled_mode2"] = leg(ops_mixed, tile=2)
+        # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
+                            ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
                             ("configs4_grover_iteration_n%d" % n, circuits.c5_grover_iteration(n)),
                             ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True))):
-            cc = st.compile_ops(cops)
-            st.apply_compiled(cc)
-            st.sync()
-            t = time.perf_counter()
-            st.apply_compiled(cc)
-            st.sync()
-            dt = time.perf_counter() - t
-            by = sum(circuit_bytes(q, n, cops))
-            extras[cname] = {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": by / dt / 1e9}
-            st.set_option("tile", 1)  # IEEE-equal multi-gate sweeps
-            st.set_option("profile", 1)
-            st.apply_compiled(cc)
-            st.sync()
-            st.profile_reset()
-            t = time.perf_counter()
-            st.apply_compiled(cc)
-            st.sync()
-            dt = time.perf_counter() - t
-            extras[cname]["tile1"] = {"ms": 1e3 * dt, "ops_per_s": len(cops) / dt,
-                                      "sweeps": sum(v["launches"] for v in st.profile().values())}
-            st.set_option("tile", 0)
-            st.set_option("profile", 0)
+            extras[cname] = leg(cops, "ops")
+            extras[cname]["tile1"] = leg(cops, "ops", tile=1)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28
@@ -307,39 +355,50 @@ def main():
         ops28 = circuits.c2_random_circuit(n28, args.gates, seed=28)
         with q.HipState(n28) as s28:
             s28.init_basis(0)
-            s28.apply_ops(circuits.h_layer(n28))
+            s28.apply_ops(circuits.h_layer(n28) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n28)])
             c28 = s28.compile_ops(ops28)
-            s28.apply_compiled(c28)
-            s28.sync()
-            t = time.perf_counter()
-            for _ in range(3):
-                s28.apply_compiled(c28)
-            s28.sync()
-            dt = (time.perf_counter() - t) / 3
-            extras["configs1_n28"] = {"GBps": sum(circuit_bytes(q, n28, ops28)) / dt / 1e9, "gates_per_s": len(ops28) / dt,
-                                      "ms_per_step": 1e3 * dt, "norm_sqr": s28.norm_sqr()}
+            dt, ts = median_time(lambda: s28.apply_compiled(c28), s28.sync)
+            extras["configs1_n28"] = {"GBps": circuit_bytes(q, n28, ops28) / dt / 1e9, "gates_per_s": len(ops28) / dt,
+                                      "ms_per_step": 1e3 * dt, "reps": REPS, "norm_sqr": s28.norm_sqr()}
 
     if world > 1 and not args.no_extras:
-        # the same step with the runs of local gates between remaps applied as LDS-resident tile sweeps on every
-        # shard (tile = 1: IEEE-equal to gate by gate).  Reported beside the headline, never as `value`; guarded so
-        # that nothing here can take the bench line down.
+        # BASELINE configs[3] (Clifford+T) and configs[4] (Grover iteration, plain and dense k = 3) on the sharded
+        # state, and the headline circuit with the local runs between remaps applied as tile sweeps (tile = 1:
+        # IEEE-equal).  Guarded: nothing here can take the bench line down.  Median of REPS, max over ranks.
+        def dist_leg(cops, batched=False, tile=0):
+            st.set_tile(tile)
+            pl = st.plan(cops)
+            st.comm_stats()  # reset the collective timer
+            st.run_plan(pl, batched=batched)
+            sync()
+            st.comm_stats()
+            ts = []
+            for _ in range(REPS):
+                barrier()
+                t = time.perf_counter()
+                st.run_plan(pl, batched=batched)
+                sync()
+                barrier()
+                ts.append(max_over_ranks(time.perf_counter() - t))
+            st.set_tile(0)
+            dt = statistics.median(ts)
+            cs = st.comm_stats()
+            return {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": circuit_bytes(q, n, cops) / dt / 1e9,
+                    "reps": REPS, "comm": cs}
+
+        for cname, cops, kw in (("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32), {}),
+                                ("configs4_grover_iteration_n%d" % n, circuits.c5_grover_iteration(n), {}),
+                                ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True), {}),
+                                ("configs1_mixed_n%d" % n, ops_mixed, {}),
+                                ("headline_tiled_mode1", ops, {"batched": True, "tile": 1})):
+            try:
+                extras[cname] = dist_leg(cops, **kw)
+            except Exception as exc:  # noqa: BLE001
+                extras[cname] = {"error": repr(exc)}
         try:
-            st.backend.state.set_option("tile", 1)
-            st.run_plan(plan, batched=True)
-            sync()
-            barrier()
-            t = time.perf_counter()
-            st.run_plan(plan, batched=True)
-            sync()
-            barrier()
-            dt = time.perf_counter() - t
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            extras["tiled_mode1"] = {"gates": len(ops), "ms_per_step": 1e3 * float(tt.item()),
-                                     "gates_per_s": len(ops) / float(tt.item())}
-            st.backend.state.set_option("tile", 0)
+            extras["norm_sqr_end"] = st.norm_sqr()
         except Exception as exc:  # noqa: BLE001
-            extras["tiled_mode1"] = {"error": repr(exc)}
+            extras["norm_sqr_end"] = repr(exc)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -347,13 +406,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "single-qubit gate apply GB/s (algorithmic bytes, random H/X/Rz+CNOT circuit)",
+            "metric": "single-qubit gate apply GB/s (algorithmic bytes: 32 * 2^n per H / X / Rz gate)",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"configs[1] generator (random H/X/Rz 3/4 + CNOT 1/4, seed 28, {args.gates} gates) at n={n} "
-                            f"({args.n_local} qubits = {16 * 2**args.n_local / 2**30:.0f} GiB per GPU), Complex<f64>, state = H^n|0>",
+                "workload": f"{args.gates} random single-qubit gates (uniform H / X / Rz(theta), uniform target; configs[1] generator, seed 28, "
+                            f"single-qubit part) at n={n} ({args.n_local} qubits = {16 * 2**args.n_local / 2**30:.0f} GiB per GPU), Complex<f64>, "
+                            f"resident non-uniform state",
                 "n_qubits": n, "n_local": args.n_local, "gates_per_step": args.gates,
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "parallelism": "single GPU" if world == 1 else f"state sharded by top {g} index bits over {world} GPUs, RCCL all-to-all qubit remap",
@@ -361,14 +421,19 @@ def main():
             "gates_per_s": args.gates * args.steps / elapsed,
             "frac_of_hbm_peak_per_gpu": value / world / HBM_PEAK_GBPS,
             "norm_sqr_after": norm,
+            "parity": parity,
+            "parity_rows_checked": parity["rows_checked"] if parity else None,
+            "max_abs_delta": parity["max_abs_delta"] if parity else None,
             "roofline": roofline,
             "kernels": kernels,
+            "mixed_circuit": mixed,
             "cpu_baseline": cpu,
         }
         if extras:
             line["extras"] = extras
         if world > 1:
-            line["comm"] = st.comm_stats()
+            line["comm"] = comm_headline
+            line["dist"] = st.describe()
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -16,7 +16,7 @@
  * For general complex values the reference's tests pin nothing; there the oracle
  * rests on the published num-complex arithmetic definitions (see qip_oracle_impl.h).
  *
- * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -ffp-contract=off).
  */
 #include <math.h>
 #include <omp.h>

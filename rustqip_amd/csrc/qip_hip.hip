@@ -208,12 +208,14 @@ enum KernelClass {
   KC_TILE_GATES,
   KC_GATHER_GENERIC,
   KC_NOOP,
+  KC_SPARSE_KQ,
+  KC_GATE_KQ_BIG,
   KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
     "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_gates",     "k_gather_generic",
-    "noop_identity"};
+    "noop_identity", "k_sparse_kq", "k_gate_big_mfma"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
 extern "C" const char* qip_hip_kernel_class_name(int cls) {
@@ -253,6 +255,7 @@ static void read_dense(const void* dense, uint64_t count, std::vector<double>* o
 
 static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
 static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5
+static constexpr uint32_t kMaxSparseK = 5;  // SparseMatrix ops applied in place (one 2^k group per lane, staged in LDS)
 static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
 
 static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p) {
@@ -271,27 +274,29 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     p->cls = KC_SWAP_BITS;
     return QIP_OK;
   }
+  if (f.inner->kind == QIP_OP_SPARSE) {
+    if (k <= kMaxSparseK) p->cls = KC_SPARSE_KQ;  // in place, stored order (qubit_iterators.rs:87-101)
+    return QIP_OK;
+  }
   if (f.inner->kind != QIP_OP_MATRIX) return QIP_OK;
   if (k > kMaxDiagK) return QIP_OK;
 
-  std::vector<double> d;
   const uint64_t side = 1ull << k;
-  if (dtype == QIP_C64)
-    read_dense<double>(f.inner->dense, side * side, &d);
-  else
-    read_dense<float>(f.inner->dense, side * side, &d);
-
+  // entries are read in place (no 4^k host copy just to look at the structure); the off-diagonal scan exits at the
+  // first non-zero, so a dense matrix costs O(1) here and only a truly diagonal one is walked completely
+  auto re_of = [&](uint64_t e) { return dtype == QIP_C64 ? static_cast<const double*>(f.inner->dense)[2 * e] : (double)static_cast<const float*>(f.inner->dense)[2 * e]; };
+  auto im_of = [&](uint64_t e) { return dtype == QIP_C64 ? static_cast<const double*>(f.inner->dense)[2 * e + 1] : (double)static_cast<const float*>(f.inner->dense)[2 * e + 1]; };
   bool diag = true;
   for (uint64_t r = 0; r < side && diag; ++r)
     for (uint64_t c = 0; c < side; ++c)
-      if (r != c && !is_zero2(d[2 * (r * side + c)], d[2 * (r * side + c) + 1])) {
+      if (r != c && !is_zero2(re_of(r * side + c), im_of(r * side + c))) {
         diag = false;
         break;
       }
   if (diag) {
     uint64_t non_one = 0, last = 0;
     for (uint64_t r = 0; r < side; ++r)
-      if (!is_one2(d[2 * (r * side + r)], d[2 * (r * side + r) + 1])) {
+      if (!is_one2(re_of(r * side + r), im_of(r * side + r))) {
         ++non_one;
         last = r;
       }
@@ -303,19 +308,26 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     if (non_one == 1) {
       p->cls = KC_PHASE;
       p->phase_ones = last;
-      p->phase[0] = d[2 * (last * side + last)];
-      p->phase[1] = d[2 * (last * side + last) + 1];
+      p->phase[0] = re_of(last * side + last);
+      p->phase[1] = im_of(last * side + last);
       p->alg_bytes = 2.0 * amp_bytes * std::ldexp(1.0, (int)(n - f.n_control - k));
       return QIP_OK;
     }
     p->cls = KC_DIAG;
     p->table.resize(side * 2);
     for (uint64_t r = 0; r < side; ++r) {
-      p->table[2 * r] = d[2 * (r * side + r)];
-      p->table[2 * r + 1] = d[2 * (r * side + r) + 1];
+      p->table[2 * r] = re_of(r * side + r);
+      p->table[2 * r + 1] = im_of(r * side + r);
     }
     p->alg_bytes = 2.0 * amp_bytes * std::ldexp(1.0, (int)(n - f.n_control - k)) * (double)non_one;
     return QIP_OK;
+  }
+  std::vector<double> d;
+  if (k <= std::max(kMaxRegK, kMaxMfmaK)) {
+    if (dtype == QIP_C64)
+      read_dense<double>(f.inner->dense, side * side, &d);
+    else
+      read_dense<float>(f.inner->dense, side * side, &d);
   }
   if (k == 1) {
     p->cls = KC_GATE1Q_PAIR;  // the launcher may pick the cross-lane variant
@@ -372,6 +384,7 @@ struct qip_hip_state {
   // device arena for op payloads (matrices, CSR)
   void* arena = nullptr;
   size_t arena_cap = 0;
+  uint64_t arena_gen = 0;  // bumped whenever the arena is re-allocated: captured graphs hold its address
   // reduction scratch
   double* d_partial = nullptr;
   size_t partial_cap = 0;
@@ -384,6 +397,7 @@ struct qip_hip_state {
   int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
   int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
+  int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default pairs them up, k_swap2)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
   size_t capture_arena_need = 0;
@@ -412,6 +426,7 @@ static int ensure_arena(qip_hip_state* s, size_t bytes) {
   size_t cap = std::max<size_t>(bytes, 1 << 16);
   HIPCHK(hipMalloc(&s->arena, cap));
   s->arena_cap = cap;
+  s->arena_gen += 1;
   return QIP_OK;
 }
 
@@ -610,6 +625,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile")) s->tile = value;
   else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
+  else if (!strcmp(key, "swap_single")) s->swap_single = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -862,15 +878,85 @@ static int launch_diag(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* 
   return QIP_OK;
 }
 
+// two transpositions (pa0 pb0)(pa1 pb1), pa < pb, in ONE sweep (k_swap2); false when the shape does not apply
+template <typename T, typename E>
+static int launch_swap2(qip_hip_state* s, uint32_t n, const Split& sp, uint32_t pa0, uint32_t pb0, uint32_t pa1,
+                        uint32_t pb1, E* st, bool* done) {
+  *done = false;
+  struct Pair { uint32_t pa, pb; int type; };
+  Pair pr[2] = {{pa0, pb0, 0}, {pa1, pb1, 0}};
+  for (Pair& q : pr) {
+    const bool la = work_bit(q.pa, sp.hi) < 6, lb = work_bit(q.pb, sp.hi) < 6;
+    q.type = (la && lb) ? SW_LL : (la ? SW_HL : SW_HH);  // pa < pb: a lane-bit pb implies a lane-bit pa
+  }
+  if (pr[0].type > pr[1].type) std::swap(pr[0], pr[1]);  // the stages act on disjoint bits: any order
+  Swap2Desc d;
+  memset(&d, 0, sizeof d);
+  std::vector<uint32_t> pos = sp.hi;
+  int r = 0;
+  for (int q = 0; q < 2; ++q) {
+    if (pr[q].type == SW_HH) {
+      d.off[r++] = 1ull << pr[q].pa;
+      d.off[r++] = 1ull << pr[q].pb;
+      pos.push_back(pr[q].pa);
+      pos.push_back(pr[q].pb);
+    } else if (pr[q].type == SW_HL) {
+      d.off[r++] = 1ull << pr[q].pb;
+      pos.push_back(pr[q].pb);
+      d.la[q] = work_bit(pr[q].pa, sp.hi);
+    } else {
+      d.la[q] = work_bit(pr[q].pa, sp.hi);
+      d.lb[q] = work_bit(pr[q].pb, sp.hi);
+    }
+  }
+  const uint32_t NH = (uint32_t)r;
+  const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
+  const uint64_t nitems = nsub >> NH;
+  if (nitems < 64) return QIP_OK;  // fewer items than lanes: the lane-bit classification does not hold
+  Ins ins = make_ins(pos, sp.hi_ones);
+#define SW2(S0, S1, UU)                                                                                              \
+  do {                                                                                                               \
+    if (nitems >= ((uint64_t)(UU) << kStrideShift)) {                                                                \
+      if (use_nt(s)) hipLaunchKernelGGL((k_swap2<T, S0, S1, UU, false, true, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low); \
+      else hipLaunchKernelGGL((k_swap2<T, S0, S1, UU, false, false, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);          \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL((k_swap2<T, S0, S1, 1, true, false, E>), grid2d(nitems, kBlock), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);                         \
+    }                                                                                                                \
+  } while (0)
+  const int code = pr[0].type * 3 + pr[1].type;
+  switch (code) {
+    case SW_HH * 3 + SW_HH: SW2(SW_HH, SW_HH, 1); break;
+    case SW_HH * 3 + SW_HL: SW2(SW_HH, SW_HL, 1); break;
+    case SW_HH * 3 + SW_LL: SW2(SW_HH, SW_LL, 2); break;
+    case SW_HL * 3 + SW_HL: SW2(SW_HL, SW_HL, 2); break;
+    case SW_HL * 3 + SW_LL: SW2(SW_HL, SW_LL, 4); break;
+    default: SW2(SW_LL, SW_LL, 4); break;
+  }
+#undef SW2
+  HIPCHK(hipGetLastError());
+  *done = true;
+  return QIP_OK;
+}
+
 template <typename T, typename E>
 static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
-  // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact,
-  // so applying them one after another is bit-identical to the single permutation.
+  // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact, so applying them in
+  // groups is bit-identical to the single permutation: two transpositions per sweep (k_swap2), a last odd one alone.
   const uint32_t h = (uint32_t)p.opos.size() / 2;
   const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
   for (uint32_t j = 0; j < h; ++j) {
     uint32_t pa = p.opos[j], pb = p.opos[h + j];
     if (pa > pb) std::swap(pa, pb);  // pa < pb
+    if (j + 1 < h && !s->swap_single) {
+      uint32_t qa = p.opos[j + 1], qb = p.opos[h + j + 1];
+      if (qa > qb) std::swap(qa, qb);
+      bool done = false;
+      QCHK((launch_swap2<T, E>(s, n, sp, pa, pb, qa, qb, st, &done)));
+      if (done) {
+        ++j;
+        continue;
+      }
+    }
     const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
     const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
     if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
@@ -1007,11 +1093,11 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
 #define KQ(K, UU)                                                                                       \
   do {                                                                                                  \
     if (groups >= ((uint64_t)(UU) << kStrideShift) && s->unroll == 2 && (UU) > 1) {                     \
-      const dim3 grid(grid_for(groups, kBlock * (UU)));                                                 \
+      const dim3 grid = grid2d(groups, kBlock * (UU));                                                  \
       if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);  \
       else hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
     } else {                                                                                            \
-      const dim3 grid(grid_for(groups, kBlock));                                                        \
+      const dim3 grid = grid2d(groups, kBlock);                                                         \
       if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
       else hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);      \
     }                                                                                                   \
@@ -1070,6 +1156,54 @@ static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, 
   }
   hipLaunchKernelGGL((k_gather_generic<T>), dim3(grid_stride(out_len)), dim3(kBlock), 0, s->stream, in,
                      out, d, dense, rowptr, cols, vals);
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// SparseMatrix (optionally controlled) on k <= 5 distinct qubits, in place (k_sparse_kq)
+template <typename T>
+static int launch_sparse_kq(qip_hip_state* s, const Plan& p, const FlatOp& f, amp_t<T>* st) {
+  const uint32_t k = f.n_op;
+  const uint64_t rows = 1ull << k;
+  const uint64_t nnz = f.inner->sparse_rowptr[rows];
+  const size_t b_rp = (rows + 1) * 8, b_cols = nnz * 8, b_vals = nnz * sizeof(amp_t<T>);
+  const size_t o_cols = (b_rp + 15) & ~(size_t)15, o_vals = (o_cols + b_cols + 15) & ~(size_t)15;
+  QCHK(ensure_arena(s, o_vals + b_vals + 16));  // one allocation: growing frees the old arena
+  QCHK(arena_upload(s, f.inner->sparse_rowptr, b_rp, 0));
+  if (nnz) {
+    QCHK(arena_upload(s, f.inner->sparse_cols, b_cols, o_cols));
+    QCHK(arena_upload(s, f.inner->sparse_vals, b_vals, o_vals));
+  }
+  const uint64_t* rowptr = (const uint64_t*)s->arena;
+  const uint64_t* cols = (const uint64_t*)((char*)s->arena + o_cols);
+  const amp_t<T>* vals = (const amp_t<T>*)((char*)s->arena + o_vals);
+  std::vector<uint32_t> pos = p.cpos;
+  uint32_t min_target = 64;
+  for (uint32_t t : p.opos) {
+    pos.push_back(t);
+    min_target = std::min(min_target, t);
+  }
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  const uint64_t groups = 1ull << (s->n - (uint32_t)pos.size());
+  const DiagDesc d = make_diagdesc(p);
+  const bool nt = use_nt(s) && min_target >= 6;
+  const unsigned threads = k <= 3 ? 256u : (k == 4 ? 128u : 64u);
+  const size_t lds = (sizeof(amp_t<T>) << k) * threads;
+  const dim3 grid = grid2d(groups, threads);
+#define SPK(K)                                                                                                          \
+  do {                                                                                                                  \
+    if (nt) hipLaunchKernelGGL((k_sparse_kq<T, K, true>), grid, dim3(threads), lds, s->stream, st, groups, ins, d, rowptr, cols, vals);  \
+    else hipLaunchKernelGGL((k_sparse_kq<T, K, false>), grid, dim3(threads), lds, s->stream, st, groups, ins, d, rowptr, cols, vals);    \
+  } while (0)
+  switch (k) {
+    case 1: SPK(1); break;
+    case 2: SPK(2); break;
+    case 3: SPK(3); break;
+    case 4: SPK(4); break;
+    case 5: SPK(5); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "in-place sparse kernel for k = %u", k);
+  }
+#undef SPK
   HIPCHK(hipGetLastError());
   return QIP_OK;
 }
@@ -1146,6 +1280,7 @@ static int apply_op_t(qip_hip_state* s, const qip_op* op) {
     case KC_DIAG: rc = launch_diag<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
     case KC_SWAP_BITS: rc = launch_swap<T, amp_t<T>>(s, s->n, p, st); break;
     case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
+    case KC_SPARSE_KQ: rc = launch_sparse_kq<T>(s, p, f, st); break;
     default: {
       QCHK(ensure_alt(s));
       rc = launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0,
@@ -1726,7 +1861,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   };
   if (s->tile_passes) {
     QCHK(begin());
-#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream, \
+#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream, \
                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats)
     if (use_nt(s)) TP(true);
     else TP(false);
@@ -1734,10 +1869,10 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   } else {
     QCHK(begin());
     if (use_nt(s))
-      hipLaunchKernelGGL((k_tile_gates<T, true>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+      hipLaunchKernelGGL((k_tile_gates<T, true>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream,
                          (amp_t<T>*)s->cur, ins, d, dg);
     else
-      hipLaunchKernelGGL((k_tile_gates<T, false>), dim3((unsigned)ntiles), dim3(kBlock), lds, s->stream,
+      hipLaunchKernelGGL((k_tile_gates<T, false>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream,
                          (amp_t<T>*)s->cur, ins, d, dg);
   }
   HIPCHK(hipGetLastError());
@@ -1963,6 +2098,7 @@ struct qip_hip_program {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   void* captured_cur = nullptr;
+  uint64_t captured_arena_gen = 0;  // the graph's memcpy / kernel nodes hold arena addresses
   std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
   int last_was_graph = 0;
 };
@@ -2015,6 +2151,7 @@ static int program_capture(qip_hip_program* p) {
       if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) == hipSuccess) {
         p->graph = g;
         p->captured_cur = s->cur;
+        p->captured_arena_gen = s->arena_gen;
         return QIP_OK;
       }
       (void)hipGetLastError();
@@ -2069,9 +2206,11 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) try {
   qip_hip_state* s = p->s;
   if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
   STATE_ENTER(s);
-  if (p->exec && (p->captured_cur != s->cur || s->profile || s->force_generic || g_force_generic)) {
+  if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen || s->profile || s->force_generic ||
+                  g_force_generic)) {
     if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
-    else QCHK(program_capture(p));  // the state moved to its other buffer: re-record against it
+    else QCHK(program_capture(p));  // the state moved to its other buffer, or the arena was re-allocated (an eager op
+                                    // needed a larger payload): the recorded addresses are stale, re-record
   }
   if (p->exec) {
     HIPCHK(hipGraphLaunch(p->exec, s->stream));
@@ -2247,18 +2386,49 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
     }
     return QIP_OK;
   }
-  if (m_count == (1ull << k) && k <= 12) {
-    // a moderate number of outcomes: per-block LDS histogram + one global atomic per bin per block
-    const uint32_t nbins = 1u << k;
-    QCHK(ensure_partial(s, nbins));
-    HIPCHK(hipMemsetAsync(s->d_partial, 0, nbins * sizeof(double), s->stream));
-    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(s->namps / (kBlock * 16), 1), 1024);
-    hipLaunchKernelGGL((k_measure_probs_hist<T>), dim3(gx), dim3(kBlock), nbins * sizeof(double), s->stream,
-                       (const amp_t<T>*)s->cur, s->namps, md, nbins, s->d_partial);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, s->d_partial, nbins * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    return QIP_OK;
+  if (m_count == (1ull << k)) {
+    // more outcomes, no atomics: measured positions >= 8 on the grid, the others resolved per lane (k_measure_probs_grid)
+    MeasGridDesc gd;
+    memset(&gd, 0, sizeof gd);
+    uint32_t gbit[kMaxIns], lbit[8];
+    std::vector<uint32_t> gp;
+    for (uint32_t i = 0; i < k; ++i) {
+      if (md.mpos[i] >= 8) {
+        gbit[gd.kg] = i;
+        gd.gpos[gd.kg++] = md.mpos[i];
+        gp.push_back(md.mpos[i]);
+      } else {
+        lbit[gd.kl] = i;
+        gd.lpos[gd.kl++] = md.mpos[i];
+      }
+    }
+    if (gd.kg <= 20) {
+      Ins ins = make_ins(gp, 0);
+      const uint64_t count = 1ull << (s->n - gd.kg);  // indices per grid outcome
+      const uint64_t ny = 1ull << gd.kg, nl = 1ull << gd.kl;
+      // about 8192 blocks in all, each with at least four 4-KiB rows when the outcome has that many
+      uint64_t gx = std::max<uint64_t>(8192 / ny, 1);
+      gx = std::min<uint64_t>(gx, std::max<uint64_t>(count / (kBlock * 4), 1));
+      const size_t np = (size_t)(ny * nl * gx);
+      QCHK(ensure_partial(s, np));
+      hipLaunchKernelGGL((k_measure_probs_grid<T>), dim3((unsigned)(ny * gx)), dim3(kBlock), 0, s->stream,
+                         (const amp_t<T>*)s->cur, count, ins, gd, (uint32_t)gx, s->d_partial);
+      HIPCHK(hipGetLastError());
+      std::vector<double> part(np);
+      HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, np * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      for (uint64_t mg = 0; mg < ny; ++mg)
+        for (uint64_t l = 0; l < nl; ++l) {
+          double t = 0;
+          const double* pp = part.data() + ((mg << gd.kl) | l) * gx;
+          for (uint64_t b = 0; b < gx; ++b) t += pp[b];
+          uint64_t m = 0;
+          for (uint32_t i = 0; i < gd.kg; ++i) m |= ((mg >> i) & 1ull) << gbit[i];
+          for (uint32_t i = 0; i < gd.kl; ++i) m |= ((l >> i) & 1ull) << lbit[i];
+          out[m] = t;
+        }
+      return QIP_OK;
+    }
   }
   if (m_count == 1) {
     // one outcome: sum over the sub-space whose measured bits read m (measure_prob_fn :65-112)

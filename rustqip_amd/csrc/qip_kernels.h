@@ -424,6 +424,104 @@ __global__ __launch_bounds__(kBlock) void k_swap_xlane1(E* __restrict__ st, uint
   }
 }
 
+// ---- TWO disjoint bit transpositions in one sweep (Swap with h >= 2, two pairs at a time) --------------------------
+// Swap(h, A ++ B) is the product of the h transpositions (A[j] B[j]); moves are exact, so any grouping of them is
+// bit-identical to the single permutation.  One sweep per PAIR of transpositions instead of one per transposition:
+// a lane holds the 2^NH amplitudes that differ on the NH "register" bits (swapped positions outside the lane index)
+// and applies each transposition as a stage on that register file:
+//   HH  both bits are register bits   -> a renaming of registers (free);
+//   HL  one register bit, one lane bit -> lanes whose lane bit differs from the register bit exchange with lane ^ bit
+//       (the k_swap_xlane2 rule, for every combination of the other register bits);
+//   LL  both bits are lane bits        -> every register comes from the lane with the two bits exchanged.
+// Global accesses stay whole contiguous rows.  When both transpositions are HH the 4 of 16 combinations that are
+// fixed points (a0 == b0 and a1 == b1) are neither loaded nor stored.
+enum SwapStage : int { SW_HH = 0, SW_HL = 1, SW_LL = 2 };
+struct Swap2Desc {
+  uint64_t off[4];  // amplitude-index bit of register bit r (1 << position); unused ones are 0
+  uint32_t la[2];   // stage s: its lane bit (HL), or its first lane bit (LL)
+  uint32_t lb[2];   // stage s: second lane bit (LL)
+};
+template <int ST> struct SwapRegBits;
+template <> struct SwapRegBits<SW_HH> { static constexpr int v = 2; };
+template <> struct SwapRegBits<SW_HL> { static constexpr int v = 1; };
+template <> struct SwapRegBits<SW_LL> { static constexpr int v = 0; };
+
+template <int ST, int R0, int NR, typename A>
+__device__ __forceinline__ void swap_stage(A (&x)[NR], uint32_t lane, uint32_t la, uint32_t lb) {
+  if constexpr (ST == SW_HH) {
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+      if (((c >> R0) & 1) == 1 && ((c >> (R0 + 1)) & 1) == 0) {
+        const int k = (c & ~(1 << R0)) | (1 << (R0 + 1));
+        const A t = x[c];
+        x[c] = x[k];
+        x[k] = t;
+      }
+  } else if constexpr (ST == SW_HL) {
+    const bool lbit = (lane >> la) & 1u;
+    // slot (reg bit r, lane bit l) <-> slot (l, r): lanes with l = 1 give away their r = 0 element, lanes with
+    // l = 0 their r = 1 element, and receive into the same slot
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+      if (((c >> R0) & 1) == 0) {
+        const int k = c | (1 << R0);
+        const A xc = x[c], xk = x[k];
+        const A got = shfl_xor_e<A>(lbit ? xc : xk, 1 << la);
+        x[c] = lbit ? got : xc;  // selects on values, never a conditional store: that would address the register file
+        x[k] = lbit ? xk : got;
+      }
+  } else {
+    const uint32_t ba = (lane >> la) & 1u, bb = (lane >> lb) & 1u;
+    const uint32_t src = (lane & ~((1u << la) | (1u << lb))) | (bb << la) | (ba << lb);
+#pragma unroll
+    for (int c = 0; c < NR; ++c) x[c] = shfl_e<A>(x[c], (int)src);
+  }
+}
+
+template <typename T, int ST0, int ST1, int U, bool GUARD, bool NT, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_swap2(E* __restrict__ st, uint64_t nitems, Ins ins, Swap2Desc d, Sel low) {
+  using A = E;
+  constexpr int NH = SwapRegBits<ST0>::v + SwapRegBits<ST1>::v;
+  constexpr int NR = 1 << NH;
+  constexpr bool kSkipFixed = ST0 == SW_HH && ST1 == SW_HH;
+  if (GUARD && work_index<0>(0) >= nitems) return;  // whole waves leave together (nitems % 64 == 0)
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t off[NR];
+#pragma unroll
+  for (int c = 0; c < NR; ++c) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int r = 0; r < NH; ++r)
+      if ((c >> r) & 1) o |= d.off[r];
+    off[c] = o;
+  }
+  auto fixed = [](int c) { return kSkipFixed && ((c & 1) == ((c >> 1) & 1)) && (((c >> 2) & 1) == ((c >> 3) & 1)); };
+  uint64_t i0[U];
+  A x[U][NR];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = insert_bits<-1>(work_index<Log2<U>::v>(u), ins);
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+      if (!fixed(c)) x[u][c] = ldg<NT>(st + (i0[u] | off[c]));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    A y[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+      if (!fixed(c)) y[c] = x[u][c];
+    swap_stage<ST0, 0, NR, A>(y, lane, d.la[0], d.lb[0]);
+    swap_stage<ST1, SwapRegBits<ST0>::v, NR, A>(y, lane, d.la[1], d.lb[1]);
+    // controls below kLineBits: the partner lanes / registers have the same control bits (controls are never
+    // swapped bits), so one predicate on this lane's index serves every slot it holds
+    const bool hit = sel_hit(i0[u], low);
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+      if (!fixed(c)) stg<NT>(st + (i0[u] | off[c]), hit ? y[c] : x[u][c]);
+  }
+}
+
 // ---- general diagonal gate on k qubits ------------------------------------------------
 // Amplitude per lane inside the control subspace; factor = diag[sub-index] (table in the arena, served
 // by the caches).  `tpos[j]` is the bit position of op index j (j = 0 is the MSB of the sub-index,
@@ -595,6 +693,50 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
   }
 }
 
+// ---- SparseMatrix on k <= 5 qubits, in place ---------------------------------------------------------------------
+// SparseMatrixOpIterator (qubit_iterators.rs:60-102): row r of the op is its stored list of (column, value), applied
+// in stored order with nothing filtered; out[r] = 0 + v_0 * x[c_0] + v_1 * x[c_1] + ...  One lane owns one group of
+// 2^K amplitudes (as in k_gate_kq: same addresses, same coalescing) and parks them in its own LDS column
+// (slot [c][tid]: conflict-free, nobody else touches the column, so no barrier), because the column a stored entry
+// names is a run-time value and registers cannot be indexed by one.  Rows are then folded exactly like the literal
+// kernel does and written straight over the input: every input of the group is already in LDS.
+// LDS: 2^K * block * 16 B = 32 KiB for every K (block = 256 lanes up to K = 3, 128 at K = 4, 64 at K = 5).
+template <typename T, int K, bool NT>
+__global__ void k_sparse_kq(amp_t<T>* __restrict__ st, uint64_t ngroups, Ins ins, DiagDesc d,
+                            const uint64_t* __restrict__ rowptr, const uint64_t* __restrict__ cols,
+                            const amp_t<T>* __restrict__ vals) {
+  using A = amp_t<T>;
+  constexpr int S = 1 << K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sparse_raw[];
+  A* col = reinterpret_cast<A*>(sparse_raw);
+  const uint32_t nthr = blockDim.x;
+  const uint64_t w = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) * nthr + threadIdx.x;
+  if (w >= ngroups) return;
+  const uint64_t i0 = insert_bits<-1>(w, ins);
+  uint64_t off[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if ((c >> (K - 1 - j)) & 1) o |= 1ull << d.tpos[j];
+    off[c] = o;
+  }
+  A x[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) x[c] = ldg<NT>(st + (i0 | off[c]));
+#pragma unroll
+  for (int c = 0; c < S; ++c) col[c * nthr + threadIdx.x] = x[c];
+  // same lane reads what it wrote: program order is enough (the compiler inserts the lgkmcnt wait)
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    A acc = czero<A>();
+    const uint64_t pe = rowptr[r + 1];
+    for (uint64_t p = rowptr[r]; p < pe; ++p) acc = cadd(acc, cmul(vals[p], col[(uint32_t)cols[p] * nthr + threadIdx.x]));
+    stg<NT>(st + (i0 | off[r]), acc);
+  }
+}
+
 // ---- LDS-resident multi-gate sweep ------------------------------------------
 // One sweep applies a whole LIST of gates: a 256-lane block stages a tile of 2^11 amplitudes in LDS
 // (32 KiB for f64) — index bits 0..5 (one contiguous 1-KiB wave row) plus kTileHigh = 5 arbitrary
@@ -671,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
   // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
-  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  const uint64_t base = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
   uint64_t idx[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
@@ -1007,7 +1149,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // everything but the lane id is wave-uniform: tile bits 6, 7 = wave id, bits 8..10 = u
-  uint64_t wbase = insert_bits<-1>((uint64_t)blockIdx.x << kTileLow, ins);
+  uint64_t wbase = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
   const uint64_t base = wbase;
   wbase |= (uint64_t)(wave & 1u) << d.hpos[0];
   wbase |= (uint64_t)((wave >> 1) & 1u) << d.hpos[1];
@@ -1287,26 +1429,56 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_small(const amp_t<T>* 
   }
 }
 
-// a moderate number of outcomes (2^k doubles fit in LDS): per-block LDS histogram, then one global
-// atomic per bin per block
+// 5 <= k <= ~20 outcomes bits without any atomic: the measured positions >= 8 go on the GRID (blockIdx.y = their
+// value mg: the block only visits indices that read mg there; `ins` opens those positions), the measured positions
+// < 8 are a function of the lane id alone.  So a lane accumulates ONE running sum over fully coalesced 4-KiB block
+// rows, and at the end the 256 lane sums are folded by lane outcome (2^kl <= 256 bins) through LDS:
+// partial[((mg << kl) | l) * gx + bx].  The host adds the gx partials per outcome.
+struct MeasGridDesc {
+  uint32_t kg, kl;
+  uint32_t gpos[kMaxIns];   // measured positions >= 8, in outcome-bit order of the grid part
+  uint32_t lpos[8];         // measured positions < 8
+};
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_measure_probs_hist(const amp_t<T>* __restrict__ st,
-                                                               uint64_t namps, MeasDesc md, uint32_t nbins,
-                                                               double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double hist[];
-  for (uint32_t b = threadIdx.x; b < nbins; b += kBlock) hist[b] = 0.0;
-  __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
-    const amp_t<T> x = __builtin_nontemporal_load(st + i);
-    if (x.x == (T)0 && x.y == (T)0) continue;  // measurement_ops.rs:98-99
-    uint32_t m = 0;
-    for (uint32_t b = 0; b < md.k; ++b) m |= (uint32_t)((i >> md.mpos[b]) & 1ull) << b;
-    atomicAdd(&hist[m], (double)(x.x * x.x + x.y * x.y));
+__global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+                                                              MeasGridDesc md, uint32_t gx, double* __restrict__ partial) {
+  __shared__ double lane_sum[kBlock];
+  // 1-D grid of (outcomes on the grid) x gx blocks: HIP caps gridDim.y at 65535 and kg may reach 20
+  const uint64_t mg = blockIdx.x / gx;
+  const uint32_t bx = blockIdx.x % gx;
+  uint64_t templ = 0;
+  for (uint32_t i = 0; i < md.kg; ++i) templ |= ((mg >> i) & 1ull) << md.gpos[i];
+  // `count` (a power of two >= 256) work items per mg, gridDim.x blocks striding over them, 4 rows in flight per lane
+  const uint64_t stride = (uint64_t)gx * kBlock;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  uint64_t w = (uint64_t)bx * kBlock + threadIdx.x;
+  for (; w + 3 * stride < count; w += 4 * stride) {
+    const amp_t<T> a = __builtin_nontemporal_load(st + (insert_bits<-1>(w, ins) | templ));
+    const amp_t<T> b = __builtin_nontemporal_load(st + (insert_bits<-1>(w + stride, ins) | templ));
+    const amp_t<T> c = __builtin_nontemporal_load(st + (insert_bits<-1>(w + 2 * stride, ins) | templ));
+    const amp_t<T> e = __builtin_nontemporal_load(st + (insert_bits<-1>(w + 3 * stride, ins) | templ));
+    s0 += (double)(a.x * a.x + a.y * a.y);
+    s1 += (double)(b.x * b.x + b.y * b.y);
+    s2 += (double)(c.x * c.x + c.y * c.y);
+    s3 += (double)(e.x * e.x + e.y * e.y);
   }
+  for (; w < count; w += stride) {
+    const amp_t<T> a = __builtin_nontemporal_load(st + (insert_bits<-1>(w, ins) | templ));
+    s0 += (double)(a.x * a.x + a.y * a.y);
+  }
+  lane_sum[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nbins; b += kBlock)
-    if (hist[b] != 0.0) atomicAdd(&out[b], hist[b]);
+  const uint32_t nl = 1u << md.kl;
+  if (threadIdx.x < nl) {
+    // lanes whose measured low bits read threadIdx.x (bit i of the lane outcome <-> position lpos[i])
+    double t = 0;
+    for (uint32_t l = 0; l < (uint32_t)kBlock; ++l) {
+      uint32_t lo = 0;
+      for (uint32_t i = 0; i < md.kl; ++i) lo |= ((l >> md.lpos[i]) & 1u) << i;
+      if (lo == threadIdx.x) t += lane_sum[l];
+    }
+    partial[((mg << md.kl) | threadIdx.x) * gx + bx] = t;
+  }
 }
 
 // probabilities of many outcomes: every amplitude adds |amp|^2 to out[its outcome]
@@ -1353,12 +1525,12 @@ __global__ __launch_bounds__(kBlock) void k_find_crossing(const amp_t<T>* __rest
   const uint64_t seg = (len + kBlock - 1) / kBlock;
   const uint64_t a = lo + (uint64_t)threadIdx.x * seg;
   const uint64_t b = a + seg < lo + len ? a + seg : lo + len;
-  T acc = 0;
+  double acc = 0;  // double for both dtypes: the skip margin below is far tighter than f32 summation error
   for (uint64_t i = a; i < b; ++i) {
     const amp_t<T> x = st[i];
-    acc += x.x * x.x + x.y * x.y;
+    acc += (double)(x.x * x.x + x.y * x.y);
   }
-  seg_sum[threadIdx.x] = (double)acc;
+  seg_sum[threadIdx.x] = acc;
   __shared__ double r_cur;
   __shared__ unsigned long long found_at;
   if (threadIdx.x == 0) {

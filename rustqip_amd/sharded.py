@@ -169,6 +169,8 @@ class HipBackend:
         fn()
         e1.record()
         self._events.append((e0, e1))
+        if len(self._events) > 4096:  # nobody is draining: keep the list bounded
+            self.collective_ms()
 
     def collective_ms(self) -> float:
         self.torch.cuda.synchronize(self.dev)
@@ -411,6 +413,11 @@ class ShardedState:
         self.dist.all_reduce(t)
         return t.cpu().numpy()
 
+    def _bcast0(self, arr: np.ndarray) -> np.ndarray:
+        t = self.backend.reduce_tensor(np.ascontiguousarray(arr, dtype=np.float64))
+        self.dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
     def norm_sqr(self) -> float:
         return float(self._allreduce_sum(np.array([self.backend.norm_sqr()]))[0])
 
@@ -445,11 +452,18 @@ class ShardedState:
         k = len(indices)
         probs = self.measure_probs(indices)
         if measured is None:
-            r, m = float(rand_u01) * float(probs.sum()), 0
-            for m, pm in enumerate(probs):
+            # every rank must collapse to the SAME outcome: rank 0's sample decides (probs is already identical on
+            # all ranks after the all-reduce; the caller's rand_u01 need not be)
+            r = float(self._bcast0(np.array([float(rand_u01)]))[0]) * float(probs.sum())
+            m = None
+            for cand, pm in enumerate(probs):
+                if pm > 0:
+                    m = cand  # fall-through (rounding left r > 0): the last outcome that can occur, never a p == 0 one
                 r -= pm
-                if r <= 0:
+                if r <= 0 and pm > 0:
                     break
+            if m is None:
+                m = 0
         else:
             m = int(measured)
         p = float(probs[m])
@@ -479,6 +493,25 @@ class ShardedState:
         return self.backend.take_profile()
 
     def comm_stats(self) -> dict:
+        """counters since the previous call (they reset), with the summed duration of the collectives"""
         s = dict(self.stats)
         s["collective_ms"] = self.backend.collective_ms()
+        for k in self.stats:
+            self.stats[k] = 0 if k != "collective_ms" else 0.0
         return s
+
+    def set_tile(self, mode: int) -> None:
+        """option "tile" of the shard's state: applies to run_plan(batched=True) batches"""
+        shard = getattr(self.backend, "state", None)
+        if shard is not None:
+            shard.set_option("tile", int(mode))
+
+    def describe(self) -> dict:
+        return {"impl": "rustqip_amd.sharded.ShardedState (host planner in Python, torch.distributed all_to_all_single)",
+                "world": self.world, "n": self.n, "n_local": self.L}
+
+
+def make_sharded_state(n: int, n_local: int, dist, device: int, host_staged: bool = False):
+    """The sharded state bench.py and the tests drive: the in-library implementation (C ABI qip_hip_dist_*, planner and
+    RCCL exchange inside libqip_hip.so) when available, else the torch.distributed one above."""
+    return ShardedState(n, dist, backend=HipBackend(n_local, device, host_staged_exchange=host_staged))

@@ -10,6 +10,7 @@ Everything goes through the C ABI (ctypes -> libqip_hip.so -> HIP kernels).  Bar
 import cmath
 import math
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -210,6 +211,161 @@ def test_swap_every_bit_pair_and_low_controls(O):
     for qa, qb, ctrl in ((8, 0, [7]), (8, 7, [6]), (0, 1, [8, 2]), (5, 2, [8, 7, 6]), (3, 4, [7, 0])):
         op = q.make_control_op(ctrl, q.make_swap_op([qa], [qb]))
         assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), (qa, qb, ctrl)
+
+
+def test_swap_two_transpositions_per_sweep(O):
+    """Swap(h >= 2) runs two transpositions per sweep (k_swap2): every combination of register-bit / lane-bit pairs
+    (HH, HL, LL stages), with controls inside and outside a 128-B line, f64 / f32 (packed and unpacked view), against
+    the oracle bit for bit and against the one-transposition-per-sweep path."""
+    n = 12
+    rng = np.random.default_rng(12)
+    lo, hi = list(range(n - 6, n)), list(range(0, n - 6))  # qubits on bit positions 0..5 / 6..11
+    shapes = {
+        "HH,HH": lambda: (list(rng.permutation(hi)[:4]), []),
+        "HH,HL": lambda: (list(rng.permutation(hi)[:3]), list(rng.permutation(lo)[:1])),
+        "HH,LL": lambda: (list(rng.permutation(hi)[:2]), list(rng.permutation(lo)[:2])),
+        "HL,HL": lambda: (list(rng.permutation(hi)[:2]), list(rng.permutation(lo)[:2])),
+        "HL,LL": lambda: (list(rng.permutation(hi)[:1]), list(rng.permutation(lo)[:3])),
+        "LL,LL": lambda: ([], list(rng.permutation(lo)[:4])),
+    }
+    for dtype in (np.complex128, np.complex64):
+        x = rand_state(n, 5, dtype)
+        for name, pick in shapes.items():
+            for trial in range(4):
+                H, L = pick()
+                H, L = [int(v) for v in H], [int(v) for v in L]
+                if name == "HH,HH":
+                    a, b = [H[0], H[2]], [H[1], H[3]]
+                elif name == "HH,HL":
+                    a, b = [H[0], H[2]], [H[1], L[0]]
+                elif name == "HH,LL":
+                    a, b = [H[0], L[0]], [H[1], L[1]]
+                elif name == "HL,HL":
+                    a, b = [H[0], L[1]], [L[0], H[1]]
+                elif name == "HL,LL":
+                    a, b = [L[0], L[1]], [H[0], L[2]]
+                else:
+                    a, b = [L[0], L[2]], [L[1], L[3]]
+                used = set(a + b)
+                free = [t for t in range(n) if t not in used]
+                for ctrl in ([], [free[0]], [t for t in free if t >= n - 3][:2], [free[-1], free[1]]):
+                    op = q.make_swap_op(a, b)
+                    if ctrl:
+                        op = q.make_control_op(ctrl, op)
+                    want = oracle_apply(O, n, op, x)
+                    assert np.array_equal(hip_apply(n, op, x), want), (name, a, b, ctrl, dtype)
+                    assert np.array_equal(hip_apply(n, op, x, swap_single=1), want), (name, a, b, ctrl)
+                    if dtype == np.complex64:
+                        assert np.array_equal(hip_apply(n, op, x, packed_f32=0), want), (name, a, b, ctrl)
+    # h = 3 and 4: two sweeps
+    x = rand_state(n, 6)
+    for h in (3, 4, 5):
+        for trial in range(6):
+            perm = [int(v) for v in rng.permutation(n)]
+            op = q.make_swap_op(perm[:h], perm[h:2 * h])
+            assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x)), (h, perm)
+    # small states fall back to one transposition per sweep
+    for m in (4, 5, 6, 7, 8):
+        xs = rand_state(m, m)
+        op = q.make_swap_op([0, 1], [m - 1, m - 2])
+        assert np.array_equal(hip_apply(m, op, xs), oracle_apply(O, m, op, xs)), m
+
+
+def test_sparse_in_place_kernel(O):
+    """SparseMatrix on k <= 5 qubits is applied in place (k_sparse_kq): rows in stored order, repeated columns, rows
+    of very different lengths, targets on low bit positions, controls — bit-equal to the oracle, no second buffer."""
+    n = 11
+    rng = np.random.default_rng(7)
+    x = rand_state(n, 7)
+    for k in (1, 2, 3, 4, 5):
+        for trial in range(5):
+            perm = [int(v) for v in rng.permutation(n)]
+            if trial == 0:
+                perm = list(range(n - k, n)) + list(range(n - k))  # targets on the lowest bit positions
+            rows = []
+            for r in range(1 << k):
+                cnt = int(rng.integers(1, (1 << k) + 3))
+                cols = rng.integers(0, 1 << k, size=cnt)  # repeats allowed, arbitrary order
+                rows.append([(int(c), complex(rng.standard_normal(), rng.standard_normal())) for c in cols])
+            op = q.make_sparse_matrix_op(perm[:k], rows)
+            for o in (op, q.make_control_op(perm[k:k + 1], op), q.make_control_op(perm[k:k + 2], op)):
+                want = oracle_apply(O, n, o, x)
+                with q.HipState(n) as st:
+                    st.set_option("profile", 1)
+                    st.upload(x)
+                    p0 = st.device_ptr()
+                    st.apply_op(o)
+                    assert st.device_ptr() == p0  # in place: the buffers were not swapped
+                    got = st.download()
+                    assert "k_sparse_kq" in st.profile(), st.profile()
+                assert np.array_equal(got, want), (k, trial, repr(o))
+        xf = rand_state(n, 8, np.complex64)
+        rows = [[(int(c), complex(rng.standard_normal(), rng.standard_normal())) for c in rng.integers(0, 1 << k, size=2)] for _ in range(1 << k)]
+        op = q.make_sparse_matrix_op([int(v) for v in rng.permutation(n)[:k]], rows)
+        assert np.array_equal(hip_apply(n, op, xf), oracle_apply(O, n, op, xf)), k
+    # k = 6 stays on the literal kernel
+    rows = [[((r + 1) % 64, 1j)] for r in range(64)]
+    check(O, 8, q.make_sparse_matrix_op([0, 7, 2, 5, 4, 3], rows))
+    # a program with a sparse op is a graph now (nothing swaps buffers)
+    ops = [q.make_matrix_op([0], circuits.H), q.make_sparse_matrix_op([1, 9], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]])]
+    with q.HipState(n) as st:
+        st.upload(x)
+        prog = st.compile_program(ops)
+        prog.run()
+        assert prog.is_graph
+        assert np.array_equal(st.download(), O.apply_ops_in_place(n, ops, x.copy()))
+        prog.close()
+
+
+def test_program_survives_arena_regrowth(O):
+    """a captured graph bakes in the device-arena address; an eager op that needs a larger payload frees
+    and regrows the arena (here: two dense k = 7 ops, which also restore `cur`).  The replay must re-record."""
+    n = 10
+    rng = np.random.default_rng(3)
+    x = rand_state(n, 9)
+    u2 = rand_unitary(2, rng)
+    ops = [q.make_matrix_op([0, 5], u2.ravel()), q.make_matrix_op([3], circuits.H),
+           q.make_matrix_op([1, 2, 9], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel())]
+    u7 = rand_unitary(7, rng)
+    big = q.make_matrix_op([0, 1, 2, 3, 4, 5, 6], u7.ravel())
+    with q.HipState(n) as st:
+        st.upload(x)
+        prog = st.compile_program(ops)
+        prog.run()
+        assert prog.is_graph
+        st.apply_op(big)
+        st.apply_op(big)
+        prog.run()
+        got = st.download()
+        prog.close()
+    want = O.apply_ops_in_place(n, ops + [big, big] + ops, x.copy())
+    assert np.max(np.abs(got - want)) <= TOL64
+
+
+def test_measure_probs_many_outcomes(O):
+    """5 <= k <= 16 measured qubits, any mix of low / high bit positions and any outcome-bit order
+    (k_measure_probs_grid: outcomes on the grid + per-lane fold, no atomics)."""
+    n = 18
+    rng = np.random.default_rng(18)
+    x = rand_state(n, 18)
+    x[::7] = 0  # zero amplitudes are skipped by the reference (measurement_ops.rs:98-99)
+    x /= np.linalg.norm(x)
+    with q.HipState(n) as st:
+        st.upload(x)
+        cases = [list(range(12)), list(range(n - 8, n)), list(range(n - 9, n - 1))[::-1], list(range(n))[:16]]
+        for k in (5, 6, 8, 9, 11, 13, 16):
+            cases.append([int(v) for v in rng.permutation(n)[:k]])
+        for idx in cases:
+            got = st.measure_probs(idx)
+            want = O.measure_probs(n, idx, x)
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-13, idx
+            assert abs(got.sum() - 1) < 1e-12
+    xf = rand_state(12, 2, np.complex64)
+    with q.HipState(12, np.complex64) as st:
+        st.upload(xf)
+        for idx in ([0, 11, 5, 6, 7, 1], list(range(12))):
+            assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(12, idx, xf))) <= 1e-5
 
 
 def test_selectors_inside_a_cache_line(O):
@@ -951,6 +1107,86 @@ def test_window_compare_at_n24(O):
     assert np.max(np.abs(got - want)) <= TOL64
 
 
+# ---- full size, directly against the oracle: closed sub-cubes of the index space (oracle/window_parity.py) --------
+def _special_gates(n, rng):
+    """one gate per kernel class / addressing corner, on the bit positions where launch shapes change"""
+    u2 = rand_unitary(2, rng)
+    u3 = rand_unitary(3, rng)
+    u5 = rand_unitary(5, rng)
+    ph = cmath.rect(1.0, 0.37)
+    return [
+        ("T_bit0", q.make_matrix_op([n - 1], circuits.T), True),
+        ("H_bit0", q.make_matrix_op([n - 1], circuits.H), True),
+        ("H_top", q.make_matrix_op([0], circuits.H), True),
+        ("Rz_top", q.make_matrix_op([0], circuits.rz(0.77)), True),
+        ("Rz_bit2", q.make_matrix_op([n - 3], circuits.rz(1.3)), True),
+        ("cnot_lowctl", q.make_control_op([n - 1], q.make_matrix_op([0], circuits.X)), True),
+        ("cnot_lowtgt", q.make_control_op([0], q.make_matrix_op([n - 2], circuits.X)), True),
+        ("toffoli", q.make_control_op([0, n - 4], q.make_matrix_op([n // 2], circuits.X)), True),
+        ("cphase", q.make_control_op([1], q.make_matrix_op([n - 1], [1, 0, 0, ph])), True),
+        ("cH", q.make_control_op([n // 2], q.make_matrix_op([0], circuits.H)), True),
+        ("swap1", q.make_swap_op([0], [n - 1]), True),
+        ("swap2", q.make_swap_op([1, n - 8], [n - 2, 2]), True),
+        ("dense2", q.make_matrix_op([0, n - 1], u2.ravel()), True),
+        ("dense3_low_mfma", q.make_matrix_op([n - 1, n - 2, n - 3], u3.ravel()), False),
+        ("dense3_high", q.make_matrix_op([0, 5, n - 9], u3.ravel()), True),
+        ("dense5_mfma", q.make_matrix_op([0, 2, n - 20, n - 7, n - 1], u5.ravel()), False),
+        ("cdense2", q.make_control_op([3], q.make_matrix_op([1, n - 5], u2.ravel())), True),
+        ("diag2", q.make_matrix_op([0, n - 2], np.diag([ph, ph.conjugate(), 1j, -1]).ravel()), True),
+        ("sparse2", q.make_sparse_matrix_op([n - 1, 0], [[(0, 0.6), (1, 0.8j)], [(1, 0.6), (0, 0.8j)], [(3, 1j)], [(2, -1)]]), True),
+    ]
+
+
+@pytest.mark.parametrize("n", [28, 30, 32])
+def test_full_size_oracle_windows(O, n):
+    """The benchmarked sizes (n = 30 is bench.py's workload; n = 32 is where streaming launches first need a second
+    grid dimension) compared with the ORACLE, gate by gate, on a seeded product state whose amplitudes are pairwise
+    distinct: >= 4 closed sub-cubes of >= 2^16 rows per gate, always including the bottom and the top of the index
+    space.  f64 gate-by-gate kernels are bit-equal (array_equal); matrix-core gates are held to 1e-12."""
+    from oracle import window_parity as W
+
+    rng = np.random.default_rng(n)
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    c2 = circuits.c2_random_circuit(n, 256, seed=28)
+    N = 1 << n
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        for off in (0, 12345, N // 2 - 777, N - (1 << 16)):
+            got = st.download(off, 1 << 16)
+            want = W.product_state_window(n, vecs, off, 1 << 16)
+            assert np.allclose(got, want, rtol=1e-12, atol=0), off
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        # the first 40 gates of the benchmarked circuit, one launch per gate
+        agg = W.check_circuit(st, n, c2[:40], O, gate_by_gate=True, seed=1)
+        assert agg["gates"] == 40 and agg["skipped"] == 0 and agg["rows"] >= 40 * 4 * (1 << 16)
+        assert agg["bit_equal"] and agg["max_abs_delta"] == 0.0, agg
+        for name, op, exact in _special_gates(n, rng):
+            r = W.check_ops(st, n, [op], O, bases=W.default_bases(n, seed=zlib.crc32(name.encode()) % 1000))
+            assert r is not None, name
+            if exact:
+                assert r["bit_equal"], (name, r)
+            else:
+                assert r["max_abs_delta"] <= TOL64, (name, r)
+        # LDS-resident multi-gate sweeps (tile = 1: IEEE-equal) on the following gates of the same circuit, in
+        # chunks whose sub-cubes stay small; the chunk is what the tile scheduler sees
+        st.set_option("tile", 1)
+        st.set_option("profile", 1)
+        st.profile_reset()
+        agg = W.check_circuit(st, n, c2[40:168], O, gate_by_gate=False, seed=2)
+        prof = st.profile()
+        assert agg["gates"] == 128 and agg["skipped"] == 0
+        assert prof.get("k_tile_gates", {}).get("launches", 0) >= 4, prof  # multi-gate sweeps really ran
+        assert agg["max_abs_delta"] == 0.0, agg  # only a -0 may differ from the gate-by-gate path
+        # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
+        g = circuits.c5_grover_iteration(n, dense_k3=True)
+        agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3)
+        assert agg["gates"] >= len(g) - 2 and agg["max_abs_delta"] <= TOL64, agg
+        st.set_option("tile", 0)
+        st.set_option("profile", 0)
+        assert abs(st.norm_sqr() - 1) < 1e-9
+
+
 # ---- N > 1 on one GPU: virtual shards (real kernels, host-staged exchange) and RCCL plumbing ----------------
 def _run_dist(nproc, extra):
     import os
@@ -982,30 +1218,30 @@ def test_sharded_rccl_plumbing_world1():
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():
-    """bench.py --gpus 2 end to end (sharded state, plan/run_plan, remap, max-over-ranks timing, JSON line)
-    with two ranks sharing the one GPU through the gloo / host-staged test hook."""
+    """`python bench.py --gpus 2` as a PLAIN command (it re-launches itself as two ranks under torch.distributed.run):
+    sharded state, plan/run_plan, remap, max-over-ranks timing, JSON line with the BASELINE configs[3]/[4] legs — with
+    two ranks sharing the one GPU through the gloo / host-staged test hook."""
     import json
     import os
-    import socket
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--n-local", "20", "--gates", "64"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
-                         env=dict(os.environ, QIP_BENCH_DIST_BACKEND="gloo"))
+                         env=dict(env, QIP_BENCH_DIST_BACKEND="gloo"))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
     assert abs(line["norm_sqr_after"] - 1) < 1e-10
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 1
-    tiled = line["extras"]["tiled_mode1"]  # tile sweeps on the shards, guarded extra
-    assert "error" not in tiled and tiled["gates_per_s"] > 0, tiled
+    ex = line["extras"]
+    for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs4_grover_dense_k3_n21",
+                 "configs1_mixed_n21", "headline_tiled_mode1"):
+        assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
+    assert abs(ex["norm_sqr_end"] - 1) < 1e-9
 
 
 def test_circuit_replay_python_and_cpp_cli(O, tmp_path):

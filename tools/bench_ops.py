@@ -48,6 +48,10 @@ def main():
         ("controlled-phase", q.make_control_op([hi], q.make_matrix_op([mid], [1, 0, 0, cmath.rect(1, 0.1)])), {}),
         ("Swap(1) bits n-1 <-> 0", q.make_swap_op([hi], [lo]), {}),
         ("Swap(2)", q.make_swap_op([hi, 1], [mid, lo]), {}),
+        ("Swap(2), one transposition per sweep", q.make_swap_op([hi, 1], [mid, lo]), {"swap_single": 1}),
+        ("Swap(2) all high bits", q.make_swap_op([hi, 1], [mid, 7]), {}),
+        ("Swap(2) all high bits, one transposition per sweep", q.make_swap_op([hi, 1], [mid, 7]), {"swap_single": 1}),
+        ("Swap(3)", q.make_swap_op([hi, 1, 2], [mid, lo, lo - 1]), {}),
         ("dense k=2 (VALU regs)", q.make_matrix_op([hi, mid], rand_unitary(2, rng).ravel()), {}),
         ("dense k=2, low bits", q.make_matrix_op([lo, lo - 1], rand_unitary(2, rng).ravel()), {}),
         ("dense k=3 (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {}),
@@ -64,7 +68,10 @@ def main():
         ("dense k=3 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 2}),
         ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
         ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
-        ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
+        ("sparse k=2 (in place)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
+        ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {"force_generic": 1}),
+        ("sparse k=4, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7], [[(r, 0.6), (r ^ 5, 0.8j)] for r in range(16)]), {}),
+        ("sparse k=5, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(32)]), {}),
         ("H via literal gather", q.make_matrix_op([mid], circuits.H), {"force_generic": 1}),
     ]
     if f32:
@@ -78,8 +85,8 @@ def main():
         for name, op, opts in cases:
             if only and only not in name:
                 continue
-            for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32"):
-                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1}[k])
+            for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32", "swap_single"):
+                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
             for k, v in opts.items():
                 st.set_option(k, v)
             comp = st.compile_ops([op] * reps)
@@ -100,7 +107,11 @@ def main():
         st.set_option("profile", 0)
         for name, fn, by in (("norm_sqr", st.norm_sqr, amp * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), amp * 2**n),
                              ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), amp * 2**n),
-                             ("measure_probs k=12 (LDS histogram)", lambda: st.measure_probs(list(range(12))), amp * 2**n)):
+                             ("measure_probs k=12 top bits", lambda: st.measure_probs(list(range(12))), amp * 2**n),
+                             ("measure_probs k=8 low bits", lambda: st.measure_probs(list(range(n - 8, n))), amp * 2**n),
+                             ("measure_probs k=12 mixed bits", lambda: st.measure_probs([0, n - 1, 3, n - 4, 7, n - 9, 11, n - 13, 15, n - 17, n - 2, 1]), amp * 2**n),
+                             ("measure_probs k=16", lambda: st.measure_probs(list(range(2, 18))), amp * 2**n),
+                             ("soft_measure (2 passes)", lambda: st.soft_measure([0, mid, lo], 0.4321), amp * 2**n)):
             fn()
             t0 = time.perf_counter()
             for _ in range(3):
