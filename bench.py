@@ -251,13 +251,15 @@ def main():
         set_profile = lambda v: st.set_option("profile", v)
         get_profile = lambda: (st.profile(), st.profile_reset())[0]
     else:
-        from rustqip_amd.sharded import make_sharded_state
+        from rustqip_amd.sharded import DistState
 
-        st = make_sharded_state(n, args.n_local, dist, device, host_staged=dist_backend != "nccl")
+        # the sharded state inside libqip_hip.so (C ABI qip_hip_dist_*): planner, pack sweep and the RCCL exchange
+        st = DistState(n, dist, device, np.complex128, host_staged=dist_backend != "nccl")
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n)])
-        plan = st.plan(ops)
-        run_step = lambda: st.run_plan(plan)
+        st.comm_stats()  # reset: the headline's comm figures cover warm-up + timed steps only
+        compiled = st.compile_ops(ops)
+        run_step = lambda: st.apply_compiled(compiled)
         sync = st.sync
         set_profile = st.set_profile
         get_profile = st.take_profile
@@ -365,32 +367,31 @@ def main():
         # BASELINE configs[3] (Clifford+T) and configs[4] (Grover iteration, plain and dense k = 3) on the sharded
         # state, and the headline circuit with the local runs between remaps applied as tile sweeps (tile = 1:
         # IEEE-equal).  Guarded: nothing here can take the bench line down.  Median of REPS, max over ranks.
-        def dist_leg(cops, batched=False, tile=0):
-            st.set_tile(tile)
-            pl = st.plan(cops)
-            st.comm_stats()  # reset the collective timer
-            st.run_plan(pl, batched=batched)
+        def dist_leg(cops, tile=0):
+            st.set_option("tile", tile)
+            cc = st.compile_ops(cops)
+            st.apply_compiled(cc)
             sync()
-            st.comm_stats()
+            st.comm_stats()  # reset the counters
             ts = []
             for _ in range(REPS):
                 barrier()
                 t = time.perf_counter()
-                st.run_plan(pl, batched=batched)
+                st.apply_compiled(cc)
                 sync()
                 barrier()
                 ts.append(max_over_ranks(time.perf_counter() - t))
-            st.set_tile(0)
+            st.set_option("tile", 0)
             dt = statistics.median(ts)
             cs = st.comm_stats()
             return {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": circuit_bytes(q, n, cops) / dt / 1e9,
-                    "reps": REPS, "comm": cs}
+                    "reps": REPS, "comm_over_reps": cs}
 
         for cname, cops, kw in (("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32), {}),
                                 ("configs4_grover_iteration_n%d" % n, circuits.c5_grover_iteration(n), {}),
                                 ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True), {}),
                                 ("configs1_mixed_n%d" % n, ops_mixed, {}),
-                                ("headline_tiled_mode1", ops, {"batched": True, "tile": 1})):
+                                ("headline_tiled_mode1", ops, {"tile": 1})):
             try:
                 extras[cname] = dist_leg(cops, **kw)
             except Exception as exc:  # noqa: BLE001

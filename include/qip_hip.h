@@ -250,6 +250,93 @@ int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
 int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* indices, uint32_t k,
                                 uint64_t measured, double prob);
 
+/* ---- the state sharded over several GPUs (SURVEY.md §8 row e) ------------------------------------------
+ * The reference is single-process; its only provision for distribution is the input / output offset windows
+ * of apply_op (qip-iterators/src/matrix_ops.rs:96-97) and of the measurement functions
+ * (qip/src/state_ops/measurement_ops.rs:17-19).  A qip_hip_dist is the outer seam
+ * (builder.rs:406-407,499,514) for a 2^n state whose index is split by its top g = log2(world) PHYSICAL bits:
+ * one process per GPU, rank r holds the 2^(n-g) amplitudes whose top physical bits read r.  A host-side
+ * logical -> physical bit permutation decides which qubits are "global" at any moment:
+ *   - an op whose amplitude-exchanging targets are all local runs on the shard as an ordinary local op; controls
+ *     and diagonal targets on rank bits are resolved per rank (skip / restrict the matrix) and never communicate;
+ *   - an op with an exchanging target on a rank bit first triggers a REMAP: the g qubits whose next use is farthest
+ *     (when the circuit is known: qip_hip_dist_apply_ops) are gathered into the top g local bit positions by ONE
+ *     out-of-place bit-permutation sweep, then ONE all-to-all exchanges those g bits with the g rank bits
+ *     (ncclGroupStart; ncclSend / ncclRecv to every peer; ncclGroupEnd: all xGMI links busy at once).
+ * Every rank must issue the same calls in the same order (SPMD). */
+typedef struct qip_hip_dist qip_hip_dist;
+
+/* How amplitudes move between ranks.  NULL selects the built-in RCCL transport (librccl is loaded on first use).
+ * A caller-supplied transport exists for tests (several ranks on one GPU, exchange staged through the host) and for
+ * hosts that already own a communicator.  Both functions are called by every rank collectively, return 0 on success.
+ *   all_to_all      `send` / `recv` are DEVICE buffers of world * chunk_bytes; chunk p of `send` goes to rank p and
+ *                   lands as chunk <sender's rank> of that rank's `recv`; `stream` is the handle's hipStream_t: the
+ *                   transfer must be ordered after the work already queued on it, and complete (or be ordered on it)
+ *                   before the function's effects are relied on by later work on that stream.
+ *   all_reduce_sum  in-place sum over ranks of `count` doubles in HOST memory. */
+typedef struct qip_hip_transport {
+  void* ctx;
+  int (*all_to_all)(void* ctx, const void* send, void* recv, uint64_t chunk_bytes, void* stream);
+  int (*all_reduce_sum)(void* ctx, double* values, uint64_t count);
+} qip_hip_transport;
+
+/* 128 opaque bytes that identify one RCCL communicator (ncclGetUniqueId): rank 0 calls this and hands the bytes to
+ * the other ranks by whatever channel the host has (the Rust side: the launcher's environment / a file / MPI). */
+#define QIP_HIP_UNIQUE_ID_BYTES 128
+int qip_hip_dist_unique_id(void* id_out);
+
+/* SURVEY.md §8(b) outer seam "qip_hip_state_create(n, dtype, n_gpus, &h)": the n-qubit state over `world` ranks
+ * (a power of two; world = 1 is allowed), this process being `rank` and driving `device`.  unique_id: the bytes from
+ * qip_hip_dist_unique_id (ignored when `transport` is given).  All amplitudes start at zero. */
+int qip_hip_dist_create(uint32_t n, int dtype, int device, int rank, int world, const void* unique_id,
+                        const qip_hip_transport* transport, qip_hip_dist** out);
+int qip_hip_dist_destroy(qip_hip_dist* d);
+
+/* state[i] = (i == logical_index) ? 1 : 0 over the whole sharded vector (builder.rs:406-421) */
+int qip_hip_dist_init_basis(qip_hip_dist* d, uint64_t logical_index);
+/* state <- op · state (apply_op_overwrite + swap, builder.rs:499,514); remaps when it has to */
+int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op);
+/* a whole circuit: the remap choices look ahead (farthest next use), and the runs of local ops between two remaps
+ * go to the shard as one qip_hip_state_apply_ops batch (so option "tile" applies to them) */
+int qip_hip_dist_apply_ops(qip_hip_dist* d, const qip_op* ops, uint64_t count);
+int qip_hip_dist_sync(qip_hip_dist* d);
+/* options: "tile", "fuse", "mfma", "profile", ... are forwarded to the shard (qip_hip_state_set_option) */
+int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value);
+
+/* measurement over the whole vector (measurement_ops.rs:11-13, 115-127, 190-269): local reductions + one all-reduce;
+ * `measure` collapses every shard with the GLOBAL probability.  Sampling (forced < 0) draws the outcome from the
+ * marginal distribution of the measured qubits with rank 0's rand_u01, walking outcomes in increasing order:
+ * statistically soft_measure (:153-176), not its sample -> outcome map (that needs the vector in logical index order). */
+int qip_hip_dist_norm_sqr(qip_hip_dist* d, double* out);
+int qip_hip_dist_measure_probs(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double* out);
+int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, int64_t forced, double rand_u01,
+                         uint64_t* measured, double* prob);
+
+/* The shard's own handle (upload / download / profile of this rank's 2^(n-g) amplitudes; owned by `d`), and the
+ * current layout: phys[p] = physical bit position of logical bit position p (= n-1-qubit), n entries; physical
+ * positions >= n-g are rank bits.  Together they let the host scatter / gather a vector in logical order. */
+int qip_hip_dist_local_state(qip_hip_dist* d, qip_hip_state** shard);
+int qip_hip_dist_layout(qip_hip_dist* d, uint32_t* phys);
+
+typedef struct qip_hip_dist_stats {
+  uint64_t remaps;            /* all-to-all exchanges */
+  uint64_t pack_sweeps;       /* bit-permutation sweeps that gathered the outgoing qubits (0 when already on top) */
+  uint64_t bytes_sent;        /* by this rank, over all remaps */
+  double exchange_ms;         /* HIP-event time of the all-to-alls on the handle's stream */
+  double pack_ms;
+} qip_hip_dist_stats;
+/* counters since the previous call (they reset) */
+int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);
+
+/* Host-only test hook: what rank `rank` of `world` would do for this circuit on a fresh state, as a JSON string
+ * (owned by the library, valid until the calling thread's next call; NULL on error): the steps
+ *   {"t":"local","op":{...}}   the op this rank applies to its shard, in LOCAL qubit indices
+ *   {"t":"pack","sel":[...]}   gather these local bit positions into the top g positions (in this order)
+ *   {"t":"exchange"}           all-to-all of the top g local bits with the g rank bits
+ * and the final layout.  tests/test_distributed_cpu.py replays it with the CPU oracle as the shard and gloo as the
+ * transport, so the planner and the per-rank localisation are covered without a GPU. */
+const char* qip_hip_dist_debug_plan(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,22 @@ QipOp._fields_ = [
     ("inner", C.POINTER(QipOp)),
 ]
 
+QIP_HIP_UNIQUE_ID_BYTES = 128
+
+# struct qip_hip_transport: the two callbacks a caller-supplied transport provides
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+ARS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
+
+
+class QipTransport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("all_to_all", A2A_FN), ("all_reduce_sum", ARS_FN)]
+
+
+class QipDistStats(C.Structure):
+    _fields_ = [("remaps", C.c_uint64), ("pack_sweeps", C.c_uint64), ("bytes_sent", C.c_uint64),
+                ("exchange_ms", C.c_double), ("pack_ms", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/qip_hip.h declares
 _u32, _u64, _i64, _int, _dbl = C.c_uint32, C.c_uint64, C.c_int64, C.c_int, C.c_double
 _vp, _cp = C.c_void_p, C.c_char_p
@@ -78,6 +94,21 @@ SIGNATURES = {
     "qip_hip_state_soft_measure": (_int, [_statep, _u64p, _u32, _dbl, _u64p]),
     "qip_hip_state_measure": (_int, [_statep, _u64p, _u32, _i64, _dbl, _u64p, _dblp]),
     "qip_hip_state_measure_state": (_int, [_statep, _u64p, _u32, _u64, _dbl]),
+    "qip_hip_dist_unique_id": (_int, [_vp]),
+    "qip_hip_dist_create": (_int, [_u32, _int, _int, _int, _int, _vp, C.POINTER(QipTransport), C.POINTER(_vp)]),
+    "qip_hip_dist_destroy": (_int, [_vp]),
+    "qip_hip_dist_init_basis": (_int, [_vp, _u64]),
+    "qip_hip_dist_apply_op": (_int, [_vp, _opp]),
+    "qip_hip_dist_apply_ops": (_int, [_vp, _opp, _u64]),
+    "qip_hip_dist_sync": (_int, [_vp]),
+    "qip_hip_dist_set_option": (_int, [_vp, _cp, _i64]),
+    "qip_hip_dist_norm_sqr": (_int, [_vp, _dblp]),
+    "qip_hip_dist_measure_probs": (_int, [_vp, _u64p, _u32, _dblp]),
+    "qip_hip_dist_measure": (_int, [_vp, _u64p, _u32, _i64, _dbl, _u64p, _dblp]),
+    "qip_hip_dist_local_state": (_int, [_vp, C.POINTER(_vp)]),
+    "qip_hip_dist_layout": (_int, [_vp, C.POINTER(C.c_uint32)]),
+    "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
+    "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
 }
 
 

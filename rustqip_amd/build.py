@@ -10,10 +10,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "qip_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "qip_kernels.h"), os.path.join(HERE, "..", "include", "qip_hip.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "qip_kernels.h"), os.path.join(HERE, "csrc", "qip_dist.inc"),
+        os.path.join(HERE, "..", "include", "qip_hip.h")]
 OUT = os.path.join(HERE, "lib", "libqip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+LIBS = ["-ldl"]  # librccl is dlopen-ed on first multi-GPU use (csrc/qip_dist.inc): no link-time dependency
 
 
 def needs_build() -> bool:
@@ -26,7 +28,7 @@ def needs_build() -> bool:
 def build(force: bool = False) -> str:
     if force or needs_build():
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        cmd = [HIPCC, *FLAGS, "-o", OUT, SRC]
+        cmd = [HIPCC, *FLAGS, "-o", OUT, SRC, *LIBS]
         print("[rustqip_amd.build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     return OUT

@@ -254,7 +254,8 @@ static void read_dense(const void* dense, uint64_t count, std::vector<double>* o
 }
 
 static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
-static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5
+static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5 (A operand in registers)
+static constexpr uint32_t kMaxBigK = 8;     // ... k = 6..8 with the A operand streamed through LDS (k_gate_big_mfma)
 static constexpr uint32_t kMaxSparseK = 5;  // SparseMatrix ops applied in place (one 2^k group per lane, staged in LDS)
 static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
 
@@ -323,7 +324,7 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     return QIP_OK;
   }
   std::vector<double> d;
-  if (k <= std::max(kMaxRegK, kMaxMfmaK)) {
+  if (k <= std::max(kMaxRegK, kMaxMfmaK) || (dtype == QIP_C64 && k <= kMaxBigK)) {
     if (dtype == QIP_C64)
       read_dense<double>(f.inner->dense, side * side, &d);
     else
@@ -339,8 +340,8 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     }
     return QIP_OK;
   }
-  if (k <= kMaxRegK || k <= kMaxMfmaK) {
-    // the launcher picks the matrix-core form for f64, k in 3..5, when >= 16 groups exist
+  if (k <= kMaxRegK || k <= kMaxMfmaK || (dtype == QIP_C64 && k <= kMaxBigK)) {
+    // the launcher picks the matrix-core forms for f64 (k in 3..5 / 6..8) when >= 16 groups exist
     p->cls = KC_GATE_KQ;
     p->table = d;
     return QIP_OK;
@@ -878,61 +879,86 @@ static int launch_diag(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* 
   return QIP_OK;
 }
 
-// two transpositions (pa0 pb0)(pa1 pb1), pa < pb, in ONE sweep (k_swap2); false when the shape does not apply
+// A group of >= 2 transpositions (pa pb), pa < pb, in ONE sweep (k_swapn).  `done` = false when the state is too
+// small for the shape (fewer work items than lanes): the caller then applies them one at a time.
+struct SwPair {
+  uint32_t pa, pb;
+};
+static inline int swap_pair_regbits(const Split& sp, const SwPair& q) {  // HH: 2, HL: 1, LL: 0 (pa < pb)
+  return (work_bit(q.pa, sp.hi) < 6 ? 0 : 1) + (work_bit(q.pb, sp.hi) < 6 ? 0 : 1);
+}
+
 template <typename T, typename E>
-static int launch_swap2(qip_hip_state* s, uint32_t n, const Split& sp, uint32_t pa0, uint32_t pb0, uint32_t pa1,
-                        uint32_t pb1, E* st, bool* done) {
+static int launch_swapn(qip_hip_state* s, uint32_t n, const Split& sp, const std::vector<SwPair>& grp, E* st, bool* done) {
   *done = false;
-  struct Pair { uint32_t pa, pb; int type; };
-  Pair pr[2] = {{pa0, pb0, 0}, {pa1, pb1, 0}};
-  for (Pair& q : pr) {
-    const bool la = work_bit(q.pa, sp.hi) < 6, lb = work_bit(q.pb, sp.hi) < 6;
-    q.type = (la && lb) ? SW_LL : (la ? SW_HL : SW_HH);  // pa < pb: a lane-bit pb implies a lane-bit pa
-  }
-  if (pr[0].type > pr[1].type) std::swap(pr[0], pr[1]);  // the stages act on disjoint bits: any order
-  Swap2Desc d;
+  SwapNDesc d;
   memset(&d, 0, sizeof d);
-  std::vector<uint32_t> pos = sp.hi;
-  int r = 0;
-  for (int q = 0; q < 2; ++q) {
-    if (pr[q].type == SW_HH) {
-      d.off[r++] = 1ull << pr[q].pa;
-      d.off[r++] = 1ull << pr[q].pb;
-      pos.push_back(pr[q].pa);
-      pos.push_back(pr[q].pb);
-    } else if (pr[q].type == SW_HL) {
-      d.off[r++] = 1ull << pr[q].pb;
-      pos.push_back(pr[q].pb);
-      d.la[q] = work_bit(pr[q].pa, sp.hi);
-    } else {
-      d.la[q] = work_bit(pr[q].pa, sp.hi);
-      d.lb[q] = work_bit(pr[q].pb, sp.hi);
+  std::vector<uint32_t> pos = sp.hi, regpos;
+  // register bits: the HL bits first, then the HH pairs (bits 2j, 2j+1 of what follows) — the order k_swapn assumes
+  for (const SwPair& q : grp)
+    if (work_bit(q.pa, sp.hi) < 6 && work_bit(q.pb, sp.hi) >= 6) {
+      d.hl_lane[regpos.size()] = work_bit(q.pa, sp.hi);
+      regpos.push_back(q.pb);
+    }
+  const uint32_t NHL = (uint32_t)regpos.size();
+  for (const SwPair& q : grp) {
+    const bool la = work_bit(q.pa, sp.hi) < 6, lb = work_bit(q.pb, sp.hi) < 6;  // a lane-bit pb implies a lane-bit pa
+    if (la && lb) {
+      d.ll_a[d.n_ll] = work_bit(q.pa, sp.hi);
+      d.ll_b[d.n_ll++] = work_bit(q.pb, sp.hi);
+    } else if (!la) {
+      regpos.push_back(q.pa);
+      regpos.push_back(q.pb);
     }
   }
-  const uint32_t NH = (uint32_t)r;
+  const uint32_t NH = (uint32_t)regpos.size();
+  if (NH > 4 || d.n_ll > 4) return fail(QIP_ERR_UNSUPPORTED, "swap group too large (internal error)");
+  for (uint32_t p : regpos) pos.push_back(p);
   const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
   const uint64_t nitems = nsub >> NH;
   if (nitems < 64) return QIP_OK;  // fewer items than lanes: the lane-bit classification does not hold
-  Ins ins = make_ins(pos, sp.hi_ones);
-#define SW2(S0, S1, UU)                                                                                              \
-  do {                                                                                                               \
-    if (nitems >= ((uint64_t)(UU) << kStrideShift)) {                                                                \
-      if (use_nt(s)) hipLaunchKernelGGL((k_swap2<T, S0, S1, UU, false, true, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low); \
-      else hipLaunchKernelGGL((k_swap2<T, S0, S1, UU, false, false, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);          \
-    } else {                                                                                                         \
-      hipLaunchKernelGGL((k_swap2<T, S0, S1, 1, true, false, E>), grid2d(nitems, kBlock), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);                         \
-    }                                                                                                                \
-  } while (0)
-  const int code = pr[0].type * 3 + pr[1].type;
-  switch (code) {
-    case SW_HH * 3 + SW_HH: SW2(SW_HH, SW_HH, 1); break;
-    case SW_HH * 3 + SW_HL: SW2(SW_HH, SW_HL, 1); break;
-    case SW_HH * 3 + SW_LL: SW2(SW_HH, SW_LL, 2); break;
-    case SW_HL * 3 + SW_HL: SW2(SW_HL, SW_HL, 2); break;
-    case SW_HL * 3 + SW_LL: SW2(SW_HL, SW_LL, 4); break;
-    default: SW2(SW_LL, SW_LL, 4); break;
+  for (uint32_t c = 0; c < (1u << NH); ++c)
+    for (uint32_t r = 0; r < NH; ++r)
+      if ((c >> r) & 1u) d.off_ld[c] |= 1ull << regpos[r];
+  for (uint32_t c = 0; c < (1u << NH); ++c) {
+    uint32_t pc = c;
+    for (uint32_t r = NHL; r + 1 < NH; r += 2) {  // HH pair on register bits (r, r + 1)
+      const uint32_t b0 = (pc >> r) & 1u, b1 = (pc >> (r + 1)) & 1u;
+      pc = (pc & ~((1u << r) | (1u << (r + 1)))) | (b1 << r) | (b0 << (r + 1));
+    }
+    d.off_st[c] = d.off_ld[pc];
   }
-#undef SW2
+  Ins ins = make_ins(pos, sp.hi_ones);
+  const bool big = use_nt(s);  // >= 1 GiB states: unguarded, several groups per lane, non-temporal; else one guarded group
+#define SWN(NHV, NHLV, LLV, UU)                                                                                             \
+  do {                                                                                                                      \
+    if (big && nitems >= ((uint64_t)(UU) << kStrideShift))                                                                  \
+      hipLaunchKernelGGL((k_swapn<T, NHV, NHLV, LLV, UU, false, true, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_swapn<T, NHV, NHLV, LLV, 1, true, false, E>), grid2d(nitems, kBlock), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);         \
+  } while (0)
+  const bool ll = d.n_ll > 0;
+  const uint32_t code = NH * 16 + NHL * 2 + (ll ? 1 : 0);
+  switch (code) {
+    case 0 * 16 + 0 * 2 + 1: SWN(0, 0, true, 4); break;
+    case 1 * 16 + 1 * 2 + 0: SWN(1, 1, false, 4); break;
+    case 1 * 16 + 1 * 2 + 1: SWN(1, 1, true, 4); break;
+    case 2 * 16 + 0 * 2 + 1: SWN(2, 0, true, 2); break;
+    case 2 * 16 + 2 * 2 + 0: SWN(2, 2, false, 2); break;
+    case 2 * 16 + 2 * 2 + 1: SWN(2, 2, true, 2); break;
+    case 3 * 16 + 1 * 2 + 0: if (s->unroll == 2) SWN(3, 1, false, 2); else SWN(3, 1, false, 1); break;
+    case 3 * 16 + 1 * 2 + 1: SWN(3, 1, true, 1); break;
+    case 3 * 16 + 3 * 2 + 0: SWN(3, 3, false, 1); break;
+    case 3 * 16 + 3 * 2 + 1: SWN(3, 3, true, 1); break;
+    case 4 * 16 + 0 * 2 + 0: SWN(4, 0, false, 1); break;
+    case 4 * 16 + 0 * 2 + 1: SWN(4, 0, true, 1); break;
+    case 4 * 16 + 2 * 2 + 0: SWN(4, 2, false, 1); break;
+    case 4 * 16 + 2 * 2 + 1: SWN(4, 2, true, 1); break;
+    case 4 * 16 + 4 * 2 + 0: SWN(4, 4, false, 1); break;
+    case 4 * 16 + 4 * 2 + 1: SWN(4, 4, true, 1); break;
+    default: return QIP_OK;  // (2, 0, no LL) is a single HH transposition: the caller's one-at-a-time kernels
+  }
+#undef SWN
   HIPCHK(hipGetLastError());
   *done = true;
   return QIP_OK;
@@ -941,45 +967,61 @@ static int launch_swap2(qip_hip_state* s, uint32_t n, const Split& sp, uint32_t 
 template <typename T, typename E>
 static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
   // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact, so applying them in
-  // groups is bit-identical to the single permutation: two transpositions per sweep (k_swap2), a last odd one alone.
+  // groups is bit-identical to the single permutation.  Groups hold as many transpositions as fit 4 register bits
+  // (16 amplitudes per lane) and go in ONE sweep each (k_swapn); a group of one uses the single-transposition kernels.
   const uint32_t h = (uint32_t)p.opos.size() / 2;
   const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
-  for (uint32_t j = 0; j < h; ++j) {
-    uint32_t pa = p.opos[j], pb = p.opos[h + j];
-    if (pa > pb) std::swap(pa, pb);  // pa < pb
-    if (j + 1 < h && !s->swap_single) {
-      uint32_t qa = p.opos[j + 1], qb = p.opos[h + j + 1];
-      if (qa > qb) std::swap(qa, qb);
-      bool done = false;
-      QCHK((launch_swap2<T, E>(s, n, sp, pa, pb, qa, qb, st, &done)));
-      if (done) {
-        ++j;
-        continue;
+  std::vector<std::vector<SwPair>> groups;
+  {
+    std::vector<SwPair> cur;
+    int regs = 0, lls = 0;
+    for (uint32_t j = 0; j < h; ++j) {
+      SwPair q{p.opos[j], p.opos[h + j]};
+      if (q.pa > q.pb) std::swap(q.pa, q.pb);
+      const int need = swap_pair_regbits(sp, q);
+      if (!cur.empty() && (s->swap_single || regs + need > 4 || (need == 0 && lls == 4))) {
+        groups.push_back(cur);
+        cur.clear();
+        regs = lls = 0;
       }
+      cur.push_back(q);
+      regs += need;
+      lls += need == 0;
     }
-    const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
-    const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
-    if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
-      Ins ins = make_ins(sp.hi, sp.hi_ones);
-      LAUNCH_STREAMING(k_swap_xlane1, T, kUXlane, nsub, ins, st, nsub, ins, wa, wb, sp.low);
-    } else if (wa < 6 && nsub >= 128) {  // low bit in the lane index, high bit picks the row
-      std::vector<uint32_t> pos = sp.hi;
-      pos.push_back(pb);
-      Ins ins = make_ins(pos, sp.hi_ones);
-      const uint64_t nitems = nsub >> 1;
-      const uint64_t hmask = 1ull << pb;
-      // wa is unchanged by opening pb (pb > pa)
-      LAUNCH_STREAMING(k_swap_xlane2, T, kUSwap, nitems, ins, st, nitems, ins, wa, hmask, sp.low);
-    } else {
-      std::vector<uint32_t> pos = sp.hi;
-      pos.push_back(pa);
-      pos.push_back(pb);
-      Ins ins = make_ins(pos, sp.hi_ones);
-      const uint64_t npairs = nsub >> 2;
-      const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
-      LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask, sp.low);
+    if (!cur.empty()) groups.push_back(cur);
+  }
+  for (const std::vector<SwPair>& grp : groups) {
+    if (grp.size() >= 2) {
+      bool done = false;
+      QCHK((launch_swapn<T, E>(s, n, sp, grp, st, &done)));
+      if (done) continue;
     }
-    HIPCHK(hipGetLastError());
+    for (const SwPair& q : grp) {
+      const uint32_t pa = q.pa, pb = q.pb;
+      const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
+      const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
+      if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
+        Ins ins = make_ins(sp.hi, sp.hi_ones);
+        LAUNCH_STREAMING(k_swap_xlane1, T, kUXlane, nsub, ins, st, nsub, ins, wa, wb, sp.low);
+      } else if (wa < 6 && nsub >= 128) {  // low bit in the lane index, high bit picks the row
+        std::vector<uint32_t> pos = sp.hi;
+        pos.push_back(pb);
+        Ins ins = make_ins(pos, sp.hi_ones);
+        const uint64_t nitems = nsub >> 1;
+        const uint64_t hmask = 1ull << pb;
+        // wa is unchanged by opening pb (pb > pa)
+        LAUNCH_STREAMING(k_swap_xlane2, T, kUSwap, nitems, ins, st, nitems, ins, wa, hmask, sp.low);
+      } else {
+        std::vector<uint32_t> pos = sp.hi;
+        pos.push_back(pa);
+        pos.push_back(pb);
+        Ins ins = make_ins(pos, sp.hi_ones);
+        const uint64_t npairs = nsub >> 2;
+        const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
+        LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask, sp.low);
+      }
+      HIPCHK(hipGetLastError());
+    }
   }
   return QIP_OK;
 }
@@ -1050,6 +1092,42 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   return QIP_OK;
 }
 
+// dense k = 6..8 on the f64 matrix cores, A operand streamed through LDS (k_gate_big_mfma)
+static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag);
+  QCHK(arena_upload(s, afrag.data(), afrag.size() * sizeof(double), 0));
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  MfmaDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
+  const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
+  const unsigned per_cu = k <= 7 ? 2u : 1u;  // resident blocks per CU (registers: 2 waves per SIMD up to k = 7; LDS: 128 KiB at k = 8)
+  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * per_cu);
+  const dim3 grid(blocks), block(kBlock);
+  const double* af = (const double*)s->arena;
+  const bool nt = use_nt(s);
+#define BM(K)                                                                                                     \
+  do {                                                                                                            \
+    if (nt) hipLaunchKernelGGL((k_gate_big_mfma<K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+    else hipLaunchKernelGGL((k_gate_big_mfma<K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);      \
+  } while (0)
+  switch (k) {
+    case 6: BM(6); break;
+    case 7: BM(7); break;
+    case 8: BM(8); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "streamed matrix-core kernel for k = %u", k);
+  }
+#undef BM
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
 template <typename T>
 static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
   const uint32_t k = (uint32_t)p.opos.size();
@@ -1069,6 +1147,12 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
       return launch_kq_mfma(s, p, st);
+    }
+  }
+  if constexpr (std::is_same<T, double>::value) {
+    if (s->mfma && k > kMaxMfmaK && k <= kMaxBigK && s->n >= used + 4) {
+      *actual_cls = KC_GATE_KQ_BIG;
+      return launch_big_mfma(s, p, st);
     }
   }
   if (k > kMaxRegK) {  // no register form: literal kernel, out of place
@@ -2133,7 +2217,7 @@ static int program_capture(qip_hip_program* p) {
     QCHK(make_plan(s->dtype, s->n, f, false, &pl));
     const bool f64 = s->dtype == QIP_C64;
     const uint32_t k = f.n_op;
-    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (f64 && s->mfma && k <= kMaxMfmaK && s->n >= f.k_all + 4));
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (f64 && s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }
   for (int attempt = 0; attempt < 3; ++attempt) {
@@ -2387,46 +2471,74 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
     return QIP_OK;
   }
   if (m_count == (1ull << k)) {
-    // more outcomes, no atomics: measured positions >= 8 on the grid, the others resolved per lane (k_measure_probs_grid)
+    // more outcomes, no atomics: measured positions >= 8 on the grid (a few of them walked per lane when the grid
+    // would be huge), the others resolved per lane (k_measure_probs_grid)
     MeasGridDesc gd;
     memset(&gd, 0, sizeof gd);
-    uint32_t gbit[kMaxIns], lbit[8];
-    std::vector<uint32_t> gp;
+    std::vector<std::pair<uint32_t, uint32_t>> high;  // (position, outcome bit) of the measured positions >= 8
+    uint32_t lbit[8];
     for (uint32_t i = 0; i < k; ++i) {
       if (md.mpos[i] >= 8) {
-        gbit[gd.kg] = i;
-        gd.gpos[gd.kg++] = md.mpos[i];
-        gp.push_back(md.mpos[i]);
+        high.push_back({md.mpos[i], i});
       } else {
         lbit[gd.kl] = i;
         gd.lpos[gd.kl++] = md.mpos[i];
       }
     }
+    std::sort(high.begin(), high.end());
+    // step bits: the lowest high positions, as many (<= 3) as it takes to bring the grid down to ~2^11 outcomes
+    uint32_t ki = 0;
+    while (ki < 3 && high.size() - ki > 11) ++ki;
+    uint32_t sbit[3] = {0, 0, 0}, gbit[kMaxIns];
+    std::vector<uint32_t> opened;
+    for (uint32_t i = 0; i < high.size(); ++i) {
+      opened.push_back(high[i].first);
+      if (i < ki) {
+        gd.spos[i] = high[i].first;
+        sbit[i] = high[i].second;
+      } else {
+        gbit[gd.kg] = high[i].second;
+        gd.gpos[gd.kg++] = high[i].first;
+      }
+    }
     if (gd.kg <= 20) {
-      Ins ins = make_ins(gp, 0);
-      const uint64_t count = 1ull << (s->n - gd.kg);  // indices per grid outcome
-      const uint64_t ny = 1ull << gd.kg, nl = 1ull << gd.kl;
+      Ins ins = make_ins(opened, 0);
+      const uint64_t count = 1ull << (s->n - (uint32_t)high.size());  // indices per (grid outcome, step value)
+      const uint64_t ny = 1ull << gd.kg, nl = 1ull << gd.kl, nc = 1ull << ki;
       // about 8192 blocks in all, each with at least four 4-KiB rows when the outcome has that many
       uint64_t gx = std::max<uint64_t>(8192 / ny, 1);
-      gx = std::min<uint64_t>(gx, std::max<uint64_t>(count / (kBlock * 4), 1));
-      const size_t np = (size_t)(ny * nl * gx);
-      QCHK(ensure_partial(s, np));
-      hipLaunchKernelGGL((k_measure_probs_grid<T>), dim3((unsigned)(ny * gx)), dim3(kBlock), 0, s->stream,
-                         (const amp_t<T>*)s->cur, count, ins, gd, (uint32_t)gx, s->d_partial);
+      gx = std::min<uint64_t>(gx, std::max<uint64_t>(count * nc / (kBlock * 4), 1));
+      const size_t nout = (size_t)(ny * nc * nl), np = nout * (size_t)gx;
+      QCHK(ensure_partial(s, np + nout));
+      const dim3 grid((unsigned)(ny * gx));
+#define MG(KI) hipLaunchKernelGGL((k_measure_probs_grid<T, KI>), grid, dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur, \
+                                  count, ins, gd, (uint32_t)gx, (uint64_t)nout, s->d_partial)
+      switch (ki) {
+        case 0: MG(0); break;
+        case 1: MG(1); break;
+        case 2: MG(2); break;
+        default: MG(3); break;
+      }
+#undef MG
       HIPCHK(hipGetLastError());
-      std::vector<double> part(np);
-      HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, np * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      const double* res = s->d_partial;
+      if (gx > 1) {  // fold the gx partials per outcome on the device: only 2^k doubles cross PCIe
+        hipLaunchKernelGGL(k_sum_partials, dim3(grid_for(nout, kBlock)), dim3(kBlock), 0, s->stream, s->d_partial, (uint32_t)gx,
+                           (uint64_t)nout, s->d_partial + np);
+        HIPCHK(hipGetLastError());
+        res = s->d_partial + np;
+      }
+      std::vector<double> part(nout);
+      HIPCHK(hipMemcpyAsync(part.data(), res, nout * sizeof(double), hipMemcpyDeviceToHost, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
-      for (uint64_t mg = 0; mg < ny; ++mg)
-        for (uint64_t l = 0; l < nl; ++l) {
-          double t = 0;
-          const double* pp = part.data() + ((mg << gd.kl) | l) * gx;
-          for (uint64_t b = 0; b < gx; ++b) t += pp[b];
-          uint64_t m = 0;
-          for (uint32_t i = 0; i < gd.kg; ++i) m |= ((mg >> i) & 1ull) << gbit[i];
-          for (uint32_t i = 0; i < gd.kl; ++i) m |= ((l >> i) & 1ull) << lbit[i];
-          out[m] = t;
-        }
+      for (uint64_t o = 0; o < nout; ++o) {
+        const uint64_t l = o & (nl - 1), c = (o >> gd.kl) & (nc - 1), mg = o >> (gd.kl + ki);
+        uint64_t m = 0;
+        for (uint32_t i = 0; i < gd.kg; ++i) m |= ((mg >> i) & 1ull) << gbit[i];
+        for (uint32_t i = 0; i < ki; ++i) m |= ((c >> i) & 1ull) << sbit[i];
+        for (uint32_t i = 0; i < gd.kl; ++i) m |= ((l >> i) & 1ull) << lbit[i];
+        out[m] = part[o];
+      }
       return QIP_OK;
     }
   }
@@ -2589,3 +2701,8 @@ extern "C" int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* ind
   if (!(prob >= 0.0)) return fail(QIP_ERR_INVALID, "probability must be >= 0");
   return collapse(s, md, measured, prob);
 } QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
+// the state sharded over several GPUs (qip_hip_dist_*)
+// ---------------------------------------------------------------------------------------
+#include "qip_dist.inc"

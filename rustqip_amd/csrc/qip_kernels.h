@@ -424,78 +424,49 @@ __global__ __launch_bounds__(kBlock) void k_swap_xlane1(E* __restrict__ st, uint
   }
 }
 
-// ---- TWO disjoint bit transpositions in one sweep (Swap with h >= 2, two pairs at a time) --------------------------
+// ---- several disjoint bit transpositions in ONE sweep (Swap with h >= 2) ---------------------------------------------
 // Swap(h, A ++ B) is the product of the h transpositions (A[j] B[j]); moves are exact, so any grouping of them is
-// bit-identical to the single permutation.  One sweep per PAIR of transpositions instead of one per transposition:
-// a lane holds the 2^NH amplitudes that differ on the NH "register" bits (swapped positions outside the lane index)
-// and applies each transposition as a stage on that register file:
-//   HH  both bits are register bits   -> a renaming of registers (free);
+// bit-identical to the single permutation.  A lane holds the 2^NH amplitudes that differ on the NH "register" bits
+// (swapped positions outside the lane index) and the transpositions act on that register file:
+//   HH  both bits are register bits    -> nothing moves between lanes: the element loaded from combination c is
+//       simply STORED at the combination with the two bits exchanged (off_st[c] = off_ld[pi_HH(c)], host tables);
 //   HL  one register bit, one lane bit -> lanes whose lane bit differs from the register bit exchange with lane ^ bit
 //       (the k_swap_xlane2 rule, for every combination of the other register bits);
-//   LL  both bits are lane bits        -> every register comes from the lane with the two bits exchanged.
-// Global accesses stay whole contiguous rows.  When both transpositions are HH the 4 of 16 combinations that are
-// fixed points (a0 == b0 and a1 == b1) are neither loaded nor stored.
-enum SwapStage : int { SW_HH = 0, SW_HL = 1, SW_LL = 2 };
-struct Swap2Desc {
-  uint64_t off[4];  // amplitude-index bit of register bit r (1 << position); unused ones are 0
-  uint32_t la[2];   // stage s: its lane bit (HL), or its first lane bit (LL)
-  uint32_t lb[2];   // stage s: second lane bit (LL)
+//   LL  both bits are lane bits        -> every register comes from the lane with those bits exchanged; all LL
+//       transpositions of the group fold into one source-lane map.
+// The stages act on disjoint bits, so they commute.  Global accesses stay whole contiguous rows.
+struct SwapNDesc {
+  uint64_t off_ld[16], off_st[16];  // amplitude-index offset of register combination c (load / store side)
+  uint32_t hl_lane[4];              // register bit r < NHL is exchanged with this lane bit
+  uint32_t n_ll;
+  uint32_t ll_a[4], ll_b[4];        // LL transpositions (lane bits)
 };
-template <int ST> struct SwapRegBits;
-template <> struct SwapRegBits<SW_HH> { static constexpr int v = 2; };
-template <> struct SwapRegBits<SW_HL> { static constexpr int v = 1; };
-template <> struct SwapRegBits<SW_LL> { static constexpr int v = 0; };
 
-template <int ST, int R0, int NR, typename A>
-__device__ __forceinline__ void swap_stage(A (&x)[NR], uint32_t lane, uint32_t la, uint32_t lb) {
-  if constexpr (ST == SW_HH) {
-#pragma unroll
-    for (int c = 0; c < NR; ++c)
-      if (((c >> R0) & 1) == 1 && ((c >> (R0 + 1)) & 1) == 0) {
-        const int k = (c & ~(1 << R0)) | (1 << (R0 + 1));
-        const A t = x[c];
-        x[c] = x[k];
-        x[k] = t;
-      }
-  } else if constexpr (ST == SW_HL) {
-    const bool lbit = (lane >> la) & 1u;
-    // slot (reg bit r, lane bit l) <-> slot (l, r): lanes with l = 1 give away their r = 0 element, lanes with
-    // l = 0 their r = 1 element, and receive into the same slot
-#pragma unroll
-    for (int c = 0; c < NR; ++c)
-      if (((c >> R0) & 1) == 0) {
-        const int k = c | (1 << R0);
-        const A xc = x[c], xk = x[k];
-        const A got = shfl_xor_e<A>(lbit ? xc : xk, 1 << la);
-        x[c] = lbit ? got : xc;  // selects on values, never a conditional store: that would address the register file
-        x[k] = lbit ? xk : got;
-      }
-  } else {
-    const uint32_t ba = (lane >> la) & 1u, bb = (lane >> lb) & 1u;
-    const uint32_t src = (lane & ~((1u << la) | (1u << lb))) | (bb << la) | (ba << lb);
-#pragma unroll
-    for (int c = 0; c < NR; ++c) x[c] = shfl_e<A>(x[c], (int)src);
-  }
-}
-
-template <typename T, int ST0, int ST1, int U, bool GUARD, bool NT, typename E = amp_t<T>>
-__global__ __launch_bounds__(kBlock) void k_swap2(E* __restrict__ st, uint64_t nitems, Ins ins, Swap2Desc d, Sel low) {
+// NH register bits, of which the first NHL are HL bits (the host orders them so; the others come in HH pairs);
+// LL: the group has lane-lane transpositions.  NHL == 0 && !LL is the all-HH group: no data crosses lanes and the
+// combinations no transposition moves are neither loaded nor stored.
+template <typename T, int NH, int NHL, bool LL, int U, bool GUARD, bool NT, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_swapn(E* __restrict__ st, uint64_t nitems, Ins ins, SwapNDesc d, Sel low) {
   using A = E;
-  constexpr int NH = SwapRegBits<ST0>::v + SwapRegBits<ST1>::v;
   constexpr int NR = 1 << NH;
-  constexpr bool kSkipFixed = ST0 == SW_HH && ST1 == SW_HH;
+  constexpr bool kPureHH = NHL == 0 && !LL;
+  static_assert((NH - NHL) % 2 == 0, "register bits that are not HL bits come in HH pairs");
   if (GUARD && work_index<0>(0) >= nitems) return;  // whole waves leave together (nitems % 64 == 0)
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t off[NR];
-#pragma unroll
-  for (int c = 0; c < NR; ++c) {
-    uint64_t o = 0;
-#pragma unroll
-    for (int r = 0; r < NH; ++r)
-      if ((c >> r) & 1) o |= d.off[r];
-    off[c] = o;
+  uint32_t src = lane;
+  if constexpr (LL) {
+    for (uint32_t q = 0; q < d.n_ll; ++q) {
+      const uint32_t ba = (src >> d.ll_a[q]) & 1u, bb = (src >> d.ll_b[q]) & 1u;
+      src = (src & ~((1u << d.ll_a[q]) | (1u << d.ll_b[q]))) | (bb << d.ll_a[q]) | (ba << d.ll_b[q]);
+    }
   }
-  auto fixed = [](int c) { return kSkipFixed && ((c & 1) == ((c >> 1) & 1)) && (((c >> 2) & 1) == ((c >> 3) & 1)); };
+  // all-HH: combination c is a fixed point when each HH pair (bits 2j, 2j+1) holds equal bits
+  auto fixed = [](int c) {
+    if (!kPureHH) return false;
+    for (int j = 0; j < NH / 2; ++j)
+      if (((c >> (2 * j)) & 1) != ((c >> (2 * j + 1)) & 1)) return false;
+    return true;
+  };
   uint64_t i0[U];
   A x[U][NR];
 #pragma unroll
@@ -503,22 +474,40 @@ __global__ __launch_bounds__(kBlock) void k_swap2(E* __restrict__ st, uint64_t n
     i0[u] = insert_bits<-1>(work_index<Log2<U>::v>(u), ins);
 #pragma unroll
     for (int c = 0; c < NR; ++c)
-      if (!fixed(c)) x[u][c] = ldg<NT>(st + (i0[u] | off[c]));
+      if (!fixed(c)) x[u][c] = ldg<NT>(st + (i0[u] | d.off_ld[c]));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    A y[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c)
-      if (!fixed(c)) y[c] = x[u][c];
-    swap_stage<ST0, 0, NR, A>(y, lane, d.la[0], d.lb[0]);
-    swap_stage<ST1, SwapRegBits<ST0>::v, NR, A>(y, lane, d.la[1], d.lb[1]);
-    // controls below kLineBits: the partner lanes / registers have the same control bits (controls are never
-    // swapped bits), so one predicate on this lane's index serves every slot it holds
+    // controls below kLineBits: a lane whose low control bits are not all 1 keeps everything it loaded.  Its HL / LL
+    // partner lanes have the same control bits (controls are never swapped bits), so switching the exchange off per
+    // lane is consistent: the registers are permuted in place, no second copy of the group is kept.
     const bool hit = sel_hit(i0[u], low);
+    A(&y)[NR] = x[u];
+#pragma unroll
+    for (int r = 0; r < NHL; ++r) {
+      const uint32_t la = d.hl_lane[r];
+      const bool lbit = (lane >> la) & 1u;
+      const bool take0 = hit && lbit, take1 = hit && !lbit;
+      // slot (reg bit r, lane bit l) <-> slot (l, r): lanes with l = 1 give away their r = 0 element, lanes with
+      // l = 0 their r = 1 element, and receive into the same slot
+#pragma unroll
+      for (int c = 0; c < NR; ++c)
+        if (((c >> r) & 1) == 0) {
+          const int k = c | (1 << r);
+          const A yc = y[c], yk = y[k];
+          const A got = shfl_xor_e<A>(lbit ? yc : yk, 1 << la);
+          y[c] = take0 ? got : yc;  // selects on values, never a conditional store: that would address the register file
+          y[k] = take1 ? got : yk;
+        }
+    }
+    if constexpr (LL) {
+      const int from = hit ? (int)src : (int)lane;
+#pragma unroll
+      for (int c = 0; c < NR; ++c) y[c] = shfl_e<A>(y[c], from);
+    }
 #pragma unroll
     for (int c = 0; c < NR; ++c)
-      if (!fixed(c)) stg<NT>(st + (i0[u] | off[c]), hit ? y[c] : x[u][c]);
+      if (!fixed(c)) stg<NT>(st + (i0[u] | (hit ? d.off_st[c] : d.off_ld[c])), y[c]);  // HH: stored exchanged
   }
 }
 
@@ -690,6 +679,92 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
     uint64_t base[WU];
     load(w, x, base);
     compute_store(x, base);
+  }
+}
+
+// ---- dense k-qubit gate on the f64 matrix cores, k = 6, 7, 8: the gate matrix streams through LDS ------------------
+// Same real-form product and the same lane mapping as k_gate_kq_mfma (a lane loads whole amplitudes with 16-B accesses,
+// ends up with re AND im of exactly those amplitudes and stores them back in place), but the A operand — (2S)^2 doubles
+// = 128 KiB / 512 KiB / 2 MiB for k = 6 / 7 / 8 — no longer fits a wave's registers.  It is read from the host-arranged
+// fragment array (afrag[(rb * KS + s) * 64 + lane], L2-resident) one 16-row block `rb` at a time into LDS, shared by
+// the block's four waves (each wave works on its own 16 groups) and double-buffered through registers: the loads of
+// block rb + 1 are issued before the KS matrix instructions of block rb and land in the other LDS half after them, one
+// barrier per row block.  X stays in registers for the whole item (S / 4 amplitudes per lane), so outputs can be
+// written over the inputs as each row block finishes.
+// Roofline: 8 * 2^k flop per amplitude against 32 B — 16 / 32 / 64 flop/B for k = 6 / 7 / 8, at or past the f64
+// matrix-core ridge (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 2048 flop / 64 clk * 1024 SIMDs * 2.4 GHz
+// = 78.6 TFLOP/s, ridge 9.8 flop/B at 8 TB/s): these sweeps are bound by the matrix pipe, not by HBM.
+// Two accumulator chains per row block (even / odd K-steps) keep the pipe busy without a second wave on the SIMD.
+template <int K, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<double>* __restrict__ st, uint64_t nitems, Ins ins,
+                                                          MfmaDesc d, const double* __restrict__ afrag) {
+  using A = amp_t<double>;
+  constexpr int S = 1 << K;
+  constexpr int TT = S / 8;        // 16-row blocks of the (2S x 2S) real matrix
+  constexpr int KS = S / 2;        // K-steps of 4
+  constexpr int NA = S / 4;        // amplitudes per lane per item
+  constexpr int CH = KS * 64;      // doubles per row-block chunk of A
+  constexpr int PF = CH / (kBlock * 2);  // 16-byte pieces per thread per chunk
+  typedef double v2f64 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) double lds[2 * CH];  // two chunks: 32 / 64 / 128 KiB (static: no 64-KiB dynamic cap)
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t j = lane & 15u, q = lane >> 4;
+  const uint64_t offq = ((uint64_t)(q & 1u) << d.tau[0]) | ((uint64_t)(q >> 1) << d.tau[1]);
+  auto offm = [&](uint32_t m) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < K - 2; ++b) o |= (uint64_t)((m >> b) & 1u) << d.tau[b + 2];
+    return o;
+  };
+  const v2f64* __restrict__ af2 = reinterpret_cast<const v2f64*>(afrag);
+  v2f64* lds2 = reinterpret_cast<v2f64*>(lds);
+  // chunk 0 -> LDS half 0
+#pragma unroll
+  for (int p = 0; p < PF; ++p) lds2[p * kBlock + tid] = af2[p * kBlock + tid];
+  __syncthreads();
+  uint32_t buf = 0;
+  const uint64_t nwg = (nitems + 3) / 4;
+  for (uint64_t it = blockIdx.x; it < nwg; it += gridDim.x) {
+    const uint64_t w = it * 4 + wave;
+    const bool active = w < nitems;  // wave-uniform
+    A x[NA];
+    uint64_t base = 0;
+    if (active) {
+      base = insert_bits<-1>((w << 4) | j, ins) | offq;
+#pragma unroll
+      for (int m = 0; m < NA; ++m) x[m] = ldg<NT>(st + (base | offm((uint32_t)m)));
+    } else {
+#pragma unroll
+      for (int m = 0; m < NA; ++m) x[m] = czero<A>();
+    }
+    for (int rb = 0; rb < TT; ++rb) {
+      // next row block of A (wrapping to block 0 for the next item) -> registers, in flight across the MFMAs
+      const int nrb = rb + 1 == TT ? 0 : rb + 1;
+      v2f64 pre[PF];
+#pragma unroll
+      for (int p = 0; p < PF; ++p) pre[p] = af2[(size_t)nrb * (CH / 2) + p * kBlock + tid];
+      const double* a = lds + buf * CH + lane;
+      v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s * 64], x[s >> 1].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(s + 1) * 64], x[s >> 1].y, acc1, 0, 0, 0);
+      }
+      if (active) {
+        A y0, y1;
+        y0.x = acc0[0] + acc1[0];
+        y0.y = acc0[1] + acc1[1];
+        y1.x = acc0[2] + acc1[2];
+        y1.y = acc0[3] + acc1[3];
+        stg<NT>(st + (base | offm(2u * (uint32_t)rb)), y0);
+        stg<NT>(st + (base | offm(2u * (uint32_t)rb + 1u)), y1);
+      }
+#pragma unroll
+      for (int p = 0; p < PF; ++p) lds2[(buf ^ 1u) * (CH / 2) + p * kBlock + tid] = pre[p];
+      __syncthreads();
+      buf ^= 1u;
+    }
   }
 }
 
@@ -1429,56 +1504,106 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_small(const amp_t<T>* 
   }
 }
 
-// 5 <= k <= ~20 outcomes bits without any atomic: the measured positions >= 8 go on the GRID (blockIdx.y = their
-// value mg: the block only visits indices that read mg there; `ins` opens those positions), the measured positions
-// < 8 are a function of the lane id alone.  So a lane accumulates ONE running sum over fully coalesced 4-KiB block
-// rows, and at the end the 256 lane sums are folded by lane outcome (2^kl <= 256 bins) through LDS:
-// partial[((mg << kl) | l) * gx + bx].  The host adds the gx partials per outcome.
+// 5 <= k <= ~23 outcome bits without any atomic.  The measured positions split three ways:
+//   lane bits   positions < 8: a function of the lane id alone (kl of them);
+//   grid bits   the block only visits indices that read `mg` there (`ins` opens them): blockIdx.x / gx = mg;
+//   step bits   up to three of the measured positions >= 8 (the lowest ones, taken off the grid when the grid would
+//               otherwise have far more blocks than the chip needs): the lane walks their 2^KI values in a fully
+//               unrolled inner loop, one running sum per value (static register index, independent loads).
+// So a lane accumulates 2^KI running sums over fully coalesced 4-KiB block rows, and at the end the 256 lane sums of
+// each are folded by lane outcome through wave shuffles and LDS.  Outcome index o = (mg << (KI + kl)) | (c << kl) | lane
+// outcome; partial[bx * nout + o] (a block's results are contiguous); k_sum_partials adds the gx blocks of an outcome.
 struct MeasGridDesc {
   uint32_t kg, kl;
-  uint32_t gpos[kMaxIns];   // measured positions >= 8, in outcome-bit order of the grid part
+  uint32_t gpos[kMaxIns];   // measured positions on the grid, in outcome-bit order of the grid part
   uint32_t lpos[8];         // measured positions < 8
+  uint32_t spos[3];         // step positions (bit i of c)
 };
-template <typename T>
+template <typename T, int KI>
 __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
-                                                              MeasGridDesc md, uint32_t gx, double* __restrict__ partial) {
+                                                              MeasGridDesc md, uint32_t gx, uint64_t nout,
+                                                              double* __restrict__ partial) {
+  constexpr int NC = 1 << KI;
   __shared__ double lane_sum[kBlock];
   // 1-D grid of (outcomes on the grid) x gx blocks: HIP caps gridDim.y at 65535 and kg may reach 20
   const uint64_t mg = blockIdx.x / gx;
   const uint32_t bx = blockIdx.x % gx;
   uint64_t templ = 0;
   for (uint32_t i = 0; i < md.kg; ++i) templ |= ((mg >> i) & 1ull) << md.gpos[i];
-  // `count` (a power of two >= 256) work items per mg, gridDim.x blocks striding over them, 4 rows in flight per lane
+  uint64_t coff[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int i = 0; i < KI; ++i)
+      if ((c >> i) & 1) o |= 1ull << md.spos[i];
+    coff[c] = o | templ;
+  }
+  // `count` (a power of two) work items per (mg, c); gx blocks stride over them; >= 4 independent rows in flight
+  constexpr int UN = NC >= 4 ? 1 : 4 / NC;
   const uint64_t stride = (uint64_t)gx * kBlock;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  double acc[NC][UN];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc[c][u] = 0.0;
   uint64_t w = (uint64_t)bx * kBlock + threadIdx.x;
-  for (; w + 3 * stride < count; w += 4 * stride) {
-    const amp_t<T> a = __builtin_nontemporal_load(st + (insert_bits<-1>(w, ins) | templ));
-    const amp_t<T> b = __builtin_nontemporal_load(st + (insert_bits<-1>(w + stride, ins) | templ));
-    const amp_t<T> c = __builtin_nontemporal_load(st + (insert_bits<-1>(w + 2 * stride, ins) | templ));
-    const amp_t<T> e = __builtin_nontemporal_load(st + (insert_bits<-1>(w + 3 * stride, ins) | templ));
-    s0 += (double)(a.x * a.x + a.y * a.y);
-    s1 += (double)(b.x * b.x + b.y * b.y);
-    s2 += (double)(c.x * c.x + c.y * c.y);
-    s3 += (double)(e.x * e.x + e.y * e.y);
+  for (; w + (UN - 1) * stride < count; w += UN * stride) {
+    amp_t<T> a[NC][UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const uint64_t base = insert_bits<-1>(w + u * stride, ins);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c][u] = __builtin_nontemporal_load(st + (base | coff[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) acc[c][u] += (double)(a[c][u].x * a[c][u].x + a[c][u].y * a[c][u].y);
   }
   for (; w < count; w += stride) {
-    const amp_t<T> a = __builtin_nontemporal_load(st + (insert_bits<-1>(w, ins) | templ));
-    s0 += (double)(a.x * a.x + a.y * a.y);
-  }
-  lane_sum[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  const uint32_t nl = 1u << md.kl;
-  if (threadIdx.x < nl) {
-    // lanes whose measured low bits read threadIdx.x (bit i of the lane outcome <-> position lpos[i])
-    double t = 0;
-    for (uint32_t l = 0; l < (uint32_t)kBlock; ++l) {
-      uint32_t lo = 0;
-      for (uint32_t i = 0; i < md.kl; ++i) lo |= ((l >> md.lpos[i]) & 1u) << i;
-      if (lo == threadIdx.x) t += lane_sum[l];
+    const uint64_t base = insert_bits<-1>(w, ins);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const amp_t<T> a = __builtin_nontemporal_load(st + (base | coff[c]));
+      acc[c][0] += (double)(a.x * a.x + a.y * a.y);
     }
-    partial[((mg << md.kl) | threadIdx.x) * gx + bx] = t;
   }
+  // fold the 256 lane sums by lane outcome: add across every lane-id bit that is NOT measured (wave shuffles for
+  // bits 0..5, LDS for the two wave-id bits); the lanes whose unmeasured bits are all zero then hold the totals
+  uint32_t lmask = 0;
+  for (uint32_t i = 0; i < md.kl; ++i) lmask |= 1u << md.lpos[i];
+  uint32_t lo = 0;  // bit i of the lane outcome <-> lane-id bit lpos[i]
+  for (uint32_t i = 0; i < md.kl; ++i) lo |= ((threadIdx.x >> md.lpos[i]) & 1u) << i;
+  const bool writer = (threadIdx.x & ~lmask & 255u) == 0u;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    double v = 0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v += acc[c][u];
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      if (!((lmask >> b) & 1u)) v += __shfl_xor(v, 1 << b, 64);  // wave-uniform condition
+    __syncthreads();  // lane_sum is reused per c
+    lane_sum[threadIdx.x] = v;
+    __syncthreads();
+    if (!((lmask >> 6) & 1u)) v += lane_sum[threadIdx.x ^ 64u];
+    __syncthreads();
+    lane_sum[threadIdx.x] = v;
+    __syncthreads();
+    if (!((lmask >> 7) & 1u)) v += lane_sum[threadIdx.x ^ 128u];
+    if (writer) partial[(uint64_t)bx * nout + ((((mg << KI) | (uint64_t)c) << md.kl) | lo)] = v;
+  }
+}
+
+// out[o] = sum of the gx per-block partial sums of outcome o (partial[b * nout + o]: coalesced across outcomes)
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restrict__ partial, uint32_t gx, uint64_t nout,
+                                                        double* __restrict__ out) {
+  const uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (o >= nout) return;
+  double t = 0;
+  for (uint32_t b = 0; b < gx; ++b) t += partial[(uint64_t)b * nout + o];
+  out[o] = t;
 }
 
 // probabilities of many outcomes: every amplitude adds |amp|^2 to out[its outcome]

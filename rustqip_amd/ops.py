@@ -201,6 +201,22 @@ def make_control_op(c_indices: Sequence[int], op: MatrixOp) -> MatrixOp:
     return MatrixOp("Control", c + list(op.indices), n_controls=len(c), inner=op)
 
 
+def flatten(op: MatrixOp):
+    """(control qubits, innermost op, target qubits) with nested Controls accumulated the way
+    sum_for_control_iterator does (ops.rs:150-154); only the OUTER index list is used (matrix_ops.rs:108)."""
+    if op.kind != "Control":
+        return [], op, list(op.indices)
+    n_control, inner = op.n_controls, op.inner
+    n_op = len(op.indices) - op.n_controls
+    while inner.kind == "Control":
+        n_control += inner.n_controls
+        n_op = len(inner.indices) - inner.n_controls
+        inner = inner.inner
+    if n_control + n_op != len(op.indices):
+        raise CircuitError("Control op index list does not match its controls + inner op indices")
+    return list(op.indices[:n_control]), inner, list(op.indices[n_control:])
+
+
 def validate_op(n: int, op: MatrixOp, dtype: int = _ffi.QIP_C64) -> None:
     """Run the C ABI validator (host code, no GPU needed); raises CircuitError."""
     cop = op.to_c(dtype)

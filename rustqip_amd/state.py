@@ -119,10 +119,22 @@ class HipState:
                                             C.byref(self._h))
             )
 
+    @classmethod
+    def from_handle(cls, handle, n: int, dtype=np.complex128) -> "HipState":
+        """A view of a qip_hip_state somebody else owns (the shard of a qip_hip_dist): never destroyed from here."""
+        self = cls.__new__(cls)
+        self.n = int(n)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = _dtype_of(np.empty(0, dtype=dtype))
+        self._h = C.c_void_p(handle.value if hasattr(handle, "value") else int(handle))
+        self._borrowed = True
+        return self
+
     # -- lifetime --------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
-            _ffi.lib.qip_hip_state_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                _ffi.lib.qip_hip_state_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

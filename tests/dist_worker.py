@@ -1,20 +1,24 @@
-"""Worker for tests/test_distributed_cpu.py: run under torch.distributed.run with gloo."""
+"""Worker for tests/test_distributed_cpu.py: run under torch.distributed.run with gloo.
+
+The C++ planner of the sharded state (csrc/qip_dist.inc: logical -> physical map, farthest-next-use remap choice,
+per-rank localisation of every op) is pure host code; qip_hip_dist_debug_plan serialises what THIS rank would do.
+Here the plan is replayed with the CPU oracle as the shard and gloo as the transport, and the gathered result is
+compared with the oracle applied to the full vector — the N > 1 logic without any GPU."""
 import math
 import os
 import sys
 
 import numpy as np
+import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from cpu_backend import OracleBackend  # noqa: E402
 from oracle import qip_oracle as O  # noqa: E402
 import rustqip_amd as q  # noqa: E402
 from rustqip_amd import circuits  # noqa: E402
-from rustqip_amd.sharded import ShardedState  # noqa: E402
+from rustqip_amd import sharded  # noqa: E402
 
 
 def rand_unitary(k, rng):
@@ -26,7 +30,7 @@ def rand_unitary(k, rng):
 def mixed_ops(n, rng, count):
     ops = []
     for _ in range(count):
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 9))
         perm = [int(v) for v in rng.permutation(n)]
         if kind == 0:
             ops.append(q.make_matrix_op([perm[0]], circuits.H))
@@ -44,69 +48,70 @@ def mixed_ops(n, rng, count):
         elif kind == 6:
             rows = [[(1, 0.5j)], [(0, 2.0)], [(3, 1.0)], [(2, -1.0), (3, 0.25)]]
             ops.append(q.make_sparse_matrix_op(perm[:2], rows))
-        else:
+        elif kind == 7:
             ops.append(q.make_control_op([perm[0]], q.make_swap_op([perm[1]], [perm[2]])))
+        else:  # block-diagonal in its first target, dense in the second: the first may stay on a rank bit
+            u0, u1 = rand_unitary(1, rng), rand_unitary(1, rng)
+            m = np.zeros((4, 4), dtype=complex)
+            m[:2, :2], m[2:, 2:] = u0, u1
+            ops.append(q.make_matrix_op(perm[:2], m.ravel()))
     return ops
+
+
+def apply_local(L, op, shard):
+    out = np.zeros_like(shard)
+    O.apply_op_overwrite(L, op, np.ascontiguousarray(shard), out)
+    return out
+
+
+def all_to_all(send):
+    t_send = torch.from_numpy(np.ascontiguousarray(send).view(np.float64))
+    t_recv = torch.empty_like(t_send)
+    dist.all_to_all_single(t_recv, t_send)
+    return t_recv.numpy().view(np.complex128)
 
 
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g = int(math.log2(world))
-    for n, seed in ((g + 3, 0), (7, 1), (9, 2)):
+    for n, seed in ((g + max(g, 3), 0), (7, 1), (9, 2)):
         rng = np.random.default_rng(seed)  # same stream on every rank
         x = circuits.random_state(n, seed + 10)
+        L = n - g
         for name, ops in (("c4", circuits.h_layer(n) + circuits.c4_clifford_t(n, 64, seed=32)),
                           ("qft", circuits.c3_qft(n)),
                           ("grover", circuits.c5_grover_iteration(n)),
+                          ("grover_k3", circuits.c5_grover_iteration(n, dense_k3=True)),
                           ("mixed", mixed_ops(n, rng, 60))):
-            st = ShardedState(n, dist, backend=OracleBackend(n - g))
-            st.upload_global(x)
-            if name == "mixed":
-                for op in ops:  # un-planned path (least-recently-used choice)
-                    st.apply_op(op)
-            else:
-                st.apply_ops(ops)  # planned path (farthest-next-use choice)
-            got = st.download_global()
+            plan = sharded.debug_plan(n, rank, world, ops)
+            assert (plan["g"], plan["L"], plan["rank"]) == (g, L, rank)
+            shard = x[rank << L:(rank + 1) << L].copy()  # a fresh state: logical = physical
+            shard = sharded.replay_plan(plan, shard, apply_local, all_to_all)
+            idx = sharded.shard_logical_indices(n, L, rank, plan["phys"]).astype(np.int64)
+            parts = [None] * world
+            dist.all_gather_object(parts, (idx, shard, [(s["t"], s.get("sel")) for s in plan["steps"] if s["t"] != "local"], plan["phys"]))
+            got = np.zeros(1 << n, dtype=np.complex128)
+            for i, v, _, _ in parts:
+                got[i] = v
             want = O.apply_ops_in_place(n, ops, x.copy())
             err = float(np.max(np.abs(got - want)))
             assert err < 1e-12, (name, n, world, err)
-            assert abs(st.norm_sqr() - O.prob_magnitude(want)) < 1e-12
-            for idx in ([0], [n - 1], [0, n - 1, 2], list(range(n))):
-                assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(n, idx, want))) < 1e-12, (name, idx)
+            # SPMD: every rank packs / exchanges at the same places with the same selection, and ends in the same layout
+            for _, _, coll, phys in parts:
+                assert coll == parts[0][2] and phys == parts[0][3], (name, n)
+            assert sorted(plan["phys"]) == list(range(n))
+            n_exchange = sum(1 for s in plan["steps"] if s["t"] == "exchange")
+            n_pack = sum(1 for s in plan["steps"] if s["t"] == "pack")
             if name in ("c4", "qft"):
-                assert st.stats["remaps"] >= 1, "circuit was expected to touch a global qubit"
-                # batched replay: the runs of local gates between remaps reach the backend as lists (what lets a
-                # HIP shard apply them as tile sweeps); same ops in the same order, so the result is identical
-                stb = ShardedState(n, dist, backend=OracleBackend(n - g))
-                stb.upload_global(x)
-                stb.run_plan(stb.plan(ops), batched=True)
-                assert np.array_equal(stb.download_global(), got), (name, n)
-                assert 1 <= len(stb.backend.batches) <= stb.stats["remaps"] + 1
-                assert (stb.stats["remaps"], stb.stats["local_swaps"]) == (st.stats["remaps"], st.stats["local_swaps"])
-            # collapsing measurement, forced outcomes: every shard rescales with the global probability
-            for idx, forced in (([0], 1), ([n - 1, 1], 2), ([2, 0, n - 1], 5)):
-                st2 = ShardedState(n, dist, backend=OracleBackend(n - g))
-                st2.upload_global(x)
-                st2.apply_ops(ops[: len(ops) // 2])
-                ref = O.apply_ops_in_place(n, ops[: len(ops) // 2], x.copy())
-                m, p = st2.measure(idx, measured=forced)
-                out = np.zeros_like(ref)
-                wm, wp = O.measure(n, idx, ref, out, forced=forced)
-                if wp == 0:
-                    out = ref
-                assert m == wm and abs(p - wp) < 1e-12, (name, idx)
-                assert np.max(np.abs(st2.download_global() - out)) < 1e-12, (name, idx)
-                ms, ps = st2.measure(idx, rand_u01=0.37)  # sampled: already collapsed, so it repeats
-                if wp > 0:
-                    assert ms == forced and abs(ps - 1) < 1e-12
-            # a basis state finds its owner through the permuted layout
-            st.init_basis(5 % (1 << n))
-            e = np.zeros(1 << n, dtype=np.complex128)
-            e[5 % (1 << n)] = 1
-            assert np.array_equal(st.download_global(), e)
+                assert n_exchange >= 1, "circuit was expected to touch a global qubit"
+            assert n_pack <= n_exchange
+            # every local op only names local qubits
+            for s in plan["steps"]:
+                if s["t"] == "local":
+                    assert all(0 <= i < L for i in s["op"]["indices"]), s
             if rank == 0:
-                print(f"ok n={n} world={world} {name}: err={err:.2e} stats={st.stats}")
+                print(f"ok n={n} world={world} {name}: err={err:.2e} exchanges={n_exchange} packs={n_pack}")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,7 +1,8 @@
 """Worker for the GPU leg of the N > 1 tests: several ranks share ONE MI355X ("virtual shards").
-Shard compute runs the real HIP kernels through HipBackend; the exchange is host-staged over gloo
-because RCCL refuses two ranks on one device.  With --nccl and world_size 1 the same script checks
-the RCCL process-group plumbing (device tensors, all_reduce) that bench.py --gpus N uses."""
+Everything goes through the C ABI's sharded state (qip_hip_dist_*: C++ planner, pack sweep, real HIP kernels on the
+shard); the exchange uses the host-staged transport callbacks over gloo because RCCL refuses two ranks on one device.
+With --nccl and world_size 1 the same script drives the built-in RCCL transport (librccl dlopen, unique id, communicator,
+all-reduce) that bench.py --gpus N uses."""
 import math
 import os
 import sys
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 from oracle import qip_oracle as O  # noqa: E402
 import rustqip_amd as q  # noqa: E402
 from rustqip_amd import circuits  # noqa: E402
-from rustqip_amd.sharded import HipBackend, ShardedState  # noqa: E402
+from rustqip_amd.sharded import DistState  # noqa: E402
 
 
 def main():
@@ -28,13 +29,18 @@ def main():
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g = int(math.log2(world))
+    rng = np.random.default_rng(5)
     for n in (12,):
         x = circuits.random_state(n, n)
-        for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 96, seed=28)),
+        u2 = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]
+        extra = [q.make_matrix_op([0, n - 1], u2.ravel()), q.make_swap_op([0, 3], [n - 1, 5]),
+                 q.make_sparse_matrix_op([1, 0], [[(1, 0.6), (0, 0.8j)], [(0, 0.6), (1, 0.8j)], [(3, 1j)], [(2, -1)]]),
+                 q.make_control_op([0], q.make_matrix_op([1], circuits.T)), q.make_matrix_op([0], circuits.rz(0.4))]
+        for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 96, seed=28) + extra),
                           ("c4", circuits.c4_clifford_t(n, 96, seed=32)),
                           ("qft", circuits.c3_qft(n)),
                           ("grover_k3", circuits.c5_grover_iteration(n, dense_k3=True))):
-            st = ShardedState(n, dist, backend=HipBackend(n - g, 0, host_staged_exchange=not use_nccl))
+            st = DistState(n, dist, 0, host_staged=not use_nccl)
             st.upload_global(x)
             st.apply_ops(ops)
             got = st.download_global()
@@ -44,16 +50,52 @@ def main():
             assert abs(st.norm_sqr() - 1) < 1e-12
             for idx in ([0], [n - 1, 0], list(range(5))):
                 assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(n, idx, want))) < 1e-12
+            stats = st.comm_stats()
             if world > 1 and name != "grover_k3":
-                assert st.stats["remaps"] >= 1
+                assert stats["remaps"] >= 1 and stats["bytes_sent_per_rank"] > 0
+            # one op at a time (least-recently-used choice instead of look-ahead): same state
+            st1 = DistState(n, dist, 0, host_staged=not use_nccl)
+            st1.upload_global(x)
+            for op in ops[:40]:
+                st1.apply_op(op)
+            assert np.max(np.abs(st1.download_global() - O.apply_ops_in_place(n, ops[:40], x.copy()))) < 1e-12, name
             # the runs of local gates between remaps as LDS-resident tile sweeps on every shard (tile = 1):
             # IEEE-equal to the gate-by-gate shards
-            stt = ShardedState(n, dist, backend=HipBackend(n - g, 0, host_staged_exchange=not use_nccl, tile=1))
+            stt = DistState(n, dist, 0, host_staged=not use_nccl)
+            stt.set_option("tile", 1)
             stt.upload_global(x)
-            stt.run_plan(stt.plan(ops), batched=True)
+            stt.apply_ops(ops)
             assert np.array_equal(stt.download_global(), got), (name, n, world)
+            # collapsing measurement: forced outcome, then a sampled one (already collapsed, so it repeats)
+            ref = O.apply_ops_in_place(n, ops[:30], x.copy())
+            for idx, forced in (([0], 1), ([n - 1, 1], 2), ([2, 0, n - 1], 5)):
+                st2 = DistState(n, dist, 0, host_staged=not use_nccl)
+                st2.upload_global(x)
+                st2.apply_ops(ops[:30])
+                m, p = st2.measure(idx, measured=forced)
+                out = np.zeros_like(ref)
+                wm, wp = O.measure(n, idx, ref, out, forced=forced)
+                if wp == 0:
+                    out = ref
+                assert m == wm and abs(p - wp) < 1e-12, (name, idx)
+                assert np.max(np.abs(st2.download_global() - out)) < 1e-12, (name, idx)
+                ms, ps = st2.measure(idx, rand_u01=0.37 + 0.1 * rank)  # ranks disagree on the sample: rank 0 decides
+                if wp > 0:
+                    assert ms == forced and abs(ps - 1) < 1e-12
+            st.init_basis(5)
+            e = np.zeros(1 << n, dtype=np.complex128)
+            e[5] = 1
+            assert np.array_equal(st.download_global(), e)
             if rank == 0:
-                print(f"ok n={n} world={world} {name}: err={err:.2e} stats={st.comm_stats()}")
+                print(f"ok n={n} world={world} {name}: err={err:.2e} stats={stats} {st.describe()['transport']}")
+    # f32 shards
+    n = 11
+    xf = circuits.random_state(n, 3, np.complex64)
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 48, seed=3)
+    sf = DistState(n, dist, 0, np.complex64, host_staged=not use_nccl)
+    sf.upload_global(xf)
+    sf.apply_ops(ops)
+    assert np.max(np.abs(sf.download_global() - O.apply_ops_in_place(n, ops, xf.copy()))) < 1e-5
     dist.barrier()
     dist.destroy_process_group()
 

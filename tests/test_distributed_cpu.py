@@ -1,10 +1,15 @@
-"""N > 1 path on CPU: world_size 2 and 4 over gloo, oracle-backed shards (tests/cpu_backend.py)."""
+"""N > 1 path on CPU: world_size 2 and 4 over gloo.  The sharded state's planner lives in libqip_hip.so
+(qip_hip_dist_debug_plan); the worker replays its plans with the CPU oracle as the shard (tests/dist_worker.py)."""
 import os
 import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+import rustqip_amd as q
+from rustqip_amd import circuits, sharded
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,4 +28,36 @@ def test_sharded_state_matches_single_process(world):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    assert res.stdout.count("ok n=") == 12
+    assert res.stdout.count("ok n=") == 15
+
+
+def test_planner_at_bench_size_without_any_device():
+    """the plans of the BASELINE multi-GPU configs at their stated sizes (host arithmetic only): n = 33 over 8 ranks,
+    n = 32 over 4: few exchanges, at most one pack sweep each, every rank the same collective sequence"""
+    for n, world, ops in ((33, 8, circuits.c2_random_circuit(33, 256, seed=28, single_only=True)),
+                          (32, 4, circuits.c4_clifford_t(32, 256, seed=32)),
+                          (33, 8, circuits.c5_grover_iteration(33, dense_k3=True))):
+        seqs = []
+        for rank in range(world):
+            plan = sharded.debug_plan(n, rank, world, ops)
+            seqs.append([(s["t"], s.get("sel")) for s in plan["steps"] if s["t"] != "local"])
+        assert all(sq == seqs[0] for sq in seqs)
+        ex = sum(1 for t, _ in seqs[0] if t == "exchange")
+        assert 1 <= ex <= 12, (n, world, ex)
+        assert sum(1 for t, _ in seqs[0] if t == "pack") <= ex
+
+
+def test_pack_bits_model_and_invalid_worlds():
+    x = np.arange(64, dtype=np.complex128)
+    y = sharded.pack_bits_numpy(x, 6, [1, 4])  # bits 1 and 4 become bits 4 and 5
+    for j in range(64):
+        src = ((j >> 4) & 1) << 1 | ((j >> 5) & 1) << 4
+        rest = j & 15
+        keep = [0, 2, 3, 5]
+        for i, p in enumerate(keep):
+            src |= ((rest >> i) & 1) << p
+        assert y[j] == x[src]
+    with pytest.raises(q.CircuitError):
+        sharded.debug_plan(6, 0, 3, [q.make_matrix_op([0], circuits.H)])
+    with pytest.raises(q.CircuitError):
+        sharded.debug_plan(3, 0, 4, [q.make_matrix_op([0], circuits.H)])

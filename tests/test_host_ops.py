@@ -175,7 +175,7 @@ def test_tile_schedule_invariants():
     free bits for its exchanging gates."""
     from rustqip_amd import circuits
     from rustqip_amd.ops import plan_tiles
-    from rustqip_amd.sharded import flatten
+    from rustqip_amd.ops import flatten
 
     n = 20
     rng = np.random.default_rng(0)

@@ -431,6 +431,42 @@ def test_dense_k_qubit(O, k):
             assert np.array_equal(hip_apply(n, cop, x, mfma=0), want)
 
 
+@pytest.mark.parametrize("k", [6, 7, 8])
+def test_dense_big_k_streamed_matrix_core_kernel(O, k):
+    """dense k = 6..8 on f64: k_gate_big_mfma (A operand streamed through LDS, X in registers, in place) — targets on
+    low / high / mixed bit positions, with controls, n from the smallest size the kernel accepts (k + 4) upwards;
+    fma chains, so the 1e-12 bar; 0/1 permutation matrices stay exact; mfma = 0 still takes the literal kernel."""
+    rng = np.random.default_rng(100 + k)
+    u = rand_unitary(k, rng)
+    for n in (k + 4, k + 5, k + 7):
+        x = rand_state(n, n)
+        picks = [list(range(k)), list(range(n - k, n)), [int(v) for v in rng.permutation(n)[:k]], [int(v) for v in rng.permutation(n)[:k]]]
+        for idx in picks:
+            op = q.make_matrix_op(idx, u.ravel())
+            want = oracle_apply(O, n, op, x)
+            with q.HipState(n) as st:
+                st.set_option("profile", 1)
+                st.upload(x)
+                p0 = st.device_ptr()
+                st.apply_op(op)
+                got = st.download()
+                assert "k_gate_big_mfma" in st.profile() and st.device_ptr() == p0, st.profile()
+            assert np.max(np.abs(got - want)) <= TOL64, (k, n, idx)
+        if n >= k + 5:
+            free = [t for t in range(n) if t not in picks[2]]
+            cop = q.make_control_op(free[:1], q.make_matrix_op(picks[2], u.ravel()))
+            assert np.max(np.abs(hip_apply(n, cop, x) - oracle_apply(O, n, cop, x))) <= TOL64
+    n = k + 5
+    x = rand_state(n, 3)
+    perm = rng.permutation(1 << k)
+    pm = np.zeros((1 << k, 1 << k))
+    pm[np.arange(1 << k), perm] = 1
+    op = q.make_matrix_op([int(v) for v in rng.permutation(n)[:k]], pm.ravel())
+    assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x))
+    op = q.make_matrix_op(list(range(k)), u.ravel())
+    assert np.array_equal(hip_apply(n, op, x, mfma=0), oracle_apply(O, n, op, x))  # literal kernel: bit-equal
+
+
 def test_dense_permutations_stay_exact_on_matrix_cores(O):
     """0/1 permutation matrices through the MFMA path: fma(1, x, 0) is exact, so IEEE `==` holds."""
     n = 9
@@ -847,8 +883,8 @@ def test_hipgraph_program_replay(O):
             assert np.array_equal(st.download(), twice)
             prog.close()
         assert np.max(np.abs(once - O.apply_ops_in_place(n, circ, x.copy()))) <= TOL64
-        # a sparse op takes the out-of-place literal kernel: the program must stay correct (eager fallback)
-        sp = circ[:20] + [q.make_sparse_matrix_op(perm[:2], [[(1, 0.5j)], [(0, 2.0)], [(3, 1.0)], [(2, -1.0)]])] + circ[20:40]
+        # a sparse op on 6 qubits takes the out-of-place literal kernel: the program must stay correct (eager fallback)
+        sp = circ[:20] + [q.make_sparse_matrix_op(perm[:6], [[((r * 5 + 1) % 64, 0.5j), (r, 2.0)] for r in range(64)])] + circ[20:40]
         with q.HipState(n) as st:
             st.upload(x)
             prog = st.compile_program(sp)
@@ -1132,6 +1168,7 @@ def _special_gates(n, rng):
         ("dense3_high", q.make_matrix_op([0, 5, n - 9], u3.ravel()), True),
         ("dense5_mfma", q.make_matrix_op([0, 2, n - 20, n - 7, n - 1], u5.ravel()), False),
         ("cdense2", q.make_control_op([3], q.make_matrix_op([1, n - 5], u2.ravel())), True),
+        ("dense7_streamed_mfma", q.make_matrix_op([0, 2, n - 20, n - 7, n - 1, 7, n - 12], rand_unitary(7, rng).ravel()), False),
         ("diag2", q.make_matrix_op([0, n - 2], np.diag([ph, ph.conjugate(), 1j, -1]).ravel()), True),
         ("sparse2", q.make_sparse_matrix_op([n - 1, 0], [[(0, 0.6), (1, 0.8j)], [(1, 0.6), (0, 0.8j)], [(3, 1j)], [(2, -1)]]), True),
     ]
@@ -1157,9 +1194,10 @@ def test_full_size_oracle_windows(O, n):
             want = W.product_state_window(n, vecs, off, 1 << 16)
             assert np.allclose(got, want, rtol=1e-12, atol=0), off
         assert abs(st.norm_sqr() - 1) < 1e-10
-        # the first 40 gates of the benchmarked circuit, one launch per gate
-        agg = W.check_circuit(st, n, c2[:40], O, gate_by_gate=True, seed=1)
-        assert agg["gates"] == 40 and agg["skipped"] == 0 and agg["rows"] >= 40 * 4 * (1 << 16)
+        # the first gates of the benchmarked circuit, one launch per gate
+        n_gbg = 40 if n <= 30 else 32
+        agg = W.check_circuit(st, n, c2[:n_gbg], O, gate_by_gate=True, seed=1)
+        assert agg["gates"] == n_gbg and agg["skipped"] == 0 and agg["rows"] >= n_gbg * 4 * (1 << 16)
         assert agg["bit_equal"] and agg["max_abs_delta"] == 0.0, agg
         for name, op, exact in _special_gates(n, rng):
             r = W.check_ops(st, n, [op], O, bases=W.default_bases(n, seed=zlib.crc32(name.encode()) % 1000))
@@ -1173,15 +1211,17 @@ def test_full_size_oracle_windows(O, n):
         st.set_option("tile", 1)
         st.set_option("profile", 1)
         st.profile_reset()
-        agg = W.check_circuit(st, n, c2[40:168], O, gate_by_gate=False, seed=2)
+        n_tile = 96 if n <= 30 else 48
+        agg = W.check_circuit(st, n, c2[40:40 + n_tile], O, gate_by_gate=False, seed=2, bases_per_step=2)
         prof = st.profile()
-        assert agg["gates"] == 128 and agg["skipped"] == 0
-        assert prof.get("k_tile_gates", {}).get("launches", 0) >= 4, prof  # multi-gate sweeps really ran
+        assert agg["gates"] == n_tile and agg["skipped"] == 0
+        assert prof.get("k_tile_gates", {}).get("launches", 0) >= 3, prof  # multi-gate sweeps really ran
         assert agg["max_abs_delta"] == 0.0, agg  # only a -0 may differ from the gate-by-gate path
-        # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
-        g = circuits.c5_grover_iteration(n, dense_k3=True)
-        agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3)
-        assert agg["gates"] >= len(g) - 2 and agg["max_abs_delta"] <= TOL64, agg
+        if n == 30:
+            # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
+            g = circuits.c5_grover_iteration(n, dense_k3=True)
+            agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3, bases_per_step=2)
+            assert agg["gates"] >= len(g) - 2 and agg["max_abs_delta"] <= TOL64, agg
         st.set_option("tile", 0)
         st.set_option("profile", 0)
         assert abs(st.norm_sqr() - 1) < 1e-9

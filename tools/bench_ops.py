@@ -49,6 +49,7 @@ def main():
         ("Swap(1) bits n-1 <-> 0", q.make_swap_op([hi], [lo]), {}),
         ("Swap(2)", q.make_swap_op([hi, 1], [mid, lo]), {}),
         ("Swap(2), one transposition per sweep", q.make_swap_op([hi, 1], [mid, lo]), {"swap_single": 1}),
+        ("Swap(2), 2 groups per lane", q.make_swap_op([hi, 1], [mid, lo]), {"unroll": 2}),
         ("Swap(2) all high bits", q.make_swap_op([hi, 1], [mid, 7]), {}),
         ("Swap(2) all high bits, one transposition per sweep", q.make_swap_op([hi, 1], [mid, 7]), {"swap_single": 1}),
         ("Swap(3)", q.make_swap_op([hi, 1, 2], [mid, lo, lo - 1]), {}),
@@ -66,6 +67,10 @@ def main():
         ("dense k=5 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, 9], rand_unitary(5, rng).ravel()), {}),
         ("dense k=4 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7], rand_unitary(4, rng).ravel()), {"mfma": 2}),
         ("dense k=3 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 2}),
+        ("dense k=6 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {}),
+        ("dense k=7 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11], rand_unitary(7, rng).ravel()), {}),
+        ("dense k=8 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13], rand_unitary(8, rng).ravel()), {}),
+        ("dense k=6 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {"mfma": 0}),
         ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
         ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
         ("sparse k=2 (in place)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
