@@ -6,8 +6,9 @@
 //! * [`sys`]     raw `extern "C"` declarations, one per entry of `include/qip_hip.h`;
 //! * [`op`]      `MatrixOp<Complex<f64>>` -> `struct qip_op` (borrowing the op's own buffers);
 //! * [`state`]   `HipState`: the device-resident amplitude vector (RAII over `qip_hip_state_*`);
-//! * [`builder`] `HipBuilder`: owns a `LocalBuilder<f64>` for all circuit bookkeeping and replaces only
-//!               `calculate_state_with_init` (`qip/src/builder.rs:400-519`) with device launches;
+//! * [`builder`] `HipBuilder<P>`: implements `CircuitBuilder` and the 12 extension traits `LocalBuilder<P>` implements
+//!               (`qip/src/builder.rs:325…969`) by delegation to an inner `LocalBuilder<P>`, replacing only
+//!               `calculate_state_with_init` (`builder.rs:400-519`) with device launches; `P = f64` or `f32`;
 //! * [`replay`]  writer for the flat circuit-replay text format (`rustqip_amd/replay.py`), for setups
 //!               where the Rust program and the GPU are not in the same process.
 //!
@@ -19,5 +20,6 @@ pub mod replay;
 pub mod state;
 pub mod sys;
 
-pub use builder::{HipBuilder, HipMeasurements};
+pub use builder::{HipBuilder, HipMeasurementHandle, HipMeasurements, HipStochasticMeasurementHandle};
+pub use op::HipPrecision;
 pub use state::{HipError, HipState};

@@ -1,24 +1,51 @@
-//! `MatrixOp<Complex<f64>>` -> `struct qip_op`.
+//! `MatrixOp<Complex<P>>` -> `struct qip_op`, for `P = f64` (`QIP_C64`) and `P = f32` (`QIP_C32`).
 //!
-//! `Complex<f64>` is `#[repr(C)] { re, im }` in `num-complex`, so dense data and sparse values are passed by
+//! `Complex<P>` is `#[repr(C)] { re, im }` in `num-complex`, so dense data and sparse values are passed by
 //! pointer without copying; only the `usize` indices (widened to `u64`) and the CSR image of
 //! `Vec<Vec<(usize, P)>>` are materialised.  A `COp` owns those and borrows the rest from the `MatrixOp`.
 use crate::sys;
 use num_complex::Complex;
+use qip::Precision;
 use qip_iterators::iterators::MatrixOp;
 use std::marker::PhantomData;
+use std::os::raw::c_int;
 
-pub struct COp<'a> {
+/// The two precisions the library is built for (`qip/src/types.rs:6-13`): selects the `dtype` argument of the C ABI.
+pub trait HipPrecision: Precision {
+    const DTYPE: c_int;
+    fn to_f64(self) -> f64;
+    fn from_f64(v: f64) -> Self;
+}
+impl HipPrecision for f64 {
+    const DTYPE: c_int = sys::QIP_C64;
+    fn to_f64(self) -> f64 {
+        self
+    }
+    fn from_f64(v: f64) -> Self {
+        v
+    }
+}
+impl HipPrecision for f32 {
+    const DTYPE: c_int = sys::QIP_C32;
+    fn to_f64(self) -> f64 {
+        self as f64
+    }
+    fn from_f64(v: f64) -> Self {
+        v as f32
+    }
+}
+
+pub struct COp<'a, P: HipPrecision> {
     raw: Box<sys::qip_op>,
     _idx: Vec<u64>,
     _rowptr: Vec<u64>,
     _cols: Vec<u64>,
-    _vals: Vec<Complex<f64>>,
-    _inner: Option<Box<COp<'a>>>,
-    _borrow: PhantomData<&'a MatrixOp<Complex<f64>>>,
+    _vals: Vec<Complex<P>>,
+    _inner: Option<Box<COp<'a, P>>>,
+    _borrow: PhantomData<&'a MatrixOp<Complex<P>>>,
 }
 
-impl<'a> COp<'a> {
+impl<'a, P: HipPrecision> COp<'a, P> {
     pub fn as_ptr(&self) -> *const sys::qip_op {
         &*self.raw
     }
@@ -29,7 +56,7 @@ impl<'a> COp<'a> {
 
 /// The index list the reference's `MatrixOp::indices()` yields (ops.rs:39-46): controls first for `Control`,
 /// A half then B half for `Swap`.
-pub fn marshal<'a>(op: &'a MatrixOp<Complex<f64>>) -> COp<'a> {
+pub fn marshal<'a, P: HipPrecision>(op: &'a MatrixOp<Complex<P>>) -> COp<'a, P> {
     let idx: Vec<u64> = op.indices().iter().map(|&i| i as u64).collect();
     let mut raw = sys::qip_op {
         kind: sys::QIP_OP_MATRIX,

@@ -1,9 +1,10 @@
 //! `HipState`: the device-resident `2^n` amplitude vector (`state` + `arena` of `builder.rs:406-407`).
-use crate::op::marshal;
+use crate::op::{marshal, HipPrecision};
 use crate::sys;
 use num_complex::Complex;
 use qip_iterators::iterators::MatrixOp;
 use std::ffi::{CStr, CString};
+use std::marker::PhantomData;
 
 /// A non-zero status of the C ABI with the library's message (`qip_hip_last_error`).
 #[derive(Debug, Clone)]
@@ -26,22 +27,23 @@ pub(crate) fn check(rc: i32) -> Result<(), HipError> {
     Err(HipError { code: rc, message })
 }
 
-pub struct HipState {
+pub struct HipState<P: HipPrecision = f64> {
     n: usize,
     h: *mut sys::qip_hip_state,
+    _p: PhantomData<P>,
 }
 
 // One host thread drives a handle at a time (the reference's run loop is sequential, builder.rs:423-517);
 // moving it to another thread is fine, sharing it is not.
-unsafe impl Send for HipState {}
+unsafe impl<P: HipPrecision> Send for HipState<P> {}
 
-impl HipState {
-    /// `2^n` `Complex<f64>` amplitudes (+ as much scratch) in the HBM of `device`.  Fails when no gfx950 device
+impl<P: HipPrecision> HipState<P> {
+    /// `2^n` `Complex<P>` amplitudes (+ as much scratch) in the HBM of `device`.  Fails when no gfx950 device
     /// is visible: there is no CPU fallback.
     pub fn new(n: usize, device: i32) -> Result<Self, HipError> {
         let mut h = std::ptr::null_mut();
-        check(unsafe { sys::qip_hip_state_create(n as u32, sys::QIP_C64, device, &mut h) })?;
-        Ok(Self { n, h })
+        check(unsafe { sys::qip_hip_state_create(n as u32, P::DTYPE, device, &mut h) })?;
+        Ok(Self { n, h, _p: PhantomData })
     }
     pub fn n(&self) -> usize {
         self.n
@@ -54,21 +56,21 @@ impl HipState {
     pub fn init_basis(&mut self, index: usize) -> Result<(), HipError> {
         check(unsafe { sys::qip_hip_state_init_basis(self.h, index as u64) })
     }
-    pub fn upload(&mut self, amps: &[Complex<f64>], offset: usize) -> Result<(), HipError> {
+    pub fn upload(&mut self, amps: &[Complex<P>], offset: usize) -> Result<(), HipError> {
         check(unsafe { sys::qip_hip_state_upload(self.h, amps.as_ptr() as *const _, offset as u64, amps.len() as u64) })
     }
-    pub fn download(&self) -> Result<Vec<Complex<f64>>, HipError> {
-        let mut out = vec![Complex::new(0.0, 0.0); 1usize << self.n];
+    pub fn download(&self) -> Result<Vec<Complex<P>>, HipError> {
+        let mut out = vec![Complex::new(P::zero(), P::zero()); 1usize << self.n];
         check(unsafe { sys::qip_hip_state_download(self.h, out.as_mut_ptr() as *mut _, 0, out.len() as u64) })?;
         Ok(out)
     }
     /// `apply_op_overwrite` + buffer swap of the reference run loop (builder.rs:499,514), in place on the device.
-    pub fn apply_op(&mut self, op: &MatrixOp<Complex<f64>>) -> Result<(), HipError> {
+    pub fn apply_op(&mut self, op: &MatrixOp<Complex<P>>) -> Result<(), HipError> {
         let c = marshal(op);
         check(unsafe { sys::qip_hip_state_apply_op(self.h, c.as_ptr()) })
     }
     /// A run of gates in one call, so the library may schedule them (options "tile", "fuse").
-    pub fn apply_ops(&mut self, ops: &[MatrixOp<Complex<f64>>]) -> Result<(), HipError> {
+    pub fn apply_ops(&mut self, ops: &[MatrixOp<Complex<P>>]) -> Result<(), HipError> {
         let keep: Vec<_> = ops.iter().map(marshal).collect();
         let flat: Vec<sys::qip_op> = keep.iter().map(|c| unsafe { std::ptr::read(c.as_ptr()) }).collect();
         let rc = unsafe { sys::qip_hip_state_apply_ops(self.h, flat.as_ptr(), flat.len() as u64) };
@@ -100,7 +102,7 @@ impl HipState {
     }
 }
 
-impl Drop for HipState {
+impl<P: HipPrecision> Drop for HipState<P> {
     fn drop(&mut self) {
         unsafe { sys::qip_hip_state_destroy(self.h) };
     }

@@ -121,6 +121,20 @@ int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op,
                           void* out, uint64_t out_len,
                           uint64_t in_off, uint64_t out_off, int accumulate);
 
+/* apply_op_row (matrix_ops.rs:38-59): the single value (op . input)[output_offset + outputrow], same window rules.
+ * `out_value` points at one qip_c64 / qip_c32.  Host pointers; for parity tests. */
+int qip_hip_apply_op_row_host(int dtype, uint32_t n, const qip_op* op, const void* in, uint64_t in_len,
+                              uint64_t outputrow, uint64_t in_off, uint64_t out_off, void* out_value);
+
+/* Host-pointer twins of measure_probs / measure_prob WITH the input_offset window every reference measurement
+ * function takes (measurement_ops.rs:44-58,115-127: `input` holds amplitudes [in_off, in_off + in_len) of the 2^n
+ * vector; what lies outside the window contributes nothing).  out: 2^k doubles / one double.  (On a device-resident
+ * state the window is always the whole vector; a sharded state resolves its rank bits itself, qip_hip_dist_*.) */
+int qip_hip_measure_probs_host(int dtype, uint32_t n, const uint64_t* indices, uint32_t k, const void* in,
+                               uint64_t in_len, uint64_t in_off, double* out);
+int qip_hip_measure_prob_host(int dtype, uint32_t n, uint64_t measured, const uint64_t* indices, uint32_t k,
+                              const void* in, uint64_t in_len, uint64_t in_off, double* out);
+
 /* ---- outer seam: device-resident state ----------------------------------
  * Replaces the two host Vecs `state` / `arena` that
  * LocalBuilder::calculate_state_with_init allocates and ping-pongs
@@ -234,7 +248,10 @@ int qip_hip_state_measure_probs(qip_hip_state* s, const uint64_t* indices, uint3
 int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, const uint64_t* indices,
                                uint32_t k, double* out);
 /* soft_measure (:153-176) with the uniform sample supplied by the caller
- * (`rand_u01` in [0,1)), so the Rust side keeps using `rand`. */
+ * (`rand_u01` in [0,1)), so the Rust side keeps using `rand`.  f64 states reproduce the reference's sample ->
+ * outcome map (the chunk that crosses zero is replayed sequentially); for f32 states the chunk sums are accumulated
+ * in double while the reference subtracts sequentially in f32, so only the DISTRIBUTION of outcomes matches, not
+ * necessarily the exact index for a given sample. */
 int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
                                double rand_u01, uint64_t* measured);
 /* measure (:190-214): forced >= 0 plays MeasuredCondition.measured;

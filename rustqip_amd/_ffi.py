@@ -64,6 +64,9 @@ SIGNATURES = {
     "qip_hip_validate_op": (_int, [_u32, _opp]),
     "qip_hip_op_algorithmic_bytes": (_int, [_int, _u32, _opp, _dblp]),
     "qip_hip_apply_op_host": (_int, [_int, _u32, _opp, _vp, _u64, _vp, _u64, _u64, _u64, _int]),
+    "qip_hip_apply_op_row_host": (_int, [_int, _u32, _opp, _vp, _u64, _u64, _u64, _u64, _vp]),
+    "qip_hip_measure_probs_host": (_int, [_int, _u32, _u64p, _u32, _vp, _u64, _u64, _dblp]),
+    "qip_hip_measure_prob_host": (_int, [_int, _u32, _u64, _u64p, _u32, _vp, _u64, _u64, _dblp]),
     "qip_hip_state_create": (_int, [_u32, _int, _int, C.POINTER(_statep)]),
     "qip_hip_state_wrap": (_int, [_u32, _int, _int, _vp, _vp, _vp, C.POINTER(_statep)]),
     "qip_hip_state_destroy": (_int, [_statep]),

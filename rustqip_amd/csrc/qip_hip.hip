@@ -2395,6 +2395,73 @@ extern "C" int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op, co
 } QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
+// host-pointer twins of apply_op_row and of the windowed measurement functions
+// ---------------------------------------------------------------------------------------
+extern "C" int qip_hip_apply_op_row_host(int dtype, uint32_t n, const qip_op* op, const void* in, uint64_t in_len,
+                                         uint64_t outputrow, uint64_t in_off, uint64_t out_off, void* out_value) try {
+  if (!out_value) return fail(QIP_ERR_INVALID, "null output");
+  // apply_op_row (matrix_ops.rs:38-59): the value of row out_off + outputrow = a one-row output window there
+  return qip_hip_apply_op_host(dtype, n, op, in, in_len, out_value, 1, in_off, out_off + outputrow, 0);
+} QIP_CATCH_ALL
+
+template <typename T>
+static int measure_probs_host_t(uint32_t n, const uint64_t* indices, uint32_t k, const void* in, uint64_t in_len,
+                                uint64_t in_off, double* out) {
+  if (k == 0 || k > n || k > 26 || !indices) return fail(QIP_ERR_INVALID, "bad measurement index list");
+  MeasDesc md;
+  memset(&md, 0, sizeof md);
+  md.k = k;
+  uint64_t seen = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    if (indices[i] >= n) return fail(QIP_ERR_INVALID, "measured qubit index out of range");
+    if (seen & (1ull << indices[i])) return fail(QIP_ERR_INVALID, "repeated measured qubit index");
+    seen |= 1ull << indices[i];
+    md.mpos[i] = (uint32_t)(n - 1 - indices[i]);
+  }
+  const uint64_t outcomes = 1ull << k;
+  for (uint64_t m = 0; m < outcomes; ++m) out[m] = 0.0;
+  if (in_len == 0) return QIP_OK;
+  if (qip_hip_device_count() <= 0) return fail(QIP_ERR_NO_DEVICE, "no HIP device visible: qip_hip has no CPU fallback");
+  HIPCHK(hipSetDevice(0));
+  void *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_in, in_len * sizeof(amp_t<T>)));
+  hipError_t e = hipMalloc(&d_out, outcomes * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d_in, in, in_len * sizeof(amp_t<T>), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d_out, 0, outcomes * sizeof(double));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((k_measure_probs_scatter<T>), dim3(grid_stride(in_len)), dim3(kBlock), 0, nullptr, (const amp_t<T>*)d_in,
+                       in_len, md, in_off, (double*)d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, outcomes * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(QIP_ERR_DEVICE, "windowed measure_probs failed: %s", hipGetErrorString(e));
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_measure_probs_host(int dtype, uint32_t n, const uint64_t* indices, uint32_t k, const void* in,
+                                          uint64_t in_len, uint64_t in_off, double* out) try {
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if ((in_len && !in) || !out) return fail(QIP_ERR_INVALID, "null buffer");
+  if (n == 0 || n > 62) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 62]", n);
+  if (in_off > (1ull << n) || in_len > (1ull << n) - in_off) return fail(QIP_ERR_INVALID, "window outside the 2^n vector");
+  return dtype == QIP_C64 ? measure_probs_host_t<double>(n, indices, k, in, in_len, in_off, out)
+                          : measure_probs_host_t<float>(n, indices, k, in, in_len, in_off, out);
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_measure_prob_host(int dtype, uint32_t n, uint64_t measured, const uint64_t* indices, uint32_t k,
+                                         const void* in, uint64_t in_len, uint64_t in_off, double* out) try {
+  if (!out) return fail(QIP_ERR_INVALID, "null output");
+  if (k > 26) return fail(QIP_ERR_UNSUPPORTED, "windowed measure_prob over %u qubits", k);
+  if (k > 0 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
+  std::vector<double> probs(1ull << k);
+  QCHK(qip_hip_measure_probs_host(dtype, n, indices, k, in, in_len, in_off, probs.data()));
+  *out = probs[measured];
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------
 static int check_measure_indices(qip_hip_state* s, const uint64_t* indices, uint32_t k, MeasDesc* md,
@@ -2523,7 +2590,7 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
       HIPCHK(hipGetLastError());
       const double* res = s->d_partial;
       if (gx > 1) {  // fold the gx partials per outcome on the device: only 2^k doubles cross PCIe
-        hipLaunchKernelGGL(k_sum_partials, dim3(grid_for(nout, kBlock)), dim3(kBlock), 0, s->stream, s->d_partial, (uint32_t)gx,
+        hipLaunchKernelGGL(k_sum_partials, dim3(grid_for(nout, kBlock / 64)), dim3(kBlock), 0, s->stream, s->d_partial, (uint32_t)gx,
                            (uint64_t)nout, s->d_partial + np);
         HIPCHK(hipGetLastError());
         res = s->d_partial + np;
@@ -2565,7 +2632,7 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
   QCHK(ensure_partial(s, outcomes));
   HIPCHK(hipMemsetAsync(s->d_partial, 0, outcomes * sizeof(double), s->stream));
   hipLaunchKernelGGL((k_measure_probs_scatter<T>), dim3(grid_stride(s->namps)), dim3(kBlock), 0,
-                     s->stream, (const amp_t<T>*)s->cur, s->namps, md, s->d_partial);
+                     s->stream, (const amp_t<T>*)s->cur, s->namps, md, (uint64_t)0, s->d_partial);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, s->d_partial, outcomes * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));

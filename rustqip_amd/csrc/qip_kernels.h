@@ -1596,25 +1596,29 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* _
   }
 }
 
-// out[o] = sum of the gx per-block partial sums of outcome o (partial[b * nout + o]: coalesced across outcomes)
+// out[o] = sum of the gx per-block partial sums of outcome o (partial[b * nout + o]); one wave per outcome
 __global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restrict__ partial, uint32_t gx, uint64_t nout,
                                                         double* __restrict__ out) {
-  const uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t o = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (o >= nout) return;
   double t = 0;
-  for (uint32_t b = 0; b < gx; ++b) t += partial[(uint64_t)b * nout + o];
-  out[o] = t;
+  for (uint32_t b = threadIdx.x & 63u; b < gx; b += 64) t += partial[(uint64_t)b * nout + o];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if ((threadIdx.x & 63u) == 0) out[o] = t;
 }
 
 // probabilities of many outcomes: every amplitude adds |amp|^2 to out[its outcome]
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_measure_probs_scatter(const amp_t<T>* __restrict__ st,
-                                                                  uint64_t namps, MeasDesc md,
+                                                                  uint64_t namps, MeasDesc md, uint64_t offset,
                                                                   double* __restrict__ out) {
+  // `offset`: st[0] is amplitude `offset` of the full vector (the input_offset window of measurement_ops.rs:17-19)
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
-    const amp_t<T> x = st[i];
+  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < namps; w += stride) {
+    const amp_t<T> x = st[w];
     if (x.x == (T)0 && x.y == (T)0) continue;  // measurement_ops.rs:98-99
+    const uint64_t i = w + offset;
     uint64_t m = 0;
     for (uint32_t b = 0; b < md.k; ++b) m |= ((i >> md.mpos[b]) & 1ull) << b;
     atomicAdd(&out[m], (double)(x.x * x.x + x.y * x.y));

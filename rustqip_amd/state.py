@@ -78,6 +78,33 @@ def apply_op_overwrite(n: int, op: MatrixOp, input: np.ndarray, output: np.ndarr
     _apply_host(n, op, input, output, input_offset, output_offset, False)
 
 
+def apply_op_row(n: int, op: MatrixOp, input: np.ndarray, outputrow: int, input_offset: int = 0,
+                 output_offset: int = 0) -> complex:
+    """apply_op_row (matrix_ops.rs:38-59): the value of row output_offset + outputrow."""
+    dtype = _dtype_of(input)
+    cop = op.to_c(dtype)
+    out = np.zeros(1, dtype=input.dtype)
+    _check(_ffi.lib.qip_hip_apply_op_row_host(dtype, n, C.byref(cop), input.ctypes.data, input.size, int(outputrow),
+                                              int(input_offset), int(output_offset), out.ctypes.data))
+    return complex(out[0])
+
+
+def measure_probs(n: int, indices: Sequence[int], input: np.ndarray, input_offset: int = 0) -> np.ndarray:
+    """measure_probs (measurement_ops.rs:115-127) on a host window `input` = amplitudes [input_offset, +len)."""
+    out = np.empty(1 << len(indices), dtype=np.float64)
+    _check(_ffi.lib.qip_hip_measure_probs_host(_dtype_of(input), n, _u64_array(indices), len(indices), input.ctypes.data,
+                                               input.size, int(input_offset), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def measure_prob(n: int, measured: int, indices: Sequence[int], input: np.ndarray, input_offset: int = 0) -> float:
+    """measure_prob (measurement_ops.rs:44-58) on a host window."""
+    out = C.c_double()
+    _check(_ffi.lib.qip_hip_measure_prob_host(_dtype_of(input), n, int(measured), _u64_array(indices), len(indices),
+                                              input.ctypes.data, input.size, int(input_offset), C.byref(out)))
+    return out.value
+
+
 def make_op_matrix(n: int, op: MatrixOp, dtype=np.complex128) -> np.ndarray:
     """Full 2^n x 2^n matrix of `op`, column by column through apply_op on basis vectors —
     the reference's test/debug helper (qip/src/state_ops/matrix_ops.rs:246-257,

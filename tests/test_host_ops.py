@@ -304,3 +304,35 @@ def test_tile_pass_layout_is_a_bijection_and_bank_conflict_free(dtype_name):
             assert (r, w) == (1, 1), (P, r, w)
     with pytest.raises(q.CircuitError):
         tile_lane_assignment((3, 3, 5), dtype)
+
+
+def test_header_is_plain_c11(tmp_path):
+    """include/qip_hip.h is the drop-in boundary: it must compile as C11 (no C++-isms) so cgo / bindgen / a C host can
+    consume it, and a C program must be able to fill the descriptor and transport structs it declares."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text("""
+#include "qip_hip.h"
+static int a2a(void* ctx, const void* send, void* recv, uint64_t chunk_bytes, void* stream) { (void)ctx; (void)send; (void)recv; (void)chunk_bytes; (void)stream; return 0; }
+static int ars(void* ctx, double* v, uint64_t count) { (void)ctx; (void)v; (void)count; return 0; }
+int main(void) {
+  static const uint64_t idx[2] = {0, 1};
+  static const qip_c64 x[4] = {{0, 0}, {1, 0}, {1, 0}, {0, 0}};
+  qip_op inner = {QIP_OP_MATRIX, 1, idx + 1, 0, x, 0, 0, 0, 0};
+  qip_op cnot = {QIP_OP_CONTROL, 2, idx, 1, 0, 0, 0, 0, &inner};
+  qip_hip_transport t = {0, a2a, ars};
+  qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0};
+  char id[QIP_HIP_UNIQUE_ID_BYTES];
+  (void)id; (void)st; (void)t;
+  return qip_hip_validate_op(2, &cnot) == QIP_OK && qip_hip_abi_version() >= 1 ? 0 : 1;
+}
+""")
+    exe = tmp_path / "use_header"
+    lib_dir = os.path.join(root, "rustqip_amd", "lib")
+    subprocess.run(["gcc", "-std=c11", "-pedantic-errors", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-lqip_hip", "-Wl,-rpath," + lib_dir], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    assert subprocess.run([str(exe)], env=env).returncode == 0  # validate_op is host code: runs without a GPU
