@@ -343,6 +343,21 @@ def main():
         extras["fused_k5"] = leg(ops_mixed, fuse=5)
         extras["tiled_mode1"] = leg(ops_mixed, tile=1)
         extras["tiled_mode2"] = leg(ops_mixed, tile=2)
+        # the same IEEE-equal sweeps with every segment compiled at run time for that segment (hiprtc; cached): the
+        # first application pays the compilation (reported), the timed repetitions replay cached kernels
+        import ctypes as _C
+
+        from rustqip_amd import _ffi as _F
+
+        def jit_stats():
+            k, ms = _C.c_uint64(), _C.c_double()
+            _F.lib.qip_hip_jit_stats(_C.byref(k), _C.byref(ms))
+            return int(k.value), ms.value
+
+        k0, ms0 = jit_stats()
+        extras["tiled_mode1_jit"] = leg(ops_mixed, tile=1, tile_jit=1)
+        k1, ms1 = jit_stats()
+        extras["tiled_mode1_jit"].update({"segments_compiled": k1 - k0, "compile_ms_once": ms1 - ms0})
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -350,6 +365,10 @@ def main():
                             ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True))):
             extras[cname] = leg(cops, "ops")
             extras[cname]["tile1"] = leg(cops, "ops", tile=1)
+            k0, ms0 = jit_stats()
+            extras[cname]["tile1_jit"] = leg(cops, "ops", tile=1, tile_jit=1)
+            k1, ms1 = jit_stats()
+            extras[cname]["tile1_jit"].update({"segments_compiled": k1 - k0, "compile_ms_once": ms1 - ms0})
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28

@@ -193,12 +193,12 @@ int qip_hip_program_destroy(qip_hip_program* p);
 int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
                        int64_t* step_of_op, uint64_t* n_steps);
 
-/* Host-only: how one pass of a tile sweep lays the lane id over the tile.  pass_bits = the pass's three exchange
- * bits (tile-index space 0..10, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the lane id.
- * The tile is stored in LDS at slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 (QIP_C64) / 5 (QIP_C32); together the two
- * make every pass free of LDS bank conflicts unless it holds both bits of a pair (j, j+S).  Exposed so the claim
- * can be checked without a GPU (tests/test_host_ops.py). */
-int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t* lanepos);
+/* Host-only: how one pass of a tile sweep lays the thread id over the tile.  pass_bits = the pass's three exchange
+ * bits (tile-index space 0..11, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the 9-bit
+ * thread id.  The tile is stored in LDS at slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 (QIP_C64) / 5 (QIP_C32);
+ * together the two make every pass free of LDS bank conflicts unless it holds both bits of a pair (j, j+S).  Exposed
+ * so the claim can be checked without a GPU (tests/test_host_ops.py). */
+int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint64_t* lanepos);
 
 /* Host-only test hook: the complete tile plan of a circuit as a JSON string (owned by the library, valid until
  * the calling thread's next call; NULL on error): the schedule of qip_hip_plan_tiles and, for every multi-gate
@@ -206,6 +206,19 @@ int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t*
  * as they are shipped to k_tile_passes.  tests/test_tile_plan_cpu.py replays it with a numpy model of the kernel
  * and checks the result against the CPU oracle, so the host half of the tile path is covered without a GPU. */
 const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode);
+
+/* Number of index bits of a tile of the LDS-resident multi-gate sweeps (low 6 bits + the free positions). */
+int qip_hip_tile_bits(void);
+
+/* Segment-specialised tile sweeps (option "tile_jit"): how many segment kernels this process has compiled with hiprtc
+ * so far and the time that took (cache misses only; a segment met again costs nothing). */
+int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
+
+/* Host-only test hook: generate AND compile (hiprtc cross-compiles for gfx950 without a device) the run-time source
+ * of every multi-gate step of the circuit's tile schedule.  *first_source (may be NULL) points at the first segment's
+ * source text, owned by the library until the calling thread's next call. */
+int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* segments,
+                           uint64_t* source_bytes, uint64_t* code_bytes, const char** first_source);
 
 /* Options: key is one of
  *   "force_generic"  1 = route every op through the literal gather kernel
@@ -218,10 +231,16 @@ const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, ui
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
  *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into segments of gates (1-qubit gates with any
  *                    controls, dense 2-qubit gates, bit swaps) whose exchanging bits live on index bits 0..5
- *                    plus five free higher bits and applies each segment in ONE sweep
+ *                    plus six free higher bits and applies each segment in ONE sweep
  *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
  *                    (IEEE-equal to the gate-by-gate path);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
+ *   "tile_jit"       1: every tile segment runs as a kernel compiled at run time for that very segment (hiprtc; the
+ *                    gate list becomes constants of the code: no descriptor fetch, no dispatch, no control-mask tests
+ *                    left), cached per process by its source.  Bit-identical to the interpreter (same helpers, same
+ *                    order).  Pays ~0.3-1 s per NEW segment: for circuits that are replayed (programs, variational
+ *                    loops), not for one-shot runs.  0 (default) = the interpreter kernel.
+ *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)
  *   "packed_f32"     1 (default): f32 states are swept as 16-B elements of two amplitudes where possible

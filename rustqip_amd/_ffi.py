@@ -84,8 +84,11 @@ SIGNATURES = {
     "qip_hip_program_is_graph": (_int, [C.c_void_p]),
     "qip_hip_program_destroy": (_int, [C.c_void_p]),
     "qip_hip_plan_tiles": (_int, [_int, _u32, _opp, _u64, _int, C.POINTER(C.c_int64), _u64p]),
-    "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "qip_hip_debug_tile_plan": (_cp, [_int, _u32, _opp, _u64, _int]),
+    "qip_hip_tile_bits": (_int, []),
+    "qip_hip_jit_stats": (_int, [_u64p, _dblp]),
+    "qip_hip_debug_tile_jit": (_int, [_int, _u32, _opp, _u64, _int, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p)]),
     "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
     "qip_hip_kernel_class_count": (_int, []),
     "qip_hip_kernel_class_name": (_cp, [_int]),

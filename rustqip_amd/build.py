@@ -25,7 +25,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+EMBED = os.path.join(HERE, "csrc", "qip_kernels_embed.inc")
+
+
+def write_embed() -> None:
+    """qip_kernels.h as a C++ raw string literal: the library hands it to hiprtc when it compiles a tile segment at run
+    time (option "tile_jit"), so the .so does not depend on the source tree."""
+    with open(DEPS[1]) as f:
+        text = f.read()
+    assert ')QIPKSRC"' not in text
+    body = 'R"QIPKSRC(' + text + ')QIPKSRC"\n'
+    if not os.path.exists(EMBED) or open(EMBED).read() != body:
+        with open(EMBED, "w") as f:
+            f.write(body)
+
+
 def build(force: bool = False) -> str:
+    write_embed()
     if force or needs_build():
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         cmd = [HIPCC, *FLAGS, "-o", OUT, SRC, *LIBS]

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -16,6 +17,8 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <dlfcn.h>
+#include <map>
 #include <string>
 #include <exception>
 #include <new>
@@ -398,7 +401,9 @@ struct qip_hip_state {
   int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
   int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
-  int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default pairs them up, k_swap2)
+  int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
+  int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached)
+  bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
   size_t capture_arena_need = 0;
@@ -627,6 +632,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else if (!strcmp(key, "swap_single")) s->swap_single = value;
+  else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -1294,6 +1300,7 @@ static int launch_sparse_kq(qip_hip_state* s, const Plan& p, const FlatOp& f, am
 
 template <typename T>
 static int apply_op_t(qip_hip_state* s, const qip_op* op) {
+  if (s->jit_prepare) return QIP_OK;  // compiling a program's segment kernels: single ops have nothing to prepare
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   FlatOp f;
   QCHK(flatten_op(s->n, op, false, &f));
@@ -1676,10 +1683,10 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
 // bits 0 / 1 only).  S = 4 for 16-byte amplitudes, 5 for 8-byte ones.  `pb` ascending and distinct.  Returns 0 if
 // the result is not a bijection onto the non-pass bits (cannot happen; the caller refuses to launch).
 // Checked against the LDS banking model of MI355X_MICROARCH.md in tests/test_host_ops.py.
-static uint32_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
+static uint64_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
   auto has = [&](uint32_t t) { return t == pb[0] || t == pb[1] || t == pb[2]; };
-  int pos_of[8];
-  for (int k = 0; k < 8; ++k) pos_of[k] = -1;
+  int pos_of[kTileLaneBits];
+  for (int k = 0; k < kTileLaneBits; ++k) pos_of[k] = -1;
   bool used[kTileBits] = {false};
   std::vector<int> rest_bits;
   for (uint32_t j = 0; j < S; ++j) {
@@ -1696,7 +1703,7 @@ static uint32_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
       rest_bits.push_back((int)j);
     }
   }
-  for (int k = (int)S; k < 8; ++k) rest_bits.push_back(k);
+  for (int k = (int)S; k < kTileLaneBits; ++k) rest_bits.push_back(k);
   std::vector<int> rest_pos;
   for (int t = 0; t < kTileBits; ++t)
     if (!has((uint32_t)t) && !used[t]) rest_pos.push_back(t);
@@ -1710,23 +1717,25 @@ static uint32_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
   std::stable_sort(rest_pos.begin(), rest_pos.end(), [&](int x, int y) { return rank(x) < rank(y); });
   if (rest_bits.size() != rest_pos.size()) return 0;
   for (size_t q = 0; q < rest_bits.size(); ++q) pos_of[rest_bits[q]] = rest_pos[q];
-  uint32_t lanepos = 0, covered = 0;
-  for (int k = 0; k < 8; ++k) {
-    lanepos |= (uint32_t)pos_of[k] << (4 * k);
+  uint64_t lanepos = 0;
+  uint32_t covered = 0;
+  for (int k = 0; k < kTileLaneBits; ++k) {
+    lanepos |= (uint64_t)pos_of[k] << (4 * k);
     covered |= 1u << pos_of[k];
   }
   for (int j = 0; j < 3; ++j) covered |= 1u << pb[j];
-  return covered == (1u << kTileBits) - 1u ? lanepos : 0u;
+  // (all-zero is not a valid assignment: thread-id bits 0 and 1 cannot both sit on tile bit 0)
+  return covered == (1u << kTileBits) - 1u ? lanepos : 0ull;
 }
 
-extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint32_t* lanepos) try {
+extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint64_t* lanepos) try {
   if (!pass_bits || !lanepos) return fail(QIP_ERR_INVALID, "null argument");
   if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   uint32_t pb[3] = {pass_bits[0], pass_bits[1], pass_bits[2]};
   if (!(pb[0] < pb[1] && pb[1] < pb[2] && pb[2] < (uint32_t)kTileBits))
     return fail(QIP_ERR_INVALID, "pass bits must be ascending, distinct and below %d", kTileBits);
   *lanepos = tile_lane_assignment(pb, dtype == QIP_C64 ? 4u : 5u);
-  if (*lanepos == 0u) return fail(QIP_ERR_UNSUPPORTED, "lane-bit assignment is not a bijection (internal error)");
+  if (*lanepos == 0ull) return fail(QIP_ERR_UNSUPPORTED, "lane-bit assignment is not a bijection (internal error)");
   return QIP_OK;
 } QIP_CATCH_ALL
 
@@ -1747,8 +1756,8 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
   // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
   for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < n; ++p)
     if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
-  // tile bits 6, 7 are wave bits (exchange through LDS), 8..10 register bits (free): give the free positions
-  // that are exchange targets least often to the wave bits
+  // the first kTileWaveBits free positions are wave bits at load / store time, the last three are the lane's own
+  // elements: give the free positions that are exchange targets least often to the wave bits
   std::vector<uint32_t> uses(64, 0);
   for (const TileItem* it : seg) {
     if (it->kind == 0) uses[it->t0] += 1;
@@ -1843,7 +1852,7 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
       ps.count = end - first;
       for (int j = 0; j < 3; ++j) ps.pb[j] = b[j];
       ps.lanepos = tile_lane_assignment(ps.pb, S);
-      if (ps.lanepos == 0u) pass_layout_ok = false;  // not a bijection: refuse to launch
+      if (ps.lanepos == 0ull) pass_layout_ok = false;  // not a bijection: refuse to launch
       first = end;
       bits.clear();
     };
@@ -1908,6 +1917,239 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
   return QIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Segment-specialised tile sweeps (option "tile_jit"): the interpreter k_tile_passes spends most of its issue slots
+// on decoding — per gate and per wave ~54 scalar + ~58 vector instructions that only depend on the segment
+// (profiles/r01_tile_pmc.md).  Here the host writes the segment out as straight-line HIP source — the same load /
+// pass / store skeleton, one call of the very same pass_* helper per gate with the gate descriptor as a constexpr
+// value — and compiles it with hiprtc against the embedded qip_kernels.h.  Every op code, bit position, control mask,
+// zero / real / X flag folds away; what is left per gate is its arithmetic, operation for operation what the
+// interpreter executes, so results are bit-identical.  Kernels are cached per process by their source text, so a
+// circuit replayed many times (programs, variational loops with fixed angles) compiles once (~0.3-1 s per segment).
+// ---------------------------------------------------------------------------------------
+static const char kKernelsHeaderSrc[] =
+#include "qip_kernels_embed.inc"
+    ;
+
+struct Hiprtc {
+  void* handle = nullptr;
+  int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*CompileProgram)(void*, int, const char**) = nullptr;
+  int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+  int (*GetProgramLog)(void*, char*) = nullptr;
+  int (*GetCodeSize)(void*, size_t*) = nullptr;
+  int (*GetCode)(void*, char*) = nullptr;
+  int (*DestroyProgram)(void**) = nullptr;
+};
+static Hiprtc g_rtc;
+static int hiprtc_load() {
+  if (g_rtc.handle) return QIP_OK;
+  void* h = nullptr;
+  for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) return fail(QIP_ERR_UNSUPPORTED, "option tile_jit needs libhiprtc: %s", dlerror());
+#define RSYM(field, name)                                                           \
+  do {                                                                              \
+    *(void**)(&g_rtc.field) = dlsym(h, name);                                       \
+    if (!g_rtc.field) return fail(QIP_ERR_UNSUPPORTED, "libhiprtc lacks %s", name); \
+  } while (0)
+  RSYM(CreateProgram, "hiprtcCreateProgram");
+  RSYM(CompileProgram, "hiprtcCompileProgram");
+  RSYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+  RSYM(GetProgramLog, "hiprtcGetProgramLog");
+  RSYM(GetCodeSize, "hiprtcGetCodeSize");
+  RSYM(GetCode, "hiprtcGetCode");
+  RSYM(DestroyProgram, "hiprtcDestroyProgram");
+#undef RSYM
+  g_rtc.handle = h;
+  return QIP_OK;
+}
+
+// source -> code object (host only: works without a device, which is how the CPU tests cover it)
+static int hiprtc_compile(const std::string& src, std::vector<char>* code) {
+  QCHK(hiprtc_load());
+  void* prog = nullptr;
+  const char* hdr_src[1] = {kKernelsHeaderSrc};
+  const char* hdr_name[1] = {"qip_kernels.h"};
+  if (g_rtc.CreateProgram(&prog, src.c_str(), "qip_segment.hip", 1, hdr_src, hdr_name) != 0)
+    return fail(QIP_ERR_DEVICE, "hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const int rc = g_rtc.CompileProgram(prog, 4, opts);
+  if (rc != 0) {
+    size_t n = 0;
+    g_rtc.GetProgramLogSize(prog, &n);
+    std::string log(n + 1, '\0');
+    if (n) g_rtc.GetProgramLog(prog, &log[0]);
+    g_rtc.DestroyProgram(&prog);
+    return fail(QIP_ERR_DEVICE, "hiprtc could not compile a tile segment (%d): %.800s", rc, log.c_str());
+  }
+  size_t sz = 0;
+  g_rtc.GetCodeSize(prog, &sz);
+  code->resize(sz);
+  g_rtc.GetCode(prog, code->data());
+  g_rtc.DestroyProgram(&prog);
+  return QIP_OK;
+}
+
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+};
+static std::map<std::string, JitKernel> g_jit_cache;  // key: device ordinal + source text
+static uint64_t g_jit_compiles = 0;
+static double g_jit_compile_ms = 0;
+
+extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
+  if (kernels_compiled) *kernels_compiled = g_jit_compiles;
+  if (compile_ms) *compile_ms = g_jit_compile_ms;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+template <typename T> static std::string fnum(T v) {
+  char buf[64];
+  if (std::is_same<T, double>::value) snprintf(buf, sizeof buf, "%.17g", (double)v);
+  else snprintf(buf, sizeof buf, "%.9gf", (double)v);
+  std::string r = buf;
+  // a bare integer literal would not be floating point ("1" / "1f")
+  if (std::is_same<T, double>::value && r.find_first_of(".eEn") == std::string::npos) r += ".0";
+  if (!std::is_same<T, double>::value && r.find_first_of(".eEn") == std::string::npos) r.insert(r.size() - 1, ".0");
+  return r;
+}
+
+// The segment as HIP source (see the block comment above).  Mirrors k_tile_passes statement by statement.
+template <typename T>
+static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt) {
+  const char* tname = std::is_same<T, double>::value ? "double" : "float";
+  std::string o;
+  auto L = [&](const std::string& line) { o += line; o += "\n"; };
+  auto U = [](uint64_t v) { return std::to_string(v) + "ull"; };
+  auto amp = [&](amp_t<T> a) { return "{" + fnum<T>(a.x) + ", " + fnum<T>(a.y) + "}"; };
+  const TilePassDesc& d = plan.pd;
+  L("#include \"qip_kernels.h\"");
+  L("using namespace qipk;");
+  L(std::string("typedef ") + tname + " T;");
+  L("typedef amp_t<T> A;");
+  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, ") + (sizeof(T) == 8 ? "5" : "1") + ") void qip_segment(A* __restrict__ st) {");
+  L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
+  L("  A* tile = reinterpret_cast<A*>(tile_raw);");
+  L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
+  L("  const uint32_t tid = threadIdx.x, lane = tid & 63u;");
+  L("  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);");
+  L("  uint64_t wbase = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow;");
+  for (uint32_t j = 0; j < ins.npos; ++j) {  // insert_bits with the positions as literals
+    const std::string p = std::to_string(ins.pos[j]);
+    L("  wbase = ((wbase >> " + p + ") << " + std::to_string(ins.pos[j] + 1) + ") | (wbase & ((1ull << " + p + ") - 1ull));");
+  }
+  if (ins.ormask) L("  wbase |= " + U(ins.ormask) + ";");
+  L("  const uint64_t base = wbase;");
+  for (int j = 0; j < kTileWaveBits; ++j)
+    L("  wbase |= (uint64_t)((wave >> " + std::to_string(j) + ") & 1u) << " + std::to_string(d.hpos[j]) + ";");
+  L("  const uint32_t slot_tid = tile_slot<A>(tid);");
+  auto ub = [&](int u) {
+    uint64_t off = 0;
+    for (int b = 0; b < 3; ++b)
+      if ((u >> b) & 1) off |= 1ull << d.hpos[kTileWaveBits + b];
+    return U(off);
+  };
+  L("  {");
+  L("    A x[8];");
+  for (int u = 0; u < 8; ++u) L("    x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
+  for (int u = 0; u < 8; ++u)
+    L("    tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)] = x[" + std::to_string(u) + "];");
+  L("  }");
+  L("  __syncthreads();");
+  for (uint32_t pi = 0; pi < d.npasses; ++pi) {
+    const TilePass& ps = d.pass[pi];
+    L("  {  // pass " + std::to_string(pi));
+    L("    uint32_t tb = 0;");
+    for (int k = 0; k < kTileLaneBits; ++k)
+      L("    tb |= ((tid >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
+    L("    const uint32_t slot_tb = tile_slot<A>(tb);");
+    std::string cs = "    const uint32_t c[8] = {";
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t c = ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) | ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+      cs += std::to_string(c) + "u" + (i < 7 ? ", " : "};");
+    }
+    L(cs);
+    L("    A e[8];");
+    for (int i = 0; i < 8; ++i) L("    e[" + std::to_string(i) + "] = tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])];");
+    for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+      const TileGate<T>& g = plan.gates[gi];
+      L("    {  // gate " + std::to_string(gi));
+      L("      constexpr TileGate<T> g = {" + std::to_string(g.kind) + "u, " + std::to_string(g.b0) + "u, " + std::to_string(g.b1) + "u, " +
+        std::to_string(g.cmask) + "u, " + std::to_string(g.nz) + "u, " + std::to_string(g.tpos_out) + "u, " + U(g.omask) + ", " +
+        std::to_string(g.op) + "u, " + std::to_string(g.cm_reg) + "u, " + std::to_string(g.cm_lane) + "u, 0u, {" + amp(g.m[0]) + ", " +
+        amp(g.m[1]) + ", " + amp(g.m[2]) + ", " + amp(g.m[3]) + "}};");
+      const std::string lane_args = "g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane";
+      std::string call;
+      switch (g.op) {
+        case TOP_DIAG_UNIFORM:
+          call = "const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0]; if (!(f.x == (T)1 && f.y == (T)0)) pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+          break;
+        case TOP_DIAG_LANE:
+        case TOP_DIAG_LANE_CTL:
+          call = std::string("const bool one = ") + (g.b0 == kTileOutside ? "((base >> g.tpos_out) & 1ull) != 0" : "((tb >> g.b0) & 1u) != 0") +
+                 "; A f = tile_sel(one, g.m[1], g.m[0]); " +
+                 (g.op == TOP_DIAG_LANE_CTL ? "{ const bool lane_ok = (tb & g.cm_lane) == g.cm_lane; f.x = lane_ok ? f.x : (T)1; f.y = lane_ok ? f.y : (T)0; } " : "") +
+                 "pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+          break;
+        case TOP_DIAG_REG0: case TOP_DIAG_REG1: case TOP_DIAG_REG2:
+          call = "pass_diag<T, " + std::to_string(g.op - TOP_DIAG_REG0) + ">(g, e, c, g.cm_reg, " + lane_args + ");";
+          break;
+        case TOP_DENSE0: case TOP_DENSE1: case TOP_DENSE2:
+          call = "pass_dense<T, " + std::to_string(g.op - TOP_DENSE0) + ">(g, e, c, g.cm_reg);";
+          break;
+        case TOP_DENSE_LANE0: case TOP_DENSE_LANE1: case TOP_DENSE_LANE2:
+          call = "pass_dense_lane<T, " + std::to_string(g.op - TOP_DENSE_LANE0) + ">(g, e, c, g.cm_reg, (tb & g.cm_lane) == g.cm_lane);";
+          break;
+        case TOP_DENSE2Q_01: case TOP_DENSE2Q_02: case TOP_DENSE2Q_10: case TOP_DENSE2Q_12: case TOP_DENSE2Q_20: case TOP_DENSE2Q_21: {
+          static const int ja[6] = {0, 0, 1, 1, 2, 2}, jb[6] = {1, 2, 0, 2, 0, 1};
+          std::string m = "const A M[16] = {";
+          for (int e = 0; e < 16; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 15 ? ", " : "}; ");
+          call = m + "pass_dense2<T, " + std::to_string(ja[g.op - TOP_DENSE2Q_01]) + ", " + std::to_string(jb[g.op - TOP_DENSE2Q_01]) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
+          break;
+        }
+        case TOP_SWAP_01: call = "pass_swap<T, 0, 1>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        case TOP_SWAP_02: call = "pass_swap<T, 0, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        case TOP_SWAP_12: call = "pass_swap<T, 1, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        default: break;
+      }
+      if (g.omask) L("      if ((base & g.omask) == g.omask) { " + call + " }");  // an outside control is 0 for this whole tile
+      else L("      { " + call + " }");
+      L("    }");
+    }
+    for (int i = 0; i < 8; ++i) L("    tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])] = e[" + std::to_string(i) + "];");
+    L("    __syncthreads();");
+    L("  }");
+  }
+  for (int u = 0; u < 8; ++u)
+    L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+  L("}");
+  return o;
+}
+
+static int jit_get_kernel(qip_hip_state* s, const std::string& src, hipFunction_t* fn) {
+  const std::string key = std::to_string(s->device) + "\n" + src;
+  auto it = g_jit_cache.find(key);
+  if (it != g_jit_cache.end()) {
+    *fn = it->second.fn;
+    return QIP_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<char> code;
+  QCHK(hiprtc_compile(src, &code));
+  JitKernel k;
+  HIPCHK(hipModuleLoadData(&k.module, code.data()));
+  HIPCHK(hipModuleGetFunction(&k.fn, k.module, "qip_segment"));
+  g_jit_compiles += 1;
+  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  g_jit_cache[key] = k;
+  *fn = k.fn;
+  return QIP_OK;
+}
+
 template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
                                std::vector<uint32_t> high_in) {
@@ -1943,9 +2185,23 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
     return QIP_OK;
   };
+  if (s->tile_passes && s->tile_jit) {
+    // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
+    hipFunction_t fn = nullptr;
+    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s)), &fn));
+    if (s->jit_prepare) return QIP_OK;
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    void* st_ptr = s->cur;
+    void* args[] = {&st_ptr};
+    const dim3 grid = grid2d(ntiles, 1);
+    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+    if (s->profile) QCHK(prof_end(s, &rec));
+    return QIP_OK;
+  }
+  if (s->jit_prepare) return QIP_OK;
   if (s->tile_passes) {
     QCHK(begin());
-#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream, \
+#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats)
     if (use_nt(s)) TP(true);
     else TP(false);
@@ -2092,7 +2348,7 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         js += "{\"first\":" + std::to_string(ps.first) + ",\"count\":" + std::to_string(ps.count) + ",\"pb\":[" +
               std::to_string(ps.pb[0]) + "," + std::to_string(ps.pb[1]) + "," + std::to_string(ps.pb[2]) +
               "],\"lanepos\":[";
-        for (int k = 0; k < 8; ++k) js += (k ? "," : "") + std::to_string((ps.lanepos >> (4 * k)) & 15u);
+        for (int k = 0; k < kTileLaneBits; ++k) js += (k ? "," : "") + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull));
         js += "]}";
       }
       js += "],\"gates\":[";
@@ -2133,6 +2389,50 @@ extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_
     return nullptr;
   }
 }
+
+// Host-only test hook: the run-time-compiled source of every multi-gate step of a circuit's tile schedule, each
+// compiled with hiprtc (no device needed: hiprtc cross-compiles for gfx950).  Returns the number of segments compiled
+// and the total source / code size through the out parameters; `first_source` (may be NULL) receives a pointer to the
+// first segment's source text (owned by the library, valid until the calling thread's next call).
+template <typename T>
+static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* nseg, uint64_t* src_bytes,
+                       uint64_t* code_bytes, std::string* first) {
+  std::vector<TileItem> items;
+  std::vector<TileStep> steps;
+  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
+  *nseg = *src_bytes = *code_bytes = 0;
+  for (const TileStep& st : steps) {
+    if (st.ops.size() < 2) continue;
+    std::vector<const TileItem*> seg;
+    for (uint64_t i : st.ops) seg.push_back(&items[i]);
+    TileSegmentPlan<T> plan;
+    QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+    Ins ins = make_ins(plan.high, 0);
+    const std::string src = tile_jit_source<T>(plan, ins, true);
+    std::vector<char> code;
+    QCHK(hiprtc_compile(src, &code));
+    if (*nseg == 0 && first) *first = src;
+    *nseg += 1;
+    *src_bytes += src.size();
+    *code_bytes += code.size();
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* segments,
+                                      uint64_t* source_bytes, uint64_t* code_bytes, const char** first_source) try {
+  static thread_local std::string first;
+  if ((count && !ops) || !segments || !source_bytes || !code_bytes) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
+  first.clear();
+  QCHK(dtype == QIP_C64 ? debug_jit_t<double>(dtype, n, ops, count, mode, segments, source_bytes, code_bytes, &first)
+                        : debug_jit_t<float>(dtype, n, ops, count, mode, segments, source_bytes, code_bytes, &first));
+  if (first_source) *first_source = first.c_str();
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
 template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
@@ -2219,6 +2519,12 @@ static int program_capture(qip_hip_program* p) {
     const uint32_t k = f.n_op;
     const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (f64 && s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
+  }
+  if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now
+    s->jit_prepare = true;
+    const int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
+    s->jit_prepare = false;
+    QCHK(rc);
   }
   for (int attempt = 0; attempt < 3; ++attempt) {
     s->capture_arena_need = 0;

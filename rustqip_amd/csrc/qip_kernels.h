@@ -15,8 +15,16 @@
 // round exactly as the reference's unfused num-complex arithmetic does).
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+// run-time compilation (hiprtc: segment-specialised tile sweeps, see tile_passes_body): no system headers there
+typedef __hip_internal::uint32_t uint32_t;
+typedef __hip_internal::uint64_t uint64_t;
+typedef __hip_internal::int32_t int32_t;
+typedef __hip_internal::int64_t int64_t;
+#endif
 
 namespace qipk {
 
@@ -827,7 +835,13 @@ __global__ void k_sparse_kq(amp_t<T>* __restrict__ st, uint64_t ngroups, Ins ins
 // 6.4 ms for a sweep of its own, so the scheduler lets a segment grow to kTileMaxGates.
 constexpr int kTileLow = 6;                        // contiguous low bits (one wave row)
 constexpr int kTileHigh = 5;                       // free bit positions per segment
-constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile
+constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile (32 KiB for f64)
+constexpr int kTileLaneBits = kTileBits - 3;       // k_tile_passes: thread-id bits (a lane holds 2^3 elements)
+constexpr int kTileBlock = 1 << kTileLaneBits;     // ... 256 lanes = 4 waves per tile
+constexpr int kTileWaveBits = kTileLaneBits - kTileLow;  // tile bits 6.. that the wave id fills at load / store time
+// (Measured in round 2: kTileHigh = 6 — 64-KiB tiles, 512 lanes, 2 blocks per CU — cuts the configs[1] circuit from 19
+// to 15 sweeps but each sweep takes 11.8 ms instead of 6.8: 177 vs 129 ms.  Five resident blocks per CU are what
+// overlaps the load / LDS / store phases; profiles/r02_tile_variants.md.)
 constexpr int kTileMaxGates = 64;  // a gate riding along costs ~0.2 ms at n = 30, a new sweep 6.4 ms
 
 // Only the bits a gate EXCHANGES amplitudes across must lie inside the tile: the target of a dense gate, the
@@ -980,7 +994,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
 struct TilePass {
   uint32_t first, count;  // gates[first .. first+count)
   uint32_t pb[3];         // the pass's three exchange bits (tile-index space, distinct, ascending)
-  uint32_t lanepos;       // nibble k = tile-index bit filled by bit k of the lane id (the 8 non-pass bits)
+  uint32_t pad_;
+  uint64_t lanepos;       // nibble k = tile-index bit filled by bit k of the thread id (the kTileLaneBits non-pass bits)
 };
 template <typename A> __device__ __forceinline__ uint32_t tile_slot(uint32_t t) {
   constexpr uint32_t S = sizeof(A) == 16 ? 4u : 5u;
@@ -1212,33 +1227,33 @@ __device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
 // (f32 keeps the default: its 16-KiB tiles already allow more, and under the bound hipcc 7.2 spills its tile.)
 template <typename T, bool NT>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
+__global__ __launch_bounds__(kTileBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
                                                                               const TileGate<T>* __restrict__ gates,
                                                                               const amp_t<T>* __restrict__ mats) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
-  constexpr int PER = (1 << kTileBits) / kBlock;
-  static_assert(PER == 8 && kTileLow == 6 && kBlock == 256, "tile index = (u << 8) | (wave << 6) | lane");
+  constexpr int PER = (1 << kTileBits) / kTileBlock;
+  static_assert(PER == 8 && kTileLow == 6, "tile index = (u << kTileLaneBits) | (wave << 6) | lane");
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // everything but the lane id is wave-uniform: tile bits 6, 7 = wave id, bits 8..10 = u
+  // everything but the lane id is wave-uniform: tile bits 6 .. 6 + kTileWaveBits - 1 = wave id, the top three = u
   uint64_t wbase = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
   const uint64_t base = wbase;
-  wbase |= (uint64_t)(wave & 1u) << d.hpos[0];
-  wbase |= (uint64_t)((wave >> 1) & 1u) << d.hpos[1];
+#pragma unroll
+  for (int j = 0; j < kTileWaveBits; ++j) wbase |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
   const uint32_t slot_tid = tile_slot<A>(tid);
   {
     A x[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[2]) | ((uint64_t)((u >> 1) & 1) << d.hpos[3]) |
-                          ((uint64_t)((u >> 2) & 1) << d.hpos[4]);
+      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
+                          ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
       x[u] = ldg<NT>(st + ub + lane);
     }
 #pragma unroll
-    for (int u = 0; u < PER; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
+    for (int u = 0; u < PER; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = x[u];
   }
   __syncthreads();
   for (uint32_t pi = 0; pi < d.npasses; ++pi) {
@@ -1246,8 +1261,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
     // this lane's group: the lane id's bits spread over the 8 non-pass tile bits (tb), and the 8 combinations
     // of the pass bits (c[i], wave-uniform); tb and c[i] have no bit in common, so slot(tb | c) = slot(tb) ^ slot(c)
     uint32_t tb = 0;
+    const uint32_t lp_lo = (uint32_t)ps.lanepos, lp_hi = (uint32_t)(ps.lanepos >> 32);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tb |= ((tid >> k) & 1u) << ((ps.lanepos >> (4 * k)) & 15u);
+    for (int k = 0; k < kTileLaneBits; ++k) tb |= ((tid >> k) & 1u) << (((k < 8 ? lp_lo : lp_hi) >> (4 * (k & 7))) & 15u);
     const uint32_t slot_tb = tile_slot<A>(tb);
     uint32_t c[8];
     A e[8];
@@ -1318,9 +1334,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(
   {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[2]) | ((uint64_t)((u >> 1) & 1) << d.hpos[3]) |
-                          ((uint64_t)((u >> 2) & 1) << d.hpos[4]);
-      stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)]);
+      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
+                          ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
+      stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
     }
   }
 }

@@ -251,15 +251,33 @@ def plan_tiles(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64):
     return steps
 
 
+TILE_BITS = int(_ffi.lib.qip_hip_tile_bits())  # kTileBits of csrc/qip_kernels.h: low 6 index bits + the free positions
+TILE_LANE_BITS = TILE_BITS - 3                 # thread-id bits of a tile block (a lane holds 2^3 elements)
+
+
 def tile_lane_assignment(pass_bits, dtype: int = _ffi.QIP_C64):
     """Host-only: for one pass of a tile sweep (its three exchange bits, tile-index space, ascending), the
-    tile-index bit each of the 8 lane-id bits fills (qip_hip_tile_lane_assignment)."""
+    tile-index bit each of the 9 thread-id bits fills (qip_hip_tile_lane_assignment)."""
     pb = (C.c_uint32 * 3)(*pass_bits)
-    out = C.c_uint32()
+    out = C.c_uint64()
     rc = _ffi.lib.qip_hip_tile_lane_assignment(dtype, pb, C.byref(out))
     if rc != _ffi.QIP_OK:
         raise CircuitError(_ffi.last_error())
-    return [(out.value >> (4 * k)) & 15 for k in range(8)]
+    return [(out.value >> (4 * k)) & 15 for k in range(TILE_LANE_BITS)]
+
+
+def debug_tile_jit(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64) -> dict:
+    """Host-only test hook (qip_hip_debug_tile_jit): write out and hiprtc-compile the run-time-specialised kernel of
+    every multi-gate tile segment of the circuit (no GPU needed)."""
+    cops = [op.to_c(dtype) for op in ops]
+    arr = (_ffi.QipOp * len(cops))(*cops)
+    nseg, nsrc, ncode = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    first = C.c_char_p()
+    rc = _ffi.lib.qip_hip_debug_tile_jit(dtype, n, arr, len(cops), mode, C.byref(nseg), C.byref(nsrc), C.byref(ncode), C.byref(first))
+    if rc != _ffi.QIP_OK:
+        raise CircuitError(_ffi.last_error())
+    return {"segments": int(nseg.value), "source_bytes": int(nsrc.value), "code_bytes": int(ncode.value),
+            "first_source": (first.value or b"").decode()}
 
 
 def debug_tile_plan(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64) -> dict:

@@ -171,7 +171,7 @@ def test_product_never_imports_oracle():
 def test_tile_schedule_invariants():
     """Host-side scheduling of the LDS-resident multi-gate sweeps (qip_hip_plan_tiles): every op lands in exactly
     one step; an op overtakes only ops it commutes with (on every shared qubit both gates only test it: controls,
-    diagonal targets), in circuit-order mode only when one of the two is rounding-free; a segment claims at most 5
+    diagonal targets), in circuit-order mode only when one of the two is rounding-free; a segment claims at most 6
     free bits for its exchanging gates."""
     from rustqip_amd import circuits
     from rustqip_amd.ops import plan_tiles
@@ -240,7 +240,7 @@ def test_tile_schedule_invariants():
                 free = set()
                 for i in st:
                     free |= {p for p in exchange_bits(ops[i]) if p >= 6}
-                assert len(free) <= 5 and len(st) <= 64
+                assert len(free) <= 6 and len(st) <= 64
                 assert all(len(flatten(ops[i])[2]) <= 2 for i in st)  # 1-qubit gates, swaps, dense 2-qubit gates
         assert [120] in steps  # the dense 3-qubit gate is launched on its own
         assert not [50] in steps  # the dense 2-qubit gate shares a sweep
@@ -254,14 +254,14 @@ def test_tile_schedule_invariants():
 def test_tile_pass_layout_is_a_bijection_and_bank_conflict_free(dtype_name):
     """The LDS layout of the tile sweeps, checked against the banking model of MI355X_MICROARCH.md (section LDS)
     without a GPU: for every choice of three pass bits the lane-bit assignment is a bijection onto the other
-    eight tile bits, and with the XOR-swizzled slot function the pass's reads (ds_read_b128: four 16-lane groups
+    nine tile bits, and with the XOR-swizzled slot function the pass's reads (ds_read_b128: four 16-lane groups
     over 16 slots of 16 B; 8-byte amplitudes: ds_read_b64, two 32-lane groups over 32 slots) and writes
     (ds_write_b128: eight 8-lane groups over 8 slots; ds_write_b64: four 16-lane groups over 16 slots) are
     conflict-free unless the pass holds both bits of a pair (j, j + S) — then exactly 2-way."""
     import itertools
 
     from rustqip_amd import _ffi
-    from rustqip_amd.ops import tile_lane_assignment
+    from rustqip_amd.ops import TILE_BITS, TILE_LANE_BITS, tile_lane_assignment
 
     if dtype_name == "c64":
         dtype, S = _ffi.QIP_C64, 4
@@ -281,21 +281,21 @@ def test_tile_pass_layout_is_a_bijection_and_bank_conflict_free(dtype_name):
 
     def worst(groups, nslots, pos, P):
         w = 1
-        for wave in range(4):
+        for wave in range(1 << (TILE_LANE_BITS - 6)):
             for i in range(8):
                 ibits = sum(((i >> j) & 1) << P[j] for j in range(3))
                 for g in groups:
                     hit = {}
                     for lane in g:
                         tid = wave * 64 + lane
-                        t = ibits | sum(((tid >> k) & 1) << pos[k] for k in range(8))
+                        t = ibits | sum(((tid >> k) & 1) << pos[k] for k in range(TILE_LANE_BITS))
                         hit.setdefault(slot(t) % nslots, set()).add(slot(t))
                     w = max(w, max(len(v) for v in hit.values()))
         return w
 
-    for P in itertools.combinations(range(11), 3):
+    for P in itertools.combinations(range(TILE_BITS), 3):
         pos = tile_lane_assignment(P, dtype)
-        assert sorted(pos + list(P)) == list(range(11)), (P, pos)
+        assert sorted(pos + list(P)) == list(range(TILE_BITS)), (P, pos)
         has_pair = any(b + S in P for b in P)
         r, w = worst(read_groups, read_slots, pos, P), worst(write_groups, write_slots, pos, P)
         if has_pair:

@@ -794,7 +794,7 @@ def test_gate_fusion_matches_gate_by_gate(O, K):
             assert sweeps < len(ops) / 1.5, (name, K, sweeps, len(ops))  # fusion really merged gates
 
 
-@pytest.mark.parametrize("n", [11, 13, 16])
+@pytest.mark.parametrize("n", [12, 13, 16])
 def test_lds_tile_multi_gate_sweeps(O, n):
     """option tile: whole segments of gates applied in one LDS-resident sweep.  tile = 1 keeps the circuit's
     gate order and must be BIT-IDENTICAL to the gate-by-gate path; tile = 2 (commuting reorder) meets 1e-12."""
@@ -852,6 +852,73 @@ def test_lds_tile_multi_gate_sweeps(O, n):
         st.upload(x)
         st.apply_ops(mixed)
         assert np.array_equal(st.download(), want)  # and bit-equal to the oracle itself
+
+
+def test_tile_segments_compiled_at_run_time_are_bit_identical(O):
+    """option tile_jit: each tile segment runs as a kernel compiled for that very segment (hiprtc, cached by source).
+    Same helpers, same order of operations => IEEE-identical to the interpreter kernel, for f64 and f32, eagerly and as a
+    captured program; a segment met again is not compiled again."""
+    import ctypes as C
+
+    from rustqip_amd import _ffi
+
+    def jit_count():
+        k, ms = C.c_uint64(), C.c_double()
+        assert _ffi.lib.qip_hip_jit_stats(C.byref(k), C.byref(ms)) == 0
+        return int(k.value), ms.value
+
+    rng = np.random.default_rng(77)
+    for n, dtype in ((13, np.complex128), (16, np.complex128), (14, np.complex64)):
+        mixed = []
+        for _ in range(80):
+            perm = [int(v) for v in rng.permutation(n)]
+            kind = int(rng.integers(0, 8))
+            if kind == 0:
+                mixed.append(q.make_swap_op([perm[0]], [perm[1]]))
+            elif kind == 1:
+                mixed.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], GATES_1Q["dense"])))
+            elif kind == 2:
+                mixed.append(q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel()))
+            elif kind == 3:
+                mixed.append(q.make_control_op([perm[0]], q.make_swap_op([perm[1]], [perm[2]])))
+            elif kind == 4:
+                mixed.append(q.make_control_op(perm[:1], q.make_matrix_op([perm[1]], [1, 0, 0, cmath.rect(1, 0.7)])))
+            else:
+                mixed.append(q.make_matrix_op([perm[0]], GATES_1Q[["H", "T", "Rz", "X", "Y", "upper", "S"][int(rng.integers(0, 7))]]))
+        for name, ops in (("c2", circuits.h_layer(n) + circuits.c2_random_circuit(n, 150, seed=28)),
+                          ("qft", circuits.c3_qft(n)), ("grover", circuits.c5_grover_iteration(n)), ("mixed", mixed)):
+            x = circuits.random_state(n, seed=n, dtype=dtype)
+            with q.HipState(n, dtype) as st:
+                st.set_option("tile", 1)
+                st.upload(x)
+                st.apply_ops(ops)
+                want = st.download()
+            before = jit_count()[0]
+            with q.HipState(n, dtype) as st:
+                st.set_option("tile", 1)
+                st.set_option("tile_jit", 1)
+                st.upload(x)
+                st.apply_ops(ops)
+                got = st.download()
+                mid = jit_count()[0]
+                st.upload(x)
+                st.apply_ops(ops)  # every segment is in the cache now
+                again = st.download()
+                assert jit_count()[0] == mid
+            assert mid > before, (name, n)
+            assert np.array_equal(got, want) and np.array_equal(again, want), (name, n, dtype)
+        with q.HipState(n, dtype) as st:  # a program: kernels are compiled before the capture, the graph replays them
+            st.set_option("tile", 1)
+            st.set_option("tile_jit", 1)
+            st.upload(x)
+            prog = st.compile_program(mixed)
+            prog.run()
+            assert prog.is_graph
+            with q.HipState(n, dtype) as ref:
+                ref.upload(x)
+                ref.apply_ops(mixed)
+                assert np.array_equal(st.download(), ref.download())
+            prog.close()
 
 
 def test_lds_tile_sweeps_complex64_and_programs(O):

@@ -12,9 +12,10 @@ import pytest
 import rustqip_amd as q
 from oracle import qip_oracle as O
 from rustqip_amd import circuits
-from rustqip_amd.ops import debug_tile_plan
+from rustqip_amd.ops import TILE_BITS, TILE_LANE_BITS, debug_tile_plan
 
-TILE_LOW, TILE_BITS, OUTSIDE = 6, 11, 0xFFFFFFFF
+TILE_LOW, OUTSIDE = 6, 0xFFFFFFFF
+NLANES = 1 << TILE_LANE_BITS
 # enum TileOp (rustqip_amd/csrc/qip_kernels.h)
 DIAG_UNIFORM, DIAG_LANE, DIAG_LANE_CTL, DIAG_REG0 = 0, 1, 2, 3
 DENSE0, DENSE_LANE0, DENSE2Q_FIRST, SWAP_FIRST = 6, 9, 12, 18
@@ -23,7 +24,7 @@ SWAPS = [(0, 1), (0, 2), (1, 2)]
 
 
 def emulate_segment(state, n, seg):
-    """k_tile_passes on a numpy vector: one block per tile, 256 lanes, 8 elements per lane and pass."""
+    """k_tile_passes on a numpy vector: one block per tile, 512 lanes, 8 elements per lane and pass."""
     high = seg["high"]
     tile_pos = list(range(TILE_LOW)) + high
     other = [p for p in range(n) if p not in tile_pos]  # the block index fills these, ascending (insert_bits)
@@ -37,21 +38,21 @@ def emulate_segment(state, n, seg):
     for b, p in enumerate(tile_pos):
         off |= ((t >> np.uint64(b)) & np.uint64(1)) << np.uint64(p)
     idx = (base[:, None] | off[None, :]).astype(np.int64)
-    tile = state[idx]  # (ntiles, 2048): the LDS-resident tile, indexed by tile index
+    tile = state[idx]  # (ntiles, 2^TILE_BITS): the LDS-resident tile, indexed by tile index
     gates = seg["gates"]
     mats = np.array([complex(a, b) for a, b in seg["mats"]], dtype=np.complex128)
-    tid = np.arange(256, dtype=np.int64)
+    tid = np.arange(NLANES, dtype=np.int64)
     seen = 0
     for ps in seg["passes"]:
         pb, lanepos = ps["pb"], ps["lanepos"]
-        assert sorted(pb + lanepos) == list(range(TILE_BITS))  # lane bits + pass bits tile the 11 bits exactly
-        tb = np.zeros(256, dtype=np.int64)
-        for k in range(8):
+        assert sorted(pb + lanepos) == list(range(TILE_BITS))  # lane bits + pass bits tile the tile bits exactly
+        tb = np.zeros(NLANES, dtype=np.int64)
+        for k in range(TILE_LANE_BITS):
             tb |= ((tid >> k) & 1) << lanepos[k]
         c = np.array([sum(((i >> j) & 1) << pb[j] for j in range(3)) for i in range(8)], dtype=np.int64)
-        te = tb[:, None] | c[None, :]  # (256, 8): a bijection onto the 2048 tile indices
+        te = tb[:, None] | c[None, :]  # (lanes, 8): a bijection onto the tile indices
         assert np.array_equal(np.sort(te.ravel()), np.arange(1 << TILE_BITS))
-        e = tile[:, te]  # (ntiles, 256, 8)
+        e = tile[:, te]  # (ntiles, lanes, 8)
         assert ps["first"] == seen
         seen += ps["count"]
         for g in gates[ps["first"]: ps["first"] + ps["count"]]:
@@ -67,10 +68,10 @@ def emulate_segment(state, n, seg):
                 assert g["kind"] == 1 and (op != DIAG_UNIFORM or (g["b0"] == OUTSIDE and g["cm_lane"] == 0))
                 assert (op == DIAG_LANE_CTL) == (g["cm_lane"] != 0) or op == DIAG_UNIFORM
                 if g["b0"] == OUTSIDE:
-                    one = np.broadcast_to((((base >> np.uint64(g["tpos_out"])) & np.uint64(1)) != 0)[:, None], (ntiles, 256))
+                    one = np.broadcast_to((((base >> np.uint64(g["tpos_out"])) & np.uint64(1)) != 0)[:, None], (ntiles, NLANES))
                 else:
                     assert not (passmask >> g["b0"]) & 1
-                    one = np.broadcast_to((((tb >> g["b0"]) & 1) != 0)[None, :], (ntiles, 256))
+                    one = np.broadcast_to((((tb >> g["b0"]) & 1) != 0)[None, :], (ntiles, NLANES))
                 f = np.where(one, m[1], m[0])
                 e = np.where(mask, f[:, :, None] * e, e)
             elif DIAG_REG0 <= op < DIAG_REG0 + 3:
@@ -125,7 +126,7 @@ def replay(n, ops, mode, x, dtype=None):
         if len(step["ops"]) == 1:
             st = O.apply_ops_in_place(n, [ops[step["ops"][0]]], st)
         else:
-            assert len(step["high"]) == 5 and len(set(step["high"])) == 5 and min(step["high"]) >= TILE_LOW
+            assert len(step["high"]) == TILE_BITS - TILE_LOW and len(set(step["high"])) == TILE_BITS - TILE_LOW and min(step["high"]) >= TILE_LOW
             emulate_segment(st, n, step)
         done += step["ops"]
     assert sorted(done) == list(range(len(ops)))
@@ -196,3 +197,36 @@ def test_tile_plan_for_complex64_states():
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.max(np.abs(got - want)) < 1e-5
     assert len(plan["steps"]) < len(ops) / 4
+
+
+def test_run_time_compiled_segments_build_without_a_gpu():
+    """option tile_jit: every multi-gate segment is written out as straight-line HIP source (one pass_* helper call per
+    gate, descriptors as constexpr values) and compiled with hiprtc.  hiprtc cross-compiles for gfx950 without a device,
+    so the generator is exercised here for every gate shape a segment can hold, in both precisions; that the compiled
+    kernels compute the interpreter's results bit for bit is the GPU test's job (tests/test_parity_gpu.py)."""
+    from rustqip_amd import _ffi
+    from rustqip_amd.ops import debug_tile_jit
+
+    n = 13
+    rng = np.random.default_rng(13)
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 60, seed=5) + circuits.c3_qft(n)[:60]
+    for _ in range(40):  # the shapes the circuits above lack: swaps, dense 2-qubit gates, controls of every kind
+        perm = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            ops.append(q.make_swap_op([perm[0]], [perm[1]]))
+        elif kind == 1:
+            a = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+            ops.append(q.make_matrix_op(perm[:2], np.linalg.qr(a)[0].ravel()))
+        elif kind == 2:
+            ops.append(q.make_control_op(perm[:3], q.make_matrix_op([perm[3]], [0.3 + 0.1j, -0.7j, 0.2, 0.9 - 0.4j])))
+        elif kind == 3:
+            ops.append(q.make_control_op([perm[0]], q.make_swap_op([perm[1]], [perm[2]])))
+        else:
+            ops.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], [1, 0, 0, cmath.rect(1, 0.7)])))
+    for dtype in (_ffi.QIP_C64, _ffi.QIP_C32):
+        r = debug_tile_jit(n, ops, 1, dtype)
+        assert r["segments"] >= 3 and r["code_bytes"] > 0
+        src = r["first_source"]
+        assert "constexpr TileGate<T> g" in src and "pass_" in src and "#include \"qip_kernels.h\"" in src
+        assert ("typedef double T;" in src) == (dtype == _ffi.QIP_C64)
