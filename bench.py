@@ -170,16 +170,21 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed):
     b = W.check_circuit(st, n, ops_mixed[:32], O, gate_by_gate=True, seed=12)
     st.set_option("tile", 1)
     c = W.check_circuit(st, n, ops_mixed[32:96], O, gate_by_gate=False, seed=13)
+    st.set_option("tile_jit", 1)  # the same sweeps as run-time-compiled segment kernels
+    cj = W.check_circuit(st, n, ops_mixed[96:160], O, gate_by_gate=False, seed=14, bases_per_step=2)
+    st.set_option("tile_jit", 0)
     st.set_option("tile", 0)
     return {
         "checker": "CPU oracle (oracle/qip_oracle.c apply_op_overwrite + apply_op_row) on closed sub-cubes, oracle/window_parity.py",
         "n": n, "state": "seeded product state, pairwise distinct amplitudes (closed form checked: max rel err %.1e)" % init_err,
-        "gates_checked": a["gates"] + b["gates"] + c["gates"], "gates_skipped": a["skipped"] + b["skipped"] + c["skipped"],
-        "rows_checked": a["rows"] + b["rows"] + c["rows"], "windows": a["windows"] + b["windows"] + c["windows"],
+        "gates_checked": a["gates"] + b["gates"] + c["gates"] + cj["gates"],
+        "gates_skipped": a["skipped"] + b["skipped"] + c["skipped"] + cj["skipped"],
+        "rows_checked": a["rows"] + b["rows"] + c["rows"] + cj["rows"],
+        "windows": a["windows"] + b["windows"] + c["windows"] + cj["windows"],
         "apply_op_row_calls": a["row_calls"] + b["row_calls"],
-        "max_abs_delta": max(a["max_abs_delta"], b["max_abs_delta"], c["max_abs_delta"]),
-        "bit_equal": bool(a["bit_equal"] and b["bit_equal"] and c["bit_equal"]),
-        "legs": {"single_qubit_gate_by_gate": a, "mixed_gate_by_gate": b, "mixed_tile1_chunks": c},
+        "max_abs_delta": max(a["max_abs_delta"], b["max_abs_delta"], c["max_abs_delta"], cj["max_abs_delta"]),
+        "bit_equal": bool(a["bit_equal"] and b["bit_equal"] and c["bit_equal"] and cj["bit_equal"]),
+        "legs": {"single_qubit_gate_by_gate": a, "mixed_gate_by_gate": b, "mixed_tile1_chunks": c, "mixed_tile1_jit_chunks": cj},
         "seconds": round(time.perf_counter() - t0, 2),
     }
 
@@ -242,9 +247,11 @@ def main():
         st = q.HipState(n, np.complex128, device=device)
         if not args.no_parity:
             parity = parity_check(q, circuits, st, n, ops, ops_mixed)
-        else:
+        else:  # same resident state as the checked run (seeded product state), without the oracle comparison
+            from oracle import window_parity as W
+
             st.init_basis(0)
-            st.apply_ops(circuits.h_layer(n))
+            st.apply_ops(W.product_state_ops(n, seed=n)[0])
         compiled = st.compile_ops(ops)
         run_step = lambda: st.apply_compiled(compiled)
         sync = st.sync

@@ -1318,6 +1318,11 @@ def test_full_size_oracle_windows(O, n):
         assert prof.get("k_tile_gates", {}).get("launches", 0) >= 3, prof  # multi-gate sweeps really ran
         assert agg["max_abs_delta"] == 0.0, agg  # only a -0 may differ from the gate-by-gate path
         if n == 30:
+            # the same sweeps as kernels compiled at run time for each segment (option tile_jit): still IEEE-equal
+            st.set_option("tile_jit", 1)
+            agg = W.check_circuit(st, n, c2[136:200], O, gate_by_gate=False, seed=4, bases_per_step=2)
+            st.set_option("tile_jit", 0)
+            assert agg["gates"] == 64 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
             # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
             g = circuits.c5_grover_iteration(n, dense_k3=True)
             agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3, bases_per_step=2)

@@ -40,8 +40,8 @@ def main():
         c = by_cls.setdefault(short(r["Name"]), {"calls": 0, "ns": 0})
         c["calls"] += int(r["Calls"])
         c["ns"] += int(r["TotalDurationNs"])
-    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline`",
-             "(MI355X, n=30, Complex<f64>; the process also runs the 30 H gates that prepare the state and one k_chunk_norms)", "",
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-parity`",
+             "(MI355X, n=30, Complex<f64>; the process also runs the 30 gates that prepare the resident product state and one k_chunk_norms)", "",
              "Per template instantiation (rocprofv3's own table):", "",
              "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
     for r in rows:
@@ -79,6 +79,7 @@ def main():
         if k.startswith("k_"):
             traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib": f, "write_size_kib": w, "launches": len(fetch.get(k, []))}
     open(os.path.join(prof, f"{tag}_pmc_traffic.md"), "w").write("\n".join(lines) + "\n")
+    traffic["_source"] = f"profiles/{tag}_pmc_traffic.md"
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
