@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline steps (profiling passes: no parity check, mixed circuit, extras or CPU baseline)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
 
@@ -191,6 +193,8 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed):
 
 def main():
     args = parse_args()
+    if args.headline_only:
+        args.no_parity = args.no_extras = args.no_cpu_baseline = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -332,7 +336,7 @@ def main():
 
     extras = {}
     mixed = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         mixed = leg(ops_mixed)
         mixed["frac_of_8TBps"] = mixed["algorithmic_GBps"] / HBM_PEAK_GBPS
         mixed["workload"] = "configs[1] generator: 3/4 H/X/Rz + 1/4 CNOT, seed 28, %d gates, n=%d" % (len(ops_mixed), n)

@@ -88,7 +88,7 @@ extern "C" {
         step_of_op: *mut i64, n_steps: *mut u64,
     ) -> c_int;
 
-    pub fn qip_hip_tile_lane_assignment(dtype: c_int, pass_bits: *const u32, lanepos: *mut u32) -> c_int;
+    pub fn qip_hip_tile_lane_assignment(dtype: c_int, pass_bits: *const u32, lanepos: *mut u64) -> c_int;
     pub fn qip_hip_debug_tile_plan(dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int) -> *const c_char;
 
     pub fn qip_hip_state_set_option(s: *mut qip_hip_state, key: *const c_char, value: i64) -> c_int;
@@ -117,4 +117,74 @@ extern "C" {
     pub fn qip_hip_state_measure_state(
         s: *mut qip_hip_state, indices: *const u64, k: u32, measured: u64, prob: c_double,
     ) -> c_int;
+
+    /// `apply_op_row` (matrix_ops.rs:38-59) and the windowed `measure_probs` / `measure_prob`
+    /// (measurement_ops.rs:44-58,115-127: `input_offset`) on host buffers.
+    pub fn qip_hip_apply_op_row_host(
+        dtype: c_int, n: u32, op: *const qip_op, input: *const c_void, in_len: u64,
+        outputrow: u64, in_off: u64, out_off: u64, out_value: *mut c_void,
+    ) -> c_int;
+    pub fn qip_hip_measure_probs_host(
+        dtype: c_int, n: u32, indices: *const u64, k: u32, input: *const c_void, in_len: u64, in_off: u64,
+        out: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_measure_prob_host(
+        dtype: c_int, n: u32, measured: u64, indices: *const u64, k: u32, input: *const c_void, in_len: u64,
+        in_off: u64, out: *mut c_double,
+    ) -> c_int;
+
+    pub fn qip_hip_tile_bits() -> c_int;
+    pub fn qip_hip_jit_stats(kernels_compiled: *mut u64, compile_ms: *mut c_double) -> c_int;
+    pub fn qip_hip_debug_tile_jit(
+        dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int, segments: *mut u64,
+        source_bytes: *mut u64, code_bytes: *mut u64, first_source: *mut *const c_char,
+    ) -> c_int;
+
+    // ---- the state sharded over several GPUs (one process per GPU) ------------------------------------------
+    pub fn qip_hip_dist_unique_id(id_out: *mut c_void) -> c_int; // QIP_HIP_UNIQUE_ID_BYTES = 128
+    pub fn qip_hip_dist_create(
+        n: u32, dtype: c_int, device: c_int, rank: c_int, world: c_int, unique_id: *const c_void,
+        transport: *const qip_hip_transport, out: *mut *mut qip_hip_dist,
+    ) -> c_int;
+    pub fn qip_hip_dist_destroy(d: *mut qip_hip_dist) -> c_int;
+    pub fn qip_hip_dist_init_basis(d: *mut qip_hip_dist, logical_index: u64) -> c_int;
+    pub fn qip_hip_dist_apply_op(d: *mut qip_hip_dist, op: *const qip_op) -> c_int;
+    pub fn qip_hip_dist_apply_ops(d: *mut qip_hip_dist, ops: *const qip_op, count: u64) -> c_int;
+    pub fn qip_hip_dist_sync(d: *mut qip_hip_dist) -> c_int;
+    pub fn qip_hip_dist_set_option(d: *mut qip_hip_dist, key: *const c_char, value: i64) -> c_int;
+    pub fn qip_hip_dist_norm_sqr(d: *mut qip_hip_dist, out: *mut c_double) -> c_int;
+    pub fn qip_hip_dist_measure_probs(d: *mut qip_hip_dist, indices: *const u64, k: u32, out: *mut c_double) -> c_int;
+    pub fn qip_hip_dist_measure(
+        d: *mut qip_hip_dist, indices: *const u64, k: u32, forced: i64, rand_u01: c_double,
+        measured: *mut u64, prob: *mut c_double,
+    ) -> c_int;
+    pub fn qip_hip_dist_local_state(d: *mut qip_hip_dist, shard: *mut *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_dist_layout(d: *mut qip_hip_dist, phys: *mut u32) -> c_int;
+    pub fn qip_hip_dist_take_stats(d: *mut qip_hip_dist, out: *mut qip_hip_dist_stats) -> c_int;
+    pub fn qip_hip_dist_debug_plan(
+        n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64,
+    ) -> *const c_char;
+}
+
+pub const QIP_HIP_UNIQUE_ID_BYTES: usize = 128;
+
+#[repr(C)]
+pub struct qip_hip_dist {
+    _private: [u8; 0],
+}
+/// `struct qip_hip_transport`: NULL selects the built-in RCCL transport.
+#[repr(C)]
+pub struct qip_hip_transport {
+    pub ctx: *mut c_void,
+    pub all_to_all: Option<unsafe extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, *mut c_void) -> c_int>,
+    pub all_reduce_sum: Option<unsafe extern "C" fn(*mut c_void, *mut c_double, u64) -> c_int>,
+}
+#[repr(C)]
+#[derive(Default, Debug, Clone, Copy)]
+pub struct qip_hip_dist_stats {
+    pub remaps: u64,
+    pub pack_sweeps: u64,
+    pub bytes_sent: u64,
+    pub exchange_ms: c_double,
+    pub pack_ms: c_double,
 }

@@ -224,9 +224,10 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *   "force_generic"  1 = route every op through the literal gather kernel
  *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)
  *   "lowbit_shuffle" 1 = cross-lane variant of the 1-qubit kernel for low bit positions (default 1)
- *   "mfma"           1 = f64 matrix-core kernel for dense k = 3..5 gates where it wins (default 1)
+ *   "mfma"           1 = matrix-core kernels: dense k = 3..5 where they win (f64 and f32 forms), k = 6..8 (f64,
+ *                    A operand streamed through LDS); 0 = VALU register kernels (k <= 4) / the literal kernel (default 1)
  *   "fuse"           K >= 2: qip_hip_state_apply_ops merges consecutive gates into dense gates on
- *                    <= K qubits (K <= 5 for f64, 4 for f32) and applies each in one sweep; results
+ *                    <= K qubits (K <= 5) and applies each in one sweep; results
  *                    then match the gate-by-gate path to rounding (1e-12 bar), not bit for bit.
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
  *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into segments of gates (1-qubit gates with any

@@ -1038,7 +1038,8 @@ static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, 
                          int accumulate);
 
 // A operand of k_gate_kq_mfma, one double per (tile row block, K-step, lane); see the kernel header.
-static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out) {
+// f32_layout: the C/D rows of v_mfma_f32_16x16x4_f32 are 4 * (lane >> 4) + reg, those of the f64 form (lane >> 4) + 4 * reg.
+static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out, bool f32_layout = false) {
   const uint32_t k = (uint32_t)p.opos.size();
   const uint32_t S = 1u << k, TT = S / 8, KS = S / 2;
   uint32_t perm_bit[8];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
@@ -1055,7 +1056,7 @@ static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::ve
     for (uint32_t s = 0; s < KS; ++s)
       for (uint32_t l = 0; l < 64; ++l) {
         const uint32_t i = l & 15, kk = l >> 4;
-        const uint32_t qp = i & 3, reg = i >> 2, partp = reg & 1, t = reg >> 1;
+        const uint32_t qp = f32_layout ? i >> 2 : i & 3, reg = f32_layout ? i & 3 : i >> 2, partp = reg & 1, t = reg >> 1;
         const uint32_t ctp = 4 * (2 * rb + t) + qp, ct = 4 * (s >> 1) + kk, part = s & 1;
         const size_t e = (size_t)c_of(ctp) * S + c_of(ct);
         const double re = p.table[2 * e], im = p.table[2 * e + 1];
@@ -1063,13 +1064,15 @@ static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::ve
       }
 }
 
-static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
+template <typename T>
+static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const uint32_t k = (uint32_t)p.opos.size();
   std::vector<uint32_t> tau = p.opos;
   std::sort(tau.begin(), tau.end());
   std::vector<double> afrag;
-  build_afrag(p, tau, &afrag);
-  QCHK(arena_upload(s, afrag.data(), afrag.size() * sizeof(double), 0));
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
   Ins ins = make_ins(pos, mask_of(p.cpos));
@@ -1079,12 +1082,12 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
   const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * 8);  // waves loop over items
   const dim3 grid(blocks), block(kBlock);
-  const double* af = (const double*)s->arena;
+  const T* af = (const T*)s->arena;
   const bool nt = use_nt(s);
 #define MF(K, WU)                                                                                            \
   do {                                                                                                       \
-    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<K, WU, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
-    else hipLaunchKernelGGL((k_gate_kq_mfma<K, WU, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<T, K, WU, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
+    else hipLaunchKernelGGL((k_gate_kq_mfma<T, K, WU, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
   } while (0)
   // WU items per iteration so that WU * 2^k / 4 = 8 loads are in flight per lane (nitems is a power of two)
   switch (k) {
@@ -1145,14 +1148,14 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
     if (t < 6) ++low_targets;
     min_target = std::min(min_target, t);
   }
-  if constexpr (std::is_same<T, double>::value) {
-    // matrix cores: always for k = 5 (no register form), and for k = 3, 4 when two or more targets are
-    // low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
+  {
+    // matrix cores (f64 and f32 forms): always for k = 5 (no register form), and for k = 3, 4 when two or more targets
+    // are low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
     // register form does not (measured at n = 30: profiles/r01_ops_table*.md)
     const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2;  // 2 = force (tuning aid)
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
-      return launch_kq_mfma(s, p, st);
+      return launch_kq_mfma<T>(s, p, st);
     }
   }
   if constexpr (std::is_same<T, double>::value) {
@@ -2458,7 +2461,7 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
                                : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
   if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
-    const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, s->dtype == QIP_C64 ? kMaxMfmaK : kMaxRegK);
+    const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, kMaxMfmaK);  // both precisions have a matrix-core k = 5 kernel
     if (s->n >= K + 4)
       return s->dtype == QIP_C64 ? apply_ops_fused<double>(s, ops, count, K) : apply_ops_fused<float>(s, ops, count, K);
   }
@@ -2517,7 +2520,7 @@ static int program_capture(qip_hip_program* p) {
     QCHK(make_plan(s->dtype, s->n, f, false, &pl));
     const bool f64 = s->dtype == QIP_C64;
     const uint32_t k = f.n_op;
-    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (f64 && s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= (f64 ? kMaxBigK : kMaxMfmaK) && s->n >= f.k_all + 4));
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now

@@ -620,12 +620,24 @@ struct MfmaDesc {
 };
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
-template <int K, int WU, bool NT>
-__global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restrict__ st,
+// one 16x16x4 step in the state's precision.  The f32 form (v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate on gfx950:
+// it is used for the same reason as the f64 one below k = 6 — operand bandwidth and whole-row addressing, not flops —
+// and is an exact f32 fma chain.  Its C/D layout is row = 4 * (lane >> 4) + reg (f64: (lane >> 4) + 4 * reg); the host
+// arranges the A rows accordingly (build_afrag), so both give a lane re and im of the amplitudes it loaded.
+__device__ __forceinline__ v4f64 mfma16(double a, double b, v4f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f32 mfma16(float a, float b, v4f32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <typename T> struct Acc4;
+template <> struct Acc4<double> { using type = v4f64; };
+template <> struct Acc4<float> { using type = v4f32; };
+
+template <typename T, int K, int WU, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<T>* __restrict__ st,
                                                          uint64_t nitems, Ins ins, MfmaDesc d,
-                                                         const double* __restrict__ afrag) {
-  using A = amp_t<double>;
+                                                         const T* __restrict__ afrag) {
+  using A = amp_t<T>;
+  using V4 = typename Acc4<T>::type;
   constexpr int S = 1 << K;
   constexpr int TT = S / 8;   // 16x16 tiles per dimension of the (2S x 2S) real matrix
   constexpr int KS = S / 2;   // K-steps of 4
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
   // A operand in registers for the whole wave lifetime.  (Measured alternative, k = 5 at n = 30: A in
   // LDS with the row-block loop rolled up frees 128 VGPRs but leaves only WU accumulator chains in
   // flight and ran 4.9 vs 5.3 TB/s: the f64 MFMA chain latency, not occupancy, is what has to be hidden.)
-  double a[TT][KS];
+  T a[TT][KS];
 #pragma unroll
   for (int rb = 0; rb < TT; ++rb)
 #pragma unroll
@@ -663,11 +675,9 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<double>* __restri
     for (int i = 0; i < WU; ++i) {
 #pragma unroll
       for (int rb = 0; rb < TT; ++rb) {
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        V4 acc = {(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][s], (s & 1) ? x[i][s >> 1].y : x[i][s >> 1].x,
-                                                     acc, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) acc = mfma16(a[rb][s], (s & 1) ? x[i][s >> 1].y : x[i][s >> 1].x, acc);
         A y0, y1;
         y0.x = acc[0];
         y0.y = acc[1];

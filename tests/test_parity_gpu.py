@@ -467,6 +467,41 @@ def test_dense_big_k_streamed_matrix_core_kernel(O, k):
     assert np.array_equal(hip_apply(n, op, x, mfma=0), oracle_apply(O, n, op, x))  # literal kernel: bit-equal
 
 
+def test_dense_k_qubit_f32_matrix_cores(O):
+    """f32 states: dense k = 3..5 on v_mfma_f32_16x16x4_f32 (exact f32 fma chains; the C/D layout differs from the f64
+    form and the host arranges the A rows for it) — 1e-5 bar vs the f32 oracle, 0/1 permutation matrices exact, k = 5 no
+    longer on the literal kernel."""
+    n = 11
+    rng = np.random.default_rng(55)
+    x = rand_state(n, 5, np.complex64)
+    for k in (3, 4, 5):
+        u = rand_unitary(k, rng).astype(np.complex64)
+        for idx in (list(range(n - k, n)), list(range(k)), [int(v) for v in rng.permutation(n)[:k]], [n - 1, n - 2] + [int(v) for v in rng.permutation(n - 2)[:k - 2]]):
+            op = q.make_matrix_op(idx, u.ravel())
+            want = oracle_apply(O, n, op, x)
+            with q.HipState(n, np.complex64) as st:
+                st.set_option("profile", 1)
+                st.set_option("mfma", 2)  # force the matrix-core form also where the register form would be chosen
+                st.upload(x)
+                st.apply_op(op)
+                got = st.download()
+                assert "k_gate_kq_mfma" in st.profile(), st.profile()
+            assert np.max(np.abs(got - want)) <= TOL32, (k, idx)
+            if k == 5:
+                with q.HipState(n, np.complex64) as st:
+                    st.set_option("profile", 1)
+                    st.upload(x)
+                    st.apply_op(op)
+                    assert "k_gate_kq_mfma" in st.profile()  # the default path for k = 5
+            cop = q.make_control_op([t for t in range(n) if t not in idx][:1], op)
+            assert np.max(np.abs(hip_apply(n, cop, x) - oracle_apply(O, n, cop, x))) <= TOL32
+        perm = rng.permutation(1 << k)
+        pm = np.zeros((1 << k, 1 << k))
+        pm[np.arange(1 << k), perm] = 1
+        op = q.make_matrix_op([int(v) for v in rng.permutation(n)[:k]], pm.ravel())
+        assert np.array_equal(hip_apply(n, op, x, mfma=2), oracle_apply(O, n, op, x))
+
+
 def test_dense_permutations_stay_exact_on_matrix_cores(O):
     """0/1 permutation matrices through the MFMA path: fma(1, x, 0) is exact, so IEEE `==` holds."""
     n = 9

@@ -7,8 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline --no-parity"
-rocprofv3 --kernel-trace --stats -d $O/prof_stats -o $TAG --output-format csv -- $B --steps 3 --warmup 1 --no-extras > $O/bench_prof.json 2> $O/bench_prof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/prof_fetch -o $TAG --output-format csv -- $B --steps 1 --warmup 0 --no-extras > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/prof_write -o $TAG --output-format csv -- $B --steps 1 --warmup 0 --no-extras > $O/pmc_write.json 2> $O/pmc_write.err
+H="python $R/bench.py --headline-only"
+rocprofv3 --kernel-trace --stats -d $O/prof_stats -o $TAG --output-format csv -- $H --steps 3 --warmup 1 > $O/bench_prof.json 2> $O/bench_prof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/prof_fetch -o $TAG --output-format csv -- $H --steps 1 --warmup 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/prof_write -o $TAG --output-format csv -- $H --steps 1 --warmup 0 > $O/pmc_write.json 2> $O/pmc_write.err
 rocprofv3 --kernel-trace --stats -d $O/prof_stats_extras -o $TAG --output-format csv -- $B --steps 2 --warmup 1 > $O/bench_prof_extras.json 2> $O/bench_prof_extras.err
 ls $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_stats_extras

@@ -40,7 +40,7 @@ def main():
         c = by_cls.setdefault(short(r["Name"]), {"calls": 0, "ns": 0})
         c["calls"] += int(r["Calls"])
         c["ns"] += int(r["TotalDurationNs"])
-    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-parity`",
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --headline-only --steps 3 --warmup 1`",
              "(MI355X, n=30, Complex<f64>; the process also runs the 30 gates that prepare the resident product state and one k_chunk_norms)", "",
              "Per template instantiation (rocprofv3's own table):", "",
              "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
