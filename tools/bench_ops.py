@@ -81,6 +81,10 @@ def main():
     ]
     if f32:
         cases = [c for c in cases if "MFMA" not in c[0] and "literal" not in c[0]]
+        cases += [("dense k=3 low bits (matrix cores f32)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {}),
+                  ("dense k=4, 2 low bits (matrix cores f32)", q.make_matrix_op([hi, mid, lo - 1, lo], rand_unitary(4, rng).ravel()), {}),
+                  ("dense k=5 (matrix cores f32)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {}),
+                  ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0})]
         cases += [("H, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.H), {"packed_f32": 0}),
                   ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
     print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")

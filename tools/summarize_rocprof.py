@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn rocprofv3 CSV output (gpurun_out/) into the committed summaries under profiles/.
 
-  python tools/summarize_rocprof.py <round-tag> <stats_dir> <fetch_dir> <write_dir> [bench_json]
+  python tools/summarize_rocprof.py <round-tag> <stats_dir> <fetch_dir> <write_dir> [bench_json] [stats_extras_dir]
 
 * <stats_dir>: `rocprofv3 --kernel-trace --stats` of `bench.py`      -> profiles/<tag>_kernel_stats.csv/.md
 * <fetch_dir>/<write_dir>: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
@@ -56,6 +56,17 @@ def main():
         lines += ["", "bench.py line of the same (profiled) run — HIP-event averages to compare with the table above:", "",
                   "```json", json.dumps({k: b[k] for k in ("value", "ms_per_step", "roofline", "kernels") if k in b}, indent=1), "```"]
     open(os.path.join(prof, f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+
+    if len(sys.argv) > 6:  # the same command with every extras leg: per-instantiation table only
+        ecsv = glob.glob(os.path.join(sys.argv[6], "*kernel_stats.csv"))[0]
+        erows = list(csv.DictReader(open(ecsv)))
+        el = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity` (extras included)",
+              "(tile sweeps: `k_tile_passes` = the interpreter, `qip_segment` = run-time-compiled segments; fusion, QFT, Clifford+T, Grover legs)", "",
+              "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
+        for r in erows:
+            el.append(f"| `{r['Name'].split('(')[0].replace('void ', '')}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | "
+                      f"{int(r['TotalDurationNs'])/1e6:.1f} | {r['Percentage']} |")
+        open(os.path.join(prof, f"{tag}_kernel_stats_with_extras.md"), "w").write("\n".join(el) + "\n")
 
     def load(d, counter):
         out = collections.defaultdict(list)
