@@ -341,9 +341,10 @@ int qip_hip_dist_sync(qip_hip_dist* d);
 int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value);
 
 /* measurement over the whole vector (measurement_ops.rs:11-13, 115-127, 190-269): local reductions + one all-reduce;
- * `measure` collapses every shard with the GLOBAL probability.  Sampling (forced < 0) draws the outcome from the
- * marginal distribution of the measured qubits with rank 0's rand_u01, walking outcomes in increasing order:
- * statistically soft_measure (:153-176), not its sample -> outcome map (that needs the vector in logical index order). */
+ * `measure` collapses every shard with the GLOBAL probability.  Sampling (forced < 0) is soft_measure (:153-176) over
+ * the whole vector in logical index order with rank 0's rand_u01: the index where the running subtraction crosses zero
+ * is found by descending the index bit by bit (one masked norm + one all-reduce per bit, ~2 sweeps in all), i.e. the
+ * reference's sample -> outcome map up to the rounding of block sums. */
 int qip_hip_dist_norm_sqr(qip_hip_dist* d, double* out);
 int qip_hip_dist_measure_probs(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double* out);
 int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, int64_t forced, double rand_u01,

@@ -82,6 +82,15 @@ def main():
                 ms, ps = st2.measure(idx, rand_u01=0.37 + 0.1 * rank)  # ranks disagree on the sample: rank 0 decides
                 if wp > 0:
                     assert ms == forced and abs(ps - 1) < 1e-12
+            # sampled outcomes follow the reference's soft_measure map over the whole vector (logical index order)
+            for r_u in (0.0137, 0.31, 0.5, 0.77, 0.993):
+                for idx in ([0], [n - 1, 3], [5, 0, n - 2, 7]):
+                    st3 = DistState(n, dist, 0, host_staged=not use_nccl)
+                    st3.upload_global(x)
+                    st3.apply_ops(ops[:30])  # a permuted layout whenever the circuit touched a global qubit
+                    ms, ps = st3.measure(idx, rand_u01=r_u if rank == 0 else 0.123)
+                    wm = O.soft_measure(n, idx, ref, r_u)
+                    assert ms == wm and abs(ps - O.measure_prob(n, wm, idx, ref)) < 1e-12, (name, idx, r_u, ms, wm)
             st.init_basis(5)
             e = np.zeros(1 << n, dtype=np.complex128)
             e[5] = 1

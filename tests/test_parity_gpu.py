@@ -1422,6 +1422,8 @@ def test_bench_multi_rank_code_path_on_one_gpu():
                  "configs1_mixed_n21", "headline_tiled_mode1"):
         assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
     assert abs(ex["norm_sqr_end"] - 1) < 1e-9
+    par = line["parity"]  # the sharded path against the oracle, inside the bench run itself
+    assert "error" not in par and par["world"] == 2 and par["remaps_exercised"] >= 1 and par["max_abs_delta"] <= 1e-12, par
 
 
 def test_circuit_replay_python_and_cpp_cli(O, tmp_path):
