@@ -68,7 +68,7 @@ static int fail(int code, const char* fmt, ...) {
   catch (...) { return fail(QIP_ERR_INVALID, "internal error: unknown C++ exception"); }
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 1; }
+extern "C" int qip_hip_abi_version(void) { return 2; }
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
@@ -327,7 +327,7 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     return QIP_OK;
   }
   std::vector<double> d;
-  if (k <= std::max(kMaxRegK, kMaxMfmaK) || (dtype == QIP_C64 && k <= kMaxBigK)) {
+  if (k <= kMaxBigK) {
     if (dtype == QIP_C64)
       read_dense<double>(f.inner->dense, side * side, &d);
     else
@@ -343,8 +343,8 @@ static int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic,
     }
     return QIP_OK;
   }
-  if (k <= kMaxRegK || k <= kMaxMfmaK || (dtype == QIP_C64 && k <= kMaxBigK)) {
-    // the launcher picks the matrix-core forms for f64 (k in 3..5 / 6..8) when >= 16 groups exist
+  if (k <= kMaxBigK) {
+    // the launcher picks the matrix-core forms (k in 3..5 / 6..8) when >= 16 groups exist
     p->cls = KC_GATE_KQ;
     p->table = d;
     return QIP_OK;
@@ -1101,14 +1101,16 @@ static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   return QIP_OK;
 }
 
-// dense k = 6..8 on the f64 matrix cores, A operand streamed through LDS (k_gate_big_mfma)
-static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
+// dense k = 6..8 on the matrix cores (f64 and f32 forms), A operand streamed through LDS (k_gate_big_mfma)
+template <typename T>
+static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const uint32_t k = (uint32_t)p.opos.size();
   std::vector<uint32_t> tau = p.opos;
   std::sort(tau.begin(), tau.end());
   std::vector<double> afrag;
-  build_afrag(p, tau, &afrag);
-  QCHK(arena_upload(s, afrag.data(), afrag.size() * sizeof(double), 0));
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
   Ins ins = make_ins(pos, mask_of(p.cpos));
@@ -1116,15 +1118,15 @@ static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<double>* st) {
   memset(&d, 0, sizeof d);
   for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
   const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
-  const unsigned per_cu = k <= 7 ? 2u : 1u;  // resident blocks per CU (registers: 2 waves per SIMD up to k = 7; LDS: 128 KiB at k = 8)
+  const unsigned per_cu = k <= 7 ? 2u : 1u;  // resident blocks per CU (registers: 2 waves per SIMD up to k = 7; LDS: 128 KiB at k = 8 in f64)
   const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * per_cu);
   const dim3 grid(blocks), block(kBlock);
-  const double* af = (const double*)s->arena;
+  const T* af = (const T*)s->arena;
   const bool nt = use_nt(s);
-#define BM(K)                                                                                                     \
-  do {                                                                                                            \
-    if (nt) hipLaunchKernelGGL((k_gate_big_mfma<K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
-    else hipLaunchKernelGGL((k_gate_big_mfma<K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);      \
+#define BM(K)                                                                                                        \
+  do {                                                                                                               \
+    if (nt) hipLaunchKernelGGL((k_gate_big_mfma<T, K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+    else hipLaunchKernelGGL((k_gate_big_mfma<T, K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);      \
   } while (0)
   switch (k) {
     case 6: BM(6); break;
@@ -1158,11 +1160,9 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
       return launch_kq_mfma<T>(s, p, st);
     }
   }
-  if constexpr (std::is_same<T, double>::value) {
-    if (s->mfma && k > kMaxMfmaK && k <= kMaxBigK && s->n >= used + 4) {
-      *actual_cls = KC_GATE_KQ_BIG;
-      return launch_big_mfma(s, p, st);
-    }
+  if (s->mfma && k > kMaxMfmaK && k <= kMaxBigK && s->n >= used + 4) {
+    *actual_cls = KC_GATE_KQ_BIG;
+    return launch_big_mfma<T>(s, p, st);
   }
   if (k > kMaxRegK) {  // no register form: literal kernel, out of place
     *actual_cls = KC_GATHER_GENERIC;
@@ -2520,7 +2520,8 @@ static int program_capture(qip_hip_program* p) {
     QCHK(make_plan(s->dtype, s->n, f, false, &pl));
     const bool f64 = s->dtype == QIP_C64;
     const uint32_t k = f.n_op;
-    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= (f64 ? kMaxBigK : kMaxMfmaK) && s->n >= f.k_all + 4));
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
+    (void)f64;
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now

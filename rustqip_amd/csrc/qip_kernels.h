@@ -713,18 +713,20 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<T>* __restrict__ 
 // matrix-core ridge (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 2048 flop / 64 clk * 1024 SIMDs * 2.4 GHz
 // = 78.6 TFLOP/s, ridge 9.8 flop/B at 8 TB/s): these sweeps are bound by the matrix pipe, not by HBM.
 // Two accumulator chains per row block (even / odd K-steps) keep the pipe busy without a second wave on the SIMD.
-template <int K, bool NT>
-__global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<double>* __restrict__ st, uint64_t nitems, Ins ins,
-                                                          MfmaDesc d, const double* __restrict__ afrag) {
-  using A = amp_t<double>;
+template <typename T, int K, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<T>* __restrict__ st, uint64_t nitems, Ins ins,
+                                                          MfmaDesc d, const T* __restrict__ afrag) {
+  using A = amp_t<T>;
+  using V4 = typename Acc4<T>::type;
   constexpr int S = 1 << K;
   constexpr int TT = S / 8;        // 16-row blocks of the (2S x 2S) real matrix
   constexpr int KS = S / 2;        // K-steps of 4
   constexpr int NA = S / 4;        // amplitudes per lane per item
-  constexpr int CH = KS * 64;      // doubles per row-block chunk of A
-  constexpr int PF = CH / (kBlock * 2);  // 16-byte pieces per thread per chunk
-  typedef double v2f64 __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) double lds[2 * CH];  // two chunks: 32 / 64 / 128 KiB (static: no 64-KiB dynamic cap)
+  constexpr int CH = KS * 64;      // values per row-block chunk of A
+  constexpr int PV = 16 / sizeof(T);     // values per 16-byte piece
+  constexpr int PF = CH / (kBlock * PV); // 16-byte pieces per thread per chunk
+  typedef T v2f64 __attribute__((ext_vector_type(16 / sizeof(T))));  // one 16-byte piece of A
+  __shared__ __attribute__((aligned(16))) T lds[2 * CH];  // two chunks: 32 / 64 / 128 KiB in f64 (static: no 64-KiB dynamic cap)
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t j = lane & 15u, q = lane >> 4;
@@ -761,13 +763,13 @@ __global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<double>* __restr
       const int nrb = rb + 1 == TT ? 0 : rb + 1;
       v2f64 pre[PF];
 #pragma unroll
-      for (int p = 0; p < PF; ++p) pre[p] = af2[(size_t)nrb * (CH / 2) + p * kBlock + tid];
-      const double* a = lds + buf * CH + lane;
-      v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      for (int p = 0; p < PF; ++p) pre[p] = af2[(size_t)nrb * (CH / PV) + p * kBlock + tid];
+      const T* a = lds + buf * CH + lane;
+      V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
       for (int s = 0; s < KS; s += 2) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s * 64], x[s >> 1].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(s + 1) * 64], x[s >> 1].y, acc1, 0, 0, 0);
+        acc0 = mfma16(a[s * 64], x[s >> 1].x, acc0);
+        acc1 = mfma16(a[(s + 1) * 64], x[s >> 1].y, acc1);
       }
       if (active) {
         A y0, y1;
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<double>* __restr
         stg<NT>(st + (base | offm(2u * (uint32_t)rb + 1u)), y1);
       }
 #pragma unroll
-      for (int p = 0; p < PF; ++p) lds2[(buf ^ 1u) * (CH / 2) + p * kBlock + tid] = pre[p];
+      for (int p = 0; p < PF; ++p) lds2[(buf ^ 1u) * (CH / PV) + p * kBlock + tid] = pre[p];
       __syncthreads();
       buf ^= 1u;
     }

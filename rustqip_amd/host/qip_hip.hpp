@@ -309,6 +309,88 @@ template <typename P> class HipState {
   qip_hip_state* h_ = nullptr;
 };
 
+// ---- the state sharded over several GPUs: one process per GPU (include/qip_hip.h, qip_hip_dist_*) --------------
+// Rank 0 calls unique_id() and hands the bytes to the other ranks over whatever the launcher offers; every rank then
+// constructs DistState with the same id and issues the same calls in the same order.
+template <typename P> class DistState {
+ public:
+  using C = std::complex<P>;
+  static std::vector<unsigned char> unique_id() {
+    std::vector<unsigned char> id(QIP_HIP_UNIQUE_ID_BYTES);
+    check(qip_hip_dist_unique_id(id.data()));
+    return id;
+  }
+  /// Built-in RCCL transport (`id` from unique_id()).
+  DistState(size_t n, int device, int rank, int world, const std::vector<unsigned char>& id) : n_(n) {
+    check(qip_hip_dist_create((uint32_t)n, dtype_of<P>::value, device, rank, world, id.data(), nullptr, &h_));
+  }
+  /// Caller-supplied transport (tests; hosts that already own a communicator).
+  DistState(size_t n, int device, int rank, int world, const qip_hip_transport& t) : n_(n) {
+    check(qip_hip_dist_create((uint32_t)n, dtype_of<P>::value, device, rank, world, nullptr, &t, &h_));
+  }
+  ~DistState() { qip_hip_dist_destroy(h_); }
+  DistState(const DistState&) = delete;
+  DistState& operator=(const DistState&) = delete;
+
+  void init_basis(size_t logical_index) { check(qip_hip_dist_init_basis(h_, logical_index)); }
+  void apply_op(const MatrixOp<P>& op) {
+    auto c = op.to_c();
+    check(qip_hip_dist_apply_op(h_, &c->op));
+  }
+  void apply_ops(const std::vector<MatrixOp<P>>& ops) {
+    std::vector<std::unique_ptr<typename MatrixOp<P>::CView>> views;
+    std::vector<qip_op> flat;
+    for (const auto& op : ops) {
+      views.push_back(op.to_c());
+      flat.push_back(views.back()->op);
+    }
+    check(qip_hip_dist_apply_ops(h_, flat.data(), flat.size()));
+  }
+  void set_option(const char* key, int64_t value) { check(qip_hip_dist_set_option(h_, key, value)); }
+  void sync() { check(qip_hip_dist_sync(h_)); }
+  double norm_sqr() {
+    double v = 0;
+    check(qip_hip_dist_norm_sqr(h_, &v));
+    return v;
+  }
+  std::vector<double> measure_probs(const std::vector<size_t>& indices) {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    std::vector<double> out(size_t(1) << idx.size());
+    check(qip_hip_dist_measure_probs(h_, idx.data(), (uint32_t)idx.size(), out.data()));
+    return out;
+  }
+  std::pair<size_t, double> measure(const std::vector<size_t>& indices, int64_t forced, double rand_u01) {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    uint64_t m = 0;
+    double p = 0;
+    check(qip_hip_dist_measure(h_, idx.data(), (uint32_t)idx.size(), forced, rand_u01, &m, &p));
+    return {size_t(m), p};
+  }
+  /// phys[p] = physical bit position of logical bit position p (= n-1-qubit)
+  std::vector<uint32_t> layout() {
+    std::vector<uint32_t> phys(n_);
+    check(qip_hip_dist_layout(h_, phys.data()));
+    return phys;
+  }
+  /// this rank's amplitudes, in local (physical) order
+  std::vector<C> download_shard(size_t n_local) {
+    qip_hip_state* sh = nullptr;
+    check(qip_hip_dist_local_state(h_, &sh));
+    std::vector<C> out(size_t(1) << n_local);
+    check(qip_hip_state_download(sh, out.data(), 0, out.size()));
+    return out;
+  }
+  qip_hip_dist_stats take_stats() {
+    qip_hip_dist_stats st;
+    check(qip_hip_dist_take_stats(h_, &st));
+    return st;
+  }
+
+ private:
+  size_t n_;
+  qip_hip_dist* h_ = nullptr;
+};
+
 // ---- LocalBuilder<P>'s recording and run loop (qip/src/builder.rs:325-519) ----------------------------
 struct Register {
   std::vector<size_t> indices;

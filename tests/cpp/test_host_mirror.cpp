@@ -170,6 +170,31 @@ static void gpu_checks() {
     std::vector<C> in(4), out(4);
     qip::apply_op<double>(2, Op::new_matrix({2}, from_reals({0, 1, 1, 0})), in, out, 0, 0);
   }, "out of range"));
+  {
+    // the sharded state through the C ABI with the built-in RCCL transport, world = 1 (unique id, communicator,
+    // all-reduce; more ranks need more GPUs): same circuit as a plain HipState, same amplitudes
+    const size_t n = 10;
+    const double s = std::sqrt(0.5);
+    std::vector<Op> ops;
+    for (size_t t = 0; t < n; ++t) ops.push_back(Op::new_matrix({t}, from_reals({s, s, s, -s})));
+    ops.push_back(Op::new_control({0}, {9}, Op::new_matrix({9}, from_reals({0, 1, 1, 0}))));
+    ops.push_back(Op::new_swap({1, 2}, {8, 7}));
+    qip::HipState<double> ref(n);
+    ref.init_basis(5);
+    ref.apply_ops(ops);
+    qip::DistState<double> ds(n, 0, 0, 1, qip::DistState<double>::unique_id());
+    ds.init_basis(5);
+    ds.apply_ops(ops);
+    const auto a = ref.download(), b = ds.download_shard(n);
+    double maxd = 0;
+    for (size_t i = 0; i < a.size(); ++i) maxd = std::max(maxd, std::abs(a[i] - b[i]));
+    EXPECT(maxd == 0.0);
+    EXPECT(std::abs(ds.norm_sqr() - 1.0) < 1e-12);
+    const auto pr = ds.measure_probs({0, 9}), pw = ref.measure_probs({0, 9});
+    for (int m = 0; m < 4; ++m) EXPECT(std::abs(pr[m] - pw[m]) < 1e-13);
+    EXPECT(ds.layout().size() == n && ds.take_stats().remaps == 0);
+    std::printf("sharded state (world 1, RCCL transport): max|delta| vs single-GPU state = %.1e\n", maxd);
+  }
 }
 
 int main(int argc, char** argv) {

@@ -465,6 +465,17 @@ def test_dense_big_k_streamed_matrix_core_kernel(O, k):
     assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x))
     op = q.make_matrix_op(list(range(k)), u.ravel())
     assert np.array_equal(hip_apply(n, op, x, mfma=0), oracle_apply(O, n, op, x))  # literal kernel: bit-equal
+    # the f32 form of the same kernel (v_mfma_f32_16x16x4_f32)
+    xf = rand_state(n, 4, np.complex64)
+    for idx in (list(range(n - k, n)), [int(v) for v in rng.permutation(n)[:k]]):
+        opf = q.make_matrix_op(idx, u.astype(np.complex64).ravel())
+        with q.HipState(n, np.complex64) as st:
+            st.set_option("profile", 1)
+            st.upload(xf)
+            st.apply_op(opf)
+            got = st.download()
+            assert "k_gate_big_mfma" in st.profile()
+        assert np.max(np.abs(got - oracle_apply(O, n, opf, xf))) <= TOL32, (k, idx)
 
 
 def test_dense_k_qubit_f32_matrix_cores(O):
