@@ -79,9 +79,16 @@ extern "C" int qip_hip_device_count(void) try {
 } QIP_CATCH_ALL
 
 static int64_t g_force_generic = 0;
+// Selector bits below this position stay in the grid as a per-lane predicate (whole lines are swept); see kLineBits.
+static uint32_t g_line_bits = qipk::kLineBits;
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "line_bits")) {  // tuning aid (tools/bench_ops.py): 0..3
+    if (value < 0 || value > 3) return fail(QIP_ERR_INVALID, "line_bits must be 0..3");
+    g_line_bits = (uint32_t)value;
     return QIP_OK;
   }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
@@ -795,7 +802,7 @@ static Split split_selectors(const std::vector<uint32_t>& pos, uint64_t ones_mas
   Split sp;
   for (uint32_t p : pos) {
     const uint64_t bit = 1ull << p;
-    if (p < kLineBits) {
+    if (p < g_line_bits) {
       sp.low.mask |= bit;
       sp.low.val |= ones_mask & bit;
     } else {

@@ -368,8 +368,17 @@ def test_measure_probs_many_outcomes(O):
             assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(12, idx, xf))) <= 1e-5
 
 
-def test_selectors_inside_a_cache_line(O):
-    """controls / phase bits at bit positions 0..2 become lane predicates (full-line sweeps)."""
+@pytest.fixture
+def line_bits(request):
+    q.set_global_option("line_bits", request.param)
+    yield request.param
+    q.set_global_option("line_bits", 3)
+
+
+@pytest.mark.parametrize("line_bits", [3, 2, 1, 0], indirect=True)
+def test_selectors_inside_a_cache_line(O, line_bits):
+    """controls / phase bits at bit positions below `line_bits` become lane predicates (full-line sweeps); at or above
+    it they are removed from the grid (only the matching sub-space is swept).  Every threshold is bit-equal."""
     n = 10
     x = rand_state(n, 4)
     low_q = [n - 1, n - 2, n - 3]  # qubits at bit positions 0, 1, 2
