@@ -72,6 +72,7 @@ extern "C" {
     pub fn qip_hip_state_scratch_ptr(s: *mut qip_hip_state, scratch: *mut *mut c_void) -> c_int;
     pub fn qip_hip_state_swap_buffers(s: *mut qip_hip_state) -> c_int;
     pub fn qip_hip_state_sync(s: *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_state_permute_bits(s: *mut qip_hip_state, pi: *const u32) -> c_int;
 
     pub fn qip_hip_state_apply_op(s: *mut qip_hip_state, op: *const qip_op) -> c_int;
     pub fn qip_hip_state_apply_ops(s: *mut qip_hip_state, ops: *const qip_op, count: u64) -> c_int;

@@ -169,6 +169,15 @@ int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch);
 int qip_hip_state_swap_buffers(qip_hip_state* s);
 int qip_hip_state_sync(qip_hip_state* s);
 
+/* Any permutation of the index bits in ONE out-of-place sweep: new[j] = old[src(j)] where bit pi[d] of src(j) is
+ * bit d of j (pi has n entries).  This is what a run of Swap ops composes to (SwapOpIterator,
+ * qip-iterators/src/iterators/qubit_iterators.rs:208-218: every Swap is a product of bit transpositions and moves
+ * amplitudes without arithmetic, so the composition is bit-identical to applying them one by one); the tile scheduler
+ * uses it for runs of swaps (QFT's closing bit reversal) and the multi-GPU remap for its gather.  Uses the scratch buffer. */
+int qip_hip_state_permute_bits(qip_hip_state* s, const uint32_t* pi);
+/* Host-only test hook: the descriptor of that sweep as JSON (tile bit positions, LDS swizzle), NULL on error. */
+const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi, uint32_t row_bits, uint32_t fold_bits);
+
 /* state <- op · state.  Equivalent to apply_op_overwrite(n, op, state, arena, 0, 0)
  * followed by the buffer swap (builder.rs:499,514). */
 int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op);

@@ -77,6 +77,8 @@ SIGNATURES = {
     "qip_hip_state_scratch_ptr": (_int, [_statep, C.POINTER(_vp)]),
     "qip_hip_state_swap_buffers": (_int, [_statep]),
     "qip_hip_state_sync": (_int, [_statep]),
+    "qip_hip_state_permute_bits": (_int, [_statep, C.POINTER(C.c_uint32)]),
+    "qip_hip_debug_permute_plan": (_cp, [_u32, C.POINTER(C.c_uint32), _u32, _u32]),
     "qip_hip_state_apply_op": (_int, [_statep, _opp]),
     "qip_hip_state_apply_ops": (_int, [_statep, _opp, _u64]),
     "qip_hip_program_create": (_int, [_statep, _opp, _u64, C.POINTER(C.c_void_p)]),

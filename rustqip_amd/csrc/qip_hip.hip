@@ -220,12 +220,13 @@ enum KernelClass {
   KC_NOOP,
   KC_SPARSE_KQ,
   KC_GATE_KQ_BIG,
+  KC_PERMUTE,
   KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
     "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_gates",     "k_gather_generic",
-    "noop_identity", "k_sparse_kq", "k_gate_big_mfma"};
+    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
 extern "C" const char* qip_hip_kernel_class_name(int cls) {
@@ -1039,6 +1040,167 @@ static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
   return QIP_OK;
 }
 
+// ---- any permutation of the index bits in one out-of-place sweep (k_permute_bits) ---------------------------------
+// pi[d] = source bit position that destination bit position d takes its value from: out[j] = in[src(j)], bit pi[d] of
+// src(j) = bit d of j.  Pure host code; exported through qip_hip_debug_permute_plan for the CPU tests.
+static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t fold_bits, PermDesc* out) {
+  const uint32_t TB = 2 * R;
+  if (n < TB || TB > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "internal: permutation tile does not fit n = %u", n);
+  PermDesc& d = *out;
+  memset(&d, 0, sizeof d);
+  std::vector<char> in_tile(n, 0);
+  for (uint32_t b = 0; b < R; ++b) in_tile[b] = 1;             // the destination's row bits
+  for (uint32_t b = 0; b < n; ++b)
+    if (pi[b] < R) in_tile[b] = 1;                              // destination bits fed by the source's row bits
+  uint32_t cnt = 0;
+  for (uint32_t b = 0; b < n; ++b) cnt += in_tile[b];
+  for (uint32_t b = 0; b < n && cnt < TB; ++b)                  // pad with the lowest positions left
+    if (!in_tile[b]) {
+      in_tile[b] = 1;
+      ++cnt;
+    }
+  std::vector<uint32_t> tb, sb;
+  for (uint32_t b = 0; b < n; ++b)
+    if (in_tile[b]) {
+      tb.push_back(b);
+      sb.push_back(pi[b]);
+    }
+  std::sort(sb.begin(), sb.end());
+  for (uint32_t i = 0; i < TB; ++i) {
+    d.tbits[i] = tb[i];
+    d.sbits[i] = sb[i];
+  }
+  for (uint32_t i = 0; i < TB; ++i) {  // source coordinate bit i is source position sb[i] = pi[tb[k]] -> tile bit k
+    uint32_t k = 0;
+    while (k < TB && pi[tb[k]] != sb[i]) ++k;
+    if (k == TB) return fail(QIP_ERR_INVALID, "internal: permutation tile is not closed");
+    d.u2c[i] = k;
+  }
+  // LDS swizzle: the source-side lanes of one bank group vary tile bits u2c[0..FB-1], the destination-side lanes tile
+  // bits 0..FB-1; fold every u2c[i] >= FB into a low bit no u2c[j] < FB occupies, so both sides spread over all banks
+  std::vector<char> taken(fold_bits, 0);
+  for (uint32_t i = 0; i < fold_bits; ++i)
+    if (d.u2c[i] < fold_bits) taken[d.u2c[i]] = 1;
+  uint32_t slot = 0;
+  for (uint32_t i = 0; i < fold_bits; ++i) {
+    if (d.u2c[i] < fold_bits) continue;
+    while (taken[slot]) ++slot;
+    taken[slot] = 1;
+    d.fold_from[d.nfold] = d.u2c[i];
+    d.fold_to[d.nfold] = slot;
+    d.nfold += 1;
+  }
+  for (uint32_t b = 0; b < n; ++b)
+    if (!in_tile[b]) {
+      d.outer_dst[d.n_outer] = (unsigned char)b;
+      d.outer_src[d.n_outer] = (unsigned char)pi[b];
+      d.n_outer += 1;
+    }
+  return QIP_OK;
+}
+
+static int check_bit_permutation(uint32_t n, const uint32_t* pi, bool* identity) {
+  uint64_t seen = 0;
+  *identity = true;
+  for (uint32_t b = 0; b < n; ++b) {
+    if (pi[b] >= n || ((seen >> pi[b]) & 1ull)) return fail(QIP_ERR_INVALID, "not a permutation of the %u index bits", n);
+    seen |= 1ull << pi[b];
+    if (pi[b] != b) *identity = false;
+  }
+  return QIP_OK;
+}
+
+// cur -> alt through the permutation, then alt becomes the current buffer (builder.rs:514 analogue)
+static int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
+  bool identity = true;
+  QCHK(check_bit_permutation(s->n, pi_in, &identity));
+  if (identity) return QIP_OK;
+  QCHK(ensure_alt(s));
+  std::vector<uint32_t> pi(pi_in, pi_in + s->n);
+  uint32_t n = s->n;
+  // Complex<f32>: two amplitudes per 16-byte element when index bit 0 stays where it is
+  const bool packed = s->dtype == QIP_C32 && pi[0] == 0 && n >= 2 && s->packed_f32;
+  if (packed) {
+    for (uint32_t b = 0; b + 1 < n; ++b) pi[b] = pi[b + 1] - 1;
+    n -= 1;
+  }
+  const bool wide = s->dtype == QIP_C64 || packed;   // 16-byte elements
+  const uint32_t R = wide ? 5u : 6u, TB = 2 * R;
+  ProfRec rec;
+  if (s->profile) QCHK(prof_begin(s, KC_PERMUTE, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+  const bool nt = use_nt(s);
+  if (n < TB) {
+    PermSmall ps;
+    memset(&ps, 0, sizeof ps);
+    ps.n = n;
+    for (uint32_t b = 0; b < n; ++b) ps.pi[b] = (unsigned char)pi[b];
+    const uint64_t count = 1ull << n;
+    const dim3 grid(grid_for(count, kBlock)), block(kBlock);
+    if (s->dtype == QIP_C64)
+      hipLaunchKernelGGL((k_permute_bits_small<amp_t<double>>), grid, block, 0, s->stream, (const amp_t<double>*)s->cur, (amp_t<double>*)s->alt, count, ps);
+    else if (packed)
+      hipLaunchKernelGGL((k_permute_bits_small<f32x4>), grid, block, 0, s->stream, (const f32x4*)s->cur, (f32x4*)s->alt, count, ps);
+    else
+      hipLaunchKernelGGL((k_permute_bits_small<amp_t<float>>), grid, block, 0, s->stream, (const amp_t<float>*)s->cur, (amp_t<float>*)s->alt, count, ps);
+  } else {
+    PermDesc d;
+    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, &d));
+    const dim3 grid = grid2d(1ull << (n - TB), 1), block(kBlock);
+#define PB(A, RR)                                                                                                        \
+  do {                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_permute_bits<A, RR, true>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);  \
+    else hipLaunchKernelGGL((k_permute_bits<A, RR, false>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);    \
+  } while (0)
+    if (s->dtype == QIP_C64) PB(amp_t<double>, 5);
+    else if (packed) PB(f32x4, 5);
+    else PB(amp_t<float>, 6);
+#undef PB
+  }
+  HIPCHK(hipGetLastError());
+  if (s->profile) QCHK(prof_end(s, &rec));
+  std::swap(s->cur, s->alt);
+  std::swap(s->owns_cur, s->owns_alt);
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_permute_bits(qip_hip_state* s, const uint32_t* pi) try {
+  STATE_ENTER(s);
+  if (!pi) return fail(QIP_ERR_INVALID, "null permutation");
+  return launch_permute(s, pi);
+} QIP_CATCH_ALL
+
+// Host-only: the descriptor k_permute_bits would get, as JSON (tests/test_permute_plan_cpu.py replays the kernel's index
+// arithmetic with numpy: every element lands where out[j] = in[src(j)] says, the LDS slots of a tile are a bijection,
+// and the lanes of a bank group hit distinct banks).
+extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi, uint32_t row_bits, uint32_t fold_bits) {
+  static thread_local std::string json;
+  try {
+    bool identity = true;
+    if (!pi || n == 0 || n > 62) return fail(QIP_ERR_INVALID, "bad argument"), nullptr;
+    if (check_bit_permutation(n, pi, &identity) != QIP_OK) return nullptr;
+    PermDesc d;
+    if (make_perm_desc(n, pi, row_bits, fold_bits, &d) != QIP_OK) return nullptr;
+    const uint32_t TB = 2 * row_bits;
+    auto arr = [&](const char* key, const uint32_t* v, uint32_t cnt) {
+      std::string a = std::string("\"") + key + "\":[";
+      for (uint32_t i = 0; i < cnt; ++i) a += (i ? "," : "") + std::to_string(v[i]);
+      return a + "]";
+    };
+    uint32_t od[64], os[64];
+    for (uint32_t i = 0; i < d.n_outer; ++i) {
+      od[i] = d.outer_dst[i];
+      os[i] = d.outer_src[i];
+    }
+    json = "{\"n\":" + std::to_string(n) + ",\"row_bits\":" + std::to_string(row_bits) + "," + arr("tbits", d.tbits, TB) + "," +
+           arr("sbits", d.sbits, TB) + "," + arr("u2c", d.u2c, TB) + "," + arr("fold_from", d.fold_from, d.nfold) + "," +
+           arr("fold_to", d.fold_to, d.nfold) + "," + arr("outer_dst", od, d.n_outer) + "," + arr("outer_src", os, d.n_outer) + "}";
+    return json.c_str();
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  }
+}
+
 template <typename T>
 static int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_t in_len,
                          amp_t<T>* out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
@@ -1616,6 +1778,9 @@ struct TileItem {
   // bits), `d_mask` = it only tests the bit (controls, diagonal targets).  Two gates commute when on every bit
   // they share both only test it.  Ops that are not tileable count every bit as exchanged.
   uint64_t nd_mask = 0, d_mask = 0;
+  // an uncontrolled Swap(h) (any h): its h transpositions as pairs of bit positions.  A run of such ops composes to ONE
+  // permutation of the index bits (launch_permute)
+  std::vector<std::pair<uint32_t, uint32_t>> swap_pairs;
 };
 
 static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it) {
@@ -1628,8 +1793,11 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
   for (uint32_t c : p.cpos) it->pos.push_back(c);
   for (uint32_t t : p.opos) it->pos.push_back(t);
   it->cpos = p.cpos;
+  it->swap_pairs.clear();
   if (!f.distinct) return QIP_OK;
   const uint32_t k = (uint32_t)p.opos.size();
+  if (p.cls == KC_SWAP_BITS && p.cpos.empty())
+    for (uint32_t j = 0; j < k / 2; ++j) it->swap_pairs.push_back({p.opos[j], p.opos[k / 2 + j]});
   auto unit_axis = [](double re, double im) {  // 0, +-1 or +-i
     return (re == 0.0 && (im == 0.0 || im == 1.0 || im == -1.0)) || (im == 0.0 && (re == 1.0 || re == -1.0));
   };
@@ -2235,13 +2403,16 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
 struct TileStep {
   std::vector<uint64_t> ops;   // indices into the circuit, in application order
   std::vector<uint32_t> high;  // the free bit positions the segment claimed (<= kTileHigh)
+  std::vector<uint32_t> perm;  // non-empty: the ops are a run of uncontrolled Swap ops applied as ONE bit-permutation
+                               // sweep, new[j] = old[src(j)], bit perm[d] of src(j) = bit d of j (launch_permute)
 };
 
 // Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
 // qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it commutes with (on every
 // shared bit both only test it); without `reorder` only when it, or every op it overtakes, is rounding-free.
 static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
-                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps, bool allow_2q = true) {
+                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps, bool allow_2q = true,
+                          bool allow_permute = true) {
   std::vector<TileItem>& items = *items_out;
   items.assign(count, TileItem());
   for (uint64_t i = 0; i < count; ++i) {
@@ -2260,8 +2431,39 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       ++head;
       continue;
     }
+    // A run of uncontrolled Swap ops that one segment cannot hold (more than kTileHigh of the moved positions lie above
+    // the tile's fixed low bits — QFT's closing bit reversal is 15 transpositions over all 30 positions) composes to one
+    // permutation of the index bits and goes as ONE out-of-place sweep.  Swaps only move amplitudes, so this is
+    // bit-identical to applying them one by one.  Ops of the run that an earlier segment already hoisted are skipped:
+    // the hoist was only legal because they commute with everything in between.
+    if (allow_permute && !items[head].swap_pairs.empty()) {
+      TileStep run;
+      run.perm.resize(n);
+      for (uint32_t b = 0; b < n; ++b) run.perm[b] = b;
+      uint64_t moved = 0, j = head;
+      for (; j < count; ++j) {
+        if (done[j]) continue;
+        if (items[j].swap_pairs.empty()) break;
+        std::vector<uint32_t> tau(n);
+        for (uint32_t b = 0; b < n; ++b) tau[b] = b;
+        for (const auto& pr : items[j].swap_pairs) {
+          tau[pr.first] = pr.second;
+          tau[pr.second] = pr.first;
+          moved |= (1ull << pr.first) | (1ull << pr.second);
+        }
+        std::vector<uint32_t> next(n);
+        for (uint32_t b = 0; b < n; ++b) next[b] = run.perm[tau[b]];  // out2[j] = out1[tau(j)] = in[pi(tau(j))]
+        run.perm = next;
+        run.ops.push_back(j);
+      }
+      if (run.ops.size() >= 2 && __builtin_popcountll(moved >> kTileLow) > kTileHigh) {
+        for (uint64_t i : run.ops) done[i] = 1;
+        steps->push_back(run);
+        continue;
+      }
+    }
     if (!items[head].tileable) {
-      steps->push_back(TileStep{{head}, {}});
+      steps->push_back(TileStep{{head}, {}, {}});
       done[head++] = 1;
       continue;
     }
@@ -2344,7 +2546,11 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
     js += "{\"ops\":[";
     for (size_t k = 0; k < st.ops.size(); ++k) js += (k ? "," : "") + std::to_string(st.ops[k]);
     js += "]";
-    if (st.ops.size() > 1) {
+    if (!st.perm.empty()) {
+      js += ",\"perm\":[";
+      for (size_t k = 0; k < st.perm.size(); ++k) js += (k ? "," : "") + std::to_string(st.perm[k]);
+      js += "]";
+    } else if (st.ops.size() > 1) {
       std::vector<const TileItem*> seg;
       for (uint64_t i : st.ops) seg.push_back(&items[i]);
       TileSegmentPlan<T> plan;
@@ -2412,7 +2618,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
   QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
   *nseg = *src_bytes = *code_bytes = 0;
   for (const TileStep& st : steps) {
-    if (st.ops.size() < 2) continue;
+    if (st.ops.size() < 2 || !st.perm.empty()) continue;
     std::vector<const TileItem*> seg;
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
     TileSegmentPlan<T> plan;
@@ -2450,6 +2656,11 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, 
   std::vector<TileStep> steps;
   QCHK(schedule_tiles(s->dtype, s->n, ops, count, reorder, &items, &steps, s->tile_passes != 0));
   for (const TileStep& st : steps) {
+    if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
+      if (s->jit_prepare) continue;
+      QCHK(launch_permute(s, st.perm.data()));
+      continue;
+    }
     if (st.ops.size() == 1) {
       QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
       continue;
@@ -2530,6 +2741,13 @@ static int program_capture(qip_hip_program* p) {
     const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
     (void)f64;
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
+  }
+  if (s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too
+    std::vector<TileItem> items;
+    std::vector<TileStep> steps;
+    QCHK(schedule_tiles(s->dtype, s->n, p->ops, p->count, s->tile >= 2, &items, &steps, s->tile_passes != 0));
+    for (const TileStep& st : steps)
+      if (!st.perm.empty()) return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now
     s->jit_prepare = true;

@@ -519,6 +519,94 @@ __global__ __launch_bounds__(kBlock) void k_swapn(E* __restrict__ st, uint64_t n
   }
 }
 
+// ---- any permutation of the index bits in ONE out-of-place sweep ---------------------------------------------------
+// out[j] = in[src(j)] where bit pi[d] of src(j) is bit d of j: the composition of any run of Swap ops (each one a
+// product of bit transpositions, qubit_iterators.rs:208-218; pure moves, so the composition is bit-identical to the
+// ops applied one after the other), the gather of a multi-GPU remap, a qubit relabelling.
+// A block moves a tile of 2^(2R) elements chosen so that BOTH sides stream whole rows of 2^R elements (512 B): the
+// tile's destination bits are the R row bits of the destination plus the R destination bits that are fed by the
+// source's row bits (padded with the next lowest bits when the two sets overlap).  Rows are read in source order,
+// parked in LDS at their destination coordinate and written in destination order.  The LDS slot is the tile coordinate
+// with up to FB of its higher bits XOR-folded into the low FB bits (FB = 3 for 16-byte elements, 4 for 8-byte ones:
+// the lanes of one ds_write / ds_read bank group then hit distinct banks on both sides, MI355X_MICROARCH.md §LDS).
+constexpr int kPermMaxTile = 12;
+struct PermDesc {
+  uint32_t tbits[kPermMaxTile];  // destination positions of the tile bits, ascending (tbits[i] = i for i < R)
+  uint32_t sbits[kPermMaxTile];  // source positions the tile covers, ascending (sbits[i] = i for i < R)
+  uint32_t u2c[kPermMaxTile];    // bit i of the source-side coordinate is bit u2c[i] of the tile (destination) coordinate
+  uint32_t nfold, fold_from[4], fold_to[4];
+  uint32_t n_outer;              // destination positions outside the tile and the source position each one feeds
+  unsigned char outer_dst[64], outer_src[64];
+};
+__device__ __forceinline__ uint32_t perm_fold(uint32_t c, const PermDesc& d) {
+  uint32_t f = 0;
+  for (uint32_t i = 0; i < d.nfold; ++i) f ^= ((c >> d.fold_from[i]) & 1u) << d.fold_to[i];
+  return c ^ f;
+}
+template <typename A, int R, bool NT>
+__global__ __launch_bounds__(kBlock) void k_permute_bits(const A* __restrict__ in, A* __restrict__ out, PermDesc d) {
+  constexpr int TB = 2 * R, E = (1 << TB) / kBlock, EB = TB - 8;  // elements per thread; coordinate bits 8.. come from e
+  __shared__ __attribute__((aligned(16))) A tile[1 << TB];
+  uint64_t dbase = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    const uint32_t p = d.tbits[i];
+    dbase = ((dbase >> p) << (p + 1)) | (dbase & ((1ull << p) - 1ull));
+  }
+  uint64_t sbase = 0;
+  for (uint32_t i = 0; i < d.n_outer; ++i) sbase |= ((dbase >> d.outer_dst[i]) & 1ull) << d.outer_src[i];
+  const uint32_t t = threadIdx.x;
+  // thread part of: source offset, tile coordinate reached from the source side, destination offset
+  uint64_t s_t = t & ((1u << R) - 1u), d_t = t & ((1u << R) - 1u);
+  uint32_t c_t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t bit = (t >> i) & 1u;
+    c_t |= bit << d.u2c[i];
+    if (i >= R) {
+      s_t |= (uint64_t)bit << d.sbits[i];
+      d_t |= (uint64_t)bit << d.tbits[i];
+    }
+  }
+  const uint32_t slot_ld = perm_fold(c_t, d), slot_st = perm_fold(t, d);  // the fold is linear: e's part is XOR-ed in below
+  A x[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    uint64_t s_e = 0;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) s_e |= (uint64_t)((e >> i) & 1) << d.sbits[8 + i];
+    x[e] = ldg<NT>(in + (sbase | s_t | s_e));
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    uint32_t c_e = 0;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) c_e |= (uint32_t)((e >> i) & 1) << d.u2c[8 + i];
+    tile[slot_ld ^ perm_fold(c_e, d)] = x[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    uint64_t d_e = 0;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) d_e |= (uint64_t)((e >> i) & 1) << d.tbits[8 + i];
+    stg<NT>(out + (dbase | d_t | d_e), tile[slot_st ^ perm_fold((uint32_t)e << 8, d)]);
+  }
+}
+// states smaller than one tile: one element per thread, the source index bit by bit
+struct PermSmall {
+  uint32_t n;
+  unsigned char pi[64];
+};
+template <typename A>
+__global__ __launch_bounds__(kBlock) void k_permute_bits_small(const A* __restrict__ in, A* __restrict__ out, uint64_t count, PermSmall d) {
+  const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= count) return;
+  uint64_t src = 0;
+  for (uint32_t b = 0; b < d.n; ++b) src |= ((j >> b) & 1ull) << d.pi[b];
+  out[j] = in[src];
+}
+
 // ---- general diagonal gate on k qubits ------------------------------------------------
 // Amplitude per lane inside the control subspace; factor = diag[sub-index] (table in the arena, served
 // by the caches).  `tpos[j]` is the bit position of op index j (j = 0 is the MSB of the sub-index,

@@ -214,6 +214,13 @@ class HipState:
         _check(_ffi.lib.qip_hip_state_set_option(self._h, key.encode(), int(value)))
 
     # -- gates ---------------------------------------------------------------------------
+    def permute_bits(self, pi) -> None:
+        """new[j] = old[src(j)], bit pi[d] of src(j) = bit d of j: any permutation of the index bits in one sweep"""
+        if len(pi) != self.n:
+            raise CircuitError("the permutation must list all n index bits")
+        arr = (C.c_uint32 * self.n)(*[int(b) for b in pi])
+        _check(_ffi.lib.qip_hip_state_permute_bits(self._h, arr))
+
     def apply_op(self, op: MatrixOp) -> None:
         """state <- op · state  (apply_op_overwrite + swap, builder.rs:499,514)."""
         cop = op.to_c(self.dtype)

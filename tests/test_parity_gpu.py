@@ -1285,6 +1285,118 @@ def test_full_size_qft_and_grover_properties():
             assert abs(st.norm_sqr() - 1) < 1e-10
 
 
+def _permuted(n, pi, x):
+    j = np.arange(1 << n, dtype=np.uint64)
+    src = np.zeros_like(j)
+    for dbit in range(n):
+        src |= ((j >> np.uint64(dbit)) & np.uint64(1)) << np.uint64(pi[dbit])
+    return x[src.astype(np.int64)]
+
+
+def test_bit_permutation_in_one_sweep():
+    """k_permute_bits: new[j] = old[src(j)] for any permutation of the index bits (what a run of Swap ops composes to),
+    IEEE-equal, both precisions (the packed 16-byte view of Complex<f32> when bit 0 stays, 8-byte elements otherwise),
+    states smaller than a tile included."""
+    rng = np.random.default_rng(21)
+    for dtype in (np.complex128, np.complex64):
+        for n in (3, 9, 10, 11, 12, 13, 16, 20):
+            x = rand_state(n, n, dtype)
+            perms = [list(range(n))[::-1], list(range(1, n)) + [0], [n - 1] + list(range(1, n - 1)) + [0]]
+            perms += [[int(v) for v in rng.permutation(n)] for _ in range(4)]
+            perms += [[0] + [1 + int(v) for v in rng.permutation(n - 1)] for _ in range(2)]  # bit 0 fixed: packed f32 view
+            perms += [list(range(n))]  # identity: no launch
+            with q.HipState(n, dtype) as st:
+                for pi in perms:
+                    st.upload(x)
+                    st.permute_bits(pi)
+                    assert np.array_equal(st.download(), _permuted(n, pi, x)), (dtype, n, pi)
+                # a chain of permutations on the resident state (the buffers alternate)
+                st.upload(x)
+                want = x
+                for pi in perms[:5]:
+                    st.permute_bits(pi)
+                    want = _permuted(n, pi, want)
+                assert np.array_equal(st.download(), want)
+                with pytest.raises(q.CircuitError):
+                    st.permute_bits([0] * n if n > 1 else [1])
+
+
+def test_tile_schedule_sends_runs_of_swaps_through_the_permutation_sweep(O):
+    """tile >= 1: QFT's closing bit reversal (and any run of uncontrolled Swap ops no single segment can hold) is ONE
+    out-of-place sweep.  Swaps only move amplitudes, so the state stays IEEE-equal to the gate-by-gate path."""
+    n = 20
+    x = rand_state(n, 5)
+    ops = circuits.c3_qft(n)
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        plain = st.download()
+        assert np.max(np.abs(plain - want)) <= TOL64
+        for opts in ({"tile": 1}, {"tile": 1, "tile_jit": 1}):
+            for k, v in opts.items():
+                st.set_option(k, v)
+            st.upload(x)
+            st.set_option("profile", 1)
+            st.profile_reset()
+            st.apply_ops(ops)
+            prof = st.profile()
+            st.set_option("profile", 0)
+            assert prof["k_permute_bits"]["launches"] == 1, prof
+            assert np.array_equal(st.download(), plain), opts
+        st.set_option("tile_jit", 0)
+        # swaps only: bit reversal + a second run, f32 as well
+        rev = [q.make_swap_op([i], [n - 1 - i]) for i in range(n // 2)] + [q.make_swap_op([0, 3, 5], [19, 7, 11]), q.make_swap_op([2], [9])]
+        st.upload(x)
+        st.apply_ops(rev)
+        assert np.array_equal(st.download(), O.apply_ops_in_place(n, rev, x.copy()))
+        # a program whose schedule holds a permutation sweep stays eager and stays right
+        from rustqip_amd.state import HipProgram
+
+        prog = HipProgram(st, ops)
+        for _ in range(2):
+            st.upload(x)
+            prog.run()
+            assert not prog.is_graph and np.array_equal(st.download(), plain)
+        prog.close()
+    xf = rand_state(n, 6, np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.set_option("tile", 1)
+        st.upload(xf)
+        st.apply_ops(rev)
+        assert np.array_equal(st.download(), O.apply_ops_in_place(n, rev, xf.copy()))
+
+
+def test_full_size_qft_through_tile_sweeps_and_the_permutation_sweep():
+    """configs[2] at n = 28 with tile = 1 (run-time-compiled segments): closed form of QFT|j>, then QFT^-1 back to |j>."""
+    n = 28
+    N = 1 << n
+    j = 0b0110100111000111100001111101
+    qft = circuits.c3_qft(n)
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.set_option("tile_jit", 1)
+        st.init_basis(j)
+        st.apply_ops(qft)
+        for k0 in (0, 3, 54321, N // 2 + 99, N - 4096):
+            got = st.download(k0, 4096)
+            k = np.arange(k0, k0 + 4096, dtype=np.int64)
+            want = np.exp(2j * np.pi * ((j * k) % N).astype(np.float64) / N) / math.sqrt(N)
+            assert np.max(np.abs(got - want)) < 1e-13, k0
+        inverse = []
+        for op in reversed(qft):
+            if op.kind == "Control":
+                inverse.append(q.make_control_op(op.indices[:1], q.make_matrix_op(op.indices[1:], np.conj(op.inner.data))))
+            else:
+                inverse.append(op)
+        st.apply_ops(inverse)  # starts with the run of swaps: one permutation sweep
+        back = st.download(j - 5, 16)
+        expect = np.zeros(16, dtype=np.complex128)
+        expect[5] = 1
+        assert np.max(np.abs(back - expect)) < 1e-10
+        assert abs(st.norm_sqr() - 1) < 1e-10
+
+
 def test_window_compare_at_n24(O):
     """Full-vector compare against the oracle at n = 24 on a prefix of configs[1]."""
     n = 24

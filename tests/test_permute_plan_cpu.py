@@ -1,0 +1,121 @@
+"""The one-sweep bit permutation (k_permute_bits) without a GPU: the host builds the descriptor
+(qip_hip_debug_permute_plan), a numpy restatement of the kernel's index arithmetic replays it.
+
+Checked: every element lands where new[j] = old[src(j)] says; the LDS slots of a tile are a bijection; the lanes of
+one LDS bank group (8 lanes for 16-byte elements, 16 for 8-byte ones) hit distinct banks on the write side and on
+the read side; composing Swap ops into a permutation equals applying them one after the other (the oracle)."""
+import json
+
+import numpy as np
+import pytest
+
+import rustqip_amd as q
+from rustqip_amd import _ffi
+
+
+def plan(n, pi, row_bits, fold_bits):
+    import ctypes as C
+
+    arr = (C.c_uint32 * n)(*pi)
+    txt = _ffi.lib.qip_hip_debug_permute_plan(n, arr, row_bits, fold_bits)
+    assert txt, _ffi.last_error()
+    return json.loads(txt.decode())
+
+
+def spread(v, positions, first=0):
+    """bit (first + i) of v -> position positions[first + i]"""
+    out = np.zeros_like(v, dtype=np.uint64)
+    for i in range(first, len(positions)):
+        out |= ((v >> np.uint64(i)) & np.uint64(1)) << np.uint64(positions[i])
+    return out
+
+
+def fold(c, d):
+    f = np.zeros_like(c)
+    for a, b in zip(d["fold_from"], d["fold_to"]):
+        f ^= ((c >> np.uint64(a)) & np.uint64(1)) << np.uint64(b)
+    return c ^ f
+
+
+def replay(n, d, x):
+    """numpy model of k_permute_bits<A, R>: returns (out, slots of the load side [u], slots of the store side [c])"""
+    R = d["row_bits"]
+    TB = 2 * R
+    nblk = 1 << (n - TB)
+    dbase = np.arange(nblk, dtype=np.uint64)
+    for p in d["tbits"]:
+        low = dbase & np.uint64((1 << p) - 1)
+        dbase = ((dbase >> np.uint64(p)) << np.uint64(p + 1)) | low
+    sbase = np.zeros_like(dbase)
+    for a, b in zip(d["outer_dst"], d["outer_src"]):
+        sbase |= ((dbase >> np.uint64(a)) & np.uint64(1)) << np.uint64(b)
+    u = np.arange(1 << TB, dtype=np.uint64)  # e * 256 + t on the load side, the same range on the store side
+    row = u & np.uint64((1 << R) - 1)
+    s_off = row | spread(u, d["sbits"], R)
+    c_of_u = spread(u, d["u2c"])
+    slot_ld = fold(c_of_u, d)
+    slot_st = fold(u, d)
+    d_off = row | spread(u, d["tbits"], R)
+    out = np.empty_like(x)
+    for b in range(nblk):
+        lds = np.empty(1 << TB, dtype=x.dtype)
+        lds[slot_ld.astype(np.int64)] = x[(sbase[b] | s_off).astype(np.int64)]
+        out[(dbase[b] | d_off).astype(np.int64)] = lds[slot_st.astype(np.int64)]
+    return out, slot_ld, slot_st
+
+
+def want_of(n, pi, x):
+    j = np.arange(1 << n, dtype=np.uint64)
+    src = np.zeros_like(j)
+    for dbit in range(n):
+        src |= ((j >> np.uint64(dbit)) & np.uint64(1)) << np.uint64(pi[dbit])
+    return x[src.astype(np.int64)]
+
+
+@pytest.mark.parametrize("row_bits,fold_bits", [(5, 3), (6, 4)])
+def test_descriptor_replayed_with_numpy(row_bits, fold_bits):
+    rng = np.random.default_rng(7)
+    TB = 2 * row_bits
+    cases = []
+    for n in (TB, TB + 1, TB + 3):
+        cases.append((n, list(range(n))[::-1]))                      # bit reversal (QFT's closing swaps)
+        cases.append((n, [1, 0] + list(range(2, n))))                # inside a row
+        cases.append((n, list(range(1, n)) + [0]))                   # rotation
+        cases.append((n, [n - 1] + list(range(1, n - 1)) + [0]))     # one transposition, lowest <-> highest
+        for _ in range(6):
+            cases.append((n, [int(v) for v in rng.permutation(n)]))
+        # only high bits move: rows stay rows on both sides
+        hi = list(range(row_bits, n))
+        cases.append((n, list(range(row_bits)) + [int(v) for v in rng.permutation(hi)]))
+    group = 8 if fold_bits == 3 else 16
+    for n, pi in cases:
+        d = plan(n, pi, row_bits, fold_bits)
+        assert d["tbits"][:row_bits] == list(range(row_bits)) and d["sbits"][:row_bits] == list(range(row_bits))
+        x = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+        got, slot_ld, slot_st = replay(n, d, x)
+        assert np.array_equal(got, want_of(n, pi, x)), (n, pi)
+        assert len(set(slot_ld.tolist())) == 1 << TB and len(set(slot_st.tolist())) == 1 << TB
+        # banks: consecutive lanes of a bank group -> distinct slots modulo the group size
+        for slots in (slot_ld, slot_st):
+            g = (slots % np.uint64(group)).reshape(-1, group)
+            assert all(len(set(r.tolist())) == group for r in g), (n, pi)
+
+
+def test_run_of_swaps_composes_to_one_permutation():
+    """pi after a run of Swap ops: pi_new[d] = pi_old[tau[d]] (the rule schedule_tiles uses), against the oracle"""
+    from oracle import qip_oracle as O
+
+    n = 11
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    ops = [q.make_swap_op([0], [10]), q.make_swap_op([1, 2], [9, 4]), q.make_swap_op([10], [3]), q.make_swap_op([5, 6, 7], [8, 0, 1])]
+    pi = list(range(n))
+    for op in ops:
+        h = len(op.indices) // 2
+        tau = list(range(n))
+        for a, b in zip(op.indices[:h], op.indices[h:]):
+            pa, pb = n - 1 - a, n - 1 - b
+            tau[pa], tau[pb] = pb, pa
+        pi = [pi[tau[dbit]] for dbit in range(n)]
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.array_equal(want_of(n, pi, x), want)

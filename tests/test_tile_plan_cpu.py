@@ -123,7 +123,14 @@ def replay(n, ops, mode, x, dtype=None):
     st = x.copy()
     done = []
     for step in plan["steps"]:
-        if len(step["ops"]) == 1:
+        if "perm" in step:  # a run of Swap ops as one bit permutation: new[j] = old[src(j)], bit perm[d] of src = bit d of j
+            assert len(step["ops"]) >= 2 and sorted(step["perm"]) == list(range(n))
+            j = np.arange(1 << n, dtype=np.uint64)
+            src = np.zeros_like(j)
+            for dbit, sbit in enumerate(step["perm"]):
+                src |= ((j >> np.uint64(dbit)) & np.uint64(1)) << np.uint64(sbit)
+            st = st[src.astype(np.int64)]
+        elif len(step["ops"]) == 1:
             st = O.apply_ops_in_place(n, [ops[step["ops"][0]]], st)
         else:
             assert len(step["high"]) == TILE_BITS - TILE_LOW and len(set(step["high"])) == TILE_BITS - TILE_LOW and min(step["high"]) >= TILE_LOW
@@ -183,6 +190,40 @@ def test_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.max(np.abs(want))))
     assert len(plan["steps"]) < len(ops)  # gates really share sweeps
+
+
+def test_runs_of_swaps_become_one_permutation_sweep():
+    """QFT's closing bit reversal (n/2 transpositions over every index bit) cannot share a tile segment (a segment holds
+    five free positions): the scheduler composes the run into ONE bit-permutation sweep.  Exact: swaps only move data."""
+    n = 16
+    x = circuits.random_state(n, seed=3)
+    ops = [q.make_swap_op([i], [n - 1 - i]) for i in range(n // 2)] + [q.make_matrix_op([5], circuits.T), q.make_matrix_op([3], circuits.H)]
+    got, plan = replay(n, ops, 1, x)
+    perm_steps = [s for s in plan["steps"] if "perm" in s]
+    assert len(perm_steps) == 1 and len(perm_steps[0]["ops"]) == n // 2 and len(plan["steps"]) == 2
+    assert perm_steps[0]["perm"] == list(range(n))[::-1]
+    assert np.max(np.abs(got - O.apply_ops_in_place(n, ops, x.copy()))) <= 1e-12  # (numpy's complex products round differently)
+    got, plan = replay(n, ops[: n // 2], 1, x)
+    assert len(plan["steps"]) == 1 and np.array_equal(got, O.apply_ops_in_place(n, ops[: n // 2], x.copy()))
+    # inside QFT the segments before the reversal absorb the swaps that fit them; what is left still goes as one sweep
+    n = 20
+    ops = circuits.c3_qft(n)
+    x = circuits.random_state(n, seed=4)
+    got, plan = replay(n, ops, 1, x)
+    assert sum("perm" in s for s in plan["steps"]) == 1
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= 1e-12
+    n = 16
+    x = circuits.random_state(n, seed=3)
+    # a run that fits one segment stays a segment; controlled swaps and runs broken by another gate are left alone
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        perm = [int(v) for v in rng.permutation(n)]
+        ops2 = [q.make_swap_op([perm[0]], [perm[1]]), q.make_swap_op(perm[2:4], perm[4:6]), q.make_swap_op([perm[6], perm[0]], [perm[7], perm[8]]),
+                q.make_matrix_op([perm[9]], circuits.H), q.make_swap_op([perm[1]], [perm[10]]),
+                q.make_control_op([perm[11]], q.make_swap_op([perm[2]], [perm[3]])), q.make_swap_op([perm[12]], [perm[13]])]
+        got2, plan2 = replay(n, ops2, 1 + trial % 2, x)
+        assert np.max(np.abs(got2 - O.apply_ops_in_place(n, ops2, x.copy()))) <= 1e-12, perm
 
 
 def test_tile_plan_for_complex64_states():

@@ -1,6 +1,6 @@
 """Time the LDS-resident multi-gate sweeps (option "tile") on the configured circuits.
 
-    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2] [f32]
+    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2] [f32]      (QIP_TILE_JIT=1: run-time-compiled segments)
 
 Prints one JSON line per (circuit, mode): sweeps launched, ms per run of the circuit, gates/s, and the
 per-sweep HBM rate (each sweep reads and writes the vector once: 32 * 2^n bytes)."""
@@ -51,6 +51,7 @@ def main():
             for mode, passes in [(m, 1) for m in modes]:
                 st.set_option("tile", mode)
                 st.set_option("tile_passes", passes)
+                st.set_option("tile_jit", 1 if os.environ.get("QIP_TILE_JIT") == "1" and mode else 0)
                 cops = st.compile_ops(ops)
                 st.set_option("profile", 1)
                 st.profile_reset()
@@ -70,6 +71,7 @@ def main():
                                   "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64",
                                   "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
+        st.set_option("tile_jit", 0)
 
 
 if __name__ == "__main__":
