@@ -198,7 +198,10 @@ int qip_hip_program_destroy(qip_hip_program* p);
 
 /* The schedule option "tile" would use for this circuit, without touching a device: step_of_op[i] = index of
  * the step op i belongs to; a step holding one op is an ordinary launch, a step holding several is one
- * LDS-resident sweep.  mode 1 = circuit order, 2 = with commuting reorder.  Pure host code. */
+ * LDS-resident sweep (or, for a run of uncontrolled Swap ops no segment can hold, one bit-permutation sweep).
+ * mode bits 0-1: 1 = circuit order, 2 = with commuting reorder; bit 2 (+4): option "tile_relabel" (an uncontrolled Swap
+ * op that became a label exchange gets step -1; the closing permutation is a step of its own); bit 3 (+8): keep the
+ * relabelled plan even when it is not shorter.  Pure host code. */
 int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
                        int64_t* step_of_op, uint64_t* n_steps);
 
@@ -250,6 +253,14 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    left), cached per process by its source.  Bit-identical to the interpreter (same helpers, same
  *                    order).  Pays ~0.3-1 s per NEW segment: for circuits that are replayed (programs, variational
  *                    loops), not for one-shot runs.  0 (default) = the interpreter kernel.
+ *   "tile_relabel"   1: the tile scheduler keeps a logical -> physical map of the qubits: at the end of every segment
+ *                    in-tile bit swaps (riding along in the same sweep) put the qubits whose next amplitude-exchanging use
+ *                    comes soonest on index bits 0..5, so the next segment spends its five free positions on five OTHER
+ *                    qubits; uncontrolled Swap ops become label exchanges (no sweep at all); one bit-permutation sweep at
+ *                    the end restores the order.  Only moves are added and no gate changes its place in the plain schedule's
+ *                    order: bit-identical to "tile" without it.  The plan is only used when it is shorter than the plain
+ *                    one (random circuits: 19 -> 14 sweeps for configs[1]; layered ones like QFT / Grover keep the plain
+ *                    plan).  2 = use it unconditionally (tests).  0 (default) = off.  Needs the scratch buffer.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

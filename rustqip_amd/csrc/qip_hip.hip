@@ -409,6 +409,7 @@ struct qip_hip_state {
   int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
   int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
+  int64_t tile_relabel = 0;  // tile sweeps: the scheduler relabels the qubits (schedule_tiles_relabel)
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
   int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached)
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
@@ -641,6 +642,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "unroll")) s->unroll = value;
   else if (!strcmp(key, "swap_single")) s->swap_single = value;
   else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
+  else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -2511,17 +2513,236 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
   return QIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Qubit relabelling above the tile sweeps (option "tile_relabel"; `mode` bit 2 in the host-only hooks).
+//
+// A tile always holds index bits 0..5 (that is what makes its rows contiguous), so six of its eleven bits are spent on
+// whatever qubits happen to live there.  With a logical -> physical map of the bit positions the scheduler decides who
+// lives there: at the end of every segment the tile's eleven qubits are rearranged — in-tile bit swaps riding along in the
+// same sweep — so that the six whose next amplitude-exchanging use comes soonest sit on positions 0..5 (Belady's rule),
+// and the next segment spends its five free positions on five OTHER qubits.  An uncontrolled Swap op costs nothing at all:
+// it only exchanges two labels.  One bit-permutation sweep at the end puts every qubit back where the caller expects it.
+// Everything added is a pure move of amplitudes and every gate keeps its place in the order of the plain schedule, so the
+// result is bit-identical to tile = 1 / 2 without relabelling (and, for tile = 1, to the gate-by-gate path).
+// configs[1] at n = 30 (256 gates): 19 -> 13 + 1 sweeps; 1024 gates: 70 -> 47 + 1.
+// ---------------------------------------------------------------------------------------
+struct TileSchedule {
+  const qip_op* circuit = nullptr;  // what the steps' op numbers index: the caller's array, or `owned`
+  uint64_t count = 0;
+  std::vector<qip_op> owned;               // relabelled: the caller's ops under the labels in force when they run + inserted swaps
+  std::deque<std::vector<uint64_t>> idx;   // their index lists
+  std::vector<int64_t> origin;             // relabelled: position in the caller's circuit, -1 = inserted swap
+  std::vector<TileItem> items;             // one per entry of `circuit`
+  std::vector<TileStep> steps;
+  uint64_t absorbed = 0, inserted = 0;     // Swap ops turned into label exchanges / in-tile swaps added
+};
+
+static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder, bool allow_2q,
+                                  TileSchedule* out) {
+  std::vector<TileItem> L(count);  // the caller's ops, logical bit positions
+  for (uint64_t i = 0; i < count; ++i) {
+    int rc = classify_tile_item(dtype, n, &ops[i], &L[i]);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+    if (L[i].kind == 3 && !allow_2q) L[i].tileable = false;
+  }
+  std::vector<uint32_t> phys(n);  // phys[p] = physical position of logical bit position p
+  for (uint32_t p = 0; p < n; ++p) phys[p] = p;
+  auto push_op = [&](const qip_op& o, int64_t origin) -> int {
+    out->owned.push_back(o);
+    out->origin.push_back(origin);
+    out->items.emplace_back();
+    int rc = classify_tile_item(dtype, n, &out->owned.back(), &out->items.back());
+    if (rc == QIP_OK && out->items.back().kind == 3 && !allow_2q) out->items.back().tileable = false;
+    return rc;
+  };
+  // the caller's op i under the labels in force now: same descriptor, qubit indices mapped through `phys`
+  auto emit = [&](uint64_t i, uint64_t* at) -> int {
+    qip_op o = ops[i];
+    out->idx.emplace_back(o.n_indices);
+    std::vector<uint64_t>& v = out->idx.back();
+    for (uint32_t j = 0; j < o.n_indices; ++j) v[j] = (uint64_t)(n - 1 - phys[n - 1 - (uint32_t)o.indices[j]]);
+    o.indices = v.data();
+    *at = out->owned.size();
+    return push_op(o, (int64_t)i);
+  };
+  auto emit_swap = [&](uint32_t pa, uint32_t pb, uint64_t* at) -> int {  // physical positions
+    qip_op o;
+    memset(&o, 0, sizeof o);
+    o.kind = QIP_OP_SWAP;
+    o.n_indices = 2;
+    out->idx.emplace_back(std::vector<uint64_t>{(uint64_t)(n - 1 - pa), (uint64_t)(n - 1 - pb)});
+    o.indices = out->idx.back().data();
+    *at = out->owned.size();
+    return push_op(o, -1);
+  };
+  auto absorb = [&](const TileItem& it) {  // an uncontrolled Swap: the two qubits trade places by name
+    for (const auto& pr : it.swap_pairs) std::swap(phys[pr.first], phys[pr.second]);
+    out->absorbed += 1;
+  };
+  std::vector<char> done(count, 0);
+  uint64_t head = 0;
+  const uint64_t window = 256;
+  const size_t max_circuit_ops = (size_t)kTileMaxGates;  // (closing swaps only go into segments with room left)
+  while (head < count) {
+    if (done[head]) {
+      ++head;
+      continue;
+    }
+    if (!L[head].swap_pairs.empty()) {  // everything before it is done; ops hoisted over it share no qubit with it
+      absorb(L[head]);
+      done[head++] = 1;
+      continue;
+    }
+    if (!L[head].tileable) {
+      uint64_t at = 0;
+      QCHK(emit(head, &at));
+      out->steps.push_back(TileStep{{at}, {}, {}});
+      done[head++] = 1;
+      continue;
+    }
+    // the segment: schedule_tiles' rules on the logical masks (commutation does not depend on names), the tile test on
+    // the physical positions
+    TileStep st;
+    uint64_t blocked_nd = 0, blocked_d = 0;
+    bool skipped_inexact = false, any_skipped = false;
+    size_t joined = 0;
+    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && joined < max_circuit_ops; ++i) {
+      if (done[i]) continue;
+      const TileItem& it = L[i];
+      if (!any_skipped && !it.swap_pairs.empty()) {  // in circuit order, nothing pending before it: a label exchange
+        absorb(it);
+        done[i] = 1;
+        continue;
+      }
+      const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact);
+      std::vector<uint32_t> need;
+      if (fits) {
+        std::vector<uint32_t> exch;
+        if (it.kind == 0) exch = {it.t0};
+        if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
+        for (uint32_t p : exch) {
+          const uint32_t pp = phys[p];
+          if (pp >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), pp) == st.high.end() &&
+              std::find(need.begin(), need.end(), pp) == need.end())
+            need.push_back(pp);
+        }
+        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
+      }
+      if (fits) {
+        for (uint32_t pp : need) st.high.push_back(pp);
+        uint64_t at = 0;
+        QCHK(emit(i, &at));
+        st.ops.push_back(at);
+        done[i] = 1;
+        joined += 1;
+      } else {
+        blocked_nd |= it.nd_mask;
+        blocked_d |= it.d_mask;
+        skipped_inexact = skipped_inexact || !it.exact;
+        any_skipped = true;
+      }
+    }
+    // Who should live on positions 0..5 next?  Next amplitude-exchanging use of every qubit (ops not done yet, circuit
+    // order).  First spend the tile's unclaimed free positions on the soonest-needed qubits outside the tile (they can
+    // then be brought down as well), then bring the soonest-needed of the tile's qubits down, evicting the ones needed
+    // last.  A lone gate keeps its own kernel (it touches only what can change): no swaps for it.
+    if (st.ops.size() >= 2) {
+      std::vector<uint64_t> nxt(n, ~0ull);
+      {
+        uint32_t found = 0;
+        for (uint64_t i = head; i < count && found < n; ++i) {
+          if (done[i] || !L[i].tileable) continue;
+          uint64_t m = L[i].nd_mask;
+          while (m) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            if (nxt[p] == ~0ull) {
+              nxt[p] = i;
+              ++found;
+            }
+          }
+        }
+      }
+      auto in_tile = [&](uint32_t pp) { return pp < (uint32_t)kTileLow || std::find(st.high.begin(), st.high.end(), pp) != st.high.end(); };
+      std::vector<uint32_t> by_use;  // logical positions with a future use, soonest first
+      for (uint32_t p = 0; p < n; ++p)
+        if (nxt[p] != ~0ull) by_use.push_back(p);
+      std::stable_sort(by_use.begin(), by_use.end(), [&](uint32_t a, uint32_t b) { return nxt[a] < nxt[b]; });
+      for (uint32_t p : by_use) {
+        if (st.high.size() >= (size_t)kTileHigh) break;
+        if (!in_tile(phys[p])) st.high.push_back(phys[p]);
+      }
+      std::vector<uint32_t> tile_log;
+      for (uint32_t p = 0; p < n; ++p)
+        if (in_tile(phys[p])) tile_log.push_back(p);
+      std::stable_sort(tile_log.begin(), tile_log.end(), [&](uint32_t a, uint32_t b) { return nxt[a] < nxt[b]; });
+      std::vector<uint32_t> bring, evict;
+      for (size_t r = 0; r < tile_log.size(); ++r) {
+        const uint32_t p = tile_log[r];
+        const bool wanted = r < (size_t)kTileLow && nxt[p] != ~0ull;
+        if (wanted && phys[p] >= (uint32_t)kTileLow) bring.push_back(p);
+        if (!wanted && phys[p] < (uint32_t)kTileLow) evict.push_back(p);
+      }
+      std::reverse(evict.begin(), evict.end());  // needed last (or never) goes first
+      for (size_t r = 0; r < bring.size() && r < evict.size() && st.ops.size() < (size_t)kTileMaxGates; ++r) {
+        uint64_t at = 0;
+        QCHK(emit_swap(phys[bring[r]], phys[evict[r]], &at));
+        st.ops.push_back(at);
+        std::swap(phys[bring[r]], phys[evict[r]]);
+        out->inserted += 1;
+      }
+    }
+    out->steps.push_back(st);
+  }
+  // every qubit back to the position the caller expects: final index bit d takes the bit that lives on phys[d] now
+  bool identity = true;
+  for (uint32_t p = 0; p < n; ++p) identity = identity && phys[p] == p;
+  if (!identity) {
+    TileStep back;
+    back.perm = phys;
+    out->steps.push_back(back);
+  }
+  out->circuit = out->owned.data();
+  out->count = out->owned.size();
+  return QIP_OK;
+}
+
+// mode: bits 0-1 = the "tile" option (1 = circuit order, 2 = commuting reorder), bit 2 = relabel the qubits when that
+// shortens the plan, bit 3 = relabel unconditionally
+static int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out) {
+  const bool reorder = (mode & 3) >= 2;
+  if (mode & 4) {
+    // relabelling pays for random circuits; layered ones (Grover's X / H walls, QFT) gain nothing and would only pay the
+    // closing permutation: schedule both ways (host work, microseconds per gate) and keep the shorter plan
+    QCHK(schedule_tiles_relabel(dtype, n, ops, count, reorder, allow_2q, out));
+    TileSchedule plain;
+    QCHK(schedule_tiles(dtype, n, ops, count, reorder, &plain.items, &plain.steps, allow_2q));
+    if (out->steps.size() < plain.steps.size() || (mode & 8)) return QIP_OK;  // bit 3: keep it regardless (tests)
+    *out = TileSchedule();
+  }
+  out->circuit = ops;
+  out->count = count;
+  return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q);
+}
+
 extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
                                   int64_t* step_of_op, uint64_t* n_steps) try {
   if ((count && (!ops || !step_of_op)) || !n_steps) return fail(QIP_ERR_INVALID, "null argument");
   if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
-  std::vector<TileItem> items;
-  std::vector<TileStep> steps;
-  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
-  for (size_t si = 0; si < steps.size(); ++si)
-    for (uint64_t i : steps[si].ops) step_of_op[i] = (int64_t)si;
-  *n_steps = steps.size();
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  for (uint64_t i = 0; i < count; ++i) step_of_op[i] = -1;  // relabelled: an absorbed Swap op belongs to no step
+  for (size_t si = 0; si < sc.steps.size(); ++si)
+    for (uint64_t i : sc.steps[si].ops) {
+      const int64_t o = sc.origin.empty() ? (int64_t)i : sc.origin[i];
+      if (o >= 0) step_of_op[o] = (int64_t)si;
+    }
+  *n_steps = sc.steps.size();
   return QIP_OK;
 } QIP_CATCH_ALL
 
@@ -2530,16 +2751,27 @@ extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint
 // on the CPU with a numpy model of k_tile_passes and compare with the oracle, no GPU involved.
 template <typename T>
 static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, std::string* out) {
-  std::vector<TileItem> items;
-  std::vector<TileStep> steps;
-  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  const std::vector<TileItem>& items = sc.items;
+  const std::vector<TileStep>& steps = sc.steps;
   char buf[256];
   auto num = [&](double v) {
     snprintf(buf, sizeof buf, "%.17g", v);
     return std::string(buf);
   };
   std::string& js = *out;
-  js = "{\"n\":" + std::to_string(n) + ",\"steps\":[";
+  js = "{\"n\":" + std::to_string(n);
+  if (!sc.origin.empty()) {  // relabelled: the circuit the steps index (origin = the caller's op, -1 = inserted swap; qubit indices)
+    js += ",\"absorbed\":" + std::to_string(sc.absorbed) + ",\"inserted\":" + std::to_string(sc.inserted) + ",\"circuit\":[";
+    for (uint64_t i = 0; i < sc.count; ++i) {
+      js += std::string(i ? "," : "") + "{\"o\":" + std::to_string(sc.origin[i]) + ",\"i\":[";
+      for (uint32_t j = 0; j < sc.circuit[i].n_indices; ++j) js += (j ? "," : "") + std::to_string(sc.circuit[i].indices[j]);
+      js += "]}";
+    }
+    js += "]";
+  }
+  js += ",\"steps\":[";
   for (size_t si = 0; si < steps.size(); ++si) {
     const TileStep& st = steps[si];
     if (si) js += ",";
@@ -2613,11 +2845,11 @@ extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_
 template <typename T>
 static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* nseg, uint64_t* src_bytes,
                        uint64_t* code_bytes, std::string* first) {
-  std::vector<TileItem> items;
-  std::vector<TileStep> steps;
-  QCHK(schedule_tiles(dtype, n, ops, count, mode >= 2, &items, &steps));
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  const std::vector<TileItem>& items = sc.items;
   *nseg = *src_bytes = *code_bytes = 0;
-  for (const TileStep& st : steps) {
+  for (const TileStep& st : sc.steps) {
     if (st.ops.size() < 2 || !st.perm.empty()) continue;
     std::vector<const TileItem*> seg;
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
@@ -2650,12 +2882,17 @@ extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, 
 
 extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
+static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
+  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel >= 2 ? 8 : 0);
+}
+
 template <typename T>
-static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops, uint64_t count, bool reorder) {
-  std::vector<TileItem> items;
-  std::vector<TileStep> steps;
-  QCHK(schedule_tiles(s->dtype, s->n, ops, count, reorder, &items, &steps, s->tile_passes != 0));
-  for (const TileStep& st : steps) {
+static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t count, bool /*reorder*/) {
+  TileSchedule sc;
+  QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc));
+  const qip_op* ops = sc.circuit;
+  const std::vector<TileItem>& items = sc.items;
+  for (const TileStep& st : sc.steps) {
     if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
       if (s->jit_prepare) continue;
       QCHK(launch_permute(s, st.perm.data()));
@@ -2743,10 +2980,9 @@ static int program_capture(qip_hip_program* p) {
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }
   if (s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too
-    std::vector<TileItem> items;
-    std::vector<TileStep> steps;
-    QCHK(schedule_tiles(s->dtype, s->n, p->ops, p->count, s->tile >= 2, &items, &steps, s->tile_passes != 0));
-    for (const TileStep& st : steps)
+    TileSchedule sc;
+    QCHK(make_tile_schedule(s->dtype, s->n, p->ops, p->count, tile_mode_of(s), s->tile_passes != 0, &sc));
+    for (const TileStep& st : sc.steps)
       if (!st.perm.empty()) return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now

@@ -247,7 +247,8 @@ def plan_tiles(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64):
         raise CircuitError(_ffi.last_error())
     steps = [[] for _ in range(n_steps.value)]
     for i in range(len(cops)):
-        steps[step_of[i]].append(i)
+        if step_of[i] >= 0:  # mode bit 2 (relabelling): an uncontrolled Swap op became a label exchange, it is in no step
+            steps[step_of[i]].append(i)
     return steps
 
 

@@ -1397,6 +1397,88 @@ def test_full_size_qft_through_tile_sweeps_and_the_permutation_sweep():
         assert abs(st.norm_sqr() - 1) < 1e-10
 
 
+def test_tile_relabel_is_bit_identical(O):
+    """option tile_relabel: the tile scheduler keeps a logical -> physical map of the qubits (soonest-needed qubits on index
+    bits 0..5 through in-tile swaps, Swap ops as label exchanges, one closing bit-permutation sweep).  Only moves are
+    added and no gate changes its place in the plain schedule's order, so the state is IEEE-equal to tile = 1 / 2 without it
+    (and to the gate-by-gate path for tile = 1); interpreter and run-time-compiled segments, both precisions."""
+    rng = np.random.default_rng(77)
+    for n, gates in ((13, 150), (16, 220), (20, 300)):
+        ops = circuits.c2_random_circuit(n, gates, seed=n)
+        ops = ops[: gates // 2] + [q.make_swap_op([1], [n - 2]), q.make_swap_op([0, 2], [n - 1, 5])] + ops[gates // 2:]
+        x = rand_state(n, n)
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        with q.HipState(n) as st:
+            st.upload(x)
+            st.apply_ops(ops)
+            plain = st.download()
+            assert np.max(np.abs(plain - want)) <= TOL64
+            for tile in (1, 2):
+                st.set_option("tile", tile)
+                st.upload(x)
+                st.apply_ops(ops)
+                base = st.download()
+                if tile == 1:
+                    assert np.array_equal(base, plain)
+                for relabel in (1, 2):
+                    for jit in (0, 1):
+                        if jit and n != 16:
+                            continue
+                        st.set_option("tile_relabel", relabel)
+                        st.set_option("tile_jit", jit)
+                        st.upload(x)
+                        st.apply_ops(ops)
+                        got = st.download()
+                        if tile == 1:
+                            assert np.array_equal(got, plain), (n, tile, relabel, jit)
+                        else:  # tile = 2 hoists gates: the relabelled plan may group them differently (1e-12 bar, as tile = 2 itself)
+                            assert np.max(np.abs(got - want)) <= TOL64, (n, tile, relabel, jit)
+                st.set_option("tile_relabel", 0)
+                st.set_option("tile_jit", 0)
+            st.set_option("tile", 0)
+    n = 16
+    ops = circuits.c4_clifford_t(n, 200, seed=9) + circuits.c3_qft(n)[:60]
+    xf = rand_state(n, 3, np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.set_option("tile", 1)
+        st.upload(xf)
+        st.apply_ops(ops)
+        base = st.download()
+        st.set_option("tile_relabel", 2)
+        st.upload(xf)
+        st.apply_ops(ops)
+        assert np.array_equal(st.download(), base)
+    del rng
+
+
+def test_full_size_tile_relabel_saves_sweeps_and_changes_nothing():
+    """configs[1] at n = 28: the relabelled plan needs fewer sweeps (profile) and leaves the very same state, compared
+    on windows of two resident states (bottom, top and places in between)."""
+    n = 28
+    N = 1 << n
+    ops = circuits.c2_random_circuit(n, 256, seed=28)
+    init = circuits.h_layer(n) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n)]
+    with q.HipState(n) as a, q.HipState(n) as b:
+        launches = []
+        for st, relabel in ((a, 0), (b, 1)):
+            st.init_basis(5)
+            st.apply_ops(init)
+            st.set_option("tile", 1)
+            st.set_option("tile_relabel", relabel)
+            st.set_option("profile", 1)
+            st.profile_reset()
+            st.apply_ops(ops)
+            prof = st.profile()
+            st.set_option("profile", 0)
+            launches.append(sum(v["launches"] for v in prof.values()))
+            if relabel:
+                assert prof.get("k_permute_bits", {}).get("launches", 0) == 1, prof
+        assert launches[1] < launches[0], launches
+        for off in (0, 1 << 16, 123456789 & ~0xFFFF, N // 2 - (1 << 15), N - (1 << 16)):
+            assert np.array_equal(a.download(off, 1 << 16), b.download(off, 1 << 16)), off
+        assert abs(b.norm_sqr() - 1) < 1e-10
+
+
 def test_window_compare_at_n24(O):
     """Full-vector compare against the oracle at n = 24 on a prefix of configs[1]."""
     n = 24
@@ -1490,6 +1572,14 @@ def test_full_size_oracle_windows(O, n):
             agg = W.check_circuit(st, n, c2[136:200], O, gate_by_gate=False, seed=4, bases_per_step=2)
             st.set_option("tile_jit", 0)
             assert agg["gates"] == 64 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+            # the scheduler relabelling the qubits (option tile_relabel = 2: unconditionally, so every chunk goes through
+            # in-tile swaps, label exchanges and the closing bit-permutation sweep): still IEEE-equal to the oracle
+            st.set_option("tile_relabel", 2)
+            qswap = [q.make_swap_op([3], [n - 2]), q.make_swap_op([n - 9], [0])]
+            agg = W.check_circuit(st, n, c2[200:232] + qswap + c2[232:256], O, gate_by_gate=False, seed=5, bases_per_step=2)
+            st.set_option("tile_relabel", 0)
+            assert agg["gates"] == 58 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+            assert st.profile().get("k_permute_bits", {}).get("launches", 0) >= 1
             # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
             g = circuits.c5_grover_iteration(n, dense_k3=True)
             agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3, bases_per_step=2)

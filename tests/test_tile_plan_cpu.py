@@ -120,11 +120,22 @@ def emulate_segment(state, n, seg):
 def replay(n, ops, mode, x, dtype=None):
     plan = debug_tile_plan(n, ops, mode) if dtype is None else debug_tile_plan(n, ops, mode, dtype)
     assert plan["n"] == n
+    relabelled = "circuit" in plan
+    if relabelled:
+        # mode bit 2: the steps index the circuit as the scheduler rewrote it — the caller's ops under the qubit labels in
+        # force when they run ("o" = position in the caller's circuit, "i" = qubit indices), in-tile swaps it inserted
+        # ("o" = -1); uncontrolled Swap ops of the caller became label exchanges and appear nowhere
+        import dataclasses
+
+        n_in, kept = len(ops), [c["o"] for c in plan["circuit"] if c["o"] >= 0]
+        assert len(set(kept)) == len(kept) and plan["absorbed"] == n_in - len(kept) and plan["inserted"] == sum(c["o"] < 0 for c in plan["circuit"])
+        assert all(ops[o].kind == "Swap" for o in set(range(n_in)) - set(kept))
+        ops = [q.make_swap_op(c["i"][:1], c["i"][1:]) if c["o"] < 0 else dataclasses.replace(ops[c["o"]], indices=list(c["i"])) for c in plan["circuit"]]
     st = x.copy()
     done = []
     for step in plan["steps"]:
         if "perm" in step:  # a run of Swap ops as one bit permutation: new[j] = old[src(j)], bit perm[d] of src = bit d of j
-            assert len(step["ops"]) >= 2 and sorted(step["perm"]) == list(range(n))
+            assert (len(step["ops"]) >= 2 or relabelled) and sorted(step["perm"]) == list(range(n))
             j = np.arange(1 << n, dtype=np.uint64)
             src = np.zeros_like(j)
             for dbit, sbit in enumerate(step["perm"]):
@@ -224,6 +235,47 @@ def test_runs_of_swaps_become_one_permutation_sweep():
                 q.make_control_op([perm[11]], q.make_swap_op([perm[2]], [perm[3]])), q.make_swap_op([perm[12]], [perm[13]])]
         got2, plan2 = replay(n, ops2, 1 + trial % 2, x)
         assert np.max(np.abs(got2 - O.apply_ops_in_place(n, ops2, x.copy()))) <= 1e-12, perm
+
+
+@pytest.mark.parametrize("mode", [1 | 4 | 8, 2 | 4 | 8])  # bit 3: keep the relabelled plan even where it is not shorter
+@pytest.mark.parametrize("name", ["c2", "qft", "c4", "grover", "fuzz12", "fuzz13", "fuzz14", "c2long", "c2n18", "fuzz17"])
+def test_relabelled_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
+    """option tile_relabel (mode bit 2): the scheduler keeps a logical -> physical map of the qubits, brings the soonest-
+    needed ones onto index bits 0..5 with in-tile swaps, turns Swap ops into label exchanges and restores the order with one
+    bit-permutation sweep at the end.  Replayed with the numpy model; must still equal the oracle on the ORIGINAL circuit."""
+    n = {"fuzz13": 13, "fuzz14": 14, "c2long": 13, "c2n18": 18, "fuzz17": 17}.get(name, 12)
+    rng = np.random.default_rng(len(name) * 11 + n)
+    ops = {
+        "c2": lambda: circuits.h_layer(n) + circuits.c2_random_circuit(n, 120, seed=28),
+        "c2long": lambda: circuits.c2_random_circuit(n, 400, seed=3),
+        "c2n18": lambda: circuits.c2_random_circuit(n, 160, seed=18),
+        "qft": lambda: circuits.c3_qft(n),
+        "c4": lambda: circuits.c4_clifford_t(n, 120, seed=32),
+        "grover": lambda: circuits.h_layer(n) + circuits.c5_grover_iteration(n),
+    }.get(name, lambda: fuzz_circuit(n, rng, 140))()
+    x = circuits.random_state(n, seed=n)
+    got, plan = replay(n, ops, mode, x)
+    assert "circuit" in plan
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.max(np.abs(want))))
+    plain = debug_tile_plan(n, ops, mode & 3)
+    if name in ("c2", "c2long", "c4"):
+        # (a tile already covers 11 of these 12-13 bits, so nothing can be saved here: at most the closing permutation is added)
+        assert len(plan["steps"]) <= len(plain["steps"]) + 1, (len(plan["steps"]), len(plain["steps"]))
+
+
+def test_relabelling_saves_sweeps_at_bench_size():
+    """the schedule only (no state): configs[1] / Clifford+T at n = 30 need fewer sweeps with relabelling, the final
+    permutation sweep included; every caller op lands in exactly one step or is an absorbed Swap"""
+    from rustqip_amd.ops import plan_tiles
+
+    n = 30
+    for ops, plain_max, rel_max in ((circuits.c2_random_circuit(n, 256, seed=28), 19, 15), (circuits.c4_clifford_t(n, 256, seed=32), 16, 13),
+                                    (circuits.c2_random_circuit(n, 1024, seed=28), 70, 50), (circuits.c3_qft(n), 9, 9)):
+        n_plain, rel = len(plan_tiles(n, ops, 1)), plan_tiles(n, ops, 1 | 4)
+        assert n_plain <= plain_max and len(rel) <= rel_max, (n_plain, len(rel))
+        placed = sorted(i for st in rel for i in st)
+        assert len(set(placed)) == len(placed) and all(ops[i].kind == "Swap" for i in set(range(len(ops))) - set(placed))
 
 
 def test_tile_plan_for_complex64_states():

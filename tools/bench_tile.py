@@ -1,6 +1,6 @@
 """Time the LDS-resident multi-gate sweeps (option "tile") on the configured circuits.
 
-    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2] [f32]      (QIP_TILE_JIT=1: run-time-compiled segments)
+    python tools/bench_tile.py [n] [reps] [circuits, e.g. c2,qft] [modes, e.g. 1,2] [f32]      (QIP_TILE_JIT=1: run-time-compiled segments; QIP_TILE_RELABEL=1: qubit relabelling)
 
 Prints one JSON line per (circuit, mode): sweeps launched, ms per run of the circuit, gates/s, and the
 per-sweep HBM rate (each sweep reads and writes the vector once: 32 * 2^n bytes)."""
@@ -33,6 +33,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     cases = {
         "c2": circuits.c2_random_circuit(n, 256, seed=28),
+        "c2x4": circuits.c2_random_circuit(n, 1024, seed=28),
         "c4": circuits.c4_clifford_t(n, 256, seed=32),
         "qft": circuits.c3_qft(n),
         "grover": circuits.c5_grover_iteration(n),
@@ -52,6 +53,7 @@ def main():
                 st.set_option("tile", mode)
                 st.set_option("tile_passes", passes)
                 st.set_option("tile_jit", 1 if os.environ.get("QIP_TILE_JIT") == "1" and mode else 0)
+                st.set_option("tile_relabel", int(os.environ.get("QIP_TILE_RELABEL", "0")) if mode else 0)
                 cops = st.compile_ops(ops)
                 st.set_option("profile", 1)
                 st.profile_reset()
@@ -68,10 +70,11 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
                                   "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
-                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64",
+                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"),
                                   "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
         st.set_option("tile_jit", 0)
+        st.set_option("tile_relabel", 0)
 
 
 if __name__ == "__main__":
