@@ -14,7 +14,10 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "qip_kernels.h"), os.path.join(HERE, "cs
         os.path.join(HERE, "..", "include", "qip_hip.h")]
 OUT = os.path.join(HERE, "lib", "libqip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: hipcc's SLP pass pairs f32 products into v_pk_mul_f32 / v_pk_add_f32, which need their operands in
+# aligned register pairs: in the f32 tile-sweep kernel that cost 180 VGPRs (2 waves per SIMD, 8.7 ms per sweep) against 90
+# without it; the kernels are bound by HBM or by instruction issue, never by f32 flops (profiles/r02_slp.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 LIBS = ["-ldl"]  # librccl is dlopen-ed on first multi-GPU use (csrc/qip_dist.inc): no link-time dependency
 
 

@@ -1325,9 +1325,10 @@ __device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_
 // __launch_bounds__(kBlock, 5): five waves per SIMD = the five 32-KiB tiles that fit a CU's LDS.  The sweep is
 // latency-bound per wave (scalar gate fetch -> branch -> short VALU body, per gate), so resident blocks are what
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
-// (f32 keeps the default: its 16-KiB tiles already allow more, and under the bound hipcc 7.2 spills its tile.)
+// (f32: the same bound holds without spills once the SLP vectorizer is off — rustqip_amd/build.py; with it the pass
+// packs f32 products into v_pk_* pairs and the kernel needs 180 registers.)
 template <typename T, bool NT>
-__global__ __launch_bounds__(kTileBlock, sizeof(T) == 8 ? 5 : 1) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
+__global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
                                                                               const TileGate<T>* __restrict__ gates,
                                                                               const amp_t<T>* __restrict__ mats) {
   using A = amp_t<T>;
