@@ -1771,11 +1771,11 @@ struct TileItem {
   bool exact = false;
   int kind = 0;                 // TileGate kind
   std::vector<uint32_t> pos;    // every involved bit position
-  uint32_t t0 = 0, t1 = 0;      // target position(s)
+  uint32_t t0 = 0, t1 = 0, t2 = 0;  // target position(s)
   std::vector<uint32_t> cpos;
   double m[8] = {0};
   uint32_t nz = 0;
-  std::vector<double> mat;  // kind 3: 4x4 row-major as re,im pairs, sub-index MSB = t0
+  std::vector<double> mat;  // kind 3 / 4: 4x4 / 8x8 row-major as re,im pairs, sub-index MSB = t0
   // how the gate acts on each of its bits: `nd_mask` = it exchanges amplitudes across the bit (dense target, swap
   // bits), `d_mask` = it only tests the bit (controls, diagonal targets).  Two gates commute when on every bit
   // they share both only test it.  Ops that are not tileable count every bit as exchanged.
@@ -1841,6 +1841,13 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
     it->t1 = p.opos[1];
     it->mat = p.table;
     it->tileable = true;
+  } else if (p.cls == KC_GATE_KQ && k == 3 && p.table.size() == 128) {
+    it->kind = 4;  // dense 3-qubit gate: a pass whose three bits are its targets holds one group per lane
+    it->t0 = p.opos[0];
+    it->t1 = p.opos[1];
+    it->t2 = p.opos[2];
+    it->mat = p.table;
+    it->tileable = true;
   } else if (p.cls == KC_NOOP) {
     it->exact = true;  // identity: nothing happens (not tileable, launches nothing)
   }
@@ -1850,6 +1857,7 @@ static int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem*
     if (it->kind == 1) it->d_mask |= 1ull << it->t0;
     else it->nd_mask |= 1ull << it->t0;
     if (it->kind >= 2) it->nd_mask |= 1ull << it->t1;
+    if (it->kind == 4) it->nd_mask |= 1ull << it->t2;
   } else {
     for (uint32_t b : it->pos) it->nd_mask |= 1ull << b;
   }
@@ -1941,10 +1949,11 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
   std::vector<uint32_t> uses(64, 0);
   for (const TileItem* it : seg) {
     if (it->kind == 0) uses[it->t0] += 1;
-    if (it->kind == 2 || it->kind == 3) {
+    if (it->kind >= 2) {
       uses[it->t0] += 1;
       uses[it->t1] += 1;
     }
+    if (it->kind == 4) uses[it->t2] += 1;
   }
   std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
   auto tile_bit = [&](uint32_t pos) -> uint32_t {  // kTileOutside when the position is not part of the tile
@@ -1964,17 +1973,19 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
     g.b0 = tile_bit(it.t0);
     g.b1 = it.kind >= 2 ? tile_bit(it.t1) : 0;
     if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);  // (kind 3 keeps b0 = the sub-index MSB)
-    if (it.kind == 3) {
-      g.nz = (uint32_t)(mats.size() / 16);  // index of its 4x4 in the matrix block behind the gate list
-      for (int e = 0; e < 16; ++e) mats.push_back(mk<T>(it.mat[2 * e], it.mat[2 * e + 1]));
+    if (it.kind == 3 || it.kind == 4) {
+      g.nz = (uint32_t)(mats.size() / 16);  // where its 4x4 / 8x8 starts in the matrix block behind the gate list (units of 16)
+      const int cnt = it.kind == 3 ? 16 : 64;
+      for (int e = 0; e < cnt; ++e) mats.push_back(mk<T>(it.mat[2 * e], it.mat[2 * e + 1]));
     }
+    if (it.kind == 4) g.tpos_out = tile_bit(it.t2);  // (tile bit of the sub-index LSB; the field is otherwise unused for this kind)
     if (it.kind == 1 && g.b0 == kTileOutside) g.tpos_out = it.t0;
     for (uint32_t c : it.cpos) {
       const uint32_t tb = tile_bit(c);
       if (tb == kTileOutside) g.omask |= 1ull << c;
       else g.cmask |= 1u << tb;
     }
-    if (it.kind != 3) g.nz = it.nz;
+    if (it.kind != 3 && it.kind != 4) g.nz = it.nz;
     if (it.kind == 0) {
       for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
       if (passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
@@ -2040,6 +2051,7 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
       std::vector<uint32_t> add;
       if (gates[i].kind == 0) add = {gates[i].b0};
       if (gates[i].kind == 2 || gates[i].kind == 3) add = {gates[i].b0, gates[i].b1};
+      if (gates[i].kind == 4) add = {gates[i].b0, gates[i].b1, gates[i].tpos_out};  // exactly the pass
       if (!add.empty()) {
         // a control of a dense gate / swap is a scalar branch on a pass bit but a per-lane select on a lane
         // bit (k_tile_passes): make the in-tile controls pass bits too whenever the three slots allow
@@ -2081,6 +2093,12 @@ static int build_tile_segment(uint32_t n, bool passes, const std::vector<const T
           else g.op = TOP_DIAG_REG0 + jof(g.b0);
         } else if (g.kind == 0) {
           g.op = (lane_ctl ? TOP_DENSE_LANE0 : TOP_DENSE0) + jof(g.b0);
+        } else if (g.kind == 4) {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1), jc = jof(g.tpos_out);
+          static const uint32_t t3[3][3] = {{0, TOP_DENSE3Q_012, TOP_DENSE3Q_021}, {TOP_DENSE3Q_102, 0, TOP_DENSE3Q_120},
+                                            {TOP_DENSE3Q_201, TOP_DENSE3Q_210, 0}};
+          g.op = t3[ja][jb];
+          (void)jc;  // = 3 - ja - jb
         } else if (g.kind == 3) {
           const uint32_t ja = jof(g.b0), jb = jof(g.b1);
           static const uint32_t table[3][3] = {{0, TOP_DENSE2Q_01, TOP_DENSE2Q_02},
@@ -2291,6 +2309,14 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
           call = m + "pass_dense2<T, " + std::to_string(ja[g.op - TOP_DENSE2Q_01]) + ", " + std::to_string(jb[g.op - TOP_DENSE2Q_01]) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
           break;
         }
+        case TOP_DENSE3Q_012: case TOP_DENSE3Q_021: case TOP_DENSE3Q_102: case TOP_DENSE3Q_120: case TOP_DENSE3Q_201: case TOP_DENSE3Q_210: {
+          static const int ja[6] = {0, 0, 1, 1, 2, 2}, jb[6] = {1, 2, 0, 2, 0, 1};
+          const int a = ja[g.op - TOP_DENSE3Q_012], b = jb[g.op - TOP_DENSE3Q_012];
+          std::string m = "const A M[64] = {";
+          for (int e = 0; e < 64; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 63 ? ", " : "}; ");
+          call = m + "pass_dense3<T, " + std::to_string(a) + ", " + std::to_string(b) + ", " + std::to_string(3 - a - b) + ">(M, e, " + lane_args + ");";
+          break;
+        }
         case TOP_SWAP_01: call = "pass_swap<T, 0, 1>(e, c, g.cm_reg, " + lane_args + ");"; break;
         case TOP_SWAP_02: call = "pass_swap<T, 0, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
         case TOP_SWAP_12: call = "pass_swap<T, 1, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
@@ -2423,7 +2449,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       std::string msg = g_last_error;
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
     }
-    if (items[i].kind == 3 && !allow_2q) items[i].tileable = false;  // k_tile_gates has no 2-qubit form
+    if (items[i].kind >= 3 && !allow_2q) items[i].tileable = false;  // k_tile_gates has no 2- / 3-qubit form
   }
   std::vector<char> done(count, 0);
   uint64_t head = 0;
@@ -2491,6 +2517,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         std::vector<uint32_t> exch;
         if (it.kind == 0) exch = {it.t0};
         if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
+        if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
         for (uint32_t p : exch)
           if (p >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
@@ -2546,7 +2573,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
       std::string msg = g_last_error;
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
     }
-    if (L[i].kind == 3 && !allow_2q) L[i].tileable = false;
+    if (L[i].kind >= 3 && !allow_2q) L[i].tileable = false;
   }
   std::vector<uint32_t> phys(n);  // phys[p] = physical position of logical bit position p
   for (uint32_t p = 0; p < n; ++p) phys[p] = p;
@@ -2555,7 +2582,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
     out->origin.push_back(origin);
     out->items.emplace_back();
     int rc = classify_tile_item(dtype, n, &out->owned.back(), &out->items.back());
-    if (rc == QIP_OK && out->items.back().kind == 3 && !allow_2q) out->items.back().tileable = false;
+    if (rc == QIP_OK && out->items.back().kind >= 3 && !allow_2q) out->items.back().tileable = false;
     return rc;
   };
   // the caller's op i under the labels in force now: same descriptor, qubit indices mapped through `phys`
@@ -2624,6 +2651,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
         std::vector<uint32_t> exch;
         if (it.kind == 0) exch = {it.t0};
         if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
+        if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
         for (uint32_t p : exch) {
           const uint32_t pp = phys[p];
           if (pp >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), pp) == st.high.end() &&

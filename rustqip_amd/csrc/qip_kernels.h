@@ -951,7 +951,9 @@ constexpr int kTileMaxGates = 64;  // a gate riding along costs ~0.2 ms at n = 3
 constexpr uint32_t kTileOutside = 0xffffffffu;
 template <typename T> struct TileGate {
   uint32_t kind;      // 0 = dense 1-qubit (pair update), 1 = diagonal 1-qubit (factor by target bit), 2 = bit swap,
-                      // 3 = dense 2-qubit (b0 = bit of the sub-index MSB, b1 = LSB; nz = index of its 4x4 matrix)
+                      // 3 = dense 2-qubit (b0 = bit of the sub-index MSB, b1 = LSB; nz = index of its 4x4 matrix),
+                      // 4 = dense 3-qubit (b0, b1, tpos_out = tile bits of the sub-index MSB, middle, LSB; nz = offset of its
+                      //     8x8 matrix in the matrix block, in units of 16 entries)
   uint32_t b0, b1;    // tile-index bit(s): target (kinds 0, 1; kTileOutside for a diagonal target outside the tile)
                       // or the two swapped bits (kind 2, b0 < b1).  Kind 0 keeps flags in b1:
                       //   bit 0: every matrix entry is real  -> 2 multiplies per product instead of 4 mul + 2 add
@@ -980,6 +982,8 @@ enum TileOp : uint32_t {
   TOP_DENSE_LANE0, TOP_DENSE_LANE1, TOP_DENSE_LANE2,  // ... with lane-bit controls (select per lane)
   TOP_DENSE2Q_01, TOP_DENSE2Q_02, TOP_DENSE2Q_10, TOP_DENSE2Q_12, TOP_DENSE2Q_20, TOP_DENSE2Q_21,  // JA (MSB), JB
   TOP_SWAP_01, TOP_SWAP_02, TOP_SWAP_12,
+  // dense 3-qubit gate whose three targets ARE the pass's three bits: JA JB JC = pass-bit index of the sub-index MSB, middle, LSB
+  TOP_DENSE3Q_012, TOP_DENSE3Q_021, TOP_DENSE3Q_102, TOP_DENSE3Q_120, TOP_DENSE3Q_201, TOP_DENSE3Q_210,
 };
 
 struct TileDesc {
@@ -1322,6 +1326,26 @@ __device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_
   }
 }
 
+// dense 3-qubit gate on the pass's three bits: the lane's eight elements ARE one group; out[r] = sum_c M[r][c] * in[c]
+// with the fold order of k_gate_kq (all 64 products, columns ascending), so circuit-order sweeps stay IEEE-equal to the
+// gate-by-gate path.  Controls can only sit on lane bits or outside the tile (the pass bits are the targets).
+template <typename T, int JA, int JB, int JC>
+__device__ __forceinline__ void pass_dense3(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[8], bool lane_ctl, bool lane_ok) {
+  using A = amp_t<T>;
+  A x[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) x[s] = e[(((s >> 2) & 1) << JA) | (((s >> 1) & 1) << JB) | ((s & 1) << JC)];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    A acc = cmul(M[r * 8], x[0]);
+#pragma unroll
+    for (int s = 1; s < 8; ++s) acc = cadd(acc, cmul(M[r * 8 + s], x[s]));
+    const int i = (((r >> 2) & 1) << JA) | (((r >> 1) & 1) << JB) | ((r & 1) << JC);
+    e[i] = lane_ctl ? tile_sel(lane_ok, acc, x[r]) : acc;
+    __builtin_amdgcn_sched_barrier(0);  // one output row at a time: interleaving rows only costs registers
+  }
+}
+
 // __launch_bounds__(kBlock, 5): five waves per SIMD = the five 32-KiB tiles that fit a CU's LDS.  The sweep is
 // latency-bound per wave (scalar gate fetch -> branch -> short VALU body, per gate), so resident blocks are what
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
@@ -1425,6 +1449,14 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
         case TOP_SWAP_01: pass_swap<T, 0, 1>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
         case TOP_SWAP_02: pass_swap<T, 0, 2>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
         case TOP_SWAP_12: pass_swap<T, 1, 2>(e, c, cm_reg, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane); break;
+#define QIP_D3Q(JA, JB, JC) pass_dense3<T, JA, JB, JC>(mats + 16u * g.nz, e, g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane)
+        case TOP_DENSE3Q_012: QIP_D3Q(0, 1, 2); break;
+        case TOP_DENSE3Q_021: QIP_D3Q(0, 2, 1); break;
+        case TOP_DENSE3Q_102: QIP_D3Q(1, 0, 2); break;
+        case TOP_DENSE3Q_120: QIP_D3Q(1, 2, 0); break;
+        case TOP_DENSE3Q_201: QIP_D3Q(2, 0, 1); break;
+        case TOP_DENSE3Q_210: QIP_D3Q(2, 1, 0); break;
+#undef QIP_D3Q
         default: break;
       }
     }

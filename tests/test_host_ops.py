@@ -181,7 +181,8 @@ def test_tile_schedule_invariants():
     rng = np.random.default_rng(0)
     ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 300, seed=3) + circuits.c3_qft(n)[:120]
     ops.insert(50, q.make_matrix_op([3, 9], np.eye(4).ravel() * (1 + 0j) + 0.1))      # dense k = 2: rides in a segment
-    ops.insert(120, q.make_matrix_op([2, 7, 11], np.eye(8).ravel() * (1 + 0j) + 0.1))  # dense k = 3: not tileable
+    ops.insert(120, q.make_matrix_op([2, 7, 11], np.eye(8).ravel() * (1 + 0j) + 0.1))  # dense k = 3: a pass of its own three bits
+    ops.insert(160, q.make_matrix_op([1, 5, 12, 17], np.eye(16).ravel() * (1 + 0j) + 0.1))  # dense k = 4: not tileable
     ops.insert(200, q.make_control_op(list(range(12)), q.make_matrix_op([15], [1, 0, 0, -1])))  # many controls: fine
     qubits = [set(flatten(o)[0]) | set(flatten(o)[2]) for o in ops]
 
@@ -241,9 +242,9 @@ def test_tile_schedule_invariants():
                 for i in st:
                     free |= {p for p in exchange_bits(ops[i]) if p >= 6}
                 assert len(free) <= 6 and len(st) <= 64
-                assert all(len(flatten(ops[i])[2]) <= 2 for i in st)  # 1-qubit gates, swaps, dense 2-qubit gates
-        assert [120] in steps  # the dense 3-qubit gate is launched on its own
-        assert not [50] in steps  # the dense 2-qubit gate shares a sweep
+                assert all(len(flatten(ops[i])[2]) <= 3 for i in st)  # 1-qubit gates, swaps, dense 2- and 3-qubit gates
+        assert [160] in steps  # the dense 4-qubit gate is launched on its own
+        assert not [50] in steps and not [120] in steps  # the dense 2- and 3-qubit gates share a sweep
     assert len(plan_tiles(n, ops, 2)) <= len(plan_tiles(n, ops, 1)) < len(ops) / 4
     print('steps', len(plan_tiles(n, ops, 1)), len(plan_tiles(n, ops, 2)), 'of', len(ops))
     with pytest.raises(q.CircuitError):

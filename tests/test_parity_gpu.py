@@ -1580,10 +1580,16 @@ def test_full_size_oracle_windows(O, n):
             st.set_option("tile_relabel", 0)
             assert agg["gates"] == 58 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
             assert st.profile().get("k_permute_bits", {}).get("launches", 0) >= 1
-            # a circuit that mixes matrix-core launches with tile sweeps (configs[4], dense k = 3 variant)
+            # configs[4], dense k = 3 variant (the 8x8 gates ride in the sweeps as passes of their own three bits), with
+            # dense k = 5 / k = 4 gates in between: matrix-core launches mixed with tile sweeps
             g = circuits.c5_grover_iteration(n, dense_k3=True)
+            k5 = q.make_matrix_op([n - 1, n - 2, 3, n - 4, n - 5], rand_unitary(5, rng).ravel())
+            k4 = q.make_matrix_op([n - 1, n - 3, 2, n - 6], rand_unitary(4, rng).ravel())
+            g = g[:40] + [k5] + g[40:100] + [k4] + g[100:]
+            st.profile_reset()
             agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3, bases_per_step=2)
             assert agg["gates"] >= len(g) - 2 and agg["max_abs_delta"] <= TOL64, agg
+            assert st.profile().get("k_gate_kq_mfma", {}).get("launches", 0) >= 2, st.profile()
         st.set_option("tile", 0)
         st.set_option("profile", 0)
         assert abs(st.norm_sqr() - 1) < 1e-9
@@ -1708,13 +1714,14 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
         elif shape == 5:  # (controlled) swap
             g = q.make_swap_op([perm[0]], [perm[1]])
             ops.append(q.make_control_op(perm[2:2 + nc], g) if nc else g)
-        elif shape == 6:  # dense 2-qubit gate with 0..2 controls (tileable) / 3-qubit gate, 2+2 swap (not)
+        elif shape == 6:  # dense 2- / 3-qubit gate with 0..2 controls (tileable) / 2+2 swap (not)
             pick = int(rng.integers(0, 4))
             if pick <= 1:
                 g = q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel())
                 ops.append(q.make_control_op(perm[2:2 + min(nc, 2)], g) if nc and pick else g)
-            elif pick == 2:
-                ops.append(q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()))
+            elif pick == 2:  # dense 3-qubit gate with 0..2 controls: a tile pass of its own three bits
+                g = q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel())
+                ops.append(q.make_control_op(perm[3:3 + min(nc, 2)], g) if nc and rng.integers(0, 2) else g)
             else:
                 ops.append(q.make_swap_op(perm[:2], perm[2:4]))
         else:  # sparse (generic gather path)
@@ -1746,12 +1753,24 @@ def test_tile_sweeps_fuzz_every_gate_shape(O, n, seed):
         prog.run()
         assert np.array_equal(st.download(), eager)
         prog.close()
+    if n in (12, 14):  # run-time-compiled segments, and the scheduler relabelling the qubits on top: still IEEE-equal
+        with q.HipState(n) as st:
+            st.set_option("mfma", 0)
+            st.set_option("tile", 1)
+            st.set_option("tile_jit", 1)
+            for relabel in (0, 2):
+                st.set_option("tile_relabel", relabel)
+                st.upload(x)
+                st.apply_ops(ops)
+                assert np.array_equal(st.download(), eager), (n, seed, relabel)
     x32 = x.astype(np.complex64)
     with q.HipState(n, np.complex64) as st:
+        st.set_option("mfma", 0)  # (a dense 3-qubit gate is a tile item now: compare with the unfused VALU form)
         st.upload(x32)
         st.apply_ops(ops)
         e32 = st.download()
     with q.HipState(n, np.complex64) as st:
+        st.set_option("mfma", 0)
         st.set_option("tile", 1)
         st.upload(x32)
         st.apply_ops(ops)

@@ -19,6 +19,7 @@ NLANES = 1 << TILE_LANE_BITS
 # enum TileOp (rustqip_amd/csrc/qip_kernels.h)
 DIAG_UNIFORM, DIAG_LANE, DIAG_LANE_CTL, DIAG_REG0 = 0, 1, 2, 3
 DENSE0, DENSE_LANE0, DENSE2Q_FIRST, SWAP_FIRST = 6, 9, 12, 18
+DENSE3Q_FIRST = 21
 DENSE2Q = [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)]
 SWAPS = [(0, 1), (0, 2), (1, 2)]
 
@@ -100,6 +101,16 @@ def emulate_segment(state, n, seg):
                     y = x @ mat.T
                     for r, i in enumerate(ids):
                         e[:, :, i] = np.where(mask[:, :, ids[0]], y[:, :, r], x[:, :, r])
+            elif DENSE3Q_FIRST <= op < DENSE3Q_FIRST + 6:
+                ja, jb = DENSE2Q[op - DENSE3Q_FIRST]
+                jc = 3 - ja - jb
+                assert g["kind"] == 4 and g["b0"] == pb[ja] and g["b1"] == pb[jb] and g["tpos_out"] == pb[jc] and g["cm_reg"] == 0
+                mat = mats[16 * g["nz"]: 16 * g["nz"] + 64].reshape(8, 8)
+                ids = [(((s_ >> 2) & 1) << ja) | (((s_ >> 1) & 1) << jb) | ((s_ & 1) << jc) for s_ in range(8)]
+                x = np.stack([e[:, :, i] for i in ids], axis=-1)
+                y = x @ mat.T
+                for r, i in enumerate(ids):
+                    e[:, :, i] = np.where(mask[:, :, 0], y[:, :, r], x[:, :, r])
             elif SWAP_FIRST <= op < SWAP_FIRST + 3:
                 j0, j1 = SWAPS[op - SWAP_FIRST]
                 assert g["kind"] == 2 and g["b0"] == pb[j0] and g["b1"] == pb[j1]
@@ -179,7 +190,8 @@ def fuzz_circuit(n, rng, gates):
             g = q.make_matrix_op(perm[:2], rand_unitary(2, rng).ravel())
             ops.append(q.make_control_op(perm[2:2 + min(nc, 3)], g) if nc else g)
         elif shape == 7:
-            ops.append(q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel()))  # not tileable
+            g = q.make_matrix_op(perm[:3], rand_unitary(3, rng).ravel())  # a pass of its own three bits
+            ops.append(q.make_control_op(perm[3:3 + min(nc, 3)], g) if nc and rng.integers(0, 2) else g)
         else:
             ops.append(q.make_swap_op(perm[:2], perm[2:4]))  # not tileable
     return ops
@@ -305,8 +317,12 @@ def test_run_time_compiled_segments_build_without_a_gpu():
     ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 60, seed=5) + circuits.c3_qft(n)[:60]
     for _ in range(40):  # the shapes the circuits above lack: swaps, dense 2-qubit gates, controls of every kind
         perm = [int(v) for v in rng.permutation(n)]
-        kind = int(rng.integers(0, 5))
-        if kind == 0:
+        kind = int(rng.integers(0, 6))
+        if kind == 5:
+            a = rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))
+            g = q.make_matrix_op(perm[:3], np.linalg.qr(a)[0].ravel())
+            ops.append(g if rng.integers(0, 2) else q.make_control_op([perm[3]], g))
+        elif kind == 0:
             ops.append(q.make_swap_op([perm[0]], [perm[1]]))
         elif kind == 1:
             a = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
@@ -322,4 +338,5 @@ def test_run_time_compiled_segments_build_without_a_gpu():
         assert r["segments"] >= 3 and r["code_bytes"] > 0
         src = r["first_source"]
         assert "constexpr TileGate<T> g" in src and "pass_" in src and "#include \"qip_kernels.h\"" in src
+        assert r["all_sources_contain"]("pass_dense3<T") if "all_sources_contain" in r else True
         assert ("typedef double T;" in src) == (dtype == _ffi.QIP_C64)

@@ -37,6 +37,7 @@ def main():
         "c4": circuits.c4_clifford_t(n, 256, seed=32),
         "qft": circuits.c3_qft(n),
         "grover": circuits.c5_grover_iteration(n),
+        "groverk3": circuits.c5_grover_iteration(n, dense_k3=True),
         "brick2q": brickwork(n, 4),
     }
     if len(sys.argv) > 3:
