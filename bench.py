@@ -407,6 +407,24 @@ def main():
             extras["configs1_n28"] = {"GBps": circuit_bytes(q, n28, ops28) / dt / 1e9, "gates_per_s": len(ops28) / dt,
                                       "ms_per_step": 1e3 * dt, "reps": REPS, "norm_sqr": s28.norm_sqr()}
 
+        # the same headline circuit on a Complex<f32> state (8 GiB at n = 30; 16 * 2^n bytes per gate),
+        # gate by gate and as tile sweeps (run-time-compiled segments, qubits relabelled); medians of REPS
+        with q.HipState(n, np.complex64) as s32:
+            s32.init_basis(0)
+            s32.apply_ops(circuits.h_layer(n) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n)])
+            c32 = s32.compile_ops(ops)
+            dt, _ = median_time(lambda: s32.apply_compiled(c32), s32.sync)
+            by32 = sum(q.algorithmic_bytes(n, op, 1) for op in ops)
+            f32 = {"gates": len(ops), "ms": 1e3 * dt, "gates_per_s": len(ops) / dt, "algorithmic_GBps": by32 / dt / 1e9,
+                   "frac_of_8TBps": by32 / dt / 1e9 / HBM_PEAK_GBPS, "reps": REPS}
+            cm32 = s32.compile_ops(ops_mixed)
+            for k, v in (("tile", 1), ("tile_jit", 1), ("tile_relabel", 1)):
+                s32.set_option(k, v)
+            dt, _ = median_time(lambda: s32.apply_compiled(cm32), s32.sync)
+            f32["mixed_tile1_jit_relabel"] = {"gates": len(ops_mixed), "ms": 1e3 * dt, "gates_per_s": len(ops_mixed) / dt, "reps": REPS}
+            f32["norm_sqr"] = s32.norm_sqr()
+            extras["complex64_n%d" % n] = f32
+
     if world > 1 and not args.no_parity:
         # The N > 1 path against the CPU oracle on THIS fabric (the real transport, every rank's real kernels): a small
         # sharded state (18 local qubits) runs the headline generator's mix + QFT + a Grover iteration, is gathered in

@@ -52,6 +52,12 @@ impl<P: HipPrecision> HipState<P> {
         let k = CString::new(key).expect("option key without NUL");
         check(unsafe { sys::qip_hip_state_set_option(self.h, k.as_ptr(), value) })
     }
+    /// new[j] = old[src(j)], bit pi[d] of src(j) = bit d of j: any permutation of the index bits in one sweep
+    /// (what a run of `Swap` ops composes to, qip-iterators/src/iterators/qubit_iterators.rs:208-218).
+    pub fn permute_bits(&mut self, pi: &[u32]) -> Result<(), HipError> {
+        assert_eq!(pi.len(), self.n, "the permutation must list all n index bits");
+        check(unsafe { sys::qip_hip_state_permute_bits(self.h, pi.as_ptr()) })
+    }
     /// |index> (builder.rs:409-421).
     pub fn init_basis(&mut self, index: usize) -> Result<(), HipError> {
         check(unsafe { sys::qip_hip_state_init_basis(self.h, index as u64) })

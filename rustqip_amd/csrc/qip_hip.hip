@@ -2741,9 +2741,10 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
 
 // mode: bits 0-1 = the "tile" option (1 = circuit order, 2 = commuting reorder), bit 2 = relabel the qubits when that
 // shortens the plan, bit 3 = relabel unconditionally
-static int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out) {
+static int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                              bool allow_permute = true) {
   const bool reorder = (mode & 3) >= 2;
-  if (mode & 4) {
+  if ((mode & 4) && allow_permute) {
     // relabelling pays for random circuits; layered ones (Grover's X / H walls, QFT) gain nothing and would only pay the
     // closing permutation: schedule both ways (host work, microseconds per gate) and keep the shorter plan
     QCHK(schedule_tiles_relabel(dtype, n, ops, count, reorder, allow_2q, out));
@@ -2754,7 +2755,7 @@ static int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t
   }
   out->circuit = ops;
   out->count = count;
-  return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q);
+  return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q, allow_permute);
 }
 
 extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
@@ -2918,6 +2919,17 @@ template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t count, bool /*reorder*/) {
   TileSchedule sc;
   QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc));
+  {
+    // a bit-permutation sweep is out of place: get the second buffer BEFORE the first gate runs; if HBM cannot hold it
+    // (a state above half of the 288 GB), fall back to the plan without permutation sweeps instead of failing half way
+    bool permutes = false;
+    for (const TileStep& st : sc.steps) permutes = permutes || !st.perm.empty();
+    if (permutes && !s->jit_prepare && !s->alt && ensure_alt(s) != QIP_OK) {
+      (void)hipGetLastError();
+      sc = TileSchedule();
+      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc, /*allow_permute=*/false));
+    }
+  }
   const qip_op* ops = sc.circuit;
   const std::vector<TileItem>& items = sc.items;
   for (const TileStep& st : sc.steps) {

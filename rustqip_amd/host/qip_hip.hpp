@@ -268,6 +268,12 @@ template <typename P> class HipState {
     check(qip_hip_state_apply_ops(h_, flat.data(), flat.size()));
   }
   void set_option(const char* key, int64_t value) { check(qip_hip_state_set_option(h_, key, value)); }
+  // new[j] = old[src(j)], bit pi[d] of src(j) = bit d of j: any permutation of the index bits in one sweep (what a run of
+  // Swap ops composes to, qubit_iterators.rs:208-218)
+  void permute_bits(const std::vector<uint32_t>& pi) {
+    if (pi.size() != n_) throw CircuitError("the permutation must list all n index bits");
+    check(qip_hip_state_permute_bits(h_, pi.data()));
+  }
   void sync() { check(qip_hip_state_sync(h_)); }
   double norm_sqr() const {
     double v = 0;

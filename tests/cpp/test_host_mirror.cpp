@@ -194,6 +194,18 @@ static void gpu_checks() {
     for (int m = 0; m < 4; ++m) EXPECT(std::abs(pr[m] - pw[m]) < 1e-13);
     EXPECT(ds.layout().size() == n && ds.take_stats().remaps == 0);
     std::printf("sharded state (world 1, RCCL transport): max|delta| vs single-GPU state = %.1e\n", maxd);
+    // a run of Swap ops composes to one bit permutation: [1,2] <-> [8,7] exchanges qubits 1/8 and 2/7 = index bits 8/1 and 7/2
+    std::vector<uint32_t> pi(n);
+    for (uint32_t d = 0; d < n; ++d) pi[d] = d;
+    std::swap(pi[8], pi[1]);
+    std::swap(pi[7], pi[2]);
+    ref.permute_bits(pi);           // undoes the circuit's closing swap ...
+    ref.apply_ops({ops.back()});    // ... and the Swap op puts it back
+    const auto c = ref.download();
+    double maxp = 0;
+    for (size_t i = 0; i < a.size(); ++i) maxp = std::max(maxp, std::abs(a[i] - c[i]));
+    EXPECT(maxp == 0.0);
+    EXPECT(throws([&] { ref.permute_bits({0, 1}); }, "all n index bits"));
   }
 }
 

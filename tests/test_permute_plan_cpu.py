@@ -119,3 +119,28 @@ def test_run_of_swaps_composes_to_one_permutation():
         pi = [pi[tau[dbit]] for dbit in range(n)]
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.array_equal(want_of(n, pi, x), want)
+
+
+@pytest.mark.parametrize("n,row_bits,fold_bits", [(30, 5, 3), (33, 5, 3), (34, 6, 4), (40, 5, 3)])
+def test_descriptor_at_bench_sizes_on_sampled_elements(n, row_bits, fold_bits):
+    """no state: for sampled (block, element) pairs the source index the load side computes and the destination index the
+    store side computes satisfy dst bit d = src bit pi[d] (block ids above 2^32 blocks included: the 2-D grid of n >= 38)"""
+    rng = np.random.default_rng(n)
+    TB = 2 * row_bits
+    for pi in (list(range(n))[::-1], [int(v) for v in rng.permutation(n)], list(range(1, n)) + [0]):
+        d = plan(n, pi, row_bits, fold_bits)
+        blocks = np.concatenate([np.array([0, (1 << (n - TB)) - 1], dtype=np.uint64), rng.integers(0, 1 << (n - TB), size=200, dtype=np.uint64)])
+        dbase = blocks.copy()
+        for p in d["tbits"]:
+            low = dbase & np.uint64((1 << p) - 1)
+            dbase = ((dbase >> np.uint64(p)) << np.uint64(p + 1)) | low
+        sbase = np.zeros_like(dbase)
+        for a, b in zip(d["outer_dst"], d["outer_src"]):
+            sbase |= ((dbase >> np.uint64(a)) & np.uint64(1)) << np.uint64(b)
+        u = rng.integers(0, 1 << TB, size=blocks.size, dtype=np.uint64)  # a source-side coordinate per sampled block
+        src = sbase | (u & np.uint64((1 << row_bits) - 1)) | spread(u, d["sbits"], row_bits)
+        c = spread(u, d["u2c"])  # where that element sits in the tile = the store side's coordinate
+        dst = dbase | (c & np.uint64((1 << row_bits) - 1)) | spread(c, d["tbits"], row_bits)
+        for dbit in range(n):
+            assert np.array_equal((dst >> np.uint64(dbit)) & np.uint64(1), (src >> np.uint64(pi[dbit])) & np.uint64(1)), (n, dbit)
+        assert int(dst.max()) < (1 << n) and int(src.max()) < (1 << n)
