@@ -161,6 +161,7 @@ extern "C" {
     ) -> c_int;
     pub fn qip_hip_dist_local_state(d: *mut qip_hip_dist, shard: *mut *mut qip_hip_state) -> c_int;
     pub fn qip_hip_dist_layout(d: *mut qip_hip_dist, phys: *mut u32) -> c_int;
+    pub fn qip_hip_dist_rank_flip(d: *mut qip_hip_dist, mask: *mut u32) -> c_int;
     pub fn qip_hip_dist_take_stats(d: *mut qip_hip_dist, out: *mut qip_hip_dist_stats) -> c_int;
     pub fn qip_hip_dist_debug_plan(
         n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64,

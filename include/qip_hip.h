@@ -375,6 +375,11 @@ int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, i
  * positions >= n-g are rank bits.  Together they let the host scatter / gather a vector in logical order. */
 int qip_hip_dist_local_state(qip_hip_dist* d, qip_hip_state** shard);
 int qip_hip_dist_layout(qip_hip_dist* d, uint32_t* phys);
+/* Pending rank renamings: rank bit j (physical position n-g+j) reads as (bit j of the rank) XOR (bit j of *mask).  An
+ * uncontrolled anti-diagonal 1-qubit gate (X, Y, ...) on a qubit that lives on a rank bit moves nothing: the ranks trade
+ * names and scale their shards; the renaming is settled by local X sweeps at the next exchange.  The amplitudes rank r
+ * holds are those whose rank-bit values are r ^ *mask. */
+int qip_hip_dist_rank_flip(qip_hip_dist* d, uint32_t* mask);
 
 typedef struct qip_hip_dist_stats {
   uint64_t remaps;            /* all-to-all exchanges */

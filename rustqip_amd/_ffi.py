@@ -115,6 +115,7 @@ SIGNATURES = {
     "qip_hip_dist_measure": (_int, [_vp, _u64p, _u32, _i64, _dbl, _u64p, _dblp]),
     "qip_hip_dist_local_state": (_int, [_vp, C.POINTER(_vp)]),
     "qip_hip_dist_layout": (_int, [_vp, C.POINTER(C.c_uint32)]),
+    "qip_hip_dist_rank_flip": (_int, [_vp, C.POINTER(C.c_uint32)]),
     "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
     "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
 }

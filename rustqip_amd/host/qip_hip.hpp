@@ -378,6 +378,12 @@ template <typename P> class DistState {
     check(qip_hip_dist_layout(h_, phys.data()));
     return phys;
   }
+  /// pending rank renamings: this rank holds the amplitudes whose rank bits read rank ^ rank_flip()
+  uint32_t rank_flip() {
+    uint32_t m = 0;
+    check(qip_hip_dist_rank_flip(h_, &m));
+    return m;
+  }
   /// this rank's amplitudes, in local (physical) order
   std::vector<C> download_shard(size_t n_local) {
     qip_hip_state* sh = nullptr;

@@ -130,9 +130,15 @@ class DistState:
         _check(_ffi.lib.qip_hip_dist_layout(self._h, arr))
         return list(arr)
 
+    def rank_flip(self) -> int:
+        """pending rank renamings (qip_hip_dist_rank_flip): this rank holds the amplitudes whose rank bits read rank ^ flip"""
+        m = C.c_uint32()
+        _check(_ffi.lib.qip_hip_dist_rank_flip(self._h, C.byref(m)))
+        return int(m.value)
+
     def logical_indices_of_shard(self) -> np.ndarray:
         """logical index of every local amplitude, in local order"""
-        return shard_logical_indices(self.n, self.L, self.rank, self.layout())
+        return shard_logical_indices(self.n, self.L, self.rank, self.layout(), self.rank_flip())
 
     # -- data in / out (tests / small n) -----------------------------------------------------------------------------
     def init_basis(self, logical_index: int) -> None:
@@ -215,9 +221,9 @@ class DistState:
                 "world": self.world, "n": self.n, "n_local": self.L}
 
 
-def shard_logical_indices(n: int, L: int, rank: int, phys: Sequence[int]) -> np.ndarray:
+def shard_logical_indices(n: int, L: int, rank: int, phys: Sequence[int], flip: int = 0) -> np.ndarray:
     loc = np.arange(1 << L, dtype=np.uint64)
-    P = loc | (np.uint64(rank) << np.uint64(L))
+    P = loc | (np.uint64(rank ^ flip) << np.uint64(L))  # rank bits read as rank ^ flip (pending renamings)
     out = np.zeros_like(P)
     for p in range(n):
         out |= ((P >> np.uint64(phys[p])) & np.uint64(1)) << np.uint64(p)

@@ -88,7 +88,7 @@ def main():
             assert (plan["g"], plan["L"], plan["rank"]) == (g, L, rank)
             shard = x[rank << L:(rank + 1) << L].copy()  # a fresh state: logical = physical
             shard = sharded.replay_plan(plan, shard, apply_local, all_to_all)
-            idx = sharded.shard_logical_indices(n, L, rank, plan["phys"]).astype(np.int64)
+            idx = sharded.shard_logical_indices(n, L, rank, plan["phys"], plan["flip"]).astype(np.int64)
             parts = [None] * world
             dist.all_gather_object(parts, (idx, shard, [(s["t"], s.get("sel")) for s in plan["steps"] if s["t"] != "local"], plan["phys"]))
             got = np.zeros(1 << n, dtype=np.complex128)
@@ -100,6 +100,9 @@ def main():
             # SPMD: every rank packs / exchanges at the same places with the same selection, and ends in the same layout
             for _, _, coll, phys in parts:
                 assert coll == parts[0][2] and phys == parts[0][3], (name, n)
+            flips = [None] * world
+            dist.all_gather_object(flips, plan["flip"])
+            assert all(f == flips[0] for f in flips)  # the renaming of the ranks is the same decision everywhere
             assert sorted(plan["phys"]) == list(range(n))
             n_exchange = sum(1 for s in plan["steps"] if s["t"] == "exchange")
             n_pack = sum(1 for s in plan["steps"] if s["t"] == "pack")
