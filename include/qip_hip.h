@@ -246,7 +246,8 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    controls, dense 2-qubit gates, bit swaps) whose exchanging bits live on index bits 0..5
  *                    plus six free higher bits and applies each segment in ONE sweep
  *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
- *                    (IEEE-equal to the gate-by-gate path);
+ *                    (IEEE-equal to the gate-by-gate path; a dense 3-qubit gate rides along as the unfused register fold,
+ *                    i.e. equal to its gate-by-gate form under "mfma" = 0 — on the matrix cores it is an fma chain);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
  *   "tile_jit"       1: every tile segment runs as a kernel compiled at run time for that very segment (hiprtc; the
  *                    gate list becomes constants of the code: no descriptor fetch, no dispatch, no control-mask tests

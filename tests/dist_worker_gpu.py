@@ -65,7 +65,10 @@ def main():
             stt.set_option("tile", 1)
             stt.upload_global(x)
             stt.apply_ops(ops)
-            assert np.array_equal(stt.download_global(), got), (name, n, world)
+            if name == "grover_k3":  # its 8x8 gates ride in the sweeps (unfused register fold); gate by gate they ran on the matrix cores
+                assert np.max(np.abs(stt.download_global() - got)) < 1e-12, (name, n, world)
+            else:
+                assert np.array_equal(stt.download_global(), got), (name, n, world)
             # collapsing measurement: forced outcome, then a sampled one (already collapsed, so it repeats)
             ref = O.apply_ops_in_place(n, ops[:30], x.copy())
             for idx, forced in (([0], 1), ([n - 1, 1], 2), ([2, 0, n - 1], 5)):
