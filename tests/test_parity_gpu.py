@@ -1644,11 +1644,14 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
     assert abs(line["norm_sqr_after"] - 1) < 1e-10
-    assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 1
+    # (the look-ahead keeps the qubit whose next H is farthest on the rank bit, and X gates there only rename the ranks:
+    # a short headline circuit may need no exchange at all — the legs below and the parity leg do)
+    assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 0
     ex = line["extras"]
     for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs4_grover_dense_k3_n21",
                  "configs1_mixed_n21", "headline_tiled_mode1"):
         assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
+    assert sum(ex[name]["comm_over_reps"]["remaps"] for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs1_mixed_n21")) >= 1
     assert abs(ex["norm_sqr_end"] - 1) < 1e-9
     par = line["parity"]  # the sharded path against the oracle, inside the bench run itself
     assert "error" not in par and par["world"] == 2 and par["remaps_exercised"] >= 1 and par["max_abs_delta"] <= 1e-12, par
