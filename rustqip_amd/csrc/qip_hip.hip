@@ -81,9 +81,15 @@ extern "C" int qip_hip_device_count(void) try {
 static int64_t g_force_generic = 0;
 // Selector bits below this position stay in the grid as a per-lane predicate (whole lines are swept); see kLineBits.
 static uint32_t g_line_bits = qipk::kLineBits;
+static int64_t g_perm_rows = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "perm_rows")) {
+    if (value != 0 && value != 5 && value != 6) return fail(QIP_ERR_INVALID, "perm_rows must be 0 (automatic), 5 or 6");
+    g_perm_rows = value;
     return QIP_OK;
   }
   if (key && !strcmp(key, "line_bits")) {  // tuning aid (tools/bench_ops.py): 0..3
@@ -1127,7 +1133,13 @@ static int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
     n -= 1;
   }
   const bool wide = s->dtype == QIP_C64 || packed;   // 16-byte elements
-  const uint32_t R = wide ? 5u : 6u, TB = 2 * R;
+  // 16-byte elements: 512-B rows in 16-KiB tiles (8 blocks per CU) unless two or more of the source's row bits feed
+  // destination bits far above the rows — then the tile's rows are scattered on the source side and 1-KiB rows in
+  // 64-KiB tiles pay (measured at n = 30: random permutation 7.2 -> 6.5 ms, three transpositions 7.3 -> 5.9, while a
+  // single transposition is better off with the small tile: 5.9 vs 6.2 ms; profiles/r02_permute.md)
+  uint32_t scattered = 0;
+  for (uint32_t b = 10; b < n; ++b) scattered += pi[b] < 5u;
+  const uint32_t R = !wide ? 6u : (g_perm_rows ? (uint32_t)g_perm_rows : (scattered >= 2 && n >= 12 ? 6u : 5u)), TB = 2 * R;
   ProfRec rec;
   if (s->profile) QCHK(prof_begin(s, KC_PERMUTE, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
   const bool nt = use_nt(s);
@@ -1146,15 +1158,17 @@ static int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
       hipLaunchKernelGGL((k_permute_bits_small<amp_t<float>>), grid, block, 0, s->stream, (const amp_t<float>*)s->cur, (amp_t<float>*)s->alt, count, ps);
   } else {
     PermDesc d;
-    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, &d));
+    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, &d));  // (fold width follows the element size, not R)
     const dim3 grid = grid2d(1ull << (n - TB), 1), block(kBlock);
 #define PB(A, RR)                                                                                                        \
   do {                                                                                                                   \
     if (nt) hipLaunchKernelGGL((k_permute_bits<A, RR, true>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);  \
     else hipLaunchKernelGGL((k_permute_bits<A, RR, false>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);    \
   } while (0)
-    if (s->dtype == QIP_C64) PB(amp_t<double>, 5);
-    else if (packed) PB(f32x4, 5);
+    if (s->dtype == QIP_C64 && R == 5) PB(amp_t<double>, 5);
+    else if (s->dtype == QIP_C64) PB(amp_t<double>, 6);
+    else if (packed && R == 5) PB(f32x4, 5);
+    else if (packed) PB(f32x4, 6);
     else PB(amp_t<float>, 6);
 #undef PB
   }
