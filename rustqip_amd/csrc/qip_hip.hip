@@ -68,7 +68,7 @@ static int fail(int code, const char* fmt, ...) {
   catch (...) { return fail(QIP_ERR_INVALID, "internal error: unknown C++ exception"); }
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 2; }
+extern "C" int qip_hip_abi_version(void) { return 3; }  // 3: + permute_bits, dist_rank_flip, options tile_relabel / perm_rows / line_bits
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {

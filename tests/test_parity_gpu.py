@@ -1595,6 +1595,34 @@ def test_full_size_oracle_windows(O, n):
         assert abs(st.norm_sqr() - 1) < 1e-9
 
 
+def test_full_size_oracle_windows_complex64(O):
+    """SURVEY.md §8 row f3 at the benchmarked size: a Complex<f32> state at n = 30 (8 GiB; the packed 16-byte view and the
+    8-byte kernels both occur) against the f32 ORACLE on closed sub-cubes, gate by gate and through tile sweeps with the
+    qubits relabelled.  Both sides compute in unfused f32, so the comparison is held to bit equality."""
+    from oracle import window_parity as W
+
+    n = 30
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    c2 = circuits.c2_random_circuit(n, 256, seed=28)
+    with q.HipState(n, np.complex64) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        for off in (0, (1 << n) - (1 << 16)):
+            got = st.download(off, 1 << 16)
+            want = W.product_state_window(n, vecs, off, 1 << 16)
+            assert np.allclose(got, want, rtol=2e-5, atol=0), off
+        agg = W.check_circuit(st, n, c2[:24], O, gate_by_gate=True, seed=21)
+        assert agg["gates"] == 24 and agg["skipped"] == 0 and agg["rows"] >= 24 * 4 * (1 << 16)
+        assert agg["bit_equal"] and agg["max_abs_delta"] == 0.0, agg
+        st.set_option("tile", 1)
+        agg = W.check_circuit(st, n, c2[24:88], O, gate_by_gate=False, seed=22, bases_per_step=2)
+        assert agg["gates"] == 64 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+        st.set_option("tile_relabel", 2)
+        agg = W.check_circuit(st, n, c2[88:152] + [q.make_swap_op([2], [n - 3])], O, gate_by_gate=False, seed=23, bases_per_step=2)
+        assert agg["gates"] == 65 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+        assert abs(st.norm_sqr() - 1) < 1e-4
+
+
 # ---- N > 1 on one GPU: virtual shards (real kernels, host-staged exchange) and RCCL plumbing ----------------
 def _run_dist(nproc, extra):
     import os
