@@ -88,7 +88,7 @@ typedef struct qip_hip_state qip_hip_state; /* opaque device-resident state */
 const char* qip_hip_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int qip_hip_device_count(void);
-/* ABI version of this header (bumped on incompatible change). */
+/* ABI version of this header (bumped when entry points or options are added or changed). */
 int qip_hip_abi_version(void);
 /* Process-wide options.  "force_generic" = 1 routes every op (including the host twin
  * below) through the literal gather kernel; used by the parity tests to check both the

@@ -210,7 +210,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_gate1q_pair(E* __restrict__ st, uint64_t npairs,
                                                         Ins ins, uint64_t tmask, Sel low, Mat2<T> g) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A a0[U], a1[U];
@@ -313,7 +312,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_phase(E* __restrict__ st, uint64_t count, Ins ins,
                                                   Sel low, amp_t<T> value) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
@@ -332,7 +330,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_diag1q(E* __restrict__ st, uint64_t count, Ins ins,
                                                    uint64_t tmask, Sel low, amp_t<T> d0, amp_t<T> d1) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= count) return;
   uint64_t idx[U];
   A x[U];
@@ -355,7 +352,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_swap_bits(E* __restrict__ st, uint64_t npairs,
                                                       Ins ins, uint64_t amask, uint64_t bmask, Sel low) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= npairs) return;
   uint64_t i0[U];
   A xa[U], xb[U];
@@ -384,7 +380,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_swap_xlane2(E* __restrict__ st, uint64_t nitems,
                                                         Ins ins, uint32_t lb_w, uint64_t hmask, Sel low) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= nitems) return;
   const bool lbit = (threadIdx.x >> lb_w) & 1u;
   uint64_t i0[U];
@@ -413,7 +408,6 @@ template <typename T, int U, bool GUARD, bool NT, int NP, typename E = amp_t<T>>
 __global__ __launch_bounds__(kBlock) void k_swap_xlane1(E* __restrict__ st, uint64_t nitems,
                                                         Ins ins, uint32_t la_w, uint32_t lb_w, Sel low) {
   using A = E;
-  using M = amp_t<T>;
   if (GUARD && work_index<0>(0) >= nitems) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t ba = (lane >> la_w) & 1u, bb = (lane >> lb_w) & 1u;
