@@ -2519,11 +2519,13 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
     uint64_t blocked_nd = 0, blocked_d = 0;  // bits the skipped gates exchange across / only test
     bool skipped_inexact = false;            // some skipped gate rounds
     bool any_skipped = false;
+    size_t exch_gates = 0;  // gates that may open a pass (kTileMaxExchGates bounds the pass table)
     for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && st.ops.size() < (size_t)kTileMaxGates; ++i) {
       if (done[i]) continue;
       const TileItem& it = items[i];
       const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
-      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact) &&
+                  (it.kind == 1 || exch_gates < (size_t)kTileMaxExchGates);
       std::vector<uint32_t> need;
       if (fits) {
         // only bits the gate exchanges amplitudes across must be tile bits: a dense target, both swap bits;
@@ -2542,6 +2544,7 @@ static int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
         for (uint32_t p : need) st.high.push_back(p);
         st.ops.push_back(i);
         done[i] = 1;
+        exch_gates += it.kind != 1;
       } else {
         blocked_nd |= it.nd_mask;
         blocked_d |= it.d_mask;
@@ -2626,7 +2629,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
   std::vector<char> done(count, 0);
   uint64_t head = 0;
   const uint64_t window = 256;
-  const size_t max_circuit_ops = (size_t)kTileMaxGates;  // (closing swaps only go into segments with room left)
+  const size_t max_circuit_ops = (size_t)kTileMaxGates - (size_t)kTileLow;  // room for the segment's closing swaps
   while (head < count) {
     if (done[head]) {
       ++head;
@@ -2649,7 +2652,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
     TileStep st;
     uint64_t blocked_nd = 0, blocked_d = 0;
     bool skipped_inexact = false, any_skipped = false;
-    size_t joined = 0;
+    size_t joined = 0, exch_gates = 0;
     for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && joined < max_circuit_ops; ++i) {
       if (done[i]) continue;
       const TileItem& it = L[i];
@@ -2659,7 +2662,8 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
         continue;
       }
       const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
-      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact) &&
+                  (it.kind == 1 || exch_gates < (size_t)kTileMaxExchGates - (size_t)kTileLow);  // (room for the closing swaps)
       std::vector<uint32_t> need;
       if (fits) {
         std::vector<uint32_t> exch;
@@ -2681,6 +2685,7 @@ static int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint
         st.ops.push_back(at);
         done[i] = 1;
         joined += 1;
+        exch_gates += it.kind != 1;
       } else {
         blocked_nd |= it.nd_mask;
         blocked_d |= it.d_mask;

@@ -936,7 +936,11 @@ constexpr int kTileWaveBits = kTileLaneBits - kTileLow;  // tile bits 6.. that t
 // (Measured in round 2: kTileHigh = 6 — 64-KiB tiles, 512 lanes, 2 blocks per CU — cuts the configs[1] circuit from 19
 // to 15 sweeps but each sweep takes 11.8 ms instead of 6.8: 177 vs 129 ms.  Five resident blocks per CU are what
 // overlaps the load / LDS / store phases; profiles/r02_tile_variants.md.)
-constexpr int kTileMaxGates = 64;  // a gate riding along costs ~0.2 ms at n = 30, a new sweep 6.4 ms
+// A gate riding along costs 0.05-0.2 ms at n = 30, a new sweep ~6 ms, so segments may grow long.  Two caps: gates that
+// EXCHANGE amplitudes (dense targets, swaps) each may open a pass, and the pass table travels as a kernel argument;
+// diagonal gates (QFT's 435 controlled phases) open none and only lengthen the gate list in the arena.
+constexpr int kTileMaxExchGates = 64;
+constexpr int kTileMaxGates = 256;
 
 // Only the bits a gate EXCHANGES amplitudes across must lie inside the tile: the target of a dense gate, the
 // two bits of a swap.  Controls, and the target of a diagonal gate, may sit on any index bit: outside the tile
@@ -1099,7 +1103,7 @@ template <typename A> __device__ __forceinline__ uint32_t tile_slot(uint32_t t) 
   constexpr uint32_t S = sizeof(A) == 16 ? 4u : 5u;
   return t ^ ((t >> S) & ((1u << S) - 1u));
 }
-constexpr int kTileMaxPasses = kTileMaxGates;  // every gate closes at most one pass
+constexpr int kTileMaxPasses = kTileMaxExchGates;  // only a gate with exchange bits can close a pass
 struct TilePassDesc {
   uint32_t npasses;
   uint32_t hpos[kTileHigh];

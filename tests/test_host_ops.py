@@ -241,7 +241,7 @@ def test_tile_schedule_invariants():
                 free = set()
                 for i in st:
                     free |= {p for p in exchange_bits(ops[i]) if p >= 6}
-                assert len(free) <= 6 and len(st) <= 64
+                assert len(free) <= 6 and len(st) <= 256
                 assert all(len(flatten(ops[i])[2]) <= 3 for i in st)  # 1-qubit gates, swaps, dense 2- and 3-qubit gates
         assert [160] in steps  # the dense 4-qubit gate is launched on its own
         assert not [50] in steps and not [120] in steps  # the dense 2- and 3-qubit gates share a sweep
