@@ -58,6 +58,30 @@ def mixed_ops(n, rng, count):
     return ops
 
 
+def xy_ops(n, rng, count):
+    """X / Y walls and singles on every qubit (on a rank bit they only rename the ranks), interleaved with gates that read
+    those qubits as controls, as diagonal targets and as dense targets (the renaming has to be honoured / settled)"""
+    Y = [0, -1j, 1j, 0]
+    A = [0, 0.6 + 0.8j, 1j, 0]  # a general anti-diagonal gate
+    ops = []
+    for _ in range(count):
+        kind = int(rng.integers(0, 8))
+        perm = [int(v) for v in rng.permutation(n)]
+        if kind <= 2:
+            ops.append(q.make_matrix_op([perm[0]], [circuits.X, Y, A][kind]))
+        elif kind == 3:
+            ops.append(q.make_control_op([perm[0]], q.make_matrix_op([perm[1]], circuits.X)))
+        elif kind == 4:
+            ops.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], [1, 0, 0, np.exp(0.7j)])))
+        elif kind == 5:
+            ops.append(q.make_matrix_op([perm[0]], circuits.rz(0.3 + 0.1 * perm[0])))
+        elif kind == 6:
+            ops.append(q.make_matrix_op([perm[0]], circuits.H))
+        else:
+            ops += [q.make_matrix_op([t], circuits.X) for t in range(n)]  # a wall
+    return ops
+
+
 def apply_local(L, op, shard):
     out = np.zeros_like(shard)
     O.apply_op_overwrite(L, op, np.ascontiguousarray(shard), out)
@@ -83,7 +107,8 @@ def main():
                           ("qft", circuits.c3_qft(n)),
                           ("grover", circuits.c5_grover_iteration(n)),
                           ("grover_k3", circuits.c5_grover_iteration(n, dense_k3=True)),
-                          ("mixed", mixed_ops(n, rng, 60))):
+                          ("mixed", mixed_ops(n, rng, 60)),
+                          ("xy", xy_ops(n, rng, 80))):
             plan = sharded.debug_plan(n, rank, world, ops)
             assert (plan["g"], plan["L"], plan["rank"]) == (g, L, rank)
             shard = x[rank << L:(rank + 1) << L].copy()  # a fresh state: logical = physical

@@ -28,7 +28,7 @@ def test_sharded_state_matches_single_process(world):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    assert res.stdout.count("ok n=") == 15
+    assert res.stdout.count("ok n=") == 18
 
 
 def test_planner_at_bench_size_without_any_device():

@@ -205,7 +205,7 @@ def test_tile_schedule_invariants():
 
     def roles(o):  # qubit -> True when the op only TESTS the qubit (control / diagonal target), False when it exchanges
         ctrl, inner, tgt = flatten(o)
-        if len(tgt) >= 3:  # not tileable: every qubit counts as exchanged
+        if len(tgt) >= 4:  # not tileable: every qubit counts as exchanged
             return {t: False for t in list(ctrl) + list(tgt)}
         r = {c: True for c in ctrl}
         diag = inner.kind == "Matrix" and len(tgt) == 1 and not exchange_bits(o)
@@ -233,6 +233,25 @@ def test_tile_schedule_invariants():
                     if mode == 1:  # only rounding-free commutations keep the result IEEE-equal
                         assert exact(ops[a]) or exact(ops[b]), (a, b)
     assert 0 < overtakes[1] < overtakes[2] and shared > 0
+    # with the qubits relabelled (mode bits 2 + 3) the same ordering rules hold among the ops that are still ops (an
+    # uncontrolled Swap becomes a label exchange and appears in no step); swaps are put in here to see some absorbed
+    ops_sw = list(ops)
+    for at, (a, b) in ((70, (2, 17)), (150, (0, 9)), (260, (5, 6))):
+        ops_sw.insert(at, q.make_swap_op([a], [b]))
+    role_sw = [roles(o) for o in ops_sw]
+    for mode in (1 | 4 | 8, 2 | 4 | 8):
+        steps = plan_tiles(n, ops_sw, mode)
+        flat = [i for st in steps for i in st]
+        assert len(set(flat)) == len(flat)
+        gone = set(range(len(ops_sw))) - set(flat)
+        assert gone and all(ops_sw[i].kind == "Swap" for i in gone)
+        pos = {i: k for k, i in enumerate(flat)}
+        for a in flat:
+            for b in flat:
+                if a < b and pos[b] < pos[a]:
+                    assert all(role_sw[a][x] and role_sw[b][x] for x in role_sw[a].keys() & role_sw[b].keys()), (a, b)
+                    if mode & 3 == 1:
+                        assert exact(ops_sw[a]) or exact(ops_sw[b]), (a, b)
     for mode in (1, 2):
         steps = plan_tiles(n, ops, mode)
         for st in steps:
