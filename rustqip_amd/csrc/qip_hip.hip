@@ -2187,8 +2187,8 @@ static int hiprtc_compile(const std::string& src, std::vector<char>* code) {
   const char* hdr_name[1] = {"qip_kernels.h"};
   if (g_rtc.CreateProgram(&prog, src.c_str(), "qip_segment.hip", 1, hdr_src, hdr_name) != 0)
     return fail(QIP_ERR_DEVICE, "hiprtcCreateProgram failed");
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  const int rc = g_rtc.CompileProgram(prog, 4, opts);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};  // as rustqip_amd/build.py
+  const int rc = g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
   if (rc != 0) {
     size_t n = 0;
     g_rtc.GetProgramLogSize(prog, &n);
@@ -2243,7 +2243,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   L("using namespace qipk;");
   L(std::string("typedef ") + tname + " T;");
   L("typedef amp_t<T> A;");
-  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, ") + (sizeof(T) == 8 ? "5" : "1") + ") void qip_segment(A* __restrict__ st) {");
+  L("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st) {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
   L("  A* tile = reinterpret_cast<A*>(tile_raw);");
   L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
