@@ -1,0 +1,761 @@
+// qip_circuit.hip — apply_ops: gate fusion, tile sweeps (interpreter launches and run-time-compiled segments), hipGraph programs.
+#include "qip_tile.h"
+
+// ---------------------------------------------------------------------------------------
+// gate fusion: option "fuse" = K merges consecutive small gates into dense
+// gates on <= K qubits, applied in ONE sweep each.  The reference has no analogue (its apply_ops
+// multi-op path is unused and inconsistent); this is pure host bookkeeping on
+// 2^K x 2^K matrices.  Results equal the gate-by-gate path up to the rounding of the matrix
+// products (|delta| ~ 1e-15 per fused gate), so fused runs are held to the 1e-12 bar, never to
+// bit equality.  Open clusters always act on pairwise disjoint qubit sets, so they commute and
+// may be flushed in any order; an op is merged only into clusters it overlaps, or into a
+// disjoint one (which also commutes with every other open cluster).
+// ---------------------------------------------------------------------------------------
+typedef std::complex<double> cd;
+struct Cluster {
+  std::vector<uint32_t> pos;  // bit positions, descending: pos[0] is the MSB of the sub-index
+  std::vector<cd> m;          // 2^q x 2^q, row-major
+};
+
+// dense matrix of a flattened op over its own index list (controls first), MSB-first order
+template <typename T>
+static bool op_to_dense(uint32_t n, const FlatOp& f, uint32_t max_k, std::vector<uint32_t>* pos,
+                        std::vector<cd>* mat) {
+  if (!f.distinct || f.k_all > max_k) return false;
+  const uint32_t kt = f.k_all, k = f.n_op;
+  const size_t S = (size_t)1 << kt, Si = (size_t)1 << k, thr = S - Si;
+  pos->clear();
+  for (uint32_t j = 0; j < kt; ++j) pos->push_back(n - 1 - (uint32_t)f.outer->indices[j]);
+  mat->assign(S * S, cd(0, 0));
+  for (size_t r = 0; r < thr; ++r) (*mat)[r * S + r] = cd(1, 0);
+  const T* dense = static_cast<const T*>(f.inner->dense);
+  const T* vals = static_cast<const T*>(f.inner->sparse_vals);
+  for (size_t r = 0; r < Si; ++r) {
+    switch (f.inner->kind) {
+      case QIP_OP_MATRIX:
+        for (size_t c = 0; c < Si; ++c)
+          (*mat)[(thr + r) * S + thr + c] = cd(dense[2 * (r * Si + c)], dense[2 * (r * Si + c) + 1]);
+        break;
+      case QIP_OP_SPARSE:
+        for (uint64_t e = f.inner->sparse_rowptr[r]; e < f.inner->sparse_rowptr[r + 1]; ++e)
+          (*mat)[(thr + r) * S + thr + f.inner->sparse_cols[e]] += cd(vals[2 * e], vals[2 * e + 1]);
+        break;
+      default: {  // SWAP
+        const uint32_t h = k >> 1;
+        const size_t c = ((r & (((size_t)1 << h) - 1)) << h) + (r >> h);
+        (*mat)[(thr + r) * S + thr + c] = cd(1, 0);
+      }
+    }
+  }
+  return true;
+}
+
+// matrix of `m` (over positions `pos`, MSB first) embedded into the space of `upos` (descending)
+static std::vector<cd> embed(const std::vector<cd>& m, const std::vector<uint32_t>& pos,
+                             const std::vector<uint32_t>& upos) {
+  const uint32_t u = (uint32_t)upos.size(), k = (uint32_t)pos.size();
+  const size_t U = (size_t)1 << u, S = (size_t)1 << k;
+  std::vector<uint32_t> bit_in_u(k);
+  size_t opmask = 0;
+  for (uint32_t i = 0; i < k; ++i)
+    for (uint32_t j = 0; j < u; ++j)
+      if (upos[j] == pos[i]) {
+        bit_in_u[i] = u - 1 - j;
+        opmask |= (size_t)1 << (u - 1 - j);
+      }
+  auto sub = [&](size_t r) {
+    size_t s_ = 0;
+    for (uint32_t i = 0; i < k; ++i) s_ |= ((r >> bit_in_u[i]) & 1) << (k - 1 - i);
+    return s_;
+  };
+  std::vector<cd> e(U * U, cd(0, 0));
+  for (size_t r = 0; r < U; ++r)
+    for (size_t c = 0; c < U; ++c)
+      if ((r & ~opmask) == (c & ~opmask)) e[r * U + c] = m[sub(r) * S + sub(c)];
+  return e;
+}
+
+static void cluster_apply(Cluster* cl, const std::vector<uint32_t>& pos, const std::vector<cd>& m) {
+  std::vector<uint32_t> upos = cl->pos;
+  for (uint32_t p : pos)
+    if (std::find(upos.begin(), upos.end(), p) == upos.end()) upos.push_back(p);
+  std::sort(upos.begin(), upos.end(), std::greater<uint32_t>());
+  const size_t U = (size_t)1 << upos.size();
+  const std::vector<cd> a = embed(m, pos, upos);              // the new gate, applied after
+  const std::vector<cd> b = embed(cl->m, cl->pos, upos);      // what the cluster already holds
+  std::vector<cd> out(U * U, cd(0, 0));
+  for (size_t r = 0; r < U; ++r)
+    for (size_t k = 0; k < U; ++k) {
+      const cd v = a[r * U + k];
+      if (v == cd(0, 0)) continue;
+      for (size_t c = 0; c < U; ++c) out[r * U + c] += v * b[k * U + c];
+    }
+  cl->pos = upos;
+  cl->m = out;
+}
+
+template <typename T>
+static int flush_cluster(qip_hip_state* s, const Cluster& cl) {
+  const size_t S = (size_t)1 << cl.pos.size();
+  std::vector<uint64_t> idx;
+  for (uint32_t p : cl.pos) idx.push_back(s->n - 1 - p);
+  std::vector<T> data(2 * S * S);
+  for (size_t e = 0; e < S * S; ++e) {
+    data[2 * e] = (T)cl.m[e].real();
+    data[2 * e + 1] = (T)cl.m[e].imag();
+  }
+  qip_op op;
+  memset(&op, 0, sizeof op);
+  op.kind = QIP_OP_MATRIX;
+  op.n_indices = (uint32_t)idx.size();
+  op.indices = idx.data();
+  op.dense = data.data();
+  return apply_op_t<T>(s, &op);
+}
+
+template <typename T>
+int apply_ops_fused(qip_hip_state* s, const qip_op* ops, uint64_t count, uint32_t K) {
+  std::vector<Cluster> open;
+  auto overlaps = [](const Cluster& c, const std::vector<uint32_t>& pos) {
+    for (uint32_t p : pos)
+      if (std::find(c.pos.begin(), c.pos.end(), p) != c.pos.end()) return true;
+    return false;
+  };
+  auto flush_overlapping = [&](const std::vector<uint32_t>& pos) -> int {
+    for (size_t i = 0; i < open.size();) {
+      if (overlaps(open[i], pos)) {
+        QCHK(flush_cluster<T>(s, open[i]));
+        open.erase(open.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+    return QIP_OK;
+  };
+  for (uint64_t i = 0; i < count; ++i) {
+    FlatOp f;
+    int rc = flatten_op(s->n, &ops[i], false, &f);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+    std::vector<uint32_t> pos;
+    std::vector<cd> m;
+    if (!op_to_dense<T>(s->n, f, K, &pos, &m)) {
+      // not fusable (too many qubits / repeated indices): everything it touches goes first
+      std::vector<uint32_t> all;
+      for (uint32_t j = 0; j < f.k_all; ++j) all.push_back(s->n - 1 - (uint32_t)f.outer->indices[j]);
+      QCHK(flush_overlapping(all));
+      QCHK(apply_op_t<T>(s, &ops[i]));
+      continue;
+    }
+    std::vector<size_t> hit;
+    size_t union_size = pos.size();
+    for (size_t c = 0; c < open.size(); ++c)
+      if (overlaps(open[c], pos)) {
+        hit.push_back(c);
+        for (uint32_t p : open[c].pos)
+          if (std::find(pos.begin(), pos.end(), p) == pos.end()) ++union_size;
+      }
+    if (hit.empty()) {
+      // disjoint from every open cluster: join the fullest one that still has room
+      size_t best = open.size();
+      for (size_t c = 0; c < open.size(); ++c)
+        if (open[c].pos.size() + pos.size() <= K && (best == open.size() || open[c].pos.size() > open[best].pos.size()))
+          best = c;
+      if (best == open.size()) {
+        Cluster cl;
+        cl.pos = {};
+        cl.m = {cd(1, 0)};
+        open.push_back(cl);
+      }
+      cluster_apply(&open[best], pos, m);
+    } else if (union_size <= K) {
+      // merge the overlapped clusters (mutually disjoint => their product is a Kronecker product)
+      for (size_t h = 1; h < hit.size(); ++h) cluster_apply(&open[hit[0]], open[hit[h]].pos, open[hit[h]].m);
+      for (size_t h = hit.size(); h-- > 1;) open.erase(open.begin() + hit[h]);
+      cluster_apply(&open[hit[0]], pos, m);
+    } else {
+      QCHK(flush_overlapping(pos));
+      Cluster cl;
+      cl.pos = {};
+      cl.m = {cd(1, 0)};
+      cluster_apply(&cl, pos, m);
+      open.push_back(cl);
+    }
+  }
+  for (const Cluster& cl : open) QCHK(flush_cluster<T>(s, cl));
+  return QIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Segment-specialised tile sweeps (option "tile_jit"): the interpreter k_tile_passes spends most of its issue slots
+// on decoding — per gate and per wave ~54 scalar + ~58 vector instructions that only depend on the segment
+// (profiles/r01_tile_pmc.md).  Here the host writes the segment out as straight-line HIP source — the same load /
+// pass / store skeleton, one call of the very same pass_* helper per gate with the gate descriptor as a constexpr
+// value — and compiles it with hiprtc against the embedded qip_kernels.h.  Every op code, bit position, control mask,
+// zero / real / X flag folds away; what is left per gate is its arithmetic, operation for operation what the
+// interpreter executes, so results are bit-identical.  Kernels are cached per process by their source text, so a
+// circuit replayed many times (programs, variational loops with fixed angles) compiles once (~0.3-1 s per segment).
+// ---------------------------------------------------------------------------------------
+static const char kKernelsHeaderSrc[] =
+#include "qip_kernels_embed.inc"
+    ;
+
+struct Hiprtc {
+  void* handle = nullptr;
+  int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*CompileProgram)(void*, int, const char**) = nullptr;
+  int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+  int (*GetProgramLog)(void*, char*) = nullptr;
+  int (*GetCodeSize)(void*, size_t*) = nullptr;
+  int (*GetCode)(void*, char*) = nullptr;
+  int (*DestroyProgram)(void**) = nullptr;
+};
+static Hiprtc g_rtc;
+static int hiprtc_load() {
+  if (g_rtc.handle) return QIP_OK;
+  void* h = nullptr;
+  for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) return fail(QIP_ERR_UNSUPPORTED, "option tile_jit needs libhiprtc: %s", dlerror());
+#define RSYM(field, name)                                                           \
+  do {                                                                              \
+    *(void**)(&g_rtc.field) = dlsym(h, name);                                       \
+    if (!g_rtc.field) return fail(QIP_ERR_UNSUPPORTED, "libhiprtc lacks %s", name); \
+  } while (0)
+  RSYM(CreateProgram, "hiprtcCreateProgram");
+  RSYM(CompileProgram, "hiprtcCompileProgram");
+  RSYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+  RSYM(GetProgramLog, "hiprtcGetProgramLog");
+  RSYM(GetCodeSize, "hiprtcGetCodeSize");
+  RSYM(GetCode, "hiprtcGetCode");
+  RSYM(DestroyProgram, "hiprtcDestroyProgram");
+#undef RSYM
+  g_rtc.handle = h;
+  return QIP_OK;
+}
+
+// source -> code object (host only: works without a device, which is how the CPU tests cover it)
+static int hiprtc_compile(const std::string& src, std::vector<char>* code) {
+  QCHK(hiprtc_load());
+  void* prog = nullptr;
+  const char* hdr_src[1] = {kKernelsHeaderSrc};
+  const char* hdr_name[1] = {"qip_kernels.h"};
+  if (g_rtc.CreateProgram(&prog, src.c_str(), "qip_segment.hip", 1, hdr_src, hdr_name) != 0)
+    return fail(QIP_ERR_DEVICE, "hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};  // as rustqip_amd/build.py
+  const int rc = g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+  if (rc != 0) {
+    size_t n = 0;
+    g_rtc.GetProgramLogSize(prog, &n);
+    std::string log(n + 1, '\0');
+    if (n) g_rtc.GetProgramLog(prog, &log[0]);
+    g_rtc.DestroyProgram(&prog);
+    return fail(QIP_ERR_DEVICE, "hiprtc could not compile a tile segment (%d): %.800s", rc, log.c_str());
+  }
+  size_t sz = 0;
+  g_rtc.GetCodeSize(prog, &sz);
+  code->resize(sz);
+  g_rtc.GetCode(prog, code->data());
+  g_rtc.DestroyProgram(&prog);
+  return QIP_OK;
+}
+
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+};
+static std::map<std::string, JitKernel> g_jit_cache;  // key: device ordinal + source text
+static uint64_t g_jit_compiles = 0;
+static double g_jit_compile_ms = 0;
+
+extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
+  if (kernels_compiled) *kernels_compiled = g_jit_compiles;
+  if (compile_ms) *compile_ms = g_jit_compile_ms;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+template <typename T> static std::string fnum(T v) {
+  char buf[64];
+  if (std::is_same<T, double>::value) snprintf(buf, sizeof buf, "%.17g", (double)v);
+  else snprintf(buf, sizeof buf, "%.9gf", (double)v);
+  std::string r = buf;
+  // a bare integer literal would not be floating point ("1" / "1f")
+  if (std::is_same<T, double>::value && r.find_first_of(".eEn") == std::string::npos) r += ".0";
+  if (!std::is_same<T, double>::value && r.find_first_of(".eEn") == std::string::npos) r.insert(r.size() - 1, ".0");
+  return r;
+}
+
+// The segment as HIP source (see the block comment above).  Mirrors k_tile_passes statement by statement.
+template <typename T>
+static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt) {
+  const char* tname = std::is_same<T, double>::value ? "double" : "float";
+  std::string o;
+  auto L = [&](const std::string& line) { o += line; o += "\n"; };
+  auto U = [](uint64_t v) { return std::to_string(v) + "ull"; };
+  auto amp = [&](amp_t<T> a) { return "{" + fnum<T>(a.x) + ", " + fnum<T>(a.y) + "}"; };
+  const TilePassDesc& d = plan.pd;
+  L("#include \"qip_kernels.h\"");
+  L("using namespace qipk;");
+  L(std::string("typedef ") + tname + " T;");
+  L("typedef amp_t<T> A;");
+  L("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st) {");
+  L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
+  L("  A* tile = reinterpret_cast<A*>(tile_raw);");
+  L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
+  L("  const uint32_t tid = threadIdx.x, lane = tid & 63u;");
+  L("  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);");
+  L("  uint64_t wbase = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow;");
+  for (uint32_t j = 0; j < ins.npos; ++j) {  // insert_bits with the positions as literals
+    const std::string p = std::to_string(ins.pos[j]);
+    L("  wbase = ((wbase >> " + p + ") << " + std::to_string(ins.pos[j] + 1) + ") | (wbase & ((1ull << " + p + ") - 1ull));");
+  }
+  if (ins.ormask) L("  wbase |= " + U(ins.ormask) + ";");
+  L("  const uint64_t base = wbase;");
+  for (int j = 0; j < kTileWaveBits; ++j)
+    L("  wbase |= (uint64_t)((wave >> " + std::to_string(j) + ") & 1u) << " + std::to_string(d.hpos[j]) + ";");
+  L("  const uint32_t slot_tid = tile_slot<A>(tid);");
+  auto ub = [&](int u) {
+    uint64_t off = 0;
+    for (int b = 0; b < 3; ++b)
+      if ((u >> b) & 1) off |= 1ull << d.hpos[kTileWaveBits + b];
+    return U(off);
+  };
+  L("  {");
+  L("    A x[8];");
+  for (int u = 0; u < 8; ++u) L("    x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
+  for (int u = 0; u < 8; ++u)
+    L("    tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)] = x[" + std::to_string(u) + "];");
+  L("  }");
+  L("  __syncthreads();");
+  for (uint32_t pi = 0; pi < d.npasses; ++pi) {
+    const TilePass& ps = d.pass[pi];
+    L("  {  // pass " + std::to_string(pi));
+    L("    uint32_t tb = 0;");
+    for (int k = 0; k < kTileLaneBits; ++k)
+      L("    tb |= ((tid >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
+    L("    const uint32_t slot_tb = tile_slot<A>(tb);");
+    std::string cs = "    const uint32_t c[8] = {";
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t c = ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) | ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+      cs += std::to_string(c) + "u" + (i < 7 ? ", " : "};");
+    }
+    L(cs);
+    L("    A e[8];");
+    for (int i = 0; i < 8; ++i) L("    e[" + std::to_string(i) + "] = tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])];");
+    for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+      const TileGate<T>& g = plan.gates[gi];
+      L("    {  // gate " + std::to_string(gi));
+      L("      constexpr TileGate<T> g = {" + std::to_string(g.kind) + "u, " + std::to_string(g.b0) + "u, " + std::to_string(g.b1) + "u, " +
+        std::to_string(g.cmask) + "u, " + std::to_string(g.nz) + "u, " + std::to_string(g.tpos_out) + "u, " + U(g.omask) + ", " +
+        std::to_string(g.op) + "u, " + std::to_string(g.cm_reg) + "u, " + std::to_string(g.cm_lane) + "u, 0u, {" + amp(g.m[0]) + ", " +
+        amp(g.m[1]) + ", " + amp(g.m[2]) + ", " + amp(g.m[3]) + "}};");
+      const std::string lane_args = "g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane";
+      std::string call;
+      switch (g.op) {
+        case TOP_DIAG_UNIFORM:
+          call = "const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0]; if (!(f.x == (T)1 && f.y == (T)0)) pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+          break;
+        case TOP_DIAG_LANE:
+        case TOP_DIAG_LANE_CTL:
+          call = std::string("const bool one = ") + (g.b0 == kTileOutside ? "((base >> g.tpos_out) & 1ull) != 0" : "((tb >> g.b0) & 1u) != 0") +
+                 "; A f = tile_sel(one, g.m[1], g.m[0]); " +
+                 (g.op == TOP_DIAG_LANE_CTL ? "{ const bool lane_ok = (tb & g.cm_lane) == g.cm_lane; f.x = lane_ok ? f.x : (T)1; f.y = lane_ok ? f.y : (T)0; } " : "") +
+                 "pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+          break;
+        case TOP_DIAG_REG0: case TOP_DIAG_REG1: case TOP_DIAG_REG2:
+          call = "pass_diag<T, " + std::to_string(g.op - TOP_DIAG_REG0) + ">(g, e, c, g.cm_reg, " + lane_args + ");";
+          break;
+        case TOP_DENSE0: case TOP_DENSE1: case TOP_DENSE2:
+          call = "pass_dense<T, " + std::to_string(g.op - TOP_DENSE0) + ">(g, e, c, g.cm_reg);";
+          break;
+        case TOP_DENSE_LANE0: case TOP_DENSE_LANE1: case TOP_DENSE_LANE2:
+          call = "pass_dense_lane<T, " + std::to_string(g.op - TOP_DENSE_LANE0) + ">(g, e, c, g.cm_reg, (tb & g.cm_lane) == g.cm_lane);";
+          break;
+        case TOP_DENSE2Q_01: case TOP_DENSE2Q_02: case TOP_DENSE2Q_10: case TOP_DENSE2Q_12: case TOP_DENSE2Q_20: case TOP_DENSE2Q_21: {
+          static const int ja[6] = {0, 0, 1, 1, 2, 2}, jb[6] = {1, 2, 0, 2, 0, 1};
+          std::string m = "const A M[16] = {";
+          for (int e = 0; e < 16; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 15 ? ", " : "}; ");
+          call = m + "pass_dense2<T, " + std::to_string(ja[g.op - TOP_DENSE2Q_01]) + ", " + std::to_string(jb[g.op - TOP_DENSE2Q_01]) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
+          break;
+        }
+        case TOP_DENSE3Q_012: case TOP_DENSE3Q_021: case TOP_DENSE3Q_102: case TOP_DENSE3Q_120: case TOP_DENSE3Q_201: case TOP_DENSE3Q_210: {
+          static const int ja[6] = {0, 0, 1, 1, 2, 2}, jb[6] = {1, 2, 0, 2, 0, 1};
+          const int a = ja[g.op - TOP_DENSE3Q_012], b = jb[g.op - TOP_DENSE3Q_012];
+          std::string m = "const A M[64] = {";
+          for (int e = 0; e < 64; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 63 ? ", " : "}; ");
+          call = m + "pass_dense3<T, " + std::to_string(a) + ", " + std::to_string(b) + ", " + std::to_string(3 - a - b) + ">(M, e, " + lane_args + ");";
+          break;
+        }
+        case TOP_SWAP_01: call = "pass_swap<T, 0, 1>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        case TOP_SWAP_02: call = "pass_swap<T, 0, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        case TOP_SWAP_12: call = "pass_swap<T, 1, 2>(e, c, g.cm_reg, " + lane_args + ");"; break;
+        default: break;
+      }
+      if (g.omask) L("      if ((base & g.omask) == g.omask) { " + call + " }");  // an outside control is 0 for this whole tile
+      else L("      { " + call + " }");
+      L("    }");
+    }
+    for (int i = 0; i < 8; ++i) L("    tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])] = e[" + std::to_string(i) + "];");
+    L("    __syncthreads();");
+    L("  }");
+  }
+  for (int u = 0; u < 8; ++u)
+    L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+  L("}");
+  return o;
+}
+
+static int jit_get_kernel(qip_hip_state* s, const std::string& src, hipFunction_t* fn) {
+  const std::string key = std::to_string(s->device) + "\n" + src;
+  auto it = g_jit_cache.find(key);
+  if (it != g_jit_cache.end()) {
+    *fn = it->second.fn;
+    return QIP_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<char> code;
+  QCHK(hiprtc_compile(src, &code));
+  JitKernel k;
+  HIPCHK(hipModuleLoadData(&k.module, code.data()));
+  HIPCHK(hipModuleGetFunction(&k.fn, k.module, "qip_segment"));
+  g_jit_compiles += 1;
+  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  g_jit_cache[key] = k;
+  *fn = k.fn;
+  return QIP_OK;
+}
+
+template <typename T>
+static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
+                               std::vector<uint32_t> high_in) {
+  TileSegmentPlan<T> plan;
+  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan));
+  const std::vector<uint32_t>& high = plan.high;
+  std::vector<TileGate<T>>& gates = plan.gates;
+  std::vector<amp_t<T>>& mats = plan.mats;
+  TilePassDesc& pd = plan.pd;
+  const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
+  static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
+  auto upload_gates = [&]() -> int {  // after the gates are final (k_tile_passes resolves them per pass first)
+    QCHK(ensure_arena(s, gates_bytes + mats.size() * sizeof(amp_t<T>)));  // one allocation: growing frees the old arena
+    QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
+    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
+    return QIP_OK;
+  };
+  TileDesc d;
+  memset(&d, 0, sizeof d);
+  d.ngates = (uint32_t)gates.size();
+  for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
+  Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
+  const uint64_t ntiles = 1ull << (s->n - kTileBits);
+  const size_t lds = sizeof(amp_t<T>) << kTileBits;
+  const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
+  const amp_t<T>* dmats = nullptr;
+  ProfRec rec;
+  rec.cls = KC_TILE_GATES;
+  auto begin = [&]() -> int {  // descriptors up, then the timed region starts
+    QCHK(upload_gates());
+    dg = (const TileGate<T>*)s->arena;
+    dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    return QIP_OK;
+  };
+  if (s->tile_passes && s->tile_jit) {
+    // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
+    hipFunction_t fn = nullptr;
+    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s)), &fn));
+    if (s->jit_prepare) return QIP_OK;
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    void* st_ptr = s->cur;
+    void* args[] = {&st_ptr};
+    const dim3 grid = grid2d(ntiles, 1);
+    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+    if (s->profile) QCHK(prof_end(s, &rec));
+    return QIP_OK;
+  }
+  if (s->jit_prepare) return QIP_OK;
+  if (s->tile_passes) {
+    QCHK(begin());
+#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
+                                   (amp_t<T>*)s->cur, ins, pd, dg, dmats)
+    if (use_nt(s)) TP(true);
+    else TP(false);
+#undef TP
+  } else {
+    QCHK(begin());
+    if (use_nt(s))
+      hipLaunchKernelGGL((k_tile_gates<T, true>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, d, dg);
+    else
+      hipLaunchKernelGGL((k_tile_gates<T, false>), grid2d(ntiles, 1), dim3(kBlock), lds, s->stream,
+                         (amp_t<T>*)s->cur, ins, d, dg);
+  }
+  HIPCHK(hipGetLastError());
+  if (s->profile) QCHK(prof_end(s, &rec));
+  return QIP_OK;
+}
+
+template <typename T>
+static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* nseg, uint64_t* src_bytes,
+                       uint64_t* code_bytes, std::string* first) {
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  const std::vector<TileItem>& items = sc.items;
+  *nseg = *src_bytes = *code_bytes = 0;
+  for (const TileStep& st : sc.steps) {
+    if (st.ops.size() < 2 || !st.perm.empty()) continue;
+    std::vector<const TileItem*> seg;
+    for (uint64_t i : st.ops) seg.push_back(&items[i]);
+    TileSegmentPlan<T> plan;
+    QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+    Ins ins = make_ins(plan.high, 0);
+    const std::string src = tile_jit_source<T>(plan, ins, true);
+    std::vector<char> code;
+    QCHK(hiprtc_compile(src, &code));
+    if (*nseg == 0 && first) *first = src;
+    *nseg += 1;
+    *src_bytes += src.size();
+    *code_bytes += code.size();
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* segments,
+                                      uint64_t* source_bytes, uint64_t* code_bytes, const char** first_source) try {
+  static thread_local std::string first;
+  if ((count && !ops) || !segments || !source_bytes || !code_bytes) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
+  first.clear();
+  QCHK(dtype == QIP_C64 ? debug_jit_t<double>(dtype, n, ops, count, mode, segments, source_bytes, code_bytes, &first)
+                        : debug_jit_t<float>(dtype, n, ops, count, mode, segments, source_bytes, code_bytes, &first));
+  if (first_source) *first_source = first.c_str();
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
+
+static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
+  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel >= 2 ? 8 : 0);
+}
+
+template <typename T>
+static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t count, bool /*reorder*/) {
+  TileSchedule sc;
+  QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc));
+  {
+    // a bit-permutation sweep is out of place: get the second buffer BEFORE the first gate runs; if HBM cannot hold it
+    // (a state above half of the 288 GB), fall back to the plan without permutation sweeps instead of failing half way
+    bool permutes = false;
+    for (const TileStep& st : sc.steps) permutes = permutes || !st.perm.empty();
+    if (permutes && !s->jit_prepare && !s->alt && ensure_alt(s) != QIP_OK) {
+      (void)hipGetLastError();
+      sc = TileSchedule();
+      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc, /*allow_permute=*/false));
+    }
+  }
+  const qip_op* ops = sc.circuit;
+  const std::vector<TileItem>& items = sc.items;
+  for (const TileStep& st : sc.steps) {
+    if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
+      if (s->jit_prepare) continue;
+      QCHK(launch_permute(s, st.perm.data()));
+      continue;
+    }
+    if (st.ops.size() == 1) {
+      QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
+      continue;
+    }
+    std::vector<const TileItem*> seg;
+    for (uint64_t i : st.ops) seg.push_back(&items[i]);
+    QCHK(launch_tile_segment<T>(s, seg, st.high));
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) try {
+  STATE_ENTER(s);
+  if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
+  if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
+    return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
+                               : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
+  if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
+    const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, kMaxMfmaK);  // both precisions have a matrix-core k = 5 kernel
+    if (s->n >= K + 4)
+      return s->dtype == QIP_C64 ? apply_ops_fused<double>(s, ops, count, K) : apply_ops_fused<float>(s, ops, count, K);
+  }
+  for (uint64_t i = 0; i < count; ++i) {
+    int rc = s->dtype == QIP_C64 ? apply_op_t<double>(s, &ops[i]) : apply_op_t<float>(s, &ops[i]);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+  }
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
+// programs: a circuit captured once into a hipGraph and replayed with one launch
+// ---------------------------------------------------------------------------------------
+struct qip_hip_program {
+  qip_hip_state* s = nullptr;
+  const qip_op* ops = nullptr;
+  uint64_t count = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  void* captured_cur = nullptr;
+  uint64_t captured_arena_gen = 0;  // the graph's memcpy / kernel nodes hold arena addresses
+  std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
+  int last_was_graph = 0;
+};
+
+static void program_drop_graph(qip_hip_program* p);
+void programs_orphan(qip_hip_state* s) {
+  for (qip_hip_program* p : s->programs) {
+    program_drop_graph(p);
+    p->s = nullptr;
+  }
+  s->programs.clear();
+}
+
+static void program_drop_graph(qip_hip_program* p) {
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  p->exec = nullptr;
+  p->graph = nullptr;
+  p->staging.clear();
+}
+
+// Try to capture; on any obstacle leave the program in eager mode (exec == nullptr) and report success.
+static int program_capture(qip_hip_program* p) {
+  qip_hip_state* s = p->s;
+  program_drop_graph(p);
+  if (s->force_generic || g_force_generic || s->profile) return QIP_OK;
+  // an op on the out-of-place path would swap the buffers under the graph: stay eager
+  for (uint64_t i = 0; i < p->count; ++i) {
+    FlatOp f;
+    QCHK(flatten_op(s->n, &p->ops[i], false, &f));
+    Plan pl;
+    QCHK(make_plan(s->dtype, s->n, f, false, &pl));
+    const bool f64 = s->dtype == QIP_C64;
+    const uint32_t k = f.n_op;
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
+    (void)f64;
+    if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
+  }
+  if (s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too
+    TileSchedule sc;
+    QCHK(make_tile_schedule(s->dtype, s->n, p->ops, p->count, tile_mode_of(s), s->tile_passes != 0, &sc));
+    for (const TileStep& st : sc.steps)
+      if (!st.perm.empty()) return QIP_OK;
+  }
+  if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now
+    s->jit_prepare = true;
+    const int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
+    s->jit_prepare = false;
+    QCHK(rc);
+  }
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    s->capture_arena_need = 0;
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      (void)hipGetLastError();
+      return QIP_OK;
+    }
+    s->capture_staging = &p->staging;
+    int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
+    s->capture_staging = nullptr;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (rc == QIP_OK && e == hipSuccess && g) {
+      if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+        p->graph = g;
+        p->captured_cur = s->cur;
+        p->captured_arena_gen = s->arena_gen;
+        return QIP_OK;
+      }
+      (void)hipGetLastError();
+      (void)hipGraphDestroy(g);
+      p->exec = nullptr;
+      p->staging.clear();
+      return QIP_OK;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    p->staging.clear();
+    if (s->capture_arena_need > s->arena_cap) {  // grow outside the capture, then retry
+      const size_t need = s->capture_arena_need;
+      s->capture_arena_need = 0;
+      QCHK(ensure_arena(s, need));
+      continue;
+    }
+    if (rc != QIP_OK && rc != QIP_ERR_UNSUPPORTED) return rc;  // a real descriptor error
+    return QIP_OK;
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint64_t count,
+                                      qip_hip_program** out) try {
+  STATE_ENTER(s);
+  if (!out || (count && !ops)) return fail(QIP_ERR_INVALID, "null argument");
+  for (uint64_t i = 0; i < count; ++i) {
+    FlatOp f;
+    int rc = flatten_op(s->n, &ops[i], false, &f);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+  }
+  qip_hip_program* p = new qip_hip_program();
+  p->s = s;
+  p->ops = ops;
+  p->count = count;
+  int rc = program_capture(p);
+  if (rc != QIP_OK) {
+    delete p;
+    return rc;
+  }
+  s->programs.push_back(p);
+  *out = p;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_program_run(qip_hip_program* p) try {
+  if (!p) return fail(QIP_ERR_INVALID, "null program");
+  qip_hip_state* s = p->s;
+  if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
+  STATE_ENTER(s);
+  if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen || s->profile || s->force_generic ||
+                  g_force_generic)) {
+    if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
+    else QCHK(program_capture(p));  // the state moved to its other buffer, or the arena was re-allocated (an eager op
+                                    // needed a larger payload): the recorded addresses are stale, re-record
+  }
+  if (p->exec) {
+    HIPCHK(hipGraphLaunch(p->exec, s->stream));
+    p->last_was_graph = 1;
+    return QIP_OK;
+  }
+  p->last_was_graph = 0;
+  return qip_hip_state_apply_ops(s, p->ops, p->count);
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_program_is_graph(const qip_hip_program* p) try { return p ? p->last_was_graph : 0; } QIP_CATCH_ALL
+
+extern "C" int qip_hip_program_destroy(qip_hip_program* p) try {
+  if (!p) return QIP_OK;
+  if (p->s) {
+    (void)hipSetDevice(p->s->device);
+    (void)hipStreamSynchronize(p->s->stream);
+    auto& v = p->s->programs;
+    v.erase(std::remove(v.begin(), v.end(), p), v.end());
+  }
+  program_drop_graph(p);
+  delete p;
+  return QIP_OK;
+} QIP_CATCH_ALL
+

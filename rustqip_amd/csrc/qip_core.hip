@@ -1,0 +1,547 @@
+// qip_core.hip — C ABI (include/qip_hip.h) over the gfx950 kernels in qip_kernels.h: errors, options, op validation,
+// kernel choice, state handles, profiling.  (The other translation units: qip_internal.h.)
+//
+// Host side of the drop-in boundary: validates op descriptors the way the reference's
+// constructors do (qip/src/state_ops/matrix_ops.rs:12-122), classifies each op into the
+// cheapest kernel that is result-identical to the reference's gather formulation
+// (qip-iterators/src/matrix_ops.rs:62-152), and launches it on the handle's HIP stream.
+// There is NO CPU fallback: without a HIP device every compute entry point fails with
+// QIP_ERR_NO_DEVICE.
+#include "qip_internal.h"
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+
+extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int qip_hip_abi_version(void) { return 3; }  // 3: + permute_bits, dist_rank_flip, options tile_relabel / perm_rows / line_bits
+extern "C" int qip_hip_device_count(void) try {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return c;
+} QIP_CATCH_ALL
+
+int64_t g_force_generic = 0;
+// Selector bits below this position stay in the grid as a per-lane predicate (whole lines are swept); see kLineBits.
+uint32_t g_line_bits = qipk::kLineBits;
+int64_t g_perm_rows = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
+  if (key && !strcmp(key, "force_generic")) {
+    g_force_generic = value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "perm_rows")) {
+    if (value != 0 && value != 5 && value != 6) return fail(QIP_ERR_INVALID, "perm_rows must be 0 (automatic), 5 or 6");
+    g_perm_rows = value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "line_bits")) {  // tuning aid (tools/bench_ops.py): 0..3
+    if (value < 0 || value > 3) return fail(QIP_ERR_INVALID, "line_bits must be 0..3");
+    g_line_bits = (uint32_t)value;
+    return QIP_OK;
+  }
+  return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
+} QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
+// op flattening + validation
+// ---------------------------------------------------------------------------------------
+
+// strict = what make_*_op rejects; always = what would panic / read out of bounds in the
+// reference kernel.
+int flatten_op(uint32_t n, const qip_op* op, bool strict, FlatOp* f) {
+  if (!op) return fail(QIP_ERR_INVALID, "null op");
+  if (n == 0 || n > 62) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 62]", n);
+  if (op->kind < QIP_OP_MATRIX || op->kind > QIP_OP_CONTROL)
+    return fail(QIP_ERR_INVALID, "unknown op kind %d", op->kind);
+  if (op->n_indices == 0)
+    return fail(QIP_ERR_INVALID, "Must supply at least one op index");  // matrix_ops.rs:15-16
+  if (op->n_indices > (uint32_t)kMaxIns || !op->indices)
+    return fail(QIP_ERR_INVALID, "op has %u indices (max %d) or a null index list", op->n_indices,
+                kMaxIns);
+  f->outer = op;
+  f->k_all = op->n_indices;
+  uint64_t seen = 0;
+  for (uint32_t j = 0; j < op->n_indices; ++j) {
+    if (op->indices[j] >= n)
+      return fail(QIP_ERR_INVALID, "qubit index %llu out of range for n = %u",
+                  (unsigned long long)op->indices[j], n);
+    if (seen & (1ull << op->indices[j])) f->distinct = false;
+    seen |= 1ull << op->indices[j];
+  }
+  const qip_op* inner = op;
+  uint32_t n_control = 0, n_op = op->n_indices;
+  if (op->kind == QIP_OP_CONTROL) {
+    if (op->n_controls == 0)
+      return fail(QIP_ERR_INVALID, "Must supply at least one control index");  // :107-108
+    if (op->n_controls >= op->n_indices)
+      return fail(QIP_ERR_INVALID, "Control op needs at least one op index after its %u controls",
+                  op->n_controls);
+    if (!op->inner) return fail(QIP_ERR_INVALID, "Control op without inner op");
+    n_control = op->n_controls;
+    n_op = op->n_indices - op->n_controls;
+    inner = op->inner;
+    int depth = 0;
+    while (inner->kind == QIP_OP_CONTROL) {
+      if (!inner->inner || inner->n_controls == 0 || inner->n_controls >= inner->n_indices ||
+          ++depth > 64)
+        return fail(QIP_ERR_INVALID, "malformed nested Control op");
+      n_control += inner->n_controls;
+      n_op = inner->n_indices - inner->n_controls;
+      inner = inner->inner;
+    }
+    if (inner->kind < QIP_OP_MATRIX || inner->kind > QIP_OP_SWAP)
+      return fail(QIP_ERR_INVALID, "unknown inner op kind %d", inner->kind);
+    if (n_control + n_op != op->n_indices)
+      return fail(QIP_ERR_INVALID,
+                  "Control op lists %u indices but its controls (%u) + inner op indices (%u) differ",
+                  op->n_indices, n_control, n_op);
+  }
+  f->inner = inner;
+  f->n_control = n_control;
+  f->n_op = n_op;
+  if (n_op > 30) return fail(QIP_ERR_UNSUPPORTED, "inner op on %u qubits is too large", n_op);
+  switch (inner->kind) {
+    case QIP_OP_MATRIX:
+      if (!inner->dense) return fail(QIP_ERR_INVALID, "Matrix op without data");
+      // make_matrix_op :17-23 checks dat.len() == 4^k; here the length is implied by the
+      // ABI (4^n_op entries are read).  inner->indices are ignored, as in the reference.
+      break;
+    case QIP_OP_SPARSE: {
+      if (!inner->sparse_rowptr) return fail(QIP_ERR_INVALID, "Sparse op without row pointers");
+      const uint64_t rows = 1ull << n_op;
+      if (inner->sparse_rowptr[0] != 0) return fail(QIP_ERR_INVALID, "Sparse rowptr[0] != 0");
+      for (uint64_t r = 0; r < rows; ++r) {
+        if (inner->sparse_rowptr[r + 1] < inner->sparse_rowptr[r])
+          return fail(QIP_ERR_INVALID, "Sparse rowptr not monotone at row %llu",
+                      (unsigned long long)r);
+        if (strict && inner->sparse_rowptr[r + 1] == inner->sparse_rowptr[r])
+          return fail(QIP_ERR_INVALID, "All rows of sparse matrix must have data (%llu is empty)",
+                      (unsigned long long)r);  // :49-58
+      }
+      const uint64_t nnz = inner->sparse_rowptr[rows];
+      if (nnz && (!inner->sparse_cols || !inner->sparse_vals))
+        return fail(QIP_ERR_INVALID, "Sparse op without column/value arrays");
+      for (uint64_t p = 0; p < nnz; ++p)
+        if (inner->sparse_cols[p] >= rows)
+          return fail(QIP_ERR_INVALID, "Sparse column %llu out of range for %u qubits",
+                      (unsigned long long)inner->sparse_cols[p], n_op);
+      break;
+    }
+    case QIP_OP_SWAP:
+      if (n_op % 2 != 0 || n_op == 0)
+        return fail(QIP_ERR_INVALID,
+                    "Swap must be performed on two sets of indices of equal length");  // :87-93
+      break;
+    default:
+      break;
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) try {
+  FlatOp f;
+  return flatten_op(n, op, /*strict=*/true, &f);
+} QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
+// kernel classes (profiling + algorithmic bytes)
+// ---------------------------------------------------------------------------------------
+static const char* kKernelClassNames[KC_COUNT] = {
+    "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
+    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_gates",     "k_gather_generic",
+    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits"};
+
+extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
+extern "C" const char* qip_hip_kernel_class_name(int cls) {
+  return (cls >= 0 && cls < KC_COUNT) ? kKernelClassNames[cls] : "";
+}
+
+// ---------------------------------------------------------------------------------------
+// planning: which kernel applies an op
+// ---------------------------------------------------------------------------------------
+
+template <typename T>
+static void read_dense(const void* dense, uint64_t count, std::vector<double>* out) {
+  const T* p = static_cast<const T*>(dense);
+  out->resize(count * 2);
+  for (uint64_t i = 0; i < count * 2; ++i) (*out)[i] = (double)p[i];
+}
+
+
+int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p) {
+  const double amp_bytes = dtype == QIP_C64 ? 16.0 : 8.0;
+  const double N = std::ldexp(1.0, (int)n);
+  p->cls = KC_GATHER_GENERIC;
+  p->alg_bytes = 2.0 * amp_bytes * std::ldexp(1.0, (int)(n - f.n_control));
+  for (uint32_t j = 0; j < f.n_control; ++j) p->cpos.push_back(n - 1 - (uint32_t)f.outer->indices[j]);
+  for (uint32_t j = f.n_control; j < f.k_all; ++j)
+    p->opos.push_back(n - 1 - (uint32_t)f.outer->indices[j]);
+  (void)N;
+  if (force_generic || !f.distinct) return QIP_OK;
+
+  const uint32_t k = f.n_op;
+  if (f.inner->kind == QIP_OP_SWAP) {
+    p->cls = KC_SWAP_BITS;
+    return QIP_OK;
+  }
+  if (f.inner->kind == QIP_OP_SPARSE) {
+    if (k <= kMaxSparseK) p->cls = KC_SPARSE_KQ;  // in place, stored order (qubit_iterators.rs:87-101)
+    return QIP_OK;
+  }
+  if (f.inner->kind != QIP_OP_MATRIX) return QIP_OK;
+  if (k > kMaxDiagK) return QIP_OK;
+
+  const uint64_t side = 1ull << k;
+  // entries are read in place (no 4^k host copy just to look at the structure); the off-diagonal scan exits at the
+  // first non-zero, so a dense matrix costs O(1) here and only a truly diagonal one is walked completely
+  auto re_of = [&](uint64_t e) { return dtype == QIP_C64 ? static_cast<const double*>(f.inner->dense)[2 * e] : (double)static_cast<const float*>(f.inner->dense)[2 * e]; };
+  auto im_of = [&](uint64_t e) { return dtype == QIP_C64 ? static_cast<const double*>(f.inner->dense)[2 * e + 1] : (double)static_cast<const float*>(f.inner->dense)[2 * e + 1]; };
+  bool diag = true;
+  for (uint64_t r = 0; r < side && diag; ++r)
+    for (uint64_t c = 0; c < side; ++c)
+      if (r != c && !is_zero2(re_of(r * side + c), im_of(r * side + c))) {
+        diag = false;
+        break;
+      }
+  if (diag) {
+    uint64_t non_one = 0, last = 0;
+    for (uint64_t r = 0; r < side; ++r)
+      if (!is_one2(re_of(r * side + r), im_of(r * side + r))) {
+        ++non_one;
+        last = r;
+      }
+    if (non_one == 0) {
+      p->cls = KC_NOOP;
+      p->alg_bytes = 0;
+      return QIP_OK;
+    }
+    if (non_one == 1) {
+      p->cls = KC_PHASE;
+      p->phase_ones = last;
+      p->phase[0] = re_of(last * side + last);
+      p->phase[1] = im_of(last * side + last);
+      p->alg_bytes = 2.0 * amp_bytes * std::ldexp(1.0, (int)(n - f.n_control - k));
+      return QIP_OK;
+    }
+    p->cls = KC_DIAG;
+    p->table.resize(side * 2);
+    for (uint64_t r = 0; r < side; ++r) {
+      p->table[2 * r] = re_of(r * side + r);
+      p->table[2 * r + 1] = im_of(r * side + r);
+    }
+    p->alg_bytes = 2.0 * amp_bytes * std::ldexp(1.0, (int)(n - f.n_control - k)) * (double)non_one;
+    return QIP_OK;
+  }
+  std::vector<double> d;
+  if (k <= kMaxBigK) {
+    if (dtype == QIP_C64)
+      read_dense<double>(f.inner->dense, side * side, &d);
+    else
+      read_dense<float>(f.inner->dense, side * side, &d);
+  }
+  if (k == 1) {
+    p->cls = KC_GATE1Q_PAIR;  // the launcher may pick the cross-lane variant
+    p->nz = 0;
+    for (int e = 0; e < 4; ++e) {
+      p->m[2 * e] = d[2 * e];
+      p->m[2 * e + 1] = d[2 * e + 1];
+      if (!is_zero2(d[2 * e], d[2 * e + 1])) p->nz |= 1u << e;
+    }
+    return QIP_OK;
+  }
+  if (k <= kMaxBigK) {
+    // the launcher picks the matrix-core forms (k in 3..5 / 6..8) when >= 16 groups exist
+    p->cls = KC_GATE_KQ;
+    p->table = d;
+    return QIP_OK;
+  }
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op* op, double* bytes) try {
+  if (!bytes) return fail(QIP_ERR_INVALID, "null output");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  FlatOp f;
+  QCHK(flatten_op(n, op, false, &f));
+  Plan p;
+  QCHK(make_plan(dtype, n, f, false, &p));
+  // Swap(h): only amplitudes whose A and B halves differ can change, but SURVEY.md §8(d)
+  // prices Swap at the full vector; keep that convention for the reported figure.
+  *bytes = p.alg_bytes;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// ---------------------------------------------------------------------------------------
+// state handle
+// ---------------------------------------------------------------------------------------
+
+int ensure_arena(qip_hip_state* s, size_t bytes) {
+  if (bytes <= s->arena_cap) return QIP_OK;
+  if (s->capture_staging) {  // no malloc / sync inside a stream capture: ask the caller to grow and retry
+    s->capture_arena_need = std::max(s->capture_arena_need, bytes);
+    return fail(QIP_ERR_UNSUPPORTED, "arena too small during graph capture");
+  }
+  if (s->arena) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(s->arena));
+    s->arena = nullptr;
+    s->arena_cap = 0;
+  }
+  size_t cap = std::max<size_t>(bytes, 1 << 16);
+  HIPCHK(hipMalloc(&s->arena, cap));
+  s->arena_cap = cap;
+  s->arena_gen += 1;
+  return QIP_OK;
+}
+
+int ensure_partial(qip_hip_state* s, size_t count) {
+  if (count <= s->partial_cap) return QIP_OK;
+  if (s->d_partial) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(s->d_partial));
+    s->d_partial = nullptr;
+    s->partial_cap = 0;
+  }
+  size_t cap = std::max<size_t>(count, 4096);
+  HIPCHK(hipMalloc((void**)&s->d_partial, cap * sizeof(double)));
+  s->partial_cap = cap;
+  return QIP_OK;
+}
+
+int ensure_alt(qip_hip_state* s) {
+  if (s->alt) return QIP_OK;
+  HIPCHK(hipMalloc(&s->alt, s->namps * s->amp_bytes));
+  s->owns_alt = true;
+  return QIP_OK;
+}
+
+static int state_new(uint32_t n, int dtype, int device, qip_hip_state** out) {
+  if (!out) return fail(QIP_ERR_INVALID, "null output handle");
+  *out = nullptr;
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (n == 0 || n > 40) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 40]", n);
+  int count = qip_hip_device_count();
+  if (count <= 0)
+    return fail(QIP_ERR_NO_DEVICE,
+                "no HIP device visible: qip_hip has no CPU fallback (hipGetDeviceCount = 0)");
+  if (device < 0 || device >= count)
+    return fail(QIP_ERR_INVALID, "device %d out of range (have %d)", device, count);
+  HIPCHK(hipSetDevice(device));
+  qip_hip_state* s = new qip_hip_state();
+  s->n = n;
+  s->dtype = dtype;
+  s->device = device;
+  s->namps = 1ull << n;
+  s->amp_bytes = dtype == QIP_C64 ? 16 : 8;
+  *out = s;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_create(uint32_t n, int dtype, int device, qip_hip_state** out) try {
+  QCHK(state_new(n, dtype, device, out));
+  qip_hip_state* s = *out;
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    s->owns_stream = true;
+    e = hipMalloc(&s->cur, s->namps * s->amp_bytes);
+  }
+  if (e == hipSuccess) {
+    s->owns_cur = true;
+    e = hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream);
+  }
+  if (e != hipSuccess) {
+    qip_hip_state_destroy(s);
+    *out = nullptr;
+    return fail(QIP_ERR_DEVICE, "allocating a %u-qubit state failed: %s", n, hipGetErrorString(e));
+  }
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_wrap(uint32_t n, int dtype, int device, void* amps, void* scratch,
+                                  void* stream, qip_hip_state** out) try {
+  if (!amps) return fail(QIP_ERR_INVALID, "null amplitude buffer");
+  QCHK(state_new(n, dtype, device, out));
+  qip_hip_state* s = *out;
+  s->cur = amps;
+  s->alt = scratch;
+  // the caller's stream as is; NULL is the HIP null (legacy default) stream, which is what
+  // torch.cuda.current_stream().cuda_stream reports for torch's default stream on ROCm
+  s->stream = (hipStream_t)stream;
+  s->owns_stream = false;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+
+extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
+  if (!s) return QIP_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  programs_orphan(s);  // programs outliving their state become inert instead of dangling
+  for (auto& r : s->pending) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  for (auto e : s->free_events) (void)hipEventDestroy(e);
+  if (s->owns_cur && s->cur) (void)hipFree(s->cur);
+  if (s->owns_alt && s->alt) (void)hipFree(s->alt);
+  if (s->arena) (void)hipFree(s->arena);
+  if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->owns_stream && s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+
+extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
+  STATE_ENTER(s);
+  if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
+  HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
+  if (s->dtype == QIP_C64) {
+    const double one[2] = {1.0, 0.0};
+    HIPCHK(hipMemcpyAsync((char*)s->cur + index * 16, one, 16, hipMemcpyHostToDevice, s->stream));
+  } else {
+    const float one[2] = {1.0f, 0.0f};
+    HIPCHK(hipMemcpyAsync((char*)s->cur + index * 8, one, 8, hipMemcpyHostToDevice, s->stream));
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len) try {
+  STATE_ENTER(s);
+  if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "upload range out of bounds");
+  if (len == 0) return QIP_OK;
+  if (!src) return fail(QIP_ERR_INVALID, "null source");
+  HIPCHK(hipMemcpyAsync((char*)s->cur + offset * s->amp_bytes, src, len * s->amp_bytes,
+                        hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offset, uint64_t len) try {
+  STATE_ENTER(s);
+  if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "download range out of bounds");
+  if (len == 0) return QIP_OK;
+  if (!dst) return fail(QIP_ERR_INVALID, "null destination");
+  HIPCHK(hipMemcpyAsync(dst, (const char*)s->cur + offset * s->amp_bytes, len * s->amp_bytes,
+                        hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_device_ptr(qip_hip_state* s, void** amps) try {
+  if (!s || !amps) return fail(QIP_ERR_INVALID, "null argument");
+  *amps = s->cur;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_scratch_ptr(qip_hip_state* s, void** scratch) try {
+  STATE_ENTER(s);
+  if (!scratch) return fail(QIP_ERR_INVALID, "null argument");
+  QCHK(ensure_alt(s));
+  *scratch = s->alt;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) try {
+  STATE_ENTER(s);
+  QCHK(ensure_alt(s));
+  std::swap(s->cur, s->alt);
+  std::swap(s->owns_cur, s->owns_alt);
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_sync(qip_hip_state* s) try {
+  STATE_ENTER(s);
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value) try {
+  if (!s || !key) return fail(QIP_ERR_INVALID, "null argument");
+  if (!strcmp(key, "force_generic")) s->force_generic = value;
+  else if (!strcmp(key, "profile")) s->profile = value;
+  else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
+  else if (!strcmp(key, "mfma")) s->mfma = value;
+  else if (!strcmp(key, "fuse")) s->fuse = value;
+  else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
+  else if (!strcmp(key, "tile")) s->tile = value;
+  else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
+  else if (!strcmp(key, "unroll")) s->unroll = value;
+  else if (!strcmp(key, "swap_single")) s->swap_single = value;
+  else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
+  else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
+  else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// ---- profiling ---------------------------------------------------------------------------
+int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r) {
+  r->cls = cls;
+  r->bytes = bytes;
+  for (hipEvent_t* e : {&r->e0, &r->e1}) {
+    if (!s->free_events.empty()) {
+      *e = s->free_events.back();
+      s->free_events.pop_back();
+    } else {
+      HIPCHK(hipEventCreate(e));
+    }
+  }
+  HIPCHK(hipEventRecord(r->e0, s->stream));
+  return QIP_OK;
+}
+int prof_end(qip_hip_state* s, ProfRec* r) {
+  HIPCHK(hipEventRecord(r->e1, s->stream));
+  s->pending.push_back(*r);
+  return QIP_OK;
+}
+static int prof_drain(qip_hip_state* s) {
+  if (s->pending.empty()) return QIP_OK;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for (auto& r : s->pending) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    s->prof_launches[r.cls] += 1;
+    s->prof_ms[r.cls] += ms;
+    s->prof_bytes[r.cls] += r.bytes;
+    s->free_events.push_back(r.e0);
+    s->free_events.push_back(r.e1);
+  }
+  s->pending.clear();
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
+                                         double* total_ms, double* algorithmic_bytes) try {
+  STATE_ENTER(s);
+  if (cls < 0 || cls >= KC_COUNT) return fail(QIP_ERR_INVALID, "bad kernel class %d", cls);
+  QCHK(prof_drain(s));
+  if (launches) *launches = s->prof_launches[cls];
+  if (total_ms) *total_ms = s->prof_ms[cls];
+  if (algorithmic_bytes) *algorithmic_bytes = s->prof_bytes[cls];
+  return QIP_OK;
+} QIP_CATCH_ALL
+extern "C" int qip_hip_state_profile_reset(qip_hip_state* s) try {
+  STATE_ENTER(s);
+  QCHK(prof_drain(s));
+  for (int c = 0; c < KC_COUNT; ++c) {
+    s->prof_launches[c] = 0;
+    s->prof_ms[c] = 0;
+    s->prof_bytes[c] = 0;
+  }
+  return QIP_OK;
+} QIP_CATCH_ALL
+

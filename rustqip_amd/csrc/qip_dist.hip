@@ -1,5 +1,5 @@
-// qip_dist.inc — the state sharded over several GPUs (include/qip_hip.h, "qip_hip_dist_*"; SURVEY.md §8 row e).
-// Included at the end of qip_hip.hip (one translation unit: it uses the launch helpers above).
+// qip_dist.hip — the state sharded over several GPUs (include/qip_hip.h, "qip_hip_dist_*"; SURVEY.md §8 row e).
+// Uses the launch helpers of qip_launch.hip through qip_internal.h.
 //
 // Three layers, so that each can be tested where it can run:
 //   DistPlanner   pure host code: logical -> physical qubit map, which qubits go global at a remap (farthest next use),
@@ -18,6 +18,7 @@
 // 2 GiB per link, ~14 ms); exchanging one bit sends half the shard to ONE peer over one link (~56 ms).  The full
 // exchange is the cheapest one on this topology, and it buys g fresh local qubits instead of one.  What used to cost
 // extra — up to g local swap sweeps to bring the outgoing qubits to the top positions — is now one pack sweep.
+#include "qip_internal.h"
 #include <dlfcn.h>
 
 #include <map>
@@ -1018,3 +1019,4 @@ extern "C" const char* qip_hip_dist_debug_plan(uint32_t n, int dtype, int rank, 
     return nullptr;
   }
 }
+

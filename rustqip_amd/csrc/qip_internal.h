@@ -1,0 +1,211 @@
+// qip_internal.h — what the translation units of libqip_hip.so share (not part of the C ABI).
+//   qip_core.hip      errors, options, op flattening / validation, kernel choice (make_plan), state handles, profiling
+//   qip_launch.hip    one launcher per kernel class, apply_op
+//   qip_tile_sched.hip the host-only tile scheduler (segments, passes, relabelling, plan export)
+//   qip_circuit.hip   apply_ops: fusion, tile sweeps (interpreter + run-time-compiled segments), hipGraph programs
+//   qip_host.hip      host-pointer twins of the reference functions
+//   qip_measure.hip   measurement
+//   qip_dist.hip      the sharded state (planner, pack sweep, exchange)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <functional>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <dlfcn.h>
+#include <map>
+#include <string>
+#include <exception>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/qip_hip.h"
+#include "qip_kernels.h"
+
+using namespace qipk;
+
+extern thread_local std::string g_last_error;
+int fail(int code, const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(QIP_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                       \
+  } while (0)
+
+#define QCHK(expr)             \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != QIP_OK) return rc_; \
+  } while (0)
+
+// No C++ exception may cross the C ABI (include/qip_hip.h: "never aborts or throws"): every entry point that can
+// allocate is a function-try-block ending in this handler, which turns std::bad_alloc / std::length_error / ...
+// into a status + message like any other failure.
+#define QIP_CATCH_ALL                                                                       \
+  catch (const std::bad_alloc&) { return fail(QIP_ERR_DEVICE, "out of host memory"); }      \
+  catch (const std::exception& e) { return fail(QIP_ERR_INVALID, "internal error: %s", e.what()); } \
+  catch (...) { return fail(QIP_ERR_INVALID, "internal error: unknown C++ exception"); }
+
+extern int64_t g_force_generic;
+extern uint32_t g_line_bits;
+extern int64_t g_perm_rows;
+
+struct FlatOp {
+  const qip_op* outer = nullptr;
+  const qip_op* inner = nullptr;  // innermost non-Control op
+  uint32_t k_all = 0;             // outer->n_indices
+  uint32_t n_control = 0;         // flattened (ops.rs:150-154)
+  uint32_t n_op = 0;              // indices the inner iterator is built with
+  bool distinct = true;           // all outer indices distinct
+};
+int flatten_op(uint32_t n, const qip_op* op, bool strict, FlatOp* f);
+
+enum KernelClass {
+  KC_GATE1Q_PAIR = 0,
+  KC_GATE1Q_XLANE,
+  KC_PHASE,
+  KC_DIAG,
+  KC_DIAG1Q,
+  KC_SWAP_BITS,
+  KC_GATE_KQ,
+  KC_GATE_KQ_MFMA,
+  KC_TILE_GATES,
+  KC_GATHER_GENERIC,
+  KC_NOOP,
+  KC_SPARSE_KQ,
+  KC_GATE_KQ_BIG,
+  KC_PERMUTE,
+  KC_COUNT
+};
+
+template <typename T> struct HostAmp { T re, im; };  // host view of one downloaded amplitude
+
+struct Plan {
+  int cls = KC_GATHER_GENERIC;
+  double alg_bytes = 0;  // algorithmic bytes
+  // shared
+  std::vector<uint32_t> cpos;  // control bit positions
+  std::vector<uint32_t> opos;  // op bit positions, opos[0] = MSB of the sub-index
+  // 1q
+  double m[8] = {0};  // 2x2 as re,im pairs (converted to T at launch)
+  uint32_t nz = 0;
+  // phase
+  uint64_t phase_ones = 0;  // among opos: bits that must be 1 (others 0)
+  double phase[2] = {0};
+  // diag / kq: host copy of matrix data to ship to the device arena (as doubles re,im)
+  std::vector<double> table;
+};
+
+static inline bool is_zero2(double re, double im) { return re == 0.0 && im == 0.0; }
+static inline bool is_one2(double re, double im) { return re == 1.0 && im == 0.0; }
+static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
+static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5 (A operand in registers)
+static constexpr uint32_t kMaxBigK = 8;     // ... k = 6..8 with the A operand streamed through LDS (k_gate_big_mfma)
+static constexpr uint32_t kMaxSparseK = 5;  // SparseMatrix ops applied in place (one 2^k group per lane, staged in LDS)
+static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
+int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p);
+
+struct ProfRec {
+  int cls;
+  hipEvent_t e0, e1;
+  double bytes;
+};
+
+struct qip_hip_state {
+  uint32_t n = 0;
+  int dtype = QIP_C64;
+  int device = 0;
+  uint64_t namps = 0;
+  size_t amp_bytes = 16;
+  void* cur = nullptr;
+  void* alt = nullptr;
+  bool owns_cur = false, owns_alt = false;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // device arena for op payloads (matrices, CSR)
+  void* arena = nullptr;
+  size_t arena_cap = 0;
+  uint64_t arena_gen = 0;  // bumped whenever the arena is re-allocated: captured graphs hold its address
+  // reduction scratch
+  double* d_partial = nullptr;
+  size_t partial_cap = 0;
+  // options
+  int64_t force_generic = 0;
+  int64_t profile = 0;
+  int64_t lowbit_shuffle = 1;
+  int64_t mfma = 1;
+  int64_t fuse = 0;
+  int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
+  int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
+  int64_t packed_f32 = 1;
+  int64_t tile_relabel = 0;  // tile sweeps: the scheduler relabels the qubits (schedule_tiles_relabel)
+  int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
+  int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached)
+  bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
+  // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
+  std::deque<std::vector<char>>* capture_staging = nullptr;
+  size_t capture_arena_need = 0;
+  std::vector<struct qip_hip_program*> programs;  // graphs recorded against this state's buffers  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
+  int64_t unroll = 0;  // 0 = default per kernel
+  // profiling
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> free_events;
+  uint64_t prof_launches[KC_COUNT] = {0};
+  double prof_ms[KC_COUNT] = {0};
+  double prof_bytes[KC_COUNT] = {0};
+};
+
+int ensure_arena(qip_hip_state* s, size_t bytes);
+int ensure_partial(qip_hip_state* s, size_t count);
+int ensure_alt(qip_hip_state* s);
+void programs_orphan(qip_hip_state* s);  // qip_circuit.hip
+int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r);
+int prof_end(qip_hip_state* s, ProfRec* r);
+
+#define STATE_ENTER(s)                                        \
+  if (!(s)) return fail(QIP_ERR_INVALID, "null state handle"); \
+  HIPCHK(hipSetDevice((s)->device))
+
+static inline unsigned grid_for(uint64_t items, uint64_t per_block) {
+  uint64_t g = (items + per_block - 1) / per_block;
+  if (g == 0) g = 1;
+  return (unsigned)std::min<uint64_t>(g, 0x7fffffffull);
+}
+// block count -> grid; a second dimension keeps every launch under HIP's 2^32-thread limit
+static inline dim3 grid2d(uint64_t items, uint64_t per_block) {
+  uint64_t g = (items + per_block - 1) / per_block;
+  if (g == 0) g = 1;
+  const uint64_t gx = std::min<uint64_t>(g, 1ull << 22);
+  return dim3((unsigned)gx, (unsigned)((g + gx - 1) / gx));
+}
+static inline unsigned grid_stride(uint64_t items) {
+  // memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8
+  return (unsigned)std::min<uint64_t>(std::max<uint64_t>((items + kBlock - 1) / kBlock, 1), 256 * 16);
+}
+
+// qip_launch.hip
+Ins make_ins(std::vector<uint32_t> positions, uint64_t ormask);
+int arena_upload(qip_hip_state* s, const void* src, size_t bytes, size_t arena_off);
+int launch_permute(qip_hip_state* s, const uint32_t* pi_in);
+template <typename T> int apply_op_t(qip_hip_state* s, const qip_op* op);
+template <typename T>
+int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_t in_len, amp_t<T>* out, uint64_t out_len,
+                  uint64_t in_off, uint64_t out_off, int accumulate);
+
+template <typename T> static amp_t<T> mk(double re, double im) {
+  amp_t<T> a;
+  a.x = (T)re;
+  a.y = (T)im;
+  return a;
+}
+static inline bool use_nt(const qip_hip_state* s) { return s->namps * s->amp_bytes >= (1ull << 30); }

@@ -1744,8 +1744,11 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* _
 }
 
 // out[o] = sum of the gx per-block partial sums of outcome o (partial[b * nout + o]); one wave per outcome
+// (a template only so that the header can be included by several translation units)
+template <int WAVE = 64>
 __global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restrict__ partial, uint32_t gx, uint64_t nout,
                                                         double* __restrict__ out) {
+  static_assert(WAVE == 64, "gfx950 wavefronts");
   const uint64_t o = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (o >= nout) return;
   double t = 0;

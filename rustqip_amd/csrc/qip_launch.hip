@@ -1,0 +1,873 @@
+// qip_launch.hip — one launcher per kernel class (qip_kernels.h) and apply_op: the op descriptor -> plan -> launch path.
+#include "qip_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+Ins make_ins(std::vector<uint32_t> positions, uint64_t ormask) {
+  std::sort(positions.begin(), positions.end());
+  Ins ins;
+  memset(&ins, 0, sizeof ins);
+  ins.ormask = ormask;
+  ins.npos = (uint32_t)positions.size();
+  for (size_t j = 0; j < positions.size(); ++j) ins.pos[j] = positions[j];
+  return ins;
+}
+
+static uint64_t mask_of(const std::vector<uint32_t>& pos) {
+  uint64_t m = 0;
+  for (uint32_t p : pos) m |= 1ull << p;
+  return m;
+}
+
+
+// Stream-ordered copy of an op payload into the device arena.  Eagerly the (pageable) source is staged by
+// the runtime before the call returns; under graph capture the source must live as long as the graph, so
+// it is first copied into storage owned by the program.
+int arena_upload(qip_hip_state* s, const void* src, size_t bytes, size_t arena_off) {
+  if (bytes == 0) return QIP_OK;
+  QCHK(ensure_arena(s, arena_off + bytes));
+  if (s->capture_staging) {
+    s->capture_staging->emplace_back((const char*)src, (const char*)src + bytes);
+    src = s->capture_staging->back().data();
+  }
+  HIPCHK(hipMemcpyAsync((char*)s->arena + arena_off, src, bytes, hipMemcpyHostToDevice, s->stream));
+  return QIP_OK;
+}
+
+// upload `count` complex values (host doubles re,im) to the device arena as amp_t<T>
+template <typename T>
+static int upload_table(qip_hip_state* s, const std::vector<double>& tab, size_t arena_off = 0) {
+  const size_t count = tab.size() / 2;
+  std::vector<amp_t<T>> tmp(count);
+  for (size_t i = 0; i < count; ++i) tmp[i] = mk<T>(tab[2 * i], tab[2 * i + 1]);
+  return arena_upload(s, tmp.data(), count * sizeof(amp_t<T>), arena_off);
+}
+
+// Compile-time position counts 0..4 cover every 1- and 2-qubit gate with up to two extra
+// controls; anything longer takes the run-time loop (NP = -1).
+template <typename F> static void dispatch_np(uint32_t npos, F&& f) {
+  switch (npos) {
+    case 0: f(std::integral_constant<int, 0>{}); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    default: f(std::integral_constant<int, -1>{}); break;
+  }
+}
+
+// States that cannot stay in the 256-MiB Infinity Cache stream with non-temporal accesses.
+
+// (E, the 16-B element type, must be in scope: amp_t<T>, or f32x4 for the packed f32 view.)
+// LAUNCH_STREAMING(kernel, T, U, count, ins, args...): the unguarded <U> shape with the 32-KiB lane
+// spacing when the power-of-two work-item count allows it, else the guarded single-item shape.
+#define LAUNCH_STREAMING(KERNEL, T, UU, COUNT, INS, ...)                                           \
+  dispatch_np((INS).npos, [&](auto np_) {                                                          \
+    constexpr int NP = decltype(np_)::value;                                                       \
+    if ((COUNT) >= ((uint64_t)(UU) << kStrideShift)) {                                             \
+      if (use_nt(s))                                                                               \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, true, NP, E>), grid2d((COUNT), kBlock * (UU)),       \
+                           dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
+      else                                                                                         \
+        hipLaunchKernelGGL((KERNEL<T, UU, false, false, NP, E>), grid2d((COUNT), kBlock * (UU)),      \
+                           dim3(kBlock), 0, s->stream, __VA_ARGS__);                               \
+    } else {                                                                                       \
+      hipLaunchKernelGGL((KERNEL<T, 1, true, false, NP, E>), dim3(grid_for((COUNT), kBlock)),     \
+                         dim3(kBlock), 0, s->stream, __VA_ARGS__);                                 \
+    }                                                                                              \
+  })
+
+// independent accesses per stream per lane (tools/tune_gate1q.hip, MI355X, n = 30)
+constexpr int kUPair = 8;   // two streams per item (the zero-skip branches need the longer load phase)
+constexpr int kUSwap = 4;
+constexpr int kUXlane = 4;
+constexpr int kUPhase = 2;
+
+// Split selector bit positions (controls / phase bits, all required to be 1 unless `ones` says
+// otherwise) into the ones opened in the grid (>= kLineBits) and the in-line predicate (`Sel`).
+struct Split {
+  std::vector<uint32_t> hi;  // positions opened in the work index
+  uint64_t hi_ones = 0;      // bits to set among them
+  Sel low{0, 0};
+};
+static Split split_selectors(const std::vector<uint32_t>& pos, uint64_t ones_mask) {
+  Split sp;
+  for (uint32_t p : pos) {
+    const uint64_t bit = 1ull << p;
+    if (p < g_line_bits) {
+      sp.low.mask |= bit;
+      sp.low.val |= ones_mask & bit;
+    } else {
+      sp.hi.push_back(p);
+      sp.hi_ones |= ones_mask & bit;
+    }
+  }
+  return sp;
+}
+// work-index bit that amplitude-index bit `pos` maps to once the opened positions below it are removed
+static uint32_t work_bit(uint32_t pos, const std::vector<uint32_t>& opened) {
+  uint32_t below = 0;
+  for (uint32_t o : opened)
+    if (o < pos) ++below;
+  return pos - below;
+}
+
+template <typename T, typename E>
+static int launch_gate1q(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* actual_cls) {
+  const uint32_t tpos = p.opos[0];
+  Mat2<T> g;
+  for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(p.m[2 * e], p.m[2 * e + 1]);
+  g.nz = p.nz;
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
+  const uint32_t tb = work_bit(tpos, sp.hi);
+  const uint64_t namps_sub = 1ull << (n - (uint32_t)sp.hi.size());
+  if (s->lowbit_shuffle && tb < 6 && namps_sub >= 64) {
+    Ins ins = make_ins(sp.hi, sp.hi_ones);
+    *actual_cls = KC_GATE1Q_XLANE;
+    LAUNCH_STREAMING(k_gate1q_xlane, T, kUXlane, namps_sub, ins, st, namps_sub, ins, tb, sp.low, g);
+  } else {
+    std::vector<uint32_t> pos = sp.hi;
+    pos.push_back(tpos);
+    Ins ins = make_ins(pos, sp.hi_ones);
+    const uint64_t npairs = namps_sub >> 1;
+    const uint64_t tmask = 1ull << tpos;
+    LAUNCH_STREAMING(k_gate1q_pair, T, kUPair, npairs, ins, st, npairs, ins, tmask, sp.low, g);
+  }
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+template <typename T, typename E>
+static int launch_phase(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> pos = p.cpos;
+  uint64_t ones = mask_of(p.cpos);
+  for (uint32_t j = 0; j < k; ++j) {
+    pos.push_back(p.opos[j]);
+    if ((p.phase_ones >> (k - 1 - j)) & 1ull) ones |= 1ull << p.opos[j];
+  }
+  const Split sp = split_selectors(pos, ones);
+  Ins ins = make_ins(sp.hi, sp.hi_ones);
+  const uint64_t count = 1ull << (n - (uint32_t)sp.hi.size());
+  const amp_t<T> value = mk<T>(p.phase[0], p.phase[1]);
+  LAUNCH_STREAMING(k_phase, T, kUPhase, count, ins, st, count, ins, sp.low, value);
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+static DiagDesc make_diagdesc(const Plan& p) {
+  DiagDesc d;
+  memset(&d, 0, sizeof d);
+  d.k = (uint32_t)p.opos.size();
+  for (uint32_t j = 0; j < d.k && j < 32; ++j) d.tpos[j] = p.opos[j];
+  return d;
+}
+
+template <typename T, typename E>
+static int launch_diag(qip_hip_state* s, uint32_t n, const Plan& p, E* st, int* actual_cls) {
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
+  Ins ins = make_ins(sp.hi, sp.hi_ones);
+  const uint64_t count = 1ull << (n - (uint32_t)sp.hi.size());
+  if (p.opos.size() == 1) {  // Rz-like: no table, factor picked by the target bit
+    *actual_cls = KC_DIAG1Q;
+    const uint64_t tmask = 1ull << p.opos[0];
+    const amp_t<T> d0 = mk<T>(p.table[0], p.table[1]), d1 = mk<T>(p.table[2], p.table[3]);
+    LAUNCH_STREAMING(k_diag1q, T, kUPhase, count, ins, st, count, ins, tmask, sp.low, d0, d1);
+    HIPCHK(hipGetLastError());
+    return QIP_OK;
+  }
+  QCHK(upload_table<T>(s, p.table));
+  const DiagDesc dd = make_diagdesc(p);
+  const amp_t<T>* table = (const amp_t<T>*)s->arena;
+  LAUNCH_STREAMING(k_diag, T, kUPhase, count, ins, st, count, ins, sp.low, dd, table);
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// A group of >= 2 transpositions (pa pb), pa < pb, in ONE sweep (k_swapn).  `done` = false when the state is too
+// small for the shape (fewer work items than lanes): the caller then applies them one at a time.
+struct SwPair {
+  uint32_t pa, pb;
+};
+static inline int swap_pair_regbits(const Split& sp, const SwPair& q) {  // HH: 2, HL: 1, LL: 0 (pa < pb)
+  return (work_bit(q.pa, sp.hi) < 6 ? 0 : 1) + (work_bit(q.pb, sp.hi) < 6 ? 0 : 1);
+}
+
+template <typename T, typename E>
+static int launch_swapn(qip_hip_state* s, uint32_t n, const Split& sp, const std::vector<SwPair>& grp, E* st, bool* done) {
+  *done = false;
+  SwapNDesc d;
+  memset(&d, 0, sizeof d);
+  std::vector<uint32_t> pos = sp.hi, regpos;
+  // register bits: the HL bits first, then the HH pairs (bits 2j, 2j+1 of what follows) — the order k_swapn assumes
+  for (const SwPair& q : grp)
+    if (work_bit(q.pa, sp.hi) < 6 && work_bit(q.pb, sp.hi) >= 6) {
+      d.hl_lane[regpos.size()] = work_bit(q.pa, sp.hi);
+      regpos.push_back(q.pb);
+    }
+  const uint32_t NHL = (uint32_t)regpos.size();
+  for (const SwPair& q : grp) {
+    const bool la = work_bit(q.pa, sp.hi) < 6, lb = work_bit(q.pb, sp.hi) < 6;  // a lane-bit pb implies a lane-bit pa
+    if (la && lb) {
+      d.ll_a[d.n_ll] = work_bit(q.pa, sp.hi);
+      d.ll_b[d.n_ll++] = work_bit(q.pb, sp.hi);
+    } else if (!la) {
+      regpos.push_back(q.pa);
+      regpos.push_back(q.pb);
+    }
+  }
+  const uint32_t NH = (uint32_t)regpos.size();
+  if (NH > 4 || d.n_ll > 4) return fail(QIP_ERR_UNSUPPORTED, "swap group too large (internal error)");
+  for (uint32_t p : regpos) pos.push_back(p);
+  const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
+  const uint64_t nitems = nsub >> NH;
+  if (nitems < 64) return QIP_OK;  // fewer items than lanes: the lane-bit classification does not hold
+  for (uint32_t c = 0; c < (1u << NH); ++c)
+    for (uint32_t r = 0; r < NH; ++r)
+      if ((c >> r) & 1u) d.off_ld[c] |= 1ull << regpos[r];
+  for (uint32_t c = 0; c < (1u << NH); ++c) {
+    uint32_t pc = c;
+    for (uint32_t r = NHL; r + 1 < NH; r += 2) {  // HH pair on register bits (r, r + 1)
+      const uint32_t b0 = (pc >> r) & 1u, b1 = (pc >> (r + 1)) & 1u;
+      pc = (pc & ~((1u << r) | (1u << (r + 1)))) | (b1 << r) | (b0 << (r + 1));
+    }
+    d.off_st[c] = d.off_ld[pc];
+  }
+  Ins ins = make_ins(pos, sp.hi_ones);
+  const bool big = use_nt(s);  // >= 1 GiB states: unguarded, several groups per lane, non-temporal; else one guarded group
+#define SWN(NHV, NHLV, LLV, UU)                                                                                             \
+  do {                                                                                                                      \
+    if (big && nitems >= ((uint64_t)(UU) << kStrideShift))                                                                  \
+      hipLaunchKernelGGL((k_swapn<T, NHV, NHLV, LLV, UU, false, true, E>), grid2d(nitems, kBlock * (UU)), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_swapn<T, NHV, NHLV, LLV, 1, true, false, E>), grid2d(nitems, kBlock), dim3(kBlock), 0, s->stream, st, nitems, ins, d, sp.low);         \
+  } while (0)
+  const bool ll = d.n_ll > 0;
+  const uint32_t code = NH * 16 + NHL * 2 + (ll ? 1 : 0);
+  switch (code) {
+    case 0 * 16 + 0 * 2 + 1: SWN(0, 0, true, 4); break;
+    case 1 * 16 + 1 * 2 + 0: SWN(1, 1, false, 4); break;
+    case 1 * 16 + 1 * 2 + 1: SWN(1, 1, true, 4); break;
+    case 2 * 16 + 0 * 2 + 1: SWN(2, 0, true, 2); break;
+    case 2 * 16 + 2 * 2 + 0: SWN(2, 2, false, 2); break;
+    case 2 * 16 + 2 * 2 + 1: SWN(2, 2, true, 2); break;
+    case 3 * 16 + 1 * 2 + 0: if (s->unroll == 2) SWN(3, 1, false, 2); else SWN(3, 1, false, 1); break;
+    case 3 * 16 + 1 * 2 + 1: SWN(3, 1, true, 1); break;
+    case 3 * 16 + 3 * 2 + 0: SWN(3, 3, false, 1); break;
+    case 3 * 16 + 3 * 2 + 1: SWN(3, 3, true, 1); break;
+    case 4 * 16 + 0 * 2 + 0: SWN(4, 0, false, 1); break;
+    case 4 * 16 + 0 * 2 + 1: SWN(4, 0, true, 1); break;
+    case 4 * 16 + 2 * 2 + 0: SWN(4, 2, false, 1); break;
+    case 4 * 16 + 2 * 2 + 1: SWN(4, 2, true, 1); break;
+    case 4 * 16 + 4 * 2 + 0: SWN(4, 4, false, 1); break;
+    case 4 * 16 + 4 * 2 + 1: SWN(4, 4, true, 1); break;
+    default: return QIP_OK;  // (2, 0, no LL) is a single HH transposition: the caller's one-at-a-time kernels
+  }
+#undef SWN
+  HIPCHK(hipGetLastError());
+  *done = true;
+  return QIP_OK;
+}
+
+template <typename T, typename E>
+static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
+  // Swap(h, A ++ B) = product of the h disjoint transpositions (A[j] B[j]); moves are exact, so applying them in
+  // groups is bit-identical to the single permutation.  Groups hold as many transpositions as fit 4 register bits
+  // (16 amplitudes per lane) and go in ONE sweep each (k_swapn); a group of one uses the single-transposition kernels.
+  const uint32_t h = (uint32_t)p.opos.size() / 2;
+  const Split sp = split_selectors(p.cpos, mask_of(p.cpos));
+  std::vector<std::vector<SwPair>> groups;
+  {
+    std::vector<SwPair> cur;
+    int regs = 0, lls = 0;
+    for (uint32_t j = 0; j < h; ++j) {
+      SwPair q{p.opos[j], p.opos[h + j]};
+      if (q.pa > q.pb) std::swap(q.pa, q.pb);
+      const int need = swap_pair_regbits(sp, q);
+      if (!cur.empty() && (s->swap_single || regs + need > 4 || (need == 0 && lls == 4))) {
+        groups.push_back(cur);
+        cur.clear();
+        regs = lls = 0;
+      }
+      cur.push_back(q);
+      regs += need;
+      lls += need == 0;
+    }
+    if (!cur.empty()) groups.push_back(cur);
+  }
+  for (const std::vector<SwPair>& grp : groups) {
+    if (grp.size() >= 2) {
+      bool done = false;
+      QCHK((launch_swapn<T, E>(s, n, sp, grp, st, &done)));
+      if (done) continue;
+    }
+    for (const SwPair& q : grp) {
+      const uint32_t pa = q.pa, pb = q.pb;
+      const uint32_t wa = work_bit(pa, sp.hi), wb = work_bit(pb, sp.hi);
+      const uint64_t nsub = 1ull << (n - (uint32_t)sp.hi.size());
+      if (wa < 6 && wb < 6 && nsub >= 64) {  // both inside the lane index: one row, lane permutation
+        Ins ins = make_ins(sp.hi, sp.hi_ones);
+        LAUNCH_STREAMING(k_swap_xlane1, T, kUXlane, nsub, ins, st, nsub, ins, wa, wb, sp.low);
+      } else if (wa < 6 && nsub >= 128) {  // low bit in the lane index, high bit picks the row
+        std::vector<uint32_t> pos = sp.hi;
+        pos.push_back(pb);
+        Ins ins = make_ins(pos, sp.hi_ones);
+        const uint64_t nitems = nsub >> 1;
+        const uint64_t hmask = 1ull << pb;
+        // wa is unchanged by opening pb (pb > pa)
+        LAUNCH_STREAMING(k_swap_xlane2, T, kUSwap, nitems, ins, st, nitems, ins, wa, hmask, sp.low);
+      } else {
+        std::vector<uint32_t> pos = sp.hi;
+        pos.push_back(pa);
+        pos.push_back(pb);
+        Ins ins = make_ins(pos, sp.hi_ones);
+        const uint64_t npairs = nsub >> 2;
+        const uint64_t amask = 1ull << pa, bmask = 1ull << pb;
+        LAUNCH_STREAMING(k_swap_bits, T, kUSwap, npairs, ins, st, npairs, ins, amask, bmask, sp.low);
+      }
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return QIP_OK;
+}
+
+// ---- any permutation of the index bits in one out-of-place sweep (k_permute_bits) ---------------------------------
+// pi[d] = source bit position that destination bit position d takes its value from: out[j] = in[src(j)], bit pi[d] of
+// src(j) = bit d of j.  Pure host code; exported through qip_hip_debug_permute_plan for the CPU tests.
+static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t fold_bits, PermDesc* out) {
+  const uint32_t TB = 2 * R;
+  if (n < TB || TB > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "internal: permutation tile does not fit n = %u", n);
+  PermDesc& d = *out;
+  memset(&d, 0, sizeof d);
+  std::vector<char> in_tile(n, 0);
+  for (uint32_t b = 0; b < R; ++b) in_tile[b] = 1;             // the destination's row bits
+  for (uint32_t b = 0; b < n; ++b)
+    if (pi[b] < R) in_tile[b] = 1;                              // destination bits fed by the source's row bits
+  uint32_t cnt = 0;
+  for (uint32_t b = 0; b < n; ++b) cnt += in_tile[b];
+  for (uint32_t b = 0; b < n && cnt < TB; ++b)                  // pad with the lowest positions left
+    if (!in_tile[b]) {
+      in_tile[b] = 1;
+      ++cnt;
+    }
+  std::vector<uint32_t> tb, sb;
+  for (uint32_t b = 0; b < n; ++b)
+    if (in_tile[b]) {
+      tb.push_back(b);
+      sb.push_back(pi[b]);
+    }
+  std::sort(sb.begin(), sb.end());
+  for (uint32_t i = 0; i < TB; ++i) {
+    d.tbits[i] = tb[i];
+    d.sbits[i] = sb[i];
+  }
+  for (uint32_t i = 0; i < TB; ++i) {  // source coordinate bit i is source position sb[i] = pi[tb[k]] -> tile bit k
+    uint32_t k = 0;
+    while (k < TB && pi[tb[k]] != sb[i]) ++k;
+    if (k == TB) return fail(QIP_ERR_INVALID, "internal: permutation tile is not closed");
+    d.u2c[i] = k;
+  }
+  // LDS swizzle: the source-side lanes of one bank group vary tile bits u2c[0..FB-1], the destination-side lanes tile
+  // bits 0..FB-1; fold every u2c[i] >= FB into a low bit no u2c[j] < FB occupies, so both sides spread over all banks
+  std::vector<char> taken(fold_bits, 0);
+  for (uint32_t i = 0; i < fold_bits; ++i)
+    if (d.u2c[i] < fold_bits) taken[d.u2c[i]] = 1;
+  uint32_t slot = 0;
+  for (uint32_t i = 0; i < fold_bits; ++i) {
+    if (d.u2c[i] < fold_bits) continue;
+    while (taken[slot]) ++slot;
+    taken[slot] = 1;
+    d.fold_from[d.nfold] = d.u2c[i];
+    d.fold_to[d.nfold] = slot;
+    d.nfold += 1;
+  }
+  for (uint32_t b = 0; b < n; ++b)
+    if (!in_tile[b]) {
+      d.outer_dst[d.n_outer] = (unsigned char)b;
+      d.outer_src[d.n_outer] = (unsigned char)pi[b];
+      d.n_outer += 1;
+    }
+  return QIP_OK;
+}
+
+static int check_bit_permutation(uint32_t n, const uint32_t* pi, bool* identity) {
+  uint64_t seen = 0;
+  *identity = true;
+  for (uint32_t b = 0; b < n; ++b) {
+    if (pi[b] >= n || ((seen >> pi[b]) & 1ull)) return fail(QIP_ERR_INVALID, "not a permutation of the %u index bits", n);
+    seen |= 1ull << pi[b];
+    if (pi[b] != b) *identity = false;
+  }
+  return QIP_OK;
+}
+
+// cur -> alt through the permutation, then alt becomes the current buffer (builder.rs:514 analogue)
+int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
+  bool identity = true;
+  QCHK(check_bit_permutation(s->n, pi_in, &identity));
+  if (identity) return QIP_OK;
+  QCHK(ensure_alt(s));
+  std::vector<uint32_t> pi(pi_in, pi_in + s->n);
+  uint32_t n = s->n;
+  // Complex<f32>: two amplitudes per 16-byte element when index bit 0 stays where it is
+  const bool packed = s->dtype == QIP_C32 && pi[0] == 0 && n >= 2 && s->packed_f32;
+  if (packed) {
+    for (uint32_t b = 0; b + 1 < n; ++b) pi[b] = pi[b + 1] - 1;
+    n -= 1;
+  }
+  const bool wide = s->dtype == QIP_C64 || packed;   // 16-byte elements
+  // 16-byte elements: 512-B rows in 16-KiB tiles (8 blocks per CU) unless two or more of the source's row bits feed
+  // destination bits far above the rows — then the tile's rows are scattered on the source side and 1-KiB rows in
+  // 64-KiB tiles pay (measured at n = 30: random permutation 7.2 -> 6.5 ms, three transpositions 7.3 -> 5.9, while a
+  // single transposition is better off with the small tile: 5.9 vs 6.2 ms; profiles/r02_permute.md)
+  uint32_t scattered = 0;
+  for (uint32_t b = 10; b < n; ++b) scattered += pi[b] < 5u;
+  const uint32_t R = !wide ? 6u : (g_perm_rows ? (uint32_t)g_perm_rows : (scattered >= 2 && n >= 12 ? 6u : 5u)), TB = 2 * R;
+  ProfRec rec;
+  if (s->profile) QCHK(prof_begin(s, KC_PERMUTE, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+  const bool nt = use_nt(s);
+  if (n < TB) {
+    PermSmall ps;
+    memset(&ps, 0, sizeof ps);
+    ps.n = n;
+    for (uint32_t b = 0; b < n; ++b) ps.pi[b] = (unsigned char)pi[b];
+    const uint64_t count = 1ull << n;
+    const dim3 grid(grid_for(count, kBlock)), block(kBlock);
+    if (s->dtype == QIP_C64)
+      hipLaunchKernelGGL((k_permute_bits_small<amp_t<double>>), grid, block, 0, s->stream, (const amp_t<double>*)s->cur, (amp_t<double>*)s->alt, count, ps);
+    else if (packed)
+      hipLaunchKernelGGL((k_permute_bits_small<f32x4>), grid, block, 0, s->stream, (const f32x4*)s->cur, (f32x4*)s->alt, count, ps);
+    else
+      hipLaunchKernelGGL((k_permute_bits_small<amp_t<float>>), grid, block, 0, s->stream, (const amp_t<float>*)s->cur, (amp_t<float>*)s->alt, count, ps);
+  } else {
+    PermDesc d;
+    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, &d));  // (fold width follows the element size, not R)
+    const dim3 grid = grid2d(1ull << (n - TB), 1), block(kBlock);
+#define PB(A, RR)                                                                                                        \
+  do {                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_permute_bits<A, RR, true>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);  \
+    else hipLaunchKernelGGL((k_permute_bits<A, RR, false>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);    \
+  } while (0)
+    if (s->dtype == QIP_C64 && R == 5) PB(amp_t<double>, 5);
+    else if (s->dtype == QIP_C64) PB(amp_t<double>, 6);
+    else if (packed && R == 5) PB(f32x4, 5);
+    else if (packed) PB(f32x4, 6);
+    else PB(amp_t<float>, 6);
+#undef PB
+  }
+  HIPCHK(hipGetLastError());
+  if (s->profile) QCHK(prof_end(s, &rec));
+  std::swap(s->cur, s->alt);
+  std::swap(s->owns_cur, s->owns_alt);
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_permute_bits(qip_hip_state* s, const uint32_t* pi) try {
+  STATE_ENTER(s);
+  if (!pi) return fail(QIP_ERR_INVALID, "null permutation");
+  return launch_permute(s, pi);
+} QIP_CATCH_ALL
+
+// Host-only: the descriptor k_permute_bits would get, as JSON (tests/test_permute_plan_cpu.py replays the kernel's index
+// arithmetic with numpy: every element lands where out[j] = in[src(j)] says, the LDS slots of a tile are a bijection,
+// and the lanes of a bank group hit distinct banks).
+extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi, uint32_t row_bits, uint32_t fold_bits) {
+  static thread_local std::string json;
+  try {
+    bool identity = true;
+    if (!pi || n == 0 || n > 62) return fail(QIP_ERR_INVALID, "bad argument"), nullptr;
+    if (check_bit_permutation(n, pi, &identity) != QIP_OK) return nullptr;
+    PermDesc d;
+    if (make_perm_desc(n, pi, row_bits, fold_bits, &d) != QIP_OK) return nullptr;
+    const uint32_t TB = 2 * row_bits;
+    auto arr = [&](const char* key, const uint32_t* v, uint32_t cnt) {
+      std::string a = std::string("\"") + key + "\":[";
+      for (uint32_t i = 0; i < cnt; ++i) a += (i ? "," : "") + std::to_string(v[i]);
+      return a + "]";
+    };
+    uint32_t od[64], os[64];
+    for (uint32_t i = 0; i < d.n_outer; ++i) {
+      od[i] = d.outer_dst[i];
+      os[i] = d.outer_src[i];
+    }
+    json = "{\"n\":" + std::to_string(n) + ",\"row_bits\":" + std::to_string(row_bits) + "," + arr("tbits", d.tbits, TB) + "," +
+           arr("sbits", d.sbits, TB) + "," + arr("u2c", d.u2c, TB) + "," + arr("fold_from", d.fold_from, d.nfold) + "," +
+           arr("fold_to", d.fold_to, d.nfold) + "," + arr("outer_dst", od, d.n_outer) + "," + arr("outer_src", os, d.n_outer) + "}";
+    return json.c_str();
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  }
+}
+
+template <typename T>
+int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_t in_len,
+                         amp_t<T>* out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
+                         int accumulate);
+
+// A operand of k_gate_kq_mfma, one double per (tile row block, K-step, lane); see the kernel header.
+// f32_layout: the C/D rows of v_mfma_f32_16x16x4_f32 are 4 * (lane >> 4) + reg, those of the f64 form (lane >> 4) + 4 * reg.
+static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out, bool f32_layout = false) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  const uint32_t S = 1u << k, TT = S / 8, KS = S / 2;
+  uint32_t perm_bit[8];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
+  for (uint32_t b = 0; b < k; ++b)
+    for (uint32_t j = 0; j < k; ++j)
+      if (p.opos[j] == tau[b]) perm_bit[b] = k - 1 - j;
+  auto c_of = [&](uint32_t ct) {
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < k; ++b) c |= ((ct >> b) & 1u) << perm_bit[b];
+    return c;
+  };
+  out->assign((size_t)TT * KS * 64, 0.0);
+  for (uint32_t rb = 0; rb < TT; ++rb)
+    for (uint32_t s = 0; s < KS; ++s)
+      for (uint32_t l = 0; l < 64; ++l) {
+        const uint32_t i = l & 15, kk = l >> 4;
+        const uint32_t qp = f32_layout ? i >> 2 : i & 3, reg = f32_layout ? i & 3 : i >> 2, partp = reg & 1, t = reg >> 1;
+        const uint32_t ctp = 4 * (2 * rb + t) + qp, ct = 4 * (s >> 1) + kk, part = s & 1;
+        const size_t e = (size_t)c_of(ctp) * S + c_of(ct);
+        const double re = p.table[2 * e], im = p.table[2 * e + 1];
+        (*out)[((size_t)rb * KS + s) * 64 + l] = partp == 0 ? (part == 0 ? re : -im) : (part == 0 ? im : re);
+      }
+}
+
+template <typename T>
+static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  MfmaDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
+  const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
+  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * 8);  // waves loop over items
+  const dim3 grid(blocks), block(kBlock);
+  const T* af = (const T*)s->arena;
+  const bool nt = use_nt(s);
+#define MF(K, WU)                                                                                            \
+  do {                                                                                                       \
+    if (nt) hipLaunchKernelGGL((k_gate_kq_mfma<T, K, WU, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);  \
+    else hipLaunchKernelGGL((k_gate_kq_mfma<T, K, WU, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+  } while (0)
+  // WU items per iteration so that WU * 2^k / 4 = 8 loads are in flight per lane (nitems is a power of two)
+  switch (k) {
+    case 3: if (nitems >= 4 && s->unroll != 1) MF(3, 4); else MF(3, 1); break;
+    case 4: if (nitems >= 2 && s->unroll == 2) MF(4, 2); else MF(4, 1); break;
+    case 5: if (nitems >= 2 && s->unroll == 2) MF(5, 2); else MF(5, 1); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "matrix-core kernel for k = %u", k);
+  }
+#undef MF
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// dense k = 6..8 on the matrix cores (f64 and f32 forms), A operand streamed through LDS (k_gate_big_mfma)
+template <typename T>
+static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  MfmaDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
+  const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
+  const unsigned per_cu = k <= 7 ? 2u : 1u;  // resident blocks per CU (registers: 2 waves per SIMD up to k = 7; LDS: 128 KiB at k = 8 in f64)
+  const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * per_cu);
+  const dim3 grid(blocks), block(kBlock);
+  const T* af = (const T*)s->arena;
+  const bool nt = use_nt(s);
+#define BM(K)                                                                                                        \
+  do {                                                                                                               \
+    if (nt) hipLaunchKernelGGL((k_gate_big_mfma<T, K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
+    else hipLaunchKernelGGL((k_gate_big_mfma<T, K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);      \
+  } while (0)
+  switch (k) {
+    case 6: BM(6); break;
+    case 7: BM(7); break;
+    case 8: BM(8); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "streamed matrix-core kernel for k = %u", k);
+  }
+#undef BM
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+template <typename T>
+static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  const uint32_t used = (uint32_t)(p.opos.size() + p.cpos.size());
+  // how many target bits sit inside the lane index (a lane's 2^k accesses then share 1-KiB rows
+  // with its neighbours only partially)
+  uint32_t low_targets = 0, min_target = 64;
+  for (uint32_t t : p.opos) {
+    if (t < 6) ++low_targets;
+    min_target = std::min(min_target, t);
+  }
+  {
+    // matrix cores (f64 and f32 forms): always for k = 5 (no register form), and for k = 3, 4 when two or more targets
+    // are low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
+    // register form does not (measured at n = 30: profiles/r01_ops_table*.md)
+    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2;  // 2 = force (tuning aid)
+    if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
+      *actual_cls = KC_GATE_KQ_MFMA;
+      return launch_kq_mfma<T>(s, p, st);
+    }
+  }
+  if (s->mfma && k > kMaxMfmaK && k <= kMaxBigK && s->n >= used + 4) {
+    *actual_cls = KC_GATE_KQ_BIG;
+    return launch_big_mfma<T>(s, p, st);
+  }
+  if (k > kMaxRegK) {  // no register form: literal kernel, out of place
+    *actual_cls = KC_GATHER_GENERIC;
+    QCHK(ensure_alt(s));
+    QCHK(launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0, 0, 0));
+    std::swap(s->cur, s->alt);
+    std::swap(s->owns_cur, s->owns_alt);
+    return QIP_OK;
+  }
+  QCHK(upload_table<T>(s, p.table));
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  const uint64_t groups = 1ull << (s->n - (uint32_t)pos.size());
+  const DiagDesc d = make_diagdesc(p);
+  const amp_t<T>* mat = (const amp_t<T>*)s->arena;
+  const bool nt = use_nt(s) && min_target >= 6;
+  // One group (2^k amplitudes) per lane.  Several groups per lane with the 32-KiB spacing that pays off
+  // for the 1-qubit kernels were measured at n = 30 and do NOT help here (k = 2: 5.82 vs 5.85 TB/s, k = 3:
+  // 5.52 vs 5.61): option unroll = 2 still selects them for experiments.
+#define KQ(K, UU)                                                                                       \
+  do {                                                                                                  \
+    if (groups >= ((uint64_t)(UU) << kStrideShift) && s->unroll == 2 && (UU) > 1) {                     \
+      const dim3 grid = grid2d(groups, kBlock * (UU));                                                  \
+      if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);  \
+      else hipLaunchKernelGGL((k_gate_kq<T, K, UU, false, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
+    } else {                                                                                            \
+      const dim3 grid = grid2d(groups, kBlock);                                                         \
+      if (nt) hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, true>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);    \
+      else hipLaunchKernelGGL((k_gate_kq<T, K, 1, true, false>), grid, dim3(kBlock), 0, s->stream, st, groups, ins, d, mat);      \
+    }                                                                                                   \
+  } while (0)
+  switch (k) {
+    case 2: KQ(2, 4); break;
+    case 3: KQ(3, 2); break;
+    case 4: KQ(4, 1); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "register kernel for k = %u", k);
+  }
+#undef KQ
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// Ship the inner op's payload to the arena and run the literal gather kernel in -> out.
+template <typename T>
+int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_t in_len,
+                         amp_t<T>* out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
+                         int accumulate) {
+  GatherDesc d;
+  memset(&d, 0, sizeof d);
+  d.n = s->n;
+  d.k_all = f.k_all;
+  d.n_control = f.n_control;
+  d.n_op = f.n_op;
+  d.inner_kind = f.inner->kind;
+  d.accumulate = accumulate;
+  d.in_len = in_len;
+  d.out_len = out_len;
+  d.in_off = in_off;
+  d.out_off = out_off;
+  for (uint32_t j = 0; j < f.k_all; ++j) d.pos[j] = (uint32_t)(s->n - 1 - f.outer->indices[j]);
+  const amp_t<T>* dense = nullptr;
+  const uint64_t* rowptr = nullptr;
+  const uint64_t* cols = nullptr;
+  const amp_t<T>* vals = nullptr;
+  if (f.inner->kind == QIP_OP_MATRIX) {
+    const size_t bytes = (sizeof(amp_t<T>) << (2 * f.n_op));
+    QCHK(arena_upload(s, f.inner->dense, bytes, 0));
+    dense = (const amp_t<T>*)s->arena;
+  } else if (f.inner->kind == QIP_OP_SPARSE) {
+    const uint64_t rows = 1ull << f.n_op;
+    const uint64_t nnz = f.inner->sparse_rowptr[rows];
+    const size_t b_rp = (rows + 1) * 8, b_cols = nnz * 8, b_vals = nnz * sizeof(amp_t<T>);
+    const size_t o_cols = (b_rp + 15) & ~(size_t)15, o_vals = (o_cols + b_cols + 15) & ~(size_t)15;
+    QCHK(ensure_arena(s, o_vals + b_vals + 16));
+    QCHK(arena_upload(s, f.inner->sparse_rowptr, b_rp, 0));
+    if (nnz) {
+      QCHK(arena_upload(s, f.inner->sparse_cols, b_cols, o_cols));
+      QCHK(arena_upload(s, f.inner->sparse_vals, b_vals, o_vals));
+    }
+    rowptr = (const uint64_t*)s->arena;
+    cols = (const uint64_t*)((char*)s->arena + o_cols);
+    vals = (const amp_t<T>*)((char*)s->arena + o_vals);
+  }
+  hipLaunchKernelGGL((k_gather_generic<T>), dim3(grid_stride(out_len)), dim3(kBlock), 0, s->stream, in,
+                     out, d, dense, rowptr, cols, vals);
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// SparseMatrix (optionally controlled) on k <= 5 distinct qubits, in place (k_sparse_kq)
+template <typename T>
+static int launch_sparse_kq(qip_hip_state* s, const Plan& p, const FlatOp& f, amp_t<T>* st) {
+  const uint32_t k = f.n_op;
+  const uint64_t rows = 1ull << k;
+  const uint64_t nnz = f.inner->sparse_rowptr[rows];
+  const size_t b_rp = (rows + 1) * 8, b_cols = nnz * 8, b_vals = nnz * sizeof(amp_t<T>);
+  const size_t o_cols = (b_rp + 15) & ~(size_t)15, o_vals = (o_cols + b_cols + 15) & ~(size_t)15;
+  QCHK(ensure_arena(s, o_vals + b_vals + 16));  // one allocation: growing frees the old arena
+  QCHK(arena_upload(s, f.inner->sparse_rowptr, b_rp, 0));
+  if (nnz) {
+    QCHK(arena_upload(s, f.inner->sparse_cols, b_cols, o_cols));
+    QCHK(arena_upload(s, f.inner->sparse_vals, b_vals, o_vals));
+  }
+  const uint64_t* rowptr = (const uint64_t*)s->arena;
+  const uint64_t* cols = (const uint64_t*)((char*)s->arena + o_cols);
+  const amp_t<T>* vals = (const amp_t<T>*)((char*)s->arena + o_vals);
+  std::vector<uint32_t> pos = p.cpos;
+  uint32_t min_target = 64;
+  for (uint32_t t : p.opos) {
+    pos.push_back(t);
+    min_target = std::min(min_target, t);
+  }
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  const uint64_t groups = 1ull << (s->n - (uint32_t)pos.size());
+  const DiagDesc d = make_diagdesc(p);
+  const bool nt = use_nt(s) && min_target >= 6;
+  const unsigned threads = k <= 3 ? 256u : (k == 4 ? 128u : 64u);
+  const size_t lds = (sizeof(amp_t<T>) << k) * threads;
+  const dim3 grid = grid2d(groups, threads);
+#define SPK(K)                                                                                                          \
+  do {                                                                                                                  \
+    if (nt) hipLaunchKernelGGL((k_sparse_kq<T, K, true>), grid, dim3(threads), lds, s->stream, st, groups, ins, d, rowptr, cols, vals);  \
+    else hipLaunchKernelGGL((k_sparse_kq<T, K, false>), grid, dim3(threads), lds, s->stream, st, groups, ins, d, rowptr, cols, vals);    \
+  } while (0)
+  switch (k) {
+    case 1: SPK(1); break;
+    case 2: SPK(2); break;
+    case 3: SPK(3); break;
+    case 4: SPK(4); break;
+    case 5: SPK(5); break;
+    default: return fail(QIP_ERR_UNSUPPORTED, "in-place sparse kernel for k = %u", k);
+  }
+#undef SPK
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+template <typename T>
+int apply_op_t(qip_hip_state* s, const qip_op* op) {
+  if (s->jit_prepare) return QIP_OK;  // compiling a program's segment kernels: single ops have nothing to prepare
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
+  FlatOp f;
+  QCHK(flatten_op(s->n, op, false, &f));
+  Plan p;
+  QCHK(make_plan(s->dtype, s->n, f, s->force_generic || g_force_generic, &p));
+  if (p.cls == KC_NOOP) {
+    if (s->profile) s->prof_launches[KC_NOOP] += 1;
+    return QIP_OK;
+  }
+  ProfRec rec;
+  rec.cls = p.cls;
+  if (s->profile) QCHK(prof_begin(s, p.cls, p.alg_bytes, &rec));
+  amp_t<T>* st = (amp_t<T>*)s->cur;
+  int rc = QIP_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    // packed f32 view: 2^(n-1) elements of two amplitudes each, bit positions shifted down by one
+    const bool streaming = p.cls == KC_GATE1Q_PAIR || p.cls == KC_PHASE || p.cls == KC_DIAG || p.cls == KC_SWAP_BITS;
+    bool bit0_selector = false, bit0_target = false;
+    for (uint32_t c : p.cpos) bit0_selector |= c == 0;
+    for (uint32_t t : p.opos) bit0_target |= t == 0;
+    if (streaming && s->packed_f32 && s->n >= 2 && !bit0_selector &&
+        (!bit0_target || p.cls == KC_GATE1Q_PAIR)) {
+      Plan q = p;
+      for (auto& c : q.cpos) c -= 1;
+      f32x4* pst = (f32x4*)s->cur;
+      const uint32_t ne = s->n - 1;
+      using E = f32x4;
+      if (bit0_target) {  // the pair is the two halves of one element
+        Mat2<float> g;
+        for (int e = 0; e < 4; ++e) g.m[e] = mk<float>(p.m[2 * e], p.m[2 * e + 1]);
+        g.nz = p.nz;
+        const Split sp = split_selectors(q.cpos, mask_of(q.cpos));
+        Ins ins = make_ins(sp.hi, sp.hi_ones);
+        const uint64_t count = 1ull << (ne - (uint32_t)sp.hi.size());
+        rec.cls = KC_GATE1Q_XLANE;
+        dispatch_np(ins.npos, [&](auto np_) {
+          constexpr int NP = decltype(np_)::value;
+          if (count >= ((uint64_t)kUXlane << kStrideShift)) {
+            if (use_nt(s))
+              hipLaunchKernelGGL((k_gate1q_inelem<kUXlane, false, true, NP>), dim3(grid_for(count, kBlock * kUXlane)),
+                                 dim3(kBlock), 0, s->stream, pst, count, ins, sp.low, g);
+            else
+              hipLaunchKernelGGL((k_gate1q_inelem<kUXlane, false, false, NP>), dim3(grid_for(count, kBlock * kUXlane)),
+                                 dim3(kBlock), 0, s->stream, pst, count, ins, sp.low, g);
+          } else {
+            hipLaunchKernelGGL((k_gate1q_inelem<1, true, false, NP>), dim3(grid_for(count, kBlock)), dim3(kBlock), 0,
+                               s->stream, pst, count, ins, sp.low, g);
+          }
+        });
+        HIPCHK(hipGetLastError());
+      } else {
+        for (auto& t : q.opos) t -= 1;
+        switch (p.cls) {
+          case KC_GATE1Q_PAIR: rc = launch_gate1q<float, E>(s, ne, q, pst, &rec.cls); break;
+          case KC_PHASE: rc = launch_phase<float, E>(s, ne, q, pst); break;
+          case KC_DIAG: rc = launch_diag<float, E>(s, ne, q, pst, &rec.cls); break;
+          default: rc = launch_swap<float, E>(s, ne, q, pst); break;
+        }
+      }
+      if (rc != QIP_OK) return rc;
+      if (s->profile) QCHK(prof_end(s, &rec));
+      return QIP_OK;
+    }
+  }
+  switch (p.cls) {
+    case KC_GATE1Q_PAIR: rc = launch_gate1q<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
+    case KC_PHASE: rc = launch_phase<T, amp_t<T>>(s, s->n, p, st); break;
+    case KC_DIAG: rc = launch_diag<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
+    case KC_SWAP_BITS: rc = launch_swap<T, amp_t<T>>(s, s->n, p, st); break;
+    case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
+    case KC_SPARSE_KQ: rc = launch_sparse_kq<T>(s, p, f, st); break;
+    default: {
+      QCHK(ensure_alt(s));
+      rc = launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0,
+                            0, 0);
+      if (rc == QIP_OK) {
+        std::swap(s->cur, s->alt);  // builder.rs:514
+        std::swap(s->owns_cur, s->owns_alt);
+      }
+      break;
+    }
+  }
+  if (rc != QIP_OK) return rc;
+  if (s->profile) QCHK(prof_end(s, &rec));
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_apply_op(qip_hip_state* s, const qip_op* op) try {
+  STATE_ENTER(s);
+  return s->dtype == QIP_C64 ? apply_op_t<double>(s, op) : apply_op_t<float>(s, op);
+} QIP_CATCH_ALL
+
+
+// the other translation units call these (qip_internal.h)
+template int apply_op_t<double>(qip_hip_state*, const qip_op*);
+template int apply_op_t<float>(qip_hip_state*, const qip_op*);
+template int launch_gather<double>(qip_hip_state*, const FlatOp&, const amp_t<double>*, uint64_t, amp_t<double>*, uint64_t, uint64_t, uint64_t, int);
+template int launch_gather<float>(qip_hip_state*, const FlatOp&, const amp_t<float>*, uint64_t, amp_t<float>*, uint64_t, uint64_t, uint64_t, int);

@@ -1,0 +1,311 @@
+// qip_measure.hip — measurement on the device (qip/src/state_ops/measurement_ops.rs).
+#include "qip_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------
+static int check_measure_indices(qip_hip_state* s, const uint64_t* indices, uint32_t k, MeasDesc* md,
+                                 std::vector<uint32_t>* pos) {
+  if (k == 0 || k > s->n || !indices) return fail(QIP_ERR_INVALID, "bad measurement index list");
+  memset(md, 0, sizeof *md);
+  md->k = k;
+  uint64_t seen = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    if (indices[i] >= s->n) return fail(QIP_ERR_INVALID, "measured qubit index out of range");
+    if (seen & (1ull << indices[i])) return fail(QIP_ERR_INVALID, "repeated measured qubit index");
+    seen |= 1ull << indices[i];
+    md->mpos[i] = (uint32_t)(s->n - 1 - indices[i]);
+    pos->push_back(md->mpos[i]);
+  }
+  return QIP_OK;
+}
+
+template <typename T>
+static int chunk_norms(qip_hip_state* s, uint64_t* chunk_out, std::vector<double>* sums) {
+  uint64_t chunk = std::max<uint64_t>(s->namps / 4096, 1024);
+  chunk = std::min<uint64_t>(chunk, s->namps);
+  const uint64_t nchunks = (s->namps + chunk - 1) / chunk;
+  QCHK(ensure_partial(s, nchunks));
+  hipLaunchKernelGGL((k_chunk_norms<T>), dim3((unsigned)nchunks), dim3(kBlock), 0, s->stream,
+                     (const amp_t<T>*)s->cur, s->namps, chunk, s->d_partial);
+  HIPCHK(hipGetLastError());
+  sums->resize(nchunks);
+  HIPCHK(hipMemcpyAsync(sums->data(), s->d_partial, nchunks * sizeof(double), hipMemcpyDeviceToHost,
+                        s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  *chunk_out = chunk;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) try {
+  STATE_ENTER(s);
+  if (!out) return fail(QIP_ERR_INVALID, "null output");
+  std::vector<double> sums;
+  uint64_t chunk = 0;
+  QCHK(s->dtype == QIP_C64 ? chunk_norms<double>(s, &chunk, &sums) : chunk_norms<float>(s, &chunk, &sums));
+  double t = 0;
+  for (double v : sums) t += v;
+  *out = t;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+template <typename T>
+static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vector<uint32_t>& pos,
+                           uint64_t m_first, uint64_t m_count, double* out) {
+  const uint32_t k = md.k;
+  if (m_count == (1ull << k) && k <= 4) {
+    // all outcomes of a few qubits: one coalesced pass, 2^k running sums per lane
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(s->namps / (kBlock * 8), 1), 2048);
+    const size_t M = (size_t)1 << k;
+    QCHK(ensure_partial(s, (size_t)gx * M));
+    const amp_t<T>* st = (const amp_t<T>*)s->cur;
+    switch (k) {
+      case 1: hipLaunchKernelGGL((k_measure_probs_small<T, 1>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      case 2: hipLaunchKernelGGL((k_measure_probs_small<T, 2>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      case 3: hipLaunchKernelGGL((k_measure_probs_small<T, 3>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+      default: hipLaunchKernelGGL((k_measure_probs_small<T, 4>), dim3(gx), dim3(kBlock), 0, s->stream, st, s->namps, md, s->d_partial); break;
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)gx * M);
+    HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (size_t m = 0; m < M; ++m) {
+      double t = 0;
+      for (unsigned b = 0; b < gx; ++b) t += part[(size_t)b * M + m];
+      out[m] = t;
+    }
+    return QIP_OK;
+  }
+  if (m_count == (1ull << k)) {
+    // more outcomes, no atomics: measured positions >= 8 on the grid (a few of them walked per lane when the grid
+    // would be huge), the others resolved per lane (k_measure_probs_grid)
+    MeasGridDesc gd;
+    memset(&gd, 0, sizeof gd);
+    std::vector<std::pair<uint32_t, uint32_t>> high;  // (position, outcome bit) of the measured positions >= 8
+    uint32_t lbit[8];
+    for (uint32_t i = 0; i < k; ++i) {
+      if (md.mpos[i] >= 8) {
+        high.push_back({md.mpos[i], i});
+      } else {
+        lbit[gd.kl] = i;
+        gd.lpos[gd.kl++] = md.mpos[i];
+      }
+    }
+    std::sort(high.begin(), high.end());
+    // step bits: the lowest high positions, as many (<= 3) as it takes to bring the grid down to ~2^11 outcomes
+    uint32_t ki = 0;
+    while (ki < 3 && high.size() - ki > 11) ++ki;
+    uint32_t sbit[3] = {0, 0, 0}, gbit[kMaxIns];
+    std::vector<uint32_t> opened;
+    for (uint32_t i = 0; i < high.size(); ++i) {
+      opened.push_back(high[i].first);
+      if (i < ki) {
+        gd.spos[i] = high[i].first;
+        sbit[i] = high[i].second;
+      } else {
+        gbit[gd.kg] = high[i].second;
+        gd.gpos[gd.kg++] = high[i].first;
+      }
+    }
+    if (gd.kg <= 20) {
+      Ins ins = make_ins(opened, 0);
+      const uint64_t count = 1ull << (s->n - (uint32_t)high.size());  // indices per (grid outcome, step value)
+      const uint64_t ny = 1ull << gd.kg, nl = 1ull << gd.kl, nc = 1ull << ki;
+      // about 8192 blocks in all, each with at least four 4-KiB rows when the outcome has that many
+      uint64_t gx = std::max<uint64_t>(8192 / ny, 1);
+      gx = std::min<uint64_t>(gx, std::max<uint64_t>(count * nc / (kBlock * 4), 1));
+      const size_t nout = (size_t)(ny * nc * nl), np = nout * (size_t)gx;
+      QCHK(ensure_partial(s, np + nout));
+      const dim3 grid((unsigned)(ny * gx));
+#define MG(KI) hipLaunchKernelGGL((k_measure_probs_grid<T, KI>), grid, dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur, \
+                                  count, ins, gd, (uint32_t)gx, (uint64_t)nout, s->d_partial)
+      switch (ki) {
+        case 0: MG(0); break;
+        case 1: MG(1); break;
+        case 2: MG(2); break;
+        default: MG(3); break;
+      }
+#undef MG
+      HIPCHK(hipGetLastError());
+      const double* res = s->d_partial;
+      if (gx > 1) {  // fold the gx partials per outcome on the device: only 2^k doubles cross PCIe
+        hipLaunchKernelGGL((k_sum_partials<64>), dim3(grid_for(nout, kBlock / 64)), dim3(kBlock), 0, s->stream, s->d_partial, (uint32_t)gx,
+                           (uint64_t)nout, s->d_partial + np);
+        HIPCHK(hipGetLastError());
+        res = s->d_partial + np;
+      }
+      std::vector<double> part(nout);
+      HIPCHK(hipMemcpyAsync(part.data(), res, nout * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      for (uint64_t o = 0; o < nout; ++o) {
+        const uint64_t l = o & (nl - 1), c = (o >> gd.kl) & (nc - 1), mg = o >> (gd.kl + ki);
+        uint64_t m = 0;
+        for (uint32_t i = 0; i < gd.kg; ++i) m |= ((mg >> i) & 1ull) << gbit[i];
+        for (uint32_t i = 0; i < ki; ++i) m |= ((c >> i) & 1ull) << sbit[i];
+        for (uint32_t i = 0; i < gd.kl; ++i) m |= ((l >> i) & 1ull) << lbit[i];
+        out[m] = part[o];
+      }
+      return QIP_OK;
+    }
+  }
+  if (m_count == 1) {
+    // one outcome: sum over the sub-space whose measured bits read m (measure_prob_fn :65-112)
+    Ins ins = make_ins(pos, 0);
+    const uint64_t count = 1ull << (s->n - k);
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(count / (kBlock * 8), 1), 1024);
+    QCHK(ensure_partial(s, (size_t)gx));
+    hipLaunchKernelGGL((k_measure_probs<T>), dim3(gx, 1), dim3(kBlock), 0, s->stream,
+                       (const amp_t<T>*)s->cur, count, ins, md, m_first, s->d_partial);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)gx);
+    HIPCHK(hipMemcpyAsync(part.data(), s->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double t = 0;
+    for (unsigned b = 0; b < gx; ++b) t += part[b];
+    out[0] = t;
+    return QIP_OK;
+  }
+  // many outcomes: scatter-add |amp|^2 into a device table of 2^k doubles
+  const uint64_t outcomes = 1ull << k;
+  QCHK(ensure_partial(s, outcomes));
+  HIPCHK(hipMemsetAsync(s->d_partial, 0, outcomes * sizeof(double), s->stream));
+  hipLaunchKernelGGL((k_measure_probs_scatter<T>), dim3(grid_stride(s->namps)), dim3(kBlock), 0,
+                     s->stream, (const amp_t<T>*)s->cur, s->namps, md, (uint64_t)0, s->d_partial);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, s->d_partial, outcomes * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_measure_probs(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                           double* out) try {
+  STATE_ENTER(s);
+  if (!out) return fail(QIP_ERR_INVALID, "null output");
+  MeasDesc md;
+  std::vector<uint32_t> pos;
+  QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  if (k > 30) return fail(QIP_ERR_UNSUPPORTED, "measure_probs over %u qubits", k);
+  return s->dtype == QIP_C64 ? measure_probs_t<double>(s, md, pos, 0, 1ull << k, out)
+                             : measure_probs_t<float>(s, md, pos, 0, 1ull << k, out);
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_measure_prob(qip_hip_state* s, uint64_t measured, const uint64_t* indices,
+                                          uint32_t k, double* out) try {
+  STATE_ENTER(s);
+  if (!out) return fail(QIP_ERR_INVALID, "null output");
+  MeasDesc md;
+  std::vector<uint32_t> pos;
+  QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  if (k < 64 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
+  return s->dtype == QIP_C64 ? measure_probs_t<double>(s, md, pos, measured, 1, out)
+                             : measure_probs_t<float>(s, md, pos, measured, 1, out);
+} QIP_CATCH_ALL
+
+static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p);
+
+// soft_measure (measurement_ops.rs:153-176): first index at which r - Σ|amp|² <= 0.  The
+// device sums contiguous chunks; the host walks the chunk sums, then replays the
+// reference's sequential loop inside the one chunk that crosses zero.
+template <typename T>
+static int soft_measure_t(qip_hip_state* s, const MeasDesc& md, double rand_u01, uint64_t* measured) {
+  // Two device passes: per-chunk sums of |amp|^2, then k_find_crossing inside the chunk(s) that may bring the
+  // running remainder to <= 0.  The host only walks the few thousand chunk sums; no amplitude leaves HBM.
+  std::vector<double> sums;
+  uint64_t chunk = 0;
+  QCHK(chunk_norms<T>(s, &chunk, &sums));
+  QCHK(ensure_partial(s, 2));
+  double r = (double)(T)rand_u01;
+  uint64_t measured_indx = 0;
+  for (size_t c = 0; c < sums.size(); ++c) {
+    if (r - sums[c] > 1e-9 * (1.0 + sums[c])) {  // clearly past this chunk
+      r -= sums[c];
+      continue;
+    }
+    const uint64_t lo = (uint64_t)c * chunk, len = std::min<uint64_t>(chunk, s->namps - lo);
+    hipLaunchKernelGGL((k_find_crossing<T>), dim3(1), dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur, lo,
+                       len, r, (uint64_t*)s->d_partial);
+    HIPCHK(hipGetLastError());
+    uint64_t res[2];
+    HIPCHK(hipMemcpyAsync(res, s->d_partial, sizeof res, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (res[0] != ~0ull) {
+      measured_indx = res[0];
+      break;
+    }
+    memcpy(&r, &res[1], sizeof r);  // the chunk was scanned without crossing: carry its exact remainder on
+  }
+  // never crossing: the reference leaves measured_indx = 0 (:166)
+  uint64_t m = 0;
+  for (uint32_t i = 0; i < md.k; ++i) m |= ((measured_indx >> md.mpos[i]) & 1ull) << i;
+  *measured = m;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_soft_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                          double rand_u01, uint64_t* measured) try {
+  STATE_ENTER(s);
+  if (!measured) return fail(QIP_ERR_INVALID, "null output");
+  MeasDesc md;
+  std::vector<uint32_t> pos;
+  QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  return s->dtype == QIP_C64 ? soft_measure_t<double>(s, md, rand_u01, measured)
+                             : soft_measure_t<float>(s, md, rand_u01, measured);
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_measure(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                     int64_t forced, double rand_u01, uint64_t* measured, double* prob) try {
+  STATE_ENTER(s);
+  if (!measured || !prob) return fail(QIP_ERR_INVALID, "null output");
+  MeasDesc md;
+  std::vector<uint32_t> pos;
+  QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  uint64_t m = 0;
+  if (forced >= 0) {
+    m = (uint64_t)forced;
+    if (k < 64 && (m >> k) != 0) return fail(QIP_ERR_INVALID, "forced outcome has more than k bits");
+  } else {
+    QCHK(s->dtype == QIP_C64 ? soft_measure_t<double>(s, md, rand_u01, &m)
+                             : soft_measure_t<float>(s, md, rand_u01, &m));
+  }
+  double p = 0;
+  QCHK(s->dtype == QIP_C64 ? measure_probs_t<double>(s, md, pos, m, 1, &p)
+                           : measure_probs_t<float>(s, md, pos, m, 1, &p));
+  *measured = m;
+  *prob = p;
+  return collapse(s, md, m, p);
+} QIP_CATCH_ALL
+
+static int collapse(qip_hip_state* s, const MeasDesc& md, uint64_t m, double p) {
+  if (p == 0.0) return QIP_OK;  // measure_state is a no-op (:230)
+  uint64_t row_mask = 0, measured_mask = 0;
+  for (uint32_t i = 0; i < md.k; ++i) {
+    row_mask |= 1ull << md.mpos[i];
+    measured_mask |= ((m >> i) & 1ull) << md.mpos[i];
+  }
+  if (s->dtype == QIP_C64) {
+    const double p_mult = 1.0 / std::sqrt(p);
+    hipLaunchKernelGGL((k_collapse<double>), dim3(grid_stride(s->namps)), dim3(kBlock), 0, s->stream,
+                       (amp_t<double>*)s->cur, s->namps, row_mask, measured_mask, p_mult);
+  } else {
+    const float p_mult = 1.0f / std::sqrt((float)p);
+    hipLaunchKernelGGL((k_collapse<float>), dim3(grid_stride(s->namps)), dim3(kBlock), 0, s->stream,
+                       (amp_t<float>*)s->cur, s->namps, row_mask, measured_mask, p_mult);
+  }
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_state_measure_state(qip_hip_state* s, const uint64_t* indices, uint32_t k,
+                                           uint64_t measured, double prob) try {
+  STATE_ENTER(s);
+  MeasDesc md;
+  memset(&md, 0, sizeof md);
+  std::vector<uint32_t> pos;
+  if (k > 0) QCHK(check_measure_indices(s, indices, k, &md, &pos));
+  if (k < 64 && (measured >> k) != 0) return fail(QIP_ERR_INVALID, "measured value has more than k bits");
+  if (!(prob >= 0.0)) return fail(QIP_ERR_INVALID, "probability must be >= 0");
+  return collapse(s, md, measured, prob);
+} QIP_CATCH_ALL
+

@@ -1,0 +1,62 @@
+// qip_tile.h — the host-side tile plan types shared by the scheduler (qip_tile_sched.hip) and the code that runs plans
+// (qip_circuit.hip).
+#pragma once
+#include "qip_internal.h"
+
+struct TileItem {
+  bool tileable = false;
+  // every matrix entry is in {0, +-1, +-i}: the gate moves / negates / rotates amplitudes by 90 degrees without
+  // any rounding, so it commutes with gates on other qubits EXACTLY (IEEE ==), not just mathematically
+  bool exact = false;
+  int kind = 0;                 // TileGate kind
+  std::vector<uint32_t> pos;    // every involved bit position
+  uint32_t t0 = 0, t1 = 0, t2 = 0;  // target position(s)
+  std::vector<uint32_t> cpos;
+  double m[8] = {0};
+  uint32_t nz = 0;
+  std::vector<double> mat;  // kind 3 / 4: 4x4 / 8x8 row-major as re,im pairs, sub-index MSB = t0
+  // how the gate acts on each of its bits: `nd_mask` = it exchanges amplitudes across the bit (dense target, swap
+  // bits), `d_mask` = it only tests the bit (controls, diagonal targets).  Two gates commute when on every bit
+  // they share both only test it.  Ops that are not tileable count every bit as exchanged.
+  uint64_t nd_mask = 0, d_mask = 0;
+  // an uncontrolled Swap(h) (any h): its h transpositions as pairs of bit positions.  A run of such ops composes to ONE
+  // permutation of the index bits (launch_permute)
+  std::vector<std::pair<uint32_t, uint32_t>> swap_pairs;
+};
+
+// Everything the host decides about one segment before anything touches the device: which amplitude-index
+// positions the tile's free bits 6..10 stand for, the gate descriptors, the passes and each gate's resolution
+// against its pass.  Pure host code: qip_hip_debug_tile_plan serialises it so that tests can replay a plan on
+// the CPU (tests/test_tile_plan_cpu.py) and check it against the oracle without a GPU.
+template <typename T> struct TileSegmentPlan {
+  std::vector<uint32_t> high;  // amplitude-index position of tile bit 6 + j
+  std::vector<TileGate<T>> gates;
+  std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
+  TilePassDesc pd;             // passes (only when `passes`)
+};
+
+// One step of a tiled schedule: a segment of >= 2 gates applied in one sweep, or a single op applied by
+// its own kernel (not tileable, or alone — a lone gate's own kernel touches only what can change).
+struct TileStep {
+  std::vector<uint64_t> ops;   // indices into the circuit, in application order
+  std::vector<uint32_t> high;  // the free bit positions the segment claimed (<= kTileHigh)
+  std::vector<uint32_t> perm;  // non-empty: the ops are a run of uncontrolled Swap ops applied as ONE bit-permutation
+                               // sweep, new[j] = old[src(j)], bit perm[d] of src(j) = bit d of j (launch_permute)
+};
+
+struct TileSchedule {
+  const qip_op* circuit = nullptr;  // what the steps' op numbers index: the caller's array, or `owned`
+  uint64_t count = 0;
+  std::vector<qip_op> owned;               // relabelled: the caller's ops under the labels in force when they run + inserted swaps
+  std::deque<std::vector<uint64_t>> idx;   // their index lists
+  std::vector<int64_t> origin;             // relabelled: position in the caller's circuit, -1 = inserted swap
+  std::vector<TileItem> items;             // one per entry of `circuit`
+  std::vector<TileStep> steps;
+  uint64_t absorbed = 0, inserted = 0;     // Swap ops turned into label exchanges / in-tile swaps added
+};
+
+int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it);
+template <typename T>
+int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, TileSegmentPlan<T>* out);
+int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                       bool allow_permute = true);

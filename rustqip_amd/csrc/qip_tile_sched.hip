@@ -1,0 +1,770 @@
+// qip_tile_sched.hip — the host-only half of the LDS-resident tile sweeps: which gates form a segment, the passes of a
+// segment, the qubit relabelling, and the plan export the CPU tests replay.  No kernel is launched from this file.
+#include "qip_tile.h"
+
+// ---------------------------------------------------------------------------------------
+// LDS-resident multi-gate sweeps (option "tile"): the scheduler cuts the circuit into segments whose
+// gates all live on index bits 0..5 plus five freely chosen higher bits, and k_tile_gates applies a whole
+// segment with one read and one write of the vector.
+//   tile = 1  circuit order up to EXACT commutations (a rounding-free gate — X, CNOT, SWAP, Z, S ... — may pass
+//             gates on other qubits and vice versa): every amplitude sees the same rounded operations in the
+//             same order as in the gate-by-gate path, hence IEEE-equal results;
+//   tile = 2  any gate may be hoisted over skipped gates it shares no qubit with (they commute mathematically,
+//             not in floating point); equal to the reference up to rounding (1e-12 bar).
+// ---------------------------------------------------------------------------------------
+
+int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it) {
+  FlatOp f;
+  QCHK(flatten_op(n, op, false, &f));
+  Plan p;
+  QCHK(make_plan(dtype, n, f, false, &p));
+  it->tileable = false;
+  it->pos.clear();
+  for (uint32_t c : p.cpos) it->pos.push_back(c);
+  for (uint32_t t : p.opos) it->pos.push_back(t);
+  it->cpos = p.cpos;
+  it->swap_pairs.clear();
+  if (!f.distinct) return QIP_OK;
+  const uint32_t k = (uint32_t)p.opos.size();
+  if (p.cls == KC_SWAP_BITS && p.cpos.empty())
+    for (uint32_t j = 0; j < k / 2; ++j) it->swap_pairs.push_back({p.opos[j], p.opos[k / 2 + j]});
+  auto unit_axis = [](double re, double im) {  // 0, +-1 or +-i
+    return (re == 0.0 && (im == 0.0 || im == 1.0 || im == -1.0)) || (im == 0.0 && (re == 1.0 || re == -1.0));
+  };
+  if (p.cls == KC_GATE1Q_PAIR) {
+    it->kind = 0;
+    it->t0 = p.opos[0];
+    memcpy(it->m, p.m, sizeof it->m);
+    it->nz = p.nz;
+    it->tileable = true;
+    it->exact = true;
+    for (int e = 0; e < 4; ++e) it->exact = it->exact && unit_axis(p.m[2 * e], p.m[2 * e + 1]);
+    // at most one non-zero entry per row, else the row is a sum of two terms (rounded)
+    it->exact = it->exact && !((p.nz & 1u) && (p.nz & 2u)) && !((p.nz & 4u) && (p.nz & 8u));
+  } else if (p.cls == KC_PHASE && k == 1) {
+    it->kind = 1;
+    it->t0 = p.opos[0];
+    const bool on_one = p.phase_ones & 1ull;
+    it->m[0] = on_one ? 1.0 : p.phase[0];
+    it->m[1] = on_one ? 0.0 : p.phase[1];
+    it->m[2] = on_one ? p.phase[0] : 1.0;
+    it->m[3] = on_one ? p.phase[1] : 0.0;
+    it->tileable = true;
+    it->exact = unit_axis(p.phase[0], p.phase[1]);
+  } else if (p.cls == KC_DIAG && k == 1) {
+    it->kind = 1;
+    it->t0 = p.opos[0];
+    for (int e = 0; e < 4; ++e) it->m[e] = p.table[e];
+    it->tileable = true;
+    it->exact = unit_axis(p.table[0], p.table[1]) && unit_axis(p.table[2], p.table[3]);
+  } else if (p.cls == KC_SWAP_BITS && k == 2) {
+    it->kind = 2;
+    it->t0 = std::min(p.opos[0], p.opos[1]);
+    it->t1 = std::max(p.opos[0], p.opos[1]);
+    it->tileable = true;
+    it->exact = true;
+  } else if (p.cls == KC_GATE_KQ && k == 2 && p.table.size() == 32) {
+    it->kind = 3;  // dense 2-qubit gate: both targets exchange amplitudes
+    it->t0 = p.opos[0];
+    it->t1 = p.opos[1];
+    it->mat = p.table;
+    it->tileable = true;
+  } else if (p.cls == KC_GATE_KQ && k == 3 && p.table.size() == 128) {
+    it->kind = 4;  // dense 3-qubit gate: a pass whose three bits are its targets holds one group per lane
+    it->t0 = p.opos[0];
+    it->t1 = p.opos[1];
+    it->t2 = p.opos[2];
+    it->mat = p.table;
+    it->tileable = true;
+  } else if (p.cls == KC_NOOP) {
+    it->exact = true;  // identity: nothing happens (not tileable, launches nothing)
+  }
+  it->nd_mask = it->d_mask = 0;
+  if (it->tileable) {
+    for (uint32_t c : p.cpos) it->d_mask |= 1ull << c;
+    if (it->kind == 1) it->d_mask |= 1ull << it->t0;
+    else it->nd_mask |= 1ull << it->t0;
+    if (it->kind >= 2) it->nd_mask |= 1ull << it->t1;
+    if (it->kind == 4) it->nd_mask |= 1ull << it->t2;
+  } else {
+    for (uint32_t b : it->pos) it->nd_mask |= 1ull << b;
+  }
+  return QIP_OK;
+}
+
+// Lane-id bit -> tile bit for one pass of k_tile_passes (TilePass::lanepos): lane bit j < S goes on tile bit j or
+// j + S (whichever is not a pass bit), so the S swizzled slot bits enumerate the lanes of an LDS bank group; the
+// other lane bits fill what is left, bits that are not folded (>= 2S) first, then partners of the pairs that hold
+// lane bits 0 and 1 (lane bit 4 varies inside a ds_read_b128 group in a pattern that is closed under flipping lane
+// bits 0 / 1 only).  S = 4 for 16-byte amplitudes, 5 for 8-byte ones.  `pb` ascending and distinct.  Returns 0 if
+// the result is not a bijection onto the non-pass bits (cannot happen; the caller refuses to launch).
+// Checked against the LDS banking model of MI355X_MICROARCH.md in tests/test_host_ops.py.
+uint64_t tile_lane_assignment(const uint32_t pb[3], uint32_t S) {
+  auto has = [&](uint32_t t) { return t == pb[0] || t == pb[1] || t == pb[2]; };
+  int pos_of[kTileLaneBits];
+  for (int k = 0; k < kTileLaneBits; ++k) pos_of[k] = -1;
+  bool used[kTileBits] = {false};
+  std::vector<int> rest_bits;
+  for (uint32_t j = 0; j < S; ++j) {
+    int where = -1;
+    for (uint32_t c : {j, j + S})
+      if (c < (uint32_t)kTileBits && !has(c) && !used[c]) {
+        where = (int)c;
+        break;
+      }
+    if (where >= 0) {
+      pos_of[j] = where;
+      used[where] = true;
+    } else {
+      rest_bits.push_back((int)j);
+    }
+  }
+  for (int k = (int)S; k < kTileLaneBits; ++k) rest_bits.push_back(k);
+  std::vector<int> rest_pos;
+  for (int t = 0; t < kTileBits; ++t)
+    if (!has((uint32_t)t) && !used[t]) rest_pos.push_back(t);
+  auto rank = [&](int t) {
+    if (t >= (int)(2 * S)) return 0;
+    const int j = t >= (int)S ? t - (int)S : t;
+    for (int k = 0; k < 2; ++k)
+      if (pos_of[k] == j || pos_of[k] == j + (int)S) return 1;
+    return 2;
+  };
+  std::stable_sort(rest_pos.begin(), rest_pos.end(), [&](int x, int y) { return rank(x) < rank(y); });
+  if (rest_bits.size() != rest_pos.size()) return 0;
+  for (size_t q = 0; q < rest_bits.size(); ++q) pos_of[rest_bits[q]] = rest_pos[q];
+  uint64_t lanepos = 0;
+  uint32_t covered = 0;
+  for (int k = 0; k < kTileLaneBits; ++k) {
+    lanepos |= (uint64_t)pos_of[k] << (4 * k);
+    covered |= 1u << pos_of[k];
+  }
+  for (int j = 0; j < 3; ++j) covered |= 1u << pb[j];
+  // (all-zero is not a valid assignment: thread-id bits 0 and 1 cannot both sit on tile bit 0)
+  return covered == (1u << kTileBits) - 1u ? lanepos : 0ull;
+}
+
+extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint64_t* lanepos) try {
+  if (!pass_bits || !lanepos) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  uint32_t pb[3] = {pass_bits[0], pass_bits[1], pass_bits[2]};
+  if (!(pb[0] < pb[1] && pb[1] < pb[2] && pb[2] < (uint32_t)kTileBits))
+    return fail(QIP_ERR_INVALID, "pass bits must be ascending, distinct and below %d", kTileBits);
+  *lanepos = tile_lane_assignment(pb, dtype == QIP_C64 ? 4u : 5u);
+  if (*lanepos == 0ull) return fail(QIP_ERR_UNSUPPORTED, "lane-bit assignment is not a bijection (internal error)");
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+
+template <typename T>
+int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg,
+                              std::vector<uint32_t> high, TileSegmentPlan<T>* out) {
+  // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
+  for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < n; ++p)
+    if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+  // the first kTileWaveBits free positions are wave bits at load / store time, the last three are the lane's own
+  // elements: give the free positions that are exchange targets least often to the wave bits
+  std::vector<uint32_t> uses(64, 0);
+  for (const TileItem* it : seg) {
+    if (it->kind == 0) uses[it->t0] += 1;
+    if (it->kind >= 2) {
+      uses[it->t0] += 1;
+      uses[it->t1] += 1;
+    }
+    if (it->kind == 4) uses[it->t2] += 1;
+  }
+  std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
+  auto tile_bit = [&](uint32_t pos) -> uint32_t {  // kTileOutside when the position is not part of the tile
+    if (pos < (uint32_t)kTileLow) return pos;
+    const auto f = std::find(high.begin(), high.end(), pos);
+    return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
+  };
+  std::vector<TileGate<T>>& gates = out->gates;
+  std::vector<amp_t<T>>& mats = out->mats;
+  gates.assign(seg.size(), TileGate<T>());
+  mats.clear();
+  for (size_t i = 0; i < seg.size(); ++i) {
+    const TileItem& it = *seg[i];
+    TileGate<T>& g = gates[i];
+    memset(&g, 0, sizeof g);
+    g.kind = (uint32_t)it.kind;
+    g.b0 = tile_bit(it.t0);
+    g.b1 = it.kind >= 2 ? tile_bit(it.t1) : 0;
+    if (it.kind == 2 && g.b0 > g.b1) std::swap(g.b0, g.b1);  // (kind 3 keeps b0 = the sub-index MSB)
+    if (it.kind == 3 || it.kind == 4) {
+      g.nz = (uint32_t)(mats.size() / 16);  // where its 4x4 / 8x8 starts in the matrix block behind the gate list (units of 16)
+      const int cnt = it.kind == 3 ? 16 : 64;
+      for (int e = 0; e < cnt; ++e) mats.push_back(mk<T>(it.mat[2 * e], it.mat[2 * e + 1]));
+    }
+    if (it.kind == 4) g.tpos_out = tile_bit(it.t2);  // (tile bit of the sub-index LSB; the field is otherwise unused for this kind)
+    if (it.kind == 1 && g.b0 == kTileOutside) g.tpos_out = it.t0;
+    for (uint32_t c : it.cpos) {
+      const uint32_t tb = tile_bit(c);
+      if (tb == kTileOutside) g.omask |= 1ull << c;
+      else g.cmask |= 1u << tb;
+    }
+    if (it.kind != 3 && it.kind != 4) g.nz = it.nz;
+    if (it.kind == 0) {
+      for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
+      if (passes) {  // flop-saving flags (k_tile_passes only; k_tile_gates reads b1 = 0)
+        const bool real = it.m[1] == 0 && it.m[3] == 0 && it.m[5] == 0 && it.m[7] == 0;
+        const bool is_x = it.nz == 6u && it.m[2] == 1 && it.m[3] == 0 && it.m[4] == 1 && it.m[5] == 0;
+        g.b1 = (real ? 1u : 0u) | (is_x ? 2u : 0u);
+      }
+    } else if (it.kind == 1) {
+      g.m[0] = mk<T>(it.m[0], it.m[1]);
+      g.m[1] = mk<T>(it.m[2], it.m[3]);
+    }
+  }
+  out->high = high;
+  memset(&out->pd, 0, sizeof out->pd);
+  if (passes) {
+    // group consecutive gates into passes of at most three distinct exchange bits (see k_tile_passes)
+    TilePassDesc& pd = out->pd;
+    memset(&pd, 0, sizeof pd);
+    for (int j = 0; j < kTileHigh; ++j) pd.hpos[j] = high[j];
+    std::vector<uint32_t> bits;
+    uint32_t first = 0;
+    constexpr uint32_t S = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // swizzle fold width, see TilePass
+    bool pass_layout_ok = true;
+    auto close_pass = [&](uint32_t end) {
+      std::vector<uint32_t> b = bits;
+      auto has = [&](uint32_t t) { return std::find(b.begin(), b.end(), t) != b.end(); };
+      // Pad to three bits.  A free slot is best spent on a bit the pass's DIAGONAL gates test: a control on a
+      // pass bit, or the target of a gate with one unit entry (phase, T, S, Z, controlled-phase), turns "multiply
+      // all eight elements" into "multiply the four (two) that can change" by a scalar branch.  Otherwise from the
+      // top; never completing a pair (t, t +- S) unless nothing else is left: such a pass is 2-way
+      // bank-conflicted (and low pad bits are what made the linear layout 8-way).
+      int score[kTileBits] = {0};
+      for (uint32_t gi = first; gi < end; ++gi) {
+        const TileGate<T>& g = gates[gi];
+        if (g.kind != 1) continue;
+        for (int t = 0; t < kTileBits; ++t)
+          if ((g.cmask >> t) & 1u) score[t] += 1;
+        const bool unit0 = g.m[0].x == (T)1 && g.m[0].y == (T)0, unit1 = g.m[1].x == (T)1 && g.m[1].y == (T)0;
+        if (g.b0 != kTileOutside && (unit0 || unit1)) score[g.b0] += 1;
+      }
+      std::vector<int> order;
+      for (int t = kTileBits - 1; t >= 0; --t) order.push_back(t);
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return score[x] > score[y]; });
+      for (int relax = 0; relax < 2 && b.size() < 3; ++relax)
+        for (size_t q = 0; q < order.size() && b.size() < 3; ++q) {
+          const int t = order[q];
+          if (has((uint32_t)t)) continue;
+          const bool pairs = has((uint32_t)t + S) || (t >= (int)S && has((uint32_t)t - S));
+          if (pairs && relax == 0) continue;
+          b.push_back((uint32_t)t);
+        }
+      std::sort(b.begin(), b.end());
+      TilePass& ps = pd.pass[pd.npasses++];
+      ps.first = first;
+      ps.count = end - first;
+      for (int j = 0; j < 3; ++j) ps.pb[j] = b[j];
+      ps.lanepos = tile_lane_assignment(ps.pb, S);
+      if (ps.lanepos == 0ull) pass_layout_ok = false;  // not a bijection: refuse to launch
+      first = end;
+      bits.clear();
+    };
+    for (uint32_t i = 0; i < (uint32_t)gates.size(); ++i) {
+      std::vector<uint32_t> add;
+      if (gates[i].kind == 0) add = {gates[i].b0};
+      if (gates[i].kind == 2 || gates[i].kind == 3) add = {gates[i].b0, gates[i].b1};
+      if (gates[i].kind == 4) add = {gates[i].b0, gates[i].b1, gates[i].tpos_out};  // exactly the pass
+      if (!add.empty()) {
+        // a control of a dense gate / swap is a scalar branch on a pass bit but a per-lane select on a lane
+        // bit (k_tile_passes): make the in-tile controls pass bits too whenever the three slots allow
+        std::vector<uint32_t> with_ctl = add;
+        for (uint32_t t = 0; t < (uint32_t)kTileBits; ++t)
+          if ((gates[i].cmask >> t) & 1u) with_ctl.push_back(t);
+        if (with_ctl.size() <= 3) add = with_ctl;
+      }
+      auto merge = [&](const std::vector<uint32_t>& extra) {
+        std::vector<uint32_t> m = bits;
+        for (uint32_t b : extra)
+          if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
+        return m;
+      };
+      std::vector<uint32_t> merged = merge(add);
+      if (merged.size() > 3) {
+        close_pass(i);
+        merged = add;
+      }
+      bits = merged;
+    }
+    close_pass((uint32_t)gates.size());
+    if (!pass_layout_ok) return fail(QIP_ERR_UNSUPPORTED, "tile pass: lane-bit assignment is not a bijection (internal error)");
+    // resolve every gate against its pass: code path, pass-bit index of its bit(s), controls split into pass-bit
+    // and lane-bit parts (see TileGate::op)
+    for (uint32_t pi = 0; pi < pd.npasses; ++pi) {
+      const TilePass& ps = pd.pass[pi];
+      const uint32_t passmask = (1u << ps.pb[0]) | (1u << ps.pb[1]) | (1u << ps.pb[2]);
+      auto jof = [&](uint32_t bit) { return bit == ps.pb[0] ? 0u : bit == ps.pb[1] ? 1u : 2u; };
+      for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+        TileGate<T>& g = gates[gi];
+        g.cm_reg = g.cmask & passmask;
+        g.cm_lane = g.cmask & ~passmask;
+        const bool lane_ctl = g.cm_lane != 0u;
+        if (g.kind == 1) {
+          const bool outside = g.b0 == kTileOutside;
+          if (outside && !lane_ctl) g.op = TOP_DIAG_UNIFORM;
+          else if (outside || !((passmask >> g.b0) & 1u)) g.op = lane_ctl ? TOP_DIAG_LANE_CTL : TOP_DIAG_LANE;
+          else g.op = TOP_DIAG_REG0 + jof(g.b0);
+        } else if (g.kind == 0) {
+          g.op = (lane_ctl ? TOP_DENSE_LANE0 : TOP_DENSE0) + jof(g.b0);
+        } else if (g.kind == 4) {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1), jc = jof(g.tpos_out);
+          static const uint32_t t3[3][3] = {{0, TOP_DENSE3Q_012, TOP_DENSE3Q_021}, {TOP_DENSE3Q_102, 0, TOP_DENSE3Q_120},
+                                            {TOP_DENSE3Q_201, TOP_DENSE3Q_210, 0}};
+          g.op = t3[ja][jb];
+          (void)jc;  // = 3 - ja - jb
+        } else if (g.kind == 3) {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1);
+          static const uint32_t table[3][3] = {{0, TOP_DENSE2Q_01, TOP_DENSE2Q_02},
+                                               {TOP_DENSE2Q_10, 0, TOP_DENSE2Q_12},
+                                               {TOP_DENSE2Q_20, TOP_DENSE2Q_21, 0}};
+          g.op = table[ja][jb];
+        } else {
+          const uint32_t ja = jof(g.b0), jb = jof(g.b1);  // b0 < b1 and pass bits ascend, so ja < jb
+          g.op = ja == 0 ? (jb == 1 ? TOP_SWAP_01 : TOP_SWAP_02) : TOP_SWAP_12;
+        }
+      }
+    }
+  }
+  return QIP_OK;
+}
+
+
+// Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
+// qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it commutes with (on every
+// shared bit both only test it); without `reorder` only when it, or every op it overtakes, is rounding-free.
+int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder,
+                          std::vector<TileItem>* items_out, std::vector<TileStep>* steps, bool allow_2q = true,
+                          bool allow_permute = true) {
+  std::vector<TileItem>& items = *items_out;
+  items.assign(count, TileItem());
+  for (uint64_t i = 0; i < count; ++i) {
+    int rc = classify_tile_item(dtype, n, &ops[i], &items[i]);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+    if (items[i].kind >= 3 && !allow_2q) items[i].tileable = false;  // k_tile_gates has no 2- / 3-qubit form
+  }
+  std::vector<char> done(count, 0);
+  uint64_t head = 0;
+  const uint64_t window = 256;
+  while (head < count) {
+    if (done[head]) {
+      ++head;
+      continue;
+    }
+    // A run of uncontrolled Swap ops that one segment cannot hold (more than kTileHigh of the moved positions lie above
+    // the tile's fixed low bits — QFT's closing bit reversal is 15 transpositions over all 30 positions) composes to one
+    // permutation of the index bits and goes as ONE out-of-place sweep.  Swaps only move amplitudes, so this is
+    // bit-identical to applying them one by one.  Ops of the run that an earlier segment already hoisted are skipped:
+    // the hoist was only legal because they commute with everything in between.
+    if (allow_permute && !items[head].swap_pairs.empty()) {
+      TileStep run;
+      run.perm.resize(n);
+      for (uint32_t b = 0; b < n; ++b) run.perm[b] = b;
+      uint64_t moved = 0, j = head;
+      for (; j < count; ++j) {
+        if (done[j]) continue;
+        if (items[j].swap_pairs.empty()) break;
+        std::vector<uint32_t> tau(n);
+        for (uint32_t b = 0; b < n; ++b) tau[b] = b;
+        for (const auto& pr : items[j].swap_pairs) {
+          tau[pr.first] = pr.second;
+          tau[pr.second] = pr.first;
+          moved |= (1ull << pr.first) | (1ull << pr.second);
+        }
+        std::vector<uint32_t> next(n);
+        for (uint32_t b = 0; b < n; ++b) next[b] = run.perm[tau[b]];  // out2[j] = out1[tau(j)] = in[pi(tau(j))]
+        run.perm = next;
+        run.ops.push_back(j);
+      }
+      if (run.ops.size() >= 2 && __builtin_popcountll(moved >> kTileLow) > kTileHigh) {
+        for (uint64_t i : run.ops) done[i] = 1;
+        steps->push_back(run);
+        continue;
+      }
+    }
+    if (!items[head].tileable) {
+      steps->push_back(TileStep{{head}, {}, {}});
+      done[head++] = 1;
+      continue;
+    }
+    // Grow a segment from `head`, scanning ahead.  A later gate may join over the gates skipped so far only if
+    // it commutes with each of them — on every bit they share, both gates only TEST the bit (control or diagonal
+    // target), neither exchanges amplitudes across it — and, unless `reorder` (which accepts rounding-level
+    // differences), the commutation is EXACT: the gate itself, or every skipped gate, is rounding-free
+    // (entries in {0, +-1, +-i}: X, Y, Z, S, CNOT, CZ, Toffoli, SWAP ...).  Exact commutations leave every
+    // amplitude's sequence of rounded operations unchanged, so the result stays IEEE-equal to circuit order.
+    TileStep st;
+    uint64_t blocked_nd = 0, blocked_d = 0;  // bits the skipped gates exchange across / only test
+    bool skipped_inexact = false;            // some skipped gate rounds
+    bool any_skipped = false;
+    size_t exch_gates = 0;  // gates that may open a pass (kTileMaxExchGates bounds the pass table)
+    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && st.ops.size() < (size_t)kTileMaxGates; ++i) {
+      if (done[i]) continue;
+      const TileItem& it = items[i];
+      const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact) &&
+                  (it.kind == 1 || exch_gates < (size_t)kTileMaxExchGates);
+      std::vector<uint32_t> need;
+      if (fits) {
+        // only bits the gate exchanges amplitudes across must be tile bits: a dense target, both swap bits;
+        // controls and diagonal targets may stay outside (block-uniform predicates)
+        std::vector<uint32_t> exch;
+        if (it.kind == 0) exch = {it.t0};
+        if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
+        if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
+        for (uint32_t p : exch)
+          if (p >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
+              std::find(need.begin(), need.end(), p) == need.end())
+            need.push_back(p);
+        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
+      }
+      if (fits) {
+        for (uint32_t p : need) st.high.push_back(p);
+        st.ops.push_back(i);
+        done[i] = 1;
+        exch_gates += it.kind != 1;
+      } else {
+        blocked_nd |= it.nd_mask;
+        blocked_d |= it.d_mask;
+        skipped_inexact = skipped_inexact || !it.exact;
+        any_skipped = true;
+      }
+    }
+    steps->push_back(st);
+  }
+  return QIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Qubit relabelling above the tile sweeps (option "tile_relabel"; `mode` bit 2 in the host-only hooks).
+//
+// A tile always holds index bits 0..5 (that is what makes its rows contiguous), so six of its eleven bits are spent on
+// whatever qubits happen to live there.  With a logical -> physical map of the bit positions the scheduler decides who
+// lives there: at the end of every segment the tile's eleven qubits are rearranged — in-tile bit swaps riding along in the
+// same sweep — so that the six whose next amplitude-exchanging use comes soonest sit on positions 0..5 (Belady's rule),
+// and the next segment spends its five free positions on five OTHER qubits.  An uncontrolled Swap op costs nothing at all:
+// it only exchanges two labels.  One bit-permutation sweep at the end puts every qubit back where the caller expects it.
+// Everything added is a pure move of amplitudes and every gate keeps its place in the order of the plain schedule, so the
+// result is bit-identical to tile = 1 / 2 without relabelling (and, for tile = 1, to the gate-by-gate path).
+// configs[1] at n = 30 (256 gates): 19 -> 13 + 1 sweeps; 1024 gates: 70 -> 47 + 1.
+// ---------------------------------------------------------------------------------------
+
+int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder, bool allow_2q,
+                                  TileSchedule* out) {
+  std::vector<TileItem> L(count);  // the caller's ops, logical bit positions
+  for (uint64_t i = 0; i < count; ++i) {
+    int rc = classify_tile_item(dtype, n, &ops[i], &L[i]);
+    if (rc != QIP_OK) {
+      std::string msg = g_last_error;
+      return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());
+    }
+    if (L[i].kind >= 3 && !allow_2q) L[i].tileable = false;
+  }
+  std::vector<uint32_t> phys(n);  // phys[p] = physical position of logical bit position p
+  for (uint32_t p = 0; p < n; ++p) phys[p] = p;
+  auto push_op = [&](const qip_op& o, int64_t origin) -> int {
+    out->owned.push_back(o);
+    out->origin.push_back(origin);
+    out->items.emplace_back();
+    int rc = classify_tile_item(dtype, n, &out->owned.back(), &out->items.back());
+    if (rc == QIP_OK && out->items.back().kind >= 3 && !allow_2q) out->items.back().tileable = false;
+    return rc;
+  };
+  // the caller's op i under the labels in force now: same descriptor, qubit indices mapped through `phys`
+  auto emit = [&](uint64_t i, uint64_t* at) -> int {
+    qip_op o = ops[i];
+    out->idx.emplace_back(o.n_indices);
+    std::vector<uint64_t>& v = out->idx.back();
+    for (uint32_t j = 0; j < o.n_indices; ++j) v[j] = (uint64_t)(n - 1 - phys[n - 1 - (uint32_t)o.indices[j]]);
+    o.indices = v.data();
+    *at = out->owned.size();
+    return push_op(o, (int64_t)i);
+  };
+  auto emit_swap = [&](uint32_t pa, uint32_t pb, uint64_t* at) -> int {  // physical positions
+    qip_op o;
+    memset(&o, 0, sizeof o);
+    o.kind = QIP_OP_SWAP;
+    o.n_indices = 2;
+    out->idx.emplace_back(std::vector<uint64_t>{(uint64_t)(n - 1 - pa), (uint64_t)(n - 1 - pb)});
+    o.indices = out->idx.back().data();
+    *at = out->owned.size();
+    return push_op(o, -1);
+  };
+  auto absorb = [&](const TileItem& it) {  // an uncontrolled Swap: the two qubits trade places by name
+    for (const auto& pr : it.swap_pairs) std::swap(phys[pr.first], phys[pr.second]);
+    out->absorbed += 1;
+  };
+  std::vector<char> done(count, 0);
+  uint64_t head = 0;
+  const uint64_t window = 256;
+  const size_t max_circuit_ops = (size_t)kTileMaxGates - (size_t)kTileLow;  // room for the segment's closing swaps
+  while (head < count) {
+    if (done[head]) {
+      ++head;
+      continue;
+    }
+    if (!L[head].swap_pairs.empty()) {  // everything before it is done; ops hoisted over it share no qubit with it
+      absorb(L[head]);
+      done[head++] = 1;
+      continue;
+    }
+    if (!L[head].tileable) {
+      uint64_t at = 0;
+      QCHK(emit(head, &at));
+      out->steps.push_back(TileStep{{at}, {}, {}});
+      done[head++] = 1;
+      continue;
+    }
+    // the segment: schedule_tiles' rules on the logical masks (commutation does not depend on names), the tile test on
+    // the physical positions
+    TileStep st;
+    uint64_t blocked_nd = 0, blocked_d = 0;
+    bool skipped_inexact = false, any_skipped = false;
+    size_t joined = 0, exch_gates = 0;
+    for (uint64_t i = head; i < count && i <= head + (any_skipped ? window : count) && joined < max_circuit_ops; ++i) {
+      if (done[i]) continue;
+      const TileItem& it = L[i];
+      if (!any_skipped && !it.swap_pairs.empty()) {  // in circuit order, nothing pending before it: a label exchange
+        absorb(it);
+        done[i] = 1;
+        continue;
+      }
+      const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
+      bool fits = it.tileable && commutes && (reorder || it.exact || !skipped_inexact) &&
+                  (it.kind == 1 || exch_gates < (size_t)kTileMaxExchGates - (size_t)kTileLow);  // (room for the closing swaps)
+      std::vector<uint32_t> need;
+      if (fits) {
+        std::vector<uint32_t> exch;
+        if (it.kind == 0) exch = {it.t0};
+        if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
+        if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
+        for (uint32_t p : exch) {
+          const uint32_t pp = phys[p];
+          if (pp >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), pp) == st.high.end() &&
+              std::find(need.begin(), need.end(), pp) == need.end())
+            need.push_back(pp);
+        }
+        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
+      }
+      if (fits) {
+        for (uint32_t pp : need) st.high.push_back(pp);
+        uint64_t at = 0;
+        QCHK(emit(i, &at));
+        st.ops.push_back(at);
+        done[i] = 1;
+        joined += 1;
+        exch_gates += it.kind != 1;
+      } else {
+        blocked_nd |= it.nd_mask;
+        blocked_d |= it.d_mask;
+        skipped_inexact = skipped_inexact || !it.exact;
+        any_skipped = true;
+      }
+    }
+    // Who should live on positions 0..5 next?  Next amplitude-exchanging use of every qubit (ops not done yet, circuit
+    // order).  First spend the tile's unclaimed free positions on the soonest-needed qubits outside the tile (they can
+    // then be brought down as well), then bring the soonest-needed of the tile's qubits down, evicting the ones needed
+    // last.  A lone gate keeps its own kernel (it touches only what can change): no swaps for it.
+    if (st.ops.size() >= 2) {
+      std::vector<uint64_t> nxt(n, ~0ull);
+      {
+        uint32_t found = 0;
+        for (uint64_t i = head; i < count && found < n; ++i) {
+          if (done[i] || !L[i].tileable) continue;
+          uint64_t m = L[i].nd_mask;
+          while (m) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            if (nxt[p] == ~0ull) {
+              nxt[p] = i;
+              ++found;
+            }
+          }
+        }
+      }
+      auto in_tile = [&](uint32_t pp) { return pp < (uint32_t)kTileLow || std::find(st.high.begin(), st.high.end(), pp) != st.high.end(); };
+      std::vector<uint32_t> by_use;  // logical positions with a future use, soonest first
+      for (uint32_t p = 0; p < n; ++p)
+        if (nxt[p] != ~0ull) by_use.push_back(p);
+      std::stable_sort(by_use.begin(), by_use.end(), [&](uint32_t a, uint32_t b) { return nxt[a] < nxt[b]; });
+      for (uint32_t p : by_use) {
+        if (st.high.size() >= (size_t)kTileHigh) break;
+        if (!in_tile(phys[p])) st.high.push_back(phys[p]);
+      }
+      std::vector<uint32_t> tile_log;
+      for (uint32_t p = 0; p < n; ++p)
+        if (in_tile(phys[p])) tile_log.push_back(p);
+      std::stable_sort(tile_log.begin(), tile_log.end(), [&](uint32_t a, uint32_t b) { return nxt[a] < nxt[b]; });
+      std::vector<uint32_t> bring, evict;
+      for (size_t r = 0; r < tile_log.size(); ++r) {
+        const uint32_t p = tile_log[r];
+        const bool wanted = r < (size_t)kTileLow && nxt[p] != ~0ull;
+        if (wanted && phys[p] >= (uint32_t)kTileLow) bring.push_back(p);
+        if (!wanted && phys[p] < (uint32_t)kTileLow) evict.push_back(p);
+      }
+      std::reverse(evict.begin(), evict.end());  // needed last (or never) goes first
+      for (size_t r = 0; r < bring.size() && r < evict.size() && st.ops.size() < (size_t)kTileMaxGates; ++r) {
+        uint64_t at = 0;
+        QCHK(emit_swap(phys[bring[r]], phys[evict[r]], &at));
+        st.ops.push_back(at);
+        std::swap(phys[bring[r]], phys[evict[r]]);
+        out->inserted += 1;
+      }
+    }
+    out->steps.push_back(st);
+  }
+  // every qubit back to the position the caller expects: final index bit d takes the bit that lives on phys[d] now
+  bool identity = true;
+  for (uint32_t p = 0; p < n; ++p) identity = identity && phys[p] == p;
+  if (!identity) {
+    TileStep back;
+    back.perm = phys;
+    out->steps.push_back(back);
+  }
+  out->circuit = out->owned.data();
+  out->count = out->owned.size();
+  return QIP_OK;
+}
+
+// mode: bits 0-1 = the "tile" option (1 = circuit order, 2 = commuting reorder), bit 2 = relabel the qubits when that
+// shortens the plan, bit 3 = relabel unconditionally
+int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                              bool allow_permute) {
+  const bool reorder = (mode & 3) >= 2;
+  if ((mode & 4) && allow_permute) {
+    // relabelling pays for random circuits; layered ones (Grover's X / H walls, QFT) gain nothing and would only pay the
+    // closing permutation: schedule both ways (host work, microseconds per gate) and keep the shorter plan
+    QCHK(schedule_tiles_relabel(dtype, n, ops, count, reorder, allow_2q, out));
+    TileSchedule plain;
+    QCHK(schedule_tiles(dtype, n, ops, count, reorder, &plain.items, &plain.steps, allow_2q));
+    if (out->steps.size() < plain.steps.size() || (mode & 8)) return QIP_OK;  // bit 3: keep it regardless (tests)
+    *out = TileSchedule();
+  }
+  out->circuit = ops;
+  out->count = count;
+  return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q, allow_permute);
+}
+
+extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
+                                  int64_t* step_of_op, uint64_t* n_steps) try {
+  if ((count && (!ops || !step_of_op)) || !n_steps) return fail(QIP_ERR_INVALID, "null argument");
+  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits);
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  for (uint64_t i = 0; i < count; ++i) step_of_op[i] = -1;  // relabelled: an absorbed Swap op belongs to no step
+  for (size_t si = 0; si < sc.steps.size(); ++si)
+    for (uint64_t i : sc.steps[si].ops) {
+      const int64_t o = sc.origin.empty() ? (int64_t)i : sc.origin[i];
+      if (o >= 0) step_of_op[o] = (int64_t)si;
+    }
+  *n_steps = sc.steps.size();
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// Host-only: the complete tile plan of a circuit as JSON (schedule, and for every multi-gate step the segment
+// plan of build_tile_segment).  Test infrastructure for the host half of the tile path: tests replay the plan
+// on the CPU with a numpy model of k_tile_passes and compare with the oracle, no GPU involved.
+template <typename T>
+static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, std::string* out) {
+  TileSchedule sc;
+  QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
+  const std::vector<TileItem>& items = sc.items;
+  const std::vector<TileStep>& steps = sc.steps;
+  char buf[256];
+  auto num = [&](double v) {
+    snprintf(buf, sizeof buf, "%.17g", v);
+    return std::string(buf);
+  };
+  std::string& js = *out;
+  js = "{\"n\":" + std::to_string(n);
+  if (!sc.origin.empty()) {  // relabelled: the circuit the steps index (origin = the caller's op, -1 = inserted swap; qubit indices)
+    js += ",\"absorbed\":" + std::to_string(sc.absorbed) + ",\"inserted\":" + std::to_string(sc.inserted) + ",\"circuit\":[";
+    for (uint64_t i = 0; i < sc.count; ++i) {
+      js += std::string(i ? "," : "") + "{\"o\":" + std::to_string(sc.origin[i]) + ",\"i\":[";
+      for (uint32_t j = 0; j < sc.circuit[i].n_indices; ++j) js += (j ? "," : "") + std::to_string(sc.circuit[i].indices[j]);
+      js += "]}";
+    }
+    js += "]";
+  }
+  js += ",\"steps\":[";
+  for (size_t si = 0; si < steps.size(); ++si) {
+    const TileStep& st = steps[si];
+    if (si) js += ",";
+    js += "{\"ops\":[";
+    for (size_t k = 0; k < st.ops.size(); ++k) js += (k ? "," : "") + std::to_string(st.ops[k]);
+    js += "]";
+    if (!st.perm.empty()) {
+      js += ",\"perm\":[";
+      for (size_t k = 0; k < st.perm.size(); ++k) js += (k ? "," : "") + std::to_string(st.perm[k]);
+      js += "]";
+    } else if (st.ops.size() > 1) {
+      std::vector<const TileItem*> seg;
+      for (uint64_t i : st.ops) seg.push_back(&items[i]);
+      TileSegmentPlan<T> plan;
+      QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+      js += ",\"high\":[";
+      for (size_t k = 0; k < plan.high.size(); ++k) js += (k ? "," : "") + std::to_string(plan.high[k]);
+      js += "],\"passes\":[";
+      for (uint32_t pi = 0; pi < plan.pd.npasses; ++pi) {
+        const TilePass& ps = plan.pd.pass[pi];
+        if (pi) js += ",";
+        js += "{\"first\":" + std::to_string(ps.first) + ",\"count\":" + std::to_string(ps.count) + ",\"pb\":[" +
+              std::to_string(ps.pb[0]) + "," + std::to_string(ps.pb[1]) + "," + std::to_string(ps.pb[2]) +
+              "],\"lanepos\":[";
+        for (int k = 0; k < kTileLaneBits; ++k) js += (k ? "," : "") + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull));
+        js += "]}";
+      }
+      js += "],\"gates\":[";
+      for (size_t gi = 0; gi < plan.gates.size(); ++gi) {
+        const TileGate<T>& g = plan.gates[gi];
+        if (gi) js += ",";
+        js += "{\"kind\":" + std::to_string(g.kind) + ",\"op\":" + std::to_string(g.op) + ",\"b0\":" +
+              std::to_string(g.b0) + ",\"b1\":" + std::to_string(g.b1) + ",\"cmask\":" + std::to_string(g.cmask) +
+              ",\"cm_reg\":" + std::to_string(g.cm_reg) + ",\"cm_lane\":" + std::to_string(g.cm_lane) +
+              ",\"omask\":" + std::to_string(g.omask) + ",\"tpos_out\":" + std::to_string(g.tpos_out) +
+              ",\"nz\":" + std::to_string(g.nz) + ",\"m\":[";
+        for (int e = 0; e < 4; ++e)
+          js += std::string(e ? "," : "") + "[" + num((double)g.m[e].x) + "," + num((double)g.m[e].y) + "]";
+        js += "]}";
+      }
+      js += "],\"mats\":[";
+      for (size_t e = 0; e < plan.mats.size(); ++e)
+        js += std::string(e ? "," : "") + "[" + num((double)plan.mats[e].x) + "," + num((double)plan.mats[e].y) + "]";
+      js += "]";
+    }
+    js += "}";
+  }
+  js += "]}";
+  return QIP_OK;
+}
+
+extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode) {
+  static thread_local std::string json;
+  try {
+    if (count && !ops) return fail(QIP_ERR_INVALID, "null op array"), nullptr;
+    if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype), nullptr;
+    if (n < (uint32_t)kTileBits) return fail(QIP_ERR_UNSUPPORTED, "tile sweeps need n >= %d", kTileBits), nullptr;
+    const int rc = dtype == QIP_C64 ? tile_plan_json<double>(dtype, n, ops, count, mode, &json)
+                                    : tile_plan_json<float>(dtype, n, ops, count, mode, &json);
+    return rc == QIP_OK ? json.c_str() : nullptr;
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  }
+}
+
+// Host-only test hook: the run-time-compiled source of every multi-gate step of a circuit's tile schedule, each
+// compiled with hiprtc (no device needed: hiprtc cross-compiles for gfx950).  Returns the number of segments compiled
+// and the total source / code size through the out parameters; `first_source` (may be NULL) receives a pointer to the
+// first segment's source text (owned by the library, valid until the calling thread's next call).
+
+template int build_tile_segment<double>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<double>*);
+template int build_tile_segment<float>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<float>*);

@@ -2,7 +2,7 @@
 
 The reference is single-process; its only provision for distribution is the input_offset / output_offset window
 arguments (qip-iterators/src/matrix_ops.rs:96-97, qip/src/state_ops/measurement_ops.rs:17-19).  Everything that
-decides and moves anything lives in libqip_hip.so (include/qip_hip.h "qip_hip_dist_*", csrc/qip_dist.inc):
+decides and moves anything lives in libqip_hip.so (include/qip_hip.h "qip_hip_dist_*", csrc/qip_dist.hip):
 
   * layout    rank r owns the 2^L (L = n - g) amplitudes whose top g PHYSICAL index bits are r; the planner keeps a
               logical -> physical bit permutation;

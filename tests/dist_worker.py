@@ -1,6 +1,6 @@
 """Worker for tests/test_distributed_cpu.py: run under torch.distributed.run with gloo.
 
-The C++ planner of the sharded state (csrc/qip_dist.inc: logical -> physical map, farthest-next-use remap choice,
+The C++ planner of the sharded state (csrc/qip_dist.hip: logical -> physical map, farthest-next-use remap choice,
 per-rank localisation of every op) is pure host code; qip_hip_dist_debug_plan serialises what THIS rank would do.
 Here the plan is replayed with the CPU oracle as the shard and gloo as the transport, and the gathered result is
 compared with the oracle applied to the full vector — the N > 1 logic without any GPU."""

@@ -21,10 +21,12 @@ def demangle(names):
 def main():
     res = "/tmp/qip_kernel_resources.txt"
     if not (len(sys.argv) > 1 and sys.argv[1] == "--cached" and os.path.exists(res)):
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", "-o", "/tmp/qip_res.o",
-               os.path.join(ROOT, "rustqip_amd", "csrc", "qip_hip.hip"), "-Rpass-analysis=kernel-resource-usage"]
         with open(res, "w") as f:
-            subprocess.run(cmd, stderr=f, check=True)
+            for unit in ("qip_launch", "qip_circuit", "qip_measure", "qip_dist"):  # the translation units that launch kernels
+                cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+                       "-c", "-o", "/tmp/qip_res.o", os.path.join(ROOT, "rustqip_amd", "csrc", unit + ".hip"),
+                       "-Rpass-analysis=kernel-resource-usage"]
+                subprocess.run(cmd, stderr=f, check=True)
     want = [a for a in sys.argv[1:] if not a.startswith("--")]
     txt = open(res).read()
     blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
