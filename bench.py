@@ -151,9 +151,15 @@ def cpu_baseline(q, circuits, args):
     }
 
 
-def parity_check(q, circuits, st, n, ops_headline, ops_mixed):
-    """The timed configuration against the oracle (see module docstring).  Leaves the state in the seeded product
-    state advanced by the checked gates — a non-uniform state, which is also what gets timed."""
+def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
+    """Every configuration this bench TIMES against the oracle before anything is timed (see module docstring): the
+    headline gate by gate, the mix, the tile sweeps in every mode (interpreted, run-time-compiled, relabelled, tile = 2,
+    fused multiply-adds), dense fusion, and the other BASELINE circuits (QFT, Clifford+T, a Grover iteration) through the
+    run-time-compiled sweeps at full size.  Two nets: closed sub-cubes against the oracle (rounding-level equality of the
+    compared rows) and a whole-vector guard — a twin state that follows gate by gate through the literal kernel and is
+    compared over all 2^n amplitudes after every step, plus closed-form marginals while the state is a product state.
+    Leaves the state in the seeded product state advanced by the checked gates — a non-uniform state, which is also what
+    gets timed."""
     import numpy as np
 
     from oracle import qip_oracle as O
@@ -168,34 +174,92 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed):
         got = st.download(off, 1 << 16)
         want = W.product_state_window(n, vecs, off, 1 << 16)
         init_err = max(init_err, float(np.max(np.abs(got - want) / np.abs(want))))
-    a = W.check_circuit(st, n, ops_headline[:32], O, gate_by_gate=True, seed=11)
-    b = W.check_circuit(st, n, ops_mixed[:32], O, gate_by_gate=True, seed=12)
-    st.set_option("tile", 1)
-    c = W.check_circuit(st, n, ops_mixed[32:96], O, gate_by_gate=False, seed=13)
-    st.set_option("tile_jit", 1)  # the same sweeps as run-time-compiled segment kernels
-    cj = W.check_circuit(st, n, ops_mixed[96:160], O, gate_by_gate=False, seed=14, bases_per_step=2)
-    # ... and with the scheduler relabelling the qubits (tile_relabel = 2: unconditionally, so that every chunk goes through
+    twin = W.Twin(st, lambda: q.HipState(n, np.complex128, device=st_device(st)))
+    guard = W.ProductGuard(n, vecs)
+    guard.check(st)
+    legs = {}
+
+    def leg(name, ops, exact, gate_by_gate=False, seed=0, bases=2, max_len=64, **options):
+        for k, v in options.items():
+            st.set_option(k, v)
+        r = W.check_circuit(st, n, ops, O, gate_by_gate=gate_by_gate, seed=seed, bases_per_step=bases, twin=twin, max_len=max_len)
+        for k in options:
+            st.set_option(k, 0)
+        r["options"] = options
+        r["bar"] = "IEEE-equal" if exact else "1e-12"
+        r["ok"] = bool((r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0) if exact
+                       else (r["max_abs_delta"] <= 1e-12 and r["whole_vector_max_abs_delta"] <= 1e-12))
+        if not exact:
+            twin.resync()
+        legs[name] = r
+
+    # the headline, gate by gate; the state stays a product state: closed-form marginals after every gate
+    a_ops = ops_headline[:32]
+    for k0 in range(0, len(a_ops), 8):
+        leg("single_qubit_gate_by_gate_%d" % (k0 // 8), a_ops[k0:k0 + 8], True, gate_by_gate=True, seed=11 + k0, bases=4)
+        for op in a_ops[k0:k0 + 8]:
+            guard.apply(op)
+        guard.check(st)
+    single = {"gates": 0, "steps": 0, "rows": 0, "row_calls": 0, "windows": 0, "skipped": 0, "whole_vector_compares": 0}
+    for k0 in range(0, len(a_ops), 8):
+        r = legs.pop("single_qubit_gate_by_gate_%d" % (k0 // 8))
+        for key in single:
+            single[key] += r[key]
+        for key in ("max_abs_delta", "whole_vector_max_abs_delta"):
+            single[key] = max(single.get(key, 0.0), r[key])
+        single["whole_vector_amplitudes_not_equal"] = single.get("whole_vector_amplitudes_not_equal", 0) + r["whole_vector_amplitudes_not_equal"]
+        single["bit_equal"] = single.get("bit_equal", True) and r["bit_equal"]
+        single["ok"] = single.get("ok", True) and r["ok"]
+    single.update({"bar": "IEEE-equal", "product_state_marginals": {"checks": guard.checks, "index_sets": guard.sets,
+                                                                    "max_rel_err_vs_closed_form": guard.worst_rel}})
+    single["ok"] = bool(single["ok"] and guard.worst_rel <= 1e-11)
+    legs["single_qubit_gate_by_gate"] = single
+    leg("mixed_gate_by_gate", ops_mixed[:32], True, gate_by_gate=True, seed=12, bases=4)
+    leg("mixed_tile1_chunks", ops_mixed[32:96], True, seed=13, bases=4, tile=1)
+    leg("mixed_tile1_jit_chunks", ops_mixed[96:160], True, seed=14, tile=1, tile_jit=1)
+    # ... with the scheduler relabelling the qubits (tile_relabel = 2: unconditionally, so that every chunk goes through
     # in-tile swaps and the closing bit-permutation sweep); two Swap ops ride along as label exchanges
-    st.set_option("tile_relabel", 2)
     swaps = [q.make_swap_op([3], [n - 2]), q.make_swap_op([n - 9], [0])]
-    cr = W.check_circuit(st, n, ops_mixed[160:192] + swaps + ops_mixed[192:224], O, gate_by_gate=False, seed=15, bases_per_step=2)
-    st.set_option("tile_relabel", 0)
-    st.set_option("tile_jit", 0)
-    st.set_option("tile", 0)
+    leg("mixed_tile1_jit_relabel_chunks", ops_mixed[160:192] + swaps + ops_mixed[192:224], True, seed=15, tile=1, tile_jit=1, tile_relabel=2)
+    # the 1e-12 modes that are timed: commuting reorder (interpreted, compiled, compiled with fused multiply-adds), dense fusion
+    more = circuits.c2_random_circuit(n, 192, seed=29)
+    leg("mixed_tile2_chunks", more[:48], False, seed=16, tile=2)
+    leg("mixed_tile2_jit_chunks", more[48:96], False, seed=17, tile=2, tile_jit=1)
+    leg("mixed_tile2_jit_fma_relabel_chunks", more[96:144], False, seed=18, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+    leg("mixed_fuse5_chunks", more[144:192], False, seed=19, fuse=5)
+    # the other BASELINE circuits as they are timed: run-time-compiled sweeps at full size.  QFT's controlled phases only
+    # TEST their bits, so a chunk is closed over its H targets alone and holds what a timed segment holds.
+    leg("configs2_qft_tile1_jit", circuits.c3_qft(n), True, seed=20, max_len=160, tile=1, tile_jit=1)
+    leg("configs3_clifford_t_tile1_jit", circuits.c4_clifford_t(n, gates, seed=32), True, seed=21, tile=1, tile_jit=1)
+    leg("configs4_grover_tile1_jit", circuits.c5_grover_iteration(n), True, seed=22, max_len=96, tile=1, tile_jit=1)
+    leg("configs4_grover_dense_k3_tile1_jit", circuits.c5_grover_iteration(n, dense_k3=True), False, seed=23, max_len=96, tile=1, tile_jit=1)
+    twin.close()
+    # back to a product state for the timed part (the checked circuits entangled it): re-prepare and advance as before
+    st.init_basis(0)
+    st.apply_ops(ops0 + a_ops)
+    tot = lambda key: sum(r.get(key, 0) for r in legs.values())  # noqa: E731
+    exact_legs = [r for r in legs.values() if r["bar"] == "IEEE-equal"]
     return {
-        "checker": "CPU oracle (oracle/qip_oracle.c apply_op_overwrite + apply_op_row) on closed sub-cubes, oracle/window_parity.py",
+        "checker": "CPU oracle (oracle/qip_oracle.c apply_op_overwrite + apply_op_row) on closed sub-cubes (tested-only bits resolved "
+                   "against the cube's base), oracle/window_parity.py; whole-vector guard: twin state through the literal kernel compared "
+                   "over all 2^n amplitudes after every step + closed-form marginals of the product state",
         "n": n, "state": "seeded product state, pairwise distinct amplitudes (closed form checked: max rel err %.1e)" % init_err,
-        "gates_checked": a["gates"] + b["gates"] + c["gates"] + cj["gates"] + cr["gates"],
-        "gates_skipped": a["skipped"] + b["skipped"] + c["skipped"] + cj["skipped"] + cr["skipped"],
-        "rows_checked": a["rows"] + b["rows"] + c["rows"] + cj["rows"] + cr["rows"],
-        "windows": a["windows"] + b["windows"] + c["windows"] + cj["windows"] + cr["windows"],
-        "apply_op_row_calls": a["row_calls"] + b["row_calls"],
-        "max_abs_delta": max(a["max_abs_delta"], b["max_abs_delta"], c["max_abs_delta"], cj["max_abs_delta"], cr["max_abs_delta"]),
-        "bit_equal": bool(a["bit_equal"] and b["bit_equal"] and c["bit_equal"] and cj["bit_equal"] and cr["bit_equal"]),
-        "legs": {"single_qubit_gate_by_gate": a, "mixed_gate_by_gate": b, "mixed_tile1_chunks": c, "mixed_tile1_jit_chunks": cj,
-                 "mixed_tile1_jit_relabel_chunks": cr},
+        "gates_checked": tot("gates"), "gates_skipped": tot("skipped"), "rows_checked": tot("rows"), "windows": tot("windows"),
+        "apply_op_row_calls": tot("row_calls"),
+        "max_abs_delta": max(r["max_abs_delta"] for r in exact_legs),
+        "bit_equal": bool(all(r["bit_equal"] for r in exact_legs)),
+        "max_abs_delta_1e-12_legs": max(r["max_abs_delta"] for r in legs.values() if r["bar"] != "IEEE-equal"),
+        "whole_vector": {"compares": tot("whole_vector_compares"), "amplitudes_per_compare": 1 << n,
+                         "amplitudes_not_equal_in_IEEE_legs": sum(r["whole_vector_amplitudes_not_equal"] for r in exact_legs),
+                         "max_abs_delta_all_legs": max(r["whole_vector_max_abs_delta"] for r in legs.values())},
+        "all_legs_ok": bool(all(r["ok"] for r in legs.values())),
+        "legs": legs,
         "seconds": round(time.perf_counter() - t0, 2),
     }
+
+
+def st_device(st):
+    return getattr(st, "device", 0)
 
 
 def main():
@@ -257,7 +321,7 @@ def main():
     if world == 1:
         st = q.HipState(n, np.complex128, device=device)
         if not args.no_parity:
-            parity = parity_check(q, circuits, st, n, ops, ops_mixed)
+            parity = parity_check(q, circuits, st, n, ops, ops_mixed, args.gates)
         else:  # same resident state as the checked run (seeded product state), without the oracle comparison
             from oracle import window_parity as W
 

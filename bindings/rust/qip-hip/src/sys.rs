@@ -1,4 +1,4 @@
-//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 2).
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 4).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
@@ -101,6 +101,8 @@ extern "C" {
     ) -> c_int;
     pub fn qip_hip_state_profile_reset(s: *mut qip_hip_state) -> c_int;
 
+    pub fn qip_hip_state_copy_from(dst: *mut qip_hip_state, src: *mut qip_hip_state) -> c_int;
+    pub fn qip_hip_state_max_abs_diff(a: *mut qip_hip_state, b: *mut qip_hip_state, max_abs: *mut c_double, n_differ: *mut u64) -> c_int;
     pub fn qip_hip_state_norm_sqr(s: *mut qip_hip_state, out: *mut c_double) -> c_int;
     pub fn qip_hip_state_measure_probs(
         s: *mut qip_hip_state, indices: *const u64, k: u32, out: *mut c_double,

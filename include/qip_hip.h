@@ -278,6 +278,14 @@ int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
                               double* total_ms, double* algorithmic_bytes);
 int qip_hip_state_profile_reset(qip_hip_state* s);
 
+/* ---- two states side by side (validation support; no reference counterpart: the reference compares host Vecs) ---------
+ * copy_from: dst <- src (same n, precision and device; stream-ordered on dst's stream after src's queued work).
+ * max_abs_diff: max_i |a_i - b_i| over the WHOLE vector and the number of amplitudes whose components are not IEEE-equal
+ * (one coalesced pass over both states).  The parity checks use it to hold a state that went through a fast path against a
+ * twin that went gate by gate through the literal kernel, so that a stray write anywhere in the 2^n amplitudes is seen. */
+int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src);
+int qip_hip_state_max_abs_diff(qip_hip_state* a, qip_hip_state* b, double* max_abs, uint64_t* n_differ);
+
 /* ---- measurement (qip/src/state_ops/measurement_ops.rs) ----------------- */
 
 /* Σ|amp|²  (prob_magnitude, measurement_ops.rs:11-13) */

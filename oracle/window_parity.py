@@ -12,6 +12,17 @@ column order, hence the same sequence of rounded operations per row), which is w
     want    = qip_oracle apply_op_overwrite(m, op', before)   and, on sampled rows, qip_oracle apply_op_row
     after   = the same windows downloaded after the gate
 
+Bits an op only TESTS — its controls, and targets in which its matrix is diagonal — need not be part of the sub-cube:
+outside it such a bit is constant over the whole cube, so the op either is the identity there (a control reads 0), or it
+is the same op without that control / with the diagonal block its bit value selects (same matrix rows in the same column
+order, so the same rounded operations).  Only the bits an op EXCHANGES amplitudes across must be closed over.  That is
+what lets whole QFT segments (5 H + up to 135 controlled phases with controls on every index bit) be checked at n = 30.
+
+Whole-vector guard: sub-cubes prove the compared rows right; they cannot see a stray write elsewhere.  `check_ops` can
+therefore keep a TWIN state in lock step — every op applied gate by gate through the literal out-of-place kernel
+(option force_generic), an entirely different code path — and compare the two states over all 2^n amplitudes on the device
+(HipState.max_abs_diff) after every checked step.
+
 Only tests/, __graft_entry__.smoke() and bench.py's checker legs may import this module; the product never does.
 """
 from __future__ import annotations
@@ -27,6 +38,39 @@ def _remap(op: MatrixOp, qmap: Dict[int, int]) -> MatrixOp:
     inner = _remap(op.inner, qmap) if op.inner is not None else None
     return MatrixOp(op.kind, [qmap.get(int(q), 0) for q in op.indices], data=op.data, rows=op.rows, half=op.half,
                     n_controls=op.n_controls, inner=inner)
+
+
+def flatten(op: MatrixOp):
+    """(controls, targets, core): nested Control ops flattened as the reference does (ops.rs:150-154); `core` is the
+    innermost non-Control op, whose own index list is ignored at apply time (matrix_ops.rs:108)."""
+    idx = [int(q) for q in op.indices]
+    ctrls: List[int] = []
+    cur, at = op, 0
+    while cur.kind == "Control":
+        ctrls += idx[at:at + cur.n_controls]
+        at += cur.n_controls
+        cur = cur.inner
+    return ctrls, idx[at:], cur
+
+
+def diagonal_targets(core: MatrixOp, k: int) -> List[bool]:
+    """diag[j]: the dense matrix has no entry linking sub-indices that differ in target j (sub-index bit k-1-j)"""
+    if core.kind != "Matrix":
+        return [False] * k
+    m = np.asarray(core.data).reshape(1 << k, 1 << k)
+    rows, cols = np.nonzero(m)
+    out = []
+    for j in range(k):
+        bit = k - 1 - j
+        out.append(bool(np.all(((rows >> bit) & 1) == ((cols >> bit) & 1))))
+    return out
+
+
+def exchange_positions(n: int, op: MatrixOp) -> List[int]:
+    """index bit positions across which `op` moves amplitude (the bits a closed sub-cube must contain)"""
+    ctrls, targets, core = flatten(op)
+    diag = diagonal_targets(core, len(targets))
+    return [n - 1 - q for q, d in zip(targets, diag) if not d]
 
 
 class SubCube:
@@ -65,6 +109,56 @@ class SubCube:
             qmap[int(q)] = self.m - 1 - self.sub_position(self.n - 1 - int(q))
         return _remap(op, qmap)
 
+    def inside(self, p: int) -> bool:
+        return p < self.w or p in self.high
+
+    def localize_at(self, op: MatrixOp, base: int) -> Optional[MatrixOp]:
+        """`op` as it acts on the sub-cube at `base` (see the module docstring): None when a control outside the cube
+        reads 0 there.  Bits outside the cube must be controls or diagonal targets."""
+        ctrls, targets, core = flatten(op)
+        if all(self.inside(self.n - 1 - q) for q in ctrls + targets):
+            return self.localize(op)
+        sub = lambda q: self.m - 1 - self.sub_position(self.n - 1 - q)  # noqa: E731
+        bit = lambda q: (base >> (self.n - 1 - q)) & 1                  # noqa: E731
+        keep_c = []
+        for q in ctrls:
+            if self.inside(self.n - 1 - q):
+                keep_c.append(sub(q))
+            elif bit(q) == 0:
+                return None
+        k = len(targets)
+        fixed = [j for j, q in enumerate(targets) if not self.inside(self.n - 1 - q)]
+        if fixed:
+            if core.kind != "Matrix":
+                raise ValueError("a %s op with a target outside the sub-cube" % core.kind)
+            diag = diagonal_targets(core, k)
+            if not all(diag[j] for j in fixed):
+                raise ValueError("an exchanging target outside the sub-cube")
+            m = np.asarray(core.data).reshape(1 << k, 1 << k)
+            keep = [j for j in range(k) if j not in fixed]
+            sel = []
+            for r in range(1 << len(keep)):
+                full = 0
+                for jj, j in enumerate(keep):
+                    full |= ((r >> (len(keep) - 1 - jj)) & 1) << (k - 1 - j)
+                for j in fixed:
+                    full |= bit(targets[j]) << (k - 1 - j)
+                sel.append(full)
+            block = m[np.ix_(sel, sel)]
+            if keep:
+                new_targets = [sub(targets[j]) for j in keep]
+            else:  # a scalar: the same product as a one-qubit diag(s, s) on a cube qubit the op does not otherwise use
+                spare = next(q for q in range(self.m) if q not in keep_c)
+                new_targets = [spare]
+                block = np.array([[block[0, 0], 0], [0, block[0, 0]]], dtype=np.complex128)
+            new_core = MatrixOp.new_matrix(new_targets, block.ravel())
+        else:
+            new_targets = [sub(q) for q in targets]
+            new_core = MatrixOp(core.kind, new_targets, data=core.data, rows=core.rows, half=core.half)
+        if not keep_c:
+            return new_core
+        return MatrixOp.new_control(keep_c, new_targets, new_core)
+
 
 def default_bases(n: int, seed: int = 0, count: int = 4) -> List[int]:
     """bottom and top of the index space plus seeded random places in between"""
@@ -76,15 +170,44 @@ def default_bases(n: int, seed: int = 0, count: int = 4) -> List[int]:
     return bases[:count]
 
 
+class Twin:
+    """The whole-vector guard: a second state of the same size that follows the checked state gate by gate through the
+    literal out-of-place kernel (option force_generic), compared with it over all 2^n amplitudes on the device."""
+
+    def __init__(self, state, make_state: Callable[[], object]):
+        self.state = state
+        self.twin = make_state()
+        self.twin.set_option("force_generic", 1)
+        self.twin.copy_from(state)
+        self.worst, self.differ, self.compares = 0.0, 0, 0
+
+    def follow(self, ops: Sequence[MatrixOp]) -> dict:
+        self.twin.apply_ops(list(ops))
+        worst, differ = self.state.max_abs_diff(self.twin)
+        self.worst = max(self.worst, worst)
+        self.differ += differ
+        self.compares += 1
+        return {"max_abs_delta": worst, "amplitudes_not_equal": differ}
+
+    def resync(self) -> None:
+        """after a leg that is only held to a tolerance: start the next one from identical states again"""
+        self.twin.copy_from(self.state)
+
+    def close(self) -> None:
+        self.twin.close()
+
+
 def check_ops(state, n: int, ops: Sequence[MatrixOp], O, bases: Optional[Sequence[int]] = None,
-              apply: Optional[Callable[[], None]] = None, rows_sampled: int = 8, w_max: int = 16) -> Optional[dict]:
+              apply: Optional[Callable[[], None]] = None, rows_sampled: int = 8, w_max: int = 16,
+              twin: Optional[Twin] = None) -> Optional[dict]:
     """Apply `ops` to the device state (state.apply_ops, or `apply()`), and compare >= len(bases) sub-cubes of
-    2^m amplitudes against the oracle applied to what the device held before.  Returns None when the ops touch
-    too many high bit positions for a sub-cube of reasonable size (nothing is applied then), else
+    2^m amplitudes against the oracle applied to what the device held before.  Returns None when the ops exchange
+    amplitudes across too many high bit positions for a sub-cube of reasonable size (nothing is applied then), else
     {"rows": amplitudes compared, "max_abs_delta": ..., "bit_equal": every compared component IEEE-==,
-     "row_calls": rows additionally recomputed with apply_op_row, "m": ..., "windows": ...}."""
+     "row_calls": rows additionally recomputed with apply_op_row, "m": ..., "windows": ...,
+     "whole_vector": the twin comparison over all 2^n amplitudes (when a twin is given)}."""
     ops = list(ops)
-    positions = [n - 1 - int(q) for op in ops for q in op.indices]
+    positions = [p for op in ops for p in exchange_positions(n, op)]
     cube = SubCube(n, positions, w_max=w_max)
     if not cube.ok:
         return None
@@ -94,10 +217,11 @@ def check_ops(state, n: int, ops: Sequence[MatrixOp], O, bases: Optional[Sequenc
         apply()
     else:
         state.apply_ops(ops)
-    local_ops = [cube.localize(op) for op in ops]
-    worst, equal, rows, row_calls = 0.0, True, 0, 0
+    worst, equal, rows, row_calls, active = 0.0, True, 0, 0, 0
     rng = np.random.default_rng(n)
     for b, x in zip(bases, before):
+        local_ops = [lop for lop in (cube.localize_at(op, b) for op in ops) if lop is not None]
+        active += len(local_ops)
         got = cube.gather(state.download, b)
         cur, arena = x.copy(), np.zeros_like(x)
         for lop in local_ops:
@@ -107,7 +231,7 @@ def check_ops(state, n: int, ops: Sequence[MatrixOp], O, bases: Optional[Sequenc
         worst = max(worst, float(d.max()))
         equal = equal and bool(np.array_equal(got, cur))
         rows += got.size
-        if len(local_ops) == 1:
+        if len(ops) == 1 and len(local_ops) == 1:
             # the literal per-row entry point of the reference (matrix_ops.rs:38-59) on sampled rows, first and last included
             sample = [0, got.size - 1] + [int(r) for r in rng.integers(0, got.size, size=rows_sampled)]
             for r in sample:
@@ -115,18 +239,21 @@ def check_ops(state, n: int, ops: Sequence[MatrixOp], O, bases: Optional[Sequenc
                 worst = max(worst, abs(complex(got[r]) - v))
                 equal = equal and (complex(got[r]) == v)
                 row_calls += 1
-    return {"rows": rows, "max_abs_delta": worst, "bit_equal": equal, "row_calls": row_calls, "m": cube.m,
-            "windows": len(bases) * (1 << len(cube.high))}
+    out = {"rows": rows, "max_abs_delta": worst, "bit_equal": equal, "row_calls": row_calls, "m": cube.m,
+           "windows": len(bases) * (1 << len(cube.high)), "ops_active_on_cubes": active}
+    if twin is not None:
+        out["whole_vector"] = twin.follow(ops)
+    return out
 
 
 def chunk_by_high_bits(n: int, ops: Sequence[MatrixOp], max_high: int = 6, w: int = 16, max_len: int = 64) -> List[List[MatrixOp]]:
-    """Cut a circuit into consecutive chunks whose ops together touch at most `max_high` bit positions >= w, so
-    each chunk has a closed sub-cube of <= 2^(w + max_high) amplitudes."""
+    """Cut a circuit into consecutive chunks whose ops together EXCHANGE amplitudes across at most `max_high` bit positions
+    >= w, so each chunk has a closed sub-cube of <= 2^(w + max_high) amplitudes (tested-only bits may lie anywhere)."""
     chunks: List[List[MatrixOp]] = []
     cur: List[MatrixOp] = []
     high: set = set()
     for op in ops:
-        mine = {n - 1 - int(q) for q in op.indices if n - 1 - int(q) >= w}
+        mine = {p for p in exchange_positions(n, op) if p >= w}
         if cur and (len(high | mine) > max_high or len(cur) >= max_len):
             chunks.append(cur)
             cur, high = [], set()
@@ -138,16 +265,20 @@ def chunk_by_high_bits(n: int, ops: Sequence[MatrixOp], max_high: int = 6, w: in
 
 
 def check_circuit(state, n: int, ops: Sequence[MatrixOp], O, gate_by_gate: bool = True, seed: int = 0,
-                  bases_per_step: int = 4) -> dict:
+                  bases_per_step: int = 4, twin: Optional[Twin] = None, max_len: int = 64) -> dict:
     """check_ops over a whole circuit: gate by gate, or in chunks applied through state.apply_ops (which is how the
     multi-gate tile sweeps are reached).  Aggregates the per-step results."""
-    steps = [[op] for op in ops] if gate_by_gate else chunk_by_high_bits(n, ops)
+    steps = [[op] for op in ops] if gate_by_gate else chunk_by_high_bits(n, ops, max_len=max_len)
     agg = {"gates": 0, "steps": 0, "rows": 0, "row_calls": 0, "max_abs_delta": 0.0, "bit_equal": True, "skipped": 0,
            "windows": 0}
+    if twin is not None:
+        agg.update({"whole_vector_compares": 0, "whole_vector_max_abs_delta": 0.0, "whole_vector_amplitudes_not_equal": 0})
     for i, chunk in enumerate(steps):
-        r = check_ops(state, n, chunk, O, bases=default_bases(n, seed + i, bases_per_step))
+        r = check_ops(state, n, chunk, O, bases=default_bases(n, seed + i, bases_per_step), twin=twin)
         if r is None:
             state.apply_ops(chunk)
+            if twin is not None:
+                twin.follow(chunk)
             agg["skipped"] += len(chunk)
             continue
         agg["gates"] += len(chunk)
@@ -157,6 +288,10 @@ def check_circuit(state, n: int, ops: Sequence[MatrixOp], O, gate_by_gate: bool 
         agg["windows"] += r["windows"]
         agg["max_abs_delta"] = max(agg["max_abs_delta"], r["max_abs_delta"])
         agg["bit_equal"] = agg["bit_equal"] and r["bit_equal"]
+        if twin is not None:
+            agg["whole_vector_compares"] += 1
+            agg["whole_vector_max_abs_delta"] = max(agg["whole_vector_max_abs_delta"], r["whole_vector"]["max_abs_delta"])
+            agg["whole_vector_amplitudes_not_equal"] += r["whole_vector"]["amplitudes_not_equal"]
     return agg
 
 
@@ -189,3 +324,51 @@ def product_state_window(n: int, vecs, offset: int, length: int) -> np.ndarray:
         bit = (idx >> np.uint64(n - 1 - t)) & np.uint64(1)
         out *= np.where(bit == 1, v1, v0)
     return out
+
+
+class ProductGuard:
+    """Whole-vector guard with a CLOSED FORM: while only uncontrolled single-qubit gates act on the seeded product state it
+    stays a product state, amp(idx) = prod_t v[t][bit_t(idx)], and so do its marginals: the probability of reading m from
+    the qubits S is prod_{t in S} |v[t][m_t]|^2 * prod_{t not in S} (|v[t][0]|^2 + |v[t][1]|^2).  Index sets of <= 14
+    qubits that together cover every qubit are measured on the device (2^14 outcome sums over all 2^n amplitudes each) and
+    compared with that: moduli are pairwise distinct, so an amplitude that lands anywhere but in its own place, or a stray
+    write of any size above ~1e-12 of a marginal, shows in at least one set."""
+
+    def __init__(self, n: int, vecs, k: int = 14):
+        self.n = n
+        self.v = [np.array([v0, v1], dtype=np.complex128) for v0, v1 in vecs]
+        k = min(k, n)
+        starts = list(range(0, n - k + 1, max(1, k - 6)))
+        if starts[-1] != n - k:
+            starts.append(n - k)
+        self.sets = [list(range(s, s + k)) for s in starts]
+        self.worst_rel = 0.0
+        self.checks = 0
+
+    def apply(self, op: MatrixOp) -> None:
+        ctrls, targets, core = flatten(op)
+        if ctrls or len(targets) != 1 or core.kind != "Matrix":
+            raise ValueError("the product-state guard follows uncontrolled single-qubit Matrix ops only")
+        self.v[targets[0]] = np.asarray(core.data, dtype=np.complex128).reshape(2, 2) @ self.v[targets[0]]
+
+    def marginal(self, qubits: Sequence[int]) -> np.ndarray:
+        """out[m], bit i of m <-> qubits[i] (measure_probs' convention)"""
+        out = np.ones(1)
+        for tq in reversed(list(qubits)):  # the last listed qubit is the top bit of m
+            out = np.kron(out, np.abs(self.v[tq]) ** 2)
+        rest = 1.0
+        for t in range(self.n):
+            if t not in qubits:
+                rest *= float(np.sum(np.abs(self.v[t]) ** 2))
+        return out * rest
+
+    def check(self, state) -> float:
+        worst = 0.0
+        for s in self.sets:
+            got = state.measure_probs(s)
+            want = self.marginal(s)
+            worst = max(worst, float(np.max(np.abs(got - want)) / np.max(want)))
+        self.worst_rel = max(self.worst_rel, worst)
+        self.checks += 1
+        return worst
+

@@ -96,6 +96,8 @@ SIGNATURES = {
     "qip_hip_kernel_class_name": (_cp, [_int]),
     "qip_hip_state_profile_get": (_int, [_statep, _int, _u64p, _dblp, _dblp]),
     "qip_hip_state_profile_reset": (_int, [_statep]),
+    "qip_hip_state_copy_from": (_int, [_statep, _statep]),
+    "qip_hip_state_max_abs_diff": (_int, [_statep, _statep, _dblp, _u64p]),
     "qip_hip_state_norm_sqr": (_int, [_statep, _dblp]),
     "qip_hip_state_measure_probs": (_int, [_statep, _u64p, _u32, _dblp]),
     "qip_hip_state_measure_prob": (_int, [_statep, _u64, _u64p, _u32, _dblp]),

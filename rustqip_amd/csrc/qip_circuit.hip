@@ -239,14 +239,16 @@ static int hiprtc_load() {
 }
 
 // source -> code object (host only: works without a device, which is how the CPU tests cover it)
-static int hiprtc_compile(const std::string& src, std::vector<char>* code) {
+static int hiprtc_compile(const std::string& src, bool fma, std::vector<char>* code) {
   QCHK(hiprtc_load());
   void* prog = nullptr;
   const char* hdr_src[1] = {kKernelsHeaderSrc};
   const char* hdr_name[1] = {"qip_kernels.h"};
   if (g_rtc.CreateProgram(&prog, src.c_str(), "qip_segment.hip", 1, hdr_src, hdr_name) != 0)
     return fail(QIP_ERR_DEVICE, "hiprtcCreateProgram failed");
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};  // as rustqip_amd/build.py
+  // as rustqip_amd/build.py; `fma` (option "tile_fma", only honoured for tile = 2, whose bar is 1e-12 anyway): products may
+  // fuse into the sums that consume them (v_fma_f64): a complex product is 4 instead of 6 vector instructions
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", fma ? "-ffp-contract=fast" : "-ffp-contract=off", "-fno-slp-vectorize"};
   const int rc = g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
   if (rc != 0) {
     size_t n = 0;
@@ -290,8 +292,12 @@ template <typename T> static std::string fnum(T v) {
 }
 
 // The segment as HIP source (see the block comment above).  Mirrors k_tile_passes statement by statement.
+// `pipe` (option "tile_pipe"): 0 = one block per tile, as k_tile_passes; 1 = persistent blocks that walk the tiles with a
+// stride of the grid and keep the NEXT tile's eight loads in flight (in registers) across the passes of the current one:
+// the block-per-tile form has loads in flight only while a block sits in its load phase, so a CU's five resident tiles
+// leave HBM idle whenever most of them compute; here every resident block always has 32 KiB of loads under way.
 template <typename T>
-static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt) {
+static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int pipe, int remap = 0) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   std::string o;
   auto L = [&](const std::string& line) { o += line; o += "\n"; };
@@ -302,21 +308,25 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   L("using namespace qipk;");
   L(std::string("typedef ") + tname + " T;");
   L("typedef amp_t<T> A;");
-  L("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st) {");
+  // tile number -> amplitude index of the tile's element 0: insert_bits with the positions as literals
+  L("__device__ __forceinline__ uint64_t tile_base(uint64_t t) {");
+  L("  uint64_t w = t << kTileLow;");
+  for (uint32_t j = 0; j < ins.npos; ++j) {
+    const std::string p = std::to_string(ins.pos[j]);
+    L("  w = ((w >> " + p + ") << " + std::to_string(ins.pos[j] + 1) + ") | (w & ((1ull << " + p + ") - 1ull));");
+  }
+  if (ins.ormask) L("  w |= " + U(ins.ormask) + ";");
+  L("  return w;");
+  L("}");
+  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, ") + (pipe ? "4" : "5") + ") void qip_segment(A* __restrict__ st, uint64_t ntiles) {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
   L("  A* tile = reinterpret_cast<A*>(tile_raw);");
   L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
   L("  const uint32_t tid = threadIdx.x, lane = tid & 63u;");
   L("  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);");
-  L("  uint64_t wbase = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow;");
-  for (uint32_t j = 0; j < ins.npos; ++j) {  // insert_bits with the positions as literals
-    const std::string p = std::to_string(ins.pos[j]);
-    L("  wbase = ((wbase >> " + p + ") << " + std::to_string(ins.pos[j] + 1) + ") | (wbase & ((1ull << " + p + ") - 1ull));");
-  }
-  if (ins.ormask) L("  wbase |= " + U(ins.ormask) + ";");
-  L("  const uint64_t base = wbase;");
+  L("  uint64_t wave_off = 0;");
   for (int j = 0; j < kTileWaveBits; ++j)
-    L("  wbase |= (uint64_t)((wave >> " + std::to_string(j) + ") & 1u) << " + std::to_string(d.hpos[j]) + ";");
+    L("  wave_off |= (uint64_t)((wave >> " + std::to_string(j) + ") & 1u) << " + std::to_string(d.hpos[j]) + ";");
   L("  const uint32_t slot_tid = tile_slot<A>(tid);");
   auto ub = [&](int u) {
     uint64_t off = 0;
@@ -324,19 +334,46 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
       if ((u >> b) & 1) off |= 1ull << d.hpos[kTileWaveBits + b];
     return U(off);
   };
-  L("  {");
-  L("    A x[8];");
-  for (int u = 0; u < 8; ++u) L("    x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
+  L("  A x[8];");
+  if (pipe) {
+    L("  uint64_t t = blockIdx.x;");
+    L("  uint64_t base = tile_base(t), wbase = base | wave_off;");
+  } else {
+    L("  (void)ntiles;");
+    L("  uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;");
+    // consecutive blocks land on consecutive XCDs: with remap r the 2^r blocks one XCD receives in a row take ADJACENT tiles
+    if (remap == 2) L("  blk = (blk & ~31ull) | ((blk & 7ull) << 2) | ((blk >> 3) & 3ull);");
+    if (remap == 3) L("  blk = (blk & ~63ull) | ((blk & 7ull) << 3) | ((blk >> 3) & 7ull);");
+    L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
+  }
+  for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
+  if (pipe) {
+    L("  for (;;) {");
+    // everything a gate derives from the lane id alone (bit tests, per-lane factors) is loop-invariant: hoisted out of the
+    // tile loop it would pin hundreds of registers; an opaque copy of the id keeps those values where they are used
+    L("  uint32_t tidv = tid;");
+    L("  asm volatile(\"\" : \"+v\"(tidv));");
+  } else {
+    L("  const uint32_t tidv = tid;");
+  }
   for (int u = 0; u < 8; ++u)
     L("    tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)] = x[" + std::to_string(u) + "];");
-  L("  }");
   L("  __syncthreads();");
+  if (pipe) {
+    // the next tile's loads go out now and land while this tile's passes run (x is dead until the next LDS write)
+    L("  const uint64_t tn = t + gridDim.x;");
+    L("  const bool more = tn < ntiles;");
+    L("  const uint64_t base_n = tile_base(tn), wbase_n = base_n | wave_off;");
+    L("  if (more) {");
+    for (int u = 0; u < 8; ++u) L("    x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase_n | " + ub(u) + ") + lane);");
+    L("  }");
+  }
   for (uint32_t pi = 0; pi < d.npasses; ++pi) {
     const TilePass& ps = d.pass[pi];
     L("  {  // pass " + std::to_string(pi));
     L("    uint32_t tb = 0;");
     for (int k = 0; k < kTileLaneBits; ++k)
-      L("    tb |= ((tid >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
+      L("    tb |= ((tidv >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
     L("    const uint32_t slot_tb = tile_slot<A>(tb);");
     std::string cs = "    const uint32_t c[8] = {";
     for (int i = 0; i < 8; ++i) {
@@ -405,12 +442,18 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   }
   for (int u = 0; u < 8; ++u)
     L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+  if (pipe) {
+    L("  if (!more) break;");
+    L("  __syncthreads();  // every lane has read its share of this tile before the next one overwrites it");
+    L("  t = tn; base = base_n; wbase = wbase_n;");
+    L("  }");
+  }
   L("}");
   return o;
 }
 
-static int jit_get_kernel(qip_hip_state* s, const std::string& src, hipFunction_t* fn) {
-  const std::string key = std::to_string(s->device) + "\n" + src;
+static int jit_get_kernel(qip_hip_state* s, const std::string& src, bool fma, hipFunction_t* fn) {
+  const std::string key = std::to_string(s->device) + (fma ? " fma\n" : "\n") + src;
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) {
     *fn = it->second.fn;
@@ -418,7 +461,7 @@ static int jit_get_kernel(qip_hip_state* s, const std::string& src, hipFunction_
   }
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<char> code;
-  QCHK(hiprtc_compile(src, &code));
+  QCHK(hiprtc_compile(src, fma, &code));
   JitKernel k;
   HIPCHK(hipModuleLoadData(&k.module, code.data()));
   HIPCHK(hipModuleGetFunction(&k.fn, k.module, "qip_segment"));
@@ -467,12 +510,16 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   if (s->tile_passes && s->tile_jit) {
     // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
     hipFunction_t fn = nullptr;
-    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s)), &fn));
+    const int pipe = s->tile_pipe ? 1 : 0;
+    const bool fma = s->tile_fma && s->tile >= 2;  // tile = 1 promises IEEE equality with the gate-by-gate path: never fused
+    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), pipe, (ntiles % 64 == 0 && !pipe) ? (int)g_tile_remap : 0), fma, &fn));
     if (s->jit_prepare) return QIP_OK;
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
     void* st_ptr = s->cur;
-    void* args[] = {&st_ptr};
-    const dim3 grid = grid2d(ntiles, 1);
+    uint64_t ntiles_arg = ntiles;
+    void* args[] = {&st_ptr, &ntiles_arg};
+    // persistent form: as many blocks as stay resident (4 per CU: __launch_bounds__(kTileBlock, 4), 4 x 32 KiB of LDS)
+    const dim3 grid = pipe ? dim3((unsigned)std::min<uint64_t>(ntiles, (uint64_t)s->num_cus * 4u)) : grid2d(ntiles, 1);
     HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
     if (s->profile) QCHK(prof_end(s, &rec));
     return QIP_OK;
@@ -513,9 +560,9 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     TileSegmentPlan<T> plan;
     QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
     Ins ins = make_ins(plan.high, 0);
-    const std::string src = tile_jit_source<T>(plan, ins, true);
+    const std::string src = tile_jit_source<T>(plan, ins, true, (mode & 16) ? 1 : 0);  // mode bit 4: the persistent form
     std::vector<char> code;
-    QCHK(hiprtc_compile(src, &code));
+    QCHK(hiprtc_compile(src, (mode & 32) != 0, &code));  // mode bit 5: fused multiply-adds
     if (*nseg == 0 && first) *first = src;
     *nseg += 1;
     *src_bytes += src.size();

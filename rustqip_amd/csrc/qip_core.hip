@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 3; }  // 3: + permute_bits, dist_rank_flip, options tile_relabel / perm_rows / line_bits
+extern "C" int qip_hip_abi_version(void) { return 4; }  // 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
@@ -36,7 +36,12 @@ extern "C" int qip_hip_device_count(void) try {
 int64_t g_force_generic = 0;
 // Selector bits below this position stay in the grid as a per-lane predicate (whole lines are swept); see kLineBits.
 uint32_t g_line_bits = qipk::kLineBits;
-int64_t g_perm_rows = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_perm_rows = 0;
+// Tile sweeps, measured on MI355X at n = 30 (tools/tune_tile.hip, profiles/r03_tile_skeleton.md): the time of a light sweep is set
+// by WHICH five high positions the tile holds — 5.2 ms for {11..15}, 6.3 ms for {6..10}, 6.7 ms for the top five — not by the
+// block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
+// taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
+int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
@@ -52,6 +57,9 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
     g_line_bits = (uint32_t)value;
     return QIP_OK;
   }
+  if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
+  if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
+  if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
 } QIP_CATCH_ALL
 
@@ -340,7 +348,10 @@ static int state_new(uint32_t n, int dtype, int device, qip_hip_state** out) {
   if (device < 0 || device >= count)
     return fail(QIP_ERR_INVALID, "device %d out of range (have %d)", device, count);
   HIPCHK(hipSetDevice(device));
+  int cus = 0;
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
   qip_hip_state* s = new qip_hip_state();
+  if (cus > 0) s->num_cus = cus;
   s->n = n;
   s->dtype = dtype;
   s->device = device;
@@ -484,6 +495,8 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "swap_single")) s->swap_single = value;
   else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
   else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
+  else if (!strcmp(key, "tile_pipe")) s->tile_pipe = value;
+  else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

@@ -59,6 +59,7 @@ int fail(int code, const char* fmt, ...);
 extern int64_t g_force_generic;
 extern uint32_t g_line_bits;
 extern int64_t g_perm_rows;
+extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap;  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 
 struct FlatOp {
   const qip_op* outer = nullptr;
@@ -151,6 +152,9 @@ struct qip_hip_state {
   int64_t tile_relabel = 0;  // tile sweeps: the scheduler relabels the qubits (schedule_tiles_relabel)
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
   int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached)
+  int64_t tile_pipe = 0;    // run-time-compiled segments: 1 = persistent blocks, next tile's loads in flight across the passes
+  int64_t tile_fma = 0;     // run-time-compiled segments of tile = 2: products may fuse into sums (1e-12 bar, not IEEE equality)
+  int num_cus = 256;        // compute units of the device (grid size of persistent kernels)
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;

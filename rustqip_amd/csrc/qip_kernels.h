@@ -1792,6 +1792,41 @@ __global__ __launch_bounds__(kBlock) void k_chunk_norms(const amp_t<T>* __restri
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// Two states compared amplitude by amplitude over the whole vector (qip_hip_state_max_abs_diff: how far a state is from a
+// reference copy): partial[2 b] = max |a_i - b_i| over block b's share, partial[2 b + 1] = number of amplitudes whose
+// components are not IEEE-equal (NaNs count as different).  Grid-stride, one coalesced pass over both vectors.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_max_abs_diff(const amp_t<T>* __restrict__ a, const amp_t<T>* __restrict__ b,
+                                                         uint64_t namps, double* __restrict__ partial) {
+  __shared__ double smem[kBlock / 64];
+  double worst = 0, differ = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += (uint64_t)gridDim.x * kBlock) {
+    const amp_t<T> x = a[i], y = b[i];
+    if (!(x.x == y.x && x.y == y.y)) {
+      differ += 1;
+      const double dx = (double)x.x - (double)y.x, dy = (double)x.y - (double)y.y;
+      const double d = sqrt(dx * dx + dy * dy);
+      worst = (d > worst || d != d) ? d : worst;  // a NaN distance sticks
+    }
+  }
+  const double cnt = block_reduce_sum(differ, smem);
+  __syncthreads();
+  // max over the block: wave shuffles, then the four wave maxima through LDS
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(worst, off, 64);
+    worst = (o > worst || o != o) ? o : worst;
+  }
+  if ((threadIdx.x & 63u) == 0) smem[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = smem[0];
+    for (int w = 1; w < kBlock / 64; ++w) m = (smem[w] > m || smem[w] != smem[w]) ? smem[w] : m;
+    partial[2 * blockIdx.x] = m;
+    partial[2 * blockIdx.x + 1] = cnt;
+  }
+}
+
 // soft_measure's sequential scan (measurement_ops.rs:167-173) inside ONE chunk: find the first index at
 // which r - sum_{j<=i} |amp_j|^2 <= 0.  One block: every lane sums its contiguous segment, lane 0 walks the
 // 256 segment sums to the segment that crosses zero, that lane replays the sequential subtraction.

@@ -49,6 +49,46 @@ extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) try {
   return QIP_OK;
 } QIP_CATCH_ALL
 
+// ---- two states side by side (test and validation support: a state against a reference copy) ---------------------------
+extern "C" int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src) try {
+  STATE_ENTER(dst);
+  if (!src) return fail(QIP_ERR_INVALID, "null source state");
+  if (src == dst) return QIP_OK;
+  if (src->n != dst->n || src->dtype != dst->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
+  if (src->device != dst->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
+  HIPCHK(hipStreamSynchronize(src->stream));  // everything queued on the source has landed
+  HIPCHK(hipMemcpyAsync(dst->cur, src->cur, dst->namps * dst->amp_bytes, hipMemcpyDeviceToDevice, dst->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_state_max_abs_diff(qip_hip_state* a, qip_hip_state* b, double* max_abs, uint64_t* n_differ) try {
+  STATE_ENTER(a);
+  if (!b || !max_abs) return fail(QIP_ERR_INVALID, "null argument");
+  if (a->n != b->n || a->dtype != b->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
+  if (a->device != b->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(a->namps / (kBlock * 8), 1), 4096);
+  QCHK(ensure_partial(a, 2 * (size_t)gx));
+  if (a->dtype == QIP_C64)
+    hipLaunchKernelGGL((k_max_abs_diff<double>), dim3(gx), dim3(kBlock), 0, a->stream, (const amp_t<double>*)a->cur,
+                       (const amp_t<double>*)b->cur, a->namps, a->d_partial);
+  else
+    hipLaunchKernelGGL((k_max_abs_diff<float>), dim3(gx), dim3(kBlock), 0, a->stream, (const amp_t<float>*)a->cur,
+                       (const amp_t<float>*)b->cur, a->namps, a->d_partial);
+  HIPCHK(hipGetLastError());
+  std::vector<double> part(2 * (size_t)gx);
+  HIPCHK(hipMemcpyAsync(part.data(), a->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, a->stream));
+  HIPCHK(hipStreamSynchronize(a->stream));
+  double worst = 0, differ = 0;
+  for (unsigned i = 0; i < gx; ++i) {
+    if (part[2 * i] > worst || part[2 * i] != part[2 * i]) worst = part[2 * i];
+    differ += part[2 * i + 1];
+  }
+  *max_abs = worst;
+  if (n_differ) *n_differ = (uint64_t)differ;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
 template <typename T>
 static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vector<uint32_t>& pos,
                            uint64_t m_first, uint64_t m_count, double* out) {

@@ -160,6 +160,9 @@ template <typename T>
 int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg,
                               std::vector<uint32_t> high, TileSegmentPlan<T>* out) {
   // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
+  const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, n > (uint32_t)kTileBits ? n - 5 : (uint32_t)kTileLow);
+  for (uint32_t p = std::max<uint32_t>(pad_from, kTileLow); high.size() < (size_t)kTileHigh && p < n; ++p)
+    if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
   for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < n; ++p)
     if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
   // the first kTileWaveBits free positions are wave bits at load / store time, the last three are the lane's own
@@ -173,7 +176,9 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
     }
     if (it->kind == 4) uses[it->t2] += 1;
   }
-  std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
+  if (g_tile_wave_rule == 1) std::sort(high.begin(), high.end());                                  // lowest positions = wave bits
+  else if (g_tile_wave_rule == 2) std::sort(high.begin(), high.end(), std::greater<uint32_t>());  // highest positions = wave bits
+  else std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
   auto tile_bit = [&](uint32_t pos) -> uint32_t {  // kTileOutside when the position is not part of the tile
     if (pos < (uint32_t)kTileLow) return pos;
     const auto f = std::find(high.begin(), high.end(), pos);

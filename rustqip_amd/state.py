@@ -134,6 +134,7 @@ class HipState:
     def __init__(self, n: int, dtype=np.complex128, device: int = 0, *, wrap_ptr: Optional[int] = None,
                  scratch_ptr: Optional[int] = None, stream: Optional[int] = None):
         self.n = int(n)
+        self.device = int(device)
         self.np_dtype = np.dtype(dtype)
         self.dtype = _dtype_of(np.empty(0, dtype=dtype))
         self._h = C.c_void_p()
@@ -209,6 +210,16 @@ class HipState:
 
     def sync(self) -> None:
         _check(_ffi.lib.qip_hip_state_sync(self._h))
+
+    def copy_from(self, other: "HipState") -> None:
+        """self <- other, device to device (same n, precision and device)"""
+        _check(_ffi.lib.qip_hip_state_copy_from(self._h, other._h))
+
+    def max_abs_diff(self, other: "HipState") -> Tuple[float, int]:
+        """(max_i |self_i - other_i|, number of amplitudes that are not IEEE-equal) over the whole vector"""
+        worst, differ = C.c_double(), C.c_uint64()
+        _check(_ffi.lib.qip_hip_state_max_abs_diff(self._h, other._h, C.byref(worst), C.byref(differ)))
+        return worst.value, int(differ.value)
 
     def set_option(self, key: str, value: int) -> None:
         _check(_ffi.lib.qip_hip_state_set_option(self._h, key.encode(), int(value)))

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
         assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_ffi.SIGNATURES) == names
-    assert _ffi.lib.qip_hip_abi_version() == 3
+    assert _ffi.lib.qip_hip_abi_version() == 4
 
 
 def test_make_matrix_op_errors():

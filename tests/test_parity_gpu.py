@@ -1828,3 +1828,90 @@ def test_resource_and_option_errors_are_reported_not_fatal():
         st.apply_ops(circuits.h_layer(6))  # still usable
         assert abs(st.norm_sqr() - 1.0) < 1e-12
         assert np.allclose(st.measure_probs([1, 4]), 0.25)
+
+
+def test_two_states_side_by_side_copy_and_whole_vector_diff():
+    """qip_hip_state_copy_from / qip_hip_state_max_abs_diff: the primitives of the whole-vector guard"""
+    n = 14
+    x = circuits.random_state(n, 3)
+    with q.HipState(n) as a, q.HipState(n) as b:
+        a.upload(x)
+        b.copy_from(a)
+        assert np.array_equal(b.download(), x)
+        assert a.max_abs_diff(b) == (0.0, 0)
+        y = x.copy()
+        y[777] += 1e-9
+        y[(1 << n) - 1] = -y[(1 << n) - 1]
+        b.upload(y)
+        worst, differ = a.max_abs_diff(b)
+        assert differ == 2 and abs(worst - 2 * abs(x[-1])) < 1e-15
+        y = x.copy()
+        y[5] = complex(float("nan"), 0.0)
+        b.upload(y)
+        worst, differ = a.max_abs_diff(b)
+        assert differ == 1 and worst != worst
+        with q.HipState(n, np.complex64) as c:
+            with pytest.raises(q.CircuitError):
+                a.max_abs_diff(c)
+            with pytest.raises(q.CircuitError):
+                c.copy_from(a)
+    with q.HipState(n, np.complex64) as a, q.HipState(n, np.complex64) as b:
+        a.upload(x.astype(np.complex64))
+        b.copy_from(a)
+        a.apply_op(q.make_matrix_op([n - 1], circuits.X))
+        worst, differ = a.max_abs_diff(b)
+        assert differ == 1 << n and worst > 0
+        b.apply_op(q.make_matrix_op([n - 1], circuits.X))
+        assert a.max_abs_diff(b) == (0.0, 0)
+
+
+@pytest.mark.parametrize("n", [28])
+def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
+    """What bench.py's parity block does at n = 30, as a test at n = 28: every mode the bench times — tile sweeps
+    (interpreted, run-time-compiled, relabelled), the 1e-12 modes (tile = 2, fused multiply-adds, dense fusion) and the other
+    BASELINE circuits (QFT, Clifford+T, Grover) through run-time-compiled sweeps — against the oracle on closed sub-cubes, with
+    a twin state that goes gate by gate through the literal kernel compared over ALL 2^n amplitudes after every step, and
+    closed-form marginals while the state is a product state."""
+    from oracle import window_parity as W
+
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    c2s = circuits.c2_random_circuit(n, 16, seed=28, single_only=True)
+    c2 = circuits.c2_random_circuit(n, 160, seed=29)
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        twin = W.Twin(st, lambda: q.HipState(n))
+        guard = W.ProductGuard(n, vecs)
+        assert guard.check(st) < 1e-12
+        agg = W.check_circuit(st, n, c2s, O, gate_by_gate=True, seed=1, twin=twin)
+        assert agg["bit_equal"] and agg["whole_vector_amplitudes_not_equal"] == 0 and agg["whole_vector_compares"] == 16, agg
+        for op in c2s:
+            guard.apply(op)
+        assert guard.check(st) < 1e-11, guard.worst_rel
+
+        def leg(ops, exact, max_len=64, **options):
+            for k, v in options.items():
+                st.set_option(k, v)
+            r = W.check_circuit(st, n, ops, O, gate_by_gate=False, seed=len(ops), bases_per_step=2, twin=twin, max_len=max_len)
+            for k in options:
+                st.set_option(k, 0)
+            assert r["skipped"] == 0 and r["gates"] == len(ops), (options, r)
+            if exact:
+                assert r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0, (options, r)
+            else:
+                assert r["max_abs_delta"] <= TOL64 and r["whole_vector_max_abs_delta"] <= TOL64, (options, r)
+                twin.resync()
+            return r
+
+        leg(c2[:32], True, tile=1)
+        leg(c2[32:64], True, tile=1, tile_jit=1)
+        leg(c2[64:96], True, tile=1, tile_jit=1, tile_relabel=2)
+        leg(c2[96:128], False, tile=2, tile_jit=1)
+        leg(c2[128:160], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c2_random_circuit(n, 32, seed=31), False, fuse=5)
+        r = leg(circuits.c3_qft(n), True, max_len=160, tile=1, tile_jit=1)
+        assert r["steps"] <= 16  # chunks as large as the timed segments (5-6 H and their controlled phases each)
+        leg(circuits.c4_clifford_t(n, 96, seed=32), True, tile=1, tile_jit=1)
+        leg(circuits.c5_grover_iteration(n), True, max_len=96, tile=1, tile_jit=1)
+        twin.close()
+        assert abs(st.norm_sqr() - 1) < 1e-9

@@ -46,6 +46,10 @@ def main():
     import numpy as np
 
     f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
+    for key in ("tile_pad_from", "tile_wave_rule", "tile_remap"):  # tuning aids (global options)
+        if os.environ.get("QIP_" + key.upper()):
+            q.set_global_option(key, int(os.environ["QIP_" + key.upper()]))
+    tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap")}
     with q.HipState(n, np.complex64 if f32 else np.complex128) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
@@ -55,6 +59,8 @@ def main():
                 st.set_option("tile_passes", passes)
                 st.set_option("tile_jit", 1 if os.environ.get("QIP_TILE_JIT") == "1" and mode else 0)
                 st.set_option("tile_relabel", int(os.environ.get("QIP_TILE_RELABEL", "0")) if mode else 0)
+                st.set_option("tile_pipe", int(os.environ.get("QIP_TILE_PIPE", "0")) if mode else 0)
+                st.set_option("tile_fma", int(os.environ.get("QIP_TILE_FMA", "0")) if mode else 0)
                 cops = st.compile_ops(ops)
                 st.set_option("profile", 1)
                 st.profile_reset()
@@ -71,11 +77,13 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
                                   "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
-                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"),
-                                  "norm": st.norm_sqr()}), flush=True)
+                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"), "pipe": os.environ.get("QIP_TILE_PIPE", "0"), "fma": os.environ.get("QIP_TILE_FMA", "0"),
+                                  "tune": tune, "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
         st.set_option("tile_jit", 0)
         st.set_option("tile_relabel", 0)
+        st.set_option("tile_pipe", 0)
+        st.set_option("tile_fma", 0)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,331 @@
+// tune_tile.hip — standalone A/B harness for the SKELETON of the LDS-resident tile sweep (not part of the product):
+// what bounds a sweep that carries G gates, and which block structure keeps HBM busy while tiles compute.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/tune_tile.hip -o tools/tune_tile
+//   tools/tune_tile [n = 30] [reps = 5]
+// Every variant reads and writes the 2^n vector once (32 * 2^n bytes) through 2^11-amplitude tiles = index bits 0..5 plus
+// five higher positions, exactly the product's tile; the "gates" are G element-wise complex factors per pass (the cost
+// shape of a diagonal gate: 6 f64 operations per amplitude), P passes, each pass one LDS round trip as in k_tile_passes.
+//   V0  one block per tile, 5 blocks per CU (the product's form)
+//   V1  V0 without any LDS traffic or passes (registers only), still 32 KiB of LDS per block -> what 5 blocks per CU can stream
+//   V2  V1 without the LDS allocation (occupancy by registers only)
+//   V3  persistent blocks, next tile DMA-ed (global_load_lds) into a second LDS slot during the passes: 2 blocks per CU
+//   V4  persistent blocks, next tile's loads held in registers during the passes: 4 blocks per CU
+//   V5  persistent blocks without prefetch, 5 per CU (control for V3 / V4)
+#include <hip/hip_runtime.h>
+#include "../rustqip_amd/csrc/qip_kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace qipk;
+typedef amp_t<double> A;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Hp { uint32_t h[5]; uint32_t sorted[5]; };
+
+__device__ __forceinline__ uint64_t tile_base(uint64_t t, const Hp& hp) {
+  uint64_t w = t << 6;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const uint32_t p = hp.sorted[j];
+    w = ((w >> p) << (p + 1)) | (w & ((1ull << p) - 1ull));
+  }
+  return w;
+}
+__device__ __forceinline__ uint64_t row_off(int u, uint32_t wave, const Hp& hp) {  // tile row (u, wave) -> amplitude offset
+  return ((uint64_t)(wave & 1u) << hp.h[0]) | ((uint64_t)((wave >> 1) & 1u) << hp.h[1]) | ((uint64_t)(u & 1) << hp.h[2]) |
+         ((uint64_t)((u >> 1) & 1) << hp.h[3]) | ((uint64_t)((u >> 2) & 1) << hp.h[4]);
+}
+
+// __syncthreads() is fence + s_barrier + fence, and hipcc's workgroup-scope release waits for EVERY outstanding memory
+// operation (s_waitcnt vmcnt(0)): inside a persistent loop that drains the prefetch at the first barrier of the passes.
+// The passes only exchange data through LDS, so their barrier needs the LDS counter alone.
+template <bool LDSONLY> __device__ __forceinline__ void tile_barrier() {
+  if constexpr (LDSONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
+// the passes: P round trips through the swizzled tile, G element-wise factors in each (pass bits 8, 9, 10 = the u bits)
+template <int P, int G, bool LDSONLY = true>
+__device__ __forceinline__ void passes(A* tile, uint32_t tid, A f) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    A e[8];
+    const uint32_t slot_tb = tile_slot<A>(tid);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = tile[slot_tb ^ tile_slot<A>((uint32_t)i << 8)];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = cmul(f, e[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[slot_tb ^ tile_slot<A>((uint32_t)i << 8)] = e[i];
+    tile_barrier<LDSONLY>();
+  }
+}
+
+// REMAP 1: the four blocks an XCD receives in a row (b, b + 8, b + 16, b + 24) take four ADJACENT tiles (rows 1 KiB apart in
+// every one of the tile's 32 row streams) instead of tiles 8 apart
+template <int REMAP> __device__ __forceinline__ uint64_t block_tile(uint64_t b) {
+  if (REMAP == 1) return (b & ~31ull) | ((b & 7ull) << 2) | ((b >> 3) & 3ull);
+  if (REMAP == 2) return (b & ~63ull) | ((b & 7ull) << 3) | ((b >> 3) & 7ull);
+  return b;
+}
+template <int P, int G, int MODE, int REMAP = 0, bool NT = true>  // MODE 0 = V0, 1 = V1 (no LDS traffic), 2 = V2 (no LDS at all)
+__global__ __launch_bounds__(256, MODE == 2 ? 8 : 5) void k_v0(A* __restrict__ st, Hp hp, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* tile = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint64_t base = tile_base(block_tile<REMAP>(blockIdx.x), hp);
+  A x[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = ldg<NT>(st + (base | row_off(u, wave, hp)) + lane);
+  if (MODE == 0 || MODE == 3) {
+    const uint32_t slot_tid = tile_slot<A>(tid);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
+    tile_barrier<MODE == 3>();
+    passes<P, G, MODE == 3>(tile, tid, f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)];
+  } else {
+#pragma unroll
+    for (int g = 0; g < G * P; ++g) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = cmul(f, x[i]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) stg<NT>(st + (base | row_off(u, wave, hp)) + lane, x[u]);
+}
+
+// persistent, MODE 4 = next tile's loads in registers across the passes, 5 = no prefetch.
+// Loop shape: the wait for the prefetched tile sits in the SAME iteration that issued it (issue -> passes -> stores ->
+// wait -> LDS write), so hipcc's counter bookkeeping sees "8 loads, then 8 stores" every time and waits with vmcnt(8..15):
+// for the loads only.  With the wait at the top of the next iteration it merges the first entry (no stores yet) with the
+// back edge and waits with vmcnt(0..7), i.e. for the previous tile's stores as well.
+template <int P, int G, int MODE>
+__global__ __launch_bounds__(256, MODE == 4 ? 4 : 5) void k_persist(A* __restrict__ st, uint64_t ntiles, Hp hp, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* tile = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t slot_tid = tile_slot<A>(tid);
+  uint64_t t = blockIdx.x;
+  uint64_t base = tile_base(t, hp);
+  {
+    A x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(st + (base | row_off(u, wave, hp)) + lane);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
+  }
+  tile_barrier<true>();
+  for (;;) {
+    const uint64_t tn = t + gridDim.x;
+    const bool more = tn < ntiles;
+    const uint64_t base_n = tile_base(tn, hp);
+    A x[8];
+    if (MODE == 4 && more) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(st + (base_n | row_off(u, wave, hp)) + lane);
+    }
+    passes<P, G>(tile, tid, f);
+    A y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[u] = tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(y[u], st + (base | row_off(u, wave, hp)) + lane);
+    if (!more) break;
+    if (MODE == 5) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(st + (base_n | row_off(u, wave, hp)) + lane);
+    }
+    tile_barrier<true>();  // every lane has read its share of this tile
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
+    tile_barrier<true>();
+    t = tn;
+    base = base_n;
+  }
+}
+
+// persistent, the next tile DMA-ed straight into the other LDS slot (no registers): global_load_lds writes lane l's 16 bytes
+// at row base + 16 l, so the tile's swizzle goes on the SOURCE side: lane l fetches the element whose slot is l
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+template <int P, int G, int BPC>
+__global__ __launch_bounds__(256, BPC) void k_dma(A* __restrict__ st, uint64_t ntiles, Hp hp, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* slot0 = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t slot_tid = tile_slot<A>(tid);
+  auto fetch = [&](uint64_t b, A* dst) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t R = ((uint32_t)u << 2) | wave;                      // tile row = tile index >> 6
+      const uint32_t src_lane = lane ^ ((R * 4u + (lane >> 4)) & 15u);     // element of the row whose swizzled slot is `lane`
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(st + (b | row_off(u, wave, hp)) + src_lane), (lds_ptr_t)(dst + R * 64u), 16, 0, 0);
+    }
+  };
+  uint64_t t = blockIdx.x;
+  uint64_t base = tile_base(t, hp);
+  uint32_t cur = 0;
+  fetch(base, slot0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tile_barrier<true>();
+  for (;;) {
+    A* tile = slot0 + (cur ? 2048 : 0);
+    const uint64_t tn = t + gridDim.x;
+    const bool more = tn < ntiles;
+    const uint64_t base_n = tile_base(tn, hp);
+    if (more) fetch(base_n, slot0 + (cur ? 0 : 2048));
+    passes<P, G>(tile, tid, f);
+    A y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[u] = tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(y[u], st + (base | row_off(u, wave, hp)) + lane);
+    if (!more) break;
+    // the next tile's DMA is older than the eight stores just issued: wait for it (own loads by the counter, the other
+    // waves' by the barrier), not for the stores; the barrier also frees this slot for the DMA after next
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    tile_barrier<true>();
+    t = tn;
+    base = base_n;
+    cur ^= 1u;
+  }
+}
+
+__global__ void k_init(A* st, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    A v;
+    v.x = 1e-5 * (double)((i * 2654435761ull) & 0xffff) + 0.25;
+    v.y = 1e-5 * (double)((i * 40503ull) & 0xffff) - 0.125;
+    st[i] = v;
+  }
+}
+__global__ void k_sum(const A* st, uint64_t n, double* out) {
+  double s = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    s += st[i].x * (double)((i % 7) + 1) + st[i].y * (double)((i % 5) + 1);
+  atomicAdd(out, s);
+}
+
+static A* g_st;
+static uint64_t g_n;
+static int g_reps;
+static int g_cus;
+
+template <typename F> static void run(const char* name, int P, int G, const char* hname, F&& launch) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  k_init<<<4096, 256>>>(g_st, g_n);
+  launch();  // warm
+  CK(hipDeviceSynchronize());
+  double* dsum;
+  CK(hipMalloc(&dsum, 8));
+  CK(hipMemset(dsum, 0, 8));
+  k_sum<<<4096, 256>>>(g_st, 1ull << 24, dsum);
+  double hs = 0;
+  CK(hipMemcpy(&hs, dsum, 8, hipMemcpyDeviceToHost));
+  CK(hipFree(dsum));
+  float best = 1e9f;
+  for (int r = 0; r < g_reps; ++r) {
+    CK(hipEventRecord(e0));
+    launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = std::min(best, ms);
+  }
+  CK(hipGetLastError());
+  printf("%-26s P=%d G=%-3d %-14s %7.3f ms  %6.0f GB/s  chk=%.9e\n", name, P, G, hname, best, 32.0 * (double)g_n / best / 1e6, hs);
+  fflush(stdout);
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+}
+
+template <int P, int G> static void variants(const Hp& hp, const char* hname) {
+  const uint64_t ntiles = g_n >> 11;
+  A f;
+  f.x = 0.6;
+  f.y = 0.8;
+  const size_t lds = 32768;
+  run("V0 block/tile 5pCU", P, G, hname, [&] { hipLaunchKernelGGL((k_v0<P, G, 0>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V0b V0, LDS-only barrier", P, G, hname, [&] { hipLaunchKernelGGL((k_v0<P, G, 3>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V1 regs only, 32K LDS", P, G, hname, [&] { hipLaunchKernelGGL((k_v0<P, G, 1>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V2 regs only, no LDS", P, G, hname, [&] { hipLaunchKernelGGL((k_v0<P, G, 2>), dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, hp, f); });
+  run("V3 persist DMA 2pCU", P, G, hname, [&] { hipLaunchKernelGGL((k_dma<P, G, 2>), dim3((unsigned)std::min<uint64_t>(ntiles, g_cus * 2)), dim3(256), 2 * lds, 0, g_st, ntiles, hp, f); });
+  run("V4 persist regs 4pCU", P, G, hname, [&] { hipLaunchKernelGGL((k_persist<P, G, 4>), dim3((unsigned)std::min<uint64_t>(ntiles, g_cus * 4)), dim3(256), lds, 0, g_st, ntiles, hp, f); });
+  run("V5 persist nopre 5pCU", P, G, hname, [&] { hipLaunchKernelGGL((k_persist<P, G, 5>), dim3((unsigned)std::min<uint64_t>(ntiles, g_cus * 5)), dim3(256), lds, 0, g_st, ntiles, hp, f); });
+}
+
+static void light(const Hp& hp, const char* hname) {
+  const uint64_t ntiles = g_n >> 11;
+  A f;
+  f.x = 0.6;
+  f.y = 0.8;
+  const size_t lds = 32768;
+  run("V0", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 0>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V0 remap4", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 0, 1>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V0 remap8", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 0, 2>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V0 plain ld/st", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 0, 0, false>), dim3((unsigned)ntiles), dim3(256), lds, 0, g_st, hp, f); });
+  run("V2 no LDS", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 2>), dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, hp, f); });
+  run("V2 no LDS remap4", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 2, 1>), dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, hp, f); });
+}
+
+static Hp make_hp(std::vector<uint32_t> h) {
+  Hp hp;
+  for (int j = 0; j < 5; ++j) hp.h[j] = h[j];
+  std::sort(h.begin(), h.end());
+  for (int j = 0; j < 5; ++j) hp.sorted[j] = h[j];
+  return hp;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 30;
+  g_reps = argc > 2 ? atoi(argv[2]) : 5;
+  g_n = 1ull << n;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  g_cus = prop.multiProcessorCount;
+  printf("device %s, %d CUs, n = %d\n", prop.name, g_cus, n);
+  CK(hipMalloc(&g_st, g_n * sizeof(A)));
+  CK(hipFuncSetAttribute((const void*)k_dma<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  const Hp top = make_hp({(uint32_t)n - 5, (uint32_t)n - 4, (uint32_t)n - 3, (uint32_t)n - 2, (uint32_t)n - 1});
+  const Hp low = make_hp({6, 7, 8, 9, 10});
+  const Hp mix = make_hp({12, 15, 18, 21, 24});
+#define DMA_ATTR(P, G) CK(hipFuncSetAttribute((const void*)k_dma<P, G, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536))
+  DMA_ATTR(1, 0); DMA_ATTR(1, 2); DMA_ATTR(2, 8); DMA_ATTR(2, 32); DMA_ATTR(2, 64);
+  if (argc > 3 && !strcmp(argv[3], "light")) {
+    const uint32_t N = (uint32_t)n;
+    struct { std::vector<uint32_t> h; const char* name; } sets[] = {
+        {{6, 7, 8, 9, 10}, "w6,7 u8,9,10"},        {{6, 7, 11, 12, 13}, "w6,7 u11,12,13"},   {{6, 7, 12, 13, 14}, "w6,7 u12,13,14"},
+        {{8, 9, 11, 12, 13}, "w8,9 u11,12,13"},    {{11, 12, 13, 14, 15}, "w11,12 u13-15"},  {{6, 7, N - 3, N - 2, N - 1}, "w6,7 u top3"},
+        {{N - 2, N - 1, 6, 7, 8}, "w top2 u6,7,8"}, {{N - 5, N - 4, N - 3, N - 2, N - 1}, "top5"}, {{N - 3, N - 2, N - 1, N - 5, N - 4}, "top5 (u = lower two + ...)"},
+        {{12, 15, 18, 21, 24}, "w12,15 u18,21,24"}, {{6, 15, 18, 21, 24}, "w6,15 u18,21,24"}, {{6, 7, 18, 21, 24}, "w6,7 u18,21,24"},
+        {{18, 21, 24, 6, 7}, "w18,21 u24,6,7"}};
+    for (auto& s : sets) light(make_hp(s.h), s.name);
+    CK(hipFree(g_st));
+    return 0;
+  }
+  variants<1, 0>(top, "bits n-5..n-1");
+  variants<1, 0>(low, "bits 6..10");
+  variants<1, 0>(mix, "bits 12..24");
+  variants<1, 2>(top, "bits n-5..n-1");
+  variants<1, 2>(mix, "bits 12..24");
+  variants<2, 8>(top, "bits n-5..n-1");
+  variants<2, 8>(mix, "bits 12..24");
+  variants<2, 32>(top, "bits n-5..n-1");
+  variants<2, 64>(top, "bits n-5..n-1");
+  CK(hipFree(g_st));
+  return 0;
+}
