@@ -85,14 +85,29 @@ def dominant_kernel(profile):
 
 def load_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/): a STATIC
-    figure from separate --pmc passes of this same command, not a per-run measurement."""
+    figure from separate --pmc passes of this same command, not a per-run measurement.  Third value: True when the
+    kernel source has changed since those passes were taken (the figure then describes older kernels)."""
+    import hashlib
+
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(kernel_name, {}).get("hbm_bytes_per_launch"), d.get("_source", "profiles/pmc_traffic.json")
+        now = hashlib.sha256(open(os.path.join(ROOT, "rustqip_amd", "csrc", "qip_kernels.h"), "rb").read()).hexdigest()[:16]
+        stale = d.get("_kernels_sha16") != now
+        return d.get(kernel_name, {}).get("hbm_bytes_per_launch"), d.get("_source", "profiles/pmc_traffic.json"), stale
     except Exception:
-        return None, None
+        return None, None, None
+
+
+def load_n1_reference(n_local):
+    """The single-GPU value of this same bench at the same shard size (profiles/n1_reference.json, written from a measured
+    N = 1 line): the denominator of SURVEY.md §8(e)'s per-GPU efficiency."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "n1_reference.json")) as f:
+            return json.load(f).get(str(n_local))
+    except Exception:
+        return None
 
 
 def median_time(fn, sync, reps=REPS):
@@ -361,6 +376,11 @@ def main():
     profile = get_profile()
     set_profile(0)
     comm_headline = st.comm_stats() if world > 1 else None
+    rccl_ranks_min = None
+    if world > 1:
+        rr = torch.tensor([float(comm_headline["rccl_ranks"])], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(rr, op=dist.ReduceOp.MIN)
+        rccl_ranks_min = int(rr.item())
     norm = st.norm_sqr()
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -371,11 +391,15 @@ def main():
         per_launch_bytes = kstat["algorithmic_bytes"] / kstat["launches"]
         avg_ms = kstat["total_ms"] / kstat["launches"]
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = load_traffic(kname)
+        traffic, traffic_src, traffic_stale = load_traffic(kname)
+        if traffic_stale:
+            print("bench.py: warning: profiles/pmc_traffic.json was measured on an older csrc/qip_kernels.h — roofline.traffic is "
+                  "flagged stale; re-run tools/profile_round.sh", file=sys.stderr)
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": f"static, from {traffic_src} (separate rocprofv3 --pmc passes of this command; not re-measured per run)",
+            "traffic_stale": traffic_stale,
             "avg_launch_ms": avg_ms, "launches": kstat["launches"], "algorithmic_bytes_per_launch": per_launch_bytes,
         }
     kernels = {
@@ -590,6 +614,14 @@ def main():
         if world > 1:
             line["comm"] = comm_headline
             line["dist"] = st.describe()
+            # what RCCL itself reports (ncclCommCount read back from the communicator, min over ranks): proof that the
+            # collective library saw `world` ranks; 0 with the host-staged test transport
+            line["rccl_ranks"] = rccl_ranks_min
+            ref = load_n1_reference(args.n_local)
+            if ref:
+                # (aggregate GB/s / G) / single-GPU GB/s at the same shard size, communication included
+                line["per_gpu_efficiency"] = value / world / ref["value"]
+                line["per_gpu_efficiency_reference"] = ref
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

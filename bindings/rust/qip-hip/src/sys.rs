@@ -138,6 +138,7 @@ extern "C" {
 
     pub fn qip_hip_tile_bits() -> c_int;
     pub fn qip_hip_jit_stats(kernels_compiled: *mut u64, compile_ms: *mut c_double) -> c_int;
+    pub fn qip_hip_jit_cache_info(resident: *mut u64, evicted: *mut u64, cap: *mut u64) -> c_int;
     pub fn qip_hip_debug_tile_jit(
         dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int, segments: *mut u64,
         source_bytes: *mut u64, code_bytes: *mut u64, first_source: *mut *const c_char,
@@ -165,6 +166,9 @@ extern "C" {
     pub fn qip_hip_dist_layout(d: *mut qip_hip_dist, phys: *mut u32) -> c_int;
     pub fn qip_hip_dist_rank_flip(d: *mut qip_hip_dist, mask: *mut u32) -> c_int;
     pub fn qip_hip_dist_take_stats(d: *mut qip_hip_dist, out: *mut qip_hip_dist_stats) -> c_int;
+    pub fn qip_hip_dist_debug_pieces(
+        rank: c_int, world: c_int, chunk_bytes: u64, piece_bytes: u64, cap: u64, peer: *mut i32, offset: *mut u64, length: *mut u64,
+    ) -> i64;
     pub fn qip_hip_dist_debug_plan(
         n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64,
     ) -> *const c_char;
@@ -191,4 +195,9 @@ pub struct qip_hip_dist_stats {
     pub bytes_sent: u64,
     pub exchange_ms: c_double,
     pub pack_ms: c_double,
+    /// read back from the communicator (ncclCommCount / ncclCommUserRank); 0 / -1 with caller-supplied callbacks
+    pub rccl_ranks: i32,
+    pub rccl_rank: i32,
+    pub pieces_sent: u64,
+    pub piece_bytes: u64,
 }

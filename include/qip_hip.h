@@ -206,7 +206,7 @@ int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
                        int64_t* step_of_op, uint64_t* n_steps);
 
 /* Host-only: how one pass of a tile sweep lays the thread id over the tile.  pass_bits = the pass's three exchange
- * bits (tile-index space 0..11, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the 9-bit
+ * bits (tile-index space 0..10, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the 8-bit
  * thread id.  The tile is stored in LDS at slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 (QIP_C64) / 5 (QIP_C32);
  * together the two make every pass free of LDS bank conflicts unless it holds both bits of a pair (j, j+S).  Exposed
  * so the claim can be checked without a GPU (tests/test_host_ops.py). */
@@ -225,6 +225,11 @@ int qip_hip_tile_bits(void);
 /* Segment-specialised tile sweeps (option "tile_jit"): how many segment kernels this process has compiled with hiprtc
  * so far and the time that took (cache misses only; a segment met again costs nothing). */
 int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
+/* The cache of those kernels is process-wide, guarded by a mutex (handles driven by different threads stay independent)
+ * and bounded: beyond `cap` entries (qip_hip_set_global_option("jit_cache_cap", n), default 512) the least recently used
+ * kernels are unloaded; programs recorded into a hipGraph re-record themselves when an eviction happened since.
+ * Any output may be NULL. */
+int qip_hip_jit_cache_info(uint64_t* resident, uint64_t* evicted, uint64_t* cap);
 
 /* Host-only test hook: generate AND compile (hiprtc cross-compiles for gfx950 without a device) the run-time source
  * of every multi-gate step of the circuit's tile schedule.  *first_source (may be NULL) points at the first segment's
@@ -244,7 +249,7 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
  *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into segments of gates (1-qubit gates with any
  *                    controls, dense 2-qubit gates, bit swaps) whose exchanging bits live on index bits 0..5
- *                    plus six free higher bits and applies each segment in ONE sweep
+ *                    plus five free higher bits and applies each segment in ONE sweep
  *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
  *                    (IEEE-equal to the gate-by-gate path; a dense 3-qubit gate rides along as the unfused register fold,
  *                    i.e. equal to its gate-by-gate form under "mfma" = 0 — on the matrix cores it is an fma chain);
@@ -259,9 +264,15 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    comes soonest on index bits 0..5, so the next segment spends its five free positions on five OTHER
  *                    qubits; uncontrolled Swap ops become label exchanges (no sweep at all); one bit-permutation sweep at
  *                    the end restores the order.  Only moves are added and no gate changes its place in the plain schedule's
- *                    order: bit-identical to "tile" without it.  The plan is only used when it is shorter than the plain
+ *                    order: bit-identical to "tile" = 1 without it (for "tile" = 2 the hoists depend on which gates share a
+ *                    physical tile, so the two plans agree to the 1e-12 bar of that mode only; a dense 3-qubit gate that rides
+ *                    in a segment in one plan and runs alone on the matrix cores in the other likewise differs by rounding).
+ *                    The plan is only used when it is shorter than the plain
  *                    one (random circuits: 19 -> 14 sweeps for configs[1]; layered ones like QFT / Grover keep the plain
  *                    plan).  2 = use it unconditionally (tests).  0 (default) = off.  Needs the scratch buffer.
+ *   "tile_fma"       1: run-time-compiled segments of "tile" = 2 are compiled with multiply-add contraction (v_fma_f64: a complex
+ *                    product is 4 instead of 6 vector instructions; QFT at n = 30: 57 -> 50 ms).  Ignored for "tile" = 1, which
+ *                    promises IEEE equality with the gate-by-gate path.  0 (default) = off.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)
@@ -396,9 +407,22 @@ typedef struct qip_hip_dist_stats {
   uint64_t bytes_sent;        /* by this rank, over all remaps */
   double exchange_ms;         /* HIP-event time of the all-to-alls on the handle's stream */
   double pack_ms;
+  /* (ABI 4) what the transport itself reports, read back from the communicator — NOT what the caller passed in:
+   * ncclCommCount / ncclCommUserRank for the built-in RCCL transport (0 / -1 with caller-supplied callbacks).  A bench
+   * line that prints rccl_ranks = N proves RCCL saw N ranks. */
+  int32_t rccl_ranks, rccl_rank;
+  uint64_t pieces_sent;       /* ncclSend calls issued (chunks above `piece_bytes` go in several) */
+  uint64_t piece_bytes;       /* the piece size in force (option "piece_bytes", default 1 GiB) */
 } qip_hip_dist_stats;
-/* counters since the previous call (they reset) */
+/* counters since the previous call (they reset; rccl_ranks / rccl_rank / piece_bytes are properties, not counters) */
 int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);
+
+/* Host-only: how one rank's all-to-all of `chunk_bytes` per peer is cut into sends of at most `piece_bytes` — the list the
+ * built-in RCCL transport walks inside ONE ncclGroupStart / ncclGroupEnd (peer, byte offset inside the chunk, length; the
+ * matching receive has the same three numbers).  Returns the number of pieces; fills at most `cap` entries of each array
+ * (any may be NULL).  Test transports use the same list, so the loop is exercised without a second GPU. */
+int64_t qip_hip_dist_debug_pieces(int rank, int world, uint64_t chunk_bytes, uint64_t piece_bytes, uint64_t cap,
+                                  int32_t* peer, uint64_t* offset, uint64_t* length);
 
 /* Host-only test hook: what rank `rank` of `world` would do for this circuit on a fresh state, as a JSON string
  * (owned by the library, valid until the calling thread's next call; NULL on error): the steps

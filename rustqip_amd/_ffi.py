@@ -45,7 +45,8 @@ class QipTransport(C.Structure):
 
 class QipDistStats(C.Structure):
     _fields_ = [("remaps", C.c_uint64), ("pack_sweeps", C.c_uint64), ("bytes_sent", C.c_uint64),
-                ("exchange_ms", C.c_double), ("pack_ms", C.c_double)]
+                ("exchange_ms", C.c_double), ("pack_ms", C.c_double),
+                ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("pieces_sent", C.c_uint64), ("piece_bytes", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/qip_hip.h declares
@@ -89,6 +90,7 @@ SIGNATURES = {
     "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "qip_hip_debug_tile_plan": (_cp, [_int, _u32, _opp, _u64, _int]),
     "qip_hip_tile_bits": (_int, []),
+    "qip_hip_jit_cache_info": (_int, [_u64p, _u64p, _u64p]),
     "qip_hip_jit_stats": (_int, [_u64p, _dblp]),
     "qip_hip_debug_tile_jit": (_int, [_int, _u32, _opp, _u64, _int, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p)]),
     "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
@@ -120,6 +122,7 @@ SIGNATURES = {
     "qip_hip_dist_rank_flip": (_int, [_vp, C.POINTER(C.c_uint32)]),
     "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
     "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
+    "qip_hip_dist_debug_pieces": (_i64, [_int, _int, _u64, _u64, _u64, C.POINTER(C.c_int32), _u64p, _u64p]),
 }
 
 

@@ -1,6 +1,8 @@
 // qip_circuit.hip — apply_ops: gate fusion, tile sweeps (interpreter launches and run-time-compiled segments), hipGraph programs.
 #include "qip_tile.h"
 
+#include <mutex>
+
 // ---------------------------------------------------------------------------------------
 // gate fusion: option "fuse" = K merges consecutive small gates into dense
 // gates on <= K qubits, applied in ONE sweep each.  The reference has no analogue (its apply_ops
@@ -213,6 +215,10 @@ struct Hiprtc {
   int (*DestroyProgram)(void**) = nullptr;
 };
 static Hiprtc g_rtc;
+// The run-time compiler state below (loader, kernel cache, counters) is process-global while handles are per thread —
+// "separate handles are independent" (include/qip_hip.h) has to hold for two threads that both use tile_jit: one mutex
+// serialises loading, the cache and the compilation itself (hiprtc calls are not documented to be re-entrant).
+static std::mutex g_jit_mutex;
 static int hiprtc_load() {
   if (g_rtc.handle) return QIP_OK;
   void* h = nullptr;
@@ -269,16 +275,62 @@ static int hiprtc_compile(const std::string& src, bool fma, std::vector<char>* c
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
+  uint64_t last_use = 0;
+  int device = 0;
 };
-static std::map<std::string, JitKernel> g_jit_cache;  // key: device ordinal + source text
-static uint64_t g_jit_compiles = 0;
+// key: device ordinal + compile flavour + source text.  Bounded: beyond g_jit_cache_cap entries (global option
+// "jit_cache_cap", default 512 — a parameter sweep that changes matrix constants makes new sources without end) the least
+// recently used kernels are unloaded, oldest first.  A kernel that is evicted while a captured hipGraph still names it would
+// dangle, so programs hold the cache generation they were recorded under and re-record when it moved (qip_hip_program_run).
+static std::map<std::string, JitKernel> g_jit_cache;
+static uint64_t g_jit_clock = 0, g_jit_generation = 0;
+static int64_t g_jit_cache_cap = 512;
+static uint64_t g_jit_compiles = 0, g_jit_evictions = 0;
 static double g_jit_compile_ms = 0;
 
 extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
   if (kernels_compiled) *kernels_compiled = g_jit_compiles;
   if (compile_ms) *compile_ms = g_jit_compile_ms;
   return QIP_OK;
 } QIP_CATCH_ALL
+
+extern "C" int qip_hip_jit_cache_info(uint64_t* resident, uint64_t* evicted, uint64_t* cap) try {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  if (resident) *resident = g_jit_cache.size();
+  if (evicted) *evicted = g_jit_evictions;
+  if (cap) *cap = (uint64_t)g_jit_cache_cap;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+int jit_set_cache_cap(int64_t cap) {
+  if (cap < 1) return fail(QIP_ERR_INVALID, "jit_cache_cap must be >= 1");
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit_cache_cap = cap;
+  return QIP_OK;
+}
+uint64_t jit_cache_generation() {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  return g_jit_generation;
+}
+
+// under g_jit_mutex: unload least recently used kernels until the cache is within its bound
+static void jit_evict_locked() {
+  while ((int64_t)g_jit_cache.size() > g_jit_cache_cap) {
+    auto victim = g_jit_cache.begin();
+    for (auto it = g_jit_cache.begin(); it != g_jit_cache.end(); ++it)
+      if (it->second.last_use < victim->second.last_use) victim = it;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(victim->second.device);
+    (void)hipDeviceSynchronize();  // no launch of it may still be queued
+    (void)hipModuleUnload(victim->second.module);
+    (void)hipSetDevice(cur);
+    g_jit_cache.erase(victim);
+    g_jit_evictions += 1;
+    g_jit_generation += 1;
+  }
+}
 
 template <typename T> static std::string fnum(T v) {
   char buf[64];
@@ -454,8 +506,10 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
 
 static int jit_get_kernel(qip_hip_state* s, const std::string& src, bool fma, hipFunction_t* fn) {
   const std::string key = std::to_string(s->device) + (fma ? " fma\n" : "\n") + src;
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) {
+    it->second.last_use = ++g_jit_clock;
     *fn = it->second.fn;
     return QIP_OK;
   }
@@ -464,11 +518,18 @@ static int jit_get_kernel(qip_hip_state* s, const std::string& src, bool fma, hi
   QCHK(hiprtc_compile(src, fma, &code));
   JitKernel k;
   HIPCHK(hipModuleLoadData(&k.module, code.data()));
-  HIPCHK(hipModuleGetFunction(&k.fn, k.module, "qip_segment"));
+  hipError_t e = hipModuleGetFunction(&k.fn, k.module, "qip_segment");
+  if (e != hipSuccess) {
+    (void)hipModuleUnload(k.module);
+    return fail(QIP_ERR_DEVICE, "hipModuleGetFunction failed: %s", hipGetErrorString(e));
+  }
+  k.device = s->device;
+  k.last_use = ++g_jit_clock;
   g_jit_compiles += 1;
   g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   g_jit_cache[key] = k;
   *fn = k.fn;
+  jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   return QIP_OK;
 }
 
@@ -562,7 +623,10 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     Ins ins = make_ins(plan.high, 0);
     const std::string src = tile_jit_source<T>(plan, ins, true, (mode & 16) ? 1 : 0);  // mode bit 4: the persistent form
     std::vector<char> code;
-    QCHK(hiprtc_compile(src, (mode & 32) != 0, &code));  // mode bit 5: fused multiply-adds
+    {
+      std::lock_guard<std::mutex> lock(g_jit_mutex);
+      QCHK(hiprtc_compile(src, (mode & 32) != 0, &code));  // mode bit 5: fused multiply-adds
+    }
     if (*nseg == 0 && first) *first = src;
     *nseg += 1;
     *src_bytes += src.size();
@@ -656,6 +720,7 @@ struct qip_hip_program {
   hipGraphExec_t exec = nullptr;
   void* captured_cur = nullptr;
   uint64_t captured_arena_gen = 0;  // the graph's memcpy / kernel nodes hold arena addresses
+  uint64_t captured_jit_gen = 0;    // ... and run-time-compiled kernels the cache may since have unloaded
   std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
   int last_was_graph = 0;
 };
@@ -722,6 +787,7 @@ static int program_capture(qip_hip_program* p) {
         p->graph = g;
         p->captured_cur = s->cur;
         p->captured_arena_gen = s->arena_gen;
+        p->captured_jit_gen = jit_cache_generation();
         return QIP_OK;
       }
       (void)hipGetLastError();
@@ -776,8 +842,8 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) try {
   qip_hip_state* s = p->s;
   if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
   STATE_ENTER(s);
-  if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen || s->profile || s->force_generic ||
-                  g_force_generic)) {
+  if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen ||
+                  (s->tile_jit && p->captured_jit_gen != jit_cache_generation()) || s->profile || s->force_generic || g_force_generic)) {
     if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
     else QCHK(program_capture(p));  // the state moved to its other buffer, or the arena was re-allocated (an eager op
                                     // needed a larger payload): the recorded addresses are stale, re-record

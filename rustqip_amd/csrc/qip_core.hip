@@ -57,6 +57,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
     g_line_bits = (uint32_t)value;
     return QIP_OK;
   }
+  if (key && !strcmp(key, "jit_cache_cap")) return jit_set_cache_cap(value);
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }

@@ -23,6 +23,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 
 namespace qipd {
 
@@ -452,6 +453,8 @@ struct Rccl {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
+  int (*CommCount)(Comm, int*) = nullptr;
+  int (*CommUserRank)(Comm, int*) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -462,7 +465,10 @@ struct Rccl {
   static constexpr int kUint8 = 1, kFloat64 = 8, kSum = 0;  // ncclDataType_t / ncclRedOp_t values (rccl.h:448-467)
 };
 static Rccl g_rccl;
+static std::mutex g_rccl_mutex;  // handles are per thread (one thread per GPU is the natural in-process use): the first
+                                 // multi-GPU call of each may arrive at the same time
 static int rccl_load() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle) return QIP_OK;
   void* h = nullptr;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -478,6 +484,8 @@ static int rccl_load() {
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
+  SYM(CommUserRank, "ncclCommUserRank");
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(Send, "ncclSend");
@@ -500,27 +508,53 @@ struct RcclTransport {
   double* d_red = nullptr;  // small device buffer for the all-reduce
   size_t red_cap = 0;
   hipStream_t stream = nullptr;
+  uint64_t piece_bytes = 1ull << 30;  // option "piece_bytes"
+  uint64_t pieces_sent = 0;
 };
+
+// How one rank's all-to-all is cut into sends: every peer in rank order, each chunk in pieces of at most `piece_bytes` (a
+// 16-GiB shard over 8 ranks makes 2-GiB chunks: keep every count far from 2^31).  Several sends to one peer inside a group
+// are matched with its receives in order, so both sides walk the same list.  Pure: qip_hip_dist_debug_pieces exports it.
+struct Piece {
+  int peer;
+  uint64_t offset, length;
+};
+static std::vector<Piece> plan_pieces(int rank, int world, uint64_t chunk_bytes, uint64_t piece_bytes) {
+  std::vector<Piece> out;
+  if (piece_bytes == 0) piece_bytes = chunk_bytes ? chunk_bytes : 1;
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
+    for (uint64_t off = 0; off < chunk_bytes; off += piece_bytes) out.push_back({p, off, std::min<uint64_t>(piece_bytes, chunk_bytes - off)});
+  }
+  return out;
+}
+
 static int rccl_all_to_all(void* ctx, const void* send, void* recv, uint64_t chunk_bytes, void* stream) {
   RcclTransport* t = static_cast<RcclTransport*>(ctx);
   hipStream_t st = (hipStream_t)stream;
-  // own chunk: a device copy; every peer: one send + one receive, all in ONE group so that all links run at once
+  if (t->world > 1) {
+    // every peer: one send + one receive per piece, all in ONE group so that all links run at once.  An error inside the
+    // group must not leave the communicator in group mode (a later collective would hang instead of failing): remember the
+    // first one, always close the group, then report.
+    int first = 0;
+    const char* what = "";
+    int r = g_rccl.GroupStart();
+    if (r != 0) return fail(QIP_ERR_DEVICE, "ncclGroupStart failed: %s", g_rccl.GetErrorString(r));
+    for (const Piece& pc : plan_pieces(t->rank, t->world, chunk_bytes, t->piece_bytes)) {
+      r = g_rccl.Send((const char*)send + (size_t)pc.peer * chunk_bytes + pc.offset, (size_t)pc.length, Rccl::kUint8, pc.peer, t->comm, st);
+      if (r != 0 && first == 0) first = r, what = "ncclSend";
+      r = g_rccl.Recv((char*)recv + (size_t)pc.peer * chunk_bytes + pc.offset, (size_t)pc.length, Rccl::kUint8, pc.peer, t->comm, st);
+      if (r != 0 && first == 0) first = r, what = "ncclRecv";
+      if (first != 0) break;
+      t->pieces_sent += 1;
+    }
+    r = g_rccl.GroupEnd();
+    if (first != 0) return fail(QIP_ERR_DEVICE, "%s failed inside the exchange group: %s", what, g_rccl.GetErrorString(first));
+    if (r != 0) return fail(QIP_ERR_DEVICE, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(r));
+  }
+  // own chunk: a device copy
   HIPCHK(hipMemcpyAsync((char*)recv + (size_t)t->rank * chunk_bytes, (const char*)send + (size_t)t->rank * chunk_bytes, chunk_bytes,
                         hipMemcpyDeviceToDevice, st));
-  if (t->world == 1) return QIP_OK;
-  // pieces of at most 1 GiB per call (a 16-GiB shard over 8 ranks makes 2-GiB chunks: keep every count far from 2^31);
-  // several sends to one peer inside a group are matched with its receives in order
-  const uint64_t piece = 1ull << 30;
-  NCHK(g_rccl.GroupStart());
-  for (int p = 0; p < t->world; ++p) {
-    if (p == t->rank) continue;
-    for (uint64_t off = 0; off < chunk_bytes; off += piece) {
-      const size_t len = (size_t)std::min<uint64_t>(piece, chunk_bytes - off);
-      NCHK(g_rccl.Send((const char*)send + (size_t)p * chunk_bytes + off, len, Rccl::kUint8, p, t->comm, st));
-      NCHK(g_rccl.Recv((char*)recv + (size_t)p * chunk_bytes + off, len, Rccl::kUint8, p, t->comm, st));
-    }
-  }
-  NCHK(g_rccl.GroupEnd());
   return QIP_OK;
 }
 static int rccl_all_reduce(void* ctx, double* values, uint64_t count) {
@@ -583,6 +617,11 @@ struct qip_hip_dist {
   qipd::RcclTransport* rccl = nullptr;  // owned when the built-in transport is in use
   qip_hip_dist_stats stats{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_exchange, ev_pack;
+  // A batch that fails half way (a kernel launch, the transport, an allocation) leaves the shard somewhere between two
+  // layouts while the planner already describes the end of the batch — and the other ranks may sit in a collective.  Nothing
+  // computed from such a handle can be trusted: it is poisoned and every later call fails with the original message.
+  bool poisoned = false;
+  std::string poison_msg;
 };
 
 static int dist_drain_events(qip_hip_dist* d) {
@@ -697,9 +736,21 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
   return QIP_OK;
 }
 
-#define DIST_ENTER(d)                                        \
-  if (!(d)) return fail(QIP_ERR_INVALID, "null dist handle"); \
+#define DIST_ENTER(d)                                                                                                       \
+  if (!(d)) return fail(QIP_ERR_INVALID, "null dist handle");                                                                \
+  if ((d)->poisoned) return fail(QIP_ERR_DEVICE, "sharded state unusable after an earlier failure: %s", (d)->poison_msg.c_str()); \
   HIPCHK(hipSetDevice((d)->shard->device))
+
+// run a planned batch; on failure the handle is poisoned (see qip_hip_dist::poisoned)
+static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps);
+static int dist_run_or_poison(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
+  const int rc = dist_run_steps(d, steps);
+  if (rc != QIP_OK) {
+    d->poisoned = true;
+    d->poison_msg = g_last_error;
+  }
+  return rc;
+}
 
 extern "C" int qip_hip_dist_unique_id(void* id_out) try {
   if (!id_out) return fail(QIP_ERR_INVALID, "null output");
@@ -760,9 +811,27 @@ extern "C" int qip_hip_dist_create(uint32_t n, int dtype, int device, int rank, 
     d->transport.all_to_all = qipd::rccl_all_to_all;
     d->transport.all_reduce_sum = qipd::rccl_all_reduce;
   }
+  if (world > 1) {
+    // every remap goes through the second 2^L buffer: get it now, so that a state too large for two buffers fails here and
+    // not in the middle of a circuit, after local ops have already changed the shard
+    const int rc = ensure_alt(d->shard);
+    if (rc != QIP_OK) return bail(rc);
+  }
   *out = d.release();
   return QIP_OK;
 } QIP_CATCH_ALL
+
+extern "C" int64_t qip_hip_dist_debug_pieces(int rank, int world, uint64_t chunk_bytes, uint64_t piece_bytes, uint64_t cap, int32_t* peer,
+                                             uint64_t* offset, uint64_t* length) try {
+  if (world < 1 || rank < 0 || rank >= world) return fail(QIP_ERR_INVALID, "rank %d of %d", rank, world) < 0 ? -1 : -1;
+  const std::vector<qipd::Piece> ps = qipd::plan_pieces(rank, world, chunk_bytes, piece_bytes);
+  for (uint64_t i = 0; i < ps.size() && i < cap; ++i) {
+    if (peer) peer[i] = ps[i].peer;
+    if (offset) offset[i] = ps[i].offset;
+    if (length) length[i] = ps[i].length;
+  }
+  return (int64_t)ps.size();
+} catch (...) { return -1; }
 
 extern "C" int qip_hip_dist_local_state(qip_hip_dist* d, qip_hip_state** shard) try {
   if (!d || !shard) return fail(QIP_ERR_INVALID, "null argument");
@@ -784,6 +853,11 @@ extern "C" int qip_hip_dist_rank_flip(qip_hip_dist* d, uint32_t* mask) try {
 
 extern "C" int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value) try {
   if (!d) return fail(QIP_ERR_INVALID, "null dist handle");
+  if (key && !strcmp(key, "piece_bytes")) {  // largest single ncclSend / ncclRecv of the built-in transport
+    if (value < 16 || (value & 15)) return fail(QIP_ERR_INVALID, "piece_bytes must be a positive multiple of 16");
+    if (d->rccl) d->rccl->piece_bytes = (uint64_t)value;
+    return QIP_OK;
+  }
   return qip_hip_state_set_option(d->shard, key, value);
 } QIP_CATCH_ALL
 
@@ -797,6 +871,20 @@ extern "C" int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out)
   if (!out) return fail(QIP_ERR_INVALID, "null output");
   QCHK(dist_drain_events(d));
   *out = d->stats;
+  out->rccl_ranks = 0;
+  out->rccl_rank = -1;
+  out->piece_bytes = 0;
+  if (d->rccl) {
+    // read back from the communicator itself, not from what the caller passed to qip_hip_dist_create
+    int cnt = 0, ur = -1;
+    NCHK(qipd::g_rccl.CommCount(d->rccl->comm, &cnt));
+    NCHK(qipd::g_rccl.CommUserRank(d->rccl->comm, &ur));
+    out->rccl_ranks = cnt;
+    out->rccl_rank = ur;
+    out->pieces_sent = d->rccl->pieces_sent;
+    out->piece_bytes = d->rccl->piece_bytes;
+    d->rccl->pieces_sent = 0;
+  }
   d->stats = qip_hip_dist_stats{};
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -822,7 +910,7 @@ extern "C" int qip_hip_dist_apply_ops(qip_hip_dist* d, const qip_op* ops, uint64
   qipd::DistPlanner trial = d->pl;  // the layout only advances if planning succeeds
   QCHK(trial.plan(ops, count, &steps));
   d->pl = trial;
-  return dist_run_steps(d, steps);
+  return dist_run_or_poison(d, steps);
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op) try {
@@ -833,7 +921,7 @@ extern "C" int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op) try {
   qipd::DistPlanner trial = d->pl;
   QCHK(trial.step(info, nullptr, &steps));
   d->pl = trial;
-  return dist_run_steps(d, steps);
+  return dist_run_or_poison(d, steps);
 } QIP_CATCH_ALL
 
 static int dist_all_reduce(qip_hip_dist* d, double* v, uint64_t count) {

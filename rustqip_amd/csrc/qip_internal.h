@@ -173,6 +173,8 @@ int ensure_arena(qip_hip_state* s, size_t bytes);
 int ensure_partial(qip_hip_state* s, size_t count);
 int ensure_alt(qip_hip_state* s);
 void programs_orphan(qip_hip_state* s);  // qip_circuit.hip
+int jit_set_cache_cap(int64_t cap);      // qip_circuit.hip (global option "jit_cache_cap")
+uint64_t jit_cache_generation();
 int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r);
 int prof_end(qip_hip_state* s, ProfRec* r);
 

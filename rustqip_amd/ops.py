@@ -258,7 +258,7 @@ TILE_LANE_BITS = TILE_BITS - 3                 # thread-id bits of a tile block 
 
 def tile_lane_assignment(pass_bits, dtype: int = _ffi.QIP_C64):
     """Host-only: for one pass of a tile sweep (its three exchange bits, tile-index space, ascending), the
-    tile-index bit each of the 9 thread-id bits fills (qip_hip_tile_lane_assignment)."""
+    tile-index bit each of the 8 thread-id bits fills (qip_hip_tile_lane_assignment)."""
     pb = (C.c_uint32 * 3)(*pass_bits)
     out = C.c_uint64()
     rc = _ffi.lib.qip_hip_tile_lane_assignment(dtype, pb, C.byref(out))

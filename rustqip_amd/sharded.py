@@ -37,10 +37,16 @@ class HostStagedTransport:
     (gloo) and copies the result back.  Only for exercising the N > 1 path where RCCL cannot run (two ranks on one
     device); the product transport is the library's built-in RCCL one."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, piece_bytes: Optional[int] = None):
         import torch
 
         self.dist, self.torch = dist, torch
+        # None: one all_to_all_single over whole chunks.  A number: the exchange walks the SAME piece list the built-in RCCL
+        # transport walks inside its ncclGroupStart / ncclGroupEnd (qip_hip_dist_debug_pieces: every peer in rank order, each
+        # chunk in pieces of at most piece_bytes) with one send + one receive per piece, so that loop — which only triggers
+        # for >= 2-GiB chunks on real hardware — is exercised at small scale
+        self.piece_bytes = piece_bytes
+        self.pieces_moved = 0
         self._hip = C.CDLL("libamdhip64.so")
         self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -58,12 +64,19 @@ class HostStagedTransport:
                 return 1
             if self._hip.hipMemcpy(C.c_void_p(h_send.data_ptr()), C.c_void_p(send), nbytes, 2) != 0:  # device -> host
                 return 1
-            self.dist.all_to_all_single(h_recv, h_send)
+            if self.piece_bytes is None:
+                self.dist.all_to_all_single(h_recv, h_send)
+            else:
+                self._exchange_in_pieces(h_send, h_recv, int(chunk_bytes))
             if self._hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(h_recv.data_ptr()), nbytes, 1) != 0:  # host -> device
                 return 1
             return 0
         except Exception:  # noqa: BLE001  (nothing may propagate through the C frame)
             return 1
+
+    def _exchange_in_pieces(self, h_send, h_recv, chunk: int) -> None:
+        exchange_in_pieces(self.dist, h_send, h_recv, chunk, self.piece_bytes)
+        self.pieces_moved += len(piece_list(self.dist.get_rank(), self.dist.get_world_size(), chunk, self.piece_bytes))
 
     def _all_reduce(self, ctx, values, count):
         try:
@@ -74,6 +87,31 @@ class HostStagedTransport:
             return 0
         except Exception:  # noqa: BLE001
             return 1
+
+
+def piece_list(rank: int, world: int, chunk_bytes: int, piece_bytes: int):
+    """[(peer, offset, length)]: the library's piece plan for one rank's all-to-all (qip_hip_dist_debug_pieces)"""
+    n = int(_ffi.lib.qip_hip_dist_debug_pieces(rank, world, chunk_bytes, piece_bytes, 0, None, None, None))
+    if n < 0:
+        raise CircuitError(_ffi.last_error())
+    peer, off, ln = (C.c_int32 * n)(), (C.c_uint64 * n)(), (C.c_uint64 * n)()
+    _ffi.lib.qip_hip_dist_debug_pieces(rank, world, chunk_bytes, piece_bytes, n, peer, off, ln)
+    return [(int(peer[i]), int(off[i]), int(ln[i])) for i in range(n)]
+
+
+def exchange_in_pieces(dist, h_send, h_recv, chunk: int, piece_bytes: int) -> None:
+    """all-to-all of `chunk`-byte chunks between host tensors, piece by piece in the library's order: one send + one
+    receive per piece, all posted before any is waited for (what the RCCL group does on the device)"""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    h_recv[rank * chunk:(rank + 1) * chunk] = h_send[rank * chunk:(rank + 1) * chunk]
+    ops = []
+    for peer, off, ln in piece_list(rank, world, chunk, piece_bytes):
+        a = peer * chunk + off
+        ops.append(dist.P2POp(dist.isend, h_send[a:a + ln], peer))
+        ops.append(dist.P2POp(dist.irecv, h_recv[a:a + ln], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
 
 def _broadcast_unique_id(dist, rank: int) -> bytes:
@@ -91,7 +129,8 @@ def _broadcast_unique_id(dist, rank: int) -> bytes:
 class DistState:
     """qip_hip_dist: the n-qubit state over dist.get_world_size() ranks (one process per GPU)."""
 
-    def __init__(self, n: int, dist, device: int = 0, dtype=np.complex128, host_staged: bool = False):
+    def __init__(self, n: int, dist, device: int = 0, dtype=np.complex128, host_staged: bool = False,
+                 piece_bytes: Optional[int] = None):
         self.n, self.dist = int(n), dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.g = int(math.log2(self.world))
@@ -101,13 +140,15 @@ class DistState:
         self.np_dtype = np.dtype(dtype)
         self.dtype = _ffi.QIP_C64 if self.np_dtype == np.complex128 else _ffi.QIP_C32
         self._h = C.c_void_p()
-        self._transport = HostStagedTransport(dist) if host_staged else None
+        self._transport = HostStagedTransport(dist, piece_bytes) if host_staged else None
         if host_staged:
             _check(_ffi.lib.qip_hip_dist_create(self.n, self.dtype, device, self.rank, self.world, None,
                                                 C.byref(self._transport.struct), C.byref(self._h)))
         else:
             uid = _broadcast_unique_id(dist, self.rank)
             _check(_ffi.lib.qip_hip_dist_create(self.n, self.dtype, device, self.rank, self.world, uid, None, C.byref(self._h)))
+            if piece_bytes is not None:
+                _check(_ffi.lib.qip_hip_dist_set_option(self._h, b"piece_bytes", int(piece_bytes)))
         sh = C.c_void_p()
         _check(_ffi.lib.qip_hip_dist_local_state(self._h, C.byref(sh)))
         self.shard = HipState.from_handle(sh, self.L, dtype)  # this rank's 2^L amplitudes (owned by the dist handle)
@@ -205,7 +246,10 @@ class DistState:
         st = _ffi.QipDistStats()
         _check(_ffi.lib.qip_hip_dist_take_stats(self._h, C.byref(st)))
         return {"remaps": int(st.remaps), "pack_sweeps": int(st.pack_sweeps), "bytes_sent_per_rank": int(st.bytes_sent),
-                "exchange_ms": st.exchange_ms, "pack_ms": st.pack_ms}
+                "exchange_ms": st.exchange_ms, "pack_ms": st.pack_ms,
+                # read back from the communicator (ncclCommCount / ncclCommUserRank); 0 / -1 with caller-supplied callbacks
+                "rccl_ranks": int(st.rccl_ranks), "rccl_rank": int(st.rccl_rank),
+                "pieces_sent": int(st.pieces_sent), "piece_bytes": int(st.piece_bytes)}
 
     def set_profile(self, v: int) -> None:
         self.shard.set_option("profile", int(v))

@@ -95,6 +95,18 @@ def all_to_all(send):
     return t_recv.numpy().view(np.complex128)
 
 
+def all_to_all_in_pieces(send):
+    """the same exchange through the library's piece list (qip_hip_dist_debug_pieces): what the built-in RCCL transport
+    walks inside its send / receive group, here with ragged pieces of about a third of a chunk over gloo"""
+    world = dist.get_world_size()
+    t_send = torch.from_numpy(np.ascontiguousarray(send).view(np.uint8))
+    t_recv = torch.empty_like(t_send)
+    chunk = t_send.numel() // world
+    piece = max(16, (chunk // 3) // 16 * 16)
+    sharded.exchange_in_pieces(dist, t_send, t_recv, chunk, piece)
+    return t_recv.numpy().view(np.complex128)
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -112,7 +124,7 @@ def main():
             plan = sharded.debug_plan(n, rank, world, ops)
             assert (plan["g"], plan["L"], plan["rank"]) == (g, L, rank)
             shard = x[rank << L:(rank + 1) << L].copy()  # a fresh state: logical = physical
-            shard = sharded.replay_plan(plan, shard, apply_local, all_to_all)
+            shard = sharded.replay_plan(plan, shard, apply_local, all_to_all_in_pieces if name in ("qft", "mixed", "grover_k3") else all_to_all)
             idx = sharded.shard_logical_indices(n, L, rank, plan["phys"], plan["flip"]).astype(np.int64)
             parts = [None] * world
             dist.all_gather_object(parts, (idx, shard, [(s["t"], s.get("sel")) for s in plan["steps"] if s["t"] != "local"], plan["phys"]))

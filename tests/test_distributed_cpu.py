@@ -61,3 +61,25 @@ def test_pack_bits_model_and_invalid_worlds():
         sharded.debug_plan(6, 0, 3, [q.make_matrix_op([0], circuits.H)])
     with pytest.raises(q.CircuitError):
         sharded.debug_plan(3, 0, 4, [q.make_matrix_op([0], circuits.H)])
+
+
+def test_piece_plan_of_the_exchange():
+    """qip_hip_dist_debug_pieces — the list the built-in RCCL transport walks inside one send / receive group: every peer,
+    every byte of every chunk exactly once, no piece above the limit, pieces of one peer in offset order, and the list of
+    rank r towards peer p mirrors the list of p towards r (sends meet their receives in order).  At bench size: a 16-GiB
+    shard over 8 ranks has 2-GiB chunks = two 1-GiB pieces per peer."""
+    for world, chunk, piece in ((2, 96, 32), (4, 1000 * 16, 48 * 16), (8, 1 << 31, 1 << 30), (8, 5 * 16, 1 << 30), (4, 64, 16)):
+        lists = [sharded.piece_list(r, world, chunk, piece) for r in range(world)]
+        for r, ps in enumerate(lists):
+            assert all(p != r and 0 < ln <= piece for p, _, ln in ps)
+            for p in range(world):
+                mine = [(off, ln) for pp, off, ln in ps if pp == p]
+                if p == r:
+                    assert not mine
+                    continue
+                assert [off for off, _ in mine] == sorted(off for off, _ in mine)
+                assert sum(ln for _, ln in mine) == chunk and mine[0][0] == 0
+                assert all(a[0] + a[1] == b[0] for a, b in zip(mine, mine[1:]))
+                assert mine == [(off, ln) for pp, off, ln in lists[p] if pp == r]
+    assert len(sharded.piece_list(3, 8, 1 << 31, 1 << 30)) == 14
+    assert sharded.piece_list(0, 1, 1 << 20, 1 << 10) == []

@@ -1876,7 +1876,7 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
 
     ops0, vecs = W.product_state_ops(n, seed=n)
     c2s = circuits.c2_random_circuit(n, 16, seed=28, single_only=True)
-    c2 = circuits.c2_random_circuit(n, 160, seed=29)
+    c2 = circuits.c2_random_circuit(n, 5 * 24, seed=29)
     with q.HipState(n) as st:
         st.init_basis(0)
         st.apply_ops(ops0)
@@ -1903,15 +1903,15 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
                 twin.resync()
             return r
 
-        leg(c2[:32], True, tile=1)
-        leg(c2[32:64], True, tile=1, tile_jit=1)
-        leg(c2[64:96], True, tile=1, tile_jit=1, tile_relabel=2)
-        leg(c2[96:128], False, tile=2, tile_jit=1)
-        leg(c2[128:160], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
-        leg(circuits.c2_random_circuit(n, 32, seed=31), False, fuse=5)
-        r = leg(circuits.c3_qft(n), True, max_len=160, tile=1, tile_jit=1)
-        assert r["steps"] <= 16  # chunks as large as the timed segments (5-6 H and their controlled phases each)
-        leg(circuits.c4_clifford_t(n, 96, seed=32), True, tile=1, tile_jit=1)
-        leg(circuits.c5_grover_iteration(n), True, max_len=96, tile=1, tile_jit=1)
+        leg(c2[:24], True, tile=1)
+        leg(c2[24:48], True, tile=1, tile_jit=1)
+        leg(c2[48:72], True, tile=1, tile_jit=1, tile_relabel=2)
+        leg(c2[72:96], False, tile=2, tile_jit=1)
+        leg(c2[96:120], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c2_random_circuit(n, 24, seed=31), False, fuse=5)
+        r = leg(circuits.c3_qft(n)[:170], True, max_len=160, tile=1, tile_jit=1)  # the first 7 H with all their controlled phases
+        assert r["steps"] <= 3  # chunks as large as the timed segments (5-6 H and their controlled phases each)
+        leg(circuits.c4_clifford_t(n, 48, seed=32), True, tile=1, tile_jit=1)
+        leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
         twin.close()
         assert abs(st.norm_sqr() - 1) < 1e-9

@@ -91,6 +91,10 @@ def main():
             traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib": f, "write_size_kib": w, "launches": len(fetch.get(k, []))}
     open(os.path.join(prof, f"{tag}_pmc_traffic.md"), "w").write("\n".join(lines) + "\n")
     traffic["_source"] = f"profiles/{tag}_pmc_traffic.md"
+    # which kernels these figures describe: bench.py flags `traffic` as stale when csrc/qip_kernels.h has changed since
+    import hashlib
+
+    traffic["_kernels_sha16"] = hashlib.sha256(open(os.path.join(ROOT, "rustqip_amd", "csrc", "qip_kernels.h"), "rb").read()).hexdigest()[:16]
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
