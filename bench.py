@@ -124,19 +124,34 @@ def median_time(fn, sync, reps=REPS):
 
 
 def cpu_baseline(q, circuits, args):
-    """Time the oracle on a bounded sample of the same workload: the first 16 gates of the same seeded single-qubit
-    circuit at the largest n <= 28 whose 5 repetitions fit the budget; median of the repetitions."""
+    """Time the oracle on a bounded sample of the same workload at n = 28: the first gates of the same
+    seeded single-qubit circuit, as many as fit the budget (>= 4), median of 3 repetitions, all usable cores; plus the same
+    loop on ONE thread at n = 22, so that the scaling over threads is visible.  Both buffers are first touched inside the
+    OpenMP region (two untimed gates write them in parallel with the static split the timed gates use)."""
     import numpy as np
 
     from oracle import qip_oracle as O
 
-    threads = O.max_threads()
+    omp_threads = O.max_threads()
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # "max 100000" or "<quota> <period>"
+            qv, per = f.read().split()
+            quota = None if qv == "max" else float(qv) / float(per)
+    except Exception:
+        pass
+    threads = max(1, min(omp_threads, usable, int(quota) if quota and quota >= 1 else omp_threads))
 
-    def run(n, ops, reps):
+    def run(n, ops, reps, nthreads):
+        O.set_num_threads(nthreads)
         state = np.zeros(1 << n, dtype=np.complex128)
         state[0] = 1
-        arena = np.zeros_like(state)  # touch both buffers before timing
-        for op in circuits.h_layer(n)[:2]:
+        arena = np.zeros_like(state)
+        for op in circuits.h_layer(n)[:2]:  # first touch of both buffers, in parallel
             O.apply_op_overwrite(n, op, state, arena)
             state, arena = arena, state
         ts = []
@@ -148,21 +163,34 @@ def cpu_baseline(q, circuits, args):
             ts.append(time.perf_counter() - t0)
         return ts
 
-    n_cal, n_gates = 22, 16
-    t_cal = statistics.median(run(n_cal, circuits.c2_random_circuit(n_cal, n_gates, seed=28, single_only=True), 3))
-    n_cpu = n_cal
-    while n_cpu < 28 and t_cal * (2 ** (n_cpu + 1 - n_cal)) * REPS <= args.cpu_budget_s:
-        n_cpu += 1
+    reps = 3
+    n_cal = 22
+    t_cal = statistics.median(run(n_cal, circuits.c2_random_circuit(n_cal, 4, seed=28, single_only=True), 2, threads)) / 4
+    n_cpu = 28
+    per_gate = t_cal * 2 ** (n_cpu - n_cal)
+    n_gates = int(max(4, min(16, args.cpu_budget_s / (reps * per_gate))))
     ops = circuits.c2_random_circuit(n_cpu, n_gates, seed=28, single_only=True)
-    ts = run(n_cpu, ops, REPS)
+    ts = run(n_cpu, ops, reps, threads)
     t = statistics.median(ts)
     by = circuit_bytes(q, n_cpu, ops)
+    # one thread, a 64x smaller vector, two gates
+    n_one = 22
+    ops1 = circuits.c2_random_circuit(n_one, 2, seed=28, single_only=True)
+    t1 = statistics.median(run(n_one, ops1, 2, 1))
+    O.set_num_threads(omp_threads)
+    ns_row_all = 1e9 * t / n_gates / 2 ** n_cpu * threads
+    ns_row_one = 1e9 * t1 / len(ops1) / 2 ** n_one
     return {
         "value": by / t / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+        "cores_usable": usable, "omp_max_threads": omp_threads, "cgroup_cpu_quota": quota,
         "gates_per_s": n_gates / t, "ms_per_gate": 1e3 * t / n_gates, "reps_s": [round(x, 3) for x in ts],
+        "ns_per_row_per_thread": ns_row_all,
+        "one_thread": {"n": n_one, "ms_per_gate": 1e3 * t1 / len(ops1), "ns_per_row": ns_row_one, "GBps": 32.0 * 2 ** n_one / (t1 / len(ops1)) / 1e9},
+        "thread_scaling_efficiency": ns_row_one / ns_row_all if ns_row_all > 0 else None,
         "sample": f"first {n_gates} gates of the same seeded single-qubit circuit at n={n_cpu} (2 buffers x {16 * 2**n_cpu / 2**30:.2f} GiB), "
-                  f"C restatement of qip-iterators 1.5.0 apply_op_overwrite, gcc -O3 -fopenmp, {threads} threads, "
-                  f"median of {REPS} repetitions ({sum(ts):.1f} s of CPU work)",
+                  f"C restatement of qip-iterators 1.5.0 apply_op_overwrite, gcc -O3 -fopenmp, {threads} threads "
+                  f"({usable} usable cores, cgroup quota {quota}), median of {reps} repetitions ({sum(ts):.1f} s of CPU work); "
+                  f"one-thread figure: 2 gates at n={n_one}",
     }
 
 

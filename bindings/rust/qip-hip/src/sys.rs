@@ -162,6 +162,7 @@ extern "C" {
         d: *mut qip_hip_dist, indices: *const u64, k: u32, forced: i64, rand_u01: c_double,
         measured: *mut u64, prob: *mut c_double,
     ) -> c_int;
+    pub fn qip_hip_dist_soft_measure(d: *mut qip_hip_dist, indices: *const u64, k: u32, rand_u01: c_double, measured: *mut u64) -> c_int;
     pub fn qip_hip_dist_local_state(d: *mut qip_hip_dist, shard: *mut *mut qip_hip_state) -> c_int;
     pub fn qip_hip_dist_layout(d: *mut qip_hip_dist, phys: *mut u32) -> c_int;
     pub fn qip_hip_dist_rank_flip(d: *mut qip_hip_dist, mask: *mut u32) -> c_int;

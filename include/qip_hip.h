@@ -269,7 +269,12 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    in a segment in one plan and runs alone on the matrix cores in the other likewise differs by rounding).
  *                    The plan is only used when it is shorter than the plain
  *                    one (random circuits: 19 -> 14 sweeps for configs[1]; layered ones like QFT / Grover keep the plain
- *                    plan).  2 = use it unconditionally (tests).  0 (default) = off.  Needs the scratch buffer.
+ *                    plan).  2 = use it unconditionally (tests).  3 = as 1, and the layout PERSISTS across apply_ops calls: a
+ *                    batch starts from the layout the previous one left and does not pay the restoring sweep; the caller's
+ *                    order is restored (one sweep) by the first call that needs it — download / upload / measurement /
+ *                    device_ptr / a batch without relabelling / a program capture.  A circuit applied in chunks (a
+ *                    variational loop, a host that streams its ops) then costs what it costs in one piece.
+ *                    0 (default) = off.  Needs the scratch buffer.
  *   "tile_fma"       1: run-time-compiled segments of "tile" = 2 are compiled with multiply-add contraction (v_fma_f64: a complex
  *                    product is 4 instead of 6 vector instructions; QFT at n = 30: 57 -> 50 ms).  Ignored for "tile" = 1, which
  *                    promises IEEE equality with the gate-by-gate path.  0 (default) = off.
@@ -389,6 +394,10 @@ int qip_hip_dist_norm_sqr(qip_hip_dist* d, double* out);
 int qip_hip_dist_measure_probs(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double* out);
 int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, int64_t forced, double rand_u01,
                          uint64_t* measured, double* prob);
+/* (ABI 4) the sampling step alone, without the collapse: soft_measure (:153-176) of the sharded state.  How often the
+ * descent and the reference's sequential scan disagree is measured, not assumed: tests/dist_worker_gpu.py sweeps 2000
+ * samples per layout against the oracle (0 disagreements; a disagreement needs the sample within ~1e-16 of a boundary). */
+int qip_hip_dist_soft_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double rand_u01, uint64_t* measured);
 
 /* The shard's own handle (upload / download / profile of this rank's 2^(n-g) amplitudes; owned by `d`), and the
  * current layout: phys[p] = physical bit position of logical bit position p (= n-1-qubit), n entries; physical

@@ -124,3 +124,5 @@ uint64_t qip_oracle_sub_to_full(uint32_t n, const uint64_t* mat_indices, uint32_
 #undef SQRT
 
 int qip_oracle_max_threads(void) { return omp_get_max_threads(); }
+/* the CPU-baseline leg times the same loop with 1 thread and with all of them (bench.py) */
+void qip_oracle_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }

@@ -121,6 +121,11 @@ def sub_to_full(n, mat_indices, sub_index, base): return int(_lib.qip_oracle_sub
 def max_threads(): return int(_lib.qip_oracle_max_threads())
 
 
+def set_num_threads(n: int) -> None:
+    """OpenMP threads of the following oracle calls (bench.py's CPU baseline times 1 thread and all threads)"""
+    _lib.qip_oracle_set_num_threads(int(n))
+
+
 # ---- the kernel ------------------------------------------------------------------------
 def apply_op(n: int, op: MatrixOp, input: np.ndarray, output: np.ndarray, input_offset: int = 0,
              output_offset: int = 0, *, accumulate: bool = True, nthreads: int = 0) -> None:

@@ -120,6 +120,7 @@ SIGNATURES = {
     "qip_hip_dist_local_state": (_int, [_vp, C.POINTER(_vp)]),
     "qip_hip_dist_layout": (_int, [_vp, C.POINTER(C.c_uint32)]),
     "qip_hip_dist_rank_flip": (_int, [_vp, C.POINTER(C.c_uint32)]),
+    "qip_hip_dist_soft_measure": (_int, [_vp, _u64p, _u32, _dbl, _u64p]),
     "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
     "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
     "qip_hip_dist_debug_pieces": (_i64, [_int, _int, _u64, _u64, _u64, C.POINTER(C.c_int32), _u64p, _u64p]),

@@ -344,17 +344,34 @@ template <typename T> static std::string fnum(T v) {
 }
 
 // The segment as HIP source (see the block comment above).  Mirrors k_tile_passes statement by statement.
-// `pipe` (option "tile_pipe"): 0 = one block per tile, as k_tile_passes; 1 = persistent blocks that walk the tiles with a
-// stride of the grid and keep the NEXT tile's eight loads in flight (in registers) across the passes of the current one:
-// the block-per-tile form has loads in flight only while a block sits in its load phase, so a CU's five resident tiles
-// leave HBM idle whenever most of them compute; here every resident block always has 32 KiB of loads under way.
+// (Measured in round 3 and NOT adopted: persistent blocks that prefetch the next tile — into registers, or by LDS-DMA into a
+// second tile slot.  The skeleton of a sweep already overlaps its phases through the five resident blocks per CU: with the
+// passes' arithmetic scaled from 0 to 6000 f64 operations per lane the time is max(HBM time, issue time) + ~1 ms, and a
+// light sweep's time is set by which five high positions the tile holds (5.2 - 6.7 ms), not by the block structure;
+// tools/tune_tile.hip, profiles/r03_tile_skeleton.md.)
+//
+// `params` (option "tile_jit" = 2): the segment's STRUCTURE is compiled, its numbers are kernel data.  Every matrix component
+// that is not exactly 0 or +-1 becomes a read of P[k] (a wave-uniform scalar load from the device arena) and its value goes
+// to `params`; zeros and units stay literals, and the flags the host derives from them (non-zero mask, real / X shapes) stay
+// constants, so the same folding happens and the arithmetic per amplitude is unchanged: bit-identical to "tile_jit" = 1.
+// A variational loop that updates its rotation angles produces the same source every time and re-uses the compiled kernel;
+// only a value that newly becomes (or stops being) 0 / +-1 changes the structure and compiles again.
 template <typename T>
-static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int pipe, int remap = 0) {
+static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int remap = 0, std::vector<T>* params = nullptr) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   std::string o;
   auto L = [&](const std::string& line) { o += line; o += "\n"; };
   auto U = [](uint64_t v) { return std::to_string(v) + "ull"; };
-  auto amp = [&](amp_t<T> a) { return "{" + fnum<T>(a.x) + ", " + fnum<T>(a.y) + "}"; };
+  auto comp = [&](T v) -> std::string {
+    if (!params || v == (T)0 || v == (T)1 || v == (T)-1) return fnum<T>(v);  // (a -0 prints as -0.0 and stays one)
+    params->push_back(v);
+    return "P[" + std::to_string(params->size() - 1) + "]";
+  };
+  auto amp = [&](amp_t<T> a) {
+    const std::string re = comp(a.x);  // fixed evaluation order: the parameter numbering is part of the source
+    const std::string im = comp(a.y);
+    return "{" + re + ", " + im + "}";
+  };
   const TilePassDesc& d = plan.pd;
   L("#include \"qip_kernels.h\"");
   L("using namespace qipk;");
@@ -370,7 +387,8 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   if (ins.ormask) L("  w |= " + U(ins.ormask) + ";");
   L("  return w;");
   L("}");
-  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, ") + (pipe ? "4" : "5") + ") void qip_segment(A* __restrict__ st, uint64_t ntiles) {");
+  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
+    (params ? ", const T* __restrict__ P" : "") + ") {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
   L("  A* tile = reinterpret_cast<A*>(tile_raw);");
   L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
@@ -387,39 +405,17 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     return U(off);
   };
   L("  A x[8];");
-  if (pipe) {
-    L("  uint64_t t = blockIdx.x;");
-    L("  uint64_t base = tile_base(t), wbase = base | wave_off;");
-  } else {
-    L("  (void)ntiles;");
-    L("  uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;");
-    // consecutive blocks land on consecutive XCDs: with remap r the 2^r blocks one XCD receives in a row take ADJACENT tiles
-    if (remap == 2) L("  blk = (blk & ~31ull) | ((blk & 7ull) << 2) | ((blk >> 3) & 3ull);");
-    if (remap == 3) L("  blk = (blk & ~63ull) | ((blk & 7ull) << 3) | ((blk >> 3) & 7ull);");
-    L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
-  }
+  L("  (void)ntiles;");
+  L("  uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;");
+  // (tuning aid, global option "tile_remap": the 2^r blocks one XCD receives in a row take ADJACENT tiles; measured slower)
+  if (remap == 2) L("  blk = (blk & ~31ull) | ((blk & 7ull) << 2) | ((blk >> 3) & 3ull);");
+  if (remap == 3) L("  blk = (blk & ~63ull) | ((blk & 7ull) << 3) | ((blk >> 3) & 7ull);");
+  L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
   for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
-  if (pipe) {
-    L("  for (;;) {");
-    // everything a gate derives from the lane id alone (bit tests, per-lane factors) is loop-invariant: hoisted out of the
-    // tile loop it would pin hundreds of registers; an opaque copy of the id keeps those values where they are used
-    L("  uint32_t tidv = tid;");
-    L("  asm volatile(\"\" : \"+v\"(tidv));");
-  } else {
-    L("  const uint32_t tidv = tid;");
-  }
+  L("  const uint32_t tidv = tid;");
   for (int u = 0; u < 8; ++u)
     L("    tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)] = x[" + std::to_string(u) + "];");
   L("  __syncthreads();");
-  if (pipe) {
-    // the next tile's loads go out now and land while this tile's passes run (x is dead until the next LDS write)
-    L("  const uint64_t tn = t + gridDim.x;");
-    L("  const bool more = tn < ntiles;");
-    L("  const uint64_t base_n = tile_base(tn), wbase_n = base_n | wave_off;");
-    L("  if (more) {");
-    for (int u = 0; u < 8; ++u) L("    x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase_n | " + ub(u) + ") + lane);");
-    L("  }");
-  }
   for (uint32_t pi = 0; pi < d.npasses; ++pi) {
     const TilePass& ps = d.pass[pi];
     L("  {  // pass " + std::to_string(pi));
@@ -438,16 +434,26 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
       const TileGate<T>& g = plan.gates[gi];
       L("    {  // gate " + std::to_string(gi));
-      L("      constexpr TileGate<T> g = {" + std::to_string(g.kind) + "u, " + std::to_string(g.b0) + "u, " + std::to_string(g.b1) + "u, " +
-        std::to_string(g.cmask) + "u, " + std::to_string(g.nz) + "u, " + std::to_string(g.tpos_out) + "u, " + U(g.omask) + ", " +
-        std::to_string(g.op) + "u, " + std::to_string(g.cm_reg) + "u, " + std::to_string(g.cm_lane) + "u, 0u, {" + amp(g.m[0]) + ", " +
-        amp(g.m[1]) + ", " + amp(g.m[2]) + ", " + amp(g.m[3]) + "}};");
+      {
+        const std::string m0 = amp(g.m[0]), m1 = amp(g.m[1]), m2 = amp(g.m[2]), m3 = amp(g.m[3]);
+        L(std::string("      ") + (params ? "const" : "constexpr") + " TileGate<T> g = {" + std::to_string(g.kind) + "u, " + std::to_string(g.b0) + "u, " +
+          std::to_string(g.b1) + "u, " + std::to_string(g.cmask) + "u, " + std::to_string(g.nz) + "u, " + std::to_string(g.tpos_out) + "u, " + U(g.omask) +
+          ", " + std::to_string(g.op) + "u, " + std::to_string(g.cm_reg) + "u, " + std::to_string(g.cm_lane) + "u, 0u, {" + m0 + ", " + m1 + ", " + m2 +
+          ", " + m3 + "}};");
+      }
       const std::string lane_args = "g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane";
       std::string call;
       switch (g.op) {
-        case TOP_DIAG_UNIFORM:
-          call = "const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0]; if (!(f.x == (T)1 && f.y == (T)0)) pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+        // Diagonal gates: which entries are the unit is known HERE (a unit is always written as a literal, also in the
+        // parametrised form), so the helpers' run-time "unit entries leave the amplitude untouched" tests are resolved by
+        // the generator: an entry that is the unit emits nothing.  Per amplitude the products are those of pass_diag / the
+        // interpreter's switch, in the same order.
+        case TOP_DIAG_UNIFORM: {
+          const bool u0 = g.m[0].x == (T)1 && g.m[0].y == (T)0, u1 = g.m[1].x == (T)1 && g.m[1].y == (T)0;
+          const std::string s0 = u0 ? "" : "pass_scale<T, 0, -1>(g.m[0], e, c, g.cm_reg);", s1 = u1 ? "" : "pass_scale<T, 0, -1>(g.m[1], e, c, g.cm_reg);";
+          call = "if ((base >> g.tpos_out) & 1ull) { " + s1 + " } else { " + s0 + " }";
           break;
+        }
         case TOP_DIAG_LANE:
         case TOP_DIAG_LANE_CTL:
           call = std::string("const bool one = ") + (g.b0 == kTileOutside ? "((base >> g.tpos_out) & 1ull) != 0" : "((tb >> g.b0) & 1u) != 0") +
@@ -455,9 +461,18 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
                  (g.op == TOP_DIAG_LANE_CTL ? "{ const bool lane_ok = (tb & g.cm_lane) == g.cm_lane; f.x = lane_ok ? f.x : (T)1; f.y = lane_ok ? f.y : (T)0; } " : "") +
                  "pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
           break;
-        case TOP_DIAG_REG0: case TOP_DIAG_REG1: case TOP_DIAG_REG2:
-          call = "pass_diag<T, " + std::to_string(g.op - TOP_DIAG_REG0) + ">(g, e, c, g.cm_reg, " + lane_args + ");";
+        case TOP_DIAG_REG0: case TOP_DIAG_REG1: case TOP_DIAG_REG2: {
+          const std::string J = std::to_string(g.op - TOP_DIAG_REG0);
+          call.clear();
+          for (int half = 0; half < 2; ++half) {
+            if (g.m[half].x == (T)1 && g.m[half].y == (T)0) continue;
+            const std::string hs = std::to_string(half);
+            call += "{ A f = g.m[" + hs + "]; ";
+            if (g.cm_lane) call += "{ const bool lane_ok = (tb & g.cm_lane) == g.cm_lane; f.x = lane_ok ? f.x : (T)1; f.y = lane_ok ? f.y : (T)0; } ";
+            call += "pass_scale<T, " + J + ", " + hs + ">(f, e, c, g.cm_reg); } ";
+          }
           break;
+        }
         case TOP_DENSE0: case TOP_DENSE1: case TOP_DENSE2:
           call = "pass_dense<T, " + std::to_string(g.op - TOP_DENSE0) + ">(g, e, c, g.cm_reg);";
           break;
@@ -494,12 +509,6 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   }
   for (int u = 0; u < 8; ++u)
     L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
-  if (pipe) {
-    L("  if (!more) break;");
-    L("  __syncthreads();  // every lane has read its share of this tile before the next one overwrites it");
-    L("  t = tn; base = base_n; wbase = wbase_n;");
-    L("  }");
-  }
   L("}");
   return o;
 }
@@ -571,16 +580,19 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   if (s->tile_passes && s->tile_jit) {
     // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
     hipFunction_t fn = nullptr;
-    const int pipe = s->tile_pipe ? 1 : 0;
     const bool fma = s->tile_fma && s->tile >= 2;  // tile = 1 promises IEEE equality with the gate-by-gate path: never fused
-    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), pipe, (ntiles % 64 == 0 && !pipe) ? (int)g_tile_remap : 0), fma, &fn));
+    const bool parametrised = s->tile_jit >= 2;     // structure compiled, numbers in the arena (see tile_jit_source)
+    std::vector<T> params;
+    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr),
+                        fma, &fn));
     if (s->jit_prepare) return QIP_OK;
+    if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
     void* st_ptr = s->cur;
     uint64_t ntiles_arg = ntiles;
-    void* args[] = {&st_ptr, &ntiles_arg};
-    // persistent form: as many blocks as stay resident (4 per CU: __launch_bounds__(kTileBlock, 4), 4 x 32 KiB of LDS)
-    const dim3 grid = pipe ? dim3((unsigned)std::min<uint64_t>(ntiles, (uint64_t)s->num_cus * 4u)) : grid2d(ntiles, 1);
+    void* params_ptr = s->arena;
+    void* args[] = {&st_ptr, &ntiles_arg, &params_ptr};  // (the third is ignored by kernels without parameters)
+    const dim3 grid = grid2d(ntiles, 1);
     HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
     if (s->profile) QCHK(prof_end(s, &rec));
     return QIP_OK;
@@ -608,6 +620,49 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
 }
 
 template <typename T>
+int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done) {
+  *done = false;
+  if (s->n < (uint32_t)kTileBits || !s->tile_passes) return QIP_OK;
+  TileItem it;
+  QCHK(classify_tile_item(s->dtype, s->n, op, &it));
+  std::vector<TileItem> parts;
+  if (it.tileable) {
+    parts.push_back(it);
+  } else if (it.swap_pairs.size() >= 2) {
+    // an uncontrolled Swap(h >= 2) is h disjoint transpositions: h bit-swap items of ONE sweep (pure moves: any grouping is
+    // bit-identical to the single permutation)
+    for (const auto& pr : it.swap_pairs) {
+      TileItem t;
+      t.tileable = t.exact = true;
+      t.kind = 2;
+      t.t0 = std::min(pr.first, pr.second);
+      t.t1 = std::max(pr.first, pr.second);
+      t.pos = {t.t0, t.t1};
+      t.nd_mask = (1ull << t.t0) | (1ull << t.t1);
+      parts.push_back(t);
+    }
+  } else {
+    return QIP_OK;
+  }
+  std::vector<uint32_t> hp;
+  for (const TileItem& t : parts)
+    for (uint32_t p : t.pos)
+      if (p >= (uint32_t)kTileLow && std::find(hp.begin(), hp.end(), p) == hp.end()) hp.push_back(p);
+  if (hp.size() > (size_t)kTileHigh) return QIP_OK;
+  std::vector<const TileItem*> seg;
+  for (const TileItem& t : parts) seg.push_back(&t);
+  const int64_t jit = s->tile_jit;
+  s->tile_jit = 0;  // one op does not repay a run-time compilation: the interpreter kernel
+  const int rc = launch_tile_segment<T>(s, seg, hp);
+  s->tile_jit = jit;
+  QCHK(rc);
+  *done = true;
+  return QIP_OK;
+}
+template int tile_apply_single<double>(qip_hip_state*, const qip_op*, bool*);
+template int tile_apply_single<float>(qip_hip_state*, const qip_op*, bool*);
+
+template <typename T>
 static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* nseg, uint64_t* src_bytes,
                        uint64_t* code_bytes, std::string* first) {
   TileSchedule sc;
@@ -621,7 +676,8 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     TileSegmentPlan<T> plan;
     QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
     Ins ins = make_ins(plan.high, 0);
-    const std::string src = tile_jit_source<T>(plan, ins, true, (mode & 16) ? 1 : 0);  // mode bit 4: the persistent form
+    std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
+    const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr);
     std::vector<char> code;
     {
       std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -651,12 +707,19 @@ extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, 
 extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
 static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
-  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel >= 2 ? 8 : 0);
+  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel == 2 ? 8 : 0);  // (3 = persistent layout)
 }
 
 template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t count, bool /*reorder*/) {
   TileSchedule sc;
+  // tile_relabel = 3: the qubit layout persists across calls — the plan starts from the layout the previous call left and
+  // does not close with the restoring sweep (that happens once, when somebody needs the caller's order: state_settle).
+  // Not inside a graph capture or a compile-only pass: a recorded program must start and end in the caller's order.
+  const bool persist = s->tile_relabel >= 3 && !s->capture_staging && !s->jit_prepare;
+  if (!persist && !s->layout.empty()) QCHK(state_settle(s));
+  sc.init_phys = s->layout;
+  sc.keep_layout = persist;
   QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc));
   {
     // a bit-permutation sweep is out of place: get the second buffer BEFORE the first gate runs; if HBM cannot hold it
@@ -665,12 +728,17 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     for (const TileStep& st : sc.steps) permutes = permutes || !st.perm.empty();
     if (permutes && !s->jit_prepare && !s->alt && ensure_alt(s) != QIP_OK) {
       (void)hipGetLastError();
+      if (!s->layout.empty()) return fail(QIP_ERR_DEVICE, "no room for the second buffer a relabelled state needs");
       sc = TileSchedule();
       QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc, /*allow_permute=*/false));
     }
   }
   const qip_op* ops = sc.circuit;
   const std::vector<TileItem>& items = sc.items;
+  // from here on the shard is somewhere between two layouts until the last step has been issued: single ops inside the plan
+  // are already expressed in physical positions, so they must not settle (layout is cleared for the duration)
+  const std::vector<uint32_t> final_phys = sc.final_phys;
+  s->layout.clear();
   for (const TileStep& st : sc.steps) {
     if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
       if (s->jit_prepare) continue;
@@ -685,15 +753,21 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
     QCHK(launch_tile_segment<T>(s, seg, st.high));
   }
+  if (persist) {
+    bool identity = true;
+    for (uint32_t p = 0; p < final_phys.size(); ++p) identity = identity && final_phys[p] == p;
+    if (!identity) s->layout = final_phys;
+  }
   return QIP_OK;
 }
 
 extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) try {
-  STATE_ENTER(s);
+  STATE_ENTER_RAW(s);  // (a relabelled state stays relabelled for a relabelling batch: apply_ops_tiled decides)
   if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
   if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
     return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
                                : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
+  if (!s->layout.empty()) QCHK(state_settle(s));
   if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
     const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, kMaxMfmaK);  // both precisions have a matrix-core k = 5 kernel
     if (s->n >= K + 4)

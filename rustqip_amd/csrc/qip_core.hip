@@ -41,7 +41,8 @@ int64_t g_perm_rows = 0;
 // by WHICH five high positions the tile holds — 5.2 ms for {11..15}, 6.3 ms for {6..10}, 6.7 ms for the top five — not by the
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
 // taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
-int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;
+int64_t g_single_via_tile = 2;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
@@ -61,6 +62,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
+  if (key && !strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
 } QIP_CATCH_ALL
 
@@ -418,7 +420,8 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
 
 
 extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
-  STATE_ENTER(s);
+  STATE_ENTER_RAW(s);
+  s->layout.clear();  // whatever was there is overwritten: no need to restore its order first
   if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
   if (s->dtype == QIP_C64) {
@@ -455,7 +458,8 @@ extern "C" int qip_hip_state_download(qip_hip_state* s, void* dst, uint64_t offs
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_device_ptr(qip_hip_state* s, void** amps) try {
-  if (!s || !amps) return fail(QIP_ERR_INVALID, "null argument");
+  if (!amps) return fail(QIP_ERR_INVALID, "null argument");
+  STATE_ENTER(s);  // (a relabelled state is put back in the caller's order before its address is handed out)
   *amps = s->cur;
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -496,7 +500,6 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "swap_single")) s->swap_single = value;
   else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
   else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
-  else if (!strcmp(key, "tile_pipe")) s->tile_pipe = value;
   else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;

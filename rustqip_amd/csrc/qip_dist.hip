@@ -679,6 +679,7 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
       i = jx;
       continue;
     }
+    if (!s->layout.empty()) QCHK(state_settle(s));  // (a shard with a persistent relabelling: the caller's order first)
     if (steps[i].kind == qipd::Step::PACK) {
       QCHK(ensure_alt(s));
       // a selected position inside a 1-KiB row would make k_pack_bits read 16-byte pieces: such a gather goes through the
@@ -898,6 +899,7 @@ extern "C" int qip_hip_dist_init_basis(qip_hip_dist* d, uint64_t logical_index) 
   const uint64_t owner = (P >> pl.L) ^ pl.flip, local = P & ((1ull << pl.L) - 1ull);  // (pending rank renamings)
   if ((int)owner == pl.rank) return qip_hip_state_init_basis(d->shard, local);
   qip_hip_state* s = d->shard;
+  s->layout.clear();  // (an all-zero shard is the same in every order)
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
@@ -987,6 +989,70 @@ extern "C" int qip_hip_dist_measure_probs(qip_hip_dist* d, const uint64_t* indic
   return QIP_OK;
 } QIP_CATCH_ALL
 
+// soft_measure (measurement_ops.rs:153-176) over the WHOLE vector in LOGICAL index order: r -= |amp_i|^2 until r <= 0.
+// Instead of walking 2^n amplitudes across ranks, descend the index bit by bit from the top: the mass of the half-block
+// whose next bit is 0 is one masked norm (local reduction over a sub-space that halves at every local bit, so ~2 sweeps in
+// all) + one all-reduce; the crossing lies in it iff r - mass <= 0.  Same sample -> outcome map as the reference up to the
+// rounding of block sums (the caveat of the single-GPU soft_measure; tests/dist_worker_gpu.py sweeps samples against the
+// oracle and counts the disagreements).  Rank 0's sample decides, so every rank arrives at the same outcome.
+static int dist_soft_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double rand_u01, uint64_t* measured) {
+  const qipd::DistPlanner& pl = d->pl;
+  double r = pl.rank == 0 ? rand_u01 : 0.0;
+  QCHK(dist_all_reduce(d, &r, 1));
+  uint64_t logical_index = 0;
+  std::vector<uint64_t> cq;      // local qubits constrained so far
+  uint64_t cval = 0;             // their required values (bit j <-> cq[j])
+  bool rank_ok = true;           // this rank's bits agree with the prefix chosen so far
+  for (uint32_t qb = 0; qb < pl.n; ++qb) {
+    const uint32_t p_log = pl.n - 1 - qb, pp = pl.phys[p_log];
+    // mass of (prefix, bit = 0)
+    double mass = 0.0;
+    if (pp >= pl.L) {
+      if (rank_ok && pl.rank_bit(pp) == 0) {
+        if (cq.empty()) QCHK(qip_hip_state_norm_sqr(d->shard, &mass));
+        else QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &mass));
+      }
+    } else if (rank_ok) {
+      cq.push_back(pl.local_qubit(pp));  // bit value 0 for this probe: cval unchanged
+      QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &mass));
+    } else {
+      cq.push_back(pl.local_qubit(pp));
+    }
+    QCHK(dist_all_reduce(d, &mass, 1));
+    uint64_t bit = 0;
+    if (!(r - mass <= 0.0)) {
+      r -= mass;
+      bit = 1;
+    }
+    logical_index |= bit << p_log;
+    if (pp >= pl.L) rank_ok = rank_ok && pl.rank_bit(pp) == bit;
+    else cval |= bit << (cq.size() - 1);
+  }
+  // the walk never crossed before the LAST amplitude: the reference then tests that one too and, if the sample is
+  // still positive (it exceeds the norm by rounding), leaves measured_indx at 0 (measurement_ops.rs:166-173)
+  if (logical_index == (pl.n < 64 ? (1ull << pl.n) - 1ull : ~0ull)) {
+    double last = 0.0;
+    if (rank_ok) {
+      if (cq.empty()) QCHK(qip_hip_state_norm_sqr(d->shard, &last));
+      else QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &last));
+    }
+    QCHK(dist_all_reduce(d, &last, 1));
+    if (!(r - last <= 0.0)) logical_index = 0;
+  }
+  uint64_t m = 0;
+  for (uint32_t i = 0; i < k; ++i) m |= ((logical_index >> (pl.n - 1 - (uint32_t)indices[i])) & 1ull) << i;
+  *measured = m;
+  return QIP_OK;
+}
+
+extern "C" int qip_hip_dist_soft_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, double rand_u01, uint64_t* measured) try {
+  DIST_ENTER(d);
+  if (!measured || (k && !indices)) return fail(QIP_ERR_INVALID, "null argument");
+  for (uint32_t i = 0; i < k; ++i)
+    if (indices[i] >= d->pl.n) return fail(QIP_ERR_INVALID, "measured index %llu out of range", (unsigned long long)indices[i]);
+  return dist_soft_measure(d, indices, k, rand_u01, measured);
+} QIP_CATCH_ALL
+
 extern "C" int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t k, int64_t forced, double rand_u01,
                                     uint64_t* measured, double* prob) try {
   DIST_ENTER(d);
@@ -999,55 +1065,7 @@ extern "C" int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, ui
     m = (uint64_t)forced;
     if (k < 64 && (m >> k) != 0) return fail(QIP_ERR_INVALID, "forced outcome has more than k bits");
   } else {
-    // soft_measure (measurement_ops.rs:153-176) over the WHOLE vector in LOGICAL index order: r -= |amp_i|^2 until
-    // r <= 0.  Instead of walking 2^n amplitudes across ranks, descend the index bit by bit from the top: the mass of the
-    // half-block whose next bit is 0 is one masked norm (local reduction over a sub-space that halves at every local
-    // bit, so ~2 sweeps in all) + one all-reduce; the crossing lies in it iff r - mass <= 0.  Same sample -> outcome
-    // map as the reference up to the rounding of block sums (the caveat of the single-GPU soft_measure).  Rank 0's
-    // sample decides, so every rank collapses to the same outcome.
-    double r = pl.rank == 0 ? rand_u01 : 0.0;
-    QCHK(dist_all_reduce(d, &r, 1));
-    uint64_t logical_index = 0;
-    std::vector<uint64_t> cq;      // local qubits constrained so far
-    uint64_t cval = 0;             // their required values (bit j <-> cq[j])
-    bool rank_ok = true;           // this rank's bits agree with the prefix chosen so far
-    for (uint32_t qb = 0; qb < pl.n; ++qb) {
-      const uint32_t p_log = pl.n - 1 - qb, pp = pl.phys[p_log];
-      // mass of (prefix, bit = 0)
-      double mass = 0.0;
-      if (pp >= pl.L) {
-        if (rank_ok && pl.rank_bit(pp) == 0) {
-          if (cq.empty()) QCHK(qip_hip_state_norm_sqr(d->shard, &mass));
-          else QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &mass));
-        }
-      } else if (rank_ok) {
-        cq.push_back(pl.local_qubit(pp));  // bit value 0 for this probe: cval unchanged
-        QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &mass));
-      } else {
-        cq.push_back(pl.local_qubit(pp));
-      }
-      QCHK(dist_all_reduce(d, &mass, 1));
-      uint64_t bit = 0;
-      if (!(r - mass <= 0.0)) {
-        r -= mass;
-        bit = 1;
-      }
-      logical_index |= bit << p_log;
-      if (pp >= pl.L) rank_ok = rank_ok && pl.rank_bit(pp) == bit;
-      else cval |= bit << (cq.size() - 1);
-    }
-    // the walk never crossed before the LAST amplitude: the reference then tests that one too and, if the sample is
-    // still positive (it exceeds the norm by rounding), leaves measured_indx at 0 (measurement_ops.rs:166-173)
-    if (logical_index == (pl.n < 64 ? (1ull << pl.n) - 1ull : ~0ull)) {
-      double last = 0.0;
-      if (rank_ok) {
-        if (cq.empty()) QCHK(qip_hip_state_norm_sqr(d->shard, &last));
-        else QCHK(qip_hip_state_measure_prob(d->shard, cval, cq.data(), (uint32_t)cq.size(), &last));
-      }
-      QCHK(dist_all_reduce(d, &last, 1));
-      if (!(r - last <= 0.0)) logical_index = 0;
-    }
-    for (uint32_t i = 0; i < k; ++i) m |= ((logical_index >> (pl.n - 1 - (uint32_t)indices[i])) & 1ull) << i;
+    QCHK(dist_soft_measure(d, indices, k, rand_u01, &m));
   }
   const double p = probs[m];
   *measured = m;
@@ -1067,6 +1085,7 @@ extern "C" int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, ui
   }
   qip_hip_state* s = d->shard;
   if (!agrees) {  // this rank's bits contradict the outcome: the whole shard goes to zero
+    s->layout.clear();
     HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
     return QIP_OK;
   }

@@ -59,7 +59,8 @@ int fail(int code, const char* fmt, ...);
 extern int64_t g_force_generic;
 extern uint32_t g_line_bits;
 extern int64_t g_perm_rows;
-extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap;  // tuning aids of the tile sweeps (qip_hip_set_global_option)
+extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap;
+extern int64_t g_single_via_tile;  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 
 struct FlatOp {
   const qip_op* outer = nullptr;
@@ -149,12 +150,16 @@ struct qip_hip_state {
   int64_t tile_passes = 1;  // tile sweeps: group gates into register passes (k_tile_passes) vs one LDS pass per gate
   int64_t tile = 0;  // 0 off, 1 = LDS-resident multi-gate sweeps in circuit order, 2 = with commuting reorder
   int64_t packed_f32 = 1;
-  int64_t tile_relabel = 0;  // tile sweeps: the scheduler relabels the qubits (schedule_tiles_relabel)
+  int64_t tile_relabel = 0;  // tile sweeps: the scheduler relabels the qubits (schedule_tiles_relabel); 3 = the layout persists
+  // Persistent relabelling (tile_relabel = 3): layout[p] = physical position of logical index bit p, in force BETWEEN
+  // apply_ops calls (empty = the caller's order).  Everything that reads, writes or addresses amplitudes other than a
+  // relabelling apply_ops first restores the caller's order with one bit-permutation sweep (state_settle, part of STATE_ENTER).
+  std::vector<uint32_t> layout;
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
-  int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached)
-  int64_t tile_pipe = 0;    // run-time-compiled segments: 1 = persistent blocks, next tile's loads in flight across the passes
+  int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached);
+                            // 2 = ... with the segment's numbers as kernel data (angles can change without recompiling)
   int64_t tile_fma = 0;     // run-time-compiled segments of tile = 2: products may fuse into sums (1e-12 bar, not IEEE equality)
-  int num_cus = 256;        // compute units of the device (grid size of persistent kernels)
+  int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
@@ -175,12 +180,18 @@ int ensure_alt(qip_hip_state* s);
 void programs_orphan(qip_hip_state* s);  // qip_circuit.hip
 int jit_set_cache_cap(int64_t cap);      // qip_circuit.hip (global option "jit_cache_cap")
 uint64_t jit_cache_generation();
+// qip_circuit.hip: `op` as a one-item tile sweep; *done = false when it is not a tile item (nothing launched)
+template <typename T> int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done);
 int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r);
 int prof_end(qip_hip_state* s, ProfRec* r);
+int state_settle(qip_hip_state* s);  // qip_launch.hip: a relabelled state back to the caller's order (one permutation sweep)
 
-#define STATE_ENTER(s)                                        \
+#define STATE_ENTER_RAW(s)                                    \
   if (!(s)) return fail(QIP_ERR_INVALID, "null state handle"); \
   HIPCHK(hipSetDevice((s)->device))
+#define STATE_ENTER(s) \
+  STATE_ENTER_RAW(s);  \
+  if (!(s)->layout.empty()) QCHK(state_settle(s))
 
 static inline unsigned grid_for(uint64_t items, uint64_t per_block) {
   uint64_t g = (items + per_block - 1) / per_block;

@@ -914,6 +914,46 @@ __global__ void k_sparse_kq(amp_t<T>* __restrict__ st, uint64_t ngroups, Ins ins
   }
 }
 
+// ---- SparseMatrix on k >= 6 qubits with few entries per row, out of place ---------------------------------------------
+// The reference's own sparse bench shape (qip/benches/state_bench.rs:380-393: a 16-qubit SparseMatrix with one entry per
+// row).  A group of 2^k amplitudes no longer fits a lane, so the sweep is the reference's gather formulation — one output
+// row per lane item, rows in stored order folded from 0 (qubit_iterators.rs:60-102, ops.rs:104-110) — with the descriptor
+// flattened for the device: rows in ELL form (at most E entries each: `nnz[m]`, `off[m * E + e]` = the column's bits already
+// spread to their index positions, `val[m * E + e]`), the sub-index read off the row's index bits in runs of consecutive
+// positions.  Rows whose controls are not all 1 are the iterator's single (row, 1) entry: a copy.  Every access of a lane's
+// U items is a whole 1-KiB wave row on the output side; the input side is as contiguous as the op's columns allow (the
+// identity of the bench: a plain copy).
+struct EllDesc {
+  uint64_t cmask;     // control bit positions (all must be 1)
+  uint64_t opmask;    // the op's bit positions
+  uint32_t nruns;     // the positions in ascending order as runs of consecutive bits
+  uint32_t lo[32], len[32], shift[32];
+};
+
+template <typename T, int E, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void k_sparse_ell(const amp_t<T>* __restrict__ in, amp_t<T>* __restrict__ out, EllDesc d,
+                                                       const uint32_t* __restrict__ nnz, const uint64_t* __restrict__ off,
+                                                       const amp_t<T>* __restrict__ val) {
+  using A = amp_t<T>;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t r = work_index<Log2<U>::v>(u);
+    if ((r & d.cmask) != d.cmask) {
+      stg<NT>(out + r, ldg<NT>(in + r));  // 0 + 1 * x
+      continue;
+    }
+    uint32_t m = 0;
+    for (uint32_t j = 0; j < d.nruns; ++j) m |= (uint32_t)((r >> d.lo[j]) & ((1ull << d.len[j]) - 1ull)) << d.shift[j];
+    const uint64_t rbase = r & ~d.opmask;
+    const uint32_t cnt = nnz[m];
+    A acc = czero<A>();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((uint32_t)e < cnt) acc = cadd(acc, cmul(val[(uint64_t)m * E + e], in[rbase | off[(uint64_t)m * E + e]]));
+    stg<NT>(out + r, acc);
+  }
+}
+
 // ---- LDS-resident multi-gate sweep ------------------------------------------
 // One sweep applies a whole LIST of gates: a 256-lane block stages a tile of 2^11 amplitudes in LDS
 // (32 KiB for f64) — index bits 0..5 (one contiguous 1-KiB wave row) plus kTileHigh = 5 arbitrary

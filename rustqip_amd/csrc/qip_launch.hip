@@ -463,6 +463,15 @@ int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
   return QIP_OK;
 }
 
+int state_settle(qip_hip_state* s) {
+  if (s->layout.empty()) return QIP_OK;
+  const std::vector<uint32_t> phys = s->layout;  // final index bit d takes the bit that lives on phys[d] now
+  s->layout.clear();
+  const int rc = launch_permute(s, phys.data());
+  if (rc != QIP_OK) s->layout = phys;
+  return rc;
+}
+
 extern "C" int qip_hip_state_permute_bits(qip_hip_state* s, const uint32_t* pi) try {
   STATE_ENTER(s);
   if (!pi) return fail(QIP_ERR_INVALID, "null permutation");
@@ -770,6 +779,84 @@ static int launch_sparse_kq(qip_hip_state* s, const Plan& p, const FlatOp& f, am
   return QIP_OK;
 }
 
+// SparseMatrix on k >= 6 distinct qubits with at most four entries per row (optionally controlled): cur -> alt through
+// k_sparse_ell.  *done = false when the op does not qualify (more entries per row, too large a table): the literal kernel runs.
+constexpr uint32_t kMaxEllK = 18;
+template <typename T>
+static int launch_sparse_ell(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
+  *done = false;
+  const uint32_t k = f.n_op;
+  if (k > kMaxEllK || s->namps < ((uint64_t)4 << kStrideShift)) return QIP_OK;
+  const uint64_t rows = 1ull << k;
+  const uint64_t* rp = f.inner->sparse_rowptr;
+  uint64_t widest = 0;
+  for (uint64_t r = 0; r < rows; ++r) widest = std::max<uint64_t>(widest, rp[r + 1] - rp[r]);
+  if (widest > 4) return QIP_OK;
+  const uint32_t E = widest <= 1 ? 1u : (widest <= 2 ? 2u : 4u);
+  // the table is indexed by the sub-index in POSITION order (bit b of m' = the op's b-th lowest index position): which
+  // stored row that is, and where a stored column's bits go, are host arithmetic
+  std::vector<uint32_t> order(k);  // order[b] = j: op index j sits on the b-th lowest position
+  for (uint32_t j = 0; j < k; ++j) order[j] = j;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return p.opos[a] < p.opos[b]; });
+  EllDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t c : p.cpos) d.cmask |= 1ull << c;
+  for (uint32_t t : p.opos) d.opmask |= 1ull << t;
+  for (uint32_t b = 0; b < k;) {
+    uint32_t e = b + 1;
+    while (e < k && p.opos[order[e]] == p.opos[order[e - 1]] + 1) ++e;
+    d.lo[d.nruns] = p.opos[order[b]];
+    d.len[d.nruns] = e - b;
+    d.shift[d.nruns] = b;
+    d.nruns += 1;
+    b = e;
+  }
+  std::vector<uint32_t> nnz(rows);
+  std::vector<uint64_t> off(rows * E, 0);
+  std::vector<amp_t<T>> val(rows * E, mk<T>(0, 0));
+  const amp_t<T>* sv = (const amp_t<T>*)f.inner->sparse_vals;
+  for (uint64_t mp = 0; mp < rows; ++mp) {
+    uint64_t m = 0;  // stored row: op index j is sub-index bit k-1-j (matrix_ops.rs:12-21)
+    for (uint32_t b = 0; b < k; ++b) m |= ((mp >> b) & 1ull) << (k - 1 - order[b]);
+    nnz[mp] = (uint32_t)(rp[m + 1] - rp[m]);
+    for (uint64_t q = rp[m]; q < rp[m + 1]; ++q) {
+      const uint64_t c = f.inner->sparse_cols[q];
+      uint64_t o = 0;
+      for (uint32_t j = 0; j < k; ++j) o |= ((c >> (k - 1 - j)) & 1ull) << p.opos[j];
+      off[mp * E + (q - rp[m])] = o;
+      val[mp * E + (q - rp[m])] = sv[q];
+    }
+  }
+  const size_t b_nnz = rows * 4, b_off = rows * E * 8, b_val = rows * E * sizeof(amp_t<T>);
+  const size_t o_off = (b_nnz + 15) & ~(size_t)15, o_val = (o_off + b_off + 15) & ~(size_t)15;
+  QCHK(ensure_alt(s));
+  QCHK(ensure_arena(s, o_val + b_val + 16));
+  QCHK(arena_upload(s, nnz.data(), b_nnz, 0));
+  QCHK(arena_upload(s, off.data(), b_off, o_off));
+  QCHK(arena_upload(s, val.data(), b_val, o_val));
+  const uint32_t* dn = (const uint32_t*)s->arena;
+  const uint64_t* doff = (const uint64_t*)((char*)s->arena + o_off);
+  const amp_t<T>* dval = (const amp_t<T>*)((char*)s->arena + o_val);
+  constexpr int U = 4;
+  const dim3 grid = grid2d(s->namps, kBlock * U);
+  const amp_t<T>* in = (const amp_t<T>*)s->cur;
+  amp_t<T>* out = (amp_t<T>*)s->alt;
+#define ELL(EE)                                                                                                              \
+  do {                                                                                                                       \
+    if (use_nt(s)) hipLaunchKernelGGL((k_sparse_ell<T, EE, U, true>), grid, dim3(kBlock), 0, s->stream, in, out, d, dn, doff, dval);  \
+    else hipLaunchKernelGGL((k_sparse_ell<T, EE, U, false>), grid, dim3(kBlock), 0, s->stream, in, out, d, dn, doff, dval);           \
+  } while (0)
+  if (E == 1) ELL(1);
+  else if (E == 2) ELL(2);
+  else ELL(4);
+#undef ELL
+  HIPCHK(hipGetLastError());
+  std::swap(s->cur, s->alt);  // builder.rs:514
+  std::swap(s->owns_cur, s->owns_alt);
+  *done = true;
+  return QIP_OK;
+}
+
 template <typename T>
 int apply_op_t(qip_hip_state* s, const qip_op* op) {
   if (s->jit_prepare) return QIP_OK;  // compiling a program's segment kernels: single ops have nothing to prepare
@@ -781,6 +868,24 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
   if (p.cls == KC_NOOP) {
     if (s->profile) s->prof_launches[KC_NOOP] += 1;
     return QIP_OK;
+  }
+  // Uncontrolled dense 2- / 3-qubit gates, and Swap ops with a bit inside a 1-KiB row, run as a one-op TILE SWEEP: it streams
+  // whole rows on both sides whatever the target bits are (a lane of k_gate_kq with a target below bit 6 reads 16-byte pieces
+  // 64 bytes apart: 59 % of peak for k = 2 on bits 0, 1), its free positions are padded from 11 upwards (the fastest tile
+  // shapes measured), and the arithmetic is the unfused register fold of k_gate_kq — IEEE-equal to the dedicated VALU kernel
+  // and to the oracle, where the matrix-core form of k = 3 is an fma chain.  Measured at n = 30 (profiles/r03_ops_table.md):
+  // k = 2 73 -> 77 % (bits 0, 1: 59 -> 77), k = 3 70 -> 79 % (bits 0-2: 58 -> 78), Swap(1) n-1 <-> 0 75 -> 82 %.
+  // Global option "single_via_tile": 0 = dedicated kernels only, 1 = only when a target lies inside a row, 2 (default) = always.
+  if (g_single_via_tile && !s->force_generic && !g_force_generic && s->mfma != 0 && s->unroll == 0 && !s->swap_single &&
+      (p.cls == KC_GATE_KQ || p.cls == KC_GATE_KQ_MFMA || p.cls == KC_SWAP_BITS) && p.cpos.empty() && s->n >= 17) {
+    bool low = false;
+    for (uint32_t t : p.opos) low = low || t < 6;
+    const bool dense23 = p.cls != KC_SWAP_BITS && (p.opos.size() == 2 || p.opos.size() == 3);
+    if ((dense23 && (low || g_single_via_tile >= 2)) || (p.cls == KC_SWAP_BITS && low)) {
+      bool done = false;
+      QCHK(tile_apply_single<T>(s, op, &done));
+      if (done) return QIP_OK;
+    }
   }
   ProfRec rec;
   rec.cls = p.cls;
@@ -845,6 +950,14 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
     case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
     case KC_SPARSE_KQ: rc = launch_sparse_kq<T>(s, p, f, st); break;
     default: {
+      if (f.inner->kind == QIP_OP_SPARSE && f.distinct && f.n_op >= 6 && !s->force_generic && !g_force_generic && !s->capture_staging) {
+        bool done = false;
+        rc = launch_sparse_ell<T>(s, p, f, &done);
+        if (rc != QIP_OK || done) {
+          rec.cls = KC_SPARSE_KQ;
+          break;
+        }
+      }
       QCHK(ensure_alt(s));
       rc = launch_gather<T>(s, f, (const amp_t<T>*)s->cur, s->namps, (amp_t<T>*)s->alt, s->namps, 0,
                             0, 0);

@@ -53,6 +53,10 @@ struct TileSchedule {
   std::vector<TileItem> items;             // one per entry of `circuit`
   std::vector<TileStep> steps;
   uint64_t absorbed = 0, inserted = 0;     // Swap ops turned into label exchanges / in-tile swaps added
+  // persistent relabelling (option tile_relabel = 3): the layout the state is in when the plan starts (empty = identity), whether
+  // the plan leaves the state relabelled instead of closing with the restoring sweep, and the layout it ends in
+  std::vector<uint32_t> init_phys, final_phys;
+  bool keep_layout = false;
 };
 
 int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it);

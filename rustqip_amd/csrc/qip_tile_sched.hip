@@ -463,6 +463,9 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
 
 int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t count, bool reorder, bool allow_2q,
                                   TileSchedule* out) {
+  // `out->init_phys` (optional): the layout the state is in when the schedule starts (a previous call left it relabelled);
+  // `out->keep_layout`: do not close with the restoring permutation sweep — the final layout is returned in `final_phys`
+  // and stays in force (option tile_relabel = 3: the layout persists across apply_ops calls)
   std::vector<TileItem> L(count);  // the caller's ops, logical bit positions
   for (uint64_t i = 0; i < count; ++i) {
     int rc = classify_tile_item(dtype, n, &ops[i], &L[i]);
@@ -474,6 +477,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
   }
   std::vector<uint32_t> phys(n);  // phys[p] = physical position of logical bit position p
   for (uint32_t p = 0; p < n; ++p) phys[p] = p;
+  if (out->init_phys.size() == n) phys = out->init_phys;
   auto push_op = [&](const qip_op& o, int64_t origin) -> int {
     out->owned.push_back(o);
     out->origin.push_back(origin);
@@ -628,10 +632,12 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
   // every qubit back to the position the caller expects: final index bit d takes the bit that lives on phys[d] now
   bool identity = true;
   for (uint32_t p = 0; p < n; ++p) identity = identity && phys[p] == p;
-  if (!identity) {
+  out->final_phys = phys;
+  if (!identity && !out->keep_layout) {
     TileStep back;
     back.perm = phys;
     out->steps.push_back(back);
+    for (uint32_t p = 0; p < n; ++p) out->final_phys[p] = p;
   }
   out->circuit = out->owned.data();
   out->count = out->owned.size();
@@ -643,15 +649,26 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
 int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
                               bool allow_permute) {
   const bool reorder = (mode & 3) >= 2;
+  bool start_identity = true;
+  for (uint32_t p = 0; p < out->init_phys.size(); ++p) start_identity = start_identity && out->init_phys[p] == p;
   if ((mode & 4) && allow_permute) {
     // relabelling pays for random circuits; layered ones (Grover's X / H walls, QFT) gain nothing and would only pay the
-    // closing permutation: schedule both ways (host work, microseconds per gate) and keep the shorter plan
+    // closing permutation: schedule both ways (host work, microseconds per gate) and keep the shorter plan.  With a
+    // persistent layout (keep_layout) the closing sweep is not part of this call; a plan that starts from a relabelled
+    // state has no plain alternative short of restoring the order first (one sweep).
+    const std::vector<uint32_t> init = out->init_phys;
+    const bool keep = out->keep_layout;
     QCHK(schedule_tiles_relabel(dtype, n, ops, count, reorder, allow_2q, out));
+    if (!start_identity) return QIP_OK;
     TileSchedule plain;
     QCHK(schedule_tiles(dtype, n, ops, count, reorder, &plain.items, &plain.steps, allow_2q));
     if (out->steps.size() < plain.steps.size() || (mode & 8)) return QIP_OK;  // bit 3: keep it regardless (tests)
     *out = TileSchedule();
+    out->init_phys = init;
+    out->keep_layout = keep;
   }
+  out->final_phys.resize(n);
+  for (uint32_t p = 0; p < n; ++p) out->final_phys[p] = p;
   out->circuit = ops;
   out->count = count;
   return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q, allow_permute);

@@ -241,6 +241,12 @@ class DistState:
         return int(m.value), p.value
 
     # -- bench / profiling ----------------------------------------------------------------------------------------------------------
+    def soft_measure(self, indices: Sequence[int], rand_u01: float) -> int:
+        """soft_measure (measurement_ops.rs:153-176) of the sharded state: rank 0's sample decides; no collapse"""
+        out = C.c_uint64()
+        _check(_ffi.lib.qip_hip_dist_soft_measure(self._h, _u64_array(indices), len(indices), float(rand_u01), C.byref(out)))
+        return int(out.value)
+
     def comm_stats(self) -> dict:
         """counters since the previous call (they reset)"""
         st = _ffi.QipDistStats()

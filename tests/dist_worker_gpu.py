@@ -94,6 +94,20 @@ def main():
                     ms, ps = st3.measure(idx, rand_u01=r_u if rank == 0 else 0.123)
                     wm = O.soft_measure(n, idx, ref, r_u)
                     assert ms == wm and abs(ps - O.measure_prob(n, wm, idx, ref)) < 1e-12, (name, idx, r_u, ms, wm)
+            if name in ("c2", "qft"):
+                # ... and how OFTEN: 2000 samples through the sampling step alone (no collapse), in a permuted layout, against
+                # the oracle's sequential scan.  The descent sums blocks in another order than the scan subtracts amplitudes, so
+                # a disagreement needs the sample within rounding (~1e-16) of a boundary: the count is reported and must be 0.
+                st4 = DistState(n, dist, 0, host_staged=not use_nccl)
+                st4.upload_global(x)
+                st4.apply_ops(ops[:30])
+                srng = np.random.default_rng(99)
+                samples = srng.uniform(0, 1, 2000)
+                idx = [3, 0, n - 1, 6]
+                differ = sum(1 for r_u in samples if st4.soft_measure(idx, float(r_u) if rank == 0 else 0.5) != O.soft_measure(n, idx, ref, float(r_u)))
+                assert differ == 0, (name, differ)
+                if rank == 0:
+                    print(f"soft_measure map n={n} world={world} {name}: {differ} of {len(samples)} samples differ from the reference's scan")
             st.init_basis(5)
             e = np.zeros(1 << n, dtype=np.complex128)
             e[5] = 1

@@ -1915,3 +1915,292 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
         leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
         twin.close()
         assert abs(st.norm_sqr() - 1) < 1e-9
+
+
+def _jit_info():
+    import ctypes as C
+
+    from rustqip_amd import _ffi
+
+    k, ms = C.c_uint64(), C.c_double()
+    assert _ffi.lib.qip_hip_jit_stats(C.byref(k), C.byref(ms)) == 0
+    res, ev, cap = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert _ffi.lib.qip_hip_jit_cache_info(C.byref(res), C.byref(ev), C.byref(cap)) == 0
+    return {"compiled": int(k.value), "resident": int(res.value), "evicted": int(ev.value), "cap": int(cap.value)}
+
+
+def _ansatz(n, thetas):
+    """two layers of Rz / real rotations / controlled phases with one angle per qubit and layer, CNOT ladders between"""
+    ops = []
+    for layer in range(len(thetas)):
+        for t in range(n):
+            th = float(thetas[layer][t])
+            ops.append(q.make_matrix_op([t], circuits.rz(th)))
+            c, s = math.cos(th / 2), math.sin(th / 2)
+            ops.append(q.make_matrix_op([(t + 3) % n], [c, -s, s, c]))
+        for t in range(0, n - 1, 2):
+            ops.append(q.make_control_op([t], q.make_matrix_op([t + 1], circuits.X)))
+        for t in range(0, n - 2, 3):
+            ops.append(q.make_control_op([t], q.make_matrix_op([t + 2], [1, 0, 0, cmath.rect(1, float(thetas[layer][t]) * 0.5)])))
+    return ops
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_parametrised_segments_variational_loop_compiles_once(O, dtype):
+    """option tile_jit = 2: the segment's structure is code, its numbers are kernel data.  64 angles updated 20 times: the
+    number of compiled kernels stays what the first pass made it; every pass is bit-identical to the interpreter sweeps and
+    to tile_jit = 1 (same arithmetic per amplitude), and the f64 result equals the oracle's."""
+    n = 16
+    rng = np.random.default_rng(5)
+    x = circuits.random_state(n, seed=3, dtype=dtype)
+    compiled_after_first = None
+    with q.HipState(n, dtype) as st, q.HipState(n, dtype) as ref:
+        st.set_option("tile", 1)
+        st.set_option("tile_jit", 2)
+        ref.set_option("tile", 1)
+        for it in range(20):
+            ops = _ansatz(n, rng.uniform(0.05, 3.0, (4, n)))  # 64 angles
+            st.upload(x)
+            st.apply_ops(ops)
+            got = st.download()
+            ref.upload(x)
+            ref.apply_ops(ops)
+            assert np.array_equal(got, ref.download()), it
+            if it == 0:
+                compiled_after_first = _jit_info()["compiled"]
+                if dtype == np.complex128:
+                    assert np.array_equal(got, O.apply_ops_in_place(n, ops, x.copy()))
+                ref.set_option("tile_jit", 1)  # from here on the reference is the literal run-time-compiled form
+        assert _jit_info()["compiled"] - compiled_after_first >= 19  # the literal form compiled new kernels every pass ...
+        st_only = _jit_info()["compiled"]
+        ops = _ansatz(n, rng.uniform(0.05, 3.0, (4, n)))
+        st.upload(x)
+        st.apply_ops(ops)
+        assert _jit_info()["compiled"] == st_only  # ... the parametrised form none after its first
+        # as a captured program: the parameters travel through the arena; re-recording with new angles reuses the kernels
+        st.upload(x)
+        prog = st.compile_program(ops)
+        prog.run()
+        assert prog.is_graph and _jit_info()["compiled"] == st_only
+        ref.upload(x)
+        ref.apply_ops(ops)
+        assert np.array_equal(st.download(), ref.download())
+        prog.close()
+
+
+def test_jit_cache_is_bounded_and_programs_survive_evictions():
+    """global option jit_cache_cap: least recently used kernels are unloaded beyond the bound; a program recorded into a
+    hipGraph notices that an eviction happened since and re-records (its kernels are compiled again) instead of launching
+    an unloaded module."""
+    n = 14
+    x = circuits.random_state(n, seed=8)
+    base = _jit_info()
+    q.set_global_option("jit_cache_cap", 3)
+    try:
+        with q.HipState(n) as st, q.HipState(n) as ref:
+            st.set_option("tile", 1)
+            st.set_option("tile_jit", 1)
+            first = circuits.c2_random_circuit(n, 40, seed=1)
+            st.upload(x)
+            prog = st.compile_program(first)
+            prog.run()
+            assert prog.is_graph
+            ref.upload(x)
+            ref.apply_ops(first)
+            assert np.array_equal(st.download(), ref.download())
+            for seed in range(2, 8):  # new sources push the program's kernels out
+                st.apply_ops(circuits.c2_random_circuit(n, 40, seed=seed))
+            info = _jit_info()
+            assert info["resident"] <= 3 and info["evicted"] > base["evicted"] and info["cap"] == 3
+            st.upload(x)
+            prog.run()  # re-records: the evicted kernels are compiled again
+            assert np.array_equal(st.download(), ref.download())
+            assert _jit_info()["compiled"] > info["compiled"]
+            prog.close()
+    finally:
+        q.set_global_option("jit_cache_cap", 512)
+
+
+def test_two_threads_compile_and_run_segments_at_once():
+    """'separate handles are independent': two host threads, each with its own state, both with tile_jit, hammering the
+    process-wide run-time compiler (loader, cache, counters) at the same time — results stay bit-identical to the
+    interpreter sweeps."""
+    import threading
+
+    n = 13
+    errors = []
+
+    def work(tid):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            x = circuits.random_state(n, seed=tid)
+            with q.HipState(n) as st, q.HipState(n) as ref:
+                st.set_option("tile", 1)
+                st.set_option("tile_jit", 1 + tid % 2)
+                ref.set_option("tile", 1)
+                for it in range(12):
+                    ops = circuits.c2_random_circuit(n, 30, seed=int(rng.integers(0, 1 << 30)))
+                    st.upload(x)
+                    st.apply_ops(ops)
+                    ref.upload(x)
+                    ref.apply_ops(ops)
+                    if not np.array_equal(st.download(), ref.download()):
+                        errors.append((tid, it, "mismatch"))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((tid, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_sparse_on_many_qubits_out_of_place_ell_kernel(O, dtype):
+    """SparseMatrix on k >= 6 qubits with <= 4 entries per row (k_sparse_ell; the reference's bench shape is a 16-qubit
+    sparse identity, state_bench.rs:380-393): rows in stored order folded from 0, repeated columns and ragged rows included,
+    optionally controlled, targets in any order — bit-equal to the oracle; wider rows fall back to the literal kernel."""
+    n = 18
+    rng = np.random.default_rng(11)
+    x = circuits.random_state(n, seed=5, dtype=dtype)
+
+    def rand_rows(k, width, phases=True):
+        rows = []
+        for r in range(1 << k):
+            w = int(rng.integers(1, width + 1))
+            ent = []
+            for _ in range(w):
+                c = int(rng.integers(0, 1 << k))
+                v = complex(np.exp(1j * rng.uniform(0, 6))) if phases else complex(rng.standard_normal(), rng.standard_normal())
+                ent.append((c, v))
+            rows.append(ent)
+        return rows
+
+    k16 = [[(r, 1.0)] for r in range(1 << 16)]                                   # the bench's identity
+    perm = rng.permutation(1 << 8)
+    perm_phase = [[(int(perm[r]), complex(np.exp(1j * 0.1 * r)))] for r in range(1 << 8)]  # a generalised permutation
+    cases = [
+        ("identity16", q.make_sparse_matrix_op(list(range(16)), k16)),
+        ("identity16_scattered", q.make_sparse_matrix_op([int(v) for v in rng.permutation(n)[:16]], k16)),
+        ("perm_phase8", q.make_sparse_matrix_op([17, 0, 9, 3, 12, 5, 1, 16], perm_phase)),
+        ("two_per_row6", q.make_sparse_matrix_op([2, 17, 8, 0, 11, 5], rand_rows(6, 2))),
+        ("four_per_row7_ragged", q.make_sparse_matrix_op([4, 1, 16, 9, 13, 0, 7], rand_rows(7, 4, phases=False))),
+        ("controlled6", q.make_control_op([3, 17], q.make_sparse_matrix_op([0, 6, 10, 12, 15, 1], rand_rows(6, 3)))),
+        ("five_per_row6_literal", q.make_sparse_matrix_op([2, 17, 8, 0, 11, 5], rand_rows(6, 5))),
+    ]
+    with q.HipState(n, dtype) as st:
+        st.set_option("profile", 1)
+        for name, op in cases:
+            st.upload(x)
+            st.profile_reset()
+            st.apply_op(op)
+            got = st.download()
+            want = O.apply_ops_in_place(n, [op], x.copy())
+            assert np.array_equal(got, want), name
+            prof = st.profile()
+            assert ("k_gather_generic" in prof) == (name == "five_per_row6_literal"), (name, prof)
+
+
+def test_soft_measure_map_sample_sweep_f64_and_f32(O):
+    """How often does the device's sample -> outcome map differ from the reference's sequential scan
+    (measurement_ops.rs:153-176: r -= |amp_i|^2 until r <= 0)?  10^4 samples each.
+    f64: the device subtracts chunk sums (summed in another order) and replays only the crossing chunk sequentially, so a
+    disagreement needs the sample within rounding of a chunk boundary: 0 of 10^4 here.
+    f32: the reference subtracts 2^n single-precision numbers from a single-precision r one after the other — every
+    subtraction rounds to ~6e-8 relative of r, so at n = 14 its own crossing point is already off by thousands of ulps and
+    amplitudes below r * 6e-8 do not move r at all — while the device accumulates the chunk sums in double.  The two maps
+    therefore agree only where the sample is far from a boundary on the f32 scale: the fraction that differs is measured and
+    bounded here (it is the reference's rounding, not the device's), and the distributions agree (chi-square over outcomes)."""
+    rng = np.random.default_rng(2024)
+    samples = rng.uniform(0, 1, 10000)
+    n = 14
+    idx = [0, 5, 13]
+    x = rand_state(n, 77)
+    with q.HipState(n) as st:
+        st.upload(x)
+        got = np.array([st.soft_measure(idx, float(r)) for r in samples])
+    want = np.array([O.soft_measure(n, idx, x, float(r)) for r in samples])
+    assert int(np.count_nonzero(got != want)) == 0
+    x32 = x.astype(np.complex64)
+    with q.HipState(n, np.complex64) as st:
+        st.upload(x32)
+        got32 = np.array([st.soft_measure(idx, float(r)) for r in samples])
+    want32 = np.array([O.soft_measure(n, idx, x32, float(r)) for r in samples])
+    differ = int(np.count_nonzero(got32 != want32))
+    print(f"f32 soft_measure: {differ} of {len(samples)} samples map to another outcome than the reference's f32 scan")
+    assert differ <= 100, differ  # ~1e-3 expected: samples within the f32 scan's accumulated rounding of an outcome boundary
+    # the device's f32 outcomes are those of the exact (double) cumulative sums of the same f32 amplitudes
+    p = np.abs(x32.astype(np.complex128)) ** 2
+    cum = np.cumsum(p)
+    exact_idx = np.minimum(np.searchsorted(cum, samples.astype(np.float32).astype(np.float64), side="left"), (1 << n) - 1)
+    exact = np.array([sum(((int(i) >> (n - 1 - qq)) & 1) << b for b, qq in enumerate(idx)) for i in exact_idx])
+    assert int(np.count_nonzero(got32 != exact)) <= 2
+    probs = O.measure_probs(n, idx, x).astype(np.float64)
+    for outcomes in (got32, want32):
+        counts = np.bincount(outcomes, minlength=8).astype(np.float64)
+        chi2 = float(np.sum((counts - len(samples) * probs) ** 2 / (len(samples) * probs)))
+        assert chi2 < 40, chi2  # 7 degrees of freedom
+
+
+def test_relabelled_layout_persists_across_apply_ops_calls(O):
+    """option tile_relabel = 3: a circuit applied in chunks keeps the scheduler's qubit layout between the calls — fewer
+    sweeps than paying the restoring permutation after every chunk — and whatever needs the caller's order (download,
+    measurement, a gate-by-gate call, a second state's comparison) restores it first.  Only moves differ: bit-identical
+    to the plain tile sweeps and to the oracle."""
+    n = 18
+    ops = circuits.c2_random_circuit(n, 240, seed=41)
+    x = circuits.random_state(n, seed=4)
+    want = O.apply_ops_in_place(n, ops, x.copy())
+
+    def run(relabel, chunks):
+        with q.HipState(n) as st:
+            st.set_option("tile", 1)
+            st.set_option("tile_relabel", relabel)
+            st.set_option("profile", 1)
+            st.upload(x)
+            st.profile_reset()
+            step = len(ops) // chunks
+            for c in range(chunks):
+                st.apply_ops(ops[c * step:(c + 1) * step if c + 1 < chunks else len(ops)])
+            prof = st.profile()
+            sweeps = sum(v["launches"] for v in prof.values())
+            perms = prof.get("k_permute_bits", {}).get("launches", 0)
+            got = st.download()
+            return got, sweeps, perms
+
+    plain, sweeps_plain, _ = run(0, 6)
+    each, sweeps_each, perms_each = run(2, 6)     # relabel, restore after every chunk
+    kept, sweeps_kept, perms_kept = run(3, 6)     # relabel, layout kept between the chunks
+    assert np.array_equal(plain, want) and np.array_equal(each, want) and np.array_equal(kept, want)
+    assert perms_kept == 0 and perms_each >= 4
+    assert sweeps_kept < sweeps_each and sweeps_kept <= sweeps_plain, (sweeps_plain, sweeps_each, sweeps_kept)
+    # everything that addresses amplitudes sees the caller's order
+    with q.HipState(n) as st, q.HipState(n) as ref:
+        st.set_option("tile", 1)
+        st.set_option("tile_relabel", 3)
+        st.upload(x)
+        ref.upload(x)
+        st.apply_ops(ops[:80])
+        ref.apply_ops(ops[:80])
+        assert np.array_equal(st.measure_probs([0, 7, n - 1]), ref.measure_probs([0, 7, n - 1]))  # settles
+        st.apply_ops(ops[80:160])
+        ref.apply_ops(ops[80:160])
+        assert st.max_abs_diff(ref) == (0.0, 0)
+        st.apply_ops(ops[160:200])
+        st.apply_op(ops[200])  # a single op: gate-by-gate entry point
+        ref.apply_ops(ops[160:201])
+        assert np.array_equal(st.download(1000, 4096), ref.download(1000, 4096))
+        st.apply_ops(ops[201:])
+        ref.apply_ops(ops[201:])
+        prog = st.compile_program(ops[:40])  # a capture starts and ends in the caller's order
+        prog.run()
+        ref.apply_ops(ops[:40])
+        assert np.array_equal(st.download(), ref.download())
+        prog.close()
+        st.apply_ops(ops[40:120])
+        st.init_basis(3)  # overwrites: no restoring sweep needed, and none left pending
+        e = np.zeros(1 << n, dtype=np.complex128)
+        e[3] = 1
+        assert np.array_equal(st.download(), e)

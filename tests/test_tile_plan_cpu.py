@@ -5,6 +5,7 @@ result must match the oracle applying the circuit gate by gate.  Covers: schedul
 free-bit selection, pass grouping, the lane-bit assignment, the dispatch codes and pass-bit indices the host
 resolves, the split of controls into pass-bit / lane-bit / outside-the-tile parts, 2-qubit matrix order."""
 import cmath
+import math
 
 import numpy as np
 import pytest
@@ -340,3 +341,43 @@ def test_run_time_compiled_segments_build_without_a_gpu():
         assert "constexpr TileGate<T> g" in src and "pass_" in src and "#include \"qip_kernels.h\"" in src
         assert r["all_sources_contain"]("pass_dense3<T") if "all_sources_contain" in r else True
         assert ("typedef double T;" in src) == (dtype == _ffi.QIP_C64)
+
+
+def test_parametrised_segments_keep_their_source_when_angles_change():
+    """option tile_jit = 2 (host hook: mode bit 6): a segment's numbers are kernel data (P[k] reads), its structure is code.
+    New rotation angles give the SAME source — the cache key — so a variational loop compiles once; a value that becomes
+    exactly 0 or +-1 is structure (zero-skipping, unit entries) and changes it.  Also in the contraction flavour (bit 5)."""
+    import re
+
+    from rustqip_amd.ops import debug_tile_jit
+
+    n = 14
+
+    def ansatz(thetas):
+        ops = []
+        for layer in range(2):
+            for t in range(8):
+                ops.append(q.make_matrix_op([t], circuits.rz(thetas[layer][t])))
+                c, s = math.cos(thetas[layer][t] / 2), math.sin(thetas[layer][t] / 2)
+                ops.append(q.make_matrix_op([t + 3], [c, -s, s, c]))  # a real rotation
+                ops.append(q.make_control_op([t], q.make_matrix_op([t + 5], circuits.X)))
+            ops.append(q.make_control_op([1], q.make_matrix_op([9], [1, 0, 0, cmath.rect(1, thetas[layer][0])])))
+        return ops
+
+    rng = np.random.default_rng(1)
+    a = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 1 | 64)
+    b = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 1 | 64)
+    assert a["segments"] >= 1 and a["first_source"] == b["first_source"] and a["source_bytes"] == b["source_bytes"]
+    src = a["first_source"]
+    assert "const T* __restrict__ P" in src and len(re.findall(r"P\[\d+\]", src)) >= 16 and "constexpr TileGate<T> g" not in src
+    assert "{0.0, 1.0}" in src or "{1.0, 0.0}" in src  # units and zeros stay literals (X, the unit diagonal entry)
+    lit_a = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 1)
+    lit_b = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 1)
+    assert lit_a["first_source"] != lit_b["first_source"] and "P[" not in lit_a["first_source"]
+    # an angle of exactly 0 turns Rz into the identity on one side and the rotation into units / zeros: different structure
+    th = rng.uniform(0.1, 3, (2, 8))
+    th[0][2] = 0.0
+    c = debug_tile_jit(n, ansatz(th), 1 | 64)
+    assert c["first_source"] != a["first_source"]
+    d = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 2 | 32 | 64)  # tile = 2, contraction allowed, parametrised
+    assert d["segments"] >= 1 and d["code_bytes"] > 0

@@ -55,6 +55,9 @@ def main():
         ("Swap(3)", q.make_swap_op([hi, 1, 2], [mid, lo, lo - 1]), {}),
         ("dense k=2 (VALU regs)", q.make_matrix_op([hi, mid], rand_unitary(2, rng).ravel()), {}),
         ("dense k=2, low bits", q.make_matrix_op([lo, lo - 1], rand_unitary(2, rng).ravel()), {}),
+        ("dense k=2, one low bit", q.make_matrix_op([mid, lo], rand_unitary(2, rng).ravel()), {}),
+        ("dense k=2, bits 12 and 13", q.make_matrix_op([n - 1 - 12, n - 1 - 13], rand_unitary(2, rng).ravel()), {}),
+        ("dense k=3, one low bit", q.make_matrix_op([hi, mid, lo], rand_unitary(3, rng).ravel()), {}),
         ("dense k=3 (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {}),
         ("dense k=3 (VALU regs)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 0}),
         ("dense k=3 low bits (MFMA f64)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {}),
@@ -77,6 +80,11 @@ def main():
         ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {"force_generic": 1}),
         ("sparse k=4, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7], [[(r, 0.6), (r ^ 5, 0.8j)] for r in range(16)]), {}),
         ("sparse k=5, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(32)]), {}),
+        ("sparse k=16 identity, one entry per row (state_bench.rs:380-393 shape)", q.make_sparse_matrix_op(list(range(16)), [[(r, 1.0)] for r in range(1 << 16)]), {}),
+        ("sparse k=16 identity on the low 16 bits", q.make_sparse_matrix_op(list(range(n - 16, n)), [[(r, 1.0)] for r in range(1 << 16)]), {}),
+        ("sparse k=8 permutation x phase, scattered bits", q.make_sparse_matrix_op([hi, 3, mid, 7, lo, 11, n - 9, 20], [[(int(c), complex(np.exp(0.1j * r)))] for r, c in enumerate(np.random.default_rng(1).permutation(256))]), {}),
+        ("sparse k=6, 2 entries per row", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), {}),
+        ("sparse k=6, 2 entries per row (literal gather)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), {"force_generic": 1}),
         ("H via literal gather", q.make_matrix_op([mid], circuits.H), {"force_generic": 1}),
     ]
     if f32:
@@ -87,6 +95,8 @@ def main():
                   ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0})]
         cases += [("H, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.H), {"packed_f32": 0}),
                   ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
+    if os.environ.get("QIP_SINGLE_VIA_TILE"):  # tuning aid: 0 = dedicated kernels only, 1 (default) / 2 = one-item tile sweeps
+        q.set_global_option("single_via_tile", int(os.environ["QIP_SINGLE_VIA_TILE"]))
     print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
     with q.HipState(n, dtype) as st:
         st.init_basis(0)
