@@ -42,7 +42,7 @@ int64_t g_perm_rows = 0;
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
 // taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
 int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;
-int64_t g_single_via_tile = 2;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 1;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
@@ -63,6 +63,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
   if (key && !strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
+  if (key && !strcmp(key, "single_via_tile_f32")) { g_single_via_tile_f32 = value; return QIP_OK; }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
 } QIP_CATCH_ALL
 
@@ -481,7 +482,7 @@ extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) try {
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_sync(qip_hip_state* s) try {
-  STATE_ENTER(s);
+  STATE_ENTER_RAW(s);  // (no amplitude is addressed: a relabelled state stays as it is)
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
 } QIP_CATCH_ALL
@@ -543,7 +544,7 @@ static int prof_drain(qip_hip_state* s) {
 
 extern "C" int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
                                          double* total_ms, double* algorithmic_bytes) try {
-  STATE_ENTER(s);
+  STATE_ENTER_RAW(s);  // (no amplitude is addressed: a relabelled state stays as it is)
   if (cls < 0 || cls >= KC_COUNT) return fail(QIP_ERR_INVALID, "bad kernel class %d", cls);
   QCHK(prof_drain(s));
   if (launches) *launches = s->prof_launches[cls];
@@ -552,7 +553,7 @@ extern "C" int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* la
   return QIP_OK;
 } QIP_CATCH_ALL
 extern "C" int qip_hip_state_profile_reset(qip_hip_state* s) try {
-  STATE_ENTER(s);
+  STATE_ENTER_RAW(s);  // (no amplitude is addressed: a relabelled state stays as it is)
   QCHK(prof_drain(s));
   for (int c = 0; c < KC_COUNT; ++c) {
     s->prof_launches[c] = 0;

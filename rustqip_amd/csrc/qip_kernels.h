@@ -930,27 +930,51 @@ struct EllDesc {
   uint32_t lo[32], len[32], shift[32];
 };
 
-template <typename T, int E, int U, bool NT>
+// FULL: every row has exactly E entries (no count to fetch); CTL: the op has controls (rows outside their subspace copy).
+// A lane's U rows go through the three dependent fetches — table entry, gathered amplitude, store — side by side: all table
+// reads are issued before the first gather, all gathers before the first store.  Table slots beyond a row's count hold
+// (offset 0, value 0): their loads are harmless and their terms are NOT added (the fold sees exactly the stored entries).
+template <typename T, int E, int U, bool NT, bool FULL, bool CTL>
 __global__ __launch_bounds__(kBlock) void k_sparse_ell(const amp_t<T>* __restrict__ in, amp_t<T>* __restrict__ out, EllDesc d,
                                                        const uint32_t* __restrict__ nnz, const uint64_t* __restrict__ off,
                                                        const amp_t<T>* __restrict__ val) {
   using A = amp_t<T>;
+  uint64_t r[U], rbase[U];
+  uint32_t m[U], cnt[U];
+  A acc[U], keep[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const uint64_t r = work_index<Log2<U>::v>(u);
-    if ((r & d.cmask) != d.cmask) {
-      stg<NT>(out + r, ldg<NT>(in + r));  // 0 + 1 * x
-      continue;
-    }
-    uint32_t m = 0;
-    for (uint32_t j = 0; j < d.nruns; ++j) m |= (uint32_t)((r >> d.lo[j]) & ((1ull << d.len[j]) - 1ull)) << d.shift[j];
-    const uint64_t rbase = r & ~d.opmask;
-    const uint32_t cnt = nnz[m];
-    A acc = czero<A>();
+    r[u] = work_index<Log2<U>::v>(u);
+    uint32_t mm = 0;
+    for (uint32_t j = 0; j < d.nruns; ++j) mm |= (uint32_t)((r[u] >> d.lo[j]) & ((1ull << d.len[j]) - 1ull)) << d.shift[j];
+    m[u] = mm;
+    rbase[u] = r[u] & ~d.opmask;
+    acc[u] = czero<A>();
+  }
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if ((uint32_t)e < cnt) acc = cadd(acc, cmul(val[(uint64_t)m * E + e], in[rbase | off[(uint64_t)m * E + e]]));
-    stg<NT>(out + r, acc);
+  for (int u = 0; u < U; ++u) {
+    cnt[u] = FULL ? (uint32_t)E : nnz[m[u]];
+    if (CTL) keep[u] = ldg<NT>(in + r[u]);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    uint64_t o[U];
+    A v[U], x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      o[u] = off[(uint64_t)m[u] * E + e];
+      v[u] = val[(uint64_t)m[u] * E + e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = in[rbase[u] | o[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (FULL || (uint32_t)e < cnt[u]) acc[u] = cadd(acc[u], cmul(v[u], x[u]));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool active = !CTL || (r[u] & d.cmask) == d.cmask;
+    stg<NT>(out + r[u], active ? acc[u] : keep[u]);  // outside the controls: 0 + 1 * x
   }
 }
 

@@ -841,14 +841,27 @@ static int launch_sparse_ell(qip_hip_state* s, const Plan& p, const FlatOp& f, b
   const dim3 grid = grid2d(s->namps, kBlock * U);
   const amp_t<T>* in = (const amp_t<T>*)s->cur;
   amp_t<T>* out = (amp_t<T>*)s->alt;
-#define ELL(EE)                                                                                                              \
-  do {                                                                                                                       \
-    if (use_nt(s)) hipLaunchKernelGGL((k_sparse_ell<T, EE, U, true>), grid, dim3(kBlock), 0, s->stream, in, out, d, dn, doff, dval);  \
-    else hipLaunchKernelGGL((k_sparse_ell<T, EE, U, false>), grid, dim3(kBlock), 0, s->stream, in, out, d, dn, doff, dval);           \
+  bool full = true;
+  for (uint64_t r = 0; r < rows; ++r) full = full && rp[r + 1] - rp[r] == E;
+  const bool ctl = d.cmask != 0;
+#define ELL2(EE, NTV, FULLV, CTLV) \
+  hipLaunchKernelGGL((k_sparse_ell<T, EE, U, NTV, FULLV, CTLV>), grid, dim3(kBlock), 0, s->stream, in, out, d, dn, doff, dval)
+#define ELL(EE)                                                 \
+  do {                                                          \
+    const bool nt = use_nt(s);                                  \
+    if (nt && full && ctl) ELL2(EE, true, true, true);          \
+    else if (nt && full) ELL2(EE, true, true, false);           \
+    else if (nt && ctl) ELL2(EE, true, false, true);            \
+    else if (nt) ELL2(EE, true, false, false);                  \
+    else if (full && ctl) ELL2(EE, false, true, true);          \
+    else if (full) ELL2(EE, false, true, false);                \
+    else if (ctl) ELL2(EE, false, false, true);                 \
+    else ELL2(EE, false, false, false);                         \
   } while (0)
   if (E == 1) ELL(1);
   else if (E == 2) ELL(2);
   else ELL(4);
+#undef ELL2
 #undef ELL
   HIPCHK(hipGetLastError());
   std::swap(s->cur, s->alt);  // builder.rs:514
@@ -875,13 +888,21 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
   // shapes measured), and the arithmetic is the unfused register fold of k_gate_kq — IEEE-equal to the dedicated VALU kernel
   // and to the oracle, where the matrix-core form of k = 3 is an fma chain.  Measured at n = 30 (profiles/r03_ops_table.md):
   // k = 2 73 -> 77 % (bits 0, 1: 59 -> 77), k = 3 70 -> 79 % (bits 0-2: 58 -> 78), Swap(1) n-1 <-> 0 75 -> 82 %.
-  // Global option "single_via_tile": 0 = dedicated kernels only, 1 = only when a target lies inside a row, 2 (default) = always.
+  // Uncontrolled dense single-qubit gates on a position above the rows take the same route (H / X over all targets at n = 30:
+  // median 6.53 TB/s against 6.30 for k_gate1q_pair; positions 0..5 keep the cross-lane kernel, 6.5 TB/s).
+  // Global option "single_via_tile": 0 = dedicated kernels only, 1 = only when a target lies inside a row, 2 = every dense
+  // k = 2, 3 and low-bit swap, 3 (default) = single-qubit gates as well.
   if (g_single_via_tile && !s->force_generic && !g_force_generic && s->mfma != 0 && s->unroll == 0 && !s->swap_single &&
-      (p.cls == KC_GATE_KQ || p.cls == KC_GATE_KQ_MFMA || p.cls == KC_SWAP_BITS) && p.cpos.empty() && s->n >= 17) {
+      (p.cls == KC_GATE_KQ || p.cls == KC_GATE_KQ_MFMA || p.cls == KC_SWAP_BITS || (p.cls == KC_GATE1Q_PAIR && g_single_via_tile >= 3)) &&
+      p.cpos.empty() && s->n >= 17) {
     bool low = false;
     for (uint32_t t : p.opos) low = low || t < 6;
-    const bool dense23 = p.cls != KC_SWAP_BITS && (p.opos.size() == 2 || p.opos.size() == 3);
-    if ((dense23 && (low || g_single_via_tile >= 2)) || (p.cls == KC_SWAP_BITS && low)) {
+    // Complex<f32>: a tile row is 512 B (8-byte amplitudes) while the dedicated kernels sweep packed 16-byte elements, so only
+    // the shapes whose dedicated form reads pieces of a row go through the sweep (global option "single_via_tile_f32" widens it)
+    const int64_t mode = std::is_same<T, double>::value ? g_single_via_tile : std::min<int64_t>(g_single_via_tile, g_single_via_tile_f32);
+    const bool dense23 = p.cls != KC_SWAP_BITS && p.cls != KC_GATE1Q_PAIR && (p.opos.size() == 2 || p.opos.size() == 3);
+    const bool dense1 = p.cls == KC_GATE1Q_PAIR && !low && mode >= 3;
+    if ((dense23 && (low || mode >= 2)) || (p.cls == KC_SWAP_BITS && low) || dense1) {
       bool done = false;
       QCHK(tile_apply_single<T>(s, op, &done));
       if (done) return QIP_OK;

@@ -97,6 +97,8 @@ def main():
                   ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
     if os.environ.get("QIP_SINGLE_VIA_TILE"):  # tuning aid: 0 = dedicated kernels only, 1 (default) / 2 = one-item tile sweeps
         q.set_global_option("single_via_tile", int(os.environ["QIP_SINGLE_VIA_TILE"]))
+    if os.environ.get("QIP_SINGLE_VIA_TILE_F32"):
+        q.set_global_option("single_via_tile_f32", int(os.environ["QIP_SINGLE_VIA_TILE_F32"]))
     print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
     with q.HipState(n, dtype) as st:
         st.init_basis(0)

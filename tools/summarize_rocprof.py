@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     m = re.match(r"void qipk::(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else name.split("(")[0]
+    k = m.group(1) if m else name.split("(")[0]
+    return "k_tile_gates" if k == "k_tile_passes" else k  # (the profiling class of the tile sweeps keeps its first kernel's name)
 
 
 def main():
