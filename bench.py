@@ -268,7 +268,7 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     more = circuits.c2_random_circuit(n, 192, seed=29)
     leg("mixed_tile2_chunks", more[:48], False, seed=16, tile=2)
     leg("mixed_tile2_jit_chunks", more[48:96], False, seed=17, tile=2, tile_jit=1)
-    leg("mixed_tile2_jit_fma_relabel_chunks", more[96:144], False, seed=18, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+    leg("mixed_tile2_jit_fma_merge_relabel_chunks", more[96:144], False, seed=18, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
     leg("mixed_fuse5_chunks", more[144:192], False, seed=19, fuse=5)
     # the other BASELINE circuits as they are timed: run-time-compiled sweeps at full size.  QFT's controlled phases only
     # TEST their bits, so a chunk is closed over its H targets alone and holds what a timed segment holds.
@@ -276,6 +276,7 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs3_clifford_t_tile1_jit", circuits.c4_clifford_t(n, gates, seed=32), True, seed=21, tile=1, tile_jit=1)
     leg("configs4_grover_tile1_jit", circuits.c5_grover_iteration(n), True, seed=22, max_len=96, tile=1, tile_jit=1)
     leg("configs4_grover_dense_k3_tile1_jit", circuits.c5_grover_iteration(n, dense_k3=True), False, seed=23, max_len=96, tile=1, tile_jit=1)
+    leg("configs2_qft_tile2_jit_fma_merge", circuits.c3_qft(n)[:200], False, seed=24, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
     twin.close()
     # back to a product state for the timed part (the checked circuits entangled it): re-prepare and advance as before
     st.init_basis(0)
@@ -497,6 +498,10 @@ def main():
         extras["tiled_mode1_jit_relabel"] = leg(ops_mixed, tile=1, tile_jit=1, tile_relabel=1)
         extras["tiled_mode2_jit"] = leg(ops_mixed, tile=2, tile_jit=1)
         extras["tiled_mode2_jit_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_relabel=1)
+        # r3: multiply-add contraction + merged runs of diagonal gates in the compiled tile = 2 segments (1e-12 bar); tile_jit = 1
+        # compiles a segment's structure and takes its numbers as kernel data (tile_jit = 3: numbers as literals, for comparison)
+        extras["tiled_mode2_jit_fma_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
+        extras["tiled_mode1_jit_literal_relabel"] = leg(ops_mixed, tile=1, tile_jit=3, tile_relabel=1)  # (tuning aid: numbers as literals)
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -510,6 +515,9 @@ def main():
             extras[cname]["tile1_jit"].update({"segments_compiled": k1 - k0, "compile_ms_once": ms1 - ms0})
             if "clifford" in cname:  # (QFT and Grover are layered: the scheduler keeps the plain plan for them)
                 extras[cname]["tile1_jit_relabel"] = leg(cops, "ops", tile=1, tile_jit=1, tile_relabel=1)
+            if "qft" in cname:  # the issue-bound circuit: the 1e-12 mode with fused multiply-adds
+                extras[cname]["tile2_jit_fma"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1)
+                extras[cname]["tile2_jit_fma_merge"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28

@@ -254,11 +254,14 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    (IEEE-equal to the gate-by-gate path; a dense 3-qubit gate rides along as the unfused register fold,
  *                    i.e. equal to its gate-by-gate form under "mfma" = 0 — on the matrix cores it is an fma chain);
  *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
- *   "tile_jit"       1: every tile segment runs as a kernel compiled at run time for that very segment (hiprtc; the
- *                    gate list becomes constants of the code: no descriptor fetch, no dispatch, no control-mask tests
- *                    left), cached per process by its source.  Bit-identical to the interpreter (same helpers, same
- *                    order).  Pays ~0.3-1 s per NEW segment: for circuits that are replayed (programs, variational
- *                    loops), not for one-shot runs.  0 (default) = the interpreter kernel.
+ *   "tile_jit"       1: every tile segment runs as a kernel compiled at run time for that segment's STRUCTURE (hiprtc; op
+ *                    codes, bit positions, control masks, zero / unit / real shapes become constants of the code: no descriptor
+ *                    fetch, no dispatch left), cached per process by its source.  The segment's NUMBERS — every matrix component
+ *                    that is not exactly 0 or +-1 — are kernel data (scalar loads from the arena), so new rotation angles reuse
+ *                    the compiled kernel: a variational loop compiles once.  Bit-identical to the interpreter (same helpers,
+ *                    same order).  Pays ~0.3-1 s per NEW structure: for circuits that are replayed (programs, loops), not for
+ *                    one-shot runs.  2: same as 1 (kept for round-3 callers).  3 (tuning aid): numbers as literals in the
+ *                    source (every new angle is a new kernel).  0 (default) = the interpreter kernel.
  *   "tile_relabel"   1: the tile scheduler keeps a logical -> physical map of the qubits: at the end of every segment
  *                    in-tile bit swaps (riding along in the same sweep) put the qubits whose next amplitude-exchanging use
  *                    comes soonest on index bits 0..5, so the next segment spends its five free positions on five OTHER
@@ -278,6 +281,10 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *   "tile_fma"       1: run-time-compiled segments of "tile" = 2 are compiled with multiply-add contraction (v_fma_f64: a complex
  *                    product is 4 instead of 6 vector instructions; QFT at n = 30: 57 -> 50 ms).  Ignored for "tile" = 1, which
  *                    promises IEEE equality with the gate-by-gate path.  0 (default) = off.
+ *   "tile_merge"     1: in run-time-compiled segments of "tile" = 2, a run of consecutive diagonal gates (they all commute) is
+ *                    applied as PRODUCTS: each gate's factor joins the running product of the set of a lane's elements it acts on,
+ *                    each element then takes the product of its sets (QFT: ~33 complex products per lane after each H instead of
+ *                    116).  Rounding differs from the sequential products (1e-12 bar).  Ignored for "tile" = 1.  0 (default) = off.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

@@ -357,7 +357,8 @@ template <typename T> static std::string fnum(T v) {
 // A variational loop that updates its rotation angles produces the same source every time and re-uses the compiled kernel;
 // only a value that newly becomes (or stops being) 0 / +-1 changes the structure and compiles again.
 template <typename T>
-static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int remap = 0, std::vector<T>* params = nullptr) {
+static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int remap = 0, std::vector<T>* params = nullptr,
+                                   bool merge_diag = false) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   std::string o;
   auto L = [&](const std::string& line) { o += line; o += "\n"; };
@@ -419,9 +420,13 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   for (uint32_t pi = 0; pi < d.npasses; ++pi) {
     const TilePass& ps = d.pass[pi];
     L("  {  // pass " + std::to_string(pi));
+    // the pass's LDS addresses depend on the lane id alone: left alone hipcc computes those of EVERY pass up front and keeps
+    // them live (spills in segments of many passes); an opaque copy of the id per pass pins them behind the barrier before it
+    L("    uint32_t tidp = tidv;");
+    L("    asm volatile(\"\" : \"+v\"(tidp));");
     L("    uint32_t tb = 0;");
     for (int k = 0; k < kTileLaneBits; ++k)
-      L("    tb |= ((tidv >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
+      L("    tb |= ((tidp >> " + std::to_string(k) + ") & 1u) << " + std::to_string((unsigned)((ps.lanepos >> (4 * k)) & 15ull)) + ";");
     L("    const uint32_t slot_tb = tile_slot<A>(tb);");
     std::string cs = "    const uint32_t c[8] = {";
     for (int i = 0; i < 8; ++i) {
@@ -433,6 +438,66 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     for (int i = 0; i < 8; ++i) L("    e[" + std::to_string(i) + "] = tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])];");
     for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
       const TileGate<T>& g = plan.gates[gi];
+      // `merge_diag` (option "tile_merge", tile = 2 only: 1e-12 bar): a RUN of consecutive diagonal gates — they all commute —
+      // is applied as products.  Every gate contributes a factor (per lane: its lane-bit and outside-the-tile conditions
+      // select between its entry and 1) to the SET of the lane's eight elements its register-bit conditions pick; factors of
+      // one set are multiplied together first, then each element takes the product of its sets: QFT's 29 controlled phases
+      // after an H cost ~29 + 4 complex products per lane instead of 4 x 29.
+      if (merge_diag && g.kind == 1) {
+        uint32_t ge = gi;
+        while (ge < ps.first + ps.count && plan.gates[ge].kind == 1) ++ge;
+        if (ge - gi >= 3) {
+          std::vector<uint32_t> sets;  // element masks, in order of first appearance: F<k> is the running product of set k
+          L("    {  // gates " + std::to_string(gi) + " .. " + std::to_string(ge - 1) + ": one run of diagonal gates");
+          // (each factor joins its product at once: short live ranges.  `ucond`: a block-uniform condition — a control outside the
+          // tile — stays a BRANCH around the product, as in the gate-by-gate form: no work at all where the control reads 0)
+          auto add = [&](uint32_t mask, const std::string& expr, const std::string& ucond) {
+            if (!mask) return;
+            const std::string open = ucond.empty() ? "" : "if (" + ucond + ") { QIP_KEEP_BRANCH(); ", close = ucond.empty() ? "" : " }";
+            for (size_t k = 0; k < sets.size(); ++k)
+              if (sets[k] == mask) {
+                L("      " + open + "F" + std::to_string(k) + " = cmul(F" + std::to_string(k) + ", " + expr + ");" + close);
+                return;
+              }
+            if (ucond.empty()) L("      A F" + std::to_string(sets.size()) + " = " + expr + ";");
+            else L("      A F" + std::to_string(sets.size()) + " = {(T)1, (T)0}; " + open + "F" + std::to_string(sets.size()) + " = " + expr + ";" + close);
+            sets.push_back(mask);
+          };
+          for (uint32_t gj = gi; gj < ge; ++gj) {
+            const TileGate<T>& d = plan.gates[gj];
+            uint32_t ok = 0;  // elements whose register-bit controls are all 1
+            for (int i = 0; i < 8; ++i) {
+              const uint32_t ci = ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) | ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+              if ((ci & d.cm_reg) == d.cm_reg) ok |= 1u << i;
+            }
+            const std::string m0 = amp(d.m[0]), m1 = amp(d.m[1]);
+            const bool u0 = d.m[0].x == (T)1 && d.m[0].y == (T)0, u1 = d.m[1].x == (T)1 && d.m[1].y == (T)0;
+            // the conditions every element of the lane shares: controls outside the tile (block-uniform: a branch) and on lane
+            // bits (a select between the entry and 1)
+            const std::string ucond = d.omask ? "(base & " + U(d.omask) + ") == " + U(d.omask) : "";
+            const std::string lcond = d.cm_lane ? "((tb & " + std::to_string(d.cm_lane) + "u) == " + std::to_string(d.cm_lane) + "u)" : "";
+            auto guarded = [&](const std::string& f) { return lcond.empty() ? f : "tile_sel(" + lcond + ", " + f + ", A{(T)1, (T)0})"; };
+            if (d.op >= TOP_DIAG_REG0 && d.op <= TOP_DIAG_REG2) {
+              const int J = (int)(d.op - TOP_DIAG_REG0);
+              uint32_t half1 = 0;
+              for (int i = 0; i < 8; ++i)
+                if ((i >> J) & 1) half1 |= 1u << i;
+              if (!u0) add(ok & ~half1, guarded("A" + m0), ucond);
+              if (!u1) add(ok & half1, guarded("A" + m1), ucond);
+            } else {  // the target is a lane bit or lies outside the tile: one factor for every element the controls pick
+              const std::string one = d.b0 == kTileOutside ? "(((base >> " + std::to_string(d.tpos_out) + ") & 1ull) != 0)"
+                                                           : "(((tb >> " + std::to_string(d.b0) + ") & 1u) != 0)";
+              add(ok, guarded("tile_sel(" + one + ", A" + m1 + ", A" + m0 + ")"), ucond);
+            }
+          }
+          for (int i = 0; i < 8; ++i)
+            for (size_t si = 0; si < sets.size(); ++si)
+              if ((sets[si] >> i) & 1u) L("      e[" + std::to_string(i) + "] = cmul(F" + std::to_string(si) + ", e[" + std::to_string(i) + "]);");
+          L("    }");
+          gi = ge - 1;
+          continue;
+        }
+      }
       L("    {  // gate " + std::to_string(gi));
       {
         const std::string m0 = amp(g.m[0]), m1 = amp(g.m[1]), m2 = amp(g.m[2]), m3 = amp(g.m[3]);
@@ -501,6 +566,9 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
       }
       if (g.omask) L("      if ((base & g.omask) == g.omask) { " + call + " }");  // an outside control is 0 for this whole tile
       else L("      { " + call + " }");
+      // one gate at a time: left alone hipcc interleaves neighbouring gates up to the register budget of the launch bound and
+      // then spills (16 - 104 bytes of scratch per lane in the configs[1] segments, 104 vs 90 ms for the circuit)
+      L("      __builtin_amdgcn_sched_barrier(0);");
       L("    }");
     }
     for (int i = 0; i < 8; ++i) L("    tile[slot_tb ^ tile_slot<A>(c[" + std::to_string(i) + "])] = e[" + std::to_string(i) + "];");
@@ -581,9 +649,14 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
     hipFunction_t fn = nullptr;
     const bool fma = s->tile_fma && s->tile >= 2;  // tile = 1 promises IEEE equality with the gate-by-gate path: never fused
-    const bool parametrised = s->tile_jit >= 2;     // structure compiled, numbers in the arena (see tile_jit_source)
+    // structure compiled, numbers in the arena (see tile_jit_source): the default form.  tile_jit = 3 (tuning aid) writes the
+    // numbers into the source as literals instead: every constant then occupies vector registers (gfx950's VOP3 takes no
+    // 64-bit literal), which makes the configs[1] segments spill under the five-blocks-per-CU register bound (104 vs 90 ms),
+    // and every new angle is a new kernel; its one merit is ~3 % fewer multiplies in QFT where equal constants fold
+    const bool parametrised = s->tile_jit != 3;
     std::vector<T> params;
-    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr),
+    const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
+    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr, merge),
                         fma, &fn));
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
@@ -677,7 +750,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
     Ins ins = make_ins(plan.high, 0);
     std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
-    const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr);
+    const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
     std::vector<char> code;
     {
       std::lock_guard<std::mutex> lock(g_jit_mutex);

@@ -42,7 +42,7 @@ int64_t g_perm_rows = 0;
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
 // taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
 int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;
-int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 1;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
@@ -502,6 +502,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
   else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
   else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
+  else if (!strcmp(key, "tile_merge")) s->tile_merge = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

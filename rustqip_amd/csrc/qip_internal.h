@@ -156,9 +156,10 @@ struct qip_hip_state {
   // relabelling apply_ops first restores the caller's order with one bit-permutation sweep (state_settle, part of STATE_ENTER).
   std::vector<uint32_t> layout;
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
-  int64_t tile_jit = 0;     // 1 = tile segments run as kernels compiled at run time for that very segment (hiprtc, cached);
-                            // 2 = ... with the segment's numbers as kernel data (angles can change without recompiling)
+  int64_t tile_jit = 0;     // 1 (= 2) = tile segments run as kernels compiled at run time for that segment's STRUCTURE (hiprtc,
+                            // cached), its numbers are kernel data (angles can change without recompiling); 3 = numbers as literals
   int64_t tile_fma = 0;     // run-time-compiled segments of tile = 2: products may fuse into sums (1e-12 bar, not IEEE equality)
+  int64_t tile_merge = 0;   // ... and runs of diagonal gates are applied as products of their factors
   int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request

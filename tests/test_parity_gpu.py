@@ -1947,16 +1947,16 @@ def _ansatz(n, thetas):
 
 @pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
 def test_parametrised_segments_variational_loop_compiles_once(O, dtype):
-    """option tile_jit = 2: the segment's structure is code, its numbers are kernel data.  64 angles updated 20 times: the
+    """option tile_jit = 1: the segment's structure is code, its numbers are kernel data.  64 angles updated 20 times: the
     number of compiled kernels stays what the first pass made it; every pass is bit-identical to the interpreter sweeps and
-    to tile_jit = 1 (same arithmetic per amplitude), and the f64 result equals the oracle's."""
+    to tile_jit = 3 — numbers as literals — (same arithmetic per amplitude), and the f64 result equals the oracle's."""
     n = 16
     rng = np.random.default_rng(5)
     x = circuits.random_state(n, seed=3, dtype=dtype)
     compiled_after_first = None
     with q.HipState(n, dtype) as st, q.HipState(n, dtype) as ref:
         st.set_option("tile", 1)
-        st.set_option("tile_jit", 2)
+        st.set_option("tile_jit", 1)
         ref.set_option("tile", 1)
         for it in range(20):
             ops = _ansatz(n, rng.uniform(0.05, 3.0, (4, n)))  # 64 angles
@@ -1970,7 +1970,7 @@ def test_parametrised_segments_variational_loop_compiles_once(O, dtype):
                 compiled_after_first = _jit_info()["compiled"]
                 if dtype == np.complex128:
                     assert np.array_equal(got, O.apply_ops_in_place(n, ops, x.copy()))
-                ref.set_option("tile_jit", 1)  # from here on the reference is the literal run-time-compiled form
+                ref.set_option("tile_jit", 3)  # from here on the reference is the run-time-compiled form with literal numbers
         assert _jit_info()["compiled"] - compiled_after_first >= 19  # the literal form compiled new kernels every pass ...
         st_only = _jit_info()["compiled"]
         ops = _ansatz(n, rng.uniform(0.05, 3.0, (4, n)))
@@ -2036,7 +2036,7 @@ def test_two_threads_compile_and_run_segments_at_once():
             x = circuits.random_state(n, seed=tid)
             with q.HipState(n) as st, q.HipState(n) as ref:
                 st.set_option("tile", 1)
-                st.set_option("tile_jit", 1 + tid % 2)
+                st.set_option("tile_jit", 1 + 2 * (tid % 2))
                 ref.set_option("tile", 1)
                 for it in range(12):
                     ops = circuits.c2_random_circuit(n, 30, seed=int(rng.integers(0, 1 << 30)))
@@ -2204,3 +2204,47 @@ def test_relabelled_layout_persists_across_apply_ops_calls(O):
         e = np.zeros(1 << n, dtype=np.complex128)
         e[3] = 1
         assert np.array_equal(st.download(), e)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-12), (np.complex64, 2e-5)])
+def test_tile2_merged_diagonal_runs_and_fused_multiply_adds(O, dtype, tol):
+    """options tile_merge / tile_fma (tile = 2, run-time-compiled; 1e-12 bar): runs of diagonal gates applied as products of
+    their factors — QFT's controlled phases, multi-controlled phases with controls on lane, register and outside-the-tile bits,
+    Rz layers — against the oracle, with and without contraction; tile = 1 ignores both options (stays bit-identical)."""
+    n = 17
+    rng = np.random.default_rng(3)
+    diag_heavy = []
+    for _ in range(120):
+        perm = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            diag_heavy.append(q.make_matrix_op([perm[0]], circuits.H))
+        elif kind == 1:
+            diag_heavy.append(q.make_matrix_op([perm[0]], circuits.rz(float(rng.uniform(0, 3)))))
+        elif kind == 2:
+            diag_heavy.append(q.make_control_op(perm[:1], q.make_matrix_op([perm[1]], [1, 0, 0, cmath.rect(1, float(rng.uniform(0, 3)))])))
+        elif kind == 3:
+            diag_heavy.append(q.make_control_op(perm[:3], q.make_matrix_op([perm[3]], [1, 0, 0, cmath.rect(1, float(rng.uniform(0, 3)))])))
+        elif kind == 4:
+            diag_heavy.append(q.make_control_op(perm[:2], q.make_matrix_op([perm[2]], circuits.rz(float(rng.uniform(0, 3))))))
+        else:
+            diag_heavy.append(q.make_matrix_op([perm[0]], circuits.T))
+    x = circuits.random_state(n, seed=6, dtype=dtype)
+    for name, ops in (("qft", circuits.c3_qft(n)), ("diag_heavy", diag_heavy), ("c4", circuits.c4_clifford_t(n, 120, seed=2))):
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        for merge, fma in ((1, 0), (1, 1), (0, 1)):
+            with q.HipState(n, dtype) as st:
+                for k, v in (("tile", 2), ("tile_jit", 1), ("tile_merge", merge), ("tile_fma", fma)):
+                    st.set_option(k, v)
+                st.upload(x)
+                st.apply_ops(ops)
+                err = float(np.max(np.abs(st.download() - want)))
+                assert err <= tol, (name, merge, fma, err)
+                assert abs(st.norm_sqr() - 1) <= (1e-12 if dtype == np.complex128 else 1e-4)
+        if dtype == np.complex128:
+            with q.HipState(n) as st:
+                for k, v in (("tile", 1), ("tile_jit", 1), ("tile_merge", 1), ("tile_fma", 1)):
+                    st.set_option(k, v)
+                st.upload(x)
+                st.apply_ops(ops)
+                assert np.array_equal(st.download(), want), name

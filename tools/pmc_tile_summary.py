@@ -17,7 +17,7 @@ for f in sorted(glob.glob(root + "/pmc_tile*/*_counter_collection.csv")):
     dur = collections.Counter()
     for k, c in rows.items():
         name = meta[k][0]
-        if "tile" not in name:
+        if "tile" not in name and "qip_segment" not in name:  # (qip_segment: the run-time-compiled tile sweeps)
             continue
         key = name.split("(")[0][-40:]
         cnt[key] += 1
