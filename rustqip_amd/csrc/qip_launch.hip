@@ -487,6 +487,10 @@ extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi
     bool identity = true;
     if (!pi || n == 0 || n > 62) return fail(QIP_ERR_INVALID, "bad argument"), nullptr;
     if (check_bit_permutation(n, pi, &identity) != QIP_OK) return nullptr;
+    // an exported entry point: the two shape arguments index fixed-size tables of the descriptor, so they are checked here
+    // (the library itself only ever passes 5 / 6 and 3 / 4)
+    if (row_bits < 1 || 2 * row_bits > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "row_bits must be 1..%d", kPermMaxTile / 2), nullptr;
+    if (fold_bits > 4 || fold_bits > 2 * row_bits) return fail(QIP_ERR_INVALID, "fold_bits must be <= min(4, 2 * row_bits)"), nullptr;
     PermDesc d;
     if (make_perm_desc(n, pi, row_bits, fold_bits, &d) != QIP_OK) return nullptr;
     const uint32_t TB = 2 * row_bits;

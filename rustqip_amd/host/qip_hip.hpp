@@ -275,6 +275,15 @@ template <typename P> class HipState {
     check(qip_hip_state_permute_bits(h_, pi.data()));
   }
   void sync() { check(qip_hip_state_sync(h_)); }
+  /// two states side by side (validation support): device copy, and max |a_i - b_i| + the number of amplitudes that are not
+  /// IEEE-equal over the whole vector
+  void copy_from(HipState& other) { check(qip_hip_state_copy_from(h_, other.h_)); }
+  std::pair<double, uint64_t> max_abs_diff(HipState& other) {
+    double worst = 0;
+    uint64_t differ = 0;
+    check(qip_hip_state_max_abs_diff(h_, other.h_, &worst, &differ));
+    return {worst, differ};
+  }
   double norm_sqr() const {
     double v = 0;
     check(qip_hip_state_norm_sqr(h_, &v));
@@ -391,6 +400,13 @@ template <typename P> class DistState {
     std::vector<C> out(size_t(1) << n_local);
     check(qip_hip_state_download(sh, out.data(), 0, out.size()));
     return out;
+  }
+  /// soft_measure (measurement_ops.rs:153-176) of the sharded state: rank 0's sample decides; no collapse
+  size_t soft_measure(const std::vector<size_t>& indices, double rand_u01) {
+    std::vector<uint64_t> idx(indices.begin(), indices.end());
+    uint64_t m = 0;
+    check(qip_hip_dist_soft_measure(h_, idx.data(), (uint32_t)idx.size(), rand_u01, &m));
+    return (size_t)m;
   }
   qip_hip_dist_stats take_stats() {
     qip_hip_dist_stats st;

@@ -192,7 +192,17 @@ static void gpu_checks() {
     EXPECT(std::abs(ds.norm_sqr() - 1.0) < 1e-12);
     const auto pr = ds.measure_probs({0, 9}), pw = ref.measure_probs({0, 9});
     for (int m = 0; m < 4; ++m) EXPECT(std::abs(pr[m] - pw[m]) < 1e-13);
-    EXPECT(ds.layout().size() == n && ds.take_stats().remaps == 0);
+    const qip_hip_dist_stats stats = ds.take_stats();
+    EXPECT(ds.layout().size() == n && stats.remaps == 0);
+    EXPECT(stats.rccl_ranks == 1 && stats.rccl_rank == 0 && stats.piece_bytes == (1ull << 30));  // read back from the communicator
+    EXPECT(ds.soft_measure({0, 9}, 0.3) == ref.soft_measure({0, 9}, 0.3));
+    {
+      qip::HipState<double> twin(n);
+      twin.copy_from(ref);
+      EXPECT(twin.max_abs_diff(ref) == std::make_pair(0.0, (uint64_t)0));
+      twin.apply_ops({ops[3]});
+      EXPECT(twin.max_abs_diff(ref).second > 0);
+    }
     std::printf("sharded state (world 1, RCCL transport): max|delta| vs single-GPU state = %.1e\n", maxd);
     // a run of Swap ops composes to one bit permutation: [1,2] <-> [8,7] exchanges qubits 1/8 and 2/7 = index bits 8/1 and 7/2
     std::vector<uint32_t> pi(n);

@@ -144,3 +144,17 @@ def test_descriptor_at_bench_sizes_on_sampled_elements(n, row_bits, fold_bits):
         for dbit in range(n):
             assert np.array_equal((dst >> np.uint64(dbit)) & np.uint64(1), (src >> np.uint64(pi[dbit])) & np.uint64(1)), (n, dbit)
         assert int(dst.max()) < (1 << n) and int(src.max()) < (1 << n)
+
+
+def test_plan_hook_rejects_shapes_its_tables_cannot_hold():
+    """the exported hook indexes fixed-size tables with its two shape arguments: out-of-range values are errors, not writes
+    past the descriptor"""
+    import ctypes as C
+
+    n = 16
+    arr = (C.c_uint32 * n)(*range(n))
+    arr[0], arr[9] = 9, 0
+    for row_bits, fold_bits in ((0, 0), (7, 3), (5, 5), (1, 3), (40, 2)):
+        assert not _ffi.lib.qip_hip_debug_permute_plan(n, arr, row_bits, fold_bits), (row_bits, fold_bits)
+        assert "must be" in _ffi.last_error() or "does not fit" in _ffi.last_error()
+    assert _ffi.lib.qip_hip_debug_permute_plan(n, arr, 5, 3)
