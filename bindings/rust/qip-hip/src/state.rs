@@ -83,6 +83,17 @@ impl<P: HipPrecision> HipState<P> {
         std::mem::forget(flat); // bitwise copies of descriptors that `keep` owns
         check(rc)
     }
+    /// `self <- other`, device to device (same n, precision and device).
+    pub fn copy_from(&mut self, other: &mut HipState<P>) -> Result<(), HipError> {
+        check(unsafe { sys::qip_hip_state_copy_from(self.h, other.h) })
+    }
+    /// `(max_i |self_i - other_i|, number of amplitudes that are not IEEE-equal)` over the whole vector, on the device:
+    /// what the parity checks use to hold a state against a reference copy.
+    pub fn max_abs_diff(&mut self, other: &mut HipState<P>) -> Result<(f64, u64), HipError> {
+        let (mut worst, mut differ) = (0.0f64, 0u64);
+        check(unsafe { sys::qip_hip_state_max_abs_diff(self.h, other.h, &mut worst, &mut differ) })?;
+        Ok((worst, differ))
+    }
     pub fn norm_sqr(&self) -> Result<f64, HipError> {
         let mut v = 0.0;
         check(unsafe { sys::qip_hip_state_norm_sqr(self.h, &mut v) })?;

@@ -42,7 +42,8 @@ int64_t g_perm_rows = 0;
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
 // taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
 int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;
-int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;
+int64_t g_force_k4_direct = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "force_generic")) {
     g_force_generic = value;
@@ -63,6 +64,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
   if (key && !strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
+  if (key && !strcmp(key, "k4_direct")) { g_force_k4_direct = value; return QIP_OK; }
   if (key && !strcmp(key, "single_via_tile_f32")) { g_single_via_tile_f32 = value; return QIP_OK; }
   return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
 } QIP_CATCH_ALL

@@ -1536,6 +1536,94 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
   }
 }
 
+// ---- dense 4-qubit gate on the matrix cores through an LDS-resident tile -------------------------------------------------
+// k_gate_kq_mfma reads its operands where they lie: 16 groups x 4 sub-indices per load instruction = four 256-B runs, 65 %
+// of peak for k = 4 whatever the target bits.  Here a block stages the tile the one-op sweeps use — index bits 0..5 + the
+// gate's targets above them + free positions from 11 upwards, whole 1-KiB rows on both global sides — and the wave takes
+// its matrix-core operands from LDS: same lane mapping (lane = (group j, q), c~ = 4 m + q over the targets in ascending
+// position order), same host-built A fragments (16 values per lane for k = 4), same fma chains (1e-12 bar), results written
+// back over the operands in LDS, then the tile is stored row by row.  The tile holds 2^7 groups = 8 items of 16: two per wave.
+struct TileMfmaDesc {
+  uint32_t hpos[kTileHigh];  // amplitude-index positions of tile bits 6..10 (ascending)
+  uint32_t tb[4];            // tile-bit index of the targets, ascending
+  uint32_t nb[kTileBits - 4];  // the other tile bits, ascending: nb[0..3] = group, nb[4..6] = item
+};
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kTileBlock, 5) void k_gate_k4_tile_mfma(amp_t<T>* __restrict__ st, Ins ins, TileMfmaDesc d,
+                                                                    const T* __restrict__ afrag) {
+  using A = amp_t<T>;
+  using V4 = typename Acc4<T>::type;
+  constexpr int K = 4, S = 16, TT = S / 8, KS = S / 2, NA = S / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  A* tile = reinterpret_cast<A*>(tile_raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t wbase = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
+#pragma unroll
+  for (int j = 0; j < kTileWaveBits; ++j) wbase |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
+  const uint32_t slot_tid = tile_slot<A>(tid);
+  // the gate's fragments while the rows are on their way
+  T a[TT][KS];
+#pragma unroll
+  for (int rb = 0; rb < TT; ++rb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[rb][s] = afrag[(rb * KS + s) * 64 + lane];
+  {
+    A x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
+                          ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
+      x[u] = ldg<NT>(st + ub + lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = x[u];
+  }
+  __syncthreads();
+  // lane = (group j, q): j fills the four lowest non-target tile bits, q the two lowest targets
+  const uint32_t j = lane & 15u, q = lane >> 4;
+  uint32_t t_lane = ((q & 1u) << d.tb[0]) | ((q >> 1) << d.tb[1]);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) t_lane |= ((j >> b) & 1u) << d.nb[b];
+  const uint32_t slot_lane = tile_slot<A>(t_lane);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const uint32_t item = wave * 2u + (uint32_t)it;  // (wave-uniform)
+    uint32_t t_item = 0;
+#pragma unroll
+    for (int b = 0; b < kTileBits - 4 - 4; ++b) t_item |= ((item >> b) & 1u) << d.nb[4 + b];
+    uint32_t slot[NA];
+    A x[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) {
+      const uint32_t t_m = t_item | (((uint32_t)m & 1u) << d.tb[2]) | (((uint32_t)m >> 1) << d.tb[3]);
+      slot[m] = slot_lane ^ tile_slot<A>(t_m);
+      x[m] = tile[slot[m]];
+    }
+#pragma unroll
+    for (int rb = 0; rb < TT; ++rb) {
+      V4 acc = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma16(a[rb][s], (s & 1) ? x[s >> 1].y : x[s >> 1].x, acc);
+      A y0, y1;
+      y0.x = acc[0];
+      y0.y = acc[1];
+      y1.x = acc[2];
+      y1.y = acc[3];
+      tile[slot[2 * rb]] = y0;      // every amplitude of the tile belongs to exactly one lane: in place
+      tile[slot[2 * rb + 1]] = y1;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
+                        ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
+    stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+  }
+}
+
 // ---- literal fallback: one output row per lane, out of place ------------------------------
 // The gather formulation of the reference, variant by variant (matrix_ops.rs:62-94,
 // ops.rs:100-156, qubit_iterators.rs).  Correct for every descriptor the reference accepts,

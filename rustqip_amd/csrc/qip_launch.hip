@@ -546,6 +546,58 @@ static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::ve
       }
 }
 
+// dense k = 4 through the LDS-staged matrix-core kernel (k_gate_k4_tile_mfma).  *done = false when the op does not qualify:
+// controls inside a row, more than five positions above the rows, a state below one tile.
+template <typename T>
+static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool* done) {
+  *done = false;
+  if (p.opos.size() != 4 || s->n < (uint32_t)kTileBits + 6) return QIP_OK;
+  for (uint32_t c : p.cpos)
+    if (c < (uint32_t)kTileLow) return QIP_OK;
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<uint32_t> high;  // the tile's five positions above the rows: the targets there, then free ones from 11 upwards
+  for (uint32_t t : tau)
+    if (t >= (uint32_t)kTileLow) high.push_back(t);
+  auto taken = [&](uint32_t pp) {
+    return std::find(high.begin(), high.end(), pp) != high.end() || std::find(p.cpos.begin(), p.cpos.end(), pp) != p.cpos.end();
+  };
+  if (std::find(high.begin(), high.end(), 6u) != high.end() && !taken(7u) && high.size() < (size_t)kTileHigh) high.push_back(7u);
+  for (uint32_t pp = 11; high.size() < (size_t)kTileHigh && pp < s->n; ++pp)
+    if (!taken(pp)) high.push_back(pp);
+  for (uint32_t pp = kTileLow; high.size() < (size_t)kTileHigh && pp < s->n; ++pp)
+    if (!taken(pp)) high.push_back(pp);
+  if (high.size() != (size_t)kTileHigh) return QIP_OK;
+  std::sort(high.begin(), high.end());
+  TileMfmaDesc d;
+  memset(&d, 0, sizeof d);
+  for (int jx = 0; jx < kTileHigh; ++jx) d.hpos[jx] = high[jx];
+  auto tile_bit = [&](uint32_t pos) { return pos < (uint32_t)kTileLow ? pos : (uint32_t)kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin()); };
+  uint32_t is_target = 0;
+  for (int b = 0; b < 4; ++b) {
+    d.tb[b] = tile_bit(tau[b]);
+    is_target |= 1u << d.tb[b];
+  }
+  int nn = 0;
+  for (uint32_t b = 0; b < (uint32_t)kTileBits; ++b)
+    if (!((is_target >> b) & 1u)) d.nb[nn++] = b;
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
+  std::vector<uint32_t> opened = high;
+  for (uint32_t c : p.cpos) opened.push_back(c);
+  Ins ins = make_ins(opened, mask_of(p.cpos));
+  const uint64_t ntiles = 1ull << (s->n - (uint32_t)kTileBits - (uint32_t)p.cpos.size());
+  const size_t lds = sizeof(amp_t<T>) << kTileBits;
+  const T* af = (const T*)s->arena;
+  if (use_nt(s)) hipLaunchKernelGGL((k_gate_k4_tile_mfma<T, true>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af);
+  else hipLaunchKernelGGL((k_gate_k4_tile_mfma<T, false>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af);
+  HIPCHK(hipGetLastError());
+  *done = true;
+  return QIP_OK;
+}
+
 template <typename T>
 static int launch_kq_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const uint32_t k = (uint32_t)p.opos.size();
@@ -639,6 +691,11 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
     const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2;  // 2 = force (tuning aid)
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
+      if (k == 4 && s->unroll == 0 && !g_force_k4_direct) {  // operands through an LDS-resident tile: whole rows on both global sides
+        bool done = false;
+        QCHK(launch_k4_tile_mfma<T>(s, p, st, &done));
+        if (done) return QIP_OK;
+      }
       return launch_kq_mfma<T>(s, p, st);
     }
   }

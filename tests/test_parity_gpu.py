@@ -2248,3 +2248,40 @@ def test_tile2_merged_diagonal_runs_and_fused_multiply_adds(O, dtype, tol):
                 st.upload(x)
                 st.apply_ops(ops)
                 assert np.array_equal(st.download(), want), name
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, TOL64), (np.complex64, TOL32)])
+def test_dense4_on_the_matrix_cores_through_an_lds_tile(O, dtype, tol):
+    """k_gate_k4_tile_mfma: the matrix-core form of a dense 4-qubit gate with its operands staged through the one-op sweeps'
+    tile (whole rows on both global sides).  Every placement of the targets — inside the rows, above them, mixed, adjacent to
+    the padding positions, with controls above the rows — against the oracle (fma chains: 1e-12 / 1e-5), against the
+    direct-from-HBM kernel (same fragments, same chains: identical), and the fall-back for a control inside a row."""
+    n = 19
+    rng = np.random.default_rng(19)
+    x = circuits.random_state(n, seed=2, dtype=dtype)
+    u = rand_unitary(4, rng)
+    perm01 = np.eye(16)[rng.permutation(16)]  # a 0/1 permutation matrix stays exact on the matrix cores
+    cases = []
+    for targets in ([18, 17, 16, 15], [18, 17, 0, 1], [0, 7, 18, 9], [12, 18, 17, 3], [5, 6, 7, 8], [0, 1, 2, 3], [18, 16, 14, 12]):
+        cases.append((f"targets {targets}", q.make_matrix_op(targets, u.ravel()), targets))
+    cases.append(("controlled, controls above the rows", q.make_control_op([2, 9], q.make_matrix_op([18, 17, 0, 5], u.ravel())), None))
+    cases.append(("controlled, a control inside a row (direct kernel)", q.make_control_op([16], q.make_matrix_op([18, 17, 0, 5], u.ravel())), None))
+    with q.HipState(n, dtype) as st, q.HipState(n, dtype) as direct:
+        st.set_option("mfma", 2)      # the matrix-core form for every placement (default: when two or more targets are low)
+        direct.set_option("mfma", 2)
+        for name, op, _ in cases:
+            st.upload(x)
+            st.apply_op(op)
+            got = st.download()
+            want = O.apply_ops_in_place(n, [op], x.copy())
+            assert float(np.max(np.abs(got - want))) <= tol, name
+            q.set_global_option("k4_direct", 1)
+            try:
+                direct.upload(x)
+                direct.apply_op(op)
+            finally:
+                q.set_global_option("k4_direct", 0)
+            assert np.array_equal(got, direct.download()), name
+        st.upload(x)
+        st.apply_op(q.make_matrix_op([18, 17, 0, 1], perm01.ravel()))
+        assert np.array_equal(st.download(), O.apply_ops_in_place(n, [q.make_matrix_op([18, 17, 0, 1], perm01.ravel())], x.copy()))

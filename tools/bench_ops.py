@@ -69,6 +69,8 @@ def main():
         ("dense k=4 high bits (MFMA f64, 1 item/iter)", q.make_matrix_op([hi, mid, 5, 7], rand_unitary(4, rng).ravel()), {"mfma": 2, "unroll": 1}),
         ("dense k=5 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, 9], rand_unitary(5, rng).ravel()), {}),
         ("dense k=4 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7], rand_unitary(4, rng).ravel()), {"mfma": 2}),
+        ("dense k=4, two low bits (MFMA f64)", q.make_matrix_op([hi, mid, lo - 1, lo], rand_unitary(4, rng).ravel()), {}),
+        ("dense k=4, bits 0-3 (MFMA f64)", q.make_matrix_op([lo - 3, lo - 2, lo - 1, lo], rand_unitary(4, rng).ravel()), {}),
         ("dense k=3 high bits (MFMA f64)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 2}),
         ("dense k=6 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {}),
         ("dense k=7 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11], rand_unitary(7, rng).ravel()), {}),
@@ -97,6 +99,8 @@ def main():
                   ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
     if os.environ.get("QIP_SINGLE_VIA_TILE"):  # tuning aid: 0 = dedicated kernels only, 1 (default) / 2 = one-item tile sweeps
         q.set_global_option("single_via_tile", int(os.environ["QIP_SINGLE_VIA_TILE"]))
+    if os.environ.get("QIP_K4_DIRECT"):
+        q.set_global_option("k4_direct", int(os.environ["QIP_K4_DIRECT"]))
     if os.environ.get("QIP_SINGLE_VIA_TILE_F32"):
         q.set_global_option("single_via_tile_f32", int(os.environ["QIP_SINGLE_VIA_TILE_F32"]))
     print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")

@@ -16,12 +16,18 @@ QIP_BENCH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --n-local 24 --
 tail -2 $O/bench_2ranks_one_gpu.err
 timeout 600 python tools/bench_ops.py 30 all > $O/ops_table.md 2> $O/ops_table.err
 timeout 600 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32.md 2> $O/ops_table_f32.err
-QIP_SINGLE_VIA_TILE_F32=3 timeout 600 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32_via_tile.md 2> $O/ops_table_f32_via_tile.err
+QIP_SINGLE_VIA_TILE=0 QIP_SINGLE_VIA_TILE_F32=0 timeout 600 python tools/bench_ops.py 30 all > $O/ops_table_dedicated_kernels.md 2> $O/ops_table_dedicated_kernels.err
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 cd $R
-QIP_TILE_JIT=1 bash tools/pmc_tile.sh qft,c2 1 30 > $O/pmc_tile.log 2>&1
-python tools/pmc_tile_summary.py > $O/pmc_tile_summary.txt 2>&1
-tail -20 $O/pmc_tile_summary.txt
+# PMC passes over the run-time-compiled tile sweeps of QFT alone (issue-bound, IEEE-equal) and of QFT with tile = 2 + fma + merged runs
+rm -rf $R/gpurun_out/pmc_tileA $R/gpurun_out/pmc_tileB
+QIP_TILE_JIT=1 bash tools/pmc_tile.sh qft 1 30 > $O/pmc_tile_qft.log 2>&1
+python tools/pmc_tile_summary.py > $O/pmc_tile_qft_tile1.txt 2>&1
+rm -rf $R/gpurun_out/pmc_tileA $R/gpurun_out/pmc_tileB
+QIP_TILE_JIT=1 QIP_TILE_FMA=1 QIP_TILE_MERGE=1 bash tools/pmc_tile.sh qft 2 30 >> $O/pmc_tile_qft.log 2>&1
+python tools/pmc_tile_summary.py > $O/pmc_tile_qft_tile2_merge.txt 2>&1
+rm -rf $R/gpurun_out/pmc_tileA $R/gpurun_out/pmc_tileB
+cat $O/pmc_tile_qft_tile1.txt $O/pmc_tile_qft_tile2_merge.txt
 python - <<PY
 import json
 d=json.loads(open("$O/bench_n1.json").read().strip().splitlines()[-1])

@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+sha256sum $R/rustqip_amd/csrc/qip_kernels.h | cut -c1-16 > $O/kernels_sha16.txt   # which kernels these passes describe
 B="python $R/bench.py --no-cpu-baseline --no-parity"
 H="python $R/bench.py --headline-only"
 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o $TAG --output-format csv -- $H --steps 3 --warmup 1 > $O/bench_prof.json 2> $O/bench_prof.err

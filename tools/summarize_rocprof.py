@@ -95,7 +95,11 @@ def main():
     # which kernels these figures describe: bench.py flags `traffic` as stale when csrc/qip_kernels.h has changed since
     import hashlib
 
-    traffic["_kernels_sha16"] = hashlib.sha256(open(os.path.join(ROOT, "rustqip_amd", "csrc", "qip_kernels.h"), "rb").read()).hexdigest()[:16]
+    sha_file = os.path.join(os.path.dirname(os.path.normpath(stats_dir)), "kernels_sha16.txt")  # written on the GPU box by profile_round.sh
+    if os.path.exists(sha_file):
+        traffic["_kernels_sha16"] = open(sha_file).read().strip()
+    else:
+        traffic["_kernels_sha16"] = hashlib.sha256(open(os.path.join(ROOT, "rustqip_amd", "csrc", "qip_kernels.h"), "rb").read()).hexdigest()[:16]
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
