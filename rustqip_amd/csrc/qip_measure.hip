@@ -51,11 +51,13 @@ extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) try {
 
 // ---- two states side by side (test and validation support: a state against a reference copy) ---------------------------
 extern "C" int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src) try {
-  STATE_ENTER(dst);
+  STATE_ENTER_RAW(dst);
   if (!src) return fail(QIP_ERR_INVALID, "null source state");
   if (src == dst) return QIP_OK;
   if (src->n != dst->n || src->dtype != dst->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
   if (src->device != dst->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
+  if (!src->layout.empty()) QCHK(state_settle(src));  // a relabelled source: the caller's order first
+  dst->layout.clear();                                // (the destination is overwritten: nothing of its own to restore)
   HIPCHK(hipStreamSynchronize(src->stream));  // everything queued on the source has landed
   HIPCHK(hipMemcpyAsync(dst->cur, src->cur, dst->namps * dst->amp_bytes, hipMemcpyDeviceToDevice, dst->stream));
   return QIP_OK;
@@ -66,6 +68,7 @@ extern "C" int qip_hip_state_max_abs_diff(qip_hip_state* a, qip_hip_state* b, do
   if (!b || !max_abs) return fail(QIP_ERR_INVALID, "null argument");
   if (a->n != b->n || a->dtype != b->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
   if (a->device != b->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
+  if (!b->layout.empty()) QCHK(state_settle(b));  // (a was put in the caller's order on entry)
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(a->namps / (kBlock * 8), 1), 4096);
   QCHK(ensure_partial(a, 2 * (size_t)gx));

@@ -2188,6 +2188,21 @@ def test_relabelled_layout_persists_across_apply_ops_calls(O):
         st.apply_ops(ops[80:160])
         ref.apply_ops(ops[80:160])
         assert st.max_abs_diff(ref) == (0.0, 0)
+        # ... from either side, and a copy of a relabelled state is a copy in the caller's order
+        st.set_option("profile", 0)
+        ref.set_option("tile", 1)
+        ref.set_option("tile_relabel", 3)
+        st.apply_ops(ops[:40])
+        ref.apply_ops(ops[:40])          # both relabelled now (their layouts are the same plan's, but nothing relies on that)
+        with q.HipState(n) as third:
+            third.copy_from(ref)
+            assert st.max_abs_diff(third) == (0.0, 0) and third.max_abs_diff(ref) == (0.0, 0)
+        ref.set_option("tile", 0)
+        ref.set_option("tile_relabel", 0)
+        st.upload(x)
+        ref.upload(x)
+        st.apply_ops(ops[:160])
+        ref.apply_ops(ops[:160])
         st.apply_ops(ops[160:200])
         st.apply_op(ops[200])  # a single op: gate-by-gate entry point
         ref.apply_ops(ops[160:201])

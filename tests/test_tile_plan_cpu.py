@@ -381,3 +381,25 @@ def test_parametrised_segments_keep_their_source_when_angles_change():
     assert c["first_source"] != a["first_source"]
     d = debug_tile_jit(n, ansatz(rng.uniform(0.1, 3, (2, 8))), 2 | 32 | 64)  # tile = 2, contraction allowed, parametrised
     assert d["segments"] >= 1 and d["code_bytes"] > 0
+
+
+def test_merged_diagonal_runs_are_generated_and_compile():
+    """option tile_merge (host hook: mode bit 7, with tile = 2 and contraction bit 5): a run of >= 3 consecutive diagonal gates
+    becomes products of factors per element set — outside-the-tile controls stay uniform branches, lane-bit conditions selects —
+    and the source compiles for gfx950 in both precisions, also with the numbers as kernel data."""
+    from rustqip_amd import _ffi
+    from rustqip_amd.ops import debug_tile_jit
+
+    n = 20
+    for dtype in (_ffi.QIP_C64, _ffi.QIP_C32):
+        r = debug_tile_jit(n, circuits.c3_qft(n), 2 | 32 | 128, dtype)
+        src = r["first_source"]
+        assert r["segments"] >= 2 and r["code_bytes"] > 0
+        assert "one run of diagonal gates" in src and "A F0 = " in src and "F1 = cmul(F1, " in src
+        assert "QIP_KEEP_BRANCH(); F" in src          # a control outside the tile: a branch around the product
+        assert "tile_sel(((tb & " in src               # a control on a lane bit: entry or 1 per lane
+        plain = debug_tile_jit(n, circuits.c3_qft(n), 2 | 32, dtype)
+        assert "one run of diagonal gates" not in plain["first_source"]
+        assert src.count("cmul(") < plain["first_source"].count("pass_scale") * 2  # far fewer products than gates x elements
+        par = debug_tile_jit(n, circuits.c3_qft(n), 2 | 32 | 64 | 128, dtype)
+        assert "one run of diagonal gates" in par["first_source"] and "P[" in par["first_source"] and par["code_bytes"] > 0
