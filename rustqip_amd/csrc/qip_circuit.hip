@@ -581,33 +581,39 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   return o;
 }
 
-static int jit_get_kernel(qip_hip_state* s, const std::string& src, bool fma, hipFunction_t* fn) {
+// Look the segment's kernel up (compile it on a miss) and — unless `launch` is null (compile-only pass before a graph capture)
+// — launch it, all under the cache's mutex: between "here is the function" and "it is enqueued" no other thread may evict and
+// unload it.  (Launches are asynchronous: the critical section is microseconds on a hit.)  Nothing is evicted while this
+// handle records a graph: unloading synchronises the device, which a capture forbids; the cache overshoots its bound until the
+// next ordinary call.
+static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma, const std::function<int(hipFunction_t)>& launch) {
   const std::string key = std::to_string(s->device) + (fma ? " fma\n" : "\n") + src;
   std::lock_guard<std::mutex> lock(g_jit_mutex);
+  hipFunction_t fn = nullptr;
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) {
     it->second.last_use = ++g_jit_clock;
-    *fn = it->second.fn;
-    return QIP_OK;
+    fn = it->second.fn;
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<char> code;
+    QCHK(hiprtc_compile(src, fma, &code));
+    JitKernel k;
+    HIPCHK(hipModuleLoadData(&k.module, code.data()));
+    hipError_t e = hipModuleGetFunction(&k.fn, k.module, "qip_segment");
+    if (e != hipSuccess) {
+      (void)hipModuleUnload(k.module);
+      return fail(QIP_ERR_DEVICE, "hipModuleGetFunction failed: %s", hipGetErrorString(e));
+    }
+    k.device = s->device;
+    k.last_use = ++g_jit_clock;
+    g_jit_compiles += 1;
+    g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_jit_cache[key] = k;
+    fn = k.fn;
+    if (!s->capture_staging) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  std::vector<char> code;
-  QCHK(hiprtc_compile(src, fma, &code));
-  JitKernel k;
-  HIPCHK(hipModuleLoadData(&k.module, code.data()));
-  hipError_t e = hipModuleGetFunction(&k.fn, k.module, "qip_segment");
-  if (e != hipSuccess) {
-    (void)hipModuleUnload(k.module);
-    return fail(QIP_ERR_DEVICE, "hipModuleGetFunction failed: %s", hipGetErrorString(e));
-  }
-  k.device = s->device;
-  k.last_use = ++g_jit_clock;
-  g_jit_compiles += 1;
-  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  g_jit_cache[key] = k;
-  *fn = k.fn;
-  jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
-  return QIP_OK;
+  return launch ? launch(fn) : QIP_OK;
 }
 
 template <typename T>
@@ -647,7 +653,6 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   };
   if (s->tile_passes && s->tile_jit) {
     // the segment as its own kernel: nothing to upload, the descriptors are constants of the code
-    hipFunction_t fn = nullptr;
     const bool fma = s->tile_fma && s->tile >= 2;  // tile = 1 promises IEEE equality with the gate-by-gate path: never fused
     // structure compiled, numbers in the arena (see tile_jit_source): the default form.  tile_jit = 3 (tuning aid) writes the
     // numbers into the source as literals instead: every constant then occupies vector registers (gfx950's VOP3 takes no
@@ -656,8 +661,8 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     const bool parametrised = s->tile_jit != 3;
     std::vector<T> params;
     const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
-    QCHK(jit_get_kernel(s, tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr, merge),
-                        fma, &fn));
+    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr, merge);
+    QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss BEFORE the timed region starts
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
@@ -666,7 +671,10 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     void* params_ptr = s->arena;
     void* args[] = {&st_ptr, &ntiles_arg, &params_ptr};  // (the third is ignored by kernels without parameters)
     const dim3 grid = grid2d(ntiles, 1);
-    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+    QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
+      HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+      return QIP_OK;
+    }));
     if (s->profile) QCHK(prof_end(s, &rec));
     return QIP_OK;
   }
