@@ -90,9 +90,16 @@ const char* qip_hip_last_error(void);
 int qip_hip_device_count(void);
 /* ABI version of this header (bumped when entry points or options are added or changed). */
 int qip_hip_abi_version(void);
-/* Process-wide options.  "force_generic" = 1 routes every op (including the host twin
- * below) through the literal gather kernel; used by the parity tests to check both the
- * specialised kernels and the fallback against the oracle. */
+/* Process-wide options.
+ *   "force_generic"    1 routes every op (including the host twin below) through the literal gather kernel; used by the
+ *                      parity tests to check both the specialised kernels and the fallback against the oracle.
+ *   "single_via_tile"  which single ops run as a ONE-op tile sweep (whole rows on both global sides whatever the target bits;
+ *                      the arithmetic of the dedicated VALU kernels, IEEE-equal): 0 = none, 1 = dense k = 2, 3 and Swap ops with
+ *                      a bit inside a 1-KiB row, 2 = every dense k = 2, 3, 3 (default) = uncontrolled single-qubit gates on a
+ *                      position >= 6 as well.  "single_via_tile_f32": the same switch for Complex<f32> states (default 3).
+ *   "jit_cache_cap"    bound of the run-time compiler's kernel cache (default 512, see qip_hip_jit_cache_info).
+ *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0),
+ *                      "k4_direct" (0): measured alternatives kept switchable (profiles/r02_*.md, r03_tile_skeleton.md). */
 int qip_hip_set_global_option(const char* key, int64_t value);
 
 /* ---- op validation ------------------------------------------------------
