@@ -20,6 +20,40 @@ from rustqip_amd import circuits  # noqa: E402
 from rustqip_amd.sharded import DistState  # noqa: E402
 
 
+def fault_scenario(dist, rank, world):
+    """a batch that fails half way must not leave a handle whose layout the data never reached.  The transport's
+    all-to-all fails (on every rank alike, so nobody waits in a collective): the call reports it, and every later call on the
+    handle — gates, measurement, layout — refuses with the original message instead of computing from a half-moved shard."""
+    import ctypes as C
+
+    from rustqip_amd import _ffi
+    from rustqip_amd.sharded import HostStagedTransport
+    from rustqip_amd.state import _check
+
+    n = 12
+
+    class Failing(HostStagedTransport):
+        def _all_to_all(self, ctx, send, recv, chunk_bytes, stream):
+            return 1
+
+    t = Failing(dist)
+    h = C.c_void_p()
+    _check(_ffi.lib.qip_hip_dist_create(n, _ffi.QIP_C64, 0, rank, world, None, C.byref(t.struct), C.byref(h)))
+    ops = circuits.h_layer(n)  # H on a rank bit: needs the exchange
+    cops = [op.to_c(_ffi.QIP_C64) for op in ops]
+    arr = (_ffi.QipOp * len(cops))(*cops)
+    rc = _ffi.lib.qip_hip_dist_apply_ops(h, arr, len(cops))
+    assert rc != 0 and "all_to_all" in _ffi.last_error(), _ffi.last_error()
+    out = C.c_double()
+    rc = _ffi.lib.qip_hip_dist_norm_sqr(h, C.byref(out))
+    assert rc != 0 and "unusable after an earlier failure" in _ffi.last_error(), _ffi.last_error()
+    rc = _ffi.lib.qip_hip_dist_apply_op(h, C.byref(cops[3]))
+    assert rc != 0 and "unusable after an earlier failure" in _ffi.last_error()
+    _ffi.lib.qip_hip_dist_destroy(h)
+    if rank == 0:
+        print("ok fault: a failed exchange poisons the handle")
+
+
 def main():
     use_nccl = "--nccl" in sys.argv
     torch.cuda.set_device(0)
@@ -114,6 +148,19 @@ def main():
             assert np.array_equal(st.download_global(), e)
             if rank == 0:
                 print(f"ok n={n} world={world} {name}: err={err:.2e} stats={stats} {st.describe()['transport']}")
+    if not use_nccl and world > 1:
+        fault_scenario(dist, rank, world)
+        # the exchange cut into ragged pieces (the list the RCCL transport walks, over the host-staged transport): same state
+        n = 12
+        x = circuits.random_state(n, n)
+        ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 64, seed=5) + circuits.c3_qft(n)[:50]
+        sp = DistState(n, dist, 0, host_staged=True, piece_bytes=(((1 << (n - g)) * 16 // world) // 3) // 16 * 16)
+        sp.upload_global(x)
+        sp.apply_ops(ops)
+        assert np.max(np.abs(sp.download_global() - O.apply_ops_in_place(n, ops, x.copy()))) < 1e-12
+        assert sp._transport.pieces_moved >= 3 * (world - 1)
+        if rank == 0:
+            print(f"ok pieces: {sp._transport.pieces_moved} pieces moved in {sp.comm_stats()['remaps']} exchanges")
     # f32 shards
     n = 11
     xf = circuits.random_state(n, 3, np.complex64)

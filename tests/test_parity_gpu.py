@@ -1646,6 +1646,8 @@ def test_sharded_virtual_shards_on_one_gpu():
     """world_size 2 on ONE GPU (world 4 is covered on CPU by tests/test_distributed_cpu.py)."""
     out = _run_dist(2, [])
     assert out.count("ok n=") == 4
+    assert "ok fault: a failed exchange poisons the handle" in out and "ok pieces:" in out
+    assert out.count("samples differ from the reference's scan") == 2
 
 
 def test_sharded_rccl_plumbing_world1():

@@ -198,3 +198,60 @@ def test_product_guard_closed_form_marginals():
     y = x.copy()
     y[[5, 4000]] = y[[4000, 5]]  # norm-preserving exchange of two amplitudes
     assert g.check(S(y)) > 1e-6
+
+
+def test_localize_at_fuzz_random_ops_random_cubes():
+    """300 random ops (dense with zero rows, block-diagonal, diagonal, sparse, swaps, nested controls; qubits anywhere) on a
+    10-qubit register, cubes of random width: on EVERY cube the localized op reproduces the full op's rows bit for bit."""
+    n = 10
+    rng = np.random.default_rng(12345)
+    x = circuits.random_state(n, 33)
+
+    def rand_op():
+        perm = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            m = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+            m[int(rng.integers(0, 2)), int(rng.integers(0, 2))] = 0  # a zero entry (zero-skipping)
+            core, tg = q.make_matrix_op([perm[0]], m.ravel()), 1
+        elif kind == 1:
+            core, tg = q.make_matrix_op(perm[:2], np.diag(np.exp(1j * rng.uniform(0, 6, 4))).ravel()), 2
+        elif kind == 2:
+            u0, u1 = rng.standard_normal((2, 2)), rng.standard_normal((2, 2))
+            m = np.zeros((4, 4), dtype=complex)
+            m[:2, :2], m[2:, 2:] = u0, u1  # diagonal in its first target, dense in the second
+            core, tg = q.make_matrix_op(perm[:2], m.ravel()), 2
+        elif kind == 3:
+            core, tg = q.make_swap_op(perm[:2], perm[2:4]), 4
+        elif kind == 4:
+            rows = [[(int(rng.integers(0, 4)), complex(rng.standard_normal(), rng.standard_normal()))
+                     for _ in range(int(rng.integers(1, 3)))] for _ in range(4)]
+            core, tg = q.make_sparse_matrix_op(perm[:2], rows), 2
+        elif kind == 5:
+            core, tg = q.make_matrix_op([perm[0]], [1, 0, 0, np.exp(0.37j)]), 1
+        elif kind == 6:
+            m = rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))
+            core, tg = q.make_matrix_op(perm[:3], m.ravel()), 3
+        else:
+            core, tg = q.make_matrix_op(perm[:3], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), 3
+        nc = int(rng.integers(0, 3))
+        if nc and tg + nc <= n:
+            return q.make_control_op(perm[tg:tg + nc], core)
+        return core
+
+    checked = 0
+    for _ in range(300):
+        op = rand_op()
+        full = O.apply_ops_in_place(n, [op], x.copy())
+        cube = W.SubCube(n, W.exchange_positions(n, op), w_max=int(rng.integers(2, 7)), m_max=n)
+        if cube.w == 0:
+            continue
+        for base in range(0, 1 << n, 1 << cube.w):
+            if base & cube.vmask:
+                continue
+            sel = np.concatenate([np.arange(off, off + (1 << cube.w)) for off in cube.offsets(base)])
+            lop = cube.localize_at(op, base)
+            want = x[sel] if lop is None else O.apply_ops_in_place(cube.m, [lop], x[sel].copy())
+            assert np.array_equal(full[sel], want), (op.kind, op.indices, base)
+            checked += 1
+    assert checked > 5000
