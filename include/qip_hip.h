@@ -415,7 +415,9 @@ int qip_hip_dist_soft_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t
 
 /* The shard's own handle (upload / download / profile of this rank's 2^(n-g) amplitudes; owned by `d`), and the
  * current layout: phys[p] = physical bit position of logical bit position p (= n-1-qubit), n entries; physical
- * positions >= n-g are rank bits.  Together they let the host scatter / gather a vector in logical order. */
+ * positions >= n-g are rank bits.  Together they let the host scatter / gather a vector in logical order.  The layout
+ * changes with every exchange and with every uncontrolled Swap (SwapOpIterator, qubit_iterators.rs:176-219, only permutes
+ * index bits: on a sharded state the qubits trade entries of this map and no amplitude moves). */
 int qip_hip_dist_local_state(qip_hip_dist* d, qip_hip_state** shard);
 int qip_hip_dist_layout(qip_hip_dist* d, uint32_t* phys);
 /* Pending rank renamings: rank bit j (physical position n-g+j) reads as (bit j of the rank) XOR (bit j of *mask).  An

@@ -424,8 +424,8 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
 
 extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
   STATE_ENTER_RAW(s);
-  s->layout.clear();  // whatever was there is overwritten: no need to restore its order first
   if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
+  s->layout.clear();  // whatever was there is overwritten: no need to restore its order first
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
   if (s->dtype == QIP_C64) {
     const double one[2] = {1.0, 0.0};

@@ -75,6 +75,7 @@ struct OpInfo {
   std::vector<uint32_t> nondiag_bits;  // logical bit positions (n-1-q) that must be physically local
   // an uncontrolled anti-diagonal 1-qubit gate [[0, a], [b, 0]] (X, Y, ...): on a rank bit it only renames the ranks
   bool antidiag1q = false;
+  bool relabel_swap = false;  // an uncontrolled Swap: served by exchanging entries of the logical -> physical map
   double a_re = 0, a_im = 0, b_re = 0, b_im = 0;
 };
 
@@ -120,6 +121,7 @@ static int analyse(uint32_t n, int dtype, const qip_op* op, OpInfo* info) {
     info->diag[j] = !((diff >> (k - 1 - j)) & 1ull);
     if (!info->diag[j]) info->nondiag_bits.push_back(n - 1 - info->tgt[j]);
   }
+  info->relabel_swap = f.inner->kind == QIP_OP_SWAP && f.n_control == 0;
   if (f.inner->kind == QIP_OP_MATRIX && k == 1 && f.n_control == 0) {
     double d0r, d0i, d1r, d1i;
     entry(dtype, f.inner->dense, 0, &d0r, &d0i);
@@ -375,6 +377,15 @@ struct DistPlanner {
       }
       return QIP_OK;
     }
+    if (info.relabel_swap) {
+      // An uncontrolled Swap(h, A ++ B) is a permutation of the index bits and nothing else (SwapOpIterator,
+      // qubit_iterators.rs:176-219: one (col, 1) per row): with a logical -> physical map already kept per qubit, the two
+      // halves trade physical positions and no amplitude moves — wherever the qubits live, rank bits included (a pending
+      // rank renaming belongs to the physical bit and stays with it).
+      const uint32_t h = (uint32_t)info.tgt.size() / 2;
+      for (uint32_t j = 0; j < h; ++j) std::swap(phys[n - 1 - info.tgt[j]], phys[n - 1 - info.tgt[h + j]]);
+      return QIP_OK;
+    }
     bool needs = false;
     for (uint32_t p : info.nondiag_bits) needs = needs || phys[p] >= L;
     if (needs) QCHK(remap(info.nondiag_bits, next_use, out));
@@ -404,7 +415,7 @@ struct DistPlanner {
     std::vector<std::vector<uint64_t>> nxt(count);
     std::vector<uint64_t> cur(n, ~0ull);
     for (uint64_t i = count; i-- > 0;) {
-      if (!infos[i].antidiag1q)  // (an X-like gate is served wherever its qubit lives)
+      if (!infos[i].antidiag1q && !infos[i].relabel_swap)  // (an X-like gate / a swap is served wherever its qubits live)
         for (uint32_t p : infos[i].nondiag_bits) cur[p] = i;
       nxt[i] = cur;
     }

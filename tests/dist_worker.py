@@ -65,9 +65,13 @@ def xy_ops(n, rng, count):
     A = [0, 0.6 + 0.8j, 1j, 0]  # a general anti-diagonal gate
     ops = []
     for _ in range(count):
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 10))
         perm = [int(v) for v in rng.permutation(n)]
-        if kind <= 2:
+        if kind == 8:  # an uncontrolled swap only renames qubits — also while a rank renaming is pending on one of them
+            ops.append(q.make_swap_op([perm[0]], [perm[1]]))
+        elif kind == 9:
+            ops.append(q.make_swap_op(perm[:2], perm[2:4]))
+        elif kind <= 2:
             ops.append(q.make_matrix_op([perm[0]], [circuits.X, Y, A][kind]))
         elif kind == 3:
             ops.append(q.make_control_op([perm[0]], q.make_matrix_op([perm[1]], circuits.X)))
@@ -111,7 +115,10 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g = int(math.log2(world))
-    for n, seed in ((g + max(g, 3), 0), (7, 1), (9, 2)):
+    # (an exchange moves all g rank bits at once, so an op with k non-diagonal targets needs L >= g + k local qubits:
+    # three rank bits want shards of at least 2^6)
+    sizes = ((g + max(g, 3), 0), (7, 1), (9, 2)) if g <= 2 else ((2 * g + 3, 0), (2 * g + 4, 1), (2 * g + 5, 2))
+    for n, seed in sizes:
         rng = np.random.default_rng(seed)  # same stream on every rank
         x = circuits.random_state(n, seed + 10)
         L = n - g

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size 2 and 4 over gloo.  The sharded state's planner lives in libqip_hip.so
+"""N > 1 path on CPU: world_size 2, 4 and 8 over gloo.  The sharded state's planner lives in libqip_hip.so
 (qip_hip_dist_debug_plan); the worker replays its plans with the CPU oracle as the shard (tests/dist_worker.py)."""
 import os
 import socket
@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_state_matches_single_process(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -83,3 +83,26 @@ def test_piece_plan_of_the_exchange():
                 assert mine == [(off, ln) for pp, off, ln in lists[p] if pp == r]
     assert len(sharded.piece_list(3, 8, 1 << 31, 1 << 30)) == 14
     assert sharded.piece_list(0, 1, 1 << 20, 1 << 10) == []
+
+
+def test_uncontrolled_swap_is_a_relabelling():
+    """Swap(h, A ++ B) without controls moves no amplitude on a sharded state: the planner exchanges the qubits' entries of
+    the logical -> physical map, rank bits included (SwapOpIterator, qubit_iterators.rs:176-219, is a pure index-bit
+    permutation); a controlled swap is still executed"""
+    n, world = 10, 4
+    ops = [q.make_swap_op([0], [9]), q.make_swap_op([1, 2], [7, 3])]
+    for rank in range(world):
+        plan = sharded.debug_plan(n, rank, world, ops)
+        assert plan["steps"] == []
+        want = list(range(n))  # phys[p] for logical bit p = n - 1 - qubit
+        for a, b in ((0, 9), (1, 7), (2, 3)):
+            want[n - 1 - a], want[n - 1 - b] = want[n - 1 - b], want[n - 1 - a]
+        assert plan["phys"] == want
+    plan = sharded.debug_plan(n, 1, world, [q.make_control_op([5], q.make_swap_op([0], [9]))])
+    assert [s["t"] for s in plan["steps"]].count("exchange") == 1
+    # the closing bit reversal of a QFT costs nothing: same exchanges with and without it
+    qft = circuits.c3_qft(12)
+    with_swaps = sharded.debug_plan(12, 0, 4, qft)
+    without = sharded.debug_plan(12, 0, 4, [o for o in qft if o.kind != "Swap"])
+    count = lambda p, t: sum(1 for s in p["steps"] if s["t"] == t)
+    assert count(with_swaps, "exchange") == count(without, "exchange") and count(with_swaps, "local") == count(without, "local")
