@@ -422,6 +422,11 @@ def main():
         avg_ms = kstat["total_ms"] / kstat["launches"]
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src, traffic_stale = load_traffic(kname)
+        if args.n_local != 30 and traffic is not None:
+            # the PMC passes were taken at the default size (2^30 amplitudes per GPU): the traffic of a sweep is proportional
+            # to the shard (the kernels are the same), so the per-launch figure is scaled, and labelled as such
+            traffic *= 2.0 ** (args.n_local - 30)
+            traffic_src = f"{traffic_src}, measured at 2^30 amplitudes and scaled to 2^{args.n_local}"
         if traffic_stale:
             print("bench.py: warning: profiles/pmc_traffic.json was measured on an older csrc/qip_kernels.h — roofline.traffic is "
                   "flagged stale; re-run tools/profile_round.sh", file=sys.stderr)
