@@ -98,8 +98,9 @@ int qip_hip_abi_version(void);
  *                      a bit inside a 1-KiB row, 2 = every dense k = 2, 3, 3 (default) = uncontrolled single-qubit gates on a
  *                      position >= 6 as well.  "single_via_tile_f32": the same switch for Complex<f32> states (default 3).
  *   "jit_cache_cap"    bound of the run-time compiler's kernel cache (default 512, see qip_hip_jit_cache_info).
- *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0),
- *                      "k4_direct" (0): measured alternatives kept switchable (profiles/r02_*.md, r03_tile_skeleton.md). */
+ *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
+ *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
+ *                      (profiles/r02_*.md, r03_tile_skeleton.md). */
 int qip_hip_set_global_option(const char* key, int64_t value);
 
 /* ---- op validation ------------------------------------------------------

@@ -411,6 +411,17 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   // (tuning aid, global option "tile_remap": the 2^r blocks one XCD receives in a row take ADJACENT tiles; measured slower)
   if (remap == 2) L("  blk = (blk & ~31ull) | ((blk & 7ull) << 2) | ((blk >> 3) & 3ull);");
   if (remap == 3) L("  blk = (blk & ~63ull) | ((blk & 7ull) << 3) | ((blk >> 3) & 7ull);");
+  if (remap >= 16) {
+    // XCD-aware order (global option "tile_remap" = 4; remap = 16 + J here): consecutive block numbers go round-robin over
+    // the 8 XCDs, so block bits 0..2 name the XCD.  They drive three tile-number bits that stand for HIGH free positions
+    // (the first three at or above amplitude position 16), the remaining block bits walk the other free positions upwards:
+    // each XCD sweeps its own far-apart region with neighbouring 1-KiB rows in consecutive blocks, instead of all eight
+    // interleaving on the same rows.  Tuning aid, off by default: on the bare sweep skeleton (tools/tune_tile "order") it is
+    // worth 2 - 13 % on tiles whose five positions are scattered, on real segments it is not (configs[1] 69.3 -> 69.7 ms,
+    // QFT 36.3 -> 37.9 ms in the HBM-bound tile mode: profiles/r03_tile_skeleton.md, section 4).
+    const std::string J = std::to_string(remap - 16);
+    L("  blk = ((blk >> 3) & ((1ull << " + J + ") - 1ull)) | ((blk & 7ull) << " + J + ") | (((blk >> 3) >> " + J + ") << (" + J + " + 3));");
+  }
   L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
   for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
   L("  const uint32_t tidv = tid;");
@@ -661,7 +672,22 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     const bool parametrised = s->tile_jit != 3;
     std::vector<T> params;
     const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
-    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), ntiles % 64 == 0 ? (int)g_tile_remap : 0, parametrised ? &params : nullptr, merge);
+    int remap = ntiles % 64 == 0 ? (int)g_tile_remap : 0;
+    if (remap == 4) {  // XCD-aware: tile-number bit J is the first free position at or above 16 (see tile_jit_source)
+      uint32_t nb = 0, J = 0;
+      while ((1ull << nb) < ntiles) ++nb;
+      uint32_t seen = 0;
+      for (uint32_t pp = kTileLow; pp < s->n && seen < nb; ++pp) {
+        bool opened = false;
+        for (uint32_t j = 0; j < ins.npos; ++j) opened = opened || ins.pos[j] == pp;
+        if (opened) continue;
+        if (pp < 16) ++J;
+        ++seen;
+      }
+      if (nb < 3) remap = 0;
+      else remap = 16 + (int)std::min(J, nb - 3);
+    }
+    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), remap, parametrised ? &params : nullptr, merge);
     QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss BEFORE the timed region starts
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));

@@ -103,6 +103,31 @@ __global__ __launch_bounds__(256, MODE == 2 ? 8 : 5) void k_v0(A* __restrict__ s
   for (int u = 0; u < 8; ++u) stg<NT>(st + (base | row_off(u, wave, hp)) + lane, x[u]);
 }
 
+// "order" study: block -> tile through a bit permutation given at run time (tile-index bit src[i] is driven by block-index bit i):
+// which tiles are in flight together, and which share an XCD (blocks go round-robin over the 8 XCDs: block bits 0..2).
+struct Ord { uint8_t src[24]; uint32_t nb; };
+__global__ __launch_bounds__(256, 5) void k_ord(A* __restrict__ st, Hp hp, Ord o, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* tile = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t t = 0;
+  for (uint32_t i = 0; i < o.nb; ++i) t |= (uint64_t)((blockIdx.x >> i) & 1u) << o.src[i];
+  const uint64_t base = tile_base(t, hp);
+  A x[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = ldg<true>(st + (base | row_off(u, wave, hp)) + lane);
+  const uint32_t slot_tid = tile_slot<A>(tid);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)] = x[u];
+  tile_barrier<false>();
+  passes<1, 2, false>(tile, tid, f);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = tile[slot_tid ^ tile_slot<A>((uint32_t)u << 8)];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) stg<true>(st + (base | row_off(u, wave, hp)) + lane, x[u]);
+}
+
 // persistent, MODE 4 = next tile's loads in registers across the passes, 5 = no prefetch.
 // Loop shape: the wait for the prefetched tile sits in the SAME iteration that issued it (issue -> passes -> stores ->
 // wait -> LDS write), so hipcc's counter bookkeeping sees "8 loads, then 8 stores" every time and waits with vmcnt(8..15):
@@ -282,12 +307,59 @@ static void light(const Hp& hp, const char* hname) {
   run("V2 no LDS remap4", 1, 2, hname, [&] { hipLaunchKernelGGL((k_v0<1, 2, 2, 1>), dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, hp, f); });
 }
 
+// one tile shape under a family of block -> tile orders.  An order is the list of FREE positions (those outside the tile,
+// >= 6) in the sequence the block-index bits drive them, lowest block bit first.
+static void orders(std::vector<uint32_t> h, const char* hname, int n);
+
 static Hp make_hp(std::vector<uint32_t> h) {
   Hp hp;
   for (int j = 0; j < 5; ++j) hp.h[j] = h[j];
   std::sort(h.begin(), h.end());
   for (int j = 0; j < 5; ++j) hp.sorted[j] = h[j];
   return hp;
+}
+
+static void orders(std::vector<uint32_t> h, const char* hname, int n) {
+  const Hp hp = make_hp(h);
+  std::vector<uint32_t> free_pos;
+  for (uint32_t p = 6; p < (uint32_t)n; ++p)
+    if (std::find(h.begin(), h.end(), p) == h.end()) free_pos.push_back(p);
+  const uint32_t nb = (uint32_t)free_pos.size();
+  const uint64_t ntiles = g_n >> 11;
+  A f;
+  f.x = 0.6;
+  f.y = 0.8;
+  auto run_order = [&](const char* oname, const std::vector<uint32_t>& seq) {  // seq: free positions, lowest block bit first
+    Ord o;
+    memset(&o, 0, sizeof o);
+    o.nb = nb;
+    for (uint32_t i = 0; i < nb; ++i) o.src[i] = (uint8_t)(std::find(free_pos.begin(), free_pos.end(), seq[i]) - free_pos.begin());
+    run(oname, 1, 2, hname, [&] { hipLaunchKernelGGL(k_ord, dim3((unsigned)ntiles), dim3(256), 32768, 0, g_st, hp, o, f); });
+  };
+  auto from = [&](uint32_t P) {  // positions >= P ascending first, then the ones below
+    std::vector<uint32_t> s;
+    for (uint32_t p : free_pos) if (p >= P) s.push_back(p);
+    for (uint32_t p : free_pos) if (p < P) s.push_back(p);
+    return s;
+  };
+  auto xcd = [&](uint32_t P, bool rest_from11) {  // the three XCD bits <- the first three free positions >= P; the rest ascending (or from 11)
+    std::vector<uint32_t> first, rest;
+    for (uint32_t p : free_pos) (p >= P && first.size() < 3 ? first : rest).push_back(p);
+    if (rest_from11) {
+      std::vector<uint32_t> r2;
+      for (uint32_t p : rest) if (p >= 11) r2.push_back(p);
+      for (uint32_t p : rest) if (p < 11) r2.push_back(p);
+      rest = r2;
+    }
+    first.insert(first.end(), rest.begin(), rest.end());
+    return first;
+  };
+  char name[64];
+  run_order("asc", free_pos);
+  { std::vector<uint32_t> d(free_pos.rbegin(), free_pos.rend()); run_order("desc", d); }
+  for (uint32_t P : {8u, 9u, 11u, 13u, 16u, 19u}) { snprintf(name, sizeof name, "from %u", P); run_order(name, from(P)); }
+  for (uint32_t P : {8u, 9u, 11u, 13u, 16u, 20u, 24u}) { snprintf(name, sizeof name, "xcd<-%u.. rest asc", P); run_order(name, xcd(P, false)); }
+  for (uint32_t P : {6u, 8u, 11u, 16u, 20u, 24u}) { snprintf(name, sizeof name, "xcd<-%u.. rest from11", P); run_order(name, xcd(P, true)); }
 }
 
 int main(int argc, char** argv) {
@@ -314,6 +386,17 @@ int main(int argc, char** argv) {
         {{12, 15, 18, 21, 24}, "w12,15 u18,21,24"}, {{6, 15, 18, 21, 24}, "w6,15 u18,21,24"}, {{6, 7, 18, 21, 24}, "w6,7 u18,21,24"},
         {{18, 21, 24, 6, 7}, "w18,21 u24,6,7"}};
     for (auto& s : sets) light(make_hp(s.h), s.name);
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "order")) {
+    const uint32_t N = (uint32_t)n;
+    struct { std::vector<uint32_t> h; const char* name; } sets[] = {
+        {{11, 12, 13, 14, 15}, "11..15"}, {{6, 7, 8, 9, 10}, "6..10"}, {{N - 5, N - 4, N - 3, N - 2, N - 1}, "top5"},
+        {{6, 15, 18, 21, 24}, "6,15,18,21,24"}, {{12, 15, 18, 21, 24}, "12,15,18,21,24"}, {{20, 21, 22, 23, 24}, "20..24"},
+        {{6, 7, N - 3, N - 2, N - 1}, "6,7,top3"}, {{8, 12, 17, 22, 27}, "8,12,17,22,27"}, {{16, 17, 18, 19, 20}, "16..20"},
+        {{11, 12, N - 3, N - 2, N - 1}, "11,12,top3"}};
+    for (auto& s : sets) orders(s.h, s.name, n);
     CK(hipFree(g_st));
     return 0;
   }
