@@ -336,11 +336,11 @@ template <typename P> class DistState {
     return id;
   }
   /// Built-in RCCL transport (`id` from unique_id()).
-  DistState(size_t n, int device, int rank, int world, const std::vector<unsigned char>& id) : n_(n) {
+  DistState(size_t n, int device, int rank, int world, const std::vector<unsigned char>& id) : n_(n), rank_(rank), world_(world) {
     check(qip_hip_dist_create((uint32_t)n, dtype_of<P>::value, device, rank, world, id.data(), nullptr, &h_));
   }
   /// Caller-supplied transport (tests; hosts that already own a communicator).
-  DistState(size_t n, int device, int rank, int world, const qip_hip_transport& t) : n_(n) {
+  DistState(size_t n, int device, int rank, int world, const qip_hip_transport& t) : n_(n), rank_(rank), world_(world) {
     check(qip_hip_dist_create((uint32_t)n, dtype_of<P>::value, device, rank, world, nullptr, &t, &h_));
   }
   ~DistState() { qip_hip_dist_destroy(h_); }
@@ -401,6 +401,24 @@ template <typename P> class DistState {
     check(qip_hip_state_download(sh, out.data(), 0, out.size()));
     return out;
   }
+  /// logical (reference-order) index of every amplitude of this rank's shard, in the shard's local order: what a host
+  /// needs to gather a vector.  The layout changes with every exchange AND with every uncontrolled Swap (a relabelling),
+  /// also at world = 1.
+  std::vector<uint64_t> shard_logical_indices() {
+    uint32_t g = 0;
+    while ((1 << g) < world_) ++g;
+    const size_t L = n_ - g;
+    const std::vector<uint32_t> phys = layout();
+    const uint64_t top = (uint64_t)((uint32_t)rank_ ^ rank_flip()) << L;
+    std::vector<uint64_t> out(size_t(1) << L);
+    for (uint64_t loc = 0; loc < out.size(); ++loc) {
+      const uint64_t P64 = loc | top;
+      uint64_t idx = 0;
+      for (size_t p = 0; p < n_; ++p) idx |= ((P64 >> phys[p]) & 1ull) << p;
+      out[loc] = idx;
+    }
+    return out;
+  }
   /// soft_measure (measurement_ops.rs:153-176) of the sharded state: rank 0's sample decides; no collapse
   size_t soft_measure(const std::vector<size_t>& indices, double rand_u01) {
     std::vector<uint64_t> idx(indices.begin(), indices.end());
@@ -416,6 +434,7 @@ template <typename P> class DistState {
 
  private:
   size_t n_;
+  int rank_ = 0, world_ = 1;
   qip_hip_dist* h_ = nullptr;
 };
 
