@@ -631,7 +631,7 @@ template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
                                std::vector<uint32_t> high_in) {
   TileSegmentPlan<T> plan;
-  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan));
+  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1));
   const std::vector<uint32_t>& high = plan.high;
   std::vector<TileGate<T>>& gates = plan.gates;
   std::vector<amp_t<T>>& mats = plan.mats;
@@ -781,7 +781,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     std::vector<const TileItem*> seg;
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
     TileSegmentPlan<T> plan;
-    QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+    QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
     Ins ins = make_ins(plan.high, 0);
     std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
     const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs

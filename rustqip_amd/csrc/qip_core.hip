@@ -41,7 +41,7 @@ int64_t g_perm_rows = 0;
 // by WHICH five high positions the tile holds — 5.2 ms for {11..15}, 6.3 ms for {6..10}, 6.7 ms for the top five — not by the
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
 // taken from 11 upwards, and the two lowest of the five are the wave bits (both worth ~1 % on the benchmark circuits).
-int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0;
+int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0, g_tile_sched = 1;
 int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;
 int64_t g_force_k4_direct = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
@@ -63,6 +63,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
   if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
+  if (key && !strcmp(key, "tile_sched")) { g_tile_sched = value; return QIP_OK; }
   if (key && !strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
   if (key && !strcmp(key, "k4_direct")) { g_force_k4_direct = value; return QIP_OK; }
   if (key && !strcmp(key, "single_via_tile_f32")) { g_single_via_tile_f32 = value; return QIP_OK; }

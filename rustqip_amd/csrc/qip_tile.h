@@ -33,6 +33,7 @@ template <typename T> struct TileSegmentPlan {
   std::vector<TileGate<T>> gates;
   std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
   TilePassDesc pd;             // passes (only when `passes`)
+  std::vector<uint32_t> order; // gates[i] is the segment's order[i]-th op (build_tile_segment may reorder inside the segment)
 };
 
 // One step of a tiled schedule: a segment of >= 2 gates applied in one sweep, or a single op applied by
@@ -61,6 +62,7 @@ struct TileSchedule {
 
 int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it);
 template <typename T>
-int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, TileSegmentPlan<T>* out);
+int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, TileSegmentPlan<T>* out,
+                       int order_rule = 0);  // order_rule: 0 = gates in the given order, 1 / 2 = fewest passes under tile = 1 / 2's commutation rule
 int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
                        bool allow_permute = true);

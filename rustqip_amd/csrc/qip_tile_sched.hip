@@ -157,8 +157,16 @@ extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits
 
 
 template <typename T>
-int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg,
-                              std::vector<uint32_t> high, TileSegmentPlan<T>* out) {
+int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg_in,
+                              std::vector<uint32_t> high, TileSegmentPlan<T>* out, int order_rule) {
+  // The order of the gates INSIDE the segment (order_rule 1 / 2 = the "tile" option; 0 keeps the schedule's order).  A pass is
+  // one round trip of the tile through LDS (~0.5 ms per sweep at n = 30: 64 KiB per tile at 128 B per clock), and a pass holds
+  // the gates whose exchange bits fit its three register bits: taken in circuit order, a random circuit opens a new pass every
+  // 3 - 4 gates.  List scheduling over the commutation relation the scheduler itself uses (two gates commute when on every
+  // shared bit both only TEST it; tile = 1 additionally needs one of the two rounding-free, which keeps every amplitude's
+  // sequence of rounded operations — the result stays IEEE-equal to circuit order) fills a pass with every ready gate that
+  // fits before it opens the next one.
+  std::vector<const TileItem*> seg = seg_in;
   // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
   const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, n > (uint32_t)kTileBits ? n - 5 : (uint32_t)kTileLow);
   // position 6 in the tile without position 7 makes the waves' rows alternate 1-KiB pieces (a one-op sweep on position 6:
@@ -189,6 +197,83 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
     const auto f = std::find(high.begin(), high.end(), pos);
     return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
+  if (passes && order_rule >= 1 && g_tile_sched != 0 && seg.size() >= 3) {
+    const size_t N = seg.size();
+    auto tile_pos = [&](uint32_t pos) { return pos < (uint32_t)kTileLow || std::find(high.begin(), high.end(), pos) != high.end(); };
+    std::vector<std::vector<uint32_t>> ex(N);  // exchange positions (all inside the tile by construction)
+    std::vector<std::vector<uint32_t>> ctl(N);  // controls inside the tile
+    for (size_t i = 0; i < N; ++i) {
+      const TileItem& it = *seg[i];
+      if (it.kind == 0) ex[i] = {it.t0};
+      if (it.kind == 2 || it.kind == 3) ex[i] = {it.t0, it.t1};
+      if (it.kind == 4) ex[i] = {it.t0, it.t1, it.t2};
+      for (uint32_t c : it.cpos)
+        if (tile_pos(c)) ctl[i].push_back(c);
+    }
+    std::vector<std::vector<uint32_t>> preds(N);
+    for (size_t j = 0; j < N; ++j)
+      for (size_t i = 0; i < j; ++i) {
+        const TileItem &a = *seg[i], &b = *seg[j];
+        const bool commute = !(b.nd_mask & (a.nd_mask | a.d_mask)) && !(b.d_mask & a.nd_mask);
+        if (!commute || (order_rule < 2 && !a.exact && !b.exact)) preds[j].push_back((uint32_t)i);
+      }
+    std::vector<char> placed(N, 0);
+    std::vector<const TileItem*> order;
+    std::vector<uint32_t> bits;  // the open pass's exchange positions
+    auto ready = [&](size_t j) {
+      if (placed[j]) return false;
+      for (uint32_t i : preds[j])
+        if (!placed[i]) return false;
+      return true;
+    };
+    auto united = [&](const std::vector<uint32_t>& extra) {
+      std::vector<uint32_t> m = bits;
+      for (uint32_t b : extra)
+        if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
+      return m;
+    };
+    // what the grouping below will ask of the pass for this gate: its exchange bits, plus its in-tile controls when three slots allow
+    auto wanted = [&](size_t j) {
+      std::vector<uint32_t> w = ex[j];
+      if (!w.empty() && w.size() + ctl[j].size() <= 3) w.insert(w.end(), ctl[j].begin(), ctl[j].end());
+      return w;
+    };
+    while (order.size() < N) {
+      // every ready gate that fits the open pass as it stands (no new bit), earliest first; then the ready gate that adds the
+      // fewest bits; when nothing fits the pass closes and the earliest ready gate opens the next one
+      bool progressed = false;
+      for (size_t j = 0; j < N; ++j)
+        if (ready(j) && united(wanted(j)).size() == bits.size()) {
+          placed[j] = 1;
+          order.push_back(seg[j]);
+          progressed = true;
+        }
+      if (progressed) continue;
+      size_t pick = N, pick_sz = 4;
+      for (size_t j = 0; j < N; ++j)
+        if (ready(j)) {
+          const size_t sz = united(wanted(j)).size();
+          if (sz <= 3 && sz < pick_sz) {
+            pick = j;
+            pick_sz = sz;
+          }
+        }
+      if (pick == N) {  // nothing fits: new pass with the earliest ready gate
+        bits.clear();
+        for (size_t j = 0; j < N; ++j)
+          if (ready(j)) {
+            pick = j;
+            break;
+          }
+      }
+      bits = united(wanted(pick));
+      placed[pick] = 1;
+      order.push_back(seg[pick]);
+    }
+    seg = order;
+  }
+  out->order.resize(seg.size());
+  for (size_t i = 0; i < seg.size(); ++i) out->order[i] = (uint32_t)(std::find(seg_in.begin(), seg_in.end(), seg[i]) - seg_in.begin());
   std::vector<TileGate<T>>& gates = out->gates;
   std::vector<amp_t<T>>& mats = out->mats;
   gates.assign(seg.size(), TileGate<T>());
@@ -344,6 +429,101 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Which five positions should a segment claim?  First come, first served (the scan below claims positions in the order the
+// circuit asks for them) spends them on whatever the next few gates touch.  The gain rule looks at what each position
+// would BUY: starting from the positions the head gate needs, it repeatedly claims the free
+// position that lets the most further gates join this segment (a dry run of the same scan with the claimed set frozen;
+// gates that exchange amplitudes count 1, diagonal ones — which never need a position — a little), until five are claimed
+// or no single position adds anything; what is left is claimed first-come as before.  Host arithmetic only, and the
+// schedule's invariants do not depend on it: every gate still joins under the commutation / exactness rules of the scan.
+// ---------------------------------------------------------------------------------------
+static thread_local int t_seg_rule = 0;  // the rule in force for the plan being made (make_tile_schedule tries several)
+struct SegScan {
+  const std::vector<TileItem>& L;
+  const std::vector<char>& done;
+  uint64_t count, window;
+  bool reorder, relabel;
+  size_t max_ops, max_exch;
+};
+
+// weight of the gates that join a segment grown from `head` when exactly the positions `H` may be used above the rows
+static double seg_dry_run(const SegScan& c, uint64_t head, std::vector<uint32_t> phys, const std::vector<uint32_t>& H) {
+  uint64_t blocked_nd = 0, blocked_d = 0;
+  bool skipped_inexact = false, any_skipped = false;
+  size_t joined = 0, exch_gates = 0;
+  double w = 0;
+  for (uint64_t i = head; i < c.count && i <= head + (any_skipped ? c.window : c.count) && joined < c.max_ops; ++i) {
+    if (c.done[i]) continue;
+    const TileItem& it = c.L[i];
+    if (c.relabel && !any_skipped && !it.swap_pairs.empty()) {
+      for (const auto& pr : it.swap_pairs) std::swap(phys[pr.first], phys[pr.second]);
+      continue;
+    }
+    const bool commutes = !(it.nd_mask & (blocked_nd | blocked_d)) && !(it.d_mask & blocked_nd);
+    bool fits = it.tileable && commutes && (c.reorder || it.exact || !skipped_inexact) && (it.kind == 1 || exch_gates < c.max_exch);
+    if (fits) {
+      uint32_t exch[3];
+      int ne = 0;
+      if (it.kind == 0) exch[ne++] = it.t0;
+      if (it.kind == 2 || it.kind == 3) { exch[ne++] = it.t0; exch[ne++] = it.t1; }
+      if (it.kind == 4) { exch[ne++] = it.t0; exch[ne++] = it.t1; exch[ne++] = it.t2; }
+      for (int e = 0; e < ne && fits; ++e) {
+        const uint32_t pp = phys[exch[e]];
+        fits = pp < (uint32_t)kTileLow || std::find(H.begin(), H.end(), pp) != H.end();
+      }
+    }
+    if (fits) {
+      joined += 1;
+      exch_gates += it.kind != 1;
+      w += it.kind != 1 ? 1.0 : (t_seg_rule == 3 ? 0.5 : 0.125);
+    } else {
+      blocked_nd |= it.nd_mask;
+      blocked_d |= it.d_mask;
+      skipped_inexact = skipped_inexact || !it.exact;
+      any_skipped = true;
+    }
+  }
+  return w;
+}
+
+static std::vector<uint32_t> seg_choose_high(const SegScan& c, uint64_t head, const std::vector<uint32_t>& phys, uint32_t n) {
+  std::vector<uint32_t> H;
+  if (t_seg_rule == 0) return H;
+  {
+    const TileItem& it = c.L[head];
+    uint32_t exch[3];
+    int ne = 0;
+    if (it.kind == 0) exch[ne++] = it.t0;
+    if (it.kind == 2 || it.kind == 3) { exch[ne++] = it.t0; exch[ne++] = it.t1; }
+    if (it.kind == 4) { exch[ne++] = it.t0; exch[ne++] = it.t1; exch[ne++] = it.t2; }
+    for (int e = 0; e < ne; ++e) {
+      const uint32_t pp = phys[exch[e]];
+      if (pp >= (uint32_t)kTileLow && std::find(H.begin(), H.end(), pp) == H.end()) H.push_back(pp);
+    }
+  }
+  double base = seg_dry_run(c, head, phys, H);
+  while (H.size() < (size_t)kTileHigh) {
+    int best = -1;
+    double best_w = base;
+    for (uint32_t pp = kTileLow; pp < n; ++pp) {
+      if (std::find(H.begin(), H.end(), pp) != H.end()) continue;
+      H.push_back(pp);
+      const double w = seg_dry_run(c, head, phys, H);
+      H.pop_back();
+      if (w > best_w + 1e-9) {
+        best_w = w;
+        best = (int)pp;
+      }
+    }
+    if (best < 0) break;
+    H.push_back((uint32_t)best);
+    base = best_w;
+  }
+  return H;
+}
+
+
 // Pure host scheduling (no device, no launches).  Invariants, checked by tests/test_host_ops.py through
 // qip_hip_plan_tiles: every op appears in exactly one step; an op only overtakes ops it commutes with (on every
 // shared bit both only test it); without `reorder` only when it, or every op it overtakes, is rounding-free.
@@ -411,6 +591,12 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
     // (entries in {0, +-1, +-i}: X, Y, Z, S, CNOT, CZ, Toffoli, SWAP ...).  Exact commutations leave every
     // amplitude's sequence of rounded operations unchanged, so the result stays IEEE-equal to circuit order.
     TileStep st;
+    {
+      std::vector<uint32_t> ident(n);
+      for (uint32_t b = 0; b < n; ++b) ident[b] = b;
+      const SegScan sc{items, done, count, window, reorder, false, (size_t)kTileMaxGates, (size_t)kTileMaxExchGates};
+      st.high = seg_choose_high(sc, head, ident, n);
+    }
     uint64_t blocked_nd = 0, blocked_d = 0;  // bits the skipped gates exchange across / only test
     bool skipped_inexact = false;            // some skipped gate rounds
     bool any_skipped = false;
@@ -539,6 +725,10 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
     // the segment: schedule_tiles' rules on the logical masks (commutation does not depend on names), the tile test on
     // the physical positions
     TileStep st;
+    {
+      const SegScan sc{L, done, count, window, reorder, true, max_circuit_ops, (size_t)kTileMaxExchGates - (size_t)kTileLow};
+      st.high = seg_choose_high(sc, head, phys, n);
+    }
     uint64_t blocked_nd = 0, blocked_d = 0;
     bool skipped_inexact = false, any_skipped = false;
     size_t joined = 0, exch_gates = 0;
@@ -651,8 +841,8 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
 
 // mode: bits 0-1 = the "tile" option (1 = circuit order, 2 = commuting reorder), bit 2 = relabel the qubits when that
 // shortens the plan, bit 3 = relabel unconditionally
-int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
-                              bool allow_permute) {
+static int make_tile_schedule_rule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                                   bool allow_permute) {
   const bool reorder = (mode & 3) >= 2;
   bool start_identity = true;
   for (uint32_t p = 0; p < out->init_phys.size(); ++p) start_identity = start_identity && out->init_phys[p] == p;
@@ -677,6 +867,37 @@ int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
   out->circuit = ops;
   out->count = count;
   return schedule_tiles(dtype, n, ops, count, reorder, &out->items, &out->steps, allow_2q, allow_permute);
+}
+
+// The plan under each rule for claiming a segment's positions (first come / what a position buys, two weights for the
+// diagonal gates), shortest kept: host arithmetic, microseconds per gate, against ~6 ms per sweep saved at n = 30.  Below
+// n = 24 a sweep costs less than the search: first come only.  Global option "tile_sched": 0 = first come only.
+int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                       bool allow_permute) {
+  const bool search = g_tile_sched != 0 && (n >= 24 || g_tile_sched == 2) && count >= 8;  // (2 = at every size: tests)
+  if (!search) {
+    t_seg_rule = 0;
+    return make_tile_schedule_rule(dtype, n, ops, count, mode, allow_2q, out, allow_permute);
+  }
+  const std::vector<uint32_t> init = out->init_phys;
+  const bool keep = out->keep_layout;
+  TileSchedule best;
+  bool have = false;
+  for (int rule : {0, 1, 3}) {
+    TileSchedule cand;
+    cand.init_phys = init;
+    cand.keep_layout = keep;
+    t_seg_rule = rule;
+    const int rc = make_tile_schedule_rule(dtype, n, ops, count, mode, allow_2q, &cand, allow_permute);
+    t_seg_rule = 0;
+    QCHK(rc);
+    if (!have || cand.steps.size() < best.steps.size()) {
+      best = std::move(cand);
+      have = true;
+    }
+  }
+  *out = std::move(best);
+  return QIP_OK;
 }
 
 extern "C" int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
@@ -736,9 +957,11 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       std::vector<const TileItem*> seg;
       for (uint64_t i : st.ops) seg.push_back(&items[i]);
       TileSegmentPlan<T> plan;
-      QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan));
+      QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
       js += ",\"high\":[";
       for (size_t k = 0; k < plan.high.size(); ++k) js += (k ? "," : "") + std::to_string(plan.high[k]);
+      js += "],\"order\":[";
+      for (size_t k = 0; k < plan.order.size(); ++k) js += (k ? "," : "") + std::to_string(plan.order[k]);
       js += "],\"passes\":[";
       for (uint32_t pi = 0; pi < plan.pd.npasses; ++pi) {
         const TilePass& ps = plan.pd.pass[pi];
@@ -793,5 +1016,5 @@ extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_
 // and the total source / code size through the out parameters; `first_source` (may be NULL) receives a pointer to the
 // first segment's source text (owned by the library, valid until the calling thread's next call).
 
-template int build_tile_segment<double>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<double>*);
-template int build_tile_segment<float>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<float>*);
+template int build_tile_segment<double>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<double>*, int);
+template int build_tile_segment<float>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<float>*, int);
