@@ -270,7 +270,26 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
       placed[pick] = 1;
       order.push_back(seg[pick]);
     }
-    seg = order;
+    // adopt the new order only when it really saves passes (counted with the grouping rule below): where the circuit's own
+    // order is already as good (QFT: two passes per segment either way) it is kept — its runs of diagonal gates merge better
+    auto count_passes = [&](const std::vector<const TileItem*>& sq) {
+      std::vector<uint32_t> open;
+      size_t np = 1;
+      for (const TileItem* it : sq) {
+        const size_t j = (size_t)(std::find(seg.begin(), seg.end(), it) - seg.begin());
+        const std::vector<uint32_t> w = wanted(j);
+        std::vector<uint32_t> m = open;
+        for (uint32_t b : w)
+          if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
+        if (m.size() > 3) {
+          ++np;
+          m = w;
+        }
+        open = m;
+      }
+      return np;
+    };
+    if (count_passes(order) < count_passes(seg)) seg = order;
   }
   out->order.resize(seg.size());
   for (size_t i = 0; i < seg.size(); ++i) out->order[i] = (uint32_t)(std::find(seg_in.begin(), seg_in.end(), seg[i]) - seg_in.begin());
