@@ -890,10 +890,13 @@ static int make_tile_schedule_rule(int dtype, uint32_t n, const qip_op* ops, uin
 
 // The plan under each rule for claiming a segment's positions (first come / what a position buys, two weights for the
 // diagonal gates), shortest kept: host arithmetic, microseconds per gate, against ~6 ms per sweep saved at n = 30.  Below
-// n = 24 a sweep costs less than the search: first come only.  Global option "tile_sched": 0 = first come only.
+// n = 24 a sweep costs less than the search: first come only.  Global option "tile_sched": 0 = first come only (and the
+// circuit's own gate order inside every segment), 1 = default, 2 = search at every size and in every mode (tests).
 int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
                        bool allow_permute) {
-  const bool search = g_tile_sched != 0 && (n >= 24 || g_tile_sched == 2) && count >= 8;  // (2 = at every size: tests)
+  // (only where gates may be reordered freely, tile = 2: in the IEEE-equal mode the sweeps are bound by f64 issue, a plan with
+  // fewer, heavier sweeps is not faster there — Grover 15 -> 14 sweeps measured 2 % slower — and first come stays)
+  const bool search = g_tile_sched != 0 && (n >= 24 || g_tile_sched == 2) && count >= 8 && ((mode & 3) >= 2 || g_tile_sched == 2);  // (2 = always: tests)
   if (!search) {
     t_seg_rule = 0;
     return make_tile_schedule_rule(dtype, n, ops, count, mode, allow_2q, out, allow_permute);
