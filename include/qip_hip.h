@@ -98,6 +98,10 @@ int qip_hip_abi_version(void);
  *                      a bit inside a 1-KiB row, 2 = every dense k = 2, 3, 3 (default) = uncontrolled single-qubit gates on a
  *                      position >= 6 as well.  "single_via_tile_f32": the same switch for Complex<f32> states (default 3).
  *   "jit_cache_cap"    bound of the run-time compiler's kernel cache (default 512, see qip_hip_jit_cache_info).
+ *   "tile_sched"       the tile scheduler's host-side decisions: 1 (default) = gates inside a segment are ordered for the fewest
+ *                      LDS passes (tile = 1: only across gates that commute exactly, the result stays IEEE-equal to circuit
+ *                      order) and, with tile = 2 from n = 24, the five positions of a segment are claimed by what they buy
+ *                      (shortest of three plans); 0 = first come, circuit order inside segments; 2 = search at every size (tests).
  *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
  *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
  *                      (profiles/r02_*.md, r03_tile_skeleton.md). */
