@@ -1,6 +1,7 @@
 // qip_tile_sched.hip — the host-only half of the LDS-resident tile sweeps: which gates form a segment, the passes of a
 // segment, the qubit relabelling, and the plan export the CPU tests replay.  No kernel is launched from this file.
 #include "qip_tile.h"
+#include <array>
 
 // ---------------------------------------------------------------------------------------
 // LDS-resident multi-gate sweeps (option "tile"): the scheduler cuts the circuit into segments whose
@@ -197,99 +198,145 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
     const auto f = std::find(high.begin(), high.end(), pos);
     return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
-  if (passes && order_rule >= 1 && g_tile_sched != 0 && seg.size() >= 3) {
+  if (passes && order_rule >= 1 && g_tile_sched != 0 && seg.size() >= 3 && seg.size() <= 256) {
     const size_t N = seg.size();
-    auto tile_pos = [&](uint32_t pos) { return pos < (uint32_t)kTileLow || std::find(high.begin(), high.end(), pos) != high.end(); };
-    std::vector<std::vector<uint32_t>> ex(N);  // exchange positions (all inside the tile by construction)
-    std::vector<std::vector<uint32_t>> ctl(N);  // controls inside the tile
+    typedef std::array<uint64_t, 4> Set;  // a set of the segment's gates
+    auto has = [](const Set& m, size_t j) { return (m[j >> 6] >> (j & 63)) & 1ull; };
+    auto put = [](Set& m, size_t j) { m[j >> 6] |= 1ull << (j & 63); };
+    std::vector<uint32_t> ex(N, 0), full(N, 0);  // masks over the tile's eleven bits: exchange bits; those plus the in-tile controls when three slots allow
     for (size_t i = 0; i < N; ++i) {
       const TileItem& it = *seg[i];
-      if (it.kind == 0) ex[i] = {it.t0};
-      if (it.kind == 2 || it.kind == 3) ex[i] = {it.t0, it.t1};
-      if (it.kind == 4) ex[i] = {it.t0, it.t1, it.t2};
-      for (uint32_t c : it.cpos)
-        if (tile_pos(c)) ctl[i].push_back(c);
+      uint32_t e = 0, c = 0;
+      if (it.kind == 0) e = 1u << tile_bit(it.t0);
+      if (it.kind == 2 || it.kind == 3) e = (1u << tile_bit(it.t0)) | (1u << tile_bit(it.t1));
+      if (it.kind == 4) e = (1u << tile_bit(it.t0)) | (1u << tile_bit(it.t1)) | (1u << tile_bit(it.t2));
+      for (uint32_t cp : it.cpos)
+        if (tile_bit(cp) != kTileOutside) c |= 1u << tile_bit(cp);
+      ex[i] = e;
+      full[i] = e && __builtin_popcount(e | c) <= 3 ? (e | c) : e;
     }
-    std::vector<std::vector<uint32_t>> preds(N);
+    std::vector<Set> preds(N, Set{0, 0, 0, 0});
     for (size_t j = 0; j < N; ++j)
       for (size_t i = 0; i < j; ++i) {
         const TileItem &a = *seg[i], &b = *seg[j];
         const bool commute = !(b.nd_mask & (a.nd_mask | a.d_mask)) && !(b.d_mask & a.nd_mask);
-        if (!commute || (order_rule < 2 && !a.exact && !b.exact)) preds[j].push_back((uint32_t)i);
+        if (!commute || (order_rule < 2 && !a.exact && !b.exact)) put(preds[j], i);
       }
-    std::vector<char> placed(N, 0);
-    std::vector<const TileItem*> order;
-    std::vector<uint32_t> bits;  // the open pass's exchange positions
-    auto ready = [&](size_t j) {
-      if (placed[j]) return false;
-      for (uint32_t i : preds[j])
-        if (!placed[i]) return false;
+    auto ready = [&](const Set& placed, size_t j) {
+      if (has(placed, j)) return false;
+      for (int w = 0; w < 4; ++w)
+        if (preds[j][w] & ~placed[w]) return false;
       return true;
     };
-    auto united = [&](const std::vector<uint32_t>& extra) {
-      std::vector<uint32_t> m = bits;
-      for (uint32_t b : extra)
-        if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
-      return m;
-    };
-    // what the grouping below will ask of the pass for this gate: its exchange bits, plus its in-tile controls when three slots allow
-    auto wanted = [&](size_t j) {
-      std::vector<uint32_t> w = ex[j];
-      if (!w.empty() && w.size() + ctl[j].size() <= 3) w.insert(w.end(), ctl[j].begin(), ctl[j].end());
-      return w;
-    };
-    while (order.size() < N) {
-      // every ready gate that fits the open pass as it stands (no new bit), earliest first; then the ready gate that adds the
-      // fewest bits; when nothing fits the pass closes and the earliest ready gate opens the next one
-      bool progressed = false;
-      for (size_t j = 0; j < N; ++j)
-        if (ready(j) && united(wanted(j)).size() == bits.size()) {
-          placed[j] = 1;
-          order.push_back(seg[j]);
-          progressed = true;
-        }
-      if (progressed) continue;
-      size_t pick = N, pick_sz = 4;
-      for (size_t j = 0; j < N; ++j)
-        if (ready(j)) {
-          const size_t sz = united(wanted(j)).size();
-          if (sz <= 3 && sz < pick_sz) {
-            pick = j;
-            pick_sz = sz;
-          }
-        }
-      if (pick == N) {  // nothing fits: new pass with the earliest ready gate
-        bits.clear();
-        for (size_t j = 0; j < N; ++j)
-          if (ready(j)) {
-            pick = j;
-            break;
-          }
-      }
-      bits = united(wanted(pick));
-      placed[pick] = 1;
-      order.push_back(seg[pick]);
-    }
-    // adopt the new order only when it really saves passes (counted with the grouping rule below): where the circuit's own
-    // order is already as good (QFT: two passes per segment either way) it is kept — its runs of diagonal gates merge better
-    auto count_passes = [&](const std::vector<const TileItem*>& sq) {
-      std::vector<uint32_t> open;
+    // the grouping rule of the pass table below, as a count
+    auto count_passes = [&](const std::vector<size_t>& sq) {
+      uint32_t open = 0;
       size_t np = 1;
-      for (const TileItem* it : sq) {
-        const size_t j = (size_t)(std::find(seg.begin(), seg.end(), it) - seg.begin());
-        const std::vector<uint32_t> w = wanted(j);
-        std::vector<uint32_t> m = open;
-        for (uint32_t b : w)
-          if (std::find(m.begin(), m.end(), b) == m.end()) m.push_back(b);
-        if (m.size() > 3) {
+      for (size_t j : sq) {
+        if (__builtin_popcount(open | full[j]) <= 3) open |= full[j];
+        else if (__builtin_popcount(open | ex[j]) <= 3) open |= ex[j];
+        else {
           ++np;
-          m = w;
+          open = full[j];
         }
-        open = m;
       }
       return np;
     };
-    if (count_passes(order) < count_passes(seg)) seg = order;
+    std::vector<size_t> original(N);
+    for (size_t j = 0; j < N; ++j) original[j] = j;
+    // A: grow the open pass — every ready gate that fits it as it stands, then the ready gate that adds the fewest bits; when
+    // nothing fits the earliest ready gate opens the next pass
+    std::vector<size_t> order_a;
+    {
+      Set placed{0, 0, 0, 0};
+      uint32_t bits = 0;
+      while (order_a.size() < N) {
+        bool progressed = false;
+        for (size_t j = 0; j < N; ++j)
+          if (ready(placed, j) && (full[j] & ~bits) == 0) {
+            put(placed, j);
+            order_a.push_back(j);
+            progressed = true;
+          }
+        if (progressed) continue;
+        size_t pick = N;
+        int pick_sz = 4;
+        for (size_t j = 0; j < N; ++j)
+          if (ready(placed, j)) {
+            const int sz = __builtin_popcount(bits | full[j]);
+            if (sz <= 3 && sz < pick_sz) {
+              pick = j;
+              pick_sz = sz;
+            }
+          }
+        if (pick == N) {
+          bits = 0;
+          for (size_t j = 0; j < N; ++j)
+            if (ready(placed, j)) {
+              pick = j;
+              break;
+            }
+        }
+        bits |= full[pick];
+        put(placed, pick);
+        order_a.push_back(pick);
+      }
+    }
+    // B: pass by pass, the three tile bits whose closure — every gate that becomes ready and exchanges only across them —
+    // is largest (gates that compute count 1, diagonal ones, which fit any pass, a little)
+    std::vector<size_t> order_b;
+    {
+      Set placed{0, 0, 0, 0};
+      auto closure = [&](uint32_t tri, Set pl, std::vector<size_t>* emit) {
+        double w = 0;
+        for (bool again = true; again;) {
+          again = false;
+          for (size_t j = 0; j < N; ++j)
+            if ((ex[j] & ~tri) == 0 && ready(pl, j)) {
+              put(pl, j);
+              w += ex[j] ? 1.0 : 0.01;
+              if (emit) emit->push_back(j);
+              again = true;
+            }
+        }
+        return w;
+      };
+      while (order_b.size() < N) {
+        uint32_t best_T = 0;
+        double best_w = -1;
+        for (uint32_t a = 0; a < (uint32_t)kTileBits; ++a)
+          for (uint32_t b = a + 1; b < (uint32_t)kTileBits; ++b)
+            for (uint32_t c = b + 1; c < (uint32_t)kTileBits; ++c) {
+              const uint32_t tri = (1u << a) | (1u << b) | (1u << c);
+              const double w = closure(tri, placed, nullptr);
+              if (w > best_w) {
+                best_w = w;
+                best_T = tri;
+              }
+            }
+        std::vector<size_t> emit;
+        closure(best_T, placed, &emit);
+        if (emit.empty()) break;  // (cannot happen: some ready gate exchanges across at most three bits)
+        for (size_t j : emit) {
+          put(placed, j);
+          order_b.push_back(j);
+        }
+      }
+    }
+    // adopt a new order only when it really saves passes: where the circuit's own order is already as good (QFT: two passes
+    // per segment either way) it is kept — its runs of diagonal gates merge better
+    const std::vector<size_t>* best = &original;
+    size_t best_np = count_passes(original);
+    for (const std::vector<size_t>* cand : {&order_a, &order_b})
+      if (cand->size() == N && count_passes(*cand) < best_np) {
+        best_np = count_passes(*cand);
+        best = cand;
+      }
+    if (best != &original) {
+      std::vector<const TileItem*> sq(N);
+      for (size_t k = 0; k < N; ++k) sq[k] = seg[(*best)[k]];
+      seg = sq;
+    }
   }
   out->order.resize(seg.size());
   for (size_t i = 0; i < seg.size(); ++i) out->order[i] = (uint32_t)(std::find(seg_in.begin(), seg_in.end(), seg[i]) - seg_in.begin());
@@ -399,6 +446,13 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
         return m;
       };
       std::vector<uint32_t> merged = merge(add);
+      if (merged.size() > 3 && !add.empty()) {  // the controls were optional: the exchange bits alone may still fit the open pass
+        std::vector<uint32_t> bare;
+        if (gates[i].kind == 0) bare = {gates[i].b0};
+        if (gates[i].kind == 2 || gates[i].kind == 3) bare = {gates[i].b0, gates[i].b1};
+        if (gates[i].kind == 4) bare = {gates[i].b0, gates[i].b1, gates[i].tpos_out};
+        if (merge(bare).size() <= 3) merged = merge(bare);
+      }
       if (merged.size() > 3) {
         close_pass(i);
         merged = add;
