@@ -278,6 +278,8 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs4_grover_tile1_jit", circuits.c5_grover_iteration(n)[:100], True, seed=22, max_len=96, tile=1, tile_jit=1)
     leg("configs4_grover_dense_k3_tile1_jit", circuits.c5_grover_iteration(n, dense_k3=True)[:80], False, seed=23, max_len=96, tile=1, tile_jit=1)
     leg("configs2_qft_tile2_jit_fma_merge", circuits.c3_qft(n)[:200], False, seed=24, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
+    leg("configs3_clifford_t_tile2_jit_fma_merge_relabel", circuits.c4_clifford_t(n, gates, seed=32)[gates // 2:gates // 2 + 64], False, seed=25,
+        tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
     twin.close()
     # back to a product state for the timed part (the checked circuits entangled it): re-prepare and advance as before
     st.init_basis(0)
@@ -521,6 +523,8 @@ def main():
             extras[cname]["tile1_jit"].update({"segments_compiled": k1 - k0, "compile_ms_once": ms1 - ms0})
             if "clifford" in cname:  # (QFT and Grover are layered: the scheduler keeps the plain plan for them)
                 extras[cname]["tile1_jit_relabel"] = leg(cops, "ops", tile=1, tile_jit=1, tile_relabel=1)
+                # ... and the 1e-12 mode as it is timed for configs[1] (fused multiply-adds, merged diagonal runs, relabelled)
+                extras[cname]["tile2_jit_fma_merge_relabel"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
             if "qft" in cname:  # the issue-bound circuit: the 1e-12 mode with fused multiply-adds
                 extras[cname]["tile2_jit_fma"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1)
                 extras[cname]["tile2_jit_fma_merge"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
