@@ -208,6 +208,23 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     from oracle import qip_oracle as O
     from oracle import window_parity as W
 
+    if os.environ.get("QIP_BENCH_SABOTAGE_PARITY"):
+        # TEST HOOK (tests/test_parity_gpu.py::test_bench_fails_when_parity_fails): the CHECKER is made to disagree — the
+        # oracle's output is perturbed by one ulp-sized nudge on one row — so that the failure path of this script (parity_ok
+        # false, value null, exit status 1) can be exercised.  The product is not touched.
+        real = O.apply_op_overwrite
+
+        class _Sabotaged:
+            def __getattr__(self, name):
+                return getattr(O_real, name)
+
+            @staticmethod
+            def apply_op_overwrite(m, op, x, out, *a, **kw):
+                real(m, op, x, out, *a, **kw)
+                out[1] += 1e-9
+
+        O_real, O = O, _Sabotaged()
+
     t0 = time.perf_counter()
     ops0, vecs = W.product_state_ops(n, seed=n)
     st.init_basis(0)
@@ -217,7 +234,10 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
         got = st.download(off, 1 << 16)
         want = W.product_state_window(n, vecs, off, 1 << 16)
         init_err = max(init_err, float(np.max(np.abs(got - want) / np.abs(want))))
-    twin = W.Twin(st, lambda: q.HipState(n, np.complex128, device=st_device(st)))
+    # the twin needs a second 2^n state (and the relabelled / permutation legs a scratch buffer per state): from n = 32 on one
+    # GPU that no longer fits 288 GB, and the whole-vector guard is the closed-form marginals alone (single-qubit legs)
+    twin = W.Twin(st, lambda: q.HipState(n, np.complex128, device=st_device(st))) if n <= 31 else None
+    big = n >= 33  # one 128-GiB buffer: no leg may take the out-of-place path
     guard = W.ProductGuard(n, vecs)
     guard.check(st)
     legs = {}
@@ -230,9 +250,13 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
             st.set_option(k, 0)
         r["options"] = options
         r["bar"] = "IEEE-equal" if exact else "1e-12"
+        r.setdefault("whole_vector_compares", 0)
+        r.setdefault("whole_vector_amplitudes_not_equal", 0)
+        r.setdefault("whole_vector_max_abs_delta", 0.0)
         r["ok"] = bool((r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0) if exact
                        else (r["max_abs_delta"] <= 1e-12 and r["whole_vector_max_abs_delta"] <= 1e-12))
-        if not exact:
+        r["ok"] = bool(r["ok"] and r["skipped"] == 0)
+        if not exact and twin is not None:
             twin.resync()
         legs[name] = r
 
@@ -260,6 +284,8 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("mixed_gate_by_gate", ops_mixed[:32], True, gate_by_gate=True, seed=12, bases=4)
     leg("mixed_tile1_chunks", ops_mixed[32:96], True, seed=13, bases=4, tile=1)
     leg("mixed_tile1_jit_chunks", ops_mixed[96:160], True, seed=14, tile=1, tile_jit=1)
+    if big:
+        return finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0)
     # ... with the scheduler relabelling the qubits (tile_relabel = 2: unconditionally, so that every chunk goes through
     # in-tile swaps and the closing bit-permutation sweep); two Swap ops ride along as label exchanges
     swaps = [q.make_swap_op([3], [n - 2]), q.make_swap_op([n - 9], [0])]
@@ -280,7 +306,12 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs2_qft_tile2_jit_fma_merge", circuits.c3_qft(n)[:200], False, seed=24, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
     leg("configs3_clifford_t_tile2_jit_fma_merge_relabel", circuits.c4_clifford_t(n, gates, seed=32)[gates // 2:gates // 2 + 64], False, seed=25,
         tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
-    twin.close()
+    return finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0)
+
+
+def finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0):
+    if twin is not None:
+        twin.close()
     # back to a product state for the timed part (the checked circuits entangled it): re-prepare and advance as before
     st.init_basis(0)
     st.apply_ops(ops0 + a_ops)
@@ -295,11 +326,12 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
         "apply_op_row_calls": tot("row_calls"),
         "max_abs_delta": max(r["max_abs_delta"] for r in exact_legs),
         "bit_equal": bool(all(r["bit_equal"] for r in exact_legs)),
-        "max_abs_delta_1e-12_legs": max(r["max_abs_delta"] for r in legs.values() if r["bar"] != "IEEE-equal"),
+        "max_abs_delta_1e-12_legs": max([r["max_abs_delta"] for r in legs.values() if r["bar"] != "IEEE-equal"] or [0.0]),
+        "whole_vector_guard": "twin state + closed-form marginals" if twin is not None else "closed-form marginals only (no room for a twin state)",
         "whole_vector": {"compares": tot("whole_vector_compares"), "amplitudes_per_compare": 1 << n,
                          "amplitudes_not_equal_in_IEEE_legs": sum(r["whole_vector_amplitudes_not_equal"] for r in exact_legs),
                          "max_abs_delta_all_legs": max(r["whole_vector_max_abs_delta"] for r in legs.values())},
-        "all_legs_ok": bool(all(r["ok"] for r in legs.values())),
+        "all_legs_ok": bool(all(r["ok"] for r in legs.values()) and init_err <= 1e-12),
         "legs": legs,
         "seconds": round(time.perf_counter() - t0, 2),
     }
@@ -559,35 +591,6 @@ def main():
             f32["norm_sqr"] = s32.norm_sqr()
             extras["complex64_n%d" % n] = f32
 
-    if world > 1 and not args.no_parity:
-        # The N > 1 path against the CPU oracle on THIS fabric (the real transport, every rank's real kernels): a small
-        # sharded state (18 local qubits) runs the headline generator's mix + QFT + a Grover iteration, is gathered in
-        # logical order and compared with the oracle applied to the full vector.  The checker, never timed.  Guarded.
-        try:
-            from oracle import qip_oracle as O
-            from rustqip_amd.sharded import DistState
-
-            t_par = time.perf_counter()
-            n_s = 18 + g
-            xs = circuits.random_state(n_s, seed=n_s)
-            worst, gates, remaps = 0.0, 0, 0
-            for cops in (circuits.h_layer(n_s) + circuits.c2_random_circuit(n_s, 96, seed=28), circuits.c3_qft(n_s)[:120],
-                         circuits.c5_grover_iteration(n_s, dense_k3=True)):
-                small = DistState(n_s, dist, device, np.complex128, host_staged=dist_backend != "nccl")
-                small.upload_global(xs)
-                small.apply_ops(cops)
-                got = small.download_global()
-                remaps += small.comm_stats()["remaps"]
-                small.close()
-                want = O.apply_ops_in_place(n_s, cops, xs.copy())
-                worst = max(worst, float(np.max(np.abs(got - want))))
-                gates += len(cops)
-            parity = {"checker": "CPU oracle on the gathered full vector of a small sharded state, same transport and kernels (oracle/qip_oracle.c)",
-                      "n": n_s, "world": world, "gates_checked": gates, "rows_checked": 3 << n_s, "remaps_exercised": remaps,
-                      "max_abs_delta": max_over_ranks(worst), "tolerance": 1e-12, "seconds": round(time.perf_counter() - t_par, 2)}
-        except Exception as exc:  # noqa: BLE001
-            parity = {"error": repr(exc)}
-
     if world > 1 and not args.no_extras:
         # BASELINE configs[3] (Clifford+T) and configs[4] (Grover iteration, plain and dense k = 3) on the sharded
         # state, and the headline circuit with the local runs between remaps applied as tile sweeps (tile = 1:
@@ -626,14 +629,55 @@ def main():
         except Exception as exc:  # noqa: BLE001
             extras["norm_sqr_end"] = repr(exc)
 
+    dist_desc = st.describe() if world > 1 else None
+    if world > 1 and not args.no_parity:
+        # The N > 1 path against the CPU oracle on THIS fabric (the real transport, every rank's real kernels), at the size
+        # that was just timed: closed sub-cubes of the logical index space gathered through the layout, a twin sharded state
+        # on the literal kernel compared over all 2^n amplitudes after every step, closed-form marginals of the product state
+        # (oracle/window_parity.sharded_parity) — plus a small sharded state compared as a gathered full vector.  The
+        # checker, never timed.  A failure here is fatal for the line (parity_ok false, value null, rc 1).
+        try:
+            from oracle import qip_oracle as O
+            from oracle import window_parity as W
+            from rustqip_amd.sharded import DistState
+
+            t_par = time.perf_counter()
+            n_s = 18 + g
+            xs = circuits.random_state(n_s, seed=n_s)
+            worst, gates_s, remaps_s = 0.0, 0, 0
+            for cops in (circuits.h_layer(n_s) + circuits.c2_random_circuit(n_s, 96, seed=28), circuits.c3_qft(n_s)[:120],
+                         circuits.c5_grover_iteration(n_s, dense_k3=True)):
+                small = DistState(n_s, dist, device, np.complex128, host_staged=dist_backend != "nccl")
+                small.upload_global(xs)
+                small.apply_ops(cops)
+                got = small.download_global()
+                remaps_s += small.comm_stats()["remaps"]
+                small.close()
+                want = O.apply_ops_in_place(n_s, cops, xs.copy())
+                worst = max(worst, float(np.max(np.abs(got - want))))
+                gates_s += len(cops)
+            worst = max_over_ranks(worst)
+            st.close()  # (the timed state: its two 2^n_local buffers make room for the checked state and its twin)
+            parity = W.sharded_parity(lambda: DistState(n, dist, device, np.complex128, host_staged=dist_backend != "nccl"),
+                                      dist, n, O, q, circuits, gates=args.gates)
+            parity["small_full_vector"] = {"n": n_s, "gates_checked": gates_s, "rows_checked": 3 << n_s, "remaps_exercised": remaps_s,
+                                           "max_abs_delta": worst, "ok": bool(worst <= 1e-12)}
+            parity["all_legs_ok"] = bool(parity["all_legs_ok"] and worst <= 1e-12)
+            parity["seconds"] = round(time.perf_counter() - t_par, 2)
+            st = None
+        except Exception as exc:  # noqa: BLE001
+            parity = {"error": repr(exc), "all_legs_ok": False}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(q, circuits, args)
 
+    # parity is the first gate: a line whose checked legs did not all pass carries no value and the run fails
+    parity_ok = None if parity is None else bool(parity.get("all_legs_ok", False))
     if rank == 0:
         line = {
             "metric": "single-qubit gate apply GB/s (algorithmic bytes: 32 * 2^n per H / X / Rz gate)",
-            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value if parity_ok is not False else None, "unit": "GB/s", "parity_ok": parity_ok, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
@@ -659,7 +703,7 @@ def main():
             line["extras"] = extras
         if world > 1:
             line["comm"] = comm_headline
-            line["dist"] = st.describe()
+            line["dist"] = dist_desc
             # what RCCL itself reports (ncclCommCount read back from the communicator, min over ranks): proof that the
             # collective library saw `world` ranks; 0 with the host-staged test transport
             line["rccl_ranks"] = rccl_ranks_min
@@ -668,10 +712,16 @@ def main():
                 # (aggregate GB/s / G) / single-GPU GB/s at the same shard size, communication included
                 line["per_gpu_efficiency"] = value / world / ref["value"]
                 line["per_gpu_efficiency_reference"] = ref
+        if parity_ok is False:
+            line["value_withheld"] = value
+            print("bench.py: PARITY FAILED — the measured value is withheld (value: null) and the run exits with status 1; see parity.legs",
+                  file=sys.stderr)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_ok is False:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,12 @@ impl<P: HipPrecision> HipState<P> {
         check(unsafe { sys::qip_hip_state_max_abs_diff(self.h, other.h, &mut worst, &mut differ) })?;
         Ok((worst, differ))
     }
+    /// Amplitudes at an explicit list of indices (one gather kernel): a logical window of a sharded / relabelled state.
+    pub fn download_indices(&mut self, indices: &[u64]) -> Result<Vec<Complex<P>>, HipError> {
+        let mut out = vec![Complex::new(P::zero(), P::zero()); indices.len()];
+        check(unsafe { sys::qip_hip_state_download_indices(self.h, indices.as_ptr(), indices.len() as u64, out.as_mut_ptr() as *mut _) })?;
+        Ok(out)
+    }
     pub fn norm_sqr(&self) -> Result<f64, HipError> {
         let mut v = 0.0;
         check(unsafe { sys::qip_hip_state_norm_sqr(self.h, &mut v) })?;

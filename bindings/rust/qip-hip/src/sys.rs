@@ -1,4 +1,4 @@
-//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 4).
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 5).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
@@ -103,6 +103,7 @@ extern "C" {
 
     pub fn qip_hip_state_copy_from(dst: *mut qip_hip_state, src: *mut qip_hip_state) -> c_int;
     pub fn qip_hip_state_max_abs_diff(a: *mut qip_hip_state, b: *mut qip_hip_state, max_abs: *mut c_double, n_differ: *mut u64) -> c_int;
+    pub fn qip_hip_state_download_indices(s: *mut qip_hip_state, indices: *const u64, count: u64, dst: *mut c_void) -> c_int;
     pub fn qip_hip_state_norm_sqr(s: *mut qip_hip_state, out: *mut c_double) -> c_int;
     pub fn qip_hip_state_measure_probs(
         s: *mut qip_hip_state, indices: *const u64, k: u32, out: *mut c_double,
@@ -201,4 +202,7 @@ pub struct qip_hip_dist_stats {
     pub rccl_rank: i32,
     pub pieces_sent: u64,
     pub piece_bytes: u64,
+    /// (ABI 5) pack sweeps that took the LDS-tiled bit-permutation sweep; remaps whose gather rode in the preceding tile sweep
+    pub packs_via_permute: u64,
+    pub packs_folded: u64,
 }

@@ -314,12 +314,18 @@ int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
 int qip_hip_state_profile_reset(qip_hip_state* s);
 
 /* ---- two states side by side (validation support; no reference counterpart: the reference compares host Vecs) ---------
- * copy_from: dst <- src (same n, precision and device; stream-ordered on dst's stream after src's queued work).
+ * copy_from: dst <- src (same n, precision and device; ordered after src's queued work, and COMPLETE when the call returns:
+ * the two handles own separate streams, so the next gate queued on src must not overtake the copy's reads).
  * max_abs_diff: max_i |a_i - b_i| over the WHOLE vector and the number of amplitudes whose components are not IEEE-equal
  * (one coalesced pass over both states).  The parity checks use it to hold a state that went through a fast path against a
  * twin that went gate by gate through the literal kernel, so that a stray write anywhere in the 2^n amplitudes is seen. */
 int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src);
 int qip_hip_state_max_abs_diff(qip_hip_state* a, qip_hip_state* b, double* max_abs, uint64_t* n_differ);
+/* (ABI 5) dst[i] = state[indices[i]], i < count: amplitudes picked by an explicit index list in one small gather kernel.  The
+ * sub-cubes the parity checks compare are CONTIGUOUS windows only in the caller's own index order; on a shard of a sharded
+ * state (whose logical -> physical map moves with every exchange, qip_hip_dist_layout) a logical window is scattered, and
+ * this is how the checker reads it at shard sizes of 2^28 and more without downloading the shard.  Synchronises. */
+int qip_hip_state_download_indices(qip_hip_state* s, const uint64_t* indices, uint64_t count, void* dst);
 
 /* ---- measurement (qip/src/state_ops/measurement_ops.rs) ----------------- */
 
@@ -401,7 +407,8 @@ int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op);
  * go to the shard as one qip_hip_state_apply_ops batch (so option "tile" applies to them) */
 int qip_hip_dist_apply_ops(qip_hip_dist* d, const qip_op* ops, uint64_t count);
 int qip_hip_dist_sync(qip_hip_dist* d);
-/* options: "tile", "fuse", "mfma", "profile", ... are forwarded to the shard (qip_hip_state_set_option) */
+/* options: "tile", "fuse", "mfma", "profile", ... are forwarded to the shard (qip_hip_state_set_option); "piece_bytes"
+ * (largest single ncclSend / ncclRecv) belongs to the built-in RCCL transport: QIP_ERR_UNSUPPORTED with a caller-supplied one */
 int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value);
 
 /* measurement over the whole vector (measurement_ops.rs:11-13, 115-127, 190-269): local reductions + one all-reduce;
@@ -422,7 +429,9 @@ int qip_hip_dist_soft_measure(qip_hip_dist* d, const uint64_t* indices, uint32_t
  * current layout: phys[p] = physical bit position of logical bit position p (= n-1-qubit), n entries; physical
  * positions >= n-g are rank bits.  Together they let the host scatter / gather a vector in logical order.  The layout
  * changes with every exchange and with every uncontrolled Swap (SwapOpIterator, qubit_iterators.rs:176-219, only permutes
- * index bits: on a sharded state the qubits trade entries of this map and no amplitude moves). */
+ * index bits: on a sharded state the qubits trade entries of this map and no amplitude moves — also when world = 1: the
+ * shard of a qip_hip_dist is ALWAYS to be read through qip_hip_dist_layout, never as if it were in the caller's order;
+ * behaviour since ABI 4, where such a Swap used to run as a sweep). */
 int qip_hip_dist_local_state(qip_hip_dist* d, qip_hip_state** shard);
 int qip_hip_dist_layout(qip_hip_dist* d, uint32_t* phys);
 /* Pending rank renamings: rank bit j (physical position n-g+j) reads as (bit j of the rank) XOR (bit j of *mask).  An
@@ -443,6 +452,11 @@ typedef struct qip_hip_dist_stats {
   int32_t rccl_ranks, rccl_rank;
   uint64_t pieces_sent;       /* ncclSend calls issued (chunks above `piece_bytes` go in several) */
   uint64_t piece_bytes;       /* the piece size in force (option "piece_bytes", default 1 GiB) */
+  /* (ABI 5) how many of `pack_sweeps` took the LDS-tiled bit-permutation sweep (k_permute_bits) because a gathered position
+   * lies inside a 1-KiB row (position < 6), and how many remaps needed no sweep of their own because the gather rode in the
+   * store phase of the tile sweep before them (`packs_folded`: counted in neither pack_sweeps nor pack_ms) */
+  uint64_t packs_via_permute;
+  uint64_t packs_folded;
 } qip_hip_dist_stats;
 /* counters since the previous call (they reset; rccl_ranks / rccl_rank / piece_bytes are properties, not counters) */
 int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);

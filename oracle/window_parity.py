@@ -103,6 +103,15 @@ class SubCube:
     def gather(self, download: Callable[[int, int], np.ndarray], base: int) -> np.ndarray:
         return np.concatenate([download(off, 1 << self.w) for off in self.offsets(base)])
 
+    def gather_state(self, state, base: int) -> np.ndarray:
+        """the sub-cube at `base` out of a state: window by window (a HipState: contiguous copies), or in ONE indexed
+        gather when the state offers download_logical (a sharded state, whose logical windows are scattered over the
+        ranks' shards: rustqip_amd.sharded.DistState)"""
+        if hasattr(state, "download_logical"):
+            w = np.arange(1 << self.w, dtype=np.uint64)
+            return state.download_logical(np.concatenate([w + np.uint64(off) for off in self.offsets(base)]))
+        return self.gather(state.download, base)
+
     def localize(self, op: MatrixOp) -> MatrixOp:
         qmap = {}
         for q in op.indices:
@@ -212,17 +221,23 @@ def check_ops(state, n: int, ops: Sequence[MatrixOp], O, bases: Optional[Sequenc
     if not cube.ok:
         return None
     bases = list(bases) if bases is not None else default_bases(n)
-    before = [cube.gather(state.download, b) for b in bases]
+    before = [cube.gather_state(state, b) for b in bases]
     if apply is not None:
         apply()
     else:
         state.apply_ops(ops)
     worst, equal, rows, row_calls, active = 0.0, True, 0, 0, 0
     rng = np.random.default_rng(n)
+    # a sharded state: every rank takes part in the (collective) gathers, ONE rank evaluates the oracle — its verdict is
+    # what sharded_parity broadcasts (N ranks computing the same comparison would only fight over the host's cores)
+    compare_here = getattr(state, "oracle_on_this_rank", True)
     for b, x in zip(bases, before):
         local_ops = [lop for lop in (cube.localize_at(op, b) for op in ops) if lop is not None]
         active += len(local_ops)
-        got = cube.gather(state.download, b)
+        got = cube.gather_state(state, b)
+        rows += got.size if not compare_here else 0
+        if not compare_here:
+            continue
         cur, arena = x.copy(), np.zeros_like(x)
         for lop in local_ops:
             O.apply_op_overwrite(cube.m, lop, cur, arena)
@@ -372,3 +387,124 @@ class ProductGuard:
         self.checks += 1
         return worst
 
+
+
+# ---- the sharded state (N > 1) at bench shard size --------------------------------------------------------------------------
+def sharded_parity(make_state: Callable[[], object], dist, n: int, O, q, circuits, gates: int = 256, quick: bool = False) -> dict:
+    """The N > 1 path against the oracle at the size it is TIMED at (the reference's only provision
+    for distribution is the window arguments of apply_op, matrix_ops.rs:74-93,96-97).  `make_state()` -> a
+    rustqip_amd.sharded.DistState of n qubits over dist's ranks.  Collective: every rank calls it with the same arguments.
+
+    Two nets, as on one GPU: closed sub-cubes of the LOGICAL index space, gathered from whichever ranks hold them through
+    the layout (DistState.download_logical), against the oracle's apply_op_overwrite / apply_op_row; and a whole-vector
+    guard — a TWIN sharded state that follows batch by batch with every shard on the literal out-of-place kernel
+    (force_generic), compared shard by shard over all 2^n amplitudes after every step, plus closed-form marginals of the
+    seeded product state through qip_hip_dist_measure_probs while only single-qubit gates have acted.
+
+    Legs: the headline gate by gate; the configs[1] mix gate by gate and as tile sweeps on the shards; Clifford+T and the
+    dense-k3 Grover iteration (tile = 0 and tile = 1); and a circuit built so that the remap HAS to gather index bit 0
+    (the k_permute_bits route of the pack).  The exchanges, pack sweeps and routes taken are reported from the handle's
+    own counters.  Rank 0 evaluates the oracle; its summary is broadcast, so every rank returns the same dict."""
+    import time
+
+    t0 = time.perf_counter()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    st = make_state()
+    st.oracle_on_this_rank = rank == 0
+    st.init_basis(0)
+    twin = Twin(st, make_state)  # both fresh: same (identity) layout; from here on they see the same batches
+    ops0, vecs = product_state_ops(n, seed=n)
+    st.apply_ops(ops0)
+    prep = twin.follow(ops0)
+    init_err = 0.0
+    for off in (0, (1 << n) // 3, (1 << n) - (1 << 16)):
+        got = st.download(off, 1 << 16)
+        want = product_state_window(n, vecs, off, 1 << 16)
+        init_err = max(init_err, float(np.max(np.abs(got - want) / np.abs(want))))
+    guard = ProductGuard(n, vecs)
+    guard.check(st)
+    st.comm_stats()
+    legs: Dict[str, dict] = {}
+
+    def leg(name, ops, exact, gate_by_gate=False, seed=0, bases=2, max_len=64, **options):
+        for k, v in options.items():
+            st.set_option(k, v)
+        r = check_circuit(st, n, ops, O, gate_by_gate=gate_by_gate, seed=seed, bases_per_step=bases, twin=twin, max_len=max_len)
+        for k in options:
+            st.set_option(k, 0)
+        r["options"] = options
+        r["bar"] = "IEEE-equal" if exact else "1e-12"
+        r["comm"] = {k: v for k, v in st.comm_stats().items() if k in ("remaps", "pack_sweeps", "packs_via_permute_bits")}
+        r["ok"] = bool((r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0) if exact
+                       else (r["max_abs_delta"] <= 1e-12 and r["whole_vector_max_abs_delta"] <= 1e-12))
+        if not exact:
+            twin.resync()
+        legs[name] = r
+
+    head = circuits.c2_random_circuit(n, gates, seed=28, single_only=True)
+    mixed = circuits.c2_random_circuit(n, gates, seed=28)
+    n_gg = 8 if quick else 24
+    for k0 in range(0, n_gg, 8):
+        leg("single_qubit_gate_by_gate_%d" % (k0 // 8), head[k0:k0 + 8], True, gate_by_gate=True, seed=31 + k0, bases=4)
+        for op in head[k0:k0 + 8]:
+            guard.apply(op)
+        guard.check(st)
+    marg = {"checks": guard.checks, "index_sets": len(guard.sets), "max_rel_err_vs_closed_form": guard.worst_rel}
+    leg("mixed_gate_by_gate", mixed[:8 if quick else 24], True, gate_by_gate=True, seed=32, bases=4)
+    leg("mixed_tile1_chunks", mixed[24:88], True, seed=33, tile=1)
+    c4 = circuits.c4_clifford_t(n, gates, seed=32)
+    leg("configs3_clifford_t_chunks", c4[:32 if quick else 64], True, seed=34)
+    leg("configs3_clifford_t_tile1_chunks", c4[64:128], True, seed=35, tile=1)
+    g3 = circuits.c5_grover_iteration(n, dense_k3=True)
+    # (a dense 8x8 gate runs on the matrix cores gate by gate and as the unfused register fold inside a sweep: 1e-12 bar)
+    leg("configs4_grover_dense_k3_chunks", g3[:48 if quick else 96], False, seed=36, max_len=96)
+    leg("configs4_grover_dense_k3_tile1_chunks", g3[96:192], False, seed=37, max_len=96, tile=1)
+    # the pack HAS to gather index bit 0: the qubit that lives there becomes the least recently used one (a layer of
+    # diagonal gates on every other qubit: no exchange), then a batch opens with an H on a qubit that sits on a rank bit
+    # and never touches it: farthest next use (never) + least recently used -> it leaves, from physical position 0
+    phys = st.layout()
+    L = n - int(round(np.log2(world)))
+    qa = n - 1 - phys.index(0)
+    glob = [n - 1 - p for p in range(n) if phys[p] >= L]
+    leg("pack_from_bit0_prelude", [q.make_matrix_op([t], circuits.rz(0.3 + 0.01 * t)) for t in range(n) if t != qa], True, seed=38, max_len=96)
+    others = [t for t in range(n) if t != qa and t not in glob]
+    batch = [q.make_matrix_op([glob[0]], circuits.H)] + [q.make_matrix_op([t], circuits.H) for t in others[:4]]
+    if world > 1:
+        leg("pack_from_bit0", batch, True, seed=39, tile=1)
+    comm_total = {}
+    for r in legs.values():
+        for k, v in r["comm"].items():
+            comm_total[k] = comm_total.get(k, 0) + v
+    twin.close()
+    st.close()
+    tot = lambda key: sum(r.get(key, 0) for r in legs.values())  # noqa: E731
+    exact_legs = [r for r in legs.values() if r["bar"] == "IEEE-equal"]
+    out = {
+        "checker": "CPU oracle (oracle/qip_oracle.c apply_op_overwrite + apply_op_row) on closed sub-cubes of the LOGICAL index space gathered "
+                   "through the layout from whichever ranks hold them (oracle/window_parity.py sharded_parity); whole-vector guard: a twin "
+                   "sharded state with every shard on the literal kernel, compared over all 2^n amplitudes after every step + closed-form "
+                   "marginals of the product state through qip_hip_dist_measure_probs",
+        "n": n, "world": world, "n_local": L,
+        "state": "seeded product state, pairwise distinct amplitudes (closed form checked: max rel err %.1e)" % init_err,
+        "prep_whole_vector": prep,
+        "gates_checked": tot("gates"), "gates_skipped": tot("skipped"), "rows_checked": tot("rows"), "windows": tot("windows"),
+        "apply_op_row_calls": tot("row_calls"),
+        "max_abs_delta": max(r["max_abs_delta"] for r in exact_legs),
+        "bit_equal": bool(all(r["bit_equal"] for r in exact_legs)),
+        "max_abs_delta_1e-12_legs": max([r["max_abs_delta"] for r in legs.values() if r["bar"] != "IEEE-equal"] or [0.0]),
+        "whole_vector": {"compares": tot("whole_vector_compares"), "amplitudes_per_compare": 1 << n,
+                         "amplitudes_not_equal_in_IEEE_legs": sum(r["whole_vector_amplitudes_not_equal"] for r in exact_legs),
+                         "max_abs_delta_all_legs": max(r["whole_vector_max_abs_delta"] for r in legs.values())},
+        "product_state_marginals": marg,
+        "remaps_exercised": comm_total.get("remaps", 0), "pack_sweeps": comm_total.get("pack_sweeps", 0),
+        "packs_via_permute_bits": comm_total.get("packs_via_permute_bits", 0),
+        "tolerance": 1e-12,
+        "all_legs_ok": bool(all(r["ok"] for r in legs.values()) and prep["amplitudes_not_equal"] == 0 and init_err <= 1e-12
+                            and guard.worst_rel <= 1e-11),
+        "legs": legs,
+        "seconds": round(time.perf_counter() - t0, 2),
+    }
+    box = [out]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return box[0]

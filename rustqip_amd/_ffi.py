@@ -46,7 +46,8 @@ class QipTransport(C.Structure):
 class QipDistStats(C.Structure):
     _fields_ = [("remaps", C.c_uint64), ("pack_sweeps", C.c_uint64), ("bytes_sent", C.c_uint64),
                 ("exchange_ms", C.c_double), ("pack_ms", C.c_double),
-                ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("pieces_sent", C.c_uint64), ("piece_bytes", C.c_uint64)]
+                ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("pieces_sent", C.c_uint64), ("piece_bytes", C.c_uint64),
+                ("packs_via_permute", C.c_uint64), ("packs_folded", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/qip_hip.h declares
@@ -100,6 +101,7 @@ SIGNATURES = {
     "qip_hip_state_profile_reset": (_int, [_statep]),
     "qip_hip_state_copy_from": (_int, [_statep, _statep]),
     "qip_hip_state_max_abs_diff": (_int, [_statep, _statep, _dblp, _u64p]),
+    "qip_hip_state_download_indices": (_int, [_statep, _u64p, _u64, _vp]),
     "qip_hip_state_norm_sqr": (_int, [_statep, _dblp]),
     "qip_hip_state_measure_probs": (_int, [_statep, _u64p, _u32, _dblp]),
     "qip_hip_state_measure_prob": (_int, [_statep, _u64, _u64p, _u32, _dblp]),

@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 4; }  // 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
+extern "C" int qip_hip_abi_version(void) { return 5; }  // 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
@@ -176,7 +176,7 @@ extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) try {
 // ---------------------------------------------------------------------------------------
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
-    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_gates",     "k_gather_generic",
+    "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_passes",    "k_gather_generic",
     "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }

@@ -705,6 +705,7 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
         for (uint32_t t = 0; t < g; ++t) pi[L - g + t] = steps[i].sel[t];
         QCHK(dist_timed(d, &d->ev_pack, [&]() -> int { return launch_permute(s, pi.data()); }));  // (swaps cur / alt itself)
         d->stats.pack_sweeps += 1;
+        d->stats.packs_via_permute += 1;
         ++i;
         continue;
       }
@@ -867,7 +868,8 @@ extern "C" int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t
   if (!d) return fail(QIP_ERR_INVALID, "null dist handle");
   if (key && !strcmp(key, "piece_bytes")) {  // largest single ncclSend / ncclRecv of the built-in transport
     if (value < 16 || (value & 15)) return fail(QIP_ERR_INVALID, "piece_bytes must be a positive multiple of 16");
-    if (d->rccl) d->rccl->piece_bytes = (uint64_t)value;
+    if (!d->rccl) return fail(QIP_ERR_UNSUPPORTED, "piece_bytes belongs to the built-in RCCL transport; this handle uses caller-supplied callbacks");
+    d->rccl->piece_bytes = (uint64_t)value;
     return QIP_OK;
   }
   return qip_hip_state_set_option(d->shard, key, value);

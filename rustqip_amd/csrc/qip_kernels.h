@@ -1979,6 +1979,15 @@ __global__ __launch_bounds__(kBlock) void k_max_abs_diff(const amp_t<T>* __restr
   }
 }
 
+// Amplitudes picked by an explicit index list (qip_hip_state_download_indices: the parity checks' download of a sub-cube whose
+// index bits are scattered — a logical window of a relabelled or sharded state).  out[i] = st[idx[i]]; the indices of a sub-cube come
+// in runs, so neighbouring lanes mostly read neighbouring amplitudes.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_indices(const amp_t<T>* __restrict__ st, const uint64_t* __restrict__ idx,
+                                                           uint64_t count, amp_t<T>* __restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (uint64_t)gridDim.x * kBlock) out[i] = st[idx[i]];
+}
+
 // soft_measure's sequential scan (measurement_ops.rs:167-173) inside ONE chunk: find the first index at
 // which r - sum_{j<=i} |amp_j|^2 <= 0.  One block: every lane sums its contiguous segment, lane 0 walks the
 // 256 segment sums to the segment that crosses zero, that lane replays the sequential subtraction.

@@ -60,6 +60,39 @@ extern "C" int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src) t
   dst->layout.clear();                                // (the destination is overwritten: nothing of its own to restore)
   HIPCHK(hipStreamSynchronize(src->stream));  // everything queued on the source has landed
   HIPCHK(hipMemcpyAsync(dst->cur, src->cur, dst->namps * dst->amp_bytes, hipMemcpyDeviceToDevice, dst->stream));
+  // the two handles own separate non-blocking streams: the copy has READ the source before this call returns, so the
+  // caller may queue the next gate on `src` at once (a 16-GiB copy is not hidden by host latency)
+  HIPCHK(hipStreamSynchronize(dst->stream));
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// out[i] = state[indices[i]] for an explicit list of amplitude indices (validation support: the sub-cubes the parity checks
+// compare are scattered in a relabelled or sharded state; one small gather kernel instead of one copy per amplitude)
+extern "C" int qip_hip_state_download_indices(qip_hip_state* s, const uint64_t* indices, uint64_t count, void* dst) try {
+  STATE_ENTER(s);
+  if (count == 0) return QIP_OK;
+  if (!indices || !dst) return fail(QIP_ERR_INVALID, "null argument");
+  for (uint64_t i = 0; i < count; ++i)
+    if (indices[i] >= s->namps) return fail(QIP_ERR_INVALID, "amplitude index out of range");
+  void *d_idx = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_idx, count * sizeof(uint64_t)));
+  hipError_t e = hipMalloc(&d_out, count * s->amp_bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, indices, count * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) {
+    const unsigned gx = grid_stride(count);
+    if (s->dtype == QIP_C64)
+      hipLaunchKernelGGL((k_gather_indices<double>), dim3(gx), dim3(kBlock), 0, s->stream, (const amp_t<double>*)s->cur,
+                         (const uint64_t*)d_idx, count, (amp_t<double>*)d_out);
+    else
+      hipLaunchKernelGGL((k_gather_indices<float>), dim3(gx), dim3(kBlock), 0, s->stream, (const amp_t<float>*)s->cur,
+                         (const uint64_t*)d_idx, count, (amp_t<float>*)d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(dst, d_out, count * s->amp_bytes, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(d_idx);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(QIP_ERR_DEVICE, "download_indices failed: %s", hipGetErrorString(e));
   return QIP_OK;
 } QIP_CATCH_ALL
 

@@ -284,6 +284,12 @@ template <typename P> class HipState {
     check(qip_hip_state_max_abs_diff(h_, other.h_, &worst, &differ));
     return {worst, differ};
   }
+  /// amplitudes at an explicit list of indices (one gather kernel: a logical window of a sharded / relabelled state)
+  std::vector<std::complex<P>> download_indices(const std::vector<uint64_t>& idx) {
+    std::vector<std::complex<P>> out(idx.size());
+    check(qip_hip_state_download_indices(h_, idx.data(), idx.size(), out.data()));
+    return out;
+  }
   double norm_sqr() const {
     double v = 0;
     check(qip_hip_state_norm_sqr(h_, &v));

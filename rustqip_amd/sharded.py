@@ -126,6 +126,10 @@ def _broadcast_unique_id(dist, rank: int) -> bytes:
     return box[0]
 
 
+class QipLayoutMismatch(RuntimeError):
+    """two sharded states that were expected to share a layout do not"""
+
+
 class DistState:
     """qip_hip_dist: the n-qubit state over dist.get_world_size() ranks (one process per GPU)."""
 
@@ -200,6 +204,48 @@ class DistState:
             out[i] = v
         return out
 
+    def download_logical(self, indices) -> np.ndarray:
+        """amplitudes at the given LOGICAL indices (any order, any subset), the same array on every rank: each rank picks
+        what it holds out of its shard with one gather kernel (qip_hip_state_download_indices) and the pieces are put
+        together over the host's process group.  Collective.  This is how the parity checks read a window of a sharded
+        state at shard sizes where download_global is out of the question."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        owner, local = logical_to_shard(self.n, self.L, self.layout(), self.rank_flip(), idx)
+        mine = np.nonzero(owner == np.uint64(self.rank))[0]
+        vals = self.shard.download_indices(local[mine]) if mine.size else np.empty(0, dtype=self.np_dtype)
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, vals)
+        out = np.empty(idx.size, dtype=self.np_dtype)
+        for r, v in enumerate(parts):
+            out[owner == np.uint64(r)] = v
+        return out
+
+    def download(self, offset: int = 0, length: Optional[int] = None) -> np.ndarray:
+        """logical amplitudes [offset, offset + length), on every rank (HipState.download's signature: the window checks
+        in tests/ and bench.py take either kind of state)"""
+        length = (1 << self.n) - offset if length is None else int(length)
+        return self.download_logical(np.arange(offset, offset + length, dtype=np.uint64))
+
+    # -- two sharded states side by side (validation support, like HipState.copy_from / max_abs_diff) -----------------
+    def _same_layout(self, other: "DistState") -> None:
+        if self.layout() != other.layout() or self.rank_flip() != other.rank_flip():
+            raise QipLayoutMismatch("the two sharded states are not in the same layout (they must have seen the same batches)")
+
+    def copy_from(self, other: "DistState") -> None:
+        """self <- other, shard by shard; the two must be in the same layout (same n, same world, same op batches so far)"""
+        self._same_layout(other)
+        self.shard.copy_from(other.shard)
+
+    def max_abs_diff(self, other: "DistState"):
+        """(max |a_i - b_i|, number of amplitudes that are not IEEE-equal) over the WHOLE sharded vector: every rank
+        compares its shard on the device, the figures are combined over the ranks.  Collective."""
+        self._same_layout(other)
+        worst, differ = self.shard.max_abs_diff(other.shard)
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, (worst, differ))
+        ws = [w for w, _ in parts]
+        return (float("nan") if any(w != w for w in ws) else max(ws)), sum(d for _, d in parts)
+
     # -- gates -------------------------------------------------------------------------------------------------------------
     def apply_op(self, op: MatrixOp) -> None:
         cop = op.to_c(self.dtype)
@@ -255,7 +301,8 @@ class DistState:
                 "exchange_ms": st.exchange_ms, "pack_ms": st.pack_ms,
                 # read back from the communicator (ncclCommCount / ncclCommUserRank); 0 / -1 with caller-supplied callbacks
                 "rccl_ranks": int(st.rccl_ranks), "rccl_rank": int(st.rccl_rank),
-                "pieces_sent": int(st.pieces_sent), "piece_bytes": int(st.piece_bytes)}
+                "pieces_sent": int(st.pieces_sent), "piece_bytes": int(st.piece_bytes),
+                "packs_via_permute_bits": int(st.packs_via_permute), "packs_folded": int(st.packs_folded)}
 
     def set_profile(self, v: int) -> None:
         self.shard.set_option("profile", int(v))
@@ -269,6 +316,16 @@ class DistState:
         return {"impl": "libqip_hip.so qip_hip_dist_* (planner + pack sweep + exchange in C++)",
                 "transport": "host-staged callbacks (test hook)" if self._transport else "RCCL ncclSend/ncclRecv group (dlopen librccl)",
                 "world": self.world, "n": self.n, "n_local": self.L}
+
+
+def logical_to_shard(n: int, L: int, phys: Sequence[int], flip: int, idx: np.ndarray):
+    """(owner rank, index inside that rank's shard) of every logical index — the inverse of shard_logical_indices"""
+    idx = np.asarray(idx, dtype=np.uint64)
+    P = np.zeros_like(idx)
+    for p in range(n):
+        P |= ((idx >> np.uint64(p)) & np.uint64(1)) << np.uint64(phys[p])
+    owner = (P >> np.uint64(L)) ^ np.uint64(flip)  # rank r holds the physical rank bits r ^ flip (pending renamings)
+    return owner, P & np.uint64((1 << L) - 1)
 
 
 def shard_logical_indices(n: int, L: int, rank: int, phys: Sequence[int], flip: int = 0) -> np.ndarray:

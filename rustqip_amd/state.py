@@ -194,6 +194,13 @@ class HipState:
         _check(_ffi.lib.qip_hip_state_download(self._h, out.ctypes.data, int(offset), length))
         return out
 
+    def download_indices(self, indices) -> np.ndarray:
+        """amplitudes at an explicit list of indices (one gather kernel; the parity checks' scattered sub-cubes)"""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=self.np_dtype)
+        _check(_ffi.lib.qip_hip_state_download_indices(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), idx.size, out.ctypes.data))
+        return out
+
     def device_ptr(self) -> int:
         p = C.c_void_p()
         _check(_ffi.lib.qip_hip_state_device_ptr(self._h, C.byref(p)))

@@ -106,3 +106,23 @@ def test_uncontrolled_swap_is_a_relabelling():
     without = sharded.debug_plan(12, 0, 4, [o for o in qft if o.kind != "Swap"])
     count = lambda p, t: sum(1 for s in p["steps"] if s["t"] == t)
     assert count(with_swaps, "exchange") == count(without, "exchange") and count(with_swaps, "local") == count(without, "local")
+
+
+def test_logical_windows_of_a_sharded_state_index_math():
+    """DistState.download_logical reads a LOGICAL window out of the ranks' shards (the sharded parity checks at bench shard
+    size): its index map must be the inverse of shard_logical_indices for every layout and pending rank renaming."""
+    from rustqip_amd.sharded import logical_to_shard, shard_logical_indices
+
+    rng = np.random.default_rng(3)
+    for n, g in ((9, 1), (10, 2), (11, 3)):
+        L = n - g
+        for _ in range(5):
+            phys = [int(v) for v in rng.permutation(n)]
+            flip = int(rng.integers(0, 1 << g))
+            seen = np.zeros(1 << n, dtype=np.int64)
+            for rank in range(1 << g):
+                logical = shard_logical_indices(n, L, rank, phys, flip)
+                owner, local = logical_to_shard(n, L, phys, flip, logical)
+                assert np.all(owner == rank) and np.array_equal(local, np.arange(1 << L, dtype=np.uint64))
+                seen[logical.astype(np.int64)] += 1
+            assert np.all(seen == 1)  # the shards tile the logical index space exactly once

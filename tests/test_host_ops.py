@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
         assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_ffi.SIGNATURES) == names
-    assert _ffi.lib.qip_hip_abi_version() == 4
+    assert _ffi.lib.qip_hip_abi_version() == 5
 
 
 def test_make_matrix_op_errors():
@@ -344,7 +344,7 @@ int main(void) {
   qip_op inner = {QIP_OP_MATRIX, 1, idx + 1, 0, x, 0, 0, 0, 0};
   qip_op cnot = {QIP_OP_CONTROL, 2, idx, 1, 0, 0, 0, 0, &inner};
   qip_hip_transport t = {0, a2a, ars};
-  qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0, 0, -1, 0, 0};
+  qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0, 0, -1, 0, 0, 0, 0};
   char id[QIP_HIP_UNIQUE_ID_BYTES];
   (void)id; (void)st; (void)t;
   return qip_hip_validate_op(2, &cnot) == QIP_OK && qip_hip_abi_version() >= 1 ? 0 : 1;
