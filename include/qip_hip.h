@@ -289,7 +289,10 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    order is restored (one sweep) by the first call that needs it — download / upload / measurement /
  *                    device_ptr / a batch without relabelling / a program capture.  A circuit applied in chunks (a
  *                    variational loop, a host that streams its ops) then costs what it costs in one piece.
- *                    0 (default) = off.  Needs the scratch buffer.
+ *                    0 (default) = off.  Needs the scratch buffer (a state too large for it keeps the plain plan).  A relabelled
+ *                    batch that fails half way (a launch, an allocation, the run-time compiler) leaves the buffer in an order
+ *                    nobody can name: the handle then refuses every call that reads or computes from the amplitudes, with the
+ *                    original message, until qip_hip_state_init_basis / a full upload / copy_from overwrites them (ABI 5).
  *   "tile_fma"       1: run-time-compiled segments of "tile" = 2 are compiled with multiply-add contraction (v_fma_f64: a complex
  *                    product is 4 instead of 6 vector instructions; QFT at n = 30: 57 -> 50 ms).  Ignored for "tile" = 1, which
  *                    promises IEEE equality with the gate-by-gate path.  0 (default) = off.

@@ -287,6 +287,13 @@ static uint64_t g_jit_clock = 0, g_jit_generation = 0;
 static int64_t g_jit_cache_cap = 512;
 static uint64_t g_jit_compiles = 0, g_jit_evictions = 0;
 static double g_jit_compile_ms = 0;
+// Stream captures in progress in this process, on any handle (under g_jit_mutex).  Evicting synchronises the device and
+// unloads modules: neither may happen while ANY thread records a graph, not only the evicting handle's own capture.
+static int g_jit_captures_in_progress = 0;
+static void jit_capture_scope(int delta) {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit_captures_in_progress += delta;
+}
 
 extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
   std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -622,7 +629,7 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
     g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g_jit_cache[key] = k;
     fn = k.fn;
-    if (!s->capture_staging) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
+    if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   }
   return launch ? launch(fn) : QIP_OK;
 }
@@ -833,11 +840,17 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     // (a state above half of the 288 GB), fall back to the plan without permutation sweeps instead of failing half way
     bool permutes = false;
     for (const TileStep& st : sc.steps) permutes = permutes || !st.perm.empty();
-    if (permutes && !s->jit_prepare && !s->alt && ensure_alt(s) != QIP_OK) {
+    // ... and a plan that LEAVES the state relabelled (tile_relabel = 3) commits the first reader to a settling sweep, which
+    // needs that buffer too: a state too large for it would become unreadable — same fallback
+    bool leaves_relabelled = false;
+    if (persist)
+      for (uint32_t p = 0; p < sc.final_phys.size(); ++p) leaves_relabelled = leaves_relabelled || sc.final_phys[p] != p;
+    if ((permutes || leaves_relabelled) && !s->jit_prepare && !s->alt && ensure_alt(s) != QIP_OK) {
       (void)hipGetLastError();
       if (!s->layout.empty()) return fail(QIP_ERR_DEVICE, "no room for the second buffer a relabelled state needs");
       sc = TileSchedule();
-      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s), s->tile_passes != 0, &sc, /*allow_permute=*/false));
+      // (without relabelling: such a plan neither permutes nor leaves a layout behind)
+      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s) & 3, s->tile_passes != 0, &sc, /*allow_permute=*/false));
     }
   }
   const qip_op* ops = sc.circuit;
@@ -845,20 +858,37 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   // from here on the shard is somewhere between two layouts until the last step has been issued: single ops inside the plan
   // are already expressed in physical positions, so they must not settle (layout is cleared for the duration)
   const std::vector<uint32_t> final_phys = sc.final_phys;
+  // a relabelled plan moves the qubits between its steps: if a step fails (a launch, the arena, the run-time compiler) the
+  // buffer is in an order no caller can name — the handle is poisoned until it is re-initialised (the sharded
+  // handle does the same).  A plain plan that fails leaves a prefix of the circuit applied in the caller's order, like the
+  // gate-by-gate path: reported, not poisoned.
+  bool moves_qubits = !sc.init_phys.empty() || sc.inserted > 0 || sc.absorbed > 0;
+  for (const TileStep& st : sc.steps) moves_qubits = moves_qubits || !st.perm.empty();
   s->layout.clear();
-  for (const TileStep& st : sc.steps) {
-    if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
-      if (s->jit_prepare) continue;
-      QCHK(launch_permute(s, st.perm.data()));
-      continue;
+  auto run_steps = [&]() -> int {
+    for (const TileStep& st : sc.steps) {
+      if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
+        if (s->jit_prepare) continue;
+        QCHK(launch_permute(s, st.perm.data()));
+        continue;
+      }
+      if (st.ops.size() == 1) {
+        QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
+        continue;
+      }
+      std::vector<const TileItem*> seg;
+      for (uint64_t i : st.ops) seg.push_back(&items[i]);
+      QCHK(launch_tile_segment<T>(s, seg, st.high));
     }
-    if (st.ops.size() == 1) {
-      QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
-      continue;
+    return QIP_OK;
+  };
+  const int rc_steps = run_steps();
+  if (rc_steps != QIP_OK) {
+    if (moves_qubits && !s->jit_prepare) {
+      s->poisoned = true;
+      s->poison_msg = g_last_error;
     }
-    std::vector<const TileItem*> seg;
-    for (uint64_t i : st.ops) seg.push_back(&items[i]);
-    QCHK(launch_tile_segment<T>(s, seg, st.high));
+    return rc_steps;
   }
   if (persist) {
     bool identity = true;
@@ -959,10 +989,12 @@ static int program_capture(qip_hip_program* p) {
       return QIP_OK;
     }
     s->capture_staging = &p->staging;
+    jit_capture_scope(+1);
     int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
     s->capture_staging = nullptr;
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    jit_capture_scope(-1);
     if (rc == QIP_OK && e == hipSuccess && g) {
       if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) == hipSuccess) {
         p->graph = g;
@@ -1030,9 +1062,24 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) try {
                                     // needed a larger payload): the recorded addresses are stale, re-record
   }
   if (p->exec) {
-    HIPCHK(hipGraphLaunch(p->exec, s->stream));
-    p->last_was_graph = 1;
-    return QIP_OK;
+    // generation check and launch in ONE critical section: an eviction on another thread between the two would unload a
+    // module this graph names.  Enqueueing is asynchronous: the section is microseconds.
+    bool stale = false;
+    {
+      std::lock_guard<std::mutex> lock(g_jit_mutex);
+      stale = s->tile_jit && p->captured_jit_gen != g_jit_generation;
+      if (!stale) HIPCHK(hipGraphLaunch(p->exec, s->stream));
+    }
+    if (!stale) {
+      p->last_was_graph = 1;
+      return QIP_OK;
+    }
+    QCHK(program_capture(p));
+    if (p->exec) {
+      HIPCHK(hipGraphLaunch(p->exec, s->stream));
+      p->last_was_graph = 1;
+      return QIP_OK;
+    }
   }
   p->last_was_graph = 0;
   return qip_hip_state_apply_ops(s, p->ops, p->count);

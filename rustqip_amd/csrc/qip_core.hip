@@ -424,9 +424,10 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
 
 
 extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
-  STATE_ENTER_RAW(s);
+  STATE_ENTER_NOCHECK(s);
   if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
   s->layout.clear();  // whatever was there is overwritten: no need to restore its order first
+  s->poisoned = false;
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
   if (s->dtype == QIP_C64) {
     const double one[2] = {1.0, 0.0};
@@ -440,6 +441,10 @@ extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len) try {
+  if (s && s->poisoned && offset == 0 && len == s->namps) {  // a full upload overwrites whatever a failed batch left
+    s->poisoned = false;
+    s->layout.clear();
+  }
   STATE_ENTER(s);
   if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "upload range out of bounds");
   if (len == 0) return QIP_OK;
@@ -485,7 +490,7 @@ extern "C" int qip_hip_state_swap_buffers(qip_hip_state* s) try {
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_sync(qip_hip_state* s) try {
-  STATE_ENTER_RAW(s);  // (no amplitude is addressed: a relabelled state stays as it is)
+  STATE_ENTER_NOCHECK(s);  // (no amplitude is addressed: a relabelled state stays as it is)
   HIPCHK(hipStreamSynchronize(s->stream));
   return QIP_OK;
 } QIP_CATCH_ALL

@@ -156,6 +156,10 @@ struct qip_hip_state {
   // apply_ops calls (empty = the caller's order).  Everything that reads, writes or addresses amplitudes other than a
   // relabelling apply_ops first restores the caller's order with one bit-permutation sweep (state_settle, part of STATE_ENTER).
   std::vector<uint32_t> layout;
+  // A relabelling plan that failed half way left the buffer in an order nobody can name: every call that reads or computes
+  // from the amplitudes fails with the original message until init_basis / a full upload / copy_from overwrites them.
+  bool poisoned = false;
+  std::string poison_msg;
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
   int64_t tile_jit = 0;     // 1 (= 2) = tile segments run as kernels compiled at run time for that segment's STRUCTURE (hiprtc,
                             // cached), its numbers are kernel data (angles can change without recompiling); 3 = numbers as literals
@@ -188,9 +192,13 @@ int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r);
 int prof_end(qip_hip_state* s, ProfRec* r);
 int state_settle(qip_hip_state* s);  // qip_launch.hip: a relabelled state back to the caller's order (one permutation sweep)
 
-#define STATE_ENTER_RAW(s)                                    \
+#define STATE_ENTER_NOCHECK(s)                                 \
   if (!(s)) return fail(QIP_ERR_INVALID, "null state handle"); \
   HIPCHK(hipSetDevice((s)->device))
+#define STATE_ENTER_RAW(s)                                                                                                    \
+  STATE_ENTER_NOCHECK(s);                                                                                                     \
+  if ((s)->poisoned)                                                                                                          \
+  return fail(QIP_ERR_DEVICE, "state unusable after a relabelled batch failed half way (re-initialise it): %s", (s)->poison_msg.c_str())
 #define STATE_ENTER(s) \
   STATE_ENTER_RAW(s);  \
   if (!(s)->layout.empty()) QCHK(state_settle(s))

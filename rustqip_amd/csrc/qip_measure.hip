@@ -51,13 +51,15 @@ extern "C" int qip_hip_state_norm_sqr(qip_hip_state* s, double* out) try {
 
 // ---- two states side by side (test and validation support: a state against a reference copy) ---------------------------
 extern "C" int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src) try {
-  STATE_ENTER_RAW(dst);
+  STATE_ENTER_NOCHECK(dst);
   if (!src) return fail(QIP_ERR_INVALID, "null source state");
+  if (src->poisoned) return fail(QIP_ERR_DEVICE, "source state unusable: %s", src->poison_msg.c_str());
   if (src == dst) return QIP_OK;
   if (src->n != dst->n || src->dtype != dst->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
   if (src->device != dst->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
   if (!src->layout.empty()) QCHK(state_settle(src));  // a relabelled source: the caller's order first
   dst->layout.clear();                                // (the destination is overwritten: nothing of its own to restore)
+  dst->poisoned = false;
   HIPCHK(hipStreamSynchronize(src->stream));  // everything queued on the source has landed
   HIPCHK(hipMemcpyAsync(dst->cur, src->cur, dst->namps * dst->amp_bytes, hipMemcpyDeviceToDevice, dst->stream));
   // the two handles own separate non-blocking streams: the copy has READ the source before this call returns, so the
