@@ -393,6 +393,8 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  w = ((w >> " + p + ") << " + std::to_string(ins.pos[j] + 1) + ") | (w & ((1ull << " + p + ") - 1ull));");
   }
   if (ins.ormask) L("  w |= " + U(ins.ormask) + ";");
+  if (d.p5 != 5u)  // split rows (see tile_block_base): `ins` was opened with 5 standing for p5; the two bits trade places now
+    L("  w = (w & ~(1ull << " + std::to_string(d.p5) + ")) | (((w >> " + std::to_string(d.p5) + ") & 1ull) << 5);");
   L("  return w;");
   L("}");
   L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
@@ -430,7 +432,8 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  blk = ((blk >> 3) & ((1ull << " + J + ") - 1ull)) | ((blk & 7ull) << " + J + ") | (((blk >> 3) >> " + J + ") << (" + J + " + 3));");
   }
   L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
-  for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane);");
+  L("  const uint32_t lane_off = tile_lane_off(lane, " + std::to_string(d.p5) + "u);");
+  for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane_off);");
   L("  const uint32_t tidv = tid;");
   for (int u = 0; u < 8; ++u)
     L("    tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)] = x[" + std::to_string(u) + "];");
@@ -594,7 +597,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  }");
   }
   for (int u = 0; u < 8; ++u)
-    L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+    L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
   L("}");
   return o;
 }
@@ -636,9 +639,9 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
 
 template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
-                               std::vector<uint32_t> high_in) {
+                               std::vector<uint32_t> high_in, uint32_t p5_override = 0) {
   TileSegmentPlan<T> plan;
-  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1));
+  QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1, p5_override));
   const std::vector<uint32_t>& high = plan.high;
   std::vector<TileGate<T>>& gates = plan.gates;
   std::vector<amp_t<T>>& mats = plan.mats;
@@ -655,7 +658,8 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   memset(&d, 0, sizeof d);
   d.ngates = (uint32_t)gates.size();
   for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
-  Ins ins = make_ins(high, 0);  // make_ins sorts its own copy; `high` keeps the tile-bit order
+  d.p5 = plan.p5;
+  Ins ins = tile_ins(high, plan.p5);  // (sorts its own copy; `high` keeps the tile-bit order)
   const uint64_t ntiles = 1ull << (s->n - kTileBits);
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
@@ -758,16 +762,28 @@ int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done) {
   } else {
     return QIP_OK;
   }
+  // Which rows for this ONE op (qip_kernels.h tile_block_base)?  With at most three positions forced above contiguous rows the
+  // two free ones become 11 and 12 — the fastest tile shape measured (5.3 ms per sweep at n = 30) — so contiguous rows stay;
+  // with more, the forced positions scatter the tile over the DRAM row bits and the split rows win (k = 4 on four high
+  // positions: 72.9 -> 75.5 %, profiles/r04_tile_rows.md).
+  uint32_t p5 = tile_p5(s->dtype, s->n);
+  if (p5 != 5u) {
+    std::vector<uint32_t> forced;
+    for (const TileItem& t : parts)
+      for (uint32_t p : t.pos)
+        if (p >= (uint32_t)kTileLow && std::find(forced.begin(), forced.end(), p) == forced.end()) forced.push_back(p);
+    if (forced.size() <= 3) p5 = 5u;
+  }
   std::vector<uint32_t> hp;
   for (const TileItem& t : parts)
     for (uint32_t p : t.pos)
-      if (p >= (uint32_t)kTileLow && std::find(hp.begin(), hp.end(), p) == hp.end()) hp.push_back(p);
+      if (!tile_is_low(p, p5) && std::find(hp.begin(), hp.end(), p) == hp.end()) hp.push_back(p);
   if (hp.size() > (size_t)kTileHigh) return QIP_OK;
   std::vector<const TileItem*> seg;
   for (const TileItem& t : parts) seg.push_back(&t);
   const int64_t jit = s->tile_jit;
   s->tile_jit = 0;  // one op does not repay a run-time compilation: the interpreter kernel
-  const int rc = launch_tile_segment<T>(s, seg, hp);
+  const int rc = launch_tile_segment<T>(s, seg, hp, p5);
   s->tile_jit = jit;
   QCHK(rc);
   *done = true;
@@ -789,7 +805,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
     TileSegmentPlan<T> plan;
     QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
-    Ins ins = make_ins(plan.high, 0);
+    Ins ins = tile_ins(plan.high, plan.p5);
     std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
     const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
     std::vector<char> code;

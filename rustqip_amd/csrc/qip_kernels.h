@@ -997,6 +997,25 @@ constexpr int kTileBits = kTileLow + kTileHigh;    // 2048 amplitudes per tile (
 constexpr int kTileLaneBits = kTileBits - 3;       // k_tile_passes: thread-id bits (a lane holds 2^3 elements)
 constexpr int kTileBlock = 1 << kTileLaneBits;     // ... 256 lanes = 4 waves per tile
 constexpr int kTileWaveBits = kTileLaneBits - kTileLow;  // tile bits 6.. that the wave id fills at load / store time
+// Which amplitude-index positions the tile's six LOW bits (the lane id at load / store time) stand for: 0..4 and `p5`.
+//   p5 = 5   one contiguous 1-KiB row per wave-level access (rounds 1-3);
+//   p5 = 11  (r4, the default for 16-byte amplitudes) two 512-byte halves 32 KiB apart.  Measured on MI355X at n = 30
+//            (tools/tune_tile probe, profiles/r04_tile_rows.md): with contiguous rows a light sweep takes 5.3 ms when the
+//            tile's five high positions are 11..15 but 6.1 - 8.6 ms when they are scattered over the DRAM row bits
+//            (positions >= 17), whatever the block order; with the split rows EVERY choice of high positions runs in
+//            5.3 - 5.9 ms.  Only byte-address bit 15 does this (every other second-half distance: no gain), and four
+//            256-byte pieces are worse than either.  Position 5 is then an ordinary position a segment may claim.
+// The block number fills every position outside the tile, ascending: computed as before in the space where p5 and 5 have
+// traded places (`ins` opens the high positions with 5 standing for p5) and then put right by exchanging those two bits.
+__device__ __forceinline__ uint64_t tile_block_base(uint64_t blk, const Ins& ins, uint32_t p5) {
+  uint64_t w = insert_bits<-1>(blk << kTileLow, ins);
+  if (p5 != 5u) {  // (bit 5 of w is zero here: the tile's low bits are not the block's)
+    const uint64_t b = (w >> p5) & 1ull;
+    w = (w & ~(1ull << p5)) | (b << 5);
+  }
+  return w;
+}
+__device__ __forceinline__ uint32_t tile_lane_off(uint32_t lane, uint32_t p5) { return (lane & 31u) | ((lane >> 5) << p5); }
 // (Measured in round 2: kTileHigh = 6 — 64-KiB tiles, 512 lanes, 2 blocks per CU — cuts the configs[1] circuit from 19
 // to 15 sweeps but each sweep takes 11.8 ms instead of 6.8: 177 vs 129 ms.  Five resident blocks per CU are what
 // overlaps the load / LDS / store phases; profiles/r02_tile_variants.md.)
@@ -1051,6 +1070,7 @@ enum TileOp : uint32_t {
 struct TileDesc {
   uint32_t ngates;
   uint32_t hpos[kTileHigh];  // amplitude-index bit positions of tile bits 6..10 (ascending)
+  uint32_t p5;               // amplitude-index position of tile bit 5 (see tile_block_base)
 };
 
 // The tile is resident in LDS memory and every gate is a read-modify-write of LDS by the whole block; one
@@ -1068,13 +1088,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_gates(amp_t<T>* __restrict__ st
   A* tile = reinterpret_cast<A*>(tile_raw);
   constexpr int PER = (1 << kTileBits) / kBlock;  // 8 amplitudes per lane
   // `ins` opens the kTileHigh high positions; the low kTileLow bits of the shifted work index are zero
-  const uint64_t base = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
+  const uint64_t base = tile_block_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x, ins, d.p5);
   uint64_t idx[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const uint32_t t = u * kBlock + threadIdx.x;
     const uint32_t h = t >> kTileLow;
-    uint64_t off = t & ((1u << kTileLow) - 1u);
+    uint64_t off = tile_lane_off(t & ((1u << kTileLow) - 1u), d.p5);
 #pragma unroll
     for (int j = 0; j < kTileHigh; ++j) off |= (uint64_t)((h >> j) & 1u) << d.hpos[j];
     idx[u] = base | off;
@@ -1171,6 +1191,8 @@ constexpr int kTileMaxPasses = kTileMaxExchGates;  // only a gate with exchange 
 struct TilePassDesc {
   uint32_t npasses;
   uint32_t hpos[kTileHigh];
+  uint32_t p5;  // amplitude-index position of tile bit 5 (see tile_block_base)
+  uint32_t pad_;
   TilePass pass[kTileMaxPasses];
 };
 
@@ -1426,18 +1448,19 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // everything but the lane id is wave-uniform: tile bits 6 .. 6 + kTileWaveBits - 1 = wave id, the top three = u
-  uint64_t wbase = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
+  uint64_t wbase = tile_block_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x, ins, d.p5);
   const uint64_t base = wbase;
 #pragma unroll
   for (int j = 0; j < kTileWaveBits; ++j) wbase |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
   const uint32_t slot_tid = tile_slot<A>(tid);
+  const uint32_t lane_off = tile_lane_off(lane, d.p5);
   {
     A x[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
                           ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-      x[u] = ldg<NT>(st + ub + lane);
+      x[u] = ldg<NT>(st + ub + lane_off);
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = x[u];
@@ -1531,7 +1554,7 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
     for (int u = 0; u < PER; ++u) {
       const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
                           ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-      stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+      stg<NT>(st + ub + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
     }
   }
 }
@@ -1547,6 +1570,7 @@ struct TileMfmaDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index positions of tile bits 6..10 (ascending)
   uint32_t tb[4];            // tile-bit index of the targets, ascending
   uint32_t nb[kTileBits - 4];  // the other tile bits, ascending: nb[0..3] = group, nb[4..6] = item
+  uint32_t p5;                 // amplitude-index position of tile bit 5 (see tile_block_base)
 };
 
 template <typename T, bool NT>
@@ -1559,10 +1583,11 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_gate_k4_tile_mfma(amp_t<T>* _
   A* tile = reinterpret_cast<A*>(tile_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint64_t wbase = insert_bits<-1>((blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) << kTileLow, ins);
+  uint64_t wbase = tile_block_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x, ins, d.p5);
 #pragma unroll
   for (int j = 0; j < kTileWaveBits; ++j) wbase |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
   const uint32_t slot_tid = tile_slot<A>(tid);
+  const uint32_t lane_off = tile_lane_off(lane, d.p5);
   // the gate's fragments while the rows are on their way
   T a[TT][KS];
 #pragma unroll
@@ -1575,7 +1600,7 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_gate_k4_tile_mfma(amp_t<T>* _
     for (int u = 0; u < 8; ++u) {
       const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
                           ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-      x[u] = ldg<NT>(st + ub + lane);
+      x[u] = ldg<NT>(st + ub + lane_off);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = x[u];
@@ -1620,7 +1645,7 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_gate_k4_tile_mfma(amp_t<T>* _
   for (int u = 0; u < 8; ++u) {
     const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
                         ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-    stg<NT>(st + ub + lane, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+    stg<NT>(st + ub + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
   }
 }
 

@@ -1,5 +1,5 @@
 // qip_launch.hip — one launcher per kernel class (qip_kernels.h) and apply_op: the op descriptor -> plan -> launch path.
-#include "qip_internal.h"
+#include "qip_tile.h"
 
 // ---------------------------------------------------------------------------------------
 // launchers
@@ -552,27 +552,29 @@ template <typename T>
 static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool* done) {
   *done = false;
   if (p.opos.size() != 4 || s->n < (uint32_t)kTileBits + 6) return QIP_OK;
+  const uint32_t p5 = tile_p5_of<T>(s->n);  // the rows' sixth bit (qip_tile.h): 11 = split rows
   for (uint32_t c : p.cpos)
-    if (c < (uint32_t)kTileLow) return QIP_OK;
+    if (tile_is_low(c, p5)) return QIP_OK;
   std::vector<uint32_t> tau = p.opos;
   std::sort(tau.begin(), tau.end());
   std::vector<uint32_t> high;  // the tile's five positions above the rows: the targets there, then free ones from 11 upwards
   for (uint32_t t : tau)
-    if (t >= (uint32_t)kTileLow) high.push_back(t);
+    if (!tile_is_low(t, p5)) high.push_back(t);
   auto taken = [&](uint32_t pp) {
-    return std::find(high.begin(), high.end(), pp) != high.end() || std::find(p.cpos.begin(), p.cpos.end(), pp) != p.cpos.end();
+    return tile_is_low(pp, p5) || std::find(high.begin(), high.end(), pp) != high.end() || std::find(p.cpos.begin(), p.cpos.end(), pp) != p.cpos.end();
   };
-  if (std::find(high.begin(), high.end(), 6u) != high.end() && !taken(7u) && high.size() < (size_t)kTileHigh) high.push_back(7u);
+  if (p5 == 5u && std::find(high.begin(), high.end(), 6u) != high.end() && !taken(7u) && high.size() < (size_t)kTileHigh) high.push_back(7u);
   for (uint32_t pp = 11; high.size() < (size_t)kTileHigh && pp < s->n; ++pp)
     if (!taken(pp)) high.push_back(pp);
-  for (uint32_t pp = kTileLow; high.size() < (size_t)kTileHigh && pp < s->n; ++pp)
+  for (uint32_t pp = 5; high.size() < (size_t)kTileHigh && pp < s->n; ++pp)
     if (!taken(pp)) high.push_back(pp);
   if (high.size() != (size_t)kTileHigh) return QIP_OK;
   std::sort(high.begin(), high.end());
   TileMfmaDesc d;
   memset(&d, 0, sizeof d);
   for (int jx = 0; jx < kTileHigh; ++jx) d.hpos[jx] = high[jx];
-  auto tile_bit = [&](uint32_t pos) { return pos < (uint32_t)kTileLow ? pos : (uint32_t)kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin()); };
+  d.p5 = p5;
+  auto tile_bit = [&](uint32_t pos) { return tile_is_low(pos, p5) ? tile_low_bit(pos) : (uint32_t)kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin()); };
   uint32_t is_target = 0;
   for (int b = 0; b < 4; ++b) {
     d.tb[b] = tile_bit(tau[b]);
@@ -585,9 +587,14 @@ static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bo
   build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
   std::vector<T> af_t(afrag.begin(), afrag.end());
   QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
-  std::vector<uint32_t> opened = high;
-  for (uint32_t c : p.cpos) opened.push_back(c);
-  Ins ins = make_ins(opened, mask_of(p.cpos));
+  // (tile_block_base: positions in the space where p5 and 5 have traded places; the kernel exchanges the two bits back)
+  std::vector<uint32_t> opened = high, ctl = p.cpos;
+  for (uint32_t& c : ctl)
+    if (c == 5u) c = p5;
+  for (uint32_t c : ctl) opened.push_back(c);
+  for (uint32_t& o : opened)
+    if (o == 5u) o = p5;
+  Ins ins = make_ins(opened, mask_of(ctl));
   const uint64_t ntiles = 1ull << (s->n - (uint32_t)kTileBits - (uint32_t)p.cpos.size());
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const T* af = (const T*)s->arena;

@@ -33,6 +33,7 @@ template <typename T> struct TileSegmentPlan {
   std::vector<TileGate<T>> gates;
   std::vector<amp_t<T>> mats;  // 4x4 matrices of the dense 2-qubit gates (kind 3), 16 entries each
   TilePassDesc pd;             // passes (only when `passes`)
+  uint32_t p5 = 5;             // amplitude-index position of tile bit 5
   std::vector<uint32_t> order; // gates[i] is the segment's order[i]-th op (build_tile_segment may reorder inside the segment)
 };
 
@@ -60,9 +61,24 @@ struct TileSchedule {
   bool keep_layout = false;
 };
 
+// Which amplitude-index positions are the tile's six LOW bits (lane id at load / store time): 0..4 and p5 (qip_kernels.h,
+// tile_block_base).  p5 = 11 ("split rows": two 512-byte halves 32 KiB apart per wave-level access) for Complex<f64> states
+// with n >= 12, else 5 (one contiguous row); global option "tile_row_split" (default 11; 5 = contiguous rows everywhere).
+extern int64_t g_tile_row_split;
+static inline uint32_t tile_p5(int dtype, uint32_t n) {
+  const uint32_t p = (uint32_t)g_tile_row_split;
+  return (dtype == QIP_C64 && p > 5u && p < n && n >= 12u) ? p : 5u;
+}
+template <typename T> static inline uint32_t tile_p5_of(uint32_t n) { return tile_p5(std::is_same<T, double>::value ? QIP_C64 : QIP_C32, n); }
+static inline bool tile_is_low(uint32_t pos, uint32_t p5) { return pos < 5u || pos == p5; }
+static inline uint32_t tile_low_bit(uint32_t pos) { return pos < 5u ? pos : 5u; }  // (only for positions that are low)
+static inline uint64_t tile_low_mask(uint32_t p5) { return 31ull | (1ull << p5); }
+// the Ins a tile kernel takes: the high positions opened in the space where p5 and 5 have traded places
+Ins tile_ins(const std::vector<uint32_t>& high, uint32_t p5);
+
 int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it);
 template <typename T>
 int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, TileSegmentPlan<T>* out,
-                       int order_rule = 0);  // order_rule: 0 = gates in the given order, 1 / 2 = fewest passes under tile = 1 / 2's commutation rule
+                       int order_rule = 0, uint32_t p5_override = 0);  // p5_override: 5 / 11 = this tile's sixth low position (one-op sweeps choose)  // order_rule: 0 = gates in the given order, 1 / 2 = fewest passes under tile = 1 / 2's commutation rule
 int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
                        bool allow_permute = true);

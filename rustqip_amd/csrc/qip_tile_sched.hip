@@ -157,9 +157,16 @@ extern "C" int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits
 } QIP_CATCH_ALL
 
 
+Ins tile_ins(const std::vector<uint32_t>& high, uint32_t p5) {
+  std::vector<uint32_t> v = high;
+  for (uint32_t& h : v)
+    if (h == 5u) h = p5;  // (p5 itself is a low position and never in `high`)
+  return make_ins(v, 0);
+}
+
 template <typename T>
 int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg_in,
-                              std::vector<uint32_t> high, TileSegmentPlan<T>* out, int order_rule) {
+                              std::vector<uint32_t> high, TileSegmentPlan<T>* out, int order_rule, uint32_t p5_override) {
   // The order of the gates INSIDE the segment (order_rule 1 / 2 = the "tile" option; 0 keeps the schedule's order).  A pass is
   // one round trip of the tile through LDS (~0.5 ms per sweep at n = 30: 64 KiB per tile at 128 B per clock), and a pass holds
   // the gates whose exchange bits fit its three register bits: taken in circuit order, a random circuit opens a new pass every
@@ -168,17 +175,19 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
   // sequence of rounded operations — the result stays IEEE-equal to circuit order) fills a pass with every ready gate that
   // fits before it opens the next one.
   std::vector<const TileItem*> seg = seg_in;
-  // pad the free bits with unused positions >= kTileLow so the tile always has kTileHigh of them
+  const uint32_t p5 = p5_override ? p5_override : tile_p5_of<T>(n);
+  out->p5 = p5;
+  // pad the free bits with unused positions outside the low set so the tile always has kTileHigh of them
   const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, n > (uint32_t)kTileBits ? n - 5 : (uint32_t)kTileLow);
-  // position 6 in the tile without position 7 makes the waves' rows alternate 1-KiB pieces (a one-op sweep on position 6:
-  // 5.7 TB/s against 6.4 with 7 beside it): 7 is the first pad then
-  if (g_tile_pad_from > kTileLow && high.size() < (size_t)kTileHigh && n > 7 && std::find(high.begin(), high.end(), 6u) != high.end() &&
+  // (contiguous rows only) position 6 in the tile without position 7 makes the waves' rows alternate 1-KiB pieces (a one-op
+  // sweep on position 6: 5.7 TB/s against 6.4 with 7 beside it): 7 is the first pad then
+  if (p5 == 5u && g_tile_pad_from > kTileLow && high.size() < (size_t)kTileHigh && n > 7 && std::find(high.begin(), high.end(), 6u) != high.end() &&
       std::find(high.begin(), high.end(), 7u) == high.end())
     high.push_back(7u);
   for (uint32_t p = std::max<uint32_t>(pad_from, kTileLow); high.size() < (size_t)kTileHigh && p < n; ++p)
-    if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
-  for (uint32_t p = kTileLow; high.size() < (size_t)kTileHigh && p < n; ++p)
-    if (std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+    if (!tile_is_low(p, p5) && std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+  for (uint32_t p = 5; high.size() < (size_t)kTileHigh && p < n; ++p)
+    if (!tile_is_low(p, p5) && std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
   // the first kTileWaveBits free positions are wave bits at load / store time, the last three are the lane's own
   // elements: give the free positions that are exchange targets least often to the wave bits
   std::vector<uint32_t> uses(64, 0);
@@ -194,7 +203,7 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
   else if (g_tile_wave_rule == 2) std::sort(high.begin(), high.end(), std::greater<uint32_t>());  // highest positions = wave bits
   else std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
   auto tile_bit = [&](uint32_t pos) -> uint32_t {  // kTileOutside when the position is not part of the tile
-    if (pos < (uint32_t)kTileLow) return pos;
+    if (tile_is_low(pos, p5)) return tile_low_bit(pos);
     const auto f = std::find(high.begin(), high.end(), pos);
     return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
   };
@@ -384,6 +393,7 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
     TilePassDesc& pd = out->pd;
     memset(&pd, 0, sizeof pd);
     for (int j = 0; j < kTileHigh; ++j) pd.hpos[j] = high[j];
+    pd.p5 = p5;
     std::vector<uint32_t> bits;
     uint32_t first = 0;
     constexpr uint32_t S = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // swizzle fold width, see TilePass
@@ -518,6 +528,7 @@ struct SegScan {
   uint64_t count, window;
   bool reorder, relabel;
   size_t max_ops, max_exch;
+  uint32_t p5;  // position of tile bit 5: which positions are free of charge (tile_is_low)
 };
 
 // weight of the gates that join a segment grown from `head` when exactly the positions `H` may be used above the rows
@@ -543,7 +554,7 @@ static double seg_dry_run(const SegScan& c, uint64_t head, std::vector<uint32_t>
       if (it.kind == 4) { exch[ne++] = it.t0; exch[ne++] = it.t1; exch[ne++] = it.t2; }
       for (int e = 0; e < ne && fits; ++e) {
         const uint32_t pp = phys[exch[e]];
-        fits = pp < (uint32_t)kTileLow || std::find(H.begin(), H.end(), pp) != H.end();
+        fits = tile_is_low(pp, c.p5) || std::find(H.begin(), H.end(), pp) != H.end();
       }
     }
     if (fits) {
@@ -572,15 +583,15 @@ static std::vector<uint32_t> seg_choose_high(const SegScan& c, uint64_t head, co
     if (it.kind == 4) { exch[ne++] = it.t0; exch[ne++] = it.t1; exch[ne++] = it.t2; }
     for (int e = 0; e < ne; ++e) {
       const uint32_t pp = phys[exch[e]];
-      if (pp >= (uint32_t)kTileLow && std::find(H.begin(), H.end(), pp) == H.end()) H.push_back(pp);
+      if (!tile_is_low(pp, c.p5) && std::find(H.begin(), H.end(), pp) == H.end()) H.push_back(pp);
     }
   }
   double base = seg_dry_run(c, head, phys, H);
   while (H.size() < (size_t)kTileHigh) {
     int best = -1;
     double best_w = base;
-    for (uint32_t pp = kTileLow; pp < n; ++pp) {
-      if (std::find(H.begin(), H.end(), pp) != H.end()) continue;
+    for (uint32_t pp = 5; pp < n; ++pp) {
+      if (tile_is_low(pp, c.p5) || std::find(H.begin(), H.end(), pp) != H.end()) continue;
       H.push_back(pp);
       const double w = seg_dry_run(c, head, phys, H);
       H.pop_back();
@@ -616,6 +627,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
   std::vector<char> done(count, 0);
   uint64_t head = 0;
   const uint64_t window = 256;
+  const uint32_t p5 = tile_p5(dtype, n);
   while (head < count) {
     if (done[head]) {
       ++head;
@@ -646,7 +658,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
         run.perm = next;
         run.ops.push_back(j);
       }
-      if (run.ops.size() >= 2 && __builtin_popcountll(moved >> kTileLow) > kTileHigh) {
+      if (run.ops.size() >= 2 && __builtin_popcountll(moved & ~tile_low_mask(p5)) > kTileHigh) {
         for (uint64_t i : run.ops) done[i] = 1;
         steps->push_back(run);
         continue;
@@ -667,7 +679,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
     {
       std::vector<uint32_t> ident(n);
       for (uint32_t b = 0; b < n; ++b) ident[b] = b;
-      const SegScan sc{items, done, count, window, reorder, false, (size_t)kTileMaxGates, (size_t)kTileMaxExchGates};
+      const SegScan sc{items, done, count, window, reorder, false, (size_t)kTileMaxGates, (size_t)kTileMaxExchGates, p5};
       st.high = seg_choose_high(sc, head, ident, n);
     }
     uint64_t blocked_nd = 0, blocked_d = 0;  // bits the skipped gates exchange across / only test
@@ -689,7 +701,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
         if (it.kind == 2 || it.kind == 3) exch = {it.t0, it.t1};
         if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
         for (uint32_t p : exch)
-          if (p >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
+          if (!tile_is_low(p, p5) && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
             need.push_back(p);
         fits = st.high.size() + need.size() <= (size_t)kTileHigh;
@@ -739,6 +751,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
     }
     if (L[i].kind >= 3 && !allow_2q) L[i].tileable = false;
   }
+  const uint32_t p5 = tile_p5(dtype, n);
   std::vector<uint32_t> phys(n);  // phys[p] = physical position of logical bit position p
   for (uint32_t p = 0; p < n; ++p) phys[p] = p;
   if (out->init_phys.size() == n) phys = out->init_phys;
@@ -799,7 +812,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
     // the physical positions
     TileStep st;
     {
-      const SegScan sc{L, done, count, window, reorder, true, max_circuit_ops, (size_t)kTileMaxExchGates - (size_t)kTileLow};
+      const SegScan sc{L, done, count, window, reorder, true, max_circuit_ops, (size_t)kTileMaxExchGates - (size_t)kTileLow, p5};
       st.high = seg_choose_high(sc, head, phys, n);
     }
     uint64_t blocked_nd = 0, blocked_d = 0;
@@ -824,7 +837,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
         if (it.kind == 4) exch = {it.t0, it.t1, it.t2};
         for (uint32_t p : exch) {
           const uint32_t pp = phys[p];
-          if (pp >= (uint32_t)kTileLow && std::find(st.high.begin(), st.high.end(), pp) == st.high.end() &&
+          if (!tile_is_low(pp, p5) && std::find(st.high.begin(), st.high.end(), pp) == st.high.end() &&
               std::find(need.begin(), need.end(), pp) == need.end())
             need.push_back(pp);
         }
@@ -866,7 +879,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
           }
         }
       }
-      auto in_tile = [&](uint32_t pp) { return pp < (uint32_t)kTileLow || std::find(st.high.begin(), st.high.end(), pp) != st.high.end(); };
+      auto in_tile = [&](uint32_t pp) { return tile_is_low(pp, p5) || std::find(st.high.begin(), st.high.end(), pp) != st.high.end(); };
       std::vector<uint32_t> by_use;  // logical positions with a future use, soonest first
       for (uint32_t p = 0; p < n; ++p)
         if (nxt[p] != ~0ull) by_use.push_back(p);
@@ -883,8 +896,8 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
       for (size_t r = 0; r < tile_log.size(); ++r) {
         const uint32_t p = tile_log[r];
         const bool wanted = r < (size_t)kTileLow && nxt[p] != ~0ull;
-        if (wanted && phys[p] >= (uint32_t)kTileLow) bring.push_back(p);
-        if (!wanted && phys[p] < (uint32_t)kTileLow) evict.push_back(p);
+        if (wanted && !tile_is_low(phys[p], p5)) bring.push_back(p);
+        if (!wanted && tile_is_low(phys[p], p5)) evict.push_back(p);
       }
       std::reverse(evict.begin(), evict.end());  // needed last (or never) goes first
       for (size_t r = 0; r < bring.size() && r < evict.size() && st.ops.size() < (size_t)kTileMaxGates; ++r) {
@@ -1034,7 +1047,7 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       for (uint64_t i : st.ops) seg.push_back(&items[i]);
       TileSegmentPlan<T> plan;
       QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
-      js += ",\"high\":[";
+      js += ",\"low\":[0,1,2,3,4," + std::to_string(plan.p5) + "],\"high\":[";
       for (size_t k = 0; k < plan.high.size(); ++k) js += (k ? "," : "") + std::to_string(plan.high[k]);
       js += "],\"order\":[";
       for (size_t k = 0; k < plan.order.size(); ++k) js += (k ? "," : "") + std::to_string(plan.order[k]);
@@ -1092,5 +1105,5 @@ extern "C" const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_
 // and the total source / code size through the out parameters; `first_source` (may be NULL) receives a pointer to the
 // first segment's source text (owned by the library, valid until the calling thread's next call).
 
-template int build_tile_segment<double>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<double>*, int);
-template int build_tile_segment<float>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<float>*, int);
+template int build_tile_segment<double>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<double>*, int, uint32_t);
+template int build_tile_segment<float>(uint32_t, bool, const std::vector<const TileItem*>&, std::vector<uint32_t>, TileSegmentPlan<float>*, int, uint32_t);

@@ -259,7 +259,7 @@ def test_tile_schedule_invariants():
             if len(st) > 1:
                 free = set()
                 for i in st:
-                    free |= {p for p in exchange_bits(ops[i]) if p >= 6}
+                    free |= {p for p in exchange_bits(ops[i]) if p not in (0, 1, 2, 3, 4, 11 if n >= 12 else 5)}  # (the rows: qip_tile.h tile_p5)
                 assert len(free) <= 6 and len(st) <= 256
                 assert all(len(flatten(ops[i])[2]) <= 3 for i in st)  # 1-qubit gates, swaps, dense 2- and 3-qubit gates
         assert [160] in steps  # the dense 4-qubit gate is launched on its own

@@ -99,6 +99,8 @@ def main():
                   ("Rz, target bit n/2 (8-B unpacked path)", q.make_matrix_op([mid], circuits.rz(0.3)), {"packed_f32": 0})]
     if os.environ.get("QIP_SINGLE_VIA_TILE"):  # tuning aid: 0 = dedicated kernels only, 1 (default) / 2 = one-item tile sweeps
         q.set_global_option("single_via_tile", int(os.environ["QIP_SINGLE_VIA_TILE"]))
+    if os.environ.get("QIP_TILE_ROW_SPLIT"):  # 11 (default): split rows in the tile sweeps, 5: contiguous rows
+        q.set_global_option("tile_row_split", int(os.environ["QIP_TILE_ROW_SPLIT"]))
     if os.environ.get("QIP_K4_DIRECT"):
         q.set_global_option("k4_direct", int(os.environ["QIP_K4_DIRECT"]))
     if os.environ.get("QIP_SINGLE_VIA_TILE_F32"):

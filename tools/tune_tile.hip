@@ -227,6 +227,34 @@ __global__ __launch_bounds__(256, BPC) void k_dma(A* __restrict__ st, uint64_t n
   }
 }
 
+// r4 probe: a tile whose ELEVEN index positions are all free parameters — T[0..5] are driven by the lane id (the product: 0..5 = one
+// contiguous 1-KiB row per wave-level access), T[6..7] by the wave id, T[8..10] by a lane's eight back-to-back accesses; the block
+// index drives every other position, ascending.  No LDS (the V2 skeleton): read, scale, write back.
+struct Tp { uint32_t t[11]; uint32_t sorted[11]; };
+__global__ __launch_bounds__(256, 8) void k_probe(A* __restrict__ st, Tp tp, A f) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t w = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    const uint32_t p = tp.sorted[j];
+    w = ((w >> p) << (p + 1)) | (w & ((1ull << p) - 1ull));
+  }
+  uint64_t off = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) off |= (uint64_t)((lane >> k) & 1u) << tp.t[k];
+  off |= ((uint64_t)(wave & 1u) << tp.t[6]) | ((uint64_t)(wave >> 1) << tp.t[7]);
+  A x[8];
+  uint64_t a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    a[u] = w | off | ((uint64_t)(u & 1) << tp.t[8]) | ((uint64_t)((u >> 1) & 1) << tp.t[9]) | ((uint64_t)((u >> 2) & 1) << tp.t[10]);
+    x[u] = ldg<true>(st + a[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) stg<true>(st + a[u], cmul(f, x[u]));
+}
+
 __global__ void k_init(A* st, uint64_t n) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     A v;
@@ -386,6 +414,125 @@ int main(int argc, char** argv) {
         {{12, 15, 18, 21, 24}, "w12,15 u18,21,24"}, {{6, 15, 18, 21, 24}, "w6,15 u18,21,24"}, {{6, 7, 18, 21, 24}, "w6,7 u18,21,24"},
         {{18, 21, 24, 6, 7}, "w18,21 u24,6,7"}};
     for (auto& s : sets) light(make_hp(s.h), s.name);
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "scan")) {
+    // r4: which index positions are cheap in which ROLE of the tile.  h[0], h[1] = the positions the wave id fills (four waves of a
+    // block), h[2..4] = the positions a lane's eight back-to-back loads / stores differ in.  One pass, two factors (a light sweep), the
+    // product's block -> tile order (ascending).  Output: one line per set, `scan <tag> <h0> <h1> <h2> <h3> <h4> <ms>`.
+    const uint32_t N = (uint32_t)n;
+    const uint64_t ntiles = g_n >> 11;
+    A f;
+    f.x = 0.6;
+    f.y = 0.8;
+    auto probe = [&](const char* tag, std::vector<uint32_t> h) {
+      std::vector<uint32_t> chk = h;
+      std::sort(chk.begin(), chk.end());
+      for (int j = 0; j < 5; ++j)
+        if (chk[j] < 6 || chk[j] >= N || (j && chk[j] == chk[j - 1])) return;
+      const Hp hp = make_hp(h);
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      hipLaunchKernelGGL((k_v0<1, 2, 0>), dim3((unsigned)ntiles), dim3(256), 32768, 0, g_st, hp, f);
+      float best = 1e9f;
+      for (int r = 0; r < g_reps; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_v0<1, 2, 0>), dim3((unsigned)ntiles), dim3(256), 32768, 0, g_st, hp, f);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+      }
+      CK(hipGetLastError());
+      printf("scan %s %u %u %u %u %u %.3f\n", tag, h[0], h[1], h[2], h[3], h[4], best);
+      fflush(stdout);
+      CK(hipEventDestroy(e0));
+      CK(hipEventDestroy(e1));
+    };
+    k_init<<<4096, 256>>>(g_st, g_n);
+    CK(hipDeviceSynchronize());
+    for (uint32_t a = 8; a + 2 < N; ++a) probe("u3", {6, 7, a, a + 1, a + 2});
+    for (uint32_t a = 6; a + 1 < N; ++a) probe("w2", {a, a + 1, 11, 12, 13});
+    for (uint32_t a = 6; a + 4 < N; ++a) probe("run5", {a, a + 1, a + 2, a + 3, a + 4});
+    for (int slot = 0; slot < 5; ++slot)
+      for (uint32_t p = 6; p < N; ++p) {
+        std::vector<uint32_t> h = {11, 12, 13, 14, 15};
+        h[slot] = p;
+        char tag[16];
+        snprintf(tag, sizeof tag, "sub%d", slot);
+        probe(tag, h);
+      }
+    {  // the top five in every role assignment (which two are the wave bits)
+      const uint32_t t[5] = {N - 5, N - 4, N - 3, N - 2, N - 1};
+      for (int a = 0; a < 5; ++a)
+        for (int b = a + 1; b < 5; ++b) {
+          std::vector<uint32_t> h = {t[a], t[b]};
+          for (int c = 0; c < 5; ++c)
+            if (c != a && c != b) h.push_back(t[c]);
+          probe("top5", h);
+        }
+    }
+    {  // a dense k = 4 gate on positions {0, 14, 24, 29}: three forced positions + two free ones, in both roles
+      for (uint32_t x = 6; x + 1 < 24; ++x) {
+        if (x == 14 || x + 1 == 14) continue;
+        probe("k4wfree", {x, x + 1, 14, 24, 29});
+        probe("k4ufree", {14, 24, x, x + 1, 29});
+        probe("k4ufre2", {24, 29, x, x + 1, 14});
+      }
+    }
+    {  // strided sets
+      for (uint32_t st = 2; st <= 5; ++st)
+        for (uint32_t a = 6; a + 4 * st < N; a += 2) probe("strd", {a, a + st, a + 2 * st, a + 3 * st, a + 4 * st});
+    }
+    // the same bytes through a plain streaming kernel for reference: every position "free"
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "probe")) {
+    // `probe <l0> ... <l5> <w0> <w1> <u0> <u1> <u2>` lines on stdin -> one timing each
+    const uint64_t ntiles = g_n >> 11;
+    A f;
+    f.x = 0.6;
+    f.y = 0.8;
+    k_init<<<4096, 256>>>(g_st, g_n);
+    CK(hipDeviceSynchronize());
+    char line[256];
+    while (fgets(line, sizeof line, stdin)) {
+      Tp tp;
+      char tag[64];
+      if (sscanf(line, "%63s %u %u %u %u %u %u %u %u %u %u %u", tag, &tp.t[0], &tp.t[1], &tp.t[2], &tp.t[3], &tp.t[4], &tp.t[5], &tp.t[6], &tp.t[7],
+                 &tp.t[8], &tp.t[9], &tp.t[10]) != 12)
+        continue;
+      bool ok = true;
+      for (int j = 0; j < 11; ++j) tp.sorted[j] = tp.t[j];
+      std::sort(tp.sorted, tp.sorted + 11);
+      for (int j = 0; j < 11; ++j) ok = ok && tp.sorted[j] < (uint32_t)n && (j == 0 || tp.sorted[j] != tp.sorted[j - 1]);
+      if (!ok) { printf("probe %s bad\n", tag); continue; }
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(k_probe, dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, tp, f);
+      float best = 1e9f;
+      for (int r = 0; r < g_reps; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_probe, dim3((unsigned)ntiles), dim3(256), 0, 0, g_st, tp, f);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+      }
+      CK(hipGetLastError());
+      printf("probe %s", tag);
+      for (int j = 0; j < 11; ++j) printf(" %u", tp.t[j]);
+      printf(" %.3f\n", best);
+      fflush(stdout);
+      CK(hipEventDestroy(e0));
+      CK(hipEventDestroy(e1));
+    }
     CK(hipFree(g_st));
     return 0;
   }
