@@ -639,7 +639,11 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
 
 template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
-                               std::vector<uint32_t> high_in, uint32_t p5_override = 0) {
+                               std::vector<uint32_t> high_in, uint32_t p5_override = 0,
+                               const std::vector<uint32_t>* grid_ctl = nullptr, double alg_bytes = 0) {
+  // `grid_ctl` (one-op sweeps): control positions OUTSIDE the tile that are taken off the grid — only the blocks whose base
+  // reads 1 there are launched, so a controlled gate sweeps half / a quarter of the vector like the dedicated kernels do
+  // (the kernel's own test of `omask` against the block's base then always passes).  `alg_bytes`: what the profile credits.
   TileSegmentPlan<T> plan;
   QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1, p5_override));
   const std::vector<uint32_t>& high = plan.high;
@@ -660,7 +664,18 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   for (int j = 0; j < kTileHigh; ++j) d.hpos[j] = high[j];
   d.p5 = plan.p5;
   Ins ins = tile_ins(high, plan.p5);  // (sorts its own copy; `high` keeps the tile-bit order)
-  const uint64_t ntiles = 1ull << (s->n - kTileBits);
+  uint64_t ntiles = 1ull << (s->n - kTileBits);
+  if (grid_ctl && !grid_ctl->empty()) {
+    std::vector<uint32_t> opened = high, ctl = *grid_ctl;
+    for (uint32_t c : ctl) opened.push_back(c);
+    for (uint32_t& o : opened)
+      if (o == 5u) o = plan.p5;  // (tile_block_base: the space where p5 and 5 have traded places)
+    uint64_t ones = 0;
+    for (uint32_t c : ctl) ones |= 1ull << (c == 5u ? plan.p5 : c);
+    ins = make_ins(opened, ones);
+    ntiles >>= ctl.size();
+  }
+  const double sweep_bytes = alg_bytes > 0 ? alg_bytes : 2.0 * (double)s->amp_bytes * (double)s->namps;
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
   const amp_t<T>* dmats = nullptr;
@@ -670,7 +685,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     QCHK(upload_gates());
     dg = (const TileGate<T>*)s->arena;
     dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
-    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, sweep_bytes, &rec));
     return QIP_OK;
   };
   if (s->tile_passes && s->tile_jit) {
@@ -702,7 +717,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss BEFORE the timed region starts
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
-    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+    if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, sweep_bytes, &rec));
     void* st_ptr = s->cur;
     uint64_t ntiles_arg = ntiles;
     void* params_ptr = s->arena;
@@ -738,7 +753,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
 }
 
 template <typename T>
-int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done) {
+int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg_bytes) {
   *done = false;
   if (s->n < (uint32_t)kTileBits || !s->tile_passes) return QIP_OK;
   TileItem it;
@@ -766,31 +781,53 @@ int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done) {
   // two free ones become 11 and 12 — the fastest tile shape measured (5.3 ms per sweep at n = 30) — so contiguous rows stay;
   // with more, the forced positions scatter the tile over the DRAM row bits and the split rows win (k = 4 on four high
   // positions: 72.9 -> 75.5 %, profiles/r04_tile_rows.md).
+  // Only the positions the op EXCHANGES amplitudes across must be tile bits; its controls may sit anywhere: inside the rows they
+  // are lane predicates, above them they come off the grid (r4: controlled dense k = 2, 3 take this route too).
+  auto exchanged = [](const TileItem& t) {
+    std::vector<uint32_t> e;
+    for (uint32_t p : t.pos)
+      if ((t.nd_mask >> p) & 1ull) e.push_back(p);
+    return e;
+  };
   uint32_t p5 = tile_p5(s->dtype, s->n);
   if (p5 != 5u) {
     std::vector<uint32_t> forced;
     for (const TileItem& t : parts)
-      for (uint32_t p : t.pos)
+      for (uint32_t p : exchanged(t))
         if (p >= (uint32_t)kTileLow && std::find(forced.begin(), forced.end(), p) == forced.end()) forced.push_back(p);
     if (forced.size() <= 3) p5 = 5u;
   }
   std::vector<uint32_t> hp;
   for (const TileItem& t : parts)
-    for (uint32_t p : t.pos)
+    for (uint32_t p : exchanged(t))
       if (!tile_is_low(p, p5) && std::find(hp.begin(), hp.end(), p) == hp.end()) hp.push_back(p);
   if (hp.size() > (size_t)kTileHigh) return QIP_OK;
+  std::vector<uint32_t> grid_ctl;  // (a single item: `parts` holds several only for an uncontrolled Swap)
+  if (parts.size() == 1)
+    for (uint32_t c : parts[0].cpos)
+      if (!tile_is_low(c, p5)) grid_ctl.push_back(c);
+  if (s->n < (uint32_t)kTileBits + (uint32_t)grid_ctl.size()) return QIP_OK;
   std::vector<const TileItem*> seg;
   for (const TileItem& t : parts) seg.push_back(&t);
   const int64_t jit = s->tile_jit;
   s->tile_jit = 0;  // one op does not repay a run-time compilation: the interpreter kernel
-  const int rc = launch_tile_segment<T>(s, seg, hp, p5);
+  // the free positions that pad the tile must not be control positions that left the grid
+  if (!grid_ctl.empty()) {
+    const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, s->n > (uint32_t)kTileBits ? s->n - 5 : (uint32_t)kTileLow);
+    for (int round = 0; round < 2; ++round)
+      for (uint32_t p = round == 0 ? std::max<uint32_t>(pad_from, kTileLow) : 5u; hp.size() < (size_t)kTileHigh && p < s->n; ++p)
+        if (!tile_is_low(p, p5) && std::find(hp.begin(), hp.end(), p) == hp.end() && std::find(grid_ctl.begin(), grid_ctl.end(), p) == grid_ctl.end())
+          hp.push_back(p);
+    if (hp.size() != (size_t)kTileHigh) return QIP_OK;
+  }
+  const int rc = launch_tile_segment<T>(s, seg, hp, p5, &grid_ctl, alg_bytes);
   s->tile_jit = jit;
   QCHK(rc);
   *done = true;
   return QIP_OK;
 }
-template int tile_apply_single<double>(qip_hip_state*, const qip_op*, bool*);
-template int tile_apply_single<float>(qip_hip_state*, const qip_op*, bool*);
+template int tile_apply_single<double>(qip_hip_state*, const qip_op*, bool*, double);
+template int tile_apply_single<float>(qip_hip_state*, const qip_op*, bool*, double);
 
 template <typename T>
 static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* nseg, uint64_t* src_bytes,
@@ -982,7 +1019,7 @@ static int program_capture(qip_hip_program* p) {
     QCHK(make_plan(s->dtype, s->n, f, false, &pl));
     const bool f64 = s->dtype == QIP_C64;
     const uint32_t k = f.n_op;
-    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));  // (k = 9, 10 upload 8 - 32 MiB of fragments and synchronise: eager)
     (void)f64;
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }

@@ -270,7 +270,7 @@ int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* 
     return QIP_OK;
   }
   std::vector<double> d;
-  if (k <= kMaxBigK) {
+  if (k <= kMaxHugeK) {
     if (dtype == QIP_C64)
       read_dense<double>(f.inner->dense, side * side, &d);
     else
@@ -286,8 +286,8 @@ int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* 
     }
     return QIP_OK;
   }
-  if (k <= kMaxBigK) {
-    // the launcher picks the matrix-core forms (k in 3..5 / 6..8) when >= 16 groups exist
+  if (k <= kMaxHugeK) {
+    // the launcher picks the matrix-core forms (k in 3..5 / 6..8 / 9..10) when >= 16 groups exist
     p->cls = KC_GATE_KQ;
     p->table = d;
     return QIP_OK;

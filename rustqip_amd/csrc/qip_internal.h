@@ -114,6 +114,7 @@ static inline bool is_one2(double re, double im) { return re == 1.0 && im == 0.0
 static constexpr uint32_t kMaxRegK = 4;     // dense gates held in registers (VALU form)
 static constexpr uint32_t kMaxMfmaK = 5;    // dense gates on the f64 matrix cores: k = 3..5 (A operand in registers)
 static constexpr uint32_t kMaxBigK = 8;     // ... k = 6..8 with the A operand streamed through LDS (k_gate_big_mfma)
+static constexpr uint32_t kMaxHugeK = 10;   // ... k = 9, 10 with X in LDS and the A operand streamed from L2 (k_gate_huge_mfma)
 static constexpr uint32_t kMaxSparseK = 5;  // SparseMatrix ops applied in place (one 2^k group per lane, staged in LDS)
 static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
 int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p);
@@ -187,7 +188,7 @@ void programs_orphan(qip_hip_state* s);  // qip_circuit.hip
 int jit_set_cache_cap(int64_t cap);      // qip_circuit.hip (global option "jit_cache_cap")
 uint64_t jit_cache_generation();
 // qip_circuit.hip: `op` as a one-item tile sweep; *done = false when it is not a tile item (nothing launched)
-template <typename T> int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done);
+template <typename T> int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg_bytes = 0);
 int prof_begin(qip_hip_state* s, int cls, double bytes, ProfRec* r);
 int prof_end(qip_hip_state* s, ProfRec* r);
 int state_settle(qip_hip_state* s);  // qip_launch.hip: a relabelled state back to the caller's order (one permutation sweep)

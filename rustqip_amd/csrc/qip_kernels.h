@@ -870,6 +870,113 @@ __global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<T>* __restrict__
   }
 }
 
+// ---- dense k-qubit gate on the matrix cores, k = 9, 10: X in LDS, the gate matrix streamed from L2 (r4) ------------------
+// Nothing in the reference bounds k (qip-iterators/src/iterators/ops.rs:13); beyond k = 8 the 2^k amplitudes of 16 groups no
+// longer fit a wave's registers (k_gate_big_mfma keeps X there).  Here a block of eight waves owns ONE item of 16 groups: its
+// 16 x 2^k amplitudes (up to 128 KiB) live in LDS for the whole item (one phase of it, see below), every wave reads its B operands from there (one ds_read_b128
+// feeds two K-steps, conflict-free: the 64 lanes of a K-step pair read 64 consecutive amplitudes), and the waves split the
+// OUTPUT rows: wave v computes the 16-row blocks rb = v, v + 8, ... over ALL K-steps, so every A fragment is needed by
+// exactly one wave and goes from the L2-resident fragment array straight into registers (16-byte loads holding two
+// consecutive K-steps, eight pairs prefetched ahead of the matrix instructions), never through LDS.  The results stay in
+// registers (2 amplitudes per lane per row block) until the item's last row block is done — X in LDS is never overwritten —
+// and are then stored over the inputs.  Same real-form product, lane mapping and host-built fragments (re-ordered in pairs)
+// as k_gate_kq_mfma.  Where 16 groups x 2^k amplitudes exceed the LDS (Complex<f64>, k = 10: 256 KiB) the K dimension is
+// walked in two phases, each with half of X in LDS, the running sums of a wave's row blocks carried in registers.
+// Roofline: 8 * 2^k flop per amplitude = 128 / 256 flop/B: bound by the f64 matrix pipe (78.6 TFLOP/s), with the A stream
+// (2^(k+1) bytes of L2 traffic per amplitude: every block walks the whole 8- / 32-MiB fragment array per item) next in line.
+struct HugeDesc {
+  uint32_t tau[12];  // target bit positions, ascending
+};
+template <typename T, int K, int NPH, bool NT>
+__global__ __launch_bounds__(512) void k_gate_huge_mfma(amp_t<T>* __restrict__ st, uint64_t nitems, Ins ins, HugeDesc d,
+                                                       const T* __restrict__ afrag2) {
+  using A = amp_t<T>;
+  using V4 = typename Acc4<T>::type;
+  constexpr int NG = 16;        // groups per item (the 16 columns of the matrix instruction)
+  constexpr int S = 1 << K;
+  constexpr int TT = S / 8;     // 16-row blocks of the (2S x 2S) real matrix
+  constexpr int KP = S / 4;     // K-step PAIRS (one amplitude of X each)
+  constexpr int KPH = KP / NPH; // ... per phase: NPH > 1 when 16 x 2^K amplitudes exceed the LDS (Complex<f64>, K = 10) — the
+                                // K dimension is walked in NPH phases, each with its share of X in LDS, the row blocks'
+                                // running sums carried in registers from phase to phase
+  constexpr int NW = 8;         // waves per block
+  constexpr int RBW = TT / NW;  // row blocks per wave
+  constexpr int PF = 8;         // K-step pairs of A in flight ahead of the matrix instructions
+  static_assert(KPH % PF == 0 && TT % NW == 0 && KP % NPH == 0, "shape");
+  __shared__ __attribute__((aligned(16))) A xl[(S / NPH) * NG];  // xl[(c~ - first c~ of the phase) * NG + group]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t j = lane & 15u, q = lane >> 4;
+  const uint64_t offq = ((uint64_t)(q & 1u) << d.tau[0]) | ((uint64_t)(q >> 1) << d.tau[1]);
+  auto offm = [&](uint32_t m) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < K - 2; ++b) o |= (uint64_t)((m >> b) & 1u) << d.tau[b + 2];
+    return o;
+  };
+  typedef T pair_t __attribute__((ext_vector_type(2)));  // A values of K-steps 2p and 2p + 1
+  const pair_t* __restrict__ a2 = reinterpret_cast<const pair_t*>(afrag2);
+  for (uint64_t w = blockIdx.x; w < nitems; w += gridDim.x) {
+    const uint64_t base = insert_bits<-1>(w * NG + j, ins) | offq;
+    V4 y[RBW];  // the row blocks' sums so far; statically indexed (a rolled loop picks its slot by comparison): registers
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) y[r] = V4{(T)0, (T)0, (T)0, (T)0};
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+      if (ph) __syncthreads();  // every wave is done with the previous phase's share of X
+      // X -> LDS: wave v brings the sub-indices c~ = 4 m + q with m = first + v, first + v + NW, ...
+#pragma unroll 4
+      for (uint32_t m = wave; m < (uint32_t)KPH; m += NW)
+        xl[(4u * m + q) * NG + j] = ldg<NT>(st + (base | offm((uint32_t)ph * KPH + m)));
+      __syncthreads();
+#pragma unroll 1
+      for (int rbi = 0; rbi < RBW; ++rbi) {
+        const uint32_t rb = wave + (uint32_t)rbi * NW;
+        const pair_t* ap = a2 + ((size_t)rb * KP + (size_t)ph * KPH) * 64 + lane;
+        V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
+        if (NPH > 1) {
+#pragma unroll
+          for (int r = 0; r < RBW; ++r)
+            if (r == rbi) acc0 = y[r];
+        }
+        pair_t cur[PF], nxt[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) cur[u] = ap[(size_t)u * 64];
+#pragma unroll 1
+        for (int p0 = 0; p0 < KPH; p0 += PF) {
+          if (p0 + PF < KPH) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) nxt[u] = ap[(size_t)(p0 + PF + u) * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            const A xb = xl[(4u * (uint32_t)(p0 + u) + q) * NG + j];
+            acc0 = mfma16(cur[u].x, xb.x, acc0);
+            acc1 = mfma16(cur[u].y, xb.y, acc1);
+          }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int r = 0; r < RBW; ++r)
+          if (r == rbi) y[r] = acc0 + acc1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) {
+      const uint32_t rb = wave + (uint32_t)r * NW;
+      A y0, y1;
+      y0.x = y[r][0];
+      y0.y = y[r][1];
+      y1.x = y[r][2];
+      y1.y = y[r][3];
+      stg<NT>(st + (base | offm(2u * rb)), y0);
+      stg<NT>(st + (base | offm(2u * rb + 1u)), y1);
+    }
+    __syncthreads();  // every wave is done reading this item's X before the next item overwrites it
+  }
+}
+
 // ---- SparseMatrix on k <= 5 qubits, in place ---------------------------------------------------------------------
 // SparseMatrixOpIterator (qubit_iterators.rs:60-102): row r of the op is its stored list of (column, value), applied
 // in stored order with nothing filtered; out[r] = 0 + v_0 * x[c_0] + v_1 * x[c_1] + ...  One lane owns one group of

@@ -524,7 +524,7 @@ int launch_gather(qip_hip_state* s, const FlatOp& f, const amp_t<T>* in, uint64_
 static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out, bool f32_layout = false) {
   const uint32_t k = (uint32_t)p.opos.size();
   const uint32_t S = 1u << k, TT = S / 8, KS = S / 2;
-  uint32_t perm_bit[8];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
+  uint32_t perm_bit[12];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
   for (uint32_t b = 0; b < k; ++b)
     for (uint32_t j = 0; j < k; ++j)
       if (p.opos[j] == tau[b]) perm_bit[b] = k - 1 - j;
@@ -680,6 +680,51 @@ static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   return QIP_OK;
 }
 
+// dense k = 9, 10 on the matrix cores: X in LDS, the A operand streamed from L2 in pairs of K-steps (k_gate_huge_mfma)
+template <typename T>
+static int launch_huge_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  std::vector<uint32_t> tau = p.opos;
+  std::sort(tau.begin(), tau.end());
+  std::vector<double> afrag;
+  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  // pairs of consecutive K-steps side by side, so a lane fetches both with one 16-byte (f32: 8-byte) load
+  const size_t S = (size_t)1 << k, TT = S / 8, KS = S / 2, KP = S / 4;
+  std::vector<T> a2(afrag.size());
+  for (size_t rb = 0; rb < TT; ++rb)
+    for (size_t pr = 0; pr < KP; ++pr)
+      for (size_t l = 0; l < 64; ++l)
+        for (size_t e = 0; e < 2; ++e) a2[((rb * KP + pr) * 64 + l) * 2 + e] = (T)afrag[(rb * KS + 2 * pr + e) * 64 + l];
+  QCHK(ensure_arena(s, a2.size() * sizeof(T)));
+  QCHK(arena_upload(s, a2.data(), a2.size() * sizeof(T), 0));
+  HIPCHK(hipStreamSynchronize(s->stream));  // (the staging vector dies with this frame; 8 - 32 MiB once per gate)
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  Ins ins = make_ins(pos, mask_of(p.cpos));
+  HugeDesc d;
+  memset(&d, 0, sizeof d);
+  for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
+  const uint64_t groups = 1ull << (s->n - (uint32_t)pos.size());
+  const uint64_t nitems = groups / 16;
+  const unsigned blocks = (unsigned)std::min<uint64_t>(nitems, (uint64_t)s->num_cus);  // one 128-KiB block per CU
+  const T* af = (const T*)s->arena;
+  const bool nt = use_nt(s);
+#define HM(K, NPH)                                                                                                            \
+  do {                                                                                                                        \
+    if (nt) hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, true>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);  \
+    else hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, false>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);    \
+  } while (0)
+  // (16 groups x 2^10 Complex<f64> amplitudes are 256 KiB: two phases of 128 KiB)
+  if (k == 9) HM(9, 1);
+  else if (k == 10) {
+    if constexpr (std::is_same<T, double>::value) HM(10, 2);
+    else HM(10, 1);
+  } else return fail(QIP_ERR_UNSUPPORTED, "L2-streamed matrix-core kernel for k = %u", k);
+#undef HM
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
 template <typename T>
 static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
   const uint32_t k = (uint32_t)p.opos.size();
@@ -695,7 +740,12 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
     // matrix cores (f64 and f32 forms): always for k = 5 (no register form), and for k = 3, 4 when two or more targets
     // are low bit positions, where the MFMA mapping keeps 64-B+ runs per lane group and the per-lane
     // register form does not (measured at n = 30: profiles/r01_ops_table*.md)
-    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2;  // 2 = force (tuning aid)
+    // r4: k = 4 always where the LDS-staged form can run (a state of >= 17 qubits): the bit-exact VALU fold of a dense 16 x 16
+    // gate is 128 unfused f64 operations per amplitude = 3.5 ms of vector issue at n = 30 on top of the HBM time (65.8 % whatever
+    // the targets), the matrix-core form through the tile streams whole (split) rows: 75 - 81 % (profiles/r04_ops_table.md).
+    // Option mfma = 0 keeps the bit-exact VALU form.
+    const bool want_mfma = k == 5 || (k >= 3 && low_targets >= 2) || s->mfma == 2 ||  // 2 = force (tuning aid)
+                           (k == 4 && s->n >= (uint32_t)kTileBits + 6 && !g_force_k4_direct);
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
       if (k == 4 && s->unroll == 0 && !g_force_k4_direct) {  // operands through an LDS-resident tile: whole rows on both global sides
@@ -709,6 +759,10 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   if (s->mfma && k > kMaxMfmaK && k <= kMaxBigK && s->n >= used + 4) {
     *actual_cls = KC_GATE_KQ_BIG;
     return launch_big_mfma<T>(s, p, st);
+  }
+  if (s->mfma && k > kMaxBigK && k <= kMaxHugeK && s->n >= used + 4) {
+    *actual_cls = KC_GATE_KQ_BIG;
+    return launch_huge_mfma<T>(s, p, st);
   }
   if (k > kMaxRegK) {  // no register form: literal kernel, out of place
     *actual_cls = KC_GATHER_GENERIC;
@@ -962,7 +1016,10 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
   // k = 2, 3 and low-bit swap, 3 (default) = single-qubit gates as well.
   if (g_single_via_tile && !s->force_generic && !g_force_generic && s->mfma != 0 && s->unroll == 0 && !s->swap_single &&
       (p.cls == KC_GATE_KQ || p.cls == KC_GATE_KQ_MFMA || p.cls == KC_SWAP_BITS || (p.cls == KC_GATE1Q_PAIR && g_single_via_tile >= 3)) &&
-      p.cpos.empty() && s->n >= 17) {
+      // r4: a CONTROLLED dense k = 2, 3 gate takes the sweep as well (controls above the rows come off the grid, controls inside
+      // them are lane predicates): k_gate_kq on low targets ran at 42 - 59 %.  Controlled single-qubit gates and swaps keep
+      // their dedicated half / quarter sweeps.
+      (p.cpos.empty() || ((p.cls == KC_GATE_KQ || p.cls == KC_GATE_KQ_MFMA) && p.opos.size() <= 3)) && s->n >= 17 + (uint32_t)p.cpos.size()) {
     bool low = false;
     for (uint32_t t : p.opos) low = low || t < 6;
     // Complex<f32> (a tile row is 512 B there) has its own switch, "single_via_tile_f32"; measured at n = 30 the sweep is level
@@ -972,7 +1029,7 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
     const bool dense1 = p.cls == KC_GATE1Q_PAIR && !low && mode >= 3;
     if ((dense23 && (low || mode >= 2)) || (p.cls == KC_SWAP_BITS && low) || dense1) {
       bool done = false;
-      QCHK(tile_apply_single<T>(s, op, &done));
+      QCHK(tile_apply_single<T>(s, op, &done, p.alg_bytes));
       if (done) return QIP_OK;
     }
   }

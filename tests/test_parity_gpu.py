@@ -440,9 +440,10 @@ def test_dense_k_qubit(O, k):
             assert np.array_equal(hip_apply(n, cop, x, mfma=0), want)
 
 
-@pytest.mark.parametrize("k", [6, 7, 8])
+@pytest.mark.parametrize("k", [6, 7, 8, 9, 10])
 def test_dense_big_k_streamed_matrix_core_kernel(O, k):
-    """dense k = 6..8 on f64: k_gate_big_mfma (A operand streamed through LDS, X in registers, in place) — targets on
+    """dense k = 6..8 on f64: k_gate_big_mfma (A operand streamed through LDS, X in registers, in place); r4: k = 9, 10:
+    k_gate_huge_mfma (X in LDS, A streamed from L2 in pairs of K-steps; 8 groups per item for Complex<f64> at k = 10) — targets on
     low / high / mixed bit positions, with controls, n from the smallest size the kernel accepts (k + 4) upwards;
     fma chains, so the 1e-12 bar; 0/1 permutation matrices stay exact; mfma = 0 still takes the literal kernel."""
     rng = np.random.default_rng(100 + k)
@@ -2378,3 +2379,56 @@ def test_dense4_on_the_matrix_cores_through_an_lds_tile(O, dtype, tol):
         st.upload(x)
         st.apply_op(q.make_matrix_op([18, 17, 0, 1], perm01.ravel()))
         assert np.array_equal(st.download(), O.apply_ops_in_place(n, [q.make_matrix_op([18, 17, 0, 1], perm01.ravel())], x.copy()))
+
+
+@pytest.mark.parametrize("row_split", [11, 5])
+def test_one_op_tile_sweeps_controlled_dense_and_both_row_shapes(O, row_split):
+    """r4: (a) a CONTROLLED dense k = 2 / 3 gate runs as a one-op tile sweep too — controls above the rows come off the grid
+    (half / quarter sweeps), controls inside a row or a 128-byte line are lane predicates — with the unfused register fold:
+    bit-equal to the oracle (ControlledOpIterator, qubit_iterators.rs:124-171); (b) the tile's rows in both shapes: split
+    (two 512-byte halves 32 KiB apart, positions {0..4, 11}; position 5 is then an ordinary high position) and contiguous."""
+    n = 20
+    rng = np.random.default_rng(7)
+    x = rand_state(n, 3)
+    u2, u3 = rand_unitary(2, rng), rand_unitary(3, rng)
+    q.set_global_option("tile_row_split", row_split)
+    try:
+        cases = []
+        # position p <-> qubit n-1-p.  Targets / controls on: a line bit (0..2), a row bit (3, 4), position 5, 11, 12, high ones
+        P = lambda *pos: [n - 1 - p for p in pos]  # noqa: E731
+        for tg in (P(0, 1), P(4, 5), P(5, 11), P(11, 12), P(2, 17), P(19, 18), P(5, 6)):
+            cases.append(("dense2", q.make_matrix_op(tg, u2.ravel())))
+            for ct in (P(3), P(9), P(13, 1), P(10, 14)):
+                if not set(ct) & set(tg):
+                    cases.append(("cdense2", q.make_control_op(ct, q.make_matrix_op(tg, u2.ravel()))))
+        for tg in (P(0, 1, 2), P(5, 11, 4), P(19, 11, 5), P(16, 17, 18), P(3, 12, 15)):
+            cases.append(("dense3", q.make_matrix_op(tg, u3.ravel())))
+            for ct in (P(6), P(7, 13), P(1) if 1 not in [n - 1 - t for t in tg] else P(8)):
+                if not set(ct) & set(tg):
+                    cases.append(("cdense3", q.make_control_op(ct, q.make_matrix_op(tg, u3.ravel()))))
+        for tq in (5, 11, 12, 19, 6):  # single-qubit gates above the rows, swaps with a bit inside a row
+            cases.append(("h", q.make_matrix_op(P(tq), circuits.H)))
+            cases.append(("swap", q.make_swap_op(P(tq), P(2))))
+        with q.HipState(n) as st:
+            st.set_option("profile", 1)
+            for name, op in cases:
+                st.upload(x)
+                st.profile_reset()
+                st.apply_op(op)
+                got = st.download()
+                want = oracle_apply(O, n, op, x)
+                assert np.array_equal(got, want), (name, op.indices, row_split)
+                if name in ("cdense2", "cdense3", "dense2", "dense3"):
+                    assert "k_tile_passes" in st.profile(), (name, op.indices, st.profile())
+            # the profile credits a controlled sweep with its algorithmic bytes (half the vector per control)
+            st.profile_reset()
+            st.apply_op(q.make_control_op(P(15, 16), q.make_matrix_op(P(0, 9), u2.ravel())))
+            pr = st.profile()["k_tile_passes"]
+            assert pr["algorithmic_bytes"] == 32.0 * 2 ** (n - 2), pr
+        xf = rand_state(n, 4, np.complex64)
+        for name, op in cases[::5]:
+            got = hip_apply(n, op, xf)
+            want = oracle_apply(O, n, op, xf)
+            assert np.max(np.abs(got - want)) <= TOL32, (name, op.indices)
+    finally:
+        q.set_global_option("tile_row_split", 11)

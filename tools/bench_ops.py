@@ -62,6 +62,10 @@ def main():
         ("dense k=3 (VALU regs)", q.make_matrix_op([hi, mid, 5], rand_unitary(3, rng).ravel()), {"mfma": 0}),
         ("dense k=3 low bits (MFMA f64)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {}),
         ("dense k=3 low bits (VALU regs)", q.make_matrix_op([lo - 2, lo - 1, lo], rand_unitary(3, rng).ravel()), {"mfma": 0}),
+        ("controlled dense k=2, low targets, control above the rows", q.make_control_op([3], q.make_matrix_op([lo, lo - 1], rand_unitary(2, rng).ravel())), {}),
+        ("controlled dense k=2, high targets", q.make_control_op([3], q.make_matrix_op([hi, mid], rand_unitary(2, rng).ravel())), {}),
+        ("controlled dense k=2, control inside a row", q.make_control_op([lo - 3], q.make_matrix_op([hi, lo], rand_unitary(2, rng).ravel())), {}),
+        ("2-controlled dense k=3, one low target", q.make_control_op([3, 9], q.make_matrix_op([hi, mid, lo], rand_unitary(3, rng).ravel())), {}),
         ("dense k=4 (MFMA f64)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {}),
         ("dense k=4 (VALU regs)", q.make_matrix_op([hi, mid, 5, lo], rand_unitary(4, rng).ravel()), {"mfma": 0}),
         ("dense k=5 (MFMA f64)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {}),
@@ -75,6 +79,8 @@ def main():
         ("dense k=6 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {}),
         ("dense k=7 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11], rand_unitary(7, rng).ravel()), {}),
         ("dense k=8 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13], rand_unitary(8, rng).ravel()), {}),
+        ("dense k=9 (MFMA f64, X in LDS, A from L2)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17], rand_unitary(9, rng).ravel()), {}),
+        ("dense k=10 (MFMA f64, X in LDS, 8 groups per item)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17, 19], rand_unitary(10, rng).ravel()), {}),
         ("dense k=6 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {"mfma": 0}),
         ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
         ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
