@@ -102,6 +102,12 @@ int qip_hip_abi_version(void);
  *                      LDS passes (tile = 1: only across gates that commute exactly, the result stays IEEE-equal to circuit
  *                      order) and, with tile = 2 from n = 24, the five positions of a segment are claimed by what they buy
  *                      (shortest of three plans); 0 = first come, circuit order inside segments; 2 = search at every size (tests).
+ *   "tile_row_split"   11 (default): every wave-level access of a tile sweep is two 512-byte halves 32 KiB apart (the tile's six
+ *                      low index positions are 0..4 and 11; Complex<f64>, n >= 12), 5: one contiguous 1-KiB row (rounds 1-3).
+ *                      Same results bit for bit; which address bits travel together is what sets a sweep's HBM rate
+ *                      (profiles/r04_tile_rows.md).
+ *   "dist_fold_pack"   1 (default): the gather of a sharded state's remap rides in the store phase of the tile sweep before
+ *                      it where it can (qip_hip_dist_stats.packs_folded); 0 = always a sweep of its own.
  *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
  *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
  *                      (profiles/r02_*.md, r03_tile_skeleton.md). */

@@ -365,7 +365,7 @@ template <typename T> static std::string fnum(T v) {
 // only a value that newly becomes (or stops being) 0 / +-1 changes the structure and compiles again.
 template <typename T>
 static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int remap = 0, std::vector<T>* params = nullptr,
-                                   bool merge_diag = false) {
+                                   bool merge_diag = false, const TileStorePerm* fold = nullptr) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   std::string o;
   auto L = [&](const std::string& line) { o += line; o += "\n"; };
@@ -397,8 +397,21 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  w = (w & ~(1ull << " + std::to_string(d.p5) + ")) | (((w >> " + std::to_string(d.p5) + ") & 1ull) << 5);");
   L("  return w;");
   L("}");
+  if (fold && fold->g) {
+    // the tiles are stored elsewhere, packed for the multi-GPU exchange (TileStorePerm): the positions as literals
+    L("__device__ __forceinline__ uint64_t dst_of(uint64_t x) {");
+    L("  uint64_t top = 0;");
+    for (uint32_t t = 0; t < fold->g; ++t)
+      L("  top |= ((x >> " + std::to_string(fold->sel[t]) + ") & 1ull) << " + std::to_string(fold->Lg + t) + ";");
+    for (uint32_t t = 0; t < fold->g; ++t) {
+      const std::string p = std::to_string(fold->sel_desc[t]);
+      L("  x = ((x >> " + std::to_string(fold->sel_desc[t] + 1) + ") << " + p + ") | (x & ((1ull << " + p + ") - 1ull));");
+    }
+    L("  return x | top;");
+    L("}");
+  }
   L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
-    (params ? ", const T* __restrict__ P" : "") + ") {");
+    (params ? ", const T* __restrict__ P" : "") + (fold && fold->g ? ", A* __restrict__ out" : "") + ") {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
   L("  A* tile = reinterpret_cast<A*>(tile_raw);");
   L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
@@ -597,7 +610,10 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  }");
   }
   for (int u = 0; u < 8; ++u)
-    L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+    if (fold && fold->g)
+      L("  stg<NT>(out + dst_of(wbase | " + ub(u) + ") + dst_of(lane_off), tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
+    else
+      L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, tile[slot_tid ^ tile_slot<A>(" + std::to_string(u) + "u << kTileLaneBits)]);");
   L("}");
   return o;
 }
@@ -640,7 +656,10 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
 template <typename T>
 static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg,
                                std::vector<uint32_t> high_in, uint32_t p5_override = 0,
-                               const std::vector<uint32_t>* grid_ctl = nullptr, double alg_bytes = 0) {
+                               const std::vector<uint32_t>* grid_ctl = nullptr, double alg_bytes = 0,
+                               const TileStorePerm* fold = nullptr) {
+  // `fold`: store the tiles into the second buffer, packed for the multi-GPU exchange (TileStorePerm), and make that buffer
+  // current — the remap's gather rides in this sweep's store phase instead of costing a sweep of its own
   // `grid_ctl` (one-op sweeps): control positions OUTSIDE the tile that are taken off the grid — only the blocks whose base
   // reads 1 there are launched, so a controlled gate sweeps half / a quarter of the vector like the dedicated kernels do
   // (the kernel's own test of `omask` against the block's base then always passes).  `alg_bytes`: what the profile credits.
@@ -676,6 +695,19 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     ntiles >>= ctl.size();
   }
   const double sweep_bytes = alg_bytes > 0 ? alg_bytes : 2.0 * (double)s->amp_bytes * (double)s->namps;
+  // a packed store needs every tile written (no blocks taken off the grid), the pass kernel, rows that stay rows (none of
+  // the gathered positions is a lane position of this tile) and the second buffer; otherwise the sweep runs as usual and the
+  // remap gathers by itself
+  if (!fold && s->fold_now && s->fold_request && !s->fold_done) fold = s->fold_request;
+  bool folding = fold && fold->g && s->tile_passes && (!grid_ctl || grid_ctl->empty()) && !s->capture_staging && !s->jit_prepare;
+  if (folding)
+    for (uint32_t t = 0; t < fold->g; ++t) folding = folding && !tile_is_low(fold->sel[t], plan.p5);
+  if (folding) QCHK(ensure_alt(s));
+  auto folded_swap = [&]() {
+    std::swap(s->cur, s->alt);
+    std::swap(s->owns_cur, s->owns_alt);
+    s->fold_done = true;
+  };
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
   const amp_t<T>* dmats = nullptr;
@@ -713,7 +745,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       if (nb < 3) remap = 0;
       else remap = 16 + (int)std::min(J, nb - 3);
     }
-    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), remap, parametrised ? &params : nullptr, merge);
+    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), remap, parametrised ? &params : nullptr, merge, folding ? fold : nullptr);
     QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss BEFORE the timed region starts
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
@@ -721,18 +753,34 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     void* st_ptr = s->cur;
     uint64_t ntiles_arg = ntiles;
     void* params_ptr = s->arena;
-    void* args[] = {&st_ptr, &ntiles_arg, &params_ptr};  // (the third is ignored by kernels without parameters)
+    void* out_ptr = s->alt;
+    // (a kernel without parameters has no third argument: the packed-store destination then comes third)
+    void* args_p[] = {&st_ptr, &ntiles_arg, &params_ptr, &out_ptr};
+    void* args_np[] = {&st_ptr, &ntiles_arg, &out_ptr};
+    void** args = (parametrised || !folding) ? args_p : args_np;
     const dim3 grid = grid2d(ntiles, 1);
     QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
       HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
       return QIP_OK;
     }));
     if (s->profile) QCHK(prof_end(s, &rec));
+    if (folding) folded_swap();
     return QIP_OK;
   }
   if (s->jit_prepare) return QIP_OK;
   if (s->tile_passes) {
     QCHK(begin());
+    if (folding) {
+#define TPF(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV, true>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
+                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)s->alt, *fold)
+      if (use_nt(s)) TPF(true);
+      else TPF(false);
+#undef TPF
+      HIPCHK(hipGetLastError());
+      if (s->profile) QCHK(prof_end(s, &rec));
+      folded_swap();
+      return QIP_OK;
+    }
 #define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats)
     if (use_nt(s)) TP(true);
@@ -919,7 +967,9 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   for (const TileStep& st : sc.steps) moves_qubits = moves_qubits || !st.perm.empty();
   s->layout.clear();
   auto run_steps = [&]() -> int {
+    size_t step_no = 0;
     for (const TileStep& st : sc.steps) {
+      s->fold_now = s->fold_request && ++step_no == sc.steps.size();  // (the batch's last step may store packed)
       if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
         if (s->jit_prepare) continue;
         QCHK(launch_permute(s, st.perm.data()));
@@ -936,6 +986,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     return QIP_OK;
   };
   const int rc_steps = run_steps();
+  s->fold_now = false;
   if (rc_steps != QIP_OK) {
     if (moves_qubits && !s->jit_prepare) {
       s->poisoned = true;
@@ -964,7 +1015,9 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
       return s->dtype == QIP_C64 ? apply_ops_fused<double>(s, ops, count, K) : apply_ops_fused<float>(s, ops, count, K);
   }
   for (uint64_t i = 0; i < count; ++i) {
+    s->fold_now = s->fold_request && i + 1 == count;  // (a last op that runs as a one-op tile sweep may store packed)
     int rc = s->dtype == QIP_C64 ? apply_op_t<double>(s, &ops[i]) : apply_op_t<float>(s, &ops[i]);
+    s->fold_now = false;
     if (rc != QIP_OK) {
       std::string msg = g_last_error;
       return fail(rc, "op %llu: %s", (unsigned long long)i, msg.c_str());

@@ -25,6 +25,8 @@
 #include <memory>
 #include <mutex>
 
+int64_t g_dist_fold_pack = 1;  // global option "dist_fold_pack": 0 = the remap always gathers with a sweep of its own
+
 namespace qipd {
 
 // ---- ops owned by the planner (the localized op of a rank) -------------------------------------------------------------
@@ -685,7 +687,34 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
       for (; jx < steps.size() && steps[jx].kind == qipd::Step::LOCAL; ++jx) ptrs.push_back(qipd::marshal_one(s->dtype, *steps[jx].op, &m));
       m.flat.reserve(ptrs.size());
       for (const qip_op* p : ptrs) m.flat.push_back(*p);
-      QCHK(qip_hip_state_apply_ops(s, m.flat.data(), m.flat.size()));
+      // r4: when a remap follows, its gather (the leaving qubits' positions to the top g local positions) rides in the store
+      // phase of this batch's last tile sweep — every sweep writes whole rows anyway, so it writes them to their packed places
+      // in the second buffer — and the PACK step is skipped.  Not when a gathered position lies inside a row (the rows would
+      // break into 16-byte pieces: the bit-permutation sweep handles that), nor when the batch does not end in a tile sweep.
+      TileStorePerm sp;
+      memset(&sp, 0, sizeof sp);
+      const bool pack_next = g_dist_fold_pack && jx < steps.size() && steps[jx].kind == qipd::Step::PACK && s->layout.empty();
+      if (pack_next) {
+        sp.g = g;
+        sp.Lg = L - g;
+        std::vector<uint32_t> desc = steps[jx].sel;
+        std::sort(desc.begin(), desc.end(), std::greater<uint32_t>());
+        for (uint32_t t = 0; t < g; ++t) {
+          sp.sel[t] = steps[jx].sel[t];
+          sp.sel_desc[t] = desc[t];
+        }
+        s->fold_request = &sp;
+        s->fold_done = false;
+      }
+      const int rc_batch = qip_hip_state_apply_ops(s, m.flat.data(), m.flat.size());
+      const bool folded = pack_next && s->fold_done;
+      s->fold_request = nullptr;
+      s->fold_done = false;
+      QCHK(rc_batch);
+      if (folded) {
+        d->stats.packs_folded += 1;
+        ++jx;  // the PACK step is done
+      }
       // payload buffers of this batch die with `m`: the uploads above were staged by the runtime before returning
       i = jx;
       continue;

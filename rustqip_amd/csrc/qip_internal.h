@@ -61,6 +61,7 @@ extern uint32_t g_line_bits;
 extern int64_t g_perm_rows;
 extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap, g_tile_sched;
 extern int64_t g_single_via_tile, g_single_via_tile_f32;
+extern int64_t g_dist_fold_pack;  // qip_dist.hip
 extern int64_t g_force_k4_direct;  // tuning aid: dense k = 4 on the matrix cores reads its operands straight from HBM (k_gate_kq_mfma)  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 
 struct FlatOp {
@@ -161,6 +162,12 @@ struct qip_hip_state {
   // from the amplitudes fails with the original message until init_basis / a full upload / copy_from overwrites them.
   bool poisoned = false;
   std::string poison_msg;
+  // The sharded state's remap (qip_dist.hip) asks the batch it hands to this shard to leave its result PACKED in the second
+  // buffer (TileStorePerm: the leaving qubits' positions gathered on top): the last sweep of the batch — if it is a tile
+  // sweep — stores its tiles there and the remap needs no gather sweep of its own.  `fold_now` is raised while the batch's
+  // last step runs, `fold_done` reports that a sweep took the request.
+  const TileStorePerm* fold_request = nullptr;
+  bool fold_now = false, fold_done = false;
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
   int64_t tile_jit = 0;     // 1 (= 2) = tile segments run as kernels compiled at run time for that segment's STRUCTURE (hiprtc,
                             // cached), its numbers are kernel data (angles can change without recompiling); 3 = numbers as literals

@@ -37,6 +37,8 @@ template <typename T> struct V2;
 template <> struct V2<double> { using type = double __attribute__((ext_vector_type(2))); };
 template <> struct V2<float> { using type = float __attribute__((ext_vector_type(2))); };
 template <typename T> using amp_t = typename V2<T>::type;
+template <typename A, typename B> struct SameT { static constexpr bool v = false; };  // (std::is_same: no system headers under hiprtc)
+template <typename A> struct SameT<A, A> { static constexpr bool v = true; };
 
 // ---- index arithmetic ------------------------------------------------------
 
@@ -1123,6 +1125,26 @@ __device__ __forceinline__ uint64_t tile_block_base(uint64_t blk, const Ins& ins
   return w;
 }
 __device__ __forceinline__ uint32_t tile_lane_off(uint32_t lane, uint32_t p5) { return (lane & 31u) | ((lane >> 5) << p5); }
+// A tile sweep that stores its tiles ELSEWHERE and permuted (r4): the multi-GPU remap gathers the g leaving qubits' bit positions
+// into the top g local positions before the all-to-all — a full out-of-place sweep of its own (k_pack_bits) unless the sweep
+// that precedes it writes its rows straight to their packed places: destination index = the source index with the bits at
+// `sel` taken out (every other bit keeps its relative order) and put on top, bit sel[t] -> position Lg + t.  The map moves
+// bits, so it distributes over the disjoint parts of an address (block base | wave bits | access bits | lane offset).
+// None of `sel` may be a low (lane) position: a row stays a row (two 512-byte halves, or one KiB).
+struct TileStorePerm {
+  uint32_t g, Lg;        // g = 0: store in place (the ordinary sweep)
+  uint32_t sel[8];       // source position of destination bit Lg + t
+  uint32_t sel_desc[8];  // the same positions, descending (removal order)
+};
+__device__ __forceinline__ uint64_t tile_packed_index(uint64_t x, const TileStorePerm& sp) {
+  uint64_t top = 0;
+  for (uint32_t t = 0; t < sp.g; ++t) top |= ((x >> sp.sel[t]) & 1ull) << (sp.Lg + t);
+  for (uint32_t t = 0; t < sp.g; ++t) {
+    const uint32_t p = sp.sel_desc[t];
+    x = ((x >> (p + 1)) << p) | (x & ((1ull << p) - 1ull));
+  }
+  return x | top;
+}
 // (Measured in round 2: kTileHigh = 6 — 64-KiB tiles, 512 lanes, 2 blocks per CU — cuts the configs[1] circuit from 19
 // to 15 sweeps but each sweep takes 11.8 ms instead of 6.8: 177 vs 129 ms.  Five resident blocks per CU are what
 // overlaps the load / LDS / store phases; profiles/r02_tile_variants.md.)
@@ -1542,10 +1564,12 @@ __device__ __forceinline__ void pass_dense3(const amp_t<T>* __restrict__ M, amp_
 // hide it; left alone the compiler spent 170 registers (VGPR + AGPR) on scheduling freedom = 2 blocks per CU.
 // (f32: the same bound holds without spills once the SLP vectorizer is off — rustqip_amd/build.py; with it the pass
 // packs f32 products into v_pk_* pairs and the kernel needs 180 registers.)
-template <typename T, bool NT>
+template <typename T, bool NT, bool FOLD = false>
 __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restrict__ st, Ins ins, TilePassDesc d,
                                                                               const TileGate<T>* __restrict__ gates,
-                                                                              const amp_t<T>* __restrict__ mats) {
+                                                                              const amp_t<T>* __restrict__ mats,
+                                                                              amp_t<T>* __restrict__ out = nullptr,
+                                                                              TileStorePerm sp = TileStorePerm()) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
@@ -1661,7 +1685,8 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
     for (int u = 0; u < PER; ++u) {
       const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
                           ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-      stg<NT>(st + ub + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+      if constexpr (FOLD) stg<NT>(out + tile_packed_index(ub, sp) + tile_packed_index(lane_off, sp), tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+      else stg<NT>(st + ub + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
     }
   }
 }
@@ -1889,6 +1914,13 @@ __device__ __forceinline__ uint64_t meas_template(const MeasDesc& md, uint64_t m
   return t;
 }
 
+// |amp|^2 in the state's own precision (measurement_ops.rs:65-112 sums P values), widened for the accumulation.  A packed
+// f32 element holds two adjacent amplitudes (index bit 0 inside the element): `lo` / `hi` are theirs.
+__device__ __forceinline__ double prob_of(amp_t<double> x) { return x.x * x.x + x.y * x.y; }
+__device__ __forceinline__ double prob_of(amp_t<float> x) { return (double)(x.x * x.x + x.y * x.y); }
+__device__ __forceinline__ double prob_lo(f32x4 x) { return (double)(x.x * x.x + x.y * x.y); }
+__device__ __forceinline__ double prob_hi(f32x4 x) { return (double)(x.z * x.z + x.w * x.w); }
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_measure_probs(const amp_t<T>* __restrict__ st,
                                                           uint64_t count, Ins ins, MeasDesc md,
@@ -1909,25 +1941,53 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs(const amp_t<T>* __rest
 
 // few outcomes (k <= 4): ONE fully coalesced pass over the vector; every lane keeps 2^K running sums
 // (select-by-compare, no dynamic register indexing) and blocks write partial[blockIdx.x * 2^K + m].
-template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void k_measure_probs_small(const amp_t<T>* __restrict__ st,
-                                                                uint64_t namps, MeasDesc md,
+// r4: four independent 16-byte loads in flight per lane, 32 KiB apart (`work_index`'s spacing: 6.2 vs 5.3 TB/s for the gate
+// kernels; a lone load per iteration left this pass at 74 %), and Complex<f32> states read as 16-byte elements of two
+// amplitudes (E = f32x4, positions in units of elements: bit 0 of the amplitude index is the half of the element and is
+// measured through `bit0` = its outcome bit, or -1) — an 8-byte access per lane runs at 0.54 - 0.70x the 16-byte rate.
+template <typename T, int K, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_measure_probs_small(const E* __restrict__ st,
+                                                                uint64_t nelems, MeasDesc md, int bit0,
                                                                 double* __restrict__ partial) {
   constexpr int M = 1 << K;
+  constexpr bool PACKED = !SameT<E, amp_t<T>>::v;
   __shared__ double smem[kBlock / 64];
   double acc[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) acc[m] = 0.0;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < namps; i += stride) {
-    const amp_t<T> x = __builtin_nontemporal_load(st + i);
-    const double p = (double)(x.x * x.x + x.y * x.y);
+  auto take = [&](uint64_t i, E x) {  // `i`: element index
     uint32_t mine = 0;
 #pragma unroll
-    for (int b = 0; b < K; ++b) mine |= (uint32_t)((i >> md.mpos[b]) & 1ull) << b;
+    for (int b = 0; b < K; ++b)
+      if (!(PACKED && b == bit0)) mine |= (uint32_t)((i >> md.mpos[b]) & 1ull) << b;
+    if constexpr (PACKED) {
+      const double p0 = prob_lo(x), p1 = prob_hi(x);
+      const uint32_t hi_bit = bit0 >= 0 ? 1u << bit0 : 0u;
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] += (mine == (uint32_t)m) ? p : 0.0;
+      for (int m = 0; m < M; ++m) acc[m] += (mine == (uint32_t)m ? p0 : 0.0) + ((mine | hi_bit) == (uint32_t)m ? p1 : 0.0);
+    } else {
+      const double p = prob_of(x);
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc[m] += (mine == (uint32_t)m) ? p : 0.0;
+    }
+  };
+  constexpr int U = 4;
+  constexpr uint64_t kSpan = (uint64_t)U << kStrideShift;  // elements one round of a block covers per 256-lane row set
+  const uint64_t rounds = nelems / kSpan;                  // whole spans: blocks take them round-robin, 8 rows of 256 each
+  // span r = elements [r * kSpan, (r + 1) * kSpan): row q (0..7) of access u sits at r * kSpan + (u << kStrideShift) + q * 256
+  for (uint64_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+#pragma unroll 1
+    for (uint32_t qrow = 0; qrow < (1u << (kStrideShift - 8)); ++qrow) {
+      const uint64_t i0 = r * kSpan + (uint64_t)qrow * kBlock + threadIdx.x;
+      E x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(st + i0 + ((uint64_t)u << kStrideShift));
+#pragma unroll
+      for (int u = 0; u < U; ++u) take(i0 + ((uint64_t)u << kStrideShift), x[u]);
+    }
   }
+  for (uint64_t i = rounds * kSpan + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nelems; i += (uint64_t)gridDim.x * kBlock)
+    take(i, st[i]);
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const double t = block_reduce_sum(acc[m], smem);
@@ -2059,19 +2119,36 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_scatter(const amp_t<T>
   }
 }
 
-// partial[b] = sum |amp|^2 over the b-th contiguous chunk of `chunk` amplitudes
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_chunk_norms(const amp_t<T>* __restrict__ st,
-                                                        uint64_t namps, uint64_t chunk,
+// partial[b] = sum |amp|^2 over the b-th contiguous chunk of `chunk` amplitudes (elements, for a packed f32 state).
+// r4: four independent 16-byte loads per lane 32 KiB apart where the chunk allows it, packed elements for Complex<f32>.
+template <typename T, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_chunk_norms(const E* __restrict__ st,
+                                                        uint64_t nelems, uint64_t chunk,
                                                         double* __restrict__ partial) {
+  constexpr bool PACKED = !SameT<E, amp_t<T>>::v;
   __shared__ double smem[kBlock / 64];
   const uint64_t lo = (uint64_t)blockIdx.x * chunk;
-  const uint64_t hi = lo + chunk < namps ? lo + chunk : namps;
+  const uint64_t hi = lo + chunk < nelems ? lo + chunk : nelems;
+  auto prob = [](E x) {
+    if constexpr (PACKED) return prob_lo(x) + prob_hi(x);
+    else return prob_of(x);
+  };
   double s = 0;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
-    const amp_t<T> x = st[i];
-    s += (double)(x.x * x.x + x.y * x.y);
+  constexpr int U = 4;
+  constexpr uint64_t kSpan = (uint64_t)U << kStrideShift;
+  uint64_t i = lo;
+  for (; i + kSpan <= hi; i += kSpan) {
+#pragma unroll 1
+    for (uint32_t qrow = 0; qrow < (1u << (kStrideShift - 8)); ++qrow) {
+      const uint64_t i0 = i + (uint64_t)qrow * kBlock + threadIdx.x;
+      E x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(st + i0 + ((uint64_t)u << kStrideShift));
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += prob(x[u]);
+    }
   }
+  for (i += threadIdx.x; i < hi; i += kBlock) s += prob(st[i]);
   const double t = block_reduce_sum(s, smem);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }

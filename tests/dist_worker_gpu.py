@@ -161,6 +161,39 @@ def main():
         assert sp._transport.pieces_moved >= 3 * (world - 1)
         if rank == 0:
             print(f"ok pieces: {sp._transport.pieces_moved} pieces moved in {sp.comm_stats()['remaps']} exchanges")
+    if not use_nccl and world > 1:
+        # r4: the remap's gather folded into the store phase of the tile sweep before it (qip_hip_dist_stats.packs_folded):
+        # same amplitudes bit for bit as with a gather sweep of its own, fewer sweeps.  n = 20: real tiles (2^11) on 2^19 shards.
+        n = 20
+        x = circuits.random_state(n, n)
+        ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 160, seed=11) + circuits.c4_clifford_t(n, 96, seed=5)
+        res = {}
+        for fold in (0, 1):
+            q.set_global_option("dist_fold_pack", fold)
+            for tile, jit in ((1, 0), (1, 1), (0, 0)):
+                sf = DistState(n, dist, 0, host_staged=True)
+                sf.set_option("tile", tile)
+                sf.set_option("tile_jit", jit)
+                sf.upload_global(x)
+                sf.apply_ops(ops)
+                res[(fold, tile, jit)] = (sf.download_global(), sf.comm_stats())
+                sf.close()
+        q.set_global_option("dist_fold_pack", 1)
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        folded_total = 0
+        for tile, jit in ((1, 0), (1, 1), (0, 0)):
+            a, sa = res[(0, tile, jit)]
+            b, sb = res[(1, tile, jit)]
+            assert np.array_equal(a, b), (tile, jit)
+            assert np.max(np.abs(b - want)) < 1e-12
+            assert sa["packs_folded"] == 0 and sb["remaps"] == sa["remaps"]
+            assert sb["pack_sweeps"] + sb["packs_folded"] == sa["pack_sweeps"], (sa, sb)
+            folded_total += sb["packs_folded"]
+            if rank == 0:
+                print(f"fold tile={tile} jit={jit}: remaps={sb['remaps']} pack_sweeps {sa['pack_sweeps']} -> {sb['pack_sweeps']} (folded {sb['packs_folded']})")
+        assert folded_total >= 2, folded_total
+        if rank == 0:
+            print("ok fold: the remap's gather rides in the preceding tile sweep")
     # f32 shards
     n = 11
     xf = circuits.random_state(n, 3, np.complex64)
