@@ -588,9 +588,23 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
         case TOP_DENSE3Q_012: case TOP_DENSE3Q_021: case TOP_DENSE3Q_102: case TOP_DENSE3Q_120: case TOP_DENSE3Q_201: case TOP_DENSE3Q_210: {
           static const int ja[6] = {0, 0, 1, 1, 2, 2}, jb[6] = {1, 2, 0, 2, 0, 1};
           const int a = ja[g.op - TOP_DENSE3Q_012], b = jb[g.op - TOP_DENSE3Q_012];
-          std::string m = "const A M[64] = {";
-          for (int e = 0; e < 64; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 63 ? ", " : "}; ");
-          call = m + "pass_dense3<T, " + std::to_string(a) + ", " + std::to_string(b) + ", " + std::to_string(3 - a - b) + ">(M, e, " + lane_args + ");";
+          const std::string tail = "pass_dense3<T, " + std::to_string(a) + ", " + std::to_string(b) + ", " + std::to_string(3 - a - b) + ">(M, e, " + lane_args + ");";
+          if (params) {
+            // r4: the 8 x 8 matrix as ONE contiguous block of the parameter array, read row by row through a pointer like the
+            // interpreter does (wave-uniform scalar loads as they are needed).  Spelt out as 64 named components, all 128
+            // scalars were live at once: the dense-k3 Grover segments ran SLOWER compiled than interpreted (108.9 vs 101.4 ms).
+            if (params->size() & 1) params->push_back((T)0);  // (16-byte alignment of the block for Complex<f64>)
+            const size_t off = params->size();
+            for (int e = 0; e < 64; ++e) {
+              params->push_back(plan.mats[16 * g.nz + e].x);
+              params->push_back(plan.mats[16 * g.nz + e].y);
+            }
+            call = "const A* __restrict__ M = reinterpret_cast<const A*>(P + " + std::to_string(off) + "); " + tail;
+          } else {
+            std::string m = "const A M[64] = {";
+            for (int e = 0; e < 64; ++e) m += amp(plan.mats[16 * g.nz + e]) + (e < 63 ? ", " : "}; ");
+            call = m + tail;
+          }
           break;
         }
         case TOP_SWAP_01: call = "pass_swap<T, 0, 1>(e, c, g.cm_reg, " + lane_args + ");"; break;

@@ -1920,6 +1920,7 @@ __device__ __forceinline__ double prob_of(amp_t<double> x) { return x.x * x.x + 
 __device__ __forceinline__ double prob_of(amp_t<float> x) { return (double)(x.x * x.x + x.y * x.y); }
 __device__ __forceinline__ double prob_lo(f32x4 x) { return (double)(x.x * x.x + x.y * x.y); }
 __device__ __forceinline__ double prob_hi(f32x4 x) { return (double)(x.z * x.z + x.w * x.w); }
+__device__ __forceinline__ double prob_of(f32x4 x) { return prob_lo(x) + prob_hi(x); }  // both amplitudes of the element
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_measure_probs(const amp_t<T>* __restrict__ st,
@@ -2010,8 +2011,10 @@ struct MeasGridDesc {
   uint32_t lpos[8];         // measured positions < 8
   uint32_t spos[3];         // step positions (bit i of c)
 };
-template <typename T, int KI>
-__global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* __restrict__ st, uint64_t count, Ins ins,
+// (E = f32x4: a Complex<f32> state read as 16-byte elements of two amplitudes when index bit 0 is not measured — positions in
+// units of elements, an element contributes both of its amplitudes)
+template <typename T, int KI, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const E* __restrict__ st, uint64_t count, Ins ins,
                                                               MeasGridDesc md, uint32_t gx, uint64_t nout,
                                                               double* __restrict__ partial) {
   constexpr int NC = 1 << KI;
@@ -2040,7 +2043,7 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* _
     for (int u = 0; u < UN; ++u) acc[c][u] = 0.0;
   uint64_t w = (uint64_t)bx * kBlock + threadIdx.x;
   for (; w + (UN - 1) * stride < count; w += UN * stride) {
-    amp_t<T> a[NC][UN];
+    E a[NC][UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const uint64_t base = insert_bits<-1>(w + u * stride, ins);
@@ -2050,14 +2053,14 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const amp_t<T>* _
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) acc[c][u] += (double)(a[c][u].x * a[c][u].x + a[c][u].y * a[c][u].y);
+      for (int u = 0; u < UN; ++u) acc[c][u] += prob_of(a[c][u]);
   }
   for (; w < count; w += stride) {
     const uint64_t base = insert_bits<-1>(w, ins);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const amp_t<T> a = __builtin_nontemporal_load(st + (base | coff[c]));
-      acc[c][0] += (double)(a.x * a.x + a.y * a.y);
+      const E a = __builtin_nontemporal_load(st + (base | coff[c]));
+      acc[c][0] += prob_of(a);
     }
   }
   // fold the 256 lane sums by lane outcome: add across every lane-id bit that is NOT measured (wave shuffles for

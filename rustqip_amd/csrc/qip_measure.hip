@@ -183,14 +183,19 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
     // would be huge), the others resolved per lane (k_measure_probs_grid)
     MeasGridDesc gd;
     memset(&gd, 0, sizeof gd);
+    // Complex<f32>, index bit 0 not measured: 16-byte elements of two amplitudes (positions in units of elements)
+    bool packed = std::is_same<T, float>::value && s->packed_f32 && s->n >= 2;
+    for (uint32_t i = 0; i < k; ++i) packed = packed && md.mpos[i] != 0;
+    const uint32_t shift = packed ? 1u : 0u, n_eff = s->n - shift;
     std::vector<std::pair<uint32_t, uint32_t>> high;  // (position, outcome bit) of the measured positions >= 8
     uint32_t lbit[8];
     for (uint32_t i = 0; i < k; ++i) {
-      if (md.mpos[i] >= 8) {
-        high.push_back({md.mpos[i], i});
+      const uint32_t mp = md.mpos[i] - shift;
+      if (mp >= 8) {
+        high.push_back({mp, i});
       } else {
         lbit[gd.kl] = i;
-        gd.lpos[gd.kl++] = md.mpos[i];
+        gd.lpos[gd.kl++] = mp;
       }
     }
     std::sort(high.begin(), high.end());
@@ -211,7 +216,7 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
     }
     if (gd.kg <= 20) {
       Ins ins = make_ins(opened, 0);
-      const uint64_t count = 1ull << (s->n - (uint32_t)high.size());  // indices per (grid outcome, step value)
+      const uint64_t count = 1ull << (n_eff - (uint32_t)high.size());  // indices per (grid outcome, step value)
       const uint64_t ny = 1ull << gd.kg, nl = 1ull << gd.kl, nc = 1ull << ki;
       // about 8192 blocks in all, each with at least four 4-KiB rows when the outcome has that many
       uint64_t gx = std::max<uint64_t>(8192 / ny, 1);
@@ -219,8 +224,15 @@ static int measure_probs_t(qip_hip_state* s, const MeasDesc& md, const std::vect
       const size_t nout = (size_t)(ny * nc * nl), np = nout * (size_t)gx;
       QCHK(ensure_partial(s, np + nout));
       const dim3 grid((unsigned)(ny * gx));
-#define MG(KI) hipLaunchKernelGGL((k_measure_probs_grid<T, KI>), grid, dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur, \
-                                  count, ins, gd, (uint32_t)gx, (uint64_t)nout, s->d_partial)
+#define MG(KI)                                                                                                              \
+  do {                                                                                                                      \
+    if (packed)                                                                                                             \
+      hipLaunchKernelGGL((k_measure_probs_grid<float, KI, f32x4>), grid, dim3(kBlock), 0, s->stream, (const f32x4*)s->cur, \
+                         count, ins, gd, (uint32_t)gx, (uint64_t)nout, s->d_partial);                                       \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_measure_probs_grid<T, KI>), grid, dim3(kBlock), 0, s->stream, (const amp_t<T>*)s->cur,          \
+                         count, ins, gd, (uint32_t)gx, (uint64_t)nout, s->d_partial);                                       \
+  } while (0)
       switch (ki) {
         case 0: MG(0); break;
         case 1: MG(1); break;

@@ -255,6 +255,62 @@ __global__ __launch_bounds__(256, 8) void k_probe(A* __restrict__ st, Tp tp, A f
   for (int u = 0; u < 8; ++u) stg<true>(st + a[u], cmul(f, x[u]));
 }
 
+// r4 experiment (with a kill criterion): a 13-bit tile held in REGISTERS — 32 amplitudes per lane (five
+// register bits), 256 lanes per block, seven free positions per sweep instead of five — with LDS only as a 32-KiB transposition
+// buffer: a pass moves the tile through it in four quarters.  Keep only if a light sweep stays <= 6.5 ms at >= 2 blocks per CU.
+struct Hp7 { uint32_t h[7]; uint32_t sorted[7]; uint32_t p5; };
+template <int P, int G, int BPC>
+__global__ __launch_bounds__(256, BPC) void k_v13(A* __restrict__ st, Hp7 hp, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* buf = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t w = (uint64_t)blockIdx.x << 6;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const uint32_t p = hp.sorted[j];
+    w = ((w >> p) << (p + 1)) | (w & ((1ull << p) - 1ull));
+  }
+  if (hp.p5 != 5u) {  // split rows: positions in the space where p5 and 5 have traded places
+    const uint64_t b = (w >> hp.p5) & 1ull;
+    w = (w & ~(1ull << hp.p5)) | (b << 5);
+  }
+  w |= ((uint64_t)(wave & 1u) << hp.h[0]) | ((uint64_t)(wave >> 1) << hp.h[1]);
+  const uint32_t lane_off = (lane & 31u) | ((lane >> 5) << hp.p5);
+  A x[32];
+  auto off = [&](int u) {  // (wave-uniform: scalar registers)
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) o |= (uint64_t)((u >> b) & 1) << hp.h[2 + b];
+    return o;
+  };
+#pragma unroll
+  for (int u = 0; u < 32; ++u) x[u] = ldg<true>(st + (w | off(u)) + lane_off);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    // one pass: the tile through LDS in four quarters of 8 elements per lane, written in one arrangement and read in another
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const uint32_t slot_w = tile_slot<A>(tid);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) buf[slot_w ^ tile_slot<A>((uint32_t)i << 8)] = x[8 * qd + i];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const uint32_t tr = ((tid & 7u) << 5) | (tid >> 3);  // another lane -> tile-bit assignment
+      const uint32_t slot_r = tile_slot<A>(tr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[8 * qd + i] = buf[slot_r ^ tile_slot<A>((uint32_t)i << 8)];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) x[i] = cmul(f, x[i]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 32; ++u) stg<true>(st + (w | off(u)) + lane_off, x[u]);
+}
+
 __global__ void k_init(A* st, uint64_t n) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     A v;
@@ -488,6 +544,40 @@ int main(int argc, char** argv) {
         for (uint32_t a = 6; a + 4 * st < N; a += 2) probe("strd", {a, a + st, a + 2 * st, a + 3 * st, a + 4 * st});
     }
     // the same bytes through a plain streaming kernel for reference: every position "free"
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "v13")) {
+    const uint32_t N = (uint32_t)n;
+    const uint64_t ntiles = g_n >> 13;
+    A f;
+    f.x = 0.6;
+    f.y = 0.8;
+    auto mk7 = [&](std::vector<uint32_t> h, uint32_t p5) {
+      Hp7 hp;
+      for (int j = 0; j < 7; ++j) hp.h[j] = h[j];
+      std::vector<uint32_t> sp = h;
+      for (uint32_t& v : sp) if (v == 5u) v = p5;
+      std::sort(sp.begin(), sp.end());
+      for (int j = 0; j < 7; ++j) hp.sorted[j] = sp[j];
+      hp.p5 = p5;
+      return hp;
+    };
+    struct { std::vector<uint32_t> h; uint32_t p5; const char* name; } sets[] = {
+        {{11, 12, 13, 14, 15, 16, 17}, 5, "contig 11..17"},          {{12, 13, 14, 15, 16, 17, 18}, 11, "split 12..18"},
+        {{N - 7, N - 6, N - 5, N - 4, N - 3, N - 2, N - 1}, 5, "contig top7"}, {{N - 7, N - 6, N - 5, N - 4, N - 3, N - 2, N - 1}, 11, "split top7"},
+        {{12, 14, 17, 20, 22, 24, N - 1}, 11, "split scattered"},     {{6, 9, 14, 18, 21, 24, N - 1}, 11, "split scattered2"},
+        {{5, 6, 7, 8, 9, 10, 12}, 11, "split low"}};
+#define V13(P, G, BPC) run("V13 " #BPC " blocks/CU", P, G, s.name, [&] { hipLaunchKernelGGL((k_v13<P, G, BPC>), dim3((unsigned)ntiles), dim3(256), 32768, 0, g_st, hp, f); })
+    for (auto& s : sets) {
+      const Hp7 hp = mk7(s.h, s.p5);
+      V13(1, 2, 2);
+      V13(1, 2, 3);
+      V13(2, 8, 2);
+      V13(2, 8, 3);
+      V13(3, 8, 3);
+    }
+#undef V13
     CK(hipFree(g_st));
     return 0;
   }
