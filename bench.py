@@ -306,6 +306,13 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs2_qft_tile2_jit_fma_merge", circuits.c3_qft(n)[:200], False, seed=24, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
     leg("configs3_clifford_t_tile2_jit_fma_merge_relabel", circuits.c4_clifford_t(n, gates, seed=32)[gates // 2:gates // 2 + 64], False, seed=25,
         tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
+    # r4: wide tiles (13-bit register-resident tile, seven free positions per sweep, run-time-compiled) as they are timed
+    morew = circuits.c2_random_circuit(n, 128, seed=30)
+    leg("mixed_tile1_jit_wide_chunks", morew[:64], True, seed=26, tile=1, tile_jit=1, tile_wide=1)
+    leg("mixed_tile1_jit_wide_relabel_chunks", morew[64:128], True, seed=27, tile=1, tile_jit=1, tile_wide=1, tile_relabel=2)
+    leg("configs3_clifford_t_tile1_jit_wide_relabel", circuits.c4_clifford_t(n, gates, seed=32)[gates // 2 + 64:gates], True, seed=28,
+        tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
+    leg("configs4_grover_tile1_jit_wide", circuits.c5_grover_iteration(n)[100:], True, seed=29, max_len=96, tile=1, tile_jit=1, tile_wide=1)
     return finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0)
 
 
@@ -542,6 +549,12 @@ def main():
         # compiles a segment's structure and takes its numbers as kernel data (tile_jit = 3: numbers as literals, for comparison)
         extras["tiled_mode2_jit_fma_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
         extras["tiled_mode1_jit_literal_relabel"] = leg(ops_mixed, tile=1, tile_jit=3, tile_relabel=1)  # (tuning aid: numbers as literals)
+        # r4: wide tiles — a 13-bit tile held in registers (32 amplitudes per lane), seven free positions per sweep, LDS as a
+        # transposition buffer; run-time-compiled segments, IEEE-equal in circuit order like the 11-bit sweeps
+        extras["tiled_mode1_jit_wide"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1)
+        extras["tiled_mode1_jit_wide_relabel"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
+        extras["tiled_mode2_jit_fma_wide_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_wide=1, tile_relabel=1)
+        extras["headline_tiled_mode1_jit_wide_relabel"] = leg(ops, tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -553,7 +566,10 @@ def main():
             extras[cname]["tile1_jit"] = leg(cops, "ops", tile=1, tile_jit=1)
             k1, ms1 = jit_stats()
             extras[cname]["tile1_jit"].update({"segments_compiled": k1 - k0, "compile_ms_once": ms1 - ms0})
+            if "qft" not in cname and "dense_k3" not in cname:  # r4: wide tiles (the issue-bound QFT and the dense-k3 variant gain nothing)
+                extras[cname]["tile1_jit_wide"] = leg(cops, "ops", tile=1, tile_jit=1, tile_wide=1)
             if "clifford" in cname:  # (QFT and Grover are layered: the scheduler keeps the plain plan for them)
+                extras[cname]["tile1_jit_wide_relabel"] = leg(cops, "ops", tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
                 extras[cname]["tile1_jit_relabel"] = leg(cops, "ops", tile=1, tile_jit=1, tile_relabel=1)
                 # ... and the 1e-12 mode as it is timed for configs[1] (fused multiply-adds, merged diagonal runs, relabelled)
                 extras[cname]["tile2_jit_fma_merge_relabel"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)

@@ -306,6 +306,14 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    applied as PRODUCTS: each gate's factor joins the running product of the set of a lane's elements it acts on,
  *                    each element then takes the product of its sets (QFT: ~33 complex products per lane after each H instead of
  *                    116).  Rounding differs from the sequential products (1e-12 bar).  Ignored for "tile" = 1.  0 (default) = off.
+ *   "tile_wide"      1 (ABI 5; needs "tile_jit"): the segments run over a WIDE tile — 2^13 amplitudes per block held in registers
+ *                    (32 per lane = five register bits; 256 lanes), LDS only as a transposition buffer — so a segment claims
+ *                    SEVEN free positions instead of five and the circuit needs fewer sweeps (configs[1] in circuit order:
+ *                    18 -> 13, relabelled 14 -> 10; a light sweep costs the same 5.2 - 5.8 ms).  Gates on the five register
+ *                    bits of the moment cost no LDS traffic; a transposition (four quarters through the buffer) brings in up to
+ *                    three new register bits.  Same helpers, same gate order: "tile" = 1 stays IEEE-equal to the gate-by-gate
+ *                    path.  Merged diagonal runs ("tile_merge") are not generated for wide segments: QFT keeps the narrow form.
+ *                    0 (default) = the 11-bit LDS-resident tile.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

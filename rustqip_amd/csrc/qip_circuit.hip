@@ -632,6 +632,216 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
   return o;
 }
 
+// ---- wide tiles (r4, option "tile_wide"): the segment's source for the register-resident 13-bit tile ------------------------------
+// One array of 32 amplitudes per arrangement (straight-line code with constant indices: the arrays are names, not memory — a
+// transposition costs its LDS traffic and two barriers per quarter, no register moves); the gates go through the same helpers
+// as the 11-bit sweeps (pass_dense, pass_scale, pass_swap, pass_dense2, pass_dense3w over 32 elements: the products and sums of
+// the gate-by-gate kernels in the same order — a circuit-order segment stays IEEE-equal to them).
+template <typename T>
+static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params) {
+  const char* tname = std::is_same<T, double>::value ? "double" : "float";
+  constexpr uint32_t SW = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // tile_slot's fold width
+  auto slot = [&](uint32_t t) { return t ^ ((t >> SW) & ((1u << SW) - 1u)); };
+  std::string o;
+  auto L = [&](const std::string& line) { o += line; o += "\n"; };
+  auto U = [](uint64_t v) { return std::to_string(v) + "ull"; };
+  auto N = [](uint64_t v) { return std::to_string(v); };
+  auto comp = [&](T v) -> std::string {
+    if (!params || v == (T)0 || v == (T)1 || v == (T)-1) return fnum<T>(v);
+    params->push_back(v);
+    return "P[" + std::to_string(params->size() - 1) + "]";
+  };
+  auto amp = [&](amp_t<T> a) {
+    const std::string re = comp(a.x);
+    const std::string im = comp(a.y);
+    return "{" + re + ", " + im + "}";
+  };
+  L("#include \"qip_kernels.h\"");
+  L("using namespace qipk;");
+  L(std::string("typedef ") + tname + " T;");
+  L("typedef amp_t<T> A;");
+  L("__device__ __forceinline__ uint64_t tile_base(uint64_t t) {");
+  L("  uint64_t w = t << kTileLow;");
+  for (uint32_t j = 0; j < ins.npos; ++j) {
+    const std::string p = N(ins.pos[j]);
+    L("  w = ((w >> " + p + ") << " + N(ins.pos[j] + 1) + ") | (w & ((1ull << " + p + ") - 1ull));");
+  }
+  if (plan.p5 != 5u) L("  w = (w & ~(1ull << " + N(plan.p5) + ")) | (((w >> " + N(plan.p5) + ") & 1ull) << 5);");
+  L("  return w;");
+  L("}");
+  L(std::string("extern \"C\" __global__ __launch_bounds__(256, 2) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
+    (params ? ", const T* __restrict__ P" : "") + ") {");
+  L("  extern __shared__ __attribute__((aligned(16))) unsigned char buf_raw[];");
+  L("  A* buf = reinterpret_cast<A*>(buf_raw);");
+  L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
+  L("  const uint32_t tid = threadIdx.x, lane = tid & 63u;");
+  L("  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);");
+  L("  (void)ntiles;");
+  L("  const uint64_t base = tile_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x);");
+  L("  const uint64_t wbase = base | ((uint64_t)(wave & 1u) << " + N(plan.high[0]) + ") | ((uint64_t)(wave >> 1) << " + N(plan.high[1]) + ");");
+  L("  const uint32_t lane_off = tile_lane_off(lane, " + N(plan.p5) + "u);");
+  auto ub = [&](int u) {
+    uint64_t off = 0;
+    for (int b = 0; b < kWideRegBits; ++b)
+      if ((u >> b) & 1) off |= 1ull << plan.high[2 + b];
+    return U(off);
+  };
+  L("  A e0[32];");
+  for (int u = 0; u < 32; ++u) L("  e0[" + N(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane_off);");
+  L("  const uint32_t tidv = tid;");
+  for (size_t pi = 0; pi < plan.passes.size(); ++pi) {
+    const WidePass& ps = plan.passes[pi];
+    const std::string e = "e" + N(pi);
+    auto jof = [&](uint32_t bit) {
+      for (int j = 0; j < kWideRegBits; ++j)
+        if (ps.R[j] == bit) return j;
+      return -1;
+    };
+    if (ps.transposed) {
+      const WidePass& pa = plan.passes[pi - 1];
+      const std::string ea = "e" + N(pi - 1);
+      L("  A " + e + "[32];");
+      L("  {  // transposition into arrangement " + N(pi));
+      L("    uint32_t tidp = tidv;");
+      L("    asm volatile(\"\" : \"+v\"(tidp));");
+      L("    uint32_t wa = 0, rb = 0;");
+      for (int k = 0; k < 8; ++k) {
+        L("    wa |= ((tidp >> " + N(k) + ") & 1u) << " + N(ps.bufpos[pa.L[k]]) + ";");
+        L("    rb |= ((tidp >> " + N(k) + ") & 1u) << " + N(ps.bufpos[ps.L[k]]) + ";");
+      }
+      L("    const uint32_t swa = tile_slot<A>(wa), srb = tile_slot<A>(rb);");
+      auto split = [&](const WidePass& w, int (&jq)[2], int (&jo)[3]) {
+        int no = 0;
+        for (int j = 0; j < kWideRegBits; ++j) {
+          if (w.R[j] == ps.q[0]) jq[0] = j;
+          else if (w.R[j] == ps.q[1]) jq[1] = j;
+          else jo[no++] = j;
+        }
+      };
+      int jqa[2] = {0, 0}, joa[3] = {0, 0, 0}, jqb[2] = {0, 0}, job[3] = {0, 0, 0};
+      split(pa, jqa, joa);
+      split(ps, jqb, job);
+      // two buffer halves: quarter v + 1 is written while quarter v is read (write 0 | barrier | read 0, write 1 | barrier |
+      // read 1, write 2 | ... ): four barriers per transposition instead of seven
+      auto emit_write = [&](int qv) {
+        for (int m = 0; m < 8; ++m) {
+          uint32_t r = ((uint32_t)(qv & 1) << jqa[0]) | ((uint32_t)(qv >> 1) << jqa[1]), ci = 0;
+          for (int i = 0; i < 3; ++i)
+            if ((m >> i) & 1) {
+              r |= 1u << joa[i];
+              ci |= 1u << ps.bufpos[pa.R[joa[i]]];
+            }
+          L("    buf[" + N((qv & 1) * 2048) + "u + (swa ^ " + N(slot(ci)) + "u)] = " + ea + "[" + N(r) + "];");
+        }
+      };
+      auto emit_read = [&](int qv) {
+        for (int m = 0; m < 8; ++m) {
+          uint32_t r = ((uint32_t)(qv & 1) << jqb[0]) | ((uint32_t)(qv >> 1) << jqb[1]), ci = 0;
+          for (int i = 0; i < 3; ++i)
+            if ((m >> i) & 1) {
+              r |= 1u << job[i];
+              ci |= 1u << ps.bufpos[ps.R[job[i]]];
+            }
+          L("    " + e + "[" + N(r) + "] = buf[" + N((qv & 1) * 2048) + "u + (srb ^ " + N(slot(ci)) + "u)];");
+        }
+      };
+      emit_write(0);
+      for (int qv = 0; qv < 4; ++qv) {
+        L("    __syncthreads();");
+        emit_read(qv);
+        if (qv < 3) emit_write(qv + 1);
+      }
+      L("  }");
+      // (no barrier before the next transposition: its first write goes to half 0, whose last reads — quarter 2 — lie before
+      // the fourth barrier above; half 1 is next written after the next transposition's first barrier, behind everybody's
+      // reads of quarter 3)
+    } else if (pi > 0) {
+      return std::string();  // (cannot happen: every pass after the first is a transposition)
+    }
+    if (ps.count == 0) continue;
+    L("  {  // pass " + N(pi) + ": register bits = tile bits " + N(ps.R[0]) + "," + N(ps.R[1]) + "," + N(ps.R[2]) + "," + N(ps.R[3]) + "," + N(ps.R[4]));
+    L("    uint32_t tidq = tidv;");
+    L("    asm volatile(\"\" : \"+v\"(tidq));");
+    L("    uint32_t tb = 0;");
+    for (int k = 0; k < 8; ++k) L("    tb |= ((tidq >> " + N(k) + ") & 1u) << " + N(ps.L[k]) + ";");
+    uint32_t rmask = 0;
+    for (int j = 0; j < kWideRegBits; ++j) rmask |= 1u << ps.R[j];
+    std::string cs = "    const uint32_t c[32] = {";
+    for (int i = 0; i < 32; ++i) {
+      uint32_t c = 0;
+      for (int j = 0; j < kWideRegBits; ++j)
+        if ((i >> j) & 1) c |= 1u << ps.R[j];
+      cs += N(c) + "u" + (i < 31 ? ", " : "};");
+    }
+    L(cs);
+    L("    A (&e)[32] = " + e + ";");
+    for (uint32_t gi = ps.first; gi < ps.first + ps.count; ++gi) {
+      TileGate<T> g = plan.gates[gi];
+      g.cm_reg = g.cmask & rmask;
+      g.cm_lane = g.cmask & ~rmask;
+      g.op = 0;
+      L("    {  // gate " + N(gi));
+      {
+        const std::string m0 = amp(g.m[0]), m1 = amp(g.m[1]), m2 = amp(g.m[2]), m3 = amp(g.m[3]);
+        L(std::string("      ") + (params ? "const" : "constexpr") + " TileGate<T> g = {" + N(g.kind) + "u, " + N(g.b0) + "u, " + N(g.b1) + "u, " + N(g.cmask) + "u, " +
+          N(g.nz) + "u, " + N(g.tpos_out) + "u, " + U(g.omask) + ", 0u, " + N(g.cm_reg) + "u, " + N(g.cm_lane) + "u, 0u, {" + m0 + ", " + m1 + ", " + m2 + ", " + m3 + "}};");
+      }
+      const std::string lane_args = "g.cm_lane != 0u, (tb & g.cm_lane) == g.cm_lane";
+      auto matrix = [&](int cnt) {  // the gate's 4x4 / 8x8 matrix: a block of the parameter array, or literals
+        if (params) {
+          if (params->size() & 1) params->push_back((T)0);
+          const size_t off = params->size();
+          for (int k = 0; k < cnt; ++k) {
+            params->push_back(plan.mats[16 * g.nz + k].x);
+            params->push_back(plan.mats[16 * g.nz + k].y);
+          }
+          return "const A* __restrict__ M = reinterpret_cast<const A*>(P + " + N(off) + "); ";
+        }
+        std::string m = "const A M[" + N(cnt) + "] = {";
+        for (int k = 0; k < cnt; ++k) m += amp(plan.mats[16 * g.nz + k]) + (k + 1 < cnt ? ", " : "}; ");
+        return m;
+      };
+      std::string call;
+      if (g.kind == 1) {
+        const bool u0 = g.m[0].x == (T)1 && g.m[0].y == (T)0, u1 = g.m[1].x == (T)1 && g.m[1].y == (T)0;
+        const int J = g.b0 == kTileOutside ? -1 : jof(g.b0);
+        const std::string guard = g.cm_lane ? "{ const bool lane_ok = (tb & g.cm_lane) == g.cm_lane; f.x = lane_ok ? f.x : (T)1; f.y = lane_ok ? f.y : (T)0; } " : "";
+        if (J >= 0) {
+          for (int half = 0; half < 2; ++half) {
+            if (half == 0 ? u0 : u1) continue;
+            call += "{ A f = g.m[" + N(half) + "]; " + guard + "pass_scale<T, " + N(J) + ", " + N(half) + ">(f, e, c, g.cm_reg); } ";
+          }
+        } else if (g.b0 == kTileOutside && !g.cm_lane) {
+          const std::string s0 = u0 ? "" : "pass_scale<T, 0, -1>(g.m[0], e, c, g.cm_reg);", s1 = u1 ? "" : "pass_scale<T, 0, -1>(g.m[1], e, c, g.cm_reg);";
+          call = "if ((base >> g.tpos_out) & 1ull) { " + s1 + " } else { " + s0 + " }";
+        } else {
+          call = std::string("const bool one = ") + (g.b0 == kTileOutside ? "((base >> g.tpos_out) & 1ull) != 0" : "((tb >> g.b0) & 1u) != 0") +
+                 "; A f = tile_sel(one, g.m[1], g.m[0]); " + guard + "pass_scale<T, 0, -1>(f, e, c, g.cm_reg);";
+        }
+      } else if (g.kind == 0) {
+        const int J = jof(g.b0);
+        call = g.cm_lane ? "pass_dense_lane<T, " + N(J) + ">(g, e, c, g.cm_reg, (tb & g.cm_lane) == g.cm_lane);"
+                         : "pass_dense<T, " + N(J) + ">(g, e, c, g.cm_reg);";
+      } else if (g.kind == 2) {
+        call = "pass_swap<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ">(e, c, g.cm_reg, " + lane_args + ");";
+      } else if (g.kind == 3) {
+        call = matrix(16) + "pass_dense2<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
+      } else if (g.kind == 4) {
+        call = matrix(64) + "pass_dense3w<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ", " + N(jof(g.tpos_out)) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
+      }
+      if (g.omask) L("      if ((base & g.omask) == g.omask) { " + call + " }");
+      else L("      { " + call + " }");
+      L("      __builtin_amdgcn_sched_barrier(0);");
+      L("    }");
+    }
+    L("  }");
+  }
+  const std::string el = "e" + N(plan.passes.size() - 1);
+  for (int u = 0; u < 32; ++u) L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, " + el + "[" + N(u) + "]);");
+  L("}");
+  return o;
+}
+
 // Look the segment's kernel up (compile it on a miss) and — unless `launch` is null (compile-only pass before a graph capture)
 // — launch it, all under the cache's mutex: between "here is the function" and "it is enqueued" no other thread may evict and
 // unload it.  (Launches are asynchronous: the critical section is microseconds on a hit.)  Nothing is evicted while this
@@ -814,6 +1024,37 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   return QIP_OK;
 }
 
+// a multi-gate step of a wide plan (option "tile_wide"): always its own run-time-compiled kernel
+template <typename T>
+static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high_in) {
+  WidePlan<T> plan;
+  QCHK(build_wide_segment<T>(s->n, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1));
+  const Ins ins = tile_ins(plan.high, plan.p5);
+  const bool fma = s->tile_fma && s->tile >= 2;
+  const bool parametrised = s->tile_jit != 3;
+  std::vector<T> params;
+  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr);
+  if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
+  QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss before the timed region starts
+  if (s->jit_prepare) return QIP_OK;
+  if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
+  ProfRec rec;
+  rec.cls = KC_TILE_GATES;
+  if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
+  void* st_ptr = s->cur;
+  uint64_t ntiles = 1ull << (s->n - (uint32_t)kWideBits);
+  void* params_ptr = s->arena;
+  void* args[] = {&st_ptr, &ntiles, &params_ptr};
+  const dim3 grid = grid2d(ntiles, 1);
+  const size_t lds = 2 * (sizeof(amp_t<T>) << kTileBits);  // the transposition buffer: two quarters of the tile
+  QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
+    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, 256, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+    return QIP_OK;
+  }));
+  if (s->profile) QCHK(prof_end(s, &rec));
+  return QIP_OK;
+}
+
 template <typename T>
 int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg_bytes) {
   *done = false;
@@ -902,11 +1143,19 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     if (st.ops.size() < 2 || !st.perm.empty()) continue;
     std::vector<const TileItem*> seg;
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
-    TileSegmentPlan<T> plan;
-    QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
-    Ins ins = tile_ins(plan.high, plan.p5);
     std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
-    const std::string src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
+    std::string src;
+    if ((mode & 16) && n > (uint32_t)kWideBits) {  // mode bit 4: wide tiles
+      WidePlan<T> wplan;
+      QCHK(build_wide_segment<T>(n, seg, st.high, &wplan, mode & 3));
+      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr);
+      if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
+    } else {
+      TileSegmentPlan<T> plan;
+      QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
+      Ins ins = tile_ins(plan.high, plan.p5);
+      src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
+    }
     std::vector<char> code;
     {
       std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -935,8 +1184,12 @@ extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, 
 
 extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
+static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
+  return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits && !s->capture_staging && !s->jit_prepare;
+}
 static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
-  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel == 2 ? 8 : 0);  // (3 = persistent layout)
+  return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel == 2 ? 8 : 0) |  // (3 = persistent layout)
+         (tile_wide_of(s) ? 16 : 0);
 }
 
 template <typename T>
@@ -965,7 +1218,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
       if (!s->layout.empty()) return fail(QIP_ERR_DEVICE, "no room for the second buffer a relabelled state needs");
       sc = TileSchedule();
       // (without relabelling: such a plan neither permutes nor leaves a layout behind)
-      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s) & 3, s->tile_passes != 0, &sc, /*allow_permute=*/false));
+      QCHK(make_tile_schedule(s->dtype, s->n, ops_in, count, tile_mode_of(s) & (3 | 16), s->tile_passes != 0, &sc, /*allow_permute=*/false));
     }
   }
   const qip_op* ops = sc.circuit;
@@ -980,6 +1233,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   bool moves_qubits = !sc.init_phys.empty() || sc.inserted > 0 || sc.absorbed > 0;
   for (const TileStep& st : sc.steps) moves_qubits = moves_qubits || !st.perm.empty();
   s->layout.clear();
+  const bool wide = (tile_mode_of(s) & 16) != 0;
   auto run_steps = [&]() -> int {
     size_t step_no = 0;
     for (const TileStep& st : sc.steps) {
@@ -995,7 +1249,8 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
       }
       std::vector<const TileItem*> seg;
       for (uint64_t i : st.ops) seg.push_back(&items[i]);
-      QCHK(launch_tile_segment<T>(s, seg, st.high));
+      if (wide) QCHK(launch_wide_segment<T>(s, seg, st.high));
+      else QCHK(launch_tile_segment<T>(s, seg, st.high));
     }
     return QIP_OK;
   };

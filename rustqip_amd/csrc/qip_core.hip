@@ -521,6 +521,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
   else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
   else if (!strcmp(key, "tile_merge")) s->tile_merge = value;
+  else if (!strcmp(key, "tile_wide")) s->tile_wide = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

@@ -173,6 +173,7 @@ struct qip_hip_state {
                             // cached), its numbers are kernel data (angles can change without recompiling); 3 = numbers as literals
   int64_t tile_fma = 0;     // run-time-compiled segments of tile = 2: products may fuse into sums (1e-12 bar, not IEEE equality)
   int64_t tile_merge = 0;   // ... and runs of diagonal gates are applied as products of their factors
+  int64_t tile_wide = 0;    // r4: run-time-compiled segments over a 13-bit register-resident tile (seven free positions per sweep)
   int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request

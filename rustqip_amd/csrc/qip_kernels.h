@@ -1383,13 +1383,13 @@ __device__ __forceinline__ amp_t<T> tile_row(amp_t<T> ma, amp_t<T> mb, bool has_
 // dense 1-qubit gate on pass bit J: four register butterflies.  c[i] = the pass-bit part of element i's tile
 // index (wave-uniform), cm = the gate's controls that sit on pass bits.  The common shapes (no control on a pass
 // bit, all four entries non-zero) run as straight-line code; every test below is wave-uniform.
-template <typename T, int J, bool REAL, bool CHECKED>
-__device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+template <typename T, int J, bool REAL, bool CHECKED, int NE>
+__device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm) {
   using A = amp_t<T>;
   const bool h0 = CHECKED ? (g.nz & 1u) != 0 : true, h1 = CHECKED ? (g.nz & 2u) != 0 : true;
   const bool h2 = CHECKED ? (g.nz & 4u) != 0 : true, h3 = CHECKED ? (g.nz & 8u) != 0 : true;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NE; ++i) {
     if ((i >> J) & 1) continue;
     const int k = i | (1 << J);
     if constexpr (CHECKED) {
@@ -1403,13 +1403,13 @@ __device__ __forceinline__ void pass_dense_body(const TileGate<T>& g, amp_t<T> (
   }
 }
 
-template <typename T, int J>
-__device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+template <typename T, int J, int NE>
+__device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm) {
   using A = amp_t<T>;
   const bool is_x = (g.b1 & 2u) != 0, real = (g.b1 & 1u) != 0;
   if (is_x) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NE; ++i) {
       if ((i >> J) & 1) continue;
       const int k = i | (1 << J);
       if ((c[i] & cm) != cm) continue;
@@ -1421,23 +1421,23 @@ __device__ __forceinline__ void pass_dense(const TileGate<T>& g, amp_t<T> (&e)[8
     return;
   }
   if (cm == 0u && g.nz == 15u) {
-    if (real) pass_dense_body<T, J, true, false>(g, e, c, cm);
-    else pass_dense_body<T, J, false, false>(g, e, c, cm);
+    if (real) pass_dense_body<T, J, true, false, NE>(g, e, c, cm);
+    else pass_dense_body<T, J, false, false, NE>(g, e, c, cm);
   } else {
-    if (real) pass_dense_body<T, J, true, true>(g, e, c, cm);
-    else pass_dense_body<T, J, false, true>(g, e, c, cm);
+    if (real) pass_dense_body<T, J, true, true, NE>(g, e, c, cm);
+    else pass_dense_body<T, J, false, true, NE>(g, e, c, cm);
   }
 }
 
 // Rare shape: a dense gate that still has controls on LANE bits (more controls than a pass holds).  One generic
 // form, selected per lane — compactness over speed.
-template <typename T, int J>
-__device__ __forceinline__ void pass_dense_lane(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+template <typename T, int J, int NE>
+__device__ __forceinline__ void pass_dense_lane(const TileGate<T>& g, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm,
                                                 bool lane_ok) {
   using A = amp_t<T>;
   const bool h0 = (g.nz & 1u) != 0, h1 = (g.nz & 2u) != 0, h2 = (g.nz & 4u) != 0, h3 = (g.nz & 8u) != 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NE; ++i) {
     if ((i >> J) & 1) continue;
     const int k = i | (1 << J);
     if ((c[i] & cm) != cm) continue;
@@ -1452,16 +1452,16 @@ __device__ __forceinline__ void pass_dense_lane(const TileGate<T>& g, amp_t<T> (
 
 // e[i] <- f * e[i] for the elements whose pass-bit controls are 1 (HALF >= 0: only elements with pass bit J equal
 // to HALF); straight-line when the gate has no control on a pass bit
-template <typename T, int J, int HALF>
-__device__ __forceinline__ void pass_scale(amp_t<T> f, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm) {
+template <typename T, int J, int HALF, int NE>
+__device__ __forceinline__ void pass_scale(amp_t<T> f, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm) {
   if (cm == 0u) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NE; ++i)
       if (HALF < 0 || ((i >> J) & 1) == HALF) e[i] = cmul(f, e[i]);
   } else {
     QIP_KEEP_BRANCH();
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NE; ++i)
       if ((HALF < 0 || ((i >> J) & 1) == HALF) && (c[i] & cm) == cm) {
         QIP_KEEP_BRANCH();
         e[i] = cmul(f, e[i]);
@@ -1472,8 +1472,8 @@ __device__ __forceinline__ void pass_scale(amp_t<T> f, amp_t<T> (&e)[8], const u
 // diagonal 1-qubit gate whose target is pass bit J: the factor of element i is m[(i >> J) & 1], known at
 // compile time; unit factors (wave-uniform test) leave their four elements untouched.  With lane-bit controls
 // the lanes whose controls are 0 multiply by (1, 0) instead: x*1 - y*0 == x for finite amplitudes.
-template <typename T, int J>
-__device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+template <typename T, int J, int NE>
+__device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm,
                                           bool lane_ctl, bool lane_ok) {
   using A = amp_t<T>;
 #pragma unroll
@@ -1486,16 +1486,16 @@ __device__ __forceinline__ void pass_diag(const TileGate<T>& g, amp_t<T> (&e)[8]
       f.x = lane_ok ? f.x : (T)1;
       f.y = lane_ok ? f.y : (T)0;
     }
-    if (half == 0) pass_scale<T, J, 0>(f, e, c, cm);
-    else pass_scale<T, J, 1>(f, e, c, cm);
+    if (half == 0) pass_scale<T, J, 0, NE>(f, e, c, cm);
+    else pass_scale<T, J, 1, NE>(f, e, c, cm);
   }
 }
 
-template <typename T, int J0, int J1>
-__device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm, bool lane_ctl, bool lane_ok) {
+template <typename T, int J0, int J1, int NE>
+__device__ __forceinline__ void pass_swap(amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm, bool lane_ctl, bool lane_ok) {
   using A = amp_t<T>;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NE; ++i) {
     if (!(((i >> J0) & 1) == 1 && ((i >> J1) & 1) == 0)) continue;  // i has (J0,J1) = (1,0); partner (0,1)
     const int k = (i & ~(1 << J0)) | (1 << J1);
     if ((c[i] & cm) != cm) continue;  // controls are never J0/J1, so both elements agree
@@ -1512,17 +1512,16 @@ __device__ __forceinline__ void pass_swap(amp_t<T> (&e)[8], const uint32_t (&c)[
   }
 }
 
-// dense 2-qubit gate on pass bits JA (sub-index MSB) and JB: the lane's eight elements are two quads (the third
-// pass bit JC = 0 / 1); out[r] = sum_c M[r][c] * in[c] with the fold order of k_gate_kq (all 16 products, columns
+// dense 2-qubit gate on pass bits JA (sub-index MSB) and JB: the lane's elements are NE / 4 quads (one per value of the other
+// register bits); out[r] = sum_c M[r][c] * in[c] with the fold order of k_gate_kq (all 16 products, columns
 // ascending), so circuit-order sweeps stay IEEE-equal to the gate-by-gate path.
-template <typename T, int JA, int JB>
-__device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[8], const uint32_t (&c)[8], uint32_t cm,
+template <typename T, int JA, int JB, int NE>
+__device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm,
                                             bool lane_ctl, bool lane_ok) {
   using A = amp_t<T>;
-  constexpr int JC = 3 - JA - JB;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int base = q << JC;
+  for (int base = 0; base < NE; ++base) {
+    if (((base >> JA) & 1) || ((base >> JB) & 1)) continue;  // one quad per value of the OTHER register bits
     if ((c[base] & cm) != cm) continue;  // controls never sit on JA / JB: one test per quad
     QIP_KEEP_BRANCH();
     A x[4];
@@ -1539,24 +1538,37 @@ __device__ __forceinline__ void pass_dense2(const amp_t<T>* __restrict__ M, amp_
   }
 }
 
-// dense 3-qubit gate on the pass's three bits: the lane's eight elements ARE one group; out[r] = sum_c M[r][c] * in[c]
-// with the fold order of k_gate_kq (all 64 products, columns ascending), so circuit-order sweeps stay IEEE-equal to the
-// gate-by-gate path.  Controls can only sit on lane bits or outside the tile (the pass bits are the targets).
+// dense 3-qubit gate on three register bits: the lane's elements are NE / 8 groups (one with the product's three-bit passes);
+// out[r] = sum_c M[r][c] * in[c] with the fold order of k_gate_kq (all 64 products, columns ascending), so circuit-order sweeps
+// stay IEEE-equal to the gate-by-gate path.  `c` / `cm`: controls on the OTHER register bits (wide tiles only; a three-bit
+// pass has none: its bits are the targets).
+template <typename T, int JA, int JB, int JC, int NE>
+__device__ __forceinline__ void pass_dense3w(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[NE], const uint32_t (&c)[NE], uint32_t cm,
+                                             bool lane_ctl, bool lane_ok) {
+  using A = amp_t<T>;
+#pragma unroll
+  for (int base = 0; base < NE; ++base) {
+    if (((base >> JA) & 1) || ((base >> JB) & 1) || ((base >> JC) & 1)) continue;
+    if ((c[base] & cm) != cm) continue;
+    QIP_KEEP_BRANCH();
+    A x[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = e[base | (((s >> 2) & 1) << JA) | (((s >> 1) & 1) << JB) | ((s & 1) << JC)];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      A acc = cmul(M[r * 8], x[0]);
+#pragma unroll
+      for (int s = 1; s < 8; ++s) acc = cadd(acc, cmul(M[r * 8 + s], x[s]));
+      const int i = base | (((r >> 2) & 1) << JA) | (((r >> 1) & 1) << JB) | ((r & 1) << JC);
+      e[i] = lane_ctl ? tile_sel(lane_ok, acc, x[r]) : acc;
+      __builtin_amdgcn_sched_barrier(0);  // one output row at a time: interleaving rows only costs registers
+    }
+  }
+}
 template <typename T, int JA, int JB, int JC>
 __device__ __forceinline__ void pass_dense3(const amp_t<T>* __restrict__ M, amp_t<T> (&e)[8], bool lane_ctl, bool lane_ok) {
-  using A = amp_t<T>;
-  A x[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) x[s] = e[(((s >> 2) & 1) << JA) | (((s >> 1) & 1) << JB) | ((s & 1) << JC)];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    A acc = cmul(M[r * 8], x[0]);
-#pragma unroll
-    for (int s = 1; s < 8; ++s) acc = cadd(acc, cmul(M[r * 8 + s], x[s]));
-    const int i = (((r >> 2) & 1) << JA) | (((r >> 1) & 1) << JB) | ((r & 1) << JC);
-    e[i] = lane_ctl ? tile_sel(lane_ok, acc, x[r]) : acc;
-    __builtin_amdgcn_sched_barrier(0);  // one output row at a time: interleaving rows only costs registers
-  }
+  const uint32_t c0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  pass_dense3w<T, JA, JB, JC, 8>(M, e, c0, 0u, lane_ctl, lane_ok);
 }
 
 // __launch_bounds__(kBlock, 5): five waves per SIMD = the five 32-KiB tiles that fit a CU's LDS.  The sweep is

@@ -76,6 +76,31 @@ static inline uint64_t tile_low_mask(uint32_t p5) { return 31ull | (1ull << p5);
 // the Ins a tile kernel takes: the high positions opened in the space where p5 and 5 have traded places
 Ins tile_ins(const std::vector<uint32_t>& high, uint32_t p5);
 
+// ---- wide tiles (r4, option "tile_wide"): 2^13 amplitudes per block held in REGISTERS (32 per lane = five register bits),
+// seven free positions per sweep; LDS is a 32-KiB transposition buffer.  Run-time-compiled segments only.
+constexpr int kWideHigh = 7;
+constexpr int kWideBits = kTileLow + kWideHigh;  // 13
+constexpr int kWideRegBits = 5;
+struct WidePass {
+  uint32_t R[kWideRegBits];  // tile bit held by register-index bit j
+  uint32_t L[8];             // tile bit filled by thread-id bit k
+  bool transposed = false;   // the arrangement differs from the previous pass's: the tile goes through LDS in four quarters
+  uint32_t q[2] = {0, 0};    // the two tile bits (register bits before AND after) that select the quarter
+  uint32_t bufpos[kWideBits] = {0};  // tile bit -> bit of the buffer index (the 11 bits that are not quarter bits)
+  uint32_t first = 0, count = 0;     // gates[first .. first + count)
+};
+template <typename T> struct WidePlan {
+  std::vector<uint32_t> high;  // amplitude-index position of tile bit 6 + j (7 of them; high[0], high[1] = the wave bits at load / store)
+  uint32_t p5 = 5;
+  std::vector<TileGate<T>> gates;  // b0 / b1 / tpos_out / cmask in the 13-bit tile-index space; op, cm_reg, cm_lane unused
+  std::vector<amp_t<T>> mats;
+  std::vector<WidePass> passes;    // passes.back() may hold no gate: the way back to the load arrangement
+  std::vector<uint32_t> order;
+};
+extern thread_local int t_tile_high;  // free positions per segment the scheduler plans for (kTileHigh, or kWideHigh in wide mode)
+template <typename T>
+int build_wide_segment(uint32_t n, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, WidePlan<T>* out, int order_rule = 0);
+
 int classify_tile_item(int dtype, uint32_t n, const qip_op* op, TileItem* it);
 template <typename T>
 int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high, TileSegmentPlan<T>* out,

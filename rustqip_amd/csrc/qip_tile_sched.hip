@@ -513,6 +513,340 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
 
 
 // ---------------------------------------------------------------------------------------
+// Wide tiles (r4): the plan of one segment for the register-resident 13-bit tile (qip_tile.h WidePlan).  Tile bits 0..5 = the
+// rows (positions 0..4 and p5), 6..12 = the seven high positions.  At load / store time the thread id fills tile bits 0..7
+// (rows, then the two wave positions) and a lane's 32 accesses walk tile bits 8..12: that is arrangement 0, and gates on
+// those five bits need no LDS traffic at all.  Any other gate needs its exchange bits among the five register bits: the tile
+// is TRANSPOSED through the 32-KiB LDS buffer in four quarters — the quarter is selected by two tile bits that are register
+// bits before and after, so a transposition brings in up to three new register bits and keeps at least two.  The last
+// transposition(s) lead back to arrangement 0.  Gates keep the order they are given in.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+int build_wide_segment(uint32_t n, const std::vector<const TileItem*>& seg_in, std::vector<uint32_t> high, WidePlan<T>* out, int order_rule) {
+  std::vector<const TileItem*> seg = seg_in;
+  const uint32_t p5 = tile_p5_of<T>(n);
+  out->p5 = p5;
+  if (n < (uint32_t)kWideBits) return fail(QIP_ERR_UNSUPPORTED, "wide tiles need n >= %d", kWideBits);
+  const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, n > (uint32_t)kWideBits ? n - 7 : 5u);
+  for (uint32_t p = std::max<uint32_t>(pad_from, 5u); high.size() < (size_t)kWideHigh && p < n; ++p)
+    if (!tile_is_low(p, p5) && std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+  for (uint32_t p = 5; high.size() < (size_t)kWideHigh && p < n; ++p)
+    if (!tile_is_low(p, p5) && std::find(high.begin(), high.end(), p) == high.end()) high.push_back(p);
+  if (high.size() != (size_t)kWideHigh) return fail(QIP_ERR_UNSUPPORTED, "a wide segment with %zu high positions", high.size());
+  // the two positions that are exchange targets least often become the wave bits (tile bits 6, 7): the five others are
+  // register bits from the start
+  std::vector<uint32_t> uses(64, 0);
+  for (const TileItem* it : seg) {
+    if (it->kind == 0) uses[it->t0] += 1;
+    if (it->kind >= 2) {
+      uses[it->t0] += 1;
+      uses[it->t1] += 1;
+    }
+    if (it->kind == 4) uses[it->t2] += 1;
+  }
+  std::sort(high.begin(), high.end());
+  std::stable_sort(high.begin(), high.end(), [&](uint32_t a, uint32_t b) { return uses[a] < uses[b]; });
+  std::sort(high.begin(), high.begin() + 2);
+  std::sort(high.begin() + 2, high.end());
+  out->high = high;
+  auto tile_bit = [&](uint32_t pos) -> uint32_t {
+    if (tile_is_low(pos, p5)) return tile_low_bit(pos);
+    const auto f = std::find(high.begin(), high.end(), pos);
+    return f == high.end() ? kTileOutside : kTileLow + (uint32_t)(f - high.begin());
+  };
+  typedef std::vector<uint32_t> Bits;
+  auto has = [](const Bits& v, uint32_t b) { return std::find(v.begin(), v.end(), b) != v.end(); };
+  const Bits load_bits = {8, 9, 10, 11, 12};
+  auto item_exch = [&](const TileItem& it) {
+    Bits e;
+    if (it.kind == 0) e = {tile_bit(it.t0)};
+    if (it.kind == 2 || it.kind == 3) e = {tile_bit(it.t0), tile_bit(it.t1)};
+    if (it.kind == 4) e = {tile_bit(it.t0), tile_bit(it.t1), tile_bit(it.t2)};
+    return e;
+  };
+  // The register sets a given gate order leads to.  At a gate whose exchange bits are not all register bits the tile is
+  // transposed: the new bits of that gate and of the gates behind it join while three new bits and five in all suffice; the
+  // slots left keep the old register bits whose next use (in this order) comes soonest (Belady).  Returns the sets, one per
+  // pass, the first gate of each, and (by size) the number of transpositions including the way back to the load set.
+  struct Arr {
+    Bits R;
+    size_t first;
+  };
+  auto arrangements = [&](const std::vector<const TileItem*>& sq) {
+    std::vector<Bits> ex(sq.size());
+    for (size_t i = 0; i < sq.size(); ++i) ex[i] = item_exch(*sq[i]);
+    std::vector<Arr> arr;
+    arr.push_back({load_bits, 0});
+    for (size_t gi = 0; gi < sq.size(); ++gi) {
+      const Bits& R = arr.back().R;
+      bool fits = true;
+      for (uint32_t t : ex[gi]) fits = fits && has(R, t);
+      if (fits) continue;
+      Bits N, K;
+      for (uint32_t t : ex[gi]) (has(R, t) ? K : N).push_back(t);
+      for (size_t gj = gi + 1; gj < sq.size(); ++gj) {
+        Bits n2 = N, k2 = K;
+        for (uint32_t t : ex[gj]) {
+          if (has(n2, t) || has(k2, t)) continue;
+          (has(R, t) ? k2 : n2).push_back(t);
+        }
+        if (n2.size() > 3 || n2.size() + k2.size() > (size_t)kWideRegBits) break;
+        N = n2;
+        K = k2;
+      }
+      Bits newR = N;
+      for (uint32_t t : K) newR.push_back(t);
+      std::vector<std::pair<size_t, uint32_t>> rest;  // (next use, bit) of the old register bits not yet kept
+      for (uint32_t t : R) {
+        if (has(newR, t)) continue;
+        size_t nu = sq.size() + (has(load_bits, t) ? 0 : 1);  // (never used again: prefer the load set's bits, the way back is shorter)
+        for (size_t gj = gi + 1; gj < sq.size(); ++gj)
+          if (has(ex[gj], t)) {
+            nu = gj;
+            break;
+          }
+        rest.push_back({nu, t});
+      }
+      std::sort(rest.begin(), rest.end());
+      for (const auto& r : rest)
+        if (newR.size() < (size_t)kWideRegBits) newR.push_back(r.second);
+      arr.push_back({newR, gi});
+    }
+    if (arr.size() > 1) {
+      for (int hop = 0; hop < 3; ++hop) {
+        const Bits& R = arr.back().R;
+        size_t common = 0;
+        for (uint32_t t : load_bits) common += has(R, t);
+        if (common >= 2) {
+          arr.push_back({load_bits, sq.size()});
+          break;
+        }
+        Bits mid;
+        for (uint32_t t : R)
+          if (mid.size() < 2) mid.push_back(t);
+        for (uint32_t t : load_bits)
+          if (mid.size() < (size_t)kWideRegBits && !has(mid, t)) mid.push_back(t);
+        arr.push_back({mid, sq.size()});
+      }
+    }
+    return arr;
+  };
+  // The order of the gates inside the segment (order_rule 1 / 2 = the "tile" option, as in build_tile_segment): list scheduling
+  // over the scheduler's own commutation relation — two gates commute when on every shared bit both only test it; tile = 1
+  // additionally needs one of the two rounding-free, which keeps every amplitude's sequence of rounded operations — emits
+  // every ready gate that fits the register set before it transposes, and transposes for the ready gate that needs the
+  // fewest new bits.  Adopted only where it saves transpositions.
+  if (order_rule >= 1 && g_tile_sched != 0 && seg.size() >= 3 && seg.size() <= 256) {
+    const size_t NG = seg.size();
+    typedef std::array<uint64_t, 4> Set;
+    auto sget = [](const Set& m, size_t j) { return (m[j >> 6] >> (j & 63)) & 1ull; };
+    auto sput = [](Set& m, size_t j) { m[j >> 6] |= 1ull << (j & 63); };
+    std::vector<Set> preds(NG, Set{0, 0, 0, 0});
+    for (size_t j = 0; j < NG; ++j)
+      for (size_t i = 0; i < j; ++i) {
+        const TileItem &a = *seg[i], &b = *seg[j];
+        const bool commute = !(b.nd_mask & (a.nd_mask | a.d_mask)) && !(b.d_mask & a.nd_mask);
+        if (!commute || (order_rule < 2 && !a.exact && !b.exact)) sput(preds[j], i);
+      }
+    std::vector<Bits> ex(NG);
+    for (size_t i = 0; i < NG; ++i) ex[i] = item_exch(*seg[i]);
+    Set placed{0, 0, 0, 0};
+    auto ready = [&](size_t j) {
+      if (sget(placed, j)) return false;
+      for (int w = 0; w < 4; ++w)
+        if (preds[j][w] & ~placed[w]) return false;
+      return true;
+    };
+    std::vector<size_t> ord;
+    Bits R = load_bits;
+    while (ord.size() < NG) {
+      bool progressed = false;
+      for (size_t j = 0; j < NG; ++j) {
+        if (!ready(j)) continue;
+        bool fits = true;
+        for (uint32_t t : ex[j]) fits = fits && has(R, t);
+        if (fits) {
+          sput(placed, j);
+          ord.push_back(j);
+          progressed = true;
+        }
+      }
+      if (progressed) continue;
+      size_t pick = NG, pick_new = 9;
+      for (size_t j = 0; j < NG; ++j) {
+        if (!ready(j)) continue;
+        size_t nb = 0;
+        for (uint32_t t : ex[j]) nb += !has(R, t);
+        if (nb < pick_new) {
+          pick = j;
+          pick_new = nb;
+        }
+      }
+      if (pick == NG) break;  // (cannot happen: the earliest unplaced gate is always ready)
+      Bits N, K;
+      for (uint32_t t : ex[pick]) (has(R, t) ? K : N).push_back(t);
+      for (size_t j = 0; j < NG; ++j) {  // other ready gates whose bits still fit join the new set
+        if (!ready(j) || j == pick) continue;
+        Bits n2 = N, k2 = K;
+        for (uint32_t t : ex[j]) {
+          if (has(n2, t) || has(k2, t)) continue;
+          (has(R, t) ? k2 : n2).push_back(t);
+        }
+        if (n2.size() > 3 || n2.size() + k2.size() > (size_t)kWideRegBits) continue;
+        N = n2;
+        K = k2;
+      }
+      Bits newR = N;
+      for (uint32_t t : K) newR.push_back(t);
+      std::vector<std::pair<size_t, uint32_t>> rest;
+      for (uint32_t t : R) {
+        if (has(newR, t)) continue;
+        size_t nu = NG + (has(load_bits, t) ? 0 : 1);
+        for (size_t j = 0; j < NG; ++j)
+          if (!sget(placed, j) && has(ex[j], t)) {
+            nu = j;
+            break;
+          }
+        rest.push_back({nu, t});
+      }
+      std::sort(rest.begin(), rest.end());
+      for (const auto& r : rest)
+        if (newR.size() < (size_t)kWideRegBits) newR.push_back(r.second);
+      R = newR;
+    }
+    if (ord.size() == NG) {
+      std::vector<const TileItem*> sq(NG);
+      for (size_t k = 0; k < NG; ++k) sq[k] = seg[ord[k]];
+      if (arrangements(sq).size() < arrangements(seg).size()) seg = sq;
+    }
+  }
+  const std::vector<Arr> arr = arrangements(seg);
+  std::vector<TileGate<T>>& gates = out->gates;
+  std::vector<amp_t<T>>& mats = out->mats;
+  gates.assign(seg.size(), TileGate<T>());
+  mats.clear();
+  out->order.resize(seg.size());
+  for (size_t i = 0; i < seg.size(); ++i) {
+    out->order[i] = (uint32_t)(std::find(seg_in.begin(), seg_in.end(), seg[i]) - seg_in.begin());
+    const TileItem& it = *seg[i];
+    TileGate<T>& g = gates[i];
+    memset(&g, 0, sizeof g);
+    g.kind = (uint32_t)it.kind;
+    g.b0 = tile_bit(it.t0);
+    g.b1 = it.kind >= 2 ? tile_bit(it.t1) : 0;
+    if (it.kind == 3 || it.kind == 4) {
+      g.nz = (uint32_t)(mats.size() / 16);
+      const int cnt = it.kind == 3 ? 16 : 64;
+      for (int e = 0; e < cnt; ++e) mats.push_back(mk<T>(it.mat[2 * e], it.mat[2 * e + 1]));
+    }
+    if (it.kind == 4) g.tpos_out = tile_bit(it.t2);
+    if (it.kind == 1 && g.b0 == kTileOutside) g.tpos_out = it.t0;
+    for (uint32_t c : it.cpos) {
+      const uint32_t tb = tile_bit(c);
+      if (tb == kTileOutside) g.omask |= 1ull << c;
+      else g.cmask |= 1u << tb;
+    }
+    if (it.kind != 3 && it.kind != 4) g.nz = it.nz;
+    if (it.kind == 0) {
+      for (int e = 0; e < 4; ++e) g.m[e] = mk<T>(it.m[2 * e], it.m[2 * e + 1]);
+      const bool real = it.m[1] == 0 && it.m[3] == 0 && it.m[5] == 0 && it.m[7] == 0;
+      const bool is_x = it.nz == 6u && it.m[2] == 1 && it.m[3] == 0 && it.m[4] == 1 && it.m[5] == 0;
+      g.b1 = (real ? 1u : 0u) | (is_x ? 2u : 0u);
+    } else if (it.kind == 1) {
+      g.m[0] = mk<T>(it.m[0], it.m[1]);
+      g.m[1] = mk<T>(it.m[2], it.m[3]);
+    }
+    if ((it.kind != 1 && g.b0 == kTileOutside) || (it.kind >= 2 && g.b1 == kTileOutside) || (it.kind == 4 && g.tpos_out == kTileOutside))
+      return fail(QIP_ERR_INVALID, "internal: an exchange target outside the wide tile");
+  }
+  // LDS layout of one transposition (see WidePass::bufpos): thread-id bits 0..3 of the writing arrangement land on buffer bits
+  // 0..3, those of the reading arrangement on buffer bits of pairwise distinct class (bit mod 4, below 8) — with the slot
+  // swizzle (tile_slot: bits 4..7 folded onto 0..3) the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte slots
+  auto layout = [&](const WidePass& a, WidePass* b) {
+    int bp[kWideBits];
+    bool used[11] = {false};
+    for (int t = 0; t < kWideBits; ++t) bp[t] = -1;
+    for (int k = 0; k < 4; ++k) {
+      bp[a.L[k]] = k;
+      used[k] = true;
+    }
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t t = b->L[k];
+      if (bp[t] >= 0) continue;
+      bool cls_taken[4] = {false, false, false, false};
+      for (int k2 = 0; k2 < 4; ++k2)
+        if (bp[b->L[k2]] >= 0 && bp[b->L[k2]] < 8) cls_taken[bp[b->L[k2]] & 3] = true;
+      for (int c = 0; c < 4 && bp[t] < 0; ++c) {
+        if (cls_taken[c]) continue;
+        for (int cand : {c, c + 4})
+          if (!used[cand]) {
+            bp[t] = cand;
+            used[cand] = true;
+            break;
+          }
+      }
+    }
+    int next = 0;
+    for (int t = 0; t < kWideBits; ++t) {
+      if ((uint32_t)t == b->q[0] || (uint32_t)t == b->q[1] || bp[t] >= 0) continue;
+      while (used[next]) ++next;
+      bp[t] = next;
+      used[next] = true;
+    }
+    for (int t = 0; t < kWideBits; ++t) b->bufpos[t] = bp[t] < 0 ? 0u : (uint32_t)bp[t];
+  };
+  std::vector<WidePass>& passes = out->passes;
+  passes.clear();
+  WidePass load;
+  for (int j = 0; j < kWideRegBits; ++j) load.R[j] = 8 + (uint32_t)j;
+  for (int k = 0; k < 8; ++k) load.L[k] = (uint32_t)k;
+  for (size_t ai = 0; ai < arr.size(); ++ai) {
+    const size_t next_first = ai + 1 < arr.size() ? arr[ai + 1].first : seg.size();
+    WidePass b;
+    if (ai == 0 || (ai + 1 == arr.size() && arr[ai].R == load_bits && arr[ai].first == seg.size())) {
+      b = load;  // the load arrangement: at the start, and as the way back (same register order, same lane map)
+    } else {
+      for (int j = 0; j < kWideRegBits; ++j) b.R[j] = arr[ai].R[j];
+      int k = 0;
+      for (uint32_t t = 0; t < (uint32_t)kWideBits; ++t)
+        if (!has(arr[ai].R, t)) b.L[k++] = t;
+    }
+    b.first = (uint32_t)std::min(arr[ai].first, seg.size());
+    b.count = (uint32_t)(next_first - std::min(arr[ai].first, seg.size()));
+    if (ai == 0) {
+      b.first = 0;
+      b.count = (uint32_t)next_first;
+    } else {
+      const Bits prevR(passes.back().R, passes.back().R + kWideRegBits);
+      Bits common;
+      for (int j = 0; j < kWideRegBits; ++j)
+        if (has(prevR, b.R[j])) common.push_back(b.R[j]);
+      if (common.size() < 2) return fail(QIP_ERR_INVALID, "internal: a wide transposition needs two common register bits");
+      b.transposed = true;
+      b.q[0] = common[0];
+      b.q[1] = common[1];
+      layout(passes.back(), &b);
+    }
+    passes.push_back(b);
+  }
+  if (passes.size() > 1) {
+    const WidePass& last = passes.back();
+    for (int j = 0; j < kWideRegBits; ++j)
+      if (last.R[j] != load.R[j]) return fail(QIP_ERR_INVALID, "internal: the wide plan does not return to the load arrangement");
+    for (int k = 0; k < 8; ++k)
+      if (last.L[k] != load.L[k]) return fail(QIP_ERR_INVALID, "internal: the wide plan does not return to the load lane map");
+  }
+  if (getenv("QIP_WIDE_DEBUG")) {
+    size_t exg = 0;
+    for (const auto& g : gates) exg += g.kind != 1;
+    fprintf(stderr, "[wide] %zu gates (%zu exchanging), %zu transpositions\n", gates.size(), exg, passes.size() - 1);
+  }
+  return QIP_OK;
+}
+template int build_wide_segment<double>(uint32_t, const std::vector<const TileItem*>&, std::vector<uint32_t>, WidePlan<double>*, int);
+template int build_wide_segment<float>(uint32_t, const std::vector<const TileItem*>&, std::vector<uint32_t>, WidePlan<float>*, int);
+
+// ---------------------------------------------------------------------------------------
 // Which five positions should a segment claim?  First come, first served (the scan below claims positions in the order the
 // circuit asks for them) spends them on whatever the next few gates touch.  The gain rule looks at what each position
 // would BUY: starting from the positions the head gate needs, it repeatedly claims the free
@@ -521,6 +855,7 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
 // or no single position adds anything; what is left is claimed first-come as before.  Host arithmetic only, and the
 // schedule's invariants do not depend on it: every gate still joins under the commutation / exactness rules of the scan.
 // ---------------------------------------------------------------------------------------
+thread_local int t_tile_high = kTileHigh;  // make_tile_schedule sets it from the mode (bit 4: wide tiles, kWideHigh)
 static thread_local int t_seg_rule = 0;  // the rule in force for the plan being made (make_tile_schedule tries several)
 struct SegScan {
   const std::vector<TileItem>& L;
@@ -587,7 +922,7 @@ static std::vector<uint32_t> seg_choose_high(const SegScan& c, uint64_t head, co
     }
   }
   double base = seg_dry_run(c, head, phys, H);
-  while (H.size() < (size_t)kTileHigh) {
+  while (H.size() < (size_t)t_tile_high) {
     int best = -1;
     double best_w = base;
     for (uint32_t pp = 5; pp < n; ++pp) {
@@ -658,7 +993,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
         run.perm = next;
         run.ops.push_back(j);
       }
-      if (run.ops.size() >= 2 && __builtin_popcountll(moved & ~tile_low_mask(p5)) > kTileHigh) {
+      if (run.ops.size() >= 2 && __builtin_popcountll(moved & ~tile_low_mask(p5)) > t_tile_high) {
         for (uint64_t i : run.ops) done[i] = 1;
         steps->push_back(run);
         continue;
@@ -704,7 +1039,7 @@ int schedule_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, boo
           if (!tile_is_low(p, p5) && std::find(st.high.begin(), st.high.end(), p) == st.high.end() &&
               std::find(need.begin(), need.end(), p) == need.end())
             need.push_back(p);
-        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
+        fits = st.high.size() + need.size() <= (size_t)t_tile_high;
       }
       if (fits) {
         for (uint32_t p : need) st.high.push_back(p);
@@ -841,7 +1176,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
               std::find(need.begin(), need.end(), pp) == need.end())
             need.push_back(pp);
         }
-        fits = st.high.size() + need.size() <= (size_t)kTileHigh;
+        fits = st.high.size() + need.size() <= (size_t)t_tile_high;
       }
       if (fits) {
         for (uint32_t pp : need) st.high.push_back(pp);
@@ -885,7 +1220,7 @@ int schedule_tiles_relabel(int dtype, uint32_t n, const qip_op* ops, uint64_t co
         if (nxt[p] != ~0ull) by_use.push_back(p);
       std::stable_sort(by_use.begin(), by_use.end(), [&](uint32_t a, uint32_t b) { return nxt[a] < nxt[b]; });
       for (uint32_t p : by_use) {
-        if (st.high.size() >= (size_t)kTileHigh) break;
+        if (st.high.size() >= (size_t)t_tile_high) break;
         if (!in_tile(phys[p])) st.high.push_back(phys[p]);
       }
       std::vector<uint32_t> tile_log;
@@ -959,8 +1294,18 @@ static int make_tile_schedule_rule(int dtype, uint32_t n, const qip_op* ops, uin
 // diagonal gates), shortest kept: host arithmetic, microseconds per gate, against ~6 ms per sweep saved at n = 30.  Below
 // n = 24 a sweep costs less than the search: first come only.  Global option "tile_sched": 0 = first come only (and the
 // circuit's own gate order inside every segment), 1 = default, 2 = search at every size and in every mode (tests).
+static int make_tile_schedule_inner(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                                    bool allow_permute);
 int make_tile_schedule(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
                        bool allow_permute) {
+  // mode bit 4: wide tiles (seven free positions per segment; a state of at least kWideBits + 1 qubits)
+  t_tile_high = ((mode & 16) && n > (uint32_t)kWideBits) ? kWideHigh : kTileHigh;
+  const int rc = make_tile_schedule_inner(dtype, n, ops, count, mode, allow_2q, out, allow_permute);
+  t_tile_high = kTileHigh;
+  return rc;
+}
+static int make_tile_schedule_inner(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, bool allow_2q, TileSchedule* out,
+                                    bool allow_permute) {
   // (only where gates may be reordered freely, tile = 2: in the IEEE-equal mode the sweeps are bound by f64 issue, a plan with
   // fewer, heavier sweeps is not faster there — Grover 15 -> 14 sweeps measured 2 % slower — and first come stays)
   const bool search = g_tile_sched != 0 && (n >= 24 || g_tile_sched == 2) && count >= 8 && ((mode & 3) >= 2 || g_tile_sched == 2);  // (2 = always: tests)

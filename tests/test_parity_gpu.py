@@ -1993,6 +1993,14 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
         assert r["steps"] <= 3  # chunks as large as the timed segments (5-6 H and their controlled phases each)
         leg(circuits.c4_clifford_t(n, 48, seed=32), True, tile=1, tile_jit=1)
         leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
+        # r4: wide tiles (13-bit register-resident tile, seven free positions per sweep): IEEE-equal in circuit order, also
+        # with the qubits relabelled; the 1e-12 mode with commuting reorder
+        c2w = circuits.c2_random_circuit(n, 3 * 40, seed=33)
+        leg(c2w[:40], True, tile=1, tile_jit=1, tile_wide=1)
+        leg(c2w[40:80], True, tile=1, tile_jit=1, tile_wide=1, tile_relabel=2)
+        leg(c2w[80:120], False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c4_clifford_t(n, 48, seed=34), True, tile=1, tile_jit=1, tile_wide=1)
+        leg(circuits.c5_grover_iteration(n)[70:140], True, max_len=96, tile=1, tile_jit=1, tile_wide=1)
         twin.close()
         assert abs(st.norm_sqr() - 1) < 1e-9
 
@@ -2433,3 +2441,45 @@ def test_one_op_tile_sweeps_controlled_dense_and_both_row_shapes(O, row_split):
             assert np.max(np.abs(got - want)) <= TOL32, (name, op.indices)
     finally:
         q.set_global_option("tile_row_split", 11)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
+    """r4, option tile_wide: run-time-compiled segments over a 13-bit tile held in registers (32 amplitudes per lane, seven free
+    positions per sweep, LDS as a transposition buffer).  Same helpers and gate order as the 11-bit sweeps: tile = 1 is
+    IEEE-equal to them (and so to the gate-by-gate path and the oracle); tile = 2 and the relabelled plans to the 1e-12 bar.
+    Circuits with every item kind: single-qubit gates, CNOTs, multi-controlled gates with controls in rows / above / on register
+    bits, diagonal gates on every kind of bit, swaps, dense 2- and 3-qubit gates."""
+    n = 18
+    f64 = dtype == np.complex128
+    tol = TOL64 if f64 else TOL32
+    rng = np.random.default_rng(18)
+    u2, u3 = rand_unitary(2, rng), rand_unitary(3, rng)
+    x = rand_state(n, 5, dtype)
+    extra = []
+    for _ in range(10):
+        qs = [int(v) for v in rng.permutation(n)]
+        extra += [q.make_matrix_op(qs[:2], u2.ravel()), q.make_control_op(qs[2:4], q.make_matrix_op([qs[4]], circuits.H)),
+                  q.make_matrix_op(qs[5:8], u3.ravel()), q.make_swap_op([qs[8]], [qs[9]]),
+                  q.make_control_op([qs[10]], q.make_matrix_op([qs[11]], [1, 0, 0, cmath.rect(1, 0.3)])),
+                  q.make_control_op([qs[12]], q.make_matrix_op(qs[13:15], u2.ravel())), q.make_matrix_op([qs[15]], circuits.rz(0.7))]
+    cases = {"c2": circuits.h_layer(n) + circuits.c2_random_circuit(n, 200, seed=28),
+             "c4": circuits.c4_clifford_t(n, 160, seed=32),
+             "qft": circuits.c3_qft(n),
+             "grover_k3": circuits.c5_grover_iteration(n, dense_k3=True),
+             "mixed_items": circuits.c2_random_circuit(n, 40, seed=3) + extra}
+    for name, ops in cases.items():
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        for tile, relabel in ((1, 0), (1, 2), (2, 0), (2, 1)):
+            res = {}
+            for wide in (0, 1):
+                with q.HipState(n, dtype) as st:
+                    for k, v in (("tile", tile), ("tile_jit", 1), ("tile_relabel", relabel), ("tile_wide", wide), ("profile", 1)):
+                        st.set_option(k, v)
+                    st.upload(x)
+                    st.apply_ops(ops)
+                    res[wide] = (st.download(), sum(v["launches"] for v in st.profile().values()))
+            assert float(np.max(np.abs(res[1][0] - want))) <= tol, (name, tile, relabel)
+            if tile == 1 and relabel == 0 and f64 and name != "grover_k3":
+                assert np.array_equal(res[1][0], res[0][0]), (name, "wide and narrow circuit-order sweeps differ")
+            assert res[1][1] <= res[0][1], (name, tile, relabel, res[0][1], res[1][1])  # never more sweeps than the narrow plan

@@ -478,3 +478,34 @@ def test_tile_1_plans_only_reorder_what_commutes_exactly(name, mode, sched):
     assert np.array_equal(got.view(np.float64), want.view(np.float64)) or np.array_equal(got, want)
     if sched == 2 and name in ("c2", "fuzz17"):
         assert moved > 0  # the reordering really happened
+
+
+def test_wide_tile_segments_plan_and_compile_without_a_gpu():
+    """r4, option tile_wide (mode bit 4 of the host hooks): segments over a 13-bit register-resident tile claim seven free
+    positions — fewer sweeps for the same circuit, every op still in exactly one step — and their generated source (32-element
+    register arrays, LDS transpositions in four quarters) compiles with hiprtc for gfx950 without a device, also in the
+    parametrised form and with contraction allowed.  (What the compiled kernels compute is checked on the GPU against the
+    narrow sweeps bit for bit and against the oracle: tests/test_parity_gpu.py::test_wide_tiles_...)"""
+    from rustqip_amd.ops import debug_tile_jit, plan_tiles
+
+    n = 30
+    for ops, narrow_max, wide_max in ((circuits.c2_random_circuit(n, 256, seed=28), 18, 13), (circuits.c4_clifford_t(n, 256, seed=32), 15, 11),
+                                      (circuits.c5_grover_iteration(n), 15, 11)):
+        a, b = plan_tiles(n, ops, 1), plan_tiles(n, ops, 1 | 16)
+        assert len(a) <= narrow_max and len(b) <= wide_max, (len(a), len(b))
+        assert sorted(i for st in b for i in st) == list(range(len(ops)))
+    assert len(plan_tiles(n, circuits.c2_random_circuit(n, 256, seed=28), 1 | 4 | 16)) <= 10
+    n = 16
+    rng = np.random.default_rng(4)
+    u2, u3 = rand_unitary(2, rng), rand_unitary(3, rng)
+    ops = circuits.c2_random_circuit(n, 60, seed=9) + [q.make_matrix_op([3, 12], u2.ravel()), q.make_matrix_op([15, 0, 7], u3.ravel()),
+                                                        q.make_control_op([1, 14], q.make_matrix_op([9], circuits.H)), q.make_swap_op([2], [13])]
+    for mode in (1 | 16, 1 | 16 | 64, 2 | 16 | 32 | 64, 1 | 4 | 8 | 16 | 64):
+        r = debug_tile_jit(n, ops, mode)
+        assert r["segments"] >= 1 and r["code_bytes"] > 0, (mode, r)
+        src = r["first_source"] if isinstance(r["first_source"], str) else r["first_source"].decode()
+        assert "A e0[32];" in src and "__launch_bounds__(256, 2)" in src
+    from rustqip_amd import _ffi
+
+    r = debug_tile_jit(n, ops, 1 | 16 | 64, _ffi.QIP_C32)
+    assert r["segments"] >= 1

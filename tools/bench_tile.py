@@ -61,6 +61,7 @@ def main():
                 st.set_option("tile_relabel", int(os.environ.get("QIP_TILE_RELABEL", "0")) if mode else 0)
                 st.set_option("tile_fma", int(os.environ.get("QIP_TILE_FMA", "0")) if mode else 0)
                 st.set_option("tile_merge", int(os.environ.get("QIP_TILE_MERGE", "0")) if mode else 0)
+                st.set_option("tile_wide", int(os.environ.get("QIP_TILE_WIDE", "0")) if mode else 0)
                 cops = st.compile_ops(ops)
                 st.set_option("profile", 1)
                 st.profile_reset()
@@ -77,13 +78,14 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
                                   "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
-                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"), "fma": os.environ.get("QIP_TILE_FMA", "0"), "merge": os.environ.get("QIP_TILE_MERGE", "0"),
+                                  "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"), "fma": os.environ.get("QIP_TILE_FMA", "0"), "merge": os.environ.get("QIP_TILE_MERGE", "0"), "wide": os.environ.get("QIP_TILE_WIDE", "0"),
                                   "tune": tune, "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
         st.set_option("tile_jit", 0)
         st.set_option("tile_relabel", 0)
         st.set_option("tile_fma", 0)
         st.set_option("tile_merge", 0)
+        st.set_option("tile_wide", 0)
 
 
 if __name__ == "__main__":
