@@ -524,7 +524,6 @@ def main():
         # bytes, never per-gate bytes over sweep time) and LDS-resident multi-gate sweeps
         extras["fused_k5"] = leg(ops_mixed, fuse=5)
         extras["tiled_mode1"] = leg(ops_mixed, tile=1)
-        extras["tiled_mode2"] = leg(ops_mixed, tile=2)
         # the same IEEE-equal sweeps with every segment compiled at run time for that segment (hiprtc; cached): the
         # first application pays the compilation (reported), the timed repetitions replay cached kernels
         import ctypes as _C
@@ -543,18 +542,15 @@ def main():
         # ... with the scheduler relabelling the qubits (soonest-needed qubits on index bits 0..5, one closing bit-permutation
         # sweep; only moves are added: still IEEE-equal), and the reordering mode (1e-12 bar) compiled the same way
         extras["tiled_mode1_jit_relabel"] = leg(ops_mixed, tile=1, tile_jit=1, tile_relabel=1)
-        extras["tiled_mode2_jit"] = leg(ops_mixed, tile=2, tile_jit=1)
-        extras["tiled_mode2_jit_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_relabel=1)
         # r3: multiply-add contraction + merged runs of diagonal gates in the compiled tile = 2 segments (1e-12 bar); tile_jit = 1
         # compiles a segment's structure and takes its numbers as kernel data (tile_jit = 3: numbers as literals, for comparison)
         extras["tiled_mode2_jit_fma_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
-        extras["tiled_mode1_jit_literal_relabel"] = leg(ops_mixed, tile=1, tile_jit=3, tile_relabel=1)  # (tuning aid: numbers as literals)
         # r4: wide tiles — a 13-bit tile held in registers (32 amplitudes per lane), seven free positions per sweep, LDS as a
         # transposition buffer; run-time-compiled segments, IEEE-equal in circuit order like the 11-bit sweeps
         extras["tiled_mode1_jit_wide"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1)
         extras["tiled_mode1_jit_wide_relabel"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
-        extras["tiled_mode2_jit_fma_wide_relabel"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_wide=1, tile_relabel=1)
-        extras["headline_tiled_mode1_jit_wide_relabel"] = leg(ops, tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
+        # (the 1e-12 mode gains nothing from wide tiles — its heavier segments are bound by LDS transpositions and f64 issue at two
+        # blocks per CU: 57.4 vs 56.8 ms, profiles/r04_wide_tiles.md — and is timed in the narrow form above)
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -574,7 +570,6 @@ def main():
                 # ... and the 1e-12 mode as it is timed for configs[1] (fused multiply-adds, merged diagonal runs, relabelled)
                 extras[cname]["tile2_jit_fma_merge_relabel"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
             if "qft" in cname:  # the issue-bound circuit: the 1e-12 mode with fused multiply-adds
-                extras[cname]["tile2_jit_fma"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1)
                 extras[cname]["tile2_jit_fma_merge"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()

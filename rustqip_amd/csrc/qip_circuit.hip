@@ -1,5 +1,7 @@
 // qip_circuit.hip — apply_ops: gate fusion, tile sweeps (interpreter launches and run-time-compiled segments), hipGraph programs.
 #include "qip_tile.h"
+#include <atomic>
+#include <thread>
 
 #include <mutex>
 
@@ -847,34 +849,101 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
 // unload it.  (Launches are asynchronous: the critical section is microseconds on a hit.)  Nothing is evicted while this
 // handle records a graph: unloading synchronises the device, which a capture forbids; the cache overshoots its bound until the
 // next ordinary call.
+static std::string jit_key(const qip_hip_state* s, const std::string& src, bool fma) {
+  return std::to_string(s->device) + (fma ? " fma\n" : "\n") + src;
+}
+// under g_jit_mutex: a compiled code object becomes a resident kernel of the cache
+static int jit_insert_locked(qip_hip_state* s, const std::string& key, const std::vector<char>& code, hipFunction_t* fn) {
+  JitKernel k;
+  HIPCHK(hipModuleLoadData(&k.module, code.data()));
+  hipError_t e = hipModuleGetFunction(&k.fn, k.module, "qip_segment");
+  if (e != hipSuccess) {
+    (void)hipModuleUnload(k.module);
+    return fail(QIP_ERR_DEVICE, "hipModuleGetFunction failed: %s", hipGetErrorString(e));
+  }
+  k.device = s->device;
+  k.last_use = ++g_jit_clock;
+  g_jit_compiles += 1;
+  g_jit_cache[key] = k;
+  if (fn) *fn = k.fn;
+  return QIP_OK;
+}
 static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma, const std::function<int(hipFunction_t)>& launch) {
-  const std::string key = std::to_string(s->device) + (fma ? " fma\n" : "\n") + src;
+  const std::string key = jit_key(s, src, fma);
   std::lock_guard<std::mutex> lock(g_jit_mutex);
   hipFunction_t fn = nullptr;
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) {
     it->second.last_use = ++g_jit_clock;
     fn = it->second.fn;
+  } else if (!launch && s->jit_collect) {
+    s->jit_collect->push_back({src, fma});  // (the parallel pre-compilation of a plan: jit_compile_collected)
+    return QIP_OK;
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<char> code;
     QCHK(hiprtc_compile(src, fma, &code));
-    JitKernel k;
-    HIPCHK(hipModuleLoadData(&k.module, code.data()));
-    hipError_t e = hipModuleGetFunction(&k.fn, k.module, "qip_segment");
-    if (e != hipSuccess) {
-      (void)hipModuleUnload(k.module);
-      return fail(QIP_ERR_DEVICE, "hipModuleGetFunction failed: %s", hipGetErrorString(e));
-    }
-    k.device = s->device;
-    k.last_use = ++g_jit_clock;
-    g_jit_compiles += 1;
+    QCHK(jit_insert_locked(s, key, code, &fn));
     g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    g_jit_cache[key] = k;
-    fn = k.fn;
     if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   }
   return launch ? launch(fn) : QIP_OK;
+}
+
+// The segments of a plan that are not compiled yet, compiled side by side: hiprtc programs are independent objects, one host
+// thread each (at most `jit_threads`, global option); loading the code objects and entering them in the cache happens on the
+// calling thread under the cache's mutex.  A compilation that fails is reported like a serial one.
+// MEASURED (r4, ROCm 7.2, 8 host cores): no gain — 18 narrow segments 8.4 s on 8 threads against 9.0 s on one, 12 wide ones
+// 14.3 against 15.3: the code-object manager behind hiprtc serialises the compilations of one process.  Default 1 = off
+// (segments compile on first use, as before); what does make a second process fast is comgr's own on-disk cache.
+int64_t g_jit_threads = 1;
+static int hiprtc_compile_many(const std::vector<std::pair<std::string, bool>>& jobs, std::vector<std::vector<char>>* code_out) {
+  QCHK(hiprtc_load());
+  const size_t nj = jobs.size();
+  std::vector<std::vector<char>>& code = *code_out;
+  code.assign(nj, std::vector<char>());
+  std::vector<int> rc(nj, QIP_OK);
+  std::vector<std::string> msg(nj);
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({nj, (size_t)std::max<int64_t>(g_jit_threads, 1), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (size_t i = next.fetch_add(1); i < nj; i = next.fetch_add(1)) {
+      rc[i] = hiprtc_compile(jobs[i].first, jobs[i].second, &code[i]);
+      if (rc[i] != QIP_OK) msg[i] = g_last_error;  // (thread-local: carried over to the caller's thread below)
+    }
+  };
+  if (nthreads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
+  }
+  for (size_t i = 0; i < nj; ++i)
+    if (rc[i] != QIP_OK) return fail(rc[i], "%s", msg[i].c_str());
+  return QIP_OK;
+}
+static int jit_compile_collected(qip_hip_state* s, std::vector<std::pair<std::string, bool>>& jobs) {
+  {  // the same segment twice in one plan: once
+    std::vector<std::pair<std::string, bool>> uniq;
+    for (auto& j : jobs)
+      if (std::find(uniq.begin(), uniq.end(), j) == uniq.end()) uniq.push_back(std::move(j));
+    jobs.swap(uniq);
+  }
+  if (jobs.empty()) return QIP_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t nj = jobs.size();
+  std::vector<std::vector<char>> code;
+  QCHK(hiprtc_compile_many(jobs, &code));
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  for (size_t i = 0; i < nj; ++i) {
+    const std::string key = jit_key(s, jobs[i].first, jobs[i].second);
+    if (g_jit_cache.find(key) != g_jit_cache.end()) continue;  // (another thread's handle got there first)
+    QCHK(jit_insert_locked(s, key, code[i], nullptr));
+  }
+  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();
+  return QIP_OK;
 }
 
 template <typename T>
@@ -1139,6 +1208,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
   QCHK(make_tile_schedule(dtype, n, ops, count, mode, true, &sc));
   const std::vector<TileItem>& items = sc.items;
   *nseg = *src_bytes = *code_bytes = 0;
+  std::vector<std::pair<std::string, bool>> jobs;
   for (const TileStep& st : sc.steps) {
     if (st.ops.size() < 2 || !st.perm.empty()) continue;
     std::vector<const TileItem*> seg;
@@ -1156,16 +1226,14 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
       Ins ins = tile_ins(plan.high, plan.p5);
       src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
     }
-    std::vector<char> code;
-    {
-      std::lock_guard<std::mutex> lock(g_jit_mutex);
-      QCHK(hiprtc_compile(src, (mode & 32) != 0, &code));  // mode bit 5: fused multiply-adds
-    }
     if (*nseg == 0 && first) *first = src;
     *nseg += 1;
     *src_bytes += src.size();
-    *code_bytes += code.size();
+    jobs.push_back({src, (mode & 32) != 0});  // mode bit 5: fused multiply-adds
   }
+  std::vector<std::vector<char>> code;  // all segments side by side (g_jit_threads host threads), as apply_ops does
+  QCHK(hiprtc_compile_many(jobs, &code));
+  for (const auto& c : code) *code_bytes += c.size();
   return QIP_OK;
 }
 
@@ -1185,7 +1253,7 @@ extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, 
 extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
 static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
-  return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits && !s->capture_staging && !s->jit_prepare;
+  return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits && !s->capture_staging && !s->jit_for_capture;
 }
 static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
   return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel == 2 ? 8 : 0) |  // (3 = persistent layout)
@@ -1234,6 +1302,24 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   for (const TileStep& st : sc.steps) moves_qubits = moves_qubits || !st.perm.empty();
   s->layout.clear();
   const bool wide = (tile_mode_of(s) & 16) != 0;
+  if (s->tile_jit && s->tile_passes && !s->capture_staging && !s->jit_prepare && g_jit_threads > 1) {
+    // every segment of the plan that is not in the kernel cache yet, compiled side by side before anything runs
+    std::vector<std::pair<std::string, bool>> jobs;
+    s->jit_collect = &jobs;
+    s->jit_prepare = true;
+    int rc = QIP_OK;
+    for (const TileStep& st : sc.steps) {
+      if (st.ops.size() < 2 || !st.perm.empty()) continue;
+      std::vector<const TileItem*> seg;
+      for (uint64_t i : st.ops) seg.push_back(&items[i]);
+      rc = wide ? launch_wide_segment<T>(s, seg, st.high) : launch_tile_segment<T>(s, seg, st.high);
+      if (rc != QIP_OK) break;
+    }
+    s->jit_prepare = false;
+    s->jit_collect = nullptr;
+    QCHK(rc);
+    QCHK(jit_compile_collected(s, jobs));
+  }
   auto run_steps = [&]() -> int {
     size_t step_no = 0;
     for (const TileStep& st : sc.steps) {
@@ -1352,9 +1438,9 @@ static int program_capture(qip_hip_program* p) {
       if (!st.perm.empty()) return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now
-    s->jit_prepare = true;
+    s->jit_prepare = s->jit_for_capture = true;
     const int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
-    s->jit_prepare = false;
+    s->jit_prepare = s->jit_for_capture = false;
     QCHK(rc);
   }
   for (int attempt = 0; attempt < 3; ++attempt) {

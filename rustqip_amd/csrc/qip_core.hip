@@ -66,6 +66,11 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "jit_cache_cap")) return jit_set_cache_cap(value);
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
+  if (key && !strcmp(key, "jit_threads")) {
+    if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
+    g_jit_threads = value;
+    return QIP_OK;
+  }
   if (key && !strcmp(key, "tile_row_split")) {
     if (value != 5 && value != 11) return fail(QIP_ERR_INVALID, "tile_row_split is 11 (split rows) or 5 (contiguous rows)");
     g_tile_row_split = value;

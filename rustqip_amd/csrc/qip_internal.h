@@ -24,6 +24,7 @@
 #include <exception>
 #include <new>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/qip_hip.h"
@@ -62,6 +63,7 @@ extern int64_t g_perm_rows;
 extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap, g_tile_sched;
 extern int64_t g_single_via_tile, g_single_via_tile_f32;
 extern int64_t g_dist_fold_pack;  // qip_dist.hip
+extern int64_t g_jit_threads;     // qip_circuit.hip: host threads that compile a plan's new segments side by side
 extern int64_t g_force_k4_direct;  // tuning aid: dense k = 4 on the matrix cores reads its operands straight from HBM (k_gate_kq_mfma)  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 
 struct FlatOp {
@@ -175,7 +177,11 @@ struct qip_hip_state {
   int64_t tile_merge = 0;   // ... and runs of diagonal gates are applied as products of their factors
   int64_t tile_wide = 0;    // r4: run-time-compiled segments over a 13-bit register-resident tile (seven free positions per sweep)
   int num_cus = 256;        // compute units of the device
-  bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture)
+  bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture; the parallel pre-compilation)
+  bool jit_for_capture = false;  // ... on behalf of a graph capture: the plan must be the one the capture will record
+  // r4: apply_ops collects the sources of a plan's segments that are not in the kernel cache yet (source text, contraction flag)
+  // and compiles them on several host threads before the first launch (hiprtc: ~0.35 s per 11-bit segment, ~1.4 s per wide one)
+  std::vector<std::pair<std::string, bool>>* jit_collect = nullptr;
   // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
   std::deque<std::vector<char>>* capture_staging = nullptr;
   size_t capture_arena_need = 0;
