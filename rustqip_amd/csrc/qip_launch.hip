@@ -797,7 +797,7 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   } while (0)
   switch (k) {
     case 2: KQ(2, 4); break;
-    case 3: KQ(3, 2); break;
+    case 3: KQ(3, 1); break;  // (r4: the two-groups-per-lane form spilled 344 SGPRs and was a tuning aid only — dropped)
     case 4: KQ(4, 1); break;
     default: return fail(QIP_ERR_UNSUPPORTED, "register kernel for k = %u", k);
   }
