@@ -1387,6 +1387,45 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       js += ",\"perm\":[";
       for (size_t k = 0; k < st.perm.size(); ++k) js += (k ? "," : "") + std::to_string(st.perm[k]);
       js += "]";
+    } else if (st.ops.size() > 1 && (mode & 16) && n > (uint32_t)kWideBits) {
+      // wide tiles (mode bit 4): the plan of build_wide_segment — arrangements (register bits, lane map, quarter bits, buffer
+      // layout of the transposition into them) and the gates in 13-bit tile-index space, in the order they are applied
+      std::vector<const TileItem*> seg;
+      for (uint64_t i : st.ops) seg.push_back(&items[i]);
+      WidePlan<T> plan;
+      QCHK(build_wide_segment<T>(n, seg, st.high, &plan, mode & 3));
+      js += ",\"wide\":1,\"low\":[0,1,2,3,4," + std::to_string(plan.p5) + "],\"high\":[";
+      for (size_t k = 0; k < plan.high.size(); ++k) js += (k ? "," : "") + std::to_string(plan.high[k]);
+      js += "],\"order\":[";
+      for (size_t k = 0; k < plan.order.size(); ++k) js += (k ? "," : "") + std::to_string(plan.order[k]);
+      js += "],\"passes\":[";
+      for (size_t pi = 0; pi < plan.passes.size(); ++pi) {
+        const WidePass& ps = plan.passes[pi];
+        if (pi) js += ",";
+        js += "{\"first\":" + std::to_string(ps.first) + ",\"count\":" + std::to_string(ps.count) + ",\"transposed\":" + (ps.transposed ? "1" : "0") +
+              ",\"q\":[" + std::to_string(ps.q[0]) + "," + std::to_string(ps.q[1]) + "],\"R\":[";
+        for (int j = 0; j < kWideRegBits; ++j) js += (j ? "," : "") + std::to_string(ps.R[j]);
+        js += "],\"L\":[";
+        for (int k = 0; k < 8; ++k) js += (k ? "," : "") + std::to_string(ps.L[k]);
+        js += "],\"bufpos\":[";
+        for (int t = 0; t < kWideBits; ++t) js += (t ? "," : "") + std::to_string(ps.bufpos[t]);
+        js += "]}";
+      }
+      js += "],\"gates\":[";
+      for (size_t gi = 0; gi < plan.gates.size(); ++gi) {
+        const TileGate<T>& g = plan.gates[gi];
+        if (gi) js += ",";
+        js += "{\"kind\":" + std::to_string(g.kind) + ",\"b0\":" + std::to_string(g.b0) + ",\"b1\":" + std::to_string(g.b1) + ",\"cmask\":" +
+              std::to_string(g.cmask) + ",\"omask\":" + std::to_string(g.omask) + ",\"tpos_out\":" + std::to_string(g.tpos_out) + ",\"nz\":" +
+              std::to_string(g.nz) + ",\"m\":[";
+        for (int e = 0; e < 4; ++e)
+          js += std::string(e ? "," : "") + "[" + num((double)g.m[e].x) + "," + num((double)g.m[e].y) + "]";
+        js += "]}";
+      }
+      js += "],\"mats\":[";
+      for (size_t e = 0; e < plan.mats.size(); ++e)
+        js += std::string(e ? "," : "") + "[" + num((double)plan.mats[e].x) + "," + num((double)plan.mats[e].y) + "]";
+      js += "]";
     } else if (st.ops.size() > 1) {
       std::vector<const TileItem*> seg;
       for (uint64_t i : st.ops) seg.push_back(&items[i]);

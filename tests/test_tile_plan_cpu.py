@@ -133,6 +133,91 @@ def emulate_segment(state, n, seg):
     state[idx] = tile
 
 
+def emulate_wide_segment(state, n, seg):
+    """A wide segment (option tile_wide: a 13-bit tile held in registers, rustqip_amd/csrc/qip_tile.h WidePlan) on a numpy vector.
+    Two things are checked: the STRUCTURE of the plan — arrangement 0 is the load arrangement, every gate's exchange bits are
+    register bits of its pass, consecutive arrangements share the two quarter bits, the buffer layout of every transposition is
+    a bijection, the plan returns to the load arrangement — and its MEANING: the gates, in the plan's order, applied in the
+    13-bit tile-index space with their tile-bit / outside-the-tile masks (a transposition moves nothing logically)."""
+    WB = 13
+    low, high = seg["low"], seg["high"]
+    tile_pos = low + high
+    other = [p for p in range(n) if p not in tile_pos]
+    ntiles = 1 << (n - WB)
+    bid = np.arange(ntiles, dtype=np.uint64)
+    base = np.zeros(ntiles, dtype=np.uint64)
+    for k, p in enumerate(other):
+        base |= ((bid >> np.uint64(k)) & np.uint64(1)) << np.uint64(p)
+    t = np.arange(1 << WB, dtype=np.int64)
+    off = np.zeros(1 << WB, dtype=np.uint64)
+    for b, p in enumerate(tile_pos):
+        off |= ((t.astype(np.uint64) >> np.uint64(b)) & np.uint64(1)) << np.uint64(p)
+    idx = (base[:, None] | off[None, :]).astype(np.int64)
+    tile = state[idx]
+    passes, gates = seg["passes"], seg["gates"]
+    mats = np.array([complex(a, b) for a, b in seg["mats"]], dtype=np.complex128)
+    load_R, load_L = [8, 9, 10, 11, 12], list(range(8))
+    assert passes[0]["R"] == load_R and passes[0]["L"] == load_L and not passes[0]["transposed"]
+    if len(passes) > 1:
+        assert passes[-1]["R"] == load_R and passes[-1]["L"] == load_L
+    seen = 0
+    for pi, ps in enumerate(passes):
+        assert sorted(ps["R"] + ps["L"]) == list(range(WB))
+        if pi:
+            prev = passes[pi - 1]
+            assert ps["transposed"] and ps["q"][0] != ps["q"][1] and set(ps["q"]) <= set(ps["R"]) & set(prev["R"])
+            assert len(set(ps["R"]) - set(prev["R"])) <= 3
+            nonq = [b for b in range(WB) if b not in ps["q"]]
+            assert sorted(ps["bufpos"][b] for b in nonq) == list(range(11))
+            # the writing arrangement's thread bits 0..3 on buffer bits 0..3; the reading one's on pairwise distinct classes
+            assert [ps["bufpos"][prev["L"][k]] for k in range(4)] == [0, 1, 2, 3]
+            cls = [ps["bufpos"][ps["L"][k]] for k in range(4)]
+            assert all(c < 8 for c in cls) and len({c & 3 for c in cls}) == 4, cls
+        assert ps["first"] == seen or ps["count"] == 0
+        for g in gates[ps["first"]: ps["first"] + ps["count"]]:
+            kind = g["kind"]
+            ex = [] if kind == 1 else [g["b0"]] if kind == 0 else [g["b0"], g["b1"]] if kind in (2, 3) else [g["b0"], g["b1"], g["tpos_out"]]
+            assert set(ex) <= set(ps["R"]), (ex, ps["R"])
+            tile_on = (base & np.uint64(g["omask"])) == np.uint64(g["omask"])
+            ok = (t & g["cmask"]) == g["cmask"]
+            m = [complex(a, b) for a, b in g["m"]]
+            if kind == 0:
+                b = g["b0"]
+                i0 = t[ok & (((t >> b) & 1) == 0)]
+                a0, a1 = tile[:, i0].copy(), tile[:, i0 | (1 << b)].copy()
+                tile[:, i0] = np.where(tile_on[:, None], m[0] * a0 + m[1] * a1, a0)
+                tile[:, i0 | (1 << b)] = np.where(tile_on[:, None], m[2] * a0 + m[3] * a1, a1)
+            elif kind == 1:
+                if g["b0"] == OUTSIDE:
+                    f = np.where(((base >> np.uint64(g["tpos_out"])) & np.uint64(1)) != 0, m[1], m[0])[:, None] * np.ones(1 << WB)[None, :]
+                else:
+                    f = np.where(((t >> g["b0"]) & 1) != 0, m[1], m[0])[None, :] * np.ones(ntiles)[:, None]
+                tile = np.where(tile_on[:, None] & ok[None, :], f * tile, tile)
+            elif kind == 2:
+                b0, b1 = g["b0"], g["b1"]
+                i10 = t[ok & (((t >> b0) & 1) == 1) & (((t >> b1) & 1) == 0)]
+                i01 = (i10 & ~(1 << b0)) | (1 << b1)
+                a, b = tile[:, i10].copy(), tile[:, i01].copy()
+                tile[:, i10] = np.where(tile_on[:, None], b, a)
+                tile[:, i01] = np.where(tile_on[:, None], a, b)
+            else:
+                bits = [g["b0"], g["b1"]] if kind == 3 else [g["b0"], g["b1"], g["tpos_out"]]  # sub-index MSB first
+                k = len(bits)
+                mat = mats[16 * g["nz"]: 16 * g["nz"] + (1 << (2 * k))].reshape(1 << k, 1 << k)
+                sel = ok.copy()
+                for b in bits:
+                    sel &= ((t >> b) & 1) == 0
+                i0 = t[sel]
+                ids = [i0 | sum(((c >> (k - 1 - j)) & 1) << bits[j] for j in range(k)) for c in range(1 << k)]
+                x = np.stack([tile[:, i] for i in ids], axis=-1)
+                y = x @ mat.T
+                for r, i in enumerate(ids):
+                    tile[:, i] = np.where(tile_on[:, None], y[:, :, r], x[:, :, r])
+        seen += ps["count"]
+    assert seen == len(gates)
+    state[idx] = tile
+
+
 def replay(n, ops, mode, x, dtype=None):
     plan = debug_tile_plan(n, ops, mode) if dtype is None else debug_tile_plan(n, ops, mode, dtype)
     assert plan["n"] == n
@@ -159,6 +244,9 @@ def replay(n, ops, mode, x, dtype=None):
             st = st[src.astype(np.int64)]
         elif len(step["ops"]) == 1:
             st = O.apply_ops_in_place(n, [ops[step["ops"][0]]], st)
+        elif step.get("wide"):
+            assert len(step["high"]) == 7 and len(set(step["high"])) == 7 and not set(step["high"]) & set(step["low"])
+            emulate_wide_segment(st, n, step)
         else:
             assert len(step["high"]) == TILE_BITS - TILE_LOW and len(set(step["high"])) == TILE_BITS - TILE_LOW
             assert not set(step["high"]) & set(step["low"]) and step["low"][5] == (11 if n >= 12 and step["low"][5] != 5 else 5)
@@ -509,3 +597,22 @@ def test_wide_tile_segments_plan_and_compile_without_a_gpu():
 
     r = debug_tile_jit(n, ops, 1 | 16 | 64, _ffi.QIP_C32)
     assert r["segments"] >= 1
+
+
+@pytest.mark.parametrize("mode", [1 | 16, 2 | 16, 1 | 4 | 8 | 16, 2 | 4 | 16])
+@pytest.mark.parametrize("name", ["c2", "fuzz", "qft", "grover_k3"])
+def test_wide_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
+    """r4: the host half of the wide tiles without a GPU — qip_hip_debug_tile_plan with mode bit 4 exports every wide segment
+    (arrangements with their register bits, lane maps, quarter bits and buffer layouts; the gates in 13-bit tile-index space,
+    in the order they are applied); `emulate_wide_segment` checks the plan's structure and replays its gates with numpy, and
+    the result must match the oracle applying the caller's circuit gate by gate.  (The generated code itself — transpositions
+    included — is compiled here with hiprtc and compared bit for bit with the 11-bit sweeps on the GPU.)"""
+    n = 15
+    rng = np.random.default_rng(15)
+    ops = {"c2": circuits.h_layer(n) + circuits.c2_random_circuit(n, 120, seed=28), "fuzz": fuzz_circuit(n, rng, 120),
+           "qft": circuits.c3_qft(n), "grover_k3": circuits.c5_grover_iteration(n, dense_k3=True)}[name]
+    x = circuits.random_state(n, seed=n)
+    got, plan = replay(n, ops, mode, x)
+    assert any(st.get("wide") for st in plan["steps"])
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= 1e-12, (name, mode)
