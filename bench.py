@@ -313,6 +313,11 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs3_clifford_t_tile1_jit_wide_relabel", circuits.c4_clifford_t(n, gates, seed=32)[gates // 2 + 64:gates], True, seed=28,
         tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
     leg("configs4_grover_tile1_jit_wide", circuits.c5_grover_iteration(n)[100:], True, seed=29, max_len=96, tile=1, tile_jit=1, tile_wide=1)
+    more2 = circuits.c2_random_circuit(n, 64, seed=31)
+    leg("mixed_tile2_jit_fma_merge_wide_chunks", more2, False, seed=30, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
+    leg("configs2_qft_tile2_jit_fma_merge_wide", circuits.c3_qft(n)[200:400], False, seed=31, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
+    leg("configs3_clifford_t_tile2_jit_fma_merge_wide_relabel", circuits.c4_clifford_t(n, gates, seed=33)[:64], False, seed=32,
+        tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1, tile_relabel=1)
     return finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0)
 
 
@@ -549,8 +554,9 @@ def main():
         # transposition buffer; run-time-compiled segments, IEEE-equal in circuit order like the 11-bit sweeps
         extras["tiled_mode1_jit_wide"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1)
         extras["tiled_mode1_jit_wide_relabel"] = leg(ops_mixed, tile=1, tile_jit=1, tile_wide=1, tile_relabel=1)
-        # (the 1e-12 mode gains nothing from wide tiles — its heavier segments are bound by LDS transpositions and f64 issue at two
-        # blocks per CU: 57.4 vs 56.8 ms, profiles/r04_wide_tiles.md — and is timed in the narrow form above)
+        # ... and the 1e-12 mode over wide tiles, with fused multiply-adds and merged runs of diagonal gates (without relabelling:
+        # seven positions per sweep leave little for it to win, and its in-tile swaps and closing sweep cost more than they save)
+        extras["tiled_mode2_jit_fma_merge_wide"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -569,8 +575,10 @@ def main():
                 extras[cname]["tile1_jit_relabel"] = leg(cops, "ops", tile=1, tile_jit=1, tile_relabel=1)
                 # ... and the 1e-12 mode as it is timed for configs[1] (fused multiply-adds, merged diagonal runs, relabelled)
                 extras[cname]["tile2_jit_fma_merge_relabel"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_relabel=1)
+                extras[cname]["tile2_jit_fma_merge_wide_relabel"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1, tile_relabel=1)
             if "qft" in cname:  # the issue-bound circuit: the 1e-12 mode with fused multiply-adds
                 extras[cname]["tile2_jit_fma_merge"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1)
+                extras[cname]["tile2_jit_fma_merge_wide"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
         # configs[1] exactly: n = 28
@@ -630,6 +638,8 @@ def main():
                                 ("configs4_grover_iteration_n%d" % n, circuits.c5_grover_iteration(n), {}),
                                 ("configs4_grover_dense_k3_n%d" % n, circuits.c5_grover_iteration(n, dense_k3=True), {}),
                                 ("configs1_mixed_n%d" % n, ops_mixed, {}),
+                                ("configs3_clifford_t_tiled_mode1", circuits.c4_clifford_t(n, args.gates, seed=32), {"tile": 1}),
+                                ("configs1_mixed_tiled_mode1", ops_mixed, {"tile": 1}),
                                 ("headline_tiled_mode1", ops, {"tile": 1})):
             try:
                 extras[cname] = dist_leg(cops, **kw)

@@ -312,7 +312,7 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    18 -> 13, relabelled 14 -> 10; a light sweep costs the same 5.2 - 5.8 ms).  Gates on the five register
  *                    bits of the moment cost no LDS traffic; a transposition (four quarters through the buffer) brings in up to
  *                    three new register bits.  Same helpers, same gate order: "tile" = 1 stays IEEE-equal to the gate-by-gate
- *                    path.  Merged diagonal runs ("tile_merge") are not generated for wide segments: QFT keeps the narrow form.
+ *                    path.  "tile_fma" / "tile_merge" apply to wide segments of "tile" = 2 as they do to narrow ones.
  *                    0 (default) = the 11-bit LDS-resident tile.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of

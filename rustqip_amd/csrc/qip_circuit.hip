@@ -640,7 +640,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
 // as the 11-bit sweeps (pass_dense, pass_scale, pass_swap, pass_dense2, pass_dense3w over 32 elements: the products and sums of
 // the gate-by-gate kernels in the same order — a circuit-order segment stays IEEE-equal to them).
 template <typename T>
-static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params) {
+static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   constexpr uint32_t SW = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // tile_slot's fold width
   auto slot = [&](uint32_t t) { return t ^ ((t >> SW) & ((1u << SW) - 1u)); };
@@ -782,6 +782,63 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
       g.cm_reg = g.cmask & rmask;
       g.cm_lane = g.cmask & ~rmask;
       g.op = 0;
+      // `merge_diag` (option "tile_merge", tile = 2 only: 1e-12 bar): a run of consecutive diagonal gates as products — every
+      // gate contributes a factor to the SET of the lane's 32 elements its register-bit conditions pick, the factors of one set
+      // are multiplied together as they come, each element then takes the product of its sets (the 11-bit generator's scheme
+      // over 32 elements: QFT's runs of controlled phases)
+      if (merge_diag && g.kind == 1) {
+        uint32_t ge = gi;
+        while (ge < ps.first + ps.count && plan.gates[ge].kind == 1) ++ge;
+        if (ge - gi >= 3) {
+          std::vector<uint32_t> sets;
+          L("    {  // gates " + N(gi) + " .. " + N(ge - 1) + ": one run of diagonal gates");
+          auto add = [&](uint32_t mask, const std::string& expr, const std::string& ucond) {
+            if (!mask) return;
+            const std::string open = ucond.empty() ? "" : "if (" + ucond + ") { QIP_KEEP_BRANCH(); ", close = ucond.empty() ? "" : " }";
+            for (size_t k = 0; k < sets.size(); ++k)
+              if (sets[k] == mask) {
+                L("      " + open + "F" + N(k) + " = cmul(F" + N(k) + ", " + expr + ");" + close);
+                return;
+              }
+            if (ucond.empty()) L("      A F" + N(sets.size()) + " = " + expr + ";");
+            else L("      A F" + N(sets.size()) + " = {(T)1, (T)0}; " + open + "F" + N(sets.size()) + " = " + expr + ";" + close);
+            sets.push_back(mask);
+          };
+          for (uint32_t gj = gi; gj < ge; ++gj) {
+            const TileGate<T>& d = plan.gates[gj];
+            const uint32_t d_reg = d.cmask & rmask, d_lane = d.cmask & ~rmask;
+            uint32_t ok = 0;  // elements whose register-bit controls are all 1
+            for (int i = 0; i < 32; ++i) {
+              uint32_t ci = 0;
+              for (int j = 0; j < kWideRegBits; ++j)
+                if ((i >> j) & 1) ci |= 1u << ps.R[j];
+              if ((ci & d_reg) == d_reg) ok |= 1u << i;
+            }
+            const std::string m0 = amp(d.m[0]), m1 = amp(d.m[1]);
+            const bool u0 = d.m[0].x == (T)1 && d.m[0].y == (T)0, u1 = d.m[1].x == (T)1 && d.m[1].y == (T)0;
+            const std::string ucond = d.omask ? "(base & " + U(d.omask) + ") == " + U(d.omask) : "";
+            const std::string lcond = d_lane ? "((tb & " + N(d_lane) + "u) == " + N(d_lane) + "u)" : "";
+            auto guarded = [&](const std::string& f) { return lcond.empty() ? f : "tile_sel(" + lcond + ", " + f + ", A{(T)1, (T)0})"; };
+            const int J = d.b0 == kTileOutside ? -1 : jof(d.b0);
+            if (J >= 0) {
+              uint32_t half1 = 0;
+              for (int i = 0; i < 32; ++i)
+                if ((i >> J) & 1) half1 |= 1u << i;
+              if (!u0) add(ok & ~half1, guarded("A" + m0), ucond);
+              if (!u1) add(ok & half1, guarded("A" + m1), ucond);
+            } else {
+              const std::string one = d.b0 == kTileOutside ? "(((base >> " + N(d.tpos_out) + ") & 1ull) != 0)" : "(((tb >> " + N(d.b0) + ") & 1u) != 0)";
+              add(ok, guarded("tile_sel(" + one + ", A" + m1 + ", A" + m0 + ")"), ucond);
+            }
+          }
+          for (int i = 0; i < 32; ++i)
+            for (size_t si = 0; si < sets.size(); ++si)
+              if ((sets[si] >> i) & 1u) L("      e[" + N(i) + "] = cmul(F" + N(si) + ", e[" + N(i) + "]);");
+          L("    }");
+          gi = ge - 1;
+          continue;
+        }
+      }
       L("    {  // gate " + N(gi));
       {
         const std::string m0 = amp(g.m[0]), m1 = amp(g.m[1]), m2 = amp(g.m[2]), m3 = amp(g.m[3]);
@@ -1102,7 +1159,8 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   const bool fma = s->tile_fma && s->tile >= 2;
   const bool parametrised = s->tile_jit != 3;
   std::vector<T> params;
-  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr);
+  const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
+  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge);
   if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
   QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss before the timed region starts
   if (s->jit_prepare) return QIP_OK;
@@ -1218,7 +1276,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     if ((mode & 16) && n > (uint32_t)kWideBits) {  // mode bit 4: wide tiles
       WidePlan<T> wplan;
       QCHK(build_wide_segment<T>(n, seg, st.high, &wplan, mode & 3));
-      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr);
+      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0);
       if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
     } else {
       TileSegmentPlan<T> plan;

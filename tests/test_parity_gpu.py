@@ -1732,7 +1732,7 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 0
     ex = line["extras"]
     for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs4_grover_dense_k3_n21",
-                 "configs1_mixed_n21", "headline_tiled_mode1"):
+                 "configs1_mixed_n21", "headline_tiled_mode1", "configs3_clifford_t_tiled_mode1", "configs1_mixed_tiled_mode1"):
         assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
     assert sum(ex[name]["comm_over_reps"]["remaps"] for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs1_mixed_n21")) >= 1
     assert abs(ex["norm_sqr_end"] - 1) < 1e-9
@@ -1999,6 +1999,8 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
         leg(c2w[:40], True, tile=1, tile_jit=1, tile_wide=1)
         leg(c2w[40:80], True, tile=1, tile_jit=1, tile_wide=1, tile_relabel=2)
         leg(c2w[80:120], False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c2_random_circuit(n, 40, seed=35), False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
+        leg(circuits.c3_qft(n)[170:330], False, max_len=160, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
         leg(circuits.c4_clifford_t(n, 48, seed=34), True, tile=1, tile_jit=1, tile_wide=1)
         leg(circuits.c5_grover_iteration(n)[70:140], True, max_len=96, tile=1, tile_jit=1, tile_wide=1)
         twin.close()
@@ -2483,3 +2485,10 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
             if tile == 1 and relabel == 0 and f64 and name != "grover_k3":
                 assert np.array_equal(res[1][0], res[0][0]), (name, "wide and narrow circuit-order sweeps differ")
             assert res[1][1] <= res[0][1], (name, tile, relabel, res[0][1], res[1][1])  # never more sweeps than the narrow plan
+        if name in ("qft", "c4"):  # merged runs of diagonal gates + fused multiply-adds in the wide generator (1e-12 mode)
+            with q.HipState(n, dtype) as st:
+                for k, v in (("tile", 2), ("tile_jit", 1), ("tile_wide", 1), ("tile_fma", 1), ("tile_merge", 1)):
+                    st.set_option(k, v)
+                st.upload(x)
+                st.apply_ops(ops)
+                assert float(np.max(np.abs(st.download() - want))) <= tol, (name, "merged")

@@ -80,7 +80,7 @@ def main():
         ("dense k=7 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11], rand_unitary(7, rng).ravel()), {}),
         ("dense k=8 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13], rand_unitary(8, rng).ravel()), {}),
         ("dense k=9 (MFMA f64, X in LDS, A from L2)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17], rand_unitary(9, rng).ravel()), {}),
-        ("dense k=10 (MFMA f64, X in LDS, 8 groups per item)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17, 19], rand_unitary(10, rng).ravel()), {}),
+        ("dense k=10 (MFMA f64, X in LDS in two K phases, A from L2)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17, 19], rand_unitary(10, rng).ravel()), {}),
         ("dense k=6 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {"mfma": 0}),
         ("dense k=5 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo], rand_unitary(5, rng).ravel()), {"mfma": 0}),
         ("diag k=3 (table)", q.make_matrix_op([hi, mid, lo], np.diag(np.exp(1j * rng.uniform(0, 6, 8))).ravel()), {}),
