@@ -607,6 +607,10 @@ def main():
                 s32.set_option(k, v)
             dt, _ = median_time(lambda: s32.apply_compiled(cm32), s32.sync)
             f32["mixed_tile1_jit_relabel"] = {"gates": len(ops_mixed), "ms": 1e3 * dt, "gates_per_s": len(ops_mixed) / dt, "reps": REPS}
+            s32.set_option("tile_relabel", 0)
+            s32.set_option("tile_wide", 1)  # r4: wide tiles (32 amplitudes per lane are 64 registers in f32)
+            dt, _ = median_time(lambda: s32.apply_compiled(cm32), s32.sync)
+            f32["mixed_tile1_jit_wide"] = {"gates": len(ops_mixed), "ms": 1e3 * dt, "gates_per_s": len(ops_mixed) / dt, "reps": REPS}
             f32["norm_sqr"] = s32.norm_sqr()
             extras["complex64_n%d" % n] = f32
 

@@ -45,7 +45,7 @@ int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0, g_tile_sch
 // r4: the tile's sixth low position (qip_tile.h tile_p5): 11 = every wave-level access of a tile sweep is two 512-byte halves
 // 32 KiB apart, 5 = one contiguous 1-KiB row (rounds 1-3).  Measured (tools/tune_tile probe, profiles/r04_tile_rows.md): the
 // split form brings EVERY choice of the five high positions to 5.3 - 5.9 ms per light sweep at n = 30 (contiguous: 5.3 - 8.6).
-int64_t g_tile_row_split = 11;
+int64_t g_tile_row_split = 11, g_tile_row_split_f32 = 5;
 int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;
 int64_t g_force_k4_direct = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
@@ -69,6 +69,11 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "jit_threads")) {
     if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
     g_jit_threads = value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "tile_row_split_f32")) {
+    if (value != 5 && value != 12) return fail(QIP_ERR_INVALID, "tile_row_split_f32 is 12 (split rows) or 5 (contiguous rows)");
+    g_tile_row_split_f32 = value;
     return QIP_OK;
   }
   if (key && !strcmp(key, "tile_row_split")) {

@@ -64,10 +64,11 @@ struct TileSchedule {
 // Which amplitude-index positions are the tile's six LOW bits (lane id at load / store time): 0..4 and p5 (qip_kernels.h,
 // tile_block_base).  p5 = 11 ("split rows": two 512-byte halves 32 KiB apart per wave-level access) for Complex<f64> states
 // with n >= 12, else 5 (one contiguous row); global option "tile_row_split" (default 11; 5 = contiguous rows everywhere).
-extern int64_t g_tile_row_split;
+extern int64_t g_tile_row_split, g_tile_row_split_f32;
 static inline uint32_t tile_p5(int dtype, uint32_t n) {
-  const uint32_t p = (uint32_t)g_tile_row_split;
-  return (dtype == QIP_C64 && p > 5u && p < n && n >= 12u) ? p : 5u;
+  // (Complex<f32>: 8-byte amplitudes, a wave-level access is 512 bytes; its own switch, position 12 = the same byte-address bit 15)
+  const uint32_t p = (uint32_t)(dtype == QIP_C64 ? g_tile_row_split : g_tile_row_split_f32);
+  return (p > 5u && p < n && n >= 13u) || (dtype == QIP_C64 && p > 5u && p < n && n >= 12u) ? p : 5u;
 }
 template <typename T> static inline uint32_t tile_p5_of(uint32_t n) { return tile_p5(std::is_same<T, double>::value ? QIP_C64 : QIP_C32, n); }
 static inline bool tile_is_low(uint32_t pos, uint32_t p5) { return pos < 5u || pos == p5; }

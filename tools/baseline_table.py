@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""BASELINE.md §8 from ONE committed bench line (+ the ops tables of the same evidence run): every figure in that section is
+printed by this script from profiles/<tag>_bench_n1.json, profiles/<tag>_ops_table*.md and profiles/<tag>_bench_2ranks_one_gpu*.json.
+
+    python tools/baseline_table.py r04 > /tmp/section8.md"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+P = lambda name: os.path.join(ROOT, "profiles", name)  # noqa: E731
+d = json.loads(open(P(f"{tag}_bench_n1.json")).read().strip().splitlines()[-1])
+ex, par, roof, cpu = d["extras"], d["parity"], d["roofline"], d["cpu_baseline"]
+
+
+def ops_rows(path):
+    out = {}
+    for line in open(path):
+        c = [x.strip() for x in line.split("|")]
+        if len(c) > 5 and c[3].replace(".", "").isdigit():
+            out[c[1]] = (c[2].strip("`"), float(c[3]), float(c[4]), float(c[5]))
+    return out
+
+
+ops, ops32 = ops_rows(P(f"{tag}_ops_table.md")), ops_rows(P(f"{tag}_ops_table_f32.md"))
+n = d["config"]["n_qubits"]
+g = d["config"]["gates_per_step"]
+L = print
+L(f"| config | backend | ms | gates/s (ops/s) | GB/s | % of 8 TB/s | parity |")
+L("|---|---|---|---|---|---|---|")
+L(f"| **headline**: {g} random single-qubit gates (H / X / Rz), **n = {n}**, f64, {d['steps']} steps | HIP kernels, 1 × MI355X | {d['ms_per_step'] / g:.2f} per gate | "
+  f"{d['gates_per_s']:.1f} | **{d['value']:.0f}** | **{100 * d['value'] / 8000:.1f}** | `parity_ok` = {d['parity_ok']}: {par['gates_checked']} gates in {len(par['legs'])} legs on closed "
+  f"sub-cubes ({par['rows_checked']:.2e} rows) vs the CPU oracle, max \\|Δ\\| = {par['max_abs_delta']:g} in the IEEE-equal legs, {par['max_abs_delta_1e-12_legs']:.1e} in the 1e-12 legs; "
+  f"{par['whole_vector']['compares']} whole-vector compares of 2^{n} amplitudes against a twin on the literal kernel: {par['whole_vector']['amplitudes_not_equal_in_IEEE_legs']} unequal |")
+m = d["mixed_circuit"]
+L(f"| configs[1] mix (¾ of those + ¼ CNOT), n = {n} | HIP kernels | {m['ms'] / m['gates']:.2f} per gate | {m['gates_per_s']:.1f} | {m['algorithmic_GBps']:.0f} | {100 * m['frac_of_8TBps']:.1f} | same block |")
+hs = ex["h_sweep_min_median_GBps"]
+L(f"| H on each target qubit, n = {n}: min / median | HIP kernels | {32 * 2**n / hs[0] / 1e6:.2f} / {32 * 2**n / hs[1] / 1e6:.2f} per gate | | {hs[0]:.0f} / {hs[1]:.0f} | {hs[0] / 80:.1f} / {hs[1] / 80:.1f} | |")
+c28 = ex["configs1_n28"]
+L(f"| configs[1] exactly: n = 28, 256 gates | HIP kernels | {c28['ms_per_step'] / 256:.2f} per gate | {c28['gates_per_s']:.0f} | {c28['GBps']:.0f} | {c28['GBps'] / 80:.1f} | oracle windows at n = 28 |")
+
+
+def leg(key, label, sub=None, bar="IEEE-equal to gate by gate; oracle + twin at n = 30 (`parity.legs`)"):
+    v = ex[key] if sub is None else ex[key][sub]
+    cnt = v.get("gates", v.get("ops"))
+    L(f"| {label} | HIP kernels + hiprtc | {v['ms']:.1f} ({v['launches']} sweeps, {v['ms'] / v['launches']:.2f} each) | {cnt / v['ms'] * 1e3:.0f} | {v['per_launch_GBps']:.0f} per sweep | "
+      f"{v['per_launch_GBps'] / 80:.0f} per sweep | {bar} |")
+
+
+t12 = "≤ 1e-12 (oracle + twin at n = 30)"
+leg("tiled_mode1", f"configs[1] at n = {n} as `tile = 1` sweeps, interpreter kernel", bar="IEEE-equal")
+leg("tiled_mode1_jit", "same, segments compiled at run time (`tile_jit`)")
+leg("tiled_mode1_jit_relabel", "same + the scheduler relabelling the qubits (`tile_relabel`)")
+leg("tiled_mode1_jit_wide", "**wide tiles** (`tile_wide`: 13-bit register-resident tile, seven free positions), circuit order")
+leg("tiled_mode1_jit_wide_relabel", "wide tiles + relabelling")
+leg("tiled_mode2_jit_fma_relabel", "`tile = 2` + fused multiply-adds + merged diagonal runs + relabelling (11-bit tile)", bar=t12)
+if "tiled_mode2_jit_fma_merge_wide" in ex:
+    leg("tiled_mode2_jit_fma_merge_wide", "**`tile = 2` + fma + merged diagonal runs over wide tiles**", bar=t12)
+leg("fused_k5", "dense fusion (`fuse = 5`): one sweep per fused gate", bar=t12)
+for key, label in (("configs2_qft_n%d" % n, "configs[2] QFT (480 ops)"), ("configs3_clifford_t_n%d" % n, "configs[3] Clifford+T on one GPU (256 ops)"),
+                   ("configs4_grover_iteration_n%d" % n, "configs[4] one Grover iteration (182 ops)"), ("configs4_grover_dense_k3_n%d" % n, "configs[4] Grover, dense-k3 variant (170 ops)")):
+    v = ex[key]
+    L(f"| {label}, n = {n}: gate by gate | HIP kernels | {v['ms']:.0f} | {v['ops'] / v['ms'] * 1e3:.0f} | {v['algorithmic_GBps']:.0f} | {v['algorithmic_GBps'] / 80:.1f} | oracle + twin at n = 30 |")
+    for sub in ("tile1", "tile1_jit", "tile1_jit_relabel", "tile1_jit_wide", "tile1_jit_wide_relabel", "tile2_jit_fma_merge", "tile2_jit_fma_merge_relabel",
+                "tile2_jit_fma_merge_wide", "tile2_jit_fma_merge_wide_relabel"):
+        if sub in v:
+            leg(key, f"  … `{sub}`", sub, bar=t12 if "tile2" in sub else "IEEE-equal")
+f32 = ex["complex64_n%d" % n]
+L(f"| Complex<f32>, the headline circuit gate by gate, n = {n} (8 GiB) | HIP kernels | {f32['ms'] / f32['gates']:.2f} per gate | {f32['gates_per_s']:.0f} | {f32['algorithmic_GBps']:.0f} | "
+  f"{100 * f32['frac_of_8TBps']:.1f} | f32 oracle windows at n = 30 |")
+L(f"| Complex<f32>, configs[1] as `tile = 1` compiled + relabelled | HIP kernels | {f32['mixed_tile1_jit_relabel']['ms']:.1f} | {f32['mixed_tile1_jit_relabel']['gates_per_s']:.0f} | | | 1e-5 |")
+if "mixed_tile1_jit_wide" in f32:
+    L(f"| Complex<f32>, configs[1] as `tile = 1` over wide tiles | HIP kernels | {f32['mixed_tile1_jit_wide']['ms']:.1f} | {f32['mixed_tile1_jit_wide']['gates_per_s']:.0f} | | | 1e-5 (bit-identical to the narrow f32 sweeps) |")
+for name in ("dense k=2 (VALU regs)", "controlled dense k=2, low targets, control above the rows", "2-controlled dense k=3, one low target", "dense k=3 (MFMA f64)", "dense k=4 (MFMA f64)",
+             "dense k=4 high bits (MFMA f64)", "dense k=4 (VALU regs)", "dense k=5 (MFMA f64)", "dense k=5 high bits (MFMA f64)"):
+    if name in ops:
+        k, ms, gb, pc = ops[name]
+        L(f"| {name} | `{k}` | {ms:.2f} | | {gb:.0f} | {pc:.1f} | `tests/test_parity_gpu.py` |")
+for name in ops:
+    if name.startswith("dense k=6 (MFMA") or name.startswith("dense k=7") or name.startswith("dense k=8") or name.startswith("dense k=9") or name.startswith("dense k=10"):
+        k, ms, gb, pc = ops[name]
+        kk = int(name.split("=")[1].split()[0])
+        tf = 8.0 * 2**kk * 2**n / (ms * 1e-3) / 1e12
+        L(f"| {name} | `{k}` | {ms:.1f} | | {tf:.1f} TFLOP/s | **{100 * tf / 78.6:.0f} % of the 78.6 TFLOP/s f64 matrix peak** | 1e-12 vs oracle |")
+for name in ("norm_sqr", "measure_probs k=1", "measure_probs k=3", "measure_probs k=12 top bits", "measure_probs k=16", "soft_measure (2 passes)"):
+    a, b = ops.get(name), ops32.get(name)
+    if a and b:
+        L(f"| {name}: f64 / f32 | reduction | {a[1]:.2f} / {b[1]:.2f} | | {a[2]:.0f} / {b[2]:.0f} | {a[3]:.1f} / {b[3]:.1f} | ≤ 1e-13 |")
+L(f"| first {cpu['sample'].split()[1]} gates of the headline circuit at **n = 28** | CPU oracle ('{cpu['kind']}', gcc -O3 -fopenmp) | {cpu['ms_per_gate']:.0f} per gate | {cpu['gates_per_s']:.1f} | **{cpu['value']:.1f}** | — | "
+  f"{cpu['cores']} threads = the cgroup CPU quota ({cpu['cores_usable']} usable by affinity); {cpu['ns_per_row_per_thread']:.1f} ns per row per thread, thread scaling {100 * cpu['thread_scaling_efficiency']:.0f} % |")
+L("")
+L(f"Dominant kernel (`roofline`): `{roof['kernel']}`, {roof['launches']} launches, {roof['avg_launch_ms']:.3f} ms average (HIP events) = {roof['achieved']:.0f} GB/s = "
+  f"**{100 * roof['frac']:.1f} %**; HBM traffic per launch (`roofline.traffic`, {'STALE: ' if roof.get('traffic_stale') else ''}{roof['traffic_source'].split('(')[0].strip()}): "
+  f"{roof['traffic']:.4e} B against {roof['algorithmic_bytes_per_launch']:.4e} algorithmic = {roof['traffic'] / roof['algorithmic_bytes_per_launch']:.4f}×.")

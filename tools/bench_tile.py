@@ -46,10 +46,10 @@ def main():
     import numpy as np
 
     f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
-    for key in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split"):  # tuning aids (global options)
+    for key in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32"):  # tuning aids (global options)
         if os.environ.get("QIP_" + key.upper()):
             q.set_global_option(key, int(os.environ["QIP_" + key.upper()]))
-    tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split")}
+    tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32")}
     with q.HipState(n, np.complex64 if f32 else np.complex128) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
