@@ -108,6 +108,13 @@ int qip_hip_abi_version(void);
  *                      (profiles/r04_tile_rows.md).
  *   "dist_fold_pack"   1 (default): the gather of a sharded state's remap rides in the store phase of the tile sweep before
  *                      it where it can (qip_hip_dist_stats.packs_folded); 0 = always a sweep of its own.
+ *   "dist_plan_cost"   1 (default): at a remap of a sharded state the leaving qubits are chosen by modelled cost — the count-optimal set
+ *                      (farthest next use) unless the set that keeps the gather out of the wave rows is cheaper over the rest of the
+ *                      circuit (exchange = shard / world bytes per link, free-standing gather = one copy of the shard); 0 = by count alone.
+ *   "sparse_tile"      1 (default): a SparseMatrix on k >= 6 qubits with <= 4 entries per row and 3..7 of its positions outside
+ *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
+ *                      gather (k_sparse_ell).  Same results bit for bit.
+ *   "tile_row_split_f32"  5 (default) / 12: the same choice for Complex<f32> states (measured: no gain, profiles/r04_summary.md).
  *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
  *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
  *                      (profiles/r02_*.md, r03_tile_skeleton.md). */

@@ -66,6 +66,8 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "jit_cache_cap")) return jit_set_cache_cap(value);
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
+  if (key && !strcmp(key, "dist_plan_cost")) { g_dist_plan_cost = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_threads")) {
     if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
     g_jit_threads = value;
@@ -197,7 +199,7 @@ extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) try {
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
     "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_passes",    "k_gather_generic",
-    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits"};
+    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits", "k_sparse_ell", "k_sparse_tile"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
 extern "C" const char* qip_hip_kernel_class_name(int cls) {

@@ -18,13 +18,14 @@
 // 2 GiB per link, ~14 ms); exchanging one bit sends half the shard to ONE peer over one link (~56 ms).  The full
 // exchange is the cheapest one on this topology, and it buys g fresh local qubits instead of one.  What used to cost
 // extra — up to g local swap sweeps to bring the outgoing qubits to the top positions — is now one pack sweep.
-#include "qip_internal.h"
+#include "qip_tile.h"
 #include <dlfcn.h>
 
 #include <map>
 #include <memory>
 #include <mutex>
 
+int64_t g_dist_plan_cost = 1;  // global option "dist_plan_cost": 0 = the leaving qubits by exchange count alone (rounds 1-3)
 int64_t g_dist_fold_pack = 1;  // global option "dist_fold_pack": 0 = the remap always gathers with a sweep of its own
 
 namespace qipd {
@@ -180,67 +181,158 @@ struct DistPlanner {
   uint32_t rank_bit(uint32_t pp) const { return ((((uint32_t)rank) ^ flip) >> (pp - L)) & 1u; }  // the LOGICAL value
   uint64_t local_qubit(uint32_t pp) const { return L - 1 - pp; }  // local qubit index of local physical bit pp
 
-  // The exchange: choose the g logical bits that leave (must stay: `must`), gather them on top, all-to-all.
-  int remap(const std::vector<uint32_t>& must, const std::vector<uint64_t>* next_use, std::vector<Step>* out) {
+  // ---- which g logical bits leave at a remap ------------------------------------------------------------------------------------
+  // Farthest next use first (never used again = infinitely far: the choice that minimises the NUMBER of exchanges), then least
+  // recently used; among equals a qubit that already sits in the top g local positions (no gather at all if all g do), then one
+  // on a high bit position (the gather then moves long contiguous runs).
+  // r4, by cost: the exchange is the expensive part (shard / world bytes per link), but the gather before it is a full sweep of
+  // the shard (k_pack_bits; k_permute_bits when a selected position lies inside a wave row) UNLESS the tile sweep before it can
+  // store its tiles packed (TileStorePerm) — which needs every selected position outside the tile's row positions.  When the
+  // count-optimal choice would gather from a row position, the same rule restricted to the other positions is tried as well;
+  // both are rolled forward over the rest of the circuit (layout only: microseconds) and the cheaper modelled total is kept.
+  struct Choice {
+    std::vector<uint32_t> leaving;  // logical bit positions, leaving[t] goes to slot slot_of[t]
+    std::vector<uint32_t> slot_of;
+    std::vector<uint32_t> sel;      // PACK: sel[slot] = local physical position gathered into local position L-g+slot
+    bool need_pack = false;
+    bool rows = false;              // a gathered position is one of the tile's row positions: the gather cannot ride in a sweep
+  };
+  uint32_t row_p5() const { return tile_p5(dtype, L); }
+  bool choose(const std::vector<uint32_t>& ph, const std::vector<uint64_t>& lu, const std::vector<uint32_t>& must,
+              const std::vector<uint64_t>* next_use, bool avoid_rows, Choice* c) const {
     std::vector<uint32_t> cand;
+    const uint32_t p5 = row_p5();
     for (uint32_t p = 0; p < n; ++p)
-      if (phys[p] < L && std::find(must.begin(), must.end(), p) == must.end()) cand.push_back(p);
-    if (cand.size() < g) return fail(QIP_ERR_UNSUPPORTED, "op touches too many qubits to keep local on this shard size");
-    // farthest next use first (never used again = infinitely far), then least recently used; among equals prefer a
-    // qubit that already sits in the top g local positions (no pack sweep if all g do), then one on a high bit
-    // position (the pack sweep then moves long contiguous runs)
+      if (ph[p] < L && std::find(must.begin(), must.end(), p) == must.end() &&
+          !(avoid_rows && ph[p] < L - g && tile_is_low(ph[p], p5)))
+        cand.push_back(p);
+    if (cand.size() < g) return false;
     auto nu = [&](uint32_t p) { return next_use ? (*next_use)[p] : ~0ull; };
     std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
       if (nu(a) != nu(b)) return nu(a) > nu(b);
-      if (last_use[a] != last_use[b]) return last_use[a] < last_use[b];
-      return phys[a] > phys[b];
+      if (lu[a] != lu[b]) return lu[a] < lu[b];
+      return ph[a] > ph[b];
     });
-    std::vector<uint32_t> leaving(cand.begin(), cand.begin() + g);
+    c->leaving.assign(cand.begin(), cand.begin() + g);
     // target slot L-g+t for leaving[t]: keep the ones already on top where they are
-    std::vector<uint32_t> slot_of(g, n);
+    c->slot_of.assign(g, n);
     std::vector<char> slot_taken(g, 0);
     for (uint32_t t = 0; t < g; ++t)
-      if (phys[leaving[t]] >= L - g) {
-        slot_of[t] = phys[leaving[t]] - (L - g);
-        slot_taken[slot_of[t]] = 1;
+      if (ph[c->leaving[t]] >= L - g) {
+        c->slot_of[t] = ph[c->leaving[t]] - (L - g);
+        slot_taken[c->slot_of[t]] = 1;
       }
-    bool need_pack = false;
+    c->need_pack = false;
+    c->rows = false;
     for (uint32_t t = 0; t < g; ++t)
-      if (slot_of[t] == n) {
-        need_pack = true;
+      if (c->slot_of[t] == n) {
+        c->need_pack = true;
+        c->rows = c->rows || tile_is_low(ph[c->leaving[t]], p5);
         for (uint32_t sl = 0; sl < g; ++sl)
           if (!slot_taken[sl]) {
-            slot_of[t] = sl;
+            c->slot_of[t] = sl;
             slot_taken[sl] = 1;
             break;
           }
       }
-    if (need_pack) {
-      Step st;
-      st.kind = Step::PACK;
-      st.sel.assign(g, 0);
-      for (uint32_t t = 0; t < g; ++t) st.sel[slot_of[t]] = phys[leaving[t]];
-      // new layout: the selected positions on top (in slot order), every other local bit keeps its relative order
+    c->sel.assign(g, 0);
+    for (uint32_t t = 0; t < g; ++t) c->sel[c->slot_of[t]] = ph[c->leaving[t]];
+    return true;
+  }
+  // the layout after the gather (if any) and the exchange
+  void layout_after(std::vector<uint32_t>& ph, const Choice& c) const {
+    if (c.need_pack) {
+      // the selected positions on top (in slot order), every other local bit keeps its relative order
       std::vector<uint32_t> newpos(L, 0);
       uint32_t next = 0;
       for (uint32_t pp = 0; pp < L; ++pp) {
-        const auto it = std::find(st.sel.begin(), st.sel.end(), pp);
-        if (it != st.sel.end()) newpos[pp] = L - g + (uint32_t)(it - st.sel.begin());
+        const auto it = std::find(c.sel.begin(), c.sel.end(), pp);
+        if (it != c.sel.end()) newpos[pp] = L - g + (uint32_t)(it - c.sel.begin());
         else newpos[pp] = next++;
       }
       for (uint32_t p = 0; p < n; ++p)
-        if (phys[p] < L) phys[p] = newpos[phys[p]];
+        if (ph[p] < L) ph[p] = newpos[ph[p]];
+    }
+    // chunk c of rank r <-> chunk r of rank c: local bit L-g+j and rank bit L+j trade places
+    std::vector<uint32_t> at(n, n);
+    for (uint32_t p = 0; p < n; ++p) at[ph[p]] = p;
+    for (uint32_t j = 0; j < g; ++j) {
+      const uint32_t a = at[L - g + j], b = at[L + j];
+      ph[a] = L + j;
+      ph[b] = L - g + j;
+    }
+  }
+  // modelled milliseconds: one exchange = shard / world bytes over each xGMI link at 153 GB/s; one gather that does
+  // not ride in a sweep = one read + one write of the shard at the measured copy rate
+  double exchange_ms() const { return 1e3 * ((double)(dtype == QIP_C64 ? 16 : 8) * (double)(1ull << L) / (double)world) / 153e9; }
+  double pack_ms() const { return 1e3 * (2.0 * (double)(dtype == QIP_C64 ? 16 : 8) * (double)(1ull << L)) / 6.2e12; }
+  // what the rest of the circuit costs in remaps when the remap before op `from` is chosen with / without the row positions
+  // (later remaps: the count-optimal rule); layout only.  `prev_local`: a local op precedes (its sweep can carry the gather).
+  const std::vector<OpInfo>* all_infos = nullptr;
+  const std::vector<std::vector<uint64_t>>* all_next = nullptr;
+  uint64_t cur_op = 0;
+  static constexpr uint64_t kRolloutHorizon = 4096;
+  double rollout(uint64_t from, bool first_avoid, bool prev_local, uint64_t* exchanges) const {
+    std::vector<uint32_t> ph = phys;
+    std::vector<uint64_t> lu = last_use;
+    uint64_t clk = clock;
+    double cost = 0;
+    uint64_t ex = 0;
+    const uint64_t end = std::min<uint64_t>(all_infos->size(), from + kRolloutHorizon);
+    for (uint64_t i = from; i < end; ++i) {
+      const OpInfo& info = (*all_infos)[i];
+      if (i > from) clk += 1;  // (the caller's clock already counts op `from`)
+      if (info.antidiag1q && ph[n - 1 - info.tgt[0]] >= L) {
+        lu[n - 1 - info.tgt[0]] = clk;
+        continue;
+      }
+      if (info.relabel_swap) {
+        const uint32_t h = (uint32_t)info.tgt.size() / 2;
+        for (uint32_t j = 0; j < h; ++j) std::swap(ph[n - 1 - info.tgt[j]], ph[n - 1 - info.tgt[h + j]]);
+        continue;
+      }
+      bool needs = false;
+      for (uint32_t p : info.nondiag_bits) needs = needs || ph[p] >= L;
+      if (needs) {
+        Choice c;
+        if (!choose(ph, lu, info.nondiag_bits, &(*all_next)[i], i == from && first_avoid, &c)) return 1e300;
+        ex += 1;
+        cost += exchange_ms();
+        if (c.need_pack && !(prev_local && !c.rows)) cost += pack_ms();
+        layout_after(ph, c);
+        prev_local = false;
+      }
+      for (uint32_t qb : info.ctrl) lu[n - 1 - qb] = clk;
+      for (uint32_t qb : info.tgt) lu[n - 1 - qb] = clk;
+      prev_local = true;
+    }
+    if (exchanges) *exchanges = ex;
+    return cost;
+  }
+
+  // The exchange: choose the g logical bits that leave (must stay: `must`), gather them on top, all-to-all.
+  int remap(const std::vector<uint32_t>& must, const std::vector<uint64_t>* next_use, std::vector<Step>* out) {
+    Choice ch;
+    if (!choose(phys, last_use, must, next_use, false, &ch))
+      return fail(QIP_ERR_UNSUPPORTED, "op touches too many qubits to keep local on this shard size");
+    if (ch.need_pack && ch.rows && all_infos && g_dist_plan_cost) {
+      Choice alt;
+      const bool prev_local = !out->empty() && out->back().kind == Step::LOCAL;
+      if (choose(phys, last_use, must, next_use, true, &alt) && !alt.rows) {
+        const double cost_a = rollout(cur_op, false, prev_local, nullptr), cost_b = rollout(cur_op, true, prev_local, nullptr);
+        if (cost_b < cost_a) ch = alt;
+      }
+    }
+    if (ch.need_pack) {
+      Step st;
+      st.kind = Step::PACK;
+      st.sel = ch.sel;
       out->push_back(std::move(st));
     }
+    layout_after(phys, ch);
     Step ex;
     ex.kind = Step::EXCHANGE;
     out->push_back(std::move(ex));
-    // chunk c of rank r <-> chunk r of rank c: local bit L-g+j and rank bit L+j trade places
-    for (uint32_t j = 0; j < g; ++j) {
-      const uint32_t a = logical_at(L - g + j), b = logical_at(L + j);
-      phys[a] = L + j;
-      phys[b] = L - g + j;
-    }
     // the old rank bits are local positions L-g .. L-1 now and hold the senders' PHYSICAL rank values: where a flip was
     // pending, physical and logical differ — one local X puts that right; the new rank bits start unflipped
     for (uint32_t j = 0; j < g; ++j)
@@ -421,8 +513,16 @@ struct DistPlanner {
         for (uint32_t p : infos[i].nondiag_bits) cur[p] = i;
       nxt[i] = cur;
     }
-    for (uint64_t i = 0; i < count; ++i) QCHK(step(infos[i], &nxt[i], out));
-    return QIP_OK;
+    all_infos = &infos;
+    all_next = &nxt;
+    int rc = QIP_OK;
+    for (uint64_t i = 0; i < count && rc == QIP_OK; ++i) {
+      cur_op = i;
+      rc = step(infos[i], &nxt[i], out);
+    }
+    all_infos = nullptr;
+    all_next = nullptr;
+    return rc;
   }
 };
 
@@ -1161,7 +1261,26 @@ extern "C" const char* qip_hip_dist_debug_plan(uint32_t n, int dtype, int rank, 
     }
     json += "],\"phys\":[";
     for (uint32_t p = 0; p < n; ++p) json += (p ? "," : "") + std::to_string(pl.phys[p]);
-    json += "],\"flip\":" + std::to_string(pl.flip) + "}";
+    json += "],\"flip\":" + std::to_string(pl.flip);
+    {  // the planner's cost model (ms): what an exchange and a gather that does not ride in a tile sweep are priced at, and which
+       // of this plan's gathers select a position inside a wave row (those can never ride)
+      uint64_t ex = 0, packs = 0, rows = 0;
+      const uint32_t p5 = pl.row_p5();
+      for (const auto& st : steps) {
+        ex += st.kind == qipd::Step::EXCHANGE;
+        if (st.kind == qipd::Step::PACK) {
+          packs += 1;
+          bool r = false;
+          for (uint32_t p : st.sel) r = r || tile_is_low(p, p5);
+          rows += r;
+        }
+      }
+      char buf[256];
+      snprintf(buf, sizeof buf, ",\"model\":{\"exchange_ms\":%.4f,\"pack_ms\":%.4f,\"exchanges\":%llu,\"packs\":%llu,\"packs_from_row_positions\":%llu,\"row_p5\":%u}",
+               pl.exchange_ms(), pl.pack_ms(), (unsigned long long)ex, (unsigned long long)packs, (unsigned long long)rows, p5);
+      json += buf;
+    }
+    json += "}";
     return json.c_str();
   } catch (const std::exception& e) {
     fail(QIP_ERR_INVALID, "internal error: %s", e.what());

@@ -1125,6 +1125,94 @@ __device__ __forceinline__ uint64_t tile_block_base(uint64_t blk, const Ins& ins
   return w;
 }
 __device__ __forceinline__ uint32_t tile_lane_off(uint32_t lane, uint32_t p5) { return (lane & 31u) | ((lane >> 5) << p5); }
+
+// ---- SparseMatrix on k >= 6 qubits, in place through an LDS-staged tile (r4) ---------------------------------------------
+// k_sparse_ell gathers straight from HBM: a row with two stored entries reads two input rows (48 instead of 32 bytes per
+// amplitude when the partner rows are too far apart for the L2 to hold, 52 % of the HBM peak at n = 30), and an op that
+// touches positions inside a wave row gathers 16-byte pieces.  Here a block stages the op's whole GROUP beside the wave row:
+// the tile is the six low positions (the lane at load / store time, tile_lane_off: 0..4 and p5) plus the op's `kh` other
+// positions, 2^(6+kh) amplitudes in LDS (kh <= 6 for Complex<f64> at two blocks per CU, 7 = 128 KiB at one), loaded and
+// stored as whole wave rows exactly like a tile sweep, every input of every row of the group present once.  A lane owns 8
+// rows of the tile; its output row folds the stored entries in stored order from 0 (qubit_iterators.rs:60-102, ops.rs:104-110)
+// out of LDS, so the result is bit-equal to the literal kernel's.  The table is indexed by m' = the op's lane bits (ascending)
+// then the tile row; `slot` = the stored column's place in the tile with the lane's other bits zero.
+// Controls: outside the tile they are taken off the grid (`ins` holds them as ones), inside the lane they are a predicate.
+struct SparseTileDesc {
+  uint32_t kh;        // the op's positions outside the tile's low six, ascending = tile bits 6 ..
+  uint32_t hpos[8];
+  uint32_t p5;        // position of lane bit 5 (tile_block_base)
+  uint32_t low_op;    // lane bits that are op positions
+  uint32_t nlow;      // how many
+  uint32_t low_ctl;   // lane bits that are controls (all must read 1 for the row to be touched)
+};
+
+template <typename T, int E, bool NT>
+__global__ void k_sparse_tile(amp_t<T>* __restrict__ st, uint64_t ntiles, Ins ins, SparseTileDesc d,
+                              const uint32_t* __restrict__ nnz, const uint32_t* __restrict__ slot,
+                              const amp_t<T>* __restrict__ val) {
+  using A = amp_t<T>;
+  constexpr int R = 8;  // rows of the tile per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char sparse_tile_raw[];
+  A* tile = reinterpret_cast<A*>(sparse_tile_raw);
+  const uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (blk >= ntiles) return;
+  const uint32_t lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+  const uint32_t wave_v = threadIdx.x >> 6;                           // as the lanes see it: indexes the table with VECTOR loads (below)
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(wave_v);       // wave-uniform: the row-address arithmetic is scalar
+  const uint64_t base = tile_block_base(blk, ins, d.p5) | tile_lane_off(lane, d.p5);
+  // row i * nw + wave of the tile: the wave number fills the low kh - 3 tile-row bits, i the top three
+  uint64_t offw = 0;
+  for (uint32_t j = 0; j + 3 < d.kh; ++j) offw |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
+  const uint64_t h0 = 1ull << d.hpos[d.kh - 3], h1 = 1ull << d.hpos[d.kh - 2], h2 = 1ull << d.hpos[d.kh - 1];
+  A x[R];
+  uint64_t g[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    g[i] = base | offw | ((i & 1) ? h0 : 0ull) | ((i & 2) ? h1 : 0ull) | ((i & 4) ? h2 : 0ull);
+    x[i] = ldg<NT>(st + g[i]);
+  }
+  uint32_t ml = 0;  // the op's lane bits, packed
+  for (uint32_t b = 0, o = 0; b < 6u; ++b)
+    if ((d.low_op >> b) & 1u) ml |= ((lane >> b) & 1u) << o++;
+  const uint32_t keep = lane & ~d.low_op;
+  const bool active = (lane & d.low_ctl) == d.low_ctl;
+  // The rows' table entries do not depend on the tile.  One entry per row: fetched while the tile's loads are in flight.  Wider rows
+  // are fetched after the barrier (8 rows x E entries ahead of time cost more registers than the occupancy can spare).  Always
+  // through vector loads, even where a wave's 64 lanes share m — measured at n = 30, k = 6, two entries per row: vector loads after
+  // the barrier 74.7 % of the HBM peak, scalar loads after it 71.2 % (they share the LDS reads' counter), scalar loads ahead 68.0 %.
+  constexpr bool PRE = E == 1;
+  uint32_t cnt[R], sl[R][E];
+  A v[R][E];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const uint32_t m = ml | (((uint32_t)i * nw + wave_v) << d.nlow);
+      cnt[i] = nnz[m];
+      sl[i][0] = slot[m];
+      v[i][0] = val[m];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) tile[(((uint32_t)i * nw + wave) << 6) | lane] = x[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const uint32_t m = ml | (((uint32_t)i * nw + wave_v) << d.nlow);
+    if constexpr (!PRE) cnt[i] = nnz[m];
+    A acc = czero<A>();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if constexpr (!PRE) {
+        sl[i][e] = slot[m * E + e];  // (slots beyond a row's count hold 0: a harmless read, not added)
+        v[i][e] = val[m * E + e];
+      }
+      const A xx = tile[sl[i][e] | keep];
+      if ((uint32_t)e < cnt[i]) acc = cadd(acc, cmul(v[i][e], xx));
+    }
+    if (active) stg<NT>(st + g[i], acc);
+  }
+}
+
 // A tile sweep that stores its tiles ELSEWHERE and permuted (r4): the multi-GPU remap gathers the g leaving qubits' bit positions
 // into the top g local positions before the all-to-all — a full out-of-place sweep of its own (k_pack_bits) unless the sweep
 // that precedes it writes its rows straight to their packed places: destination index = the source index with the bits at

@@ -992,6 +992,113 @@ static int launch_sparse_ell(qip_hip_state* s, const Plan& p, const FlatOp& f, b
   return QIP_OK;
 }
 
+// SparseMatrix on k >= 6 distinct qubits (optionally controlled), at most four entries per row, whose positions outside the
+// wave row number 3..7: in place through k_sparse_tile (the group staged in LDS beside the row).  *done = false: not this shape.
+int64_t g_sparse_tile = 1;  // global option "sparse_tile": 0 = always the out-of-place gather (k_sparse_ell), for A/B runs
+template <typename T>
+static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
+  *done = false;
+  if (!g_sparse_tile) return QIP_OK;
+  const uint32_t k = f.n_op;
+  const uint32_t p5 = tile_p5_of<T>(s->n);
+  SparseTileDesc d;
+  memset(&d, 0, sizeof d);
+  d.p5 = p5;
+  std::vector<uint32_t> hp, ctl_out;
+  for (uint32_t t : p.opos) {
+    if (tile_is_low(t, p5)) d.low_op |= 1u << tile_low_bit(t);
+    else hp.push_back(t);
+  }
+  for (uint32_t c : p.cpos) {
+    if (tile_is_low(c, p5)) d.low_ctl |= 1u << tile_low_bit(c);
+    else ctl_out.push_back(c);
+  }
+  std::sort(hp.begin(), hp.end());
+  d.kh = (uint32_t)hp.size();
+  d.nlow = (uint32_t)__builtin_popcount(d.low_op);
+  // 2^(6+kh) amplitudes per tile: up to 64 KiB (two blocks per CU) — Complex<f64> kh = 7 is one 128-KiB block of 1024 lanes per CU
+  if (d.kh < 3 || d.kh > 7 || s->n < 6 + d.kh + (uint32_t)ctl_out.size() + 2) return QIP_OK;
+  const uint64_t rows = 1ull << k;
+  const uint64_t* rp = f.inner->sparse_rowptr;
+  uint64_t widest = 0;
+  for (uint64_t r = 0; r < rows; ++r) widest = std::max<uint64_t>(widest, rp[r + 1] - rp[r]);
+  if (widest > 4) return QIP_OK;
+  const uint32_t E = widest <= 1 ? 1u : (widest <= 2 ? 2u : 4u);
+  for (uint32_t j = 0; j < d.kh; ++j) d.hpos[j] = hp[j];
+  // m' bit b <- op index order[b]: the op's lane bits ascending, then its tile rows ascending
+  std::vector<uint32_t> order;
+  for (uint32_t b = 0; b < 6; ++b)
+    if ((d.low_op >> b) & 1u)
+      for (uint32_t j = 0; j < k; ++j)
+        if (tile_is_low(p.opos[j], p5) && tile_low_bit(p.opos[j]) == b) order.push_back(j);
+  for (uint32_t h : hp)
+    for (uint32_t j = 0; j < k; ++j)
+      if (p.opos[j] == h) order.push_back(j);
+  std::vector<uint32_t> tbit(k);  // where op index j's bit lives in a tile index
+  for (uint32_t j = 0; j < k; ++j) {
+    if (tile_is_low(p.opos[j], p5)) tbit[j] = tile_low_bit(p.opos[j]);
+    else tbit[j] = 6u + (uint32_t)(std::find(hp.begin(), hp.end(), p.opos[j]) - hp.begin());
+  }
+  std::vector<uint32_t> nnz(rows), slot(rows * E, 0);
+  std::vector<amp_t<T>> val(rows * E, mk<T>(0, 0));
+  const amp_t<T>* sv = (const amp_t<T>*)f.inner->sparse_vals;
+  for (uint64_t mp = 0; mp < rows; ++mp) {
+    uint64_t m = 0;  // stored row: op index j is sub-index bit k-1-j (matrix_ops.rs:12-21)
+    for (uint32_t b = 0; b < k; ++b) m |= ((mp >> b) & 1ull) << (k - 1 - order[b]);
+    nnz[mp] = (uint32_t)(rp[m + 1] - rp[m]);
+    for (uint64_t q = rp[m]; q < rp[m + 1]; ++q) {
+      const uint64_t c = f.inner->sparse_cols[q];
+      uint32_t o = 0;
+      for (uint32_t j = 0; j < k; ++j) o |= (uint32_t)((c >> (k - 1 - j)) & 1ull) << tbit[j];
+      slot[mp * E + (q - rp[m])] = o;
+      val[mp * E + (q - rp[m])] = sv[q];
+    }
+  }
+  const size_t b_nnz = rows * 4, b_slot = rows * E * 4, b_val = rows * E * sizeof(amp_t<T>);
+  const size_t o_slot = (b_nnz + 15) & ~(size_t)15, o_val = (o_slot + b_slot + 15) & ~(size_t)15;
+  QCHK(ensure_arena(s, o_val + b_val + 16));
+  QCHK(arena_upload(s, nnz.data(), b_nnz, 0));
+  QCHK(arena_upload(s, slot.data(), b_slot, o_slot));
+  QCHK(arena_upload(s, val.data(), b_val, o_val));
+  const uint32_t* dn = (const uint32_t*)s->arena;
+  const uint32_t* dslot = (const uint32_t*)((char*)s->arena + o_slot);
+  const amp_t<T>* dval = (const amp_t<T>*)((char*)s->arena + o_val);
+  // the block base: the tile's high positions and the outside controls opened, the controls reading 1 (tile_block_base works in
+  // the space where p5 and 5 have traded places)
+  std::vector<uint32_t> opened = hp;
+  for (uint32_t c : ctl_out) opened.push_back(c);
+  uint64_t ones = 0;
+  for (uint32_t& o : opened)
+    if (o == 5u) o = p5;
+  for (uint32_t c : ctl_out) ones |= 1ull << (c == 5u ? p5 : c);
+  const Ins ins = make_ins(opened, ones);
+  const uint64_t ntiles = 1ull << (s->n - 6 - d.kh - (uint32_t)ctl_out.size());
+  const unsigned threads = 1u << (d.kh + 3);
+  const size_t lds = sizeof(amp_t<T>) << (6 + d.kh);
+  const dim3 grid = grid2d(ntiles, 1);
+  amp_t<T>* st = (amp_t<T>*)s->cur;
+  const bool nt = use_nt(s);
+#define SPT2(EE, NTV)                                                                                                             \
+  do {                                                                                                                             \
+    if (lds > 64 * 1024)                                                                                                           \
+      HIPCHK(hipFuncSetAttribute((const void*)k_sparse_tile<T, EE, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+    hipLaunchKernelGGL((k_sparse_tile<T, EE, NTV>), grid, dim3(threads), lds, s->stream, st, ntiles, ins, d, dn, dslot, dval);    \
+  } while (0)
+#define SPT(EE)                  \
+  do {                           \
+    if (nt) SPT2(EE, true);      \
+    else SPT2(EE, false);        \
+  } while (0)
+  if (E == 1) SPT(1);
+  else if (E == 2) SPT(2);
+  else SPT(4);
+#undef SPT2
+#undef SPT
+  HIPCHK(hipGetLastError());
+  *done = true;
+  return QIP_OK;
+}
+
 template <typename T>
 int apply_op_t(qip_hip_state* s, const qip_op* op) {
   if (s->jit_prepare) return QIP_OK;  // compiling a program's segment kernels: single ops have nothing to prepare
@@ -1094,13 +1201,27 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
     case KC_DIAG: rc = launch_diag<T, amp_t<T>>(s, s->n, p, st, &rec.cls); break;
     case KC_SWAP_BITS: rc = launch_swap<T, amp_t<T>>(s, s->n, p, st); break;
     case KC_GATE_KQ: rc = launch_kq<T>(s, p, st, &rec.cls, f); break;
-    case KC_SPARSE_KQ: rc = launch_sparse_kq<T>(s, p, f, st); break;
+    case KC_SPARSE_KQ: {
+      // k = 4, 5 with few entries per row and >= 3 positions outside the wave row: the LDS-staged tile form (whole wave rows, the
+      // table through scalar loads) runs ahead of one-group-per-lane; the very same fold, bit-equal
+      bool done = false;
+      // (Complex<f32>, measured at n = 30: k = 5 one group per lane 67.6 % against 63.2 % — stays; k = 4 even)
+      if (f.n_op >= 4 && std::is_same<T, double>::value && !s->capture_staging) rc = launch_sparse_tile<T>(s, p, f, &done);
+      if (rc == QIP_OK && done) rec.cls = KC_SPARSE_TILE;
+      else if (rc == QIP_OK) rc = launch_sparse_kq<T>(s, p, f, st);
+      break;
+    }
     default: {
       if (f.inner->kind == QIP_OP_SPARSE && f.distinct && f.n_op >= 6 && !s->force_generic && !g_force_generic && !s->capture_staging) {
         bool done = false;
+        rc = launch_sparse_tile<T>(s, p, f, &done);
+        if (rc != QIP_OK || done) {
+          rec.cls = KC_SPARSE_TILE;
+          break;
+        }
         rc = launch_sparse_ell<T>(s, p, f, &done);
         if (rc != QIP_OK || done) {
-          rec.cls = KC_SPARSE_KQ;
+          rec.cls = KC_SPARSE_ELL;
           break;
         }
       }

@@ -47,6 +47,32 @@ def test_planner_at_bench_size_without_any_device():
         assert sum(1 for t, _ in seqs[0] if t == "pack") <= ex
 
 
+def test_planner_chooses_the_leaving_qubits_by_modelled_cost():
+    """r4: when the count-optimal leaving set (farthest next use) would gather from a position inside a wave row — a gather
+    that can never ride in the preceding tile sweep's store — the planner also rolls the rest of the circuit forward with the row
+    positions excluded and keeps the cheaper modelled total (exchange = shard / world bytes per link at 153 GB/s, free-standing
+    gather = one copy of the shard).  Never more exchanges; fewer gathers from row positions; option 0 = the old rule."""
+    rows = {}
+    for name, n, world, ops in (("grover", 33, 8, circuits.c5_grover_iteration(33)),
+                                ("clifford_t", 32, 4, circuits.c4_clifford_t(32, 256)),
+                                ("mixed_x4", 32, 4, circuits.c2_random_circuit(32, 1024, seed=5)),
+                                ("qft", 33, 8, circuits.c3_qft(33))):
+        try:
+            q.set_global_option("dist_plan_cost", 0)
+            old = sharded.debug_plan(n, 0, world, ops)["model"]
+        finally:
+            q.set_global_option("dist_plan_cost", 1)
+        plans = [sharded.debug_plan(n, r, world, ops) for r in (0, world - 1)]
+        new = plans[0]["model"]
+        assert [s for s in plans[0]["steps"] if s["t"] != "local"] == [s for s in plans[1]["steps"] if s["t"] != "local"]  # same collectives on every rank
+        cost = lambda m: m["exchanges"] * m["exchange_ms"] + m["packs_from_row_positions"] * m["pack_ms"]
+        assert new["exchanges"] <= old["exchanges"] and cost(new) <= cost(old), (name, old, new)
+        rows[name] = (old["packs_from_row_positions"], new["packs_from_row_positions"])
+        g, L = plans[0]["g"], plans[0]["L"]
+        assert new["row_p5"] == 11 and abs(new["exchange_ms"] - 1e3 * 16 * 2**L / world / 153e9) < 1e-3
+    assert rows["grover"] == (2, 0) and rows["clifford_t"][1] < rows["clifford_t"][0] and rows["mixed_x4"][1] < rows["mixed_x4"][0], rows
+
+
 def test_pack_bits_model_and_invalid_worlds():
     x = np.arange(64, dtype=np.complex128)
     y = sharded.pack_bits_numpy(x, 6, [1, 4])  # bits 1 and 4 become bits 4 and 5

@@ -297,7 +297,7 @@ def test_sparse_in_place_kernel(O):
                     st.apply_op(o)
                     assert st.device_ptr() == p0  # in place: the buffers were not swapped
                     got = st.download()
-                    assert "k_sparse_kq" in st.profile(), st.profile()
+                    assert "k_sparse_kq" in st.profile() or "k_sparse_tile" in st.profile(), st.profile()  # (r4: k = 4, 5 with narrow rows may take the tile form)
                 assert np.array_equal(got, want), (k, trial, repr(o))
         xf = rand_state(n, 8, np.complex64)
         rows = [[(int(c), complex(rng.standard_normal(), rng.standard_normal())) for c in rng.integers(0, 1 << k, size=2)] for _ in range(1 << k)]
@@ -1521,6 +1521,12 @@ def _special_gates(n, rng):
         ("dense7_streamed_mfma", q.make_matrix_op([0, 2, n - 20, n - 7, n - 1, 7, n - 12], rand_unitary(7, rng).ravel()), False),
         ("diag2", q.make_matrix_op([0, n - 2], np.diag([ph, ph.conjugate(), 1j, -1]).ravel()), True),
         ("sparse2", q.make_sparse_matrix_op([n - 1, 0], [[(0, 0.6), (1, 0.8j)], [(1, 0.6), (0, 0.8j)], [(3, 1j)], [(2, -1)]]), True),
+        # k >= 6 SparseMatrix: the group staged in LDS beside the wave row (k_sparse_tile, r4) — all positions high / one in the row
+        ("sparse6_two_per_row_tile", q.make_sparse_matrix_op([0, n // 2, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), True),
+        ("sparse8_perm_phase_tile", q.make_sparse_matrix_op([0, 3, n // 2, 7, n - 1, 11, n - 9, 20],
+                                                            [[(int(c), complex(np.exp(0.1j * r)))] for r, c in enumerate(np.random.default_rng(1).permutation(256))]), True),
+        # (three stored entries per row, one of them a stored zero: nothing is filtered, and the op stays unitary)
+        ("csparse6_tile", q.make_control_op([1, n - 2], q.make_sparse_matrix_op([0, n // 2, 5, n - 12, 9, n - 4], [[(r ^ 33, 0.8j), ((r * 7 + 3) % 64, 0.0), (r, 0.6)] for r in range(64)])), True),
     ]
 
 
@@ -2179,7 +2185,17 @@ def test_sparse_on_many_qubits_out_of_place_ell_kernel(O, dtype):
         ("four_per_row7_ragged", q.make_sparse_matrix_op([4, 1, 16, 9, 13, 0, 7], rand_rows(7, 4, phases=False))),
         ("controlled6", q.make_control_op([3, 17], q.make_sparse_matrix_op([0, 6, 10, 12, 15, 1], rand_rows(6, 3)))),
         ("five_per_row6_literal", q.make_sparse_matrix_op([2, 17, 8, 0, 11, 5], rand_rows(6, 5))),
+        # r4, k_sparse_tile's corners (qubit q is index position n-1-q; the wave row is positions 0..4 and 11 for Complex<f64>,
+        # 0..5 for Complex<f32>): seven positions outside the row (128 KiB of LDS in f64), three, the row's split position as an
+        # op bit and as a control, position 5 as an op bit, every op bit but three inside the row, controls inside and outside
+        ("tile_kh7", q.make_sparse_matrix_op([17, 0, 9, 3, 11, 5, 1, 2], perm_phase)),
+        ("tile_kh3", q.make_sparse_matrix_op([17, 16, 15, 1, 9, 4], rand_rows(6, 2))),
+        ("tile_split_position_op", q.make_sparse_matrix_op([6, 0, 12, 3, 9, 1], rand_rows(6, 4))),
+        ("tile_split_position_ctl", q.make_control_op([6, 12], q.make_sparse_matrix_op([0, 2, 4, 8, 10, 17], rand_rows(6, 2)))),
+        ("tile_ctl_in_row_and_out", q.make_control_op([15, 1, 13], q.make_sparse_matrix_op([0, 2, 4, 8, 10, 17, 16], rand_rows(7, 3)))),
+        ("ell_only_two_outside", q.make_sparse_matrix_op([17, 16, 15, 14, 13, 0, 1], rand_rows(7, 2))),
     ]
+    tile_cases = {"perm_phase8", "two_per_row6", "four_per_row7_ragged", "controlled6"} | {c[0] for c in cases if c[0].startswith("tile_")}
     with q.HipState(n, dtype) as st:
         st.set_option("profile", 1)
         for name, op in cases:
@@ -2191,6 +2207,29 @@ def test_sparse_on_many_qubits_out_of_place_ell_kernel(O, dtype):
             assert np.array_equal(got, want), name
             prof = st.profile()
             assert ("k_gather_generic" in prof) == (name == "five_per_row6_literal"), (name, prof)
+            assert ("k_sparse_tile" in prof) == (name in tile_cases), (name, prof)
+            assert ("k_sparse_ell" in prof) == (name not in tile_cases and name != "five_per_row6_literal"), (name, prof)
+        # the out-of-place gather on the same ops (global option sparse_tile = 0): the very same bits
+        q.set_global_option("sparse_tile", 0)
+        try:
+            for name, op in cases:
+                if name not in tile_cases:
+                    continue
+                st.upload(x)
+                st.profile_reset()
+                st.apply_op(op)
+                assert np.array_equal(st.download(), O.apply_ops_in_place(n, [op], x.copy())), name
+                assert "k_sparse_ell" in st.profile(), name
+        finally:
+            q.set_global_option("sparse_tile", 1)
+    # the smallest state the tile form takes (6 + kh + outside controls + 2 positions), and one below it
+    for nn in (11, 12, 13):
+        xs = circuits.random_state(nn, seed=nn, dtype=dtype)
+        op = q.make_control_op([0], q.make_sparse_matrix_op([1, 2, 3, nn - 1, nn - 2, 5], rand_rows(6, 2)))
+        with q.HipState(nn, dtype) as st:
+            st.upload(xs)
+            st.apply_op(op)
+            assert np.array_equal(st.download(), O.apply_ops_in_place(nn, [op], xs.copy())), nn
 
 
 def test_soft_measure_map_sample_sweep_f64_and_f32(O):

@@ -87,11 +87,17 @@ def main():
         ("sparse k=2 (in place)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {}),
         ("sparse k=2 (literal gather)", q.make_sparse_matrix_op([hi, mid], [[(1, 1j)], [(0, 1.0)], [(3, 1.0)], [(2, -1.0)]]), {"force_generic": 1}),
         ("sparse k=4, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7], [[(r, 0.6), (r ^ 5, 0.8j)] for r in range(16)]), {}),
+        ("sparse k=4, 2 entries per row (one group per lane)", q.make_sparse_matrix_op([hi, mid, 5, 7], [[(r, 0.6), (r ^ 5, 0.8j)] for r in range(16)]), {"_sparse_tile": 0}),
         ("sparse k=5, 2 entries per row (in place)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(32)]), {}),
+        ("sparse k=5, 2 entries per row (one group per lane)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(32)]), {"_sparse_tile": 0}),
         ("sparse k=16 identity, one entry per row (state_bench.rs:380-393 shape)", q.make_sparse_matrix_op(list(range(16)), [[(r, 1.0)] for r in range(1 << 16)]), {}),
         ("sparse k=16 identity on the low 16 bits", q.make_sparse_matrix_op(list(range(n - 16, n)), [[(r, 1.0)] for r in range(1 << 16)]), {}),
         ("sparse k=8 permutation x phase, scattered bits", q.make_sparse_matrix_op([hi, 3, mid, 7, lo, 11, n - 9, 20], [[(int(c), complex(np.exp(0.1j * r)))] for r, c in enumerate(np.random.default_rng(1).permutation(256))]), {}),
         ("sparse k=6, 2 entries per row", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), {}),
+        ("sparse k=8 permutation x phase, scattered bits (out-of-place gather)", q.make_sparse_matrix_op([hi, 3, mid, 7, lo, 11, n - 9, 20], [[(int(c), complex(np.exp(0.1j * r)))] for r, c in enumerate(np.random.default_rng(1).permutation(256))]), {"_sparse_tile": 0}),
+        ("sparse k=6, 2 entries per row (out-of-place gather)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), {"_sparse_tile": 0}),
+        ("sparse k=7, 4 entries per row, two positions in the wave row", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, lo, lo - 3], [[(r, 0.5), (r ^ 9, 0.5j), (r ^ 64, -0.5), ((r * 5 + 1) % 128, 0.5)] for r in range(128)]), {}),
+        ("controlled sparse k=6, 2 entries per row", q.make_control_op([1], q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)])), {}),
         ("sparse k=6, 2 entries per row (literal gather)", q.make_sparse_matrix_op([hi, mid, 5, 7, 9, 12], [[(r, 0.6), (r ^ 9, 0.8j)] for r in range(64)]), {"force_generic": 1}),
         ("H via literal gather", q.make_matrix_op([mid], circuits.H), {"force_generic": 1}),
     ]
@@ -120,8 +126,10 @@ def main():
                 continue
             for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32", "swap_single"):
                 st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
+            q.set_global_option("sparse_tile", opts.get("_sparse_tile", 1))
             for k, v in opts.items():
-                st.set_option(k, v)
+                if not k.startswith("_"):
+                    st.set_option(k, v)
             comp = st.compile_ops([op] * reps)
             st.set_option("profile", 0)
             st.apply_compiled(st.compile_ops([op]))
