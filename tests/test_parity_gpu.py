@@ -2531,3 +2531,16 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
                 st.upload(x)
                 st.apply_ops(ops)
                 assert float(np.max(np.abs(st.download() - want))) <= tol, (name, "merged")
+    # the smallest states that take wide tiles at all (one and two positions above the 13-bit tile), and n = 13 (narrow sweeps: no room)
+    for nn in (13, 14, 15):
+        xs = rand_state(nn, nn, dtype)
+        ops = circuits.h_layer(nn) + circuits.c2_random_circuit(nn, 120, seed=nn) + circuits.c3_qft(nn)[:60]
+        want = O.apply_ops_in_place(nn, ops, xs.copy())
+        for tile in (1, 2):
+            with q.HipState(nn, dtype) as st:
+                for k, v in (("tile", tile), ("tile_jit", 1), ("tile_wide", 1)):
+                    st.set_option(k, v)
+                st.upload(xs)
+                st.apply_ops(ops)
+                got = st.download()
+            assert float(np.max(np.abs(got - want))) <= tol, (nn, tile)

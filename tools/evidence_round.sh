@@ -18,6 +18,10 @@ timeout 600 python tools/bench_ops.py 30 all > $O/ops_table.md 2> $O/ops_table.e
 timeout 600 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32.md 2> $O/ops_table_f32.err
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 cd $R
+if [ "$2" = "quick" ]; then  # the tests that cover what changed since the last full run of the suite (kept beside it under profiles/)
+  timeout 1500 python -m pytest tests -m gpu -q --durations=8 -k "sparse or wide_tiles or sharded_virtual or sharded_state or bench_multi_rank or every_timed_leg or (full_size_oracle_windows and 28)" > $O/gpu_tests_subset.txt 2>&1
+  tail -14 $O/gpu_tests_subset.txt
+fi
 python - <<PY
 import json
 d=json.loads(open("$O/bench_n1.json").read().strip().splitlines()[-1])
