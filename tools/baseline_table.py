@@ -83,6 +83,14 @@ for name in ops:
         kk = int(name.split("=")[1].split()[0])
         tf = 8.0 * 2**kk * 2**n / (ms * 1e-3) / 1e12
         L(f"| {name} | `{k}` | {ms:.1f} | | {tf:.1f} TFLOP/s | **{100 * tf / 78.6:.0f} % of the 78.6 TFLOP/s f64 matrix peak** | 1e-12 vs oracle |")
+for name in ("sparse k=4, 2 entries per row (in place)", "sparse k=4, 2 entries per row (one group per lane)", "sparse k=5, 2 entries per row (in place)",
+             "sparse k=5, 2 entries per row (one group per lane)", "sparse k=16 identity, one entry per row (state_bench.rs:380-393 shape)",
+             "sparse k=8 permutation x phase, scattered bits", "sparse k=8 permutation x phase, scattered bits (out-of-place gather)", "sparse k=6, 2 entries per row",
+             "sparse k=6, 2 entries per row (out-of-place gather)", "sparse k=7, 4 entries per row, two positions in the wave row", "controlled sparse k=6, 2 entries per row"):
+    if name in ops:
+        k, ms, gb, pc = ops[name]
+        b = ops32.get(name)
+        L(f"| `SparseMatrix`: {name[7:]} | `{k}` | {ms:.2f} | | {gb:.0f} | {pc:.1f}" + (f" (f32: `{b[0]}` {b[3]:.1f})" if b else "") + " | bit-equal to the oracle |")
 for name in ("norm_sqr", "measure_probs k=1", "measure_probs k=3", "measure_probs k=12 top bits", "measure_probs k=16", "soft_measure (2 passes)"):
     a, b = ops.get(name), ops32.get(name)
     if a and b:
