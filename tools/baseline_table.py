@@ -90,7 +90,7 @@ for name in ("sparse k=4, 2 entries per row (in place)", "sparse k=4, 2 entries 
     if name in ops:
         k, ms, gb, pc = ops[name]
         b = ops32.get(name)
-        L(f"| `SparseMatrix`: {name[7:]} | `{k}` | {ms:.2f} | | {gb:.0f} | {pc:.1f}" + (f" (f32: `{b[0]}` {b[3]:.1f})" if b else "") + " | bit-equal to the oracle |")
+        L(f"| `SparseMatrix`: {name.replace('sparse ', '', 1)} | `{k}` | {ms:.2f} | | {gb:.0f} | {pc:.1f}" + (f" (f32: `{b[0]}` {b[3]:.1f})" if b else "") + " | bit-equal to the oracle |")
 for name in ("norm_sqr", "measure_probs k=1", "measure_probs k=3", "measure_probs k=12 top bits", "measure_probs k=16", "soft_measure (2 passes)"):
     a, b = ops.get(name), ops32.get(name)
     if a and b:
@@ -101,3 +101,27 @@ L("")
 L(f"Dominant kernel (`roofline`): `{roof['kernel']}`, {roof['launches']} launches, {roof['avg_launch_ms']:.3f} ms average (HIP events) = {roof['achieved']:.0f} GB/s = "
   f"**{100 * roof['frac']:.1f} %**; HBM traffic per launch (`roofline.traffic`, {'STALE: ' if roof.get('traffic_stale') else ''}{roof['traffic_source'].split('(')[0].strip()}): "
   f"{roof['traffic']:.4e} B against {roof['algorithmic_bytes_per_launch']:.4e} algorithmic = {roof['traffic'] / roof['algorithmic_bytes_per_launch']:.4f}×.")
+
+import csv
+import glob
+
+rows = [r for r in csv.DictReader(open(P(f"{tag}_kernel_stats.csv"))) if "k_tile_passes" in r["Name"]]
+calls = sum(int(r["Calls"]) for r in rows)
+avg = sum(int(r["TotalDurationNs"]) for r in rows) / calls / 1e6
+L(f"rocprofv3 `--kernel-trace --stats` of the same command (`profiles/{tag}_kernel_stats.md`): `k_tile_passes` {calls} calls, {avg:.3f} ms average.")
+L("")
+if os.path.exists(P(f"{tag}_bench_n33.json")):
+    b = json.loads(open(P(f"{tag}_bench_n33.json")).read().strip().splitlines()[-1])
+    L(f"Headline generator at **n = 33** (128 GiB, eight times the headline state) on ONE GPU, in place, {b['config']['gates_per_step']} gates × {b['steps']} steps: "
+      f"{b['ms_per_step'] / b['config']['gates_per_step']:.1f} ms per gate = **{b['value']:.0f} GB/s = {b['value'] / 80:.1f} %**, norm {b['norm_sqr_after']:.15f} "
+      f"(`profiles/{tag}_bench_n33.json`; oracle windows at n = 33: `tests/test_parity_gpu.py::test_full_size_oracle_windows_n33`).")
+    L("")
+for f in sorted(glob.glob(P(f"{tag}_bench_2ranks_one_gpu*.json"))):
+    b = json.loads(open(f).read().strip().splitlines()[-1])
+    pr = b["parity"]
+    L(f"Two ranks on ONE GPU (`{os.path.basename(f)}`, host-staged transport: plumbing and parity evidence, not a throughput figure): n = {b['config']['n_qubits']}, "
+      f"`parity_ok` = {b['parity_ok']}, parity at n = {pr.get('n')}: {pr.get('rows_checked', 0):.3g} rows, max |Δ| = {pr.get('max_abs_delta')}.")
+    for k, v in b.get("extras", {}).items():
+        if isinstance(v, dict) and "comm_over_reps" in v:
+            c = v["comm_over_reps"]
+            L(f"  * `{k}`: {c['remaps']} remaps, {c['pack_sweeps']} gathers as sweeps of their own, **{c['packs_folded']} folded into the preceding tile sweep**, {c['packs_via_permute_bits']} through `k_permute_bits`")
