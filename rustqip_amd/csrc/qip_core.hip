@@ -67,6 +67,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
   if (key && !strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
   if (key && !strcmp(key, "dist_plan_cost")) { g_dist_plan_cost = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "soft_measure_one_pass")) { g_soft_measure_one_pass = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_threads")) {
     if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
@@ -439,6 +440,7 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
   if (s->owns_alt && s->alt) (void)hipFree(s->alt);
   if (s->arena) (void)hipFree(s->arena);
   if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->d_ticket) (void)hipFree(s->d_ticket);
   if (s->owns_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return QIP_OK;

@@ -2301,70 +2301,227 @@ __global__ __launch_bounds__(kBlock) void k_gather_indices(const amp_t<T>* __res
 }
 
 // soft_measure's sequential scan (measurement_ops.rs:167-173) inside ONE chunk: find the first index at
-// which r - sum_{j<=i} |amp_j|^2 <= 0.  One block: every lane sums its contiguous segment, lane 0 walks the
-// 256 segment sums to the segment that crosses zero, that lane replays the sequential subtraction.
+// which r - sum_{j<=i} |amp_j|^2 <= 0.  One block, two levels: every lane sums its contiguous segment (in double), lane 0
+// walks the 256 segment sums to a segment that may bring r to <= 0 (with a rounding margin); the block then splits THAT segment
+// into 256 sub-segments the same way, and only the sub-segment that may cross is replayed element by element, in the
+// precision and order of the reference, by the lane that owns it (r4: the round-3 form replayed a whole segment — 1024 dependent
+// loads of one lane at n = 30, most of soft_measure's time beyond the norm pass).  A (sub-)segment that came close without
+// crossing hands its exact remainder on.  *r_io / *found live in shared memory, set by the caller (found = ~0).
+__device__ __forceinline__ int walk_sums(const double* v, int start, int cnt, double& r) {
+  for (int t = start; t < cnt; ++t) {
+    if (r - v[t] <= 1e-9 * (1.0 + v[t])) return t;  // may cross (or come within rounding of it): look inside
+    r -= v[t];
+  }
+  return -1;
+}
+
+template <typename T>
+__device__ void find_crossing_block(const amp_t<T>* __restrict__ st, uint64_t lo, uint64_t len, double* r_io,
+                                    unsigned long long* found) {
+  __shared__ double seg_sum[kBlock], sub_sum[kBlock];
+  __shared__ int owner, owner2;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t end = lo + len;
+  auto sum_range = [&](uint64_t a, uint64_t b) {
+    double acc = 0;  // double for both dtypes: the skip margin is far tighter than f32 summation error
+    for (uint64_t i = a; i < b; ++i) {
+      const amp_t<T> x = st[i];
+      acc += (double)(x.x * x.x + x.y * x.y);
+    }
+    return acc;
+  };
+  const uint64_t seg = (len + kBlock - 1) / kBlock;
+  // the 256 segment sums, a wave per segment in turn: 64 lanes read consecutive amplitudes (one lane per segment would touch 64
+  // different lines per load instruction — measured: the larger part of the crossing search's time)
+  for (uint32_t sg = tid >> 6; sg < (uint32_t)kBlock; sg += kBlock / 64) {
+    const uint64_t a = lo + (uint64_t)sg * seg < end ? lo + (uint64_t)sg * seg : end;
+    const uint64_t b = a + seg < end ? a + seg : end;
+    double acc = 0;
+    for (uint64_t i = a + (tid & 63u); i < b; i += 64) {
+      const amp_t<T> x = st[i];
+      acc += (double)(x.x * x.x + x.y * x.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63u) == 0) seg_sum[sg] = acc;
+  }
+  __syncthreads();
+  int start = 0;
+  while (true) {
+    if (tid == 0) {
+      double r = *r_io;
+      owner = walk_sums(seg_sum, start, kBlock, r);
+      *r_io = r;
+    }
+    __syncthreads();
+    const int own = owner;
+    if (own < 0) return;  // the chunk never crosses: *r_io is the remainder after it
+    const uint64_t sa = lo + (uint64_t)own * seg < end ? lo + (uint64_t)own * seg : end;
+    const uint64_t sb = sa + seg < end ? sa + seg : end;
+    const uint64_t sub = (sb - sa + kBlock - 1) / kBlock;
+    const uint64_t a2 = sa + (uint64_t)tid * sub < sb ? sa + (uint64_t)tid * sub : sb;
+    const uint64_t b2 = a2 + sub < sb ? a2 + sub : sb;
+    sub_sum[tid] = sum_range(a2, b2);
+    __syncthreads();
+    int start2 = 0;
+    while (true) {
+      if (tid == 0) {
+        double r = *r_io;
+        owner2 = walk_sums(sub_sum, start2, kBlock, r);
+        *r_io = r;
+      }
+      __syncthreads();
+      const int own2 = owner2;
+      if (own2 < 0) break;  // this segment came close but did not cross: carry on after it
+      if ((int)tid == own2) {
+        T r = (T)*r_io;
+        for (uint64_t i = a2; i < b2; ++i) {
+          const amp_t<T> x = st[i];
+          r -= x.x * x.x + x.y * x.y;  // same running subtraction, same precision as the reference
+          if (r <= (T)0) {
+            *found = i;
+            break;
+          }
+        }
+        *r_io = (double)r;
+      }
+      __syncthreads();
+      if (*found != ~0ull) return;
+      start2 = own2 + 1;
+      __syncthreads();
+    }
+    start = own + 1;
+    __syncthreads();
+  }
+}
+
 // result[0] = index (or ~0 when the chunk never crosses), result[1] = bits of the remaining r (double).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_find_crossing(const amp_t<T>* __restrict__ st, uint64_t lo,
                                                           uint64_t len, double r0, uint64_t* __restrict__ result) {
-  __shared__ double seg_sum[kBlock];
-  __shared__ int owner;
-  const uint64_t seg = (len + kBlock - 1) / kBlock;
-  const uint64_t a = lo + (uint64_t)threadIdx.x * seg;
-  const uint64_t b = a + seg < lo + len ? a + seg : lo + len;
-  double acc = 0;  // double for both dtypes: the skip margin below is far tighter than f32 summation error
-  for (uint64_t i = a; i < b; ++i) {
-    const amp_t<T> x = st[i];
-    acc += (double)(x.x * x.x + x.y * x.y);
-  }
-  seg_sum[threadIdx.x] = acc;
   __shared__ double r_cur;
   __shared__ unsigned long long found_at;
   if (threadIdx.x == 0) {
     r_cur = r0;
     found_at = ~0ull;
-    owner = -1;
   }
   __syncthreads();
-  int start = 0;
-  while (true) {
-    if (threadIdx.x == 0) {
-      // walk the segment sums from `start`; a segment that may bring r to <= 0 (with a rounding margin)
-      // is scanned element by element by the lane that owns it
-      double r = r_cur;
-      owner = -1;
-      for (int t = start; t < kBlock; ++t) {
-        if (r - seg_sum[t] <= 1e-9 * (1.0 + seg_sum[t])) {
-          owner = t;
-          break;
-        }
-        r -= seg_sum[t];
-      }
-      r_cur = r;
-    }
-    __syncthreads();
-    const int own = owner;
-    if (own < 0) break;
-    if ((int)threadIdx.x == own) {
-      T r = (T)r_cur;
-      for (uint64_t i = a; i < b; ++i) {
-        const amp_t<T> x = st[i];
-        r -= x.x * x.x + x.y * x.y;  // same running subtraction, same precision as the reference
-        if (r <= (T)0) {
-          found_at = i;
-          break;
-        }
-      }
-      r_cur = (double)r;
-    }
-    __syncthreads();
-    if (found_at != ~0ull) break;
-    start = own + 1;  // the margin case: the segment came close but did not cross; carry on after it
-    __syncthreads();
-  }
+  find_crossing_block<T>(st, lo, len, &r_cur, &found_at);
+  __syncthreads();
   if (threadIdx.x == 0) {
     result[0] = found_at;
     result[1] = (uint64_t)__double_as_longlong(r_cur);
+  }
+}
+
+// soft_measure in ONE launch (r4): the chunk sums of k_chunk_norms, and the block that finishes LAST (a ticket counter) does
+// what the host did between two launches — walks the chunk sums (lanes first add up groups of chunks, lane 0 walks the 256
+// group sums, then the chunks of the group that may cross) and runs find_crossing_block inside every chunk that may bring the
+// remainder to <= 0.  No amplitude and no chunk sum leaves the device; the host reads 16 bytes.
+// `counter` must be zero at launch (the last block leaves it zero again).  result as k_find_crossing (index over the whole vector).
+template <typename T, typename E = amp_t<T>>
+__global__ __launch_bounds__(kBlock) void k_chunk_norms_cross(const E* __restrict__ st, uint64_t nelems, uint64_t chunk,
+                                                              double* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                              const amp_t<T>* __restrict__ amps, uint64_t namps, uint64_t chunk_amps,
+                                                              double r0, uint64_t* __restrict__ result) {
+  constexpr bool PACKED = !SameT<E, amp_t<T>>::v;
+  __shared__ double smem[kBlock];
+  __shared__ int last, cand_g, cand_c;
+  __shared__ double r_cur;
+  __shared__ unsigned long long found_at;
+  {
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    const uint64_t hi = lo + chunk < nelems ? lo + chunk : nelems;
+    auto prob = [](E x) {
+      if constexpr (PACKED) return prob_lo(x) + prob_hi(x);
+      else return prob_of(x);
+    };
+    double s = 0;
+    constexpr int U = 4;
+    constexpr uint64_t kSpan = (uint64_t)U << kStrideShift;
+    uint64_t i = lo;
+    for (; i + kSpan <= hi; i += kSpan) {
+#pragma unroll 1
+      for (uint32_t qrow = 0; qrow < (1u << (kStrideShift - 8)); ++qrow) {
+        const uint64_t i0 = i + (uint64_t)qrow * kBlock + threadIdx.x;
+        E x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(st + i0 + ((uint64_t)u << kStrideShift));
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += prob(x[u]);
+      }
+    }
+    for (i += threadIdx.x; i < hi; i += kBlock) s += prob(st[i]);
+    const double t = block_reduce_sum(s, smem);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      const unsigned int ticket = atomicAdd(counter, 1u);
+      last = ticket == gridDim.x - 1u;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nchunks = gridDim.x;
+  const uint32_t G = (nchunks + kBlock - 1) / kBlock;  // chunks per group
+  auto chunk_sum = [&](uint32_t c) { return __hip_atomic_load(&partial[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  {
+    double gs = 0;
+    for (uint32_t c = tid * G; c < (tid + 1) * G && c < nchunks; ++c) gs += chunk_sum(c);
+    smem[tid] = gs;
+  }
+  if (tid == 0) {
+    r_cur = r0;
+    found_at = ~0ull;
+  }
+  __syncthreads();
+  int gstart = 0;
+  while (true) {
+    if (tid == 0) {
+      double r = r_cur;
+      cand_g = walk_sums(smem, gstart, kBlock, r);
+      r_cur = r;
+    }
+    __syncthreads();
+    const int cg = cand_g;
+    if (cg < 0) break;
+    const uint32_t c1 = ((uint32_t)cg + 1u) * G < nchunks ? ((uint32_t)cg + 1u) * G : nchunks;
+    uint32_t cstart = (uint32_t)cg * G;
+    while (true) {
+      if (tid == 0) {
+        double r = r_cur;
+        int c = -1;
+        for (uint32_t t = cstart; t < c1; ++t) {
+          const double v = chunk_sum(t);
+          if (r - v <= 1e-9 * (1.0 + v)) {
+            c = (int)t;
+            break;
+          }
+          r -= v;
+        }
+        cand_c = c;
+        r_cur = r;
+      }
+      __syncthreads();
+      const int cc = cand_c;
+      if (cc < 0) break;
+      const uint64_t lo = (uint64_t)cc * chunk_amps;
+      find_crossing_block<T>(amps, lo, lo + chunk_amps < namps ? chunk_amps : namps - lo, &r_cur, &found_at);
+      __syncthreads();
+      if (found_at != ~0ull) break;
+      cstart = (uint32_t)cc + 1u;
+      __syncthreads();
+    }
+    if (found_at != ~0ull) break;
+    gstart = cg + 1;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    result[0] = found_at;
+    result[1] = (uint64_t)__double_as_longlong(r_cur);
+    *counter = 0u;  // ready for the next launch (stream order; the handle's own allocation, zeroed when made)
   }
 }
 

@@ -2252,6 +2252,28 @@ def test_soft_measure_map_sample_sweep_f64_and_f32(O):
         got = np.array([st.soft_measure(idx, float(r)) for r in samples])
     want = np.array([O.soft_measure(n, idx, x, float(r)) for r in samples])
     assert int(np.count_nonzero(got != want)) == 0
+    # r4: one launch (chunk sums + the last block's walk and replay; option soft_measure_one_pass, measured slower and off) against
+    # the two-launch form (r4: two-level replay, coalesced segment sums): the same function of
+    # the sample, also at the edges (r = 0, r = 1, r above the norm: never crossing -> outcome of index 0), on a state whose first
+    # and last amplitudes are zero, at a size with 4096 chunks of 2^10 and at one with two chunks
+    for nn, dt in ((22, np.complex128), (22, np.complex64), (11, np.complex128)):
+        xs = rand_state(nn, 5 + nn, dt)
+        xs[:3000 if nn > 11 else 5] = 0
+        xs[-(2000 if nn > 11 else 3):] = 0
+        xs /= np.sqrt(np.sum(np.abs(xs.astype(np.complex128)) ** 2)).astype(xs.real.dtype)
+        ii = [0, nn // 2, nn - 1, 3]
+        rs = [0.0, 1.5, 1e-300, 0.5, 0.99, 2.0] + [float(v) for v in rng.uniform(0, 1, 300)]  # (r = 1 exactly is decided by the summation order)
+        with q.HipState(nn, dt) as st:
+            st.upload(xs)
+            two = [st.soft_measure(ii, r) for r in rs]
+            q.set_global_option("soft_measure_one_pass", 1)
+            try:
+                one = [st.soft_measure(ii, r) for r in rs]
+            finally:
+                q.set_global_option("soft_measure_one_pass", 0)
+        assert one == two, (nn, dt, [(r, a, b) for r, a, b in zip(rs, one, two) if a != b][:5])
+        if dt == np.complex128:
+            assert one[:150] == [O.soft_measure(nn, ii, xs, r) for r in rs[:150]], nn
     x32 = x.astype(np.complex64)
     with q.HipState(n, np.complex64) as st:
         st.upload(x32)

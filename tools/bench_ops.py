@@ -152,7 +152,10 @@ def main():
                              ("measure_probs k=8 low bits", lambda: st.measure_probs(list(range(n - 8, n))), amp * 2**n),
                              ("measure_probs k=12 mixed bits", lambda: st.measure_probs([0, n - 1, 3, n - 4, 7, n - 9, 11, n - 13, 15, n - 17, n - 2, 1]), amp * 2**n),
                              ("measure_probs k=16", lambda: st.measure_probs(list(range(2, 18))), amp * 2**n),
-                             ("soft_measure (2 passes)", lambda: st.soft_measure([0, mid, lo], 0.4321), amp * 2**n)):
+                             ("soft_measure (2 passes)", lambda: st.soft_measure([0, mid, lo], 0.4321), amp * 2**n),
+                             ("soft_measure (one launch: chunk sums + last block's walk; measured alternative)",
+                              lambda: (q.set_global_option("soft_measure_one_pass", 1), st.soft_measure([0, mid, lo], 0.4321),
+                                       q.set_global_option("soft_measure_one_pass", 0)), amp * 2**n)):
             fn()
             t0 = time.perf_counter()
             for _ in range(3):
