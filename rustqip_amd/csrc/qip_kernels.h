@@ -2113,11 +2113,14 @@ struct MeasGridDesc {
 };
 // (E = f32x4: a Complex<f32> state read as 16-byte elements of two amplitudes when index bit 0 is not measured — positions in
 // units of elements, an element contributes both of its amplitudes)
-template <typename T, int KI, typename E = amp_t<T>>
+// B0 (packed elements only, r4): index bit 0 IS measured — the two halves of an element go to two outcomes; the outcome index gets
+// one more bit below the lane outcome: o' = 2 o + half.
+template <typename T, int KI, typename E = amp_t<T>, bool B0 = false>
 __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const E* __restrict__ st, uint64_t count, Ins ins,
                                                               MeasGridDesc md, uint32_t gx, uint64_t nout,
                                                               double* __restrict__ partial) {
   constexpr int NC = 1 << KI;
+  constexpr int H = B0 ? 2 : 1;
   __shared__ double lane_sum[kBlock];
   // 1-D grid of (outcomes on the grid) x gx blocks: HIP caps gridDim.y at 65535 and kg may reach 20
   const uint64_t mg = blockIdx.x / gx;
@@ -2136,11 +2139,21 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const E* __restri
   // `count` (a power of two) work items per (mg, c); gx blocks stride over them; >= 4 independent rows in flight
   constexpr int UN = NC >= 4 ? 1 : 4 / NC;
   const uint64_t stride = (uint64_t)gx * kBlock;
-  double acc[NC][UN];
+  double acc[H][NC][UN];
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int u = 0; u < UN; ++u) acc[c][u] = 0.0;
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) acc[h][c][u] = 0.0;
+  auto add = [&](int c, int u, E a) {
+    if constexpr (B0) {
+      acc[0][c][u] += prob_lo(a);
+      acc[H - 1][c][u] += prob_hi(a);
+    } else {
+      acc[0][c][u] += prob_of(a);
+    }
+  };
   uint64_t w = (uint64_t)bx * kBlock + threadIdx.x;
   for (; w + (UN - 1) * stride < count; w += UN * stride) {
     E a[NC][UN];
@@ -2153,15 +2166,12 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const E* __restri
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) acc[c][u] += prob_of(a[c][u]);
+      for (int u = 0; u < UN; ++u) add(c, u, a[c][u]);
   }
   for (; w < count; w += stride) {
     const uint64_t base = insert_bits<-1>(w, ins);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const E a = __builtin_nontemporal_load(st + (base | coff[c]));
-      acc[c][0] += prob_of(a);
-    }
+    for (int c = 0; c < NC; ++c) add(c, 0, __builtin_nontemporal_load(st + (base | coff[c])));
   }
   // fold the 256 lane sums by lane outcome: add across every lane-id bit that is NOT measured (wave shuffles for
   // bits 0..5, LDS for the two wave-id bits); the lanes whose unmeasured bits are all zero then hold the totals
@@ -2172,21 +2182,24 @@ __global__ __launch_bounds__(kBlock) void k_measure_probs_grid(const E* __restri
   const bool writer = (threadIdx.x & ~lmask & 255u) == 0u;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    double v = 0;
 #pragma unroll
-    for (int u = 0; u < UN; ++u) v += acc[c][u];
+    for (int h = 0; h < H; ++h) {
+      double v = 0;
 #pragma unroll
-    for (int b = 0; b < 6; ++b)
-      if (!((lmask >> b) & 1u)) v += __shfl_xor(v, 1 << b, 64);  // wave-uniform condition
-    __syncthreads();  // lane_sum is reused per c
-    lane_sum[threadIdx.x] = v;
-    __syncthreads();
-    if (!((lmask >> 6) & 1u)) v += lane_sum[threadIdx.x ^ 64u];
-    __syncthreads();
-    lane_sum[threadIdx.x] = v;
-    __syncthreads();
-    if (!((lmask >> 7) & 1u)) v += lane_sum[threadIdx.x ^ 128u];
-    if (writer) partial[(uint64_t)bx * nout + ((((mg << KI) | (uint64_t)c) << md.kl) | lo)] = v;
+      for (int u = 0; u < UN; ++u) v += acc[h][c][u];
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+        if (!((lmask >> b) & 1u)) v += __shfl_xor(v, 1 << b, 64);  // wave-uniform condition
+      __syncthreads();  // lane_sum is reused per (c, h)
+      lane_sum[threadIdx.x] = v;
+      __syncthreads();
+      if (!((lmask >> 6) & 1u)) v += lane_sum[threadIdx.x ^ 64u];
+      __syncthreads();
+      lane_sum[threadIdx.x] = v;
+      __syncthreads();
+      if (!((lmask >> 7) & 1u)) v += lane_sum[threadIdx.x ^ 128u];
+      if (writer) partial[(uint64_t)bx * nout + (((((mg << KI) | (uint64_t)c) << md.kl) | lo) * H + h)] = v;
+    }
   }
 }
 

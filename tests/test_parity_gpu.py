@@ -366,6 +366,23 @@ def test_measure_probs_many_outcomes(O):
         st.upload(xf)
         for idx in ([0, 11, 5, 6, 7, 1], list(range(12))):
             assert np.max(np.abs(st.measure_probs(idx) - O.measure_probs(12, idx, xf))) <= 1e-5
+    # Complex<f32> is read as 16-byte elements of two amplitudes; r4: also when index bit 0 (qubit n-1) is measured — the halves of
+    # an element go to two outcomes.  Bit 0 as the first / last / a middle outcome bit, with and without other row positions, k = 5..16
+    xf = rand_state(n, 3, np.complex64)
+    xf[::5] = 0
+    with q.HipState(n, np.complex64) as st:
+        st.upload(xf)
+        cases = [[n - 1, 0, 3, 9, 12], [0, 3, 9, 12, n - 1], [4, n - 1, n - 2, 7, n - 5, 1, 10], list(range(n - 12, n)), list(range(n - 1, n - 13, -1)),
+                 [0, n - 1, 3, n - 4, 7, n - 9, 11, n - 13, 15, 13, n - 2, 1], list(range(2, n))]
+        for k in (5, 8, 11, 14):
+            c = [int(v) for v in rng.permutation(n - 1)[:k - 1]]
+            c.insert(int(rng.integers(0, k)), n - 1)
+            cases.append(c)
+        for idx in cases:
+            got = st.measure_probs(idx)
+            want = O.measure_probs(n, idx, xf)
+            assert np.max(np.abs(got - want)) <= 2e-6 * max(1.0, float(np.max(want)) * (1 << len(idx)) / 64), idx
+            assert abs(got.sum() - float(np.sum(np.abs(xf.astype(np.complex128)) ** 2))) < 1e-5
 
 
 @pytest.fixture
