@@ -111,6 +111,8 @@ int qip_hip_abi_version(void);
  *   "dist_plan_cost"   1 (default): at a remap of a sharded state the leaving qubits are chosen by modelled cost — the count-optimal set
  *                      (farthest next use) unless the set that keeps the gather out of the wave rows is cheaper over the rest of the
  *                      circuit (exchange = shard / world bytes per link, free-standing gather = one copy of the shard); 0 = by count alone.
+ *   "soft_measure_one_pass"  0 (default): soft_measure = chunk sums, host walk, crossing search in one chunk (two launches); 1 = one launch
+ *                      whose last block does the walk and the search.  The same function of the sample; measured slower.
  *   "sparse_tile"      1 (default): a SparseMatrix on k >= 6 qubits with <= 4 entries per row and 3..7 of its positions outside
  *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
  *                      gather (k_sparse_ell).  Same results bit for bit.
