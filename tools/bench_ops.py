@@ -146,6 +146,9 @@ def main():
             by = q.algorithmic_bytes(n, op, 1 if f32 else 0)
             print(f"| {name} | `{kern}` | {dt*1e3:.3f} | {by/dt/1e9:.0f} | {100*by/dt/1e9/8000:.1f} |")
         st.set_option("profile", 0)
+        for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32", "swap_single"):  # (the last row's options must not leak into the reductions)
+            st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
+        q.set_global_option("sparse_tile", 1)
         for name, fn, by in (("norm_sqr", st.norm_sqr, amp * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), amp * 2**n),
                              ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), amp * 2**n),
                              ("measure_probs k=12 top bits", lambda: st.measure_probs(list(range(12))), amp * 2**n),
