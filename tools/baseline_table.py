@@ -91,7 +91,8 @@ for name in ("sparse k=4, 2 entries per row (in place)", "sparse k=4, 2 entries 
         k, ms, gb, pc = ops[name]
         b = ops32.get(name)
         L(f"| `SparseMatrix`: {name.replace('sparse ', '', 1)} | `{k}` | {ms:.2f} | | {gb:.0f} | {pc:.1f}" + (f" (f32: `{b[0]}` {b[3]:.1f})" if b else "") + " | bit-equal to the oracle |")
-for name in ("norm_sqr", "measure_probs k=1", "measure_probs k=3", "measure_probs k=12 top bits", "measure_probs k=16", "soft_measure (2 passes)"):
+for name in ("norm_sqr", "measure_probs k=1", "measure_probs k=3", "measure_probs k=12 top bits", "measure_probs k=12 mixed bits", "measure_probs k=16", "soft_measure (2 passes)",
+             "soft_measure (one launch: chunk sums + last block's walk; measured alternative)"):
     a, b = ops.get(name), ops32.get(name)
     if a and b:
         L(f"| {name}: f64 / f32 | reduction | {a[1]:.2f} / {b[1]:.2f} | | {a[2]:.0f} / {b[2]:.0f} | {a[3]:.1f} / {b[3]:.1f} | ≤ 1e-13 |")
