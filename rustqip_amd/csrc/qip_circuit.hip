@@ -1487,6 +1487,7 @@ static int program_capture(qip_hip_program* p) {
     const uint32_t k = f.n_op;
     const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));  // (k = 9, 10 upload 8 - 32 MiB of fragments and synchronise: eager)
     (void)f64;
+    if (pl.cls == KC_GATHER_GENERIC && sparse_tile_applies(s, pl, f)) continue;  // (r4: in place through k_sparse_tile)
     if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
   }
   if (s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too

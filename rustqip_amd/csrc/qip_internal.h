@@ -125,6 +125,8 @@ static constexpr uint32_t kMaxHugeK = 10;   // ... k = 9, 10 with X in LDS and t
 static constexpr uint32_t kMaxSparseK = 5;  // SparseMatrix ops applied in place (one 2^k group per lane, staged in LDS)
 static constexpr uint32_t kMaxDiagK = 12;   // largest Matrix op inspected for structure (4^k entries are read)
 int make_plan(int dtype, uint32_t n, const FlatOp& f, bool force_generic, Plan* p);
+struct qip_hip_state;
+bool sparse_tile_applies(const qip_hip_state* s, const Plan& p, const FlatOp& f);  // qip_launch.hip: the op would run in place through k_sparse_tile
 
 struct ProfRec {
   int cls;

@@ -995,12 +995,13 @@ static int launch_sparse_ell(qip_hip_state* s, const Plan& p, const FlatOp& f, b
 // SparseMatrix on k >= 6 distinct qubits (optionally controlled), at most four entries per row, whose positions outside the
 // wave row number 3..7: in place through k_sparse_tile (the group staged in LDS beside the row).  *done = false: not this shape.
 int64_t g_sparse_tile = 1;  // global option "sparse_tile": 0 = always the out-of-place gather (k_sparse_ell), for A/B runs
-template <typename T>
-static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
-  *done = false;
-  if (!g_sparse_tile) return QIP_OK;
+// the shape test alone (program capture asks it too: an op that takes this form stays in place, so the program can be a graph)
+static bool sparse_tile_shape(const qip_hip_state* s, const Plan& p, const FlatOp& f, SparseTileDesc* dout, std::vector<uint32_t>* hp_out,
+                              std::vector<uint32_t>* ctl_out_out, uint32_t* e_out) {
+  if (!g_sparse_tile || f.inner->kind != QIP_OP_SPARSE || !f.distinct) return false;
   const uint32_t k = f.n_op;
-  const uint32_t p5 = tile_p5_of<T>(s->n);
+  if (k < (s->dtype == QIP_C64 ? 4u : 6u)) return false;  // (Complex<f32>, measured at n = 30: k = 5 one group per lane 67.6 % against 63.2 %; k = 4 even)
+  const uint32_t p5 = tile_p5(s->dtype, s->n);
   SparseTileDesc d;
   memset(&d, 0, sizeof d);
   d.p5 = p5;
@@ -1017,14 +1018,34 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
   d.kh = (uint32_t)hp.size();
   d.nlow = (uint32_t)__builtin_popcount(d.low_op);
   // 2^(6+kh) amplitudes per tile: up to 64 KiB (two blocks per CU) — Complex<f64> kh = 7 is one 128-KiB block of 1024 lanes per CU
-  if (d.kh < 3 || d.kh > 7 || s->n < 6 + d.kh + (uint32_t)ctl_out.size() + 2) return QIP_OK;
+  if (d.kh < 3 || d.kh > 7 || s->n < 6 + d.kh + (uint32_t)ctl_out.size() + 2) return false;
   const uint64_t rows = 1ull << k;
   const uint64_t* rp = f.inner->sparse_rowptr;
   uint64_t widest = 0;
   for (uint64_t r = 0; r < rows; ++r) widest = std::max<uint64_t>(widest, rp[r + 1] - rp[r]);
-  if (widest > 4) return QIP_OK;
-  const uint32_t E = widest <= 1 ? 1u : (widest <= 2 ? 2u : 4u);
+  if (widest > 4) return false;
   for (uint32_t j = 0; j < d.kh; ++j) d.hpos[j] = hp[j];
+  if (dout) *dout = d;
+  if (hp_out) *hp_out = hp;
+  if (ctl_out_out) *ctl_out_out = ctl_out;
+  if (e_out) *e_out = widest <= 1 ? 1u : (widest <= 2 ? 2u : 4u);
+  return true;
+}
+bool sparse_tile_applies(const qip_hip_state* s, const Plan& p, const FlatOp& f) {
+  return sparse_tile_shape(s, p, f, nullptr, nullptr, nullptr, nullptr);
+}
+
+template <typename T>
+static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
+  *done = false;
+  const uint32_t k = f.n_op;
+  SparseTileDesc d;
+  std::vector<uint32_t> hp, ctl_out;
+  uint32_t E = 1;
+  if (!sparse_tile_shape(s, p, f, &d, &hp, &ctl_out, &E)) return QIP_OK;
+  const uint32_t p5 = d.p5;
+  const uint64_t rows = 1ull << k;
+  const uint64_t* rp = f.inner->sparse_rowptr;
   // m' bit b <- op index order[b]: the op's lane bits ascending, then its tile rows ascending
   std::vector<uint32_t> order;
   for (uint32_t b = 0; b < 6; ++b)
@@ -1205,24 +1226,25 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
       // k = 4, 5 with few entries per row and >= 3 positions outside the wave row: the LDS-staged tile form (whole wave rows, the
       // table through scalar loads) runs ahead of one-group-per-lane; the very same fold, bit-equal
       bool done = false;
-      // (Complex<f32>, measured at n = 30: k = 5 one group per lane 67.6 % against 63.2 % — stays; k = 4 even)
-      if (f.n_op >= 4 && std::is_same<T, double>::value && !s->capture_staging) rc = launch_sparse_tile<T>(s, p, f, &done);
+      rc = launch_sparse_tile<T>(s, p, f, &done);
       if (rc == QIP_OK && done) rec.cls = KC_SPARSE_TILE;
       else if (rc == QIP_OK) rc = launch_sparse_kq<T>(s, p, f, st);
       break;
     }
     default: {
-      if (f.inner->kind == QIP_OP_SPARSE && f.distinct && f.n_op >= 6 && !s->force_generic && !g_force_generic && !s->capture_staging) {
+      if (f.inner->kind == QIP_OP_SPARSE && f.distinct && f.n_op >= 6 && !s->force_generic && !g_force_generic) {
         bool done = false;
-        rc = launch_sparse_tile<T>(s, p, f, &done);
+        rc = launch_sparse_tile<T>(s, p, f, &done);  // in place: also inside a recorded program (nothing swaps buffers)
         if (rc != QIP_OK || done) {
           rec.cls = KC_SPARSE_TILE;
           break;
         }
-        rc = launch_sparse_ell<T>(s, p, f, &done);
-        if (rc != QIP_OK || done) {
-          rec.cls = KC_SPARSE_ELL;
-          break;
+        if (!s->capture_staging) {  // out of place: the buffers trade places, which a recorded graph cannot follow
+          rc = launch_sparse_ell<T>(s, p, f, &done);
+          if (rc != QIP_OK || done) {
+            rec.cls = KC_SPARSE_ELL;
+            break;
+          }
         }
       }
       QCHK(ensure_alt(s));

@@ -1056,17 +1056,49 @@ def test_hipgraph_program_replay(O):
             assert np.array_equal(st.download(), twice)
             prog.close()
         assert np.max(np.abs(once - O.apply_ops_in_place(n, circ, x.copy()))) <= TOL64
-        # a sparse op on 6 qubits takes the out-of-place literal kernel: the program must stay correct (eager fallback)
-        sp = circ[:20] + [q.make_sparse_matrix_op(perm[:6], [[((r * 5 + 1) % 64, 0.5j), (r, 2.0)] for r in range(64)])] + circ[20:40]
-        with q.HipState(n) as st:
-            st.upload(x)
-            prog = st.compile_program(sp)
-            prog.run()
-            prog.run()
-            assert not prog.is_graph
-            got = st.download()
-        want = O.apply_ops_in_place(n, sp + sp, x.copy())
-        assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want))))
+        # a sparse op on 6 qubits with FIVE entries in a row takes the out-of-place literal kernel: the program must stay correct
+        # (eager fallback); with two entries per row it is applied in place through k_sparse_tile where the state is large enough
+        # (r4) and the program is a graph again
+        pos = [n - 1 - qb for qb in perm[:6]]
+        kh = sum(1 for pp in pos if not (pp < 5 or pp == (11 if n >= 12 else 5)))  # the op's positions outside the wave row
+        tile_form = 3 <= kh <= 7 and n >= 6 + kh + 2
+        for width in (5, 2):
+            rows = [[((r * 5 + 1 + 7 * e) % 64, 0.5j if e == 0 else 0.25 * (e + 1)) for e in range(width - 1)] + [(r, 2.0)] for r in range(64)]
+            sp = circ[:20] + [q.make_sparse_matrix_op(perm[:6], rows)] + circ[20:40]
+            with q.HipState(n) as st:
+                st.upload(x)
+                prog = st.compile_program(sp)
+                prog.run()
+                prog.run()
+                assert prog.is_graph == (width == 2 and tile_form), (n, width, kh)
+                got = st.download()
+            want = O.apply_ops_in_place(n, sp + sp, x.copy())
+            assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want)))), (n, width)
+
+
+def test_program_with_a_sparse_op_on_six_qubits_is_a_graph(O):
+    """r4: a SparseMatrix on k >= 6 qubits with narrow rows is applied IN PLACE (k_sparse_tile), so a program that holds one
+    is recorded as a hipGraph like any other (the out-of-place kernels it used to take made the program fall back to eager)."""
+    n = 15
+    rng = np.random.default_rng(4)
+    rows = [[((r * 5 + 1) % 64, 0.5j), (r, 2.0), ((r * 11 + 3) % 64, -0.25)] for r in range(64)]
+    sp = q.make_control_op([7], q.make_sparse_matrix_op([0, 1, 5, 6, 13, 14], rows))  # positions 14, 13, 9, 8 above the rows; 1, 0 inside
+    circ = circuits.h_layer(n) + circuits.c2_random_circuit(n, 30, seed=1) + [sp] + circuits.c2_random_circuit(n, 30, seed=2) + [sp]
+    x = circuits.random_state(n, seed=3)
+    with q.HipState(n) as st:
+        st.upload(x)
+        prog = st.compile_program(circ)
+        prog.run()
+        prog.run()
+        assert prog.is_graph
+        got = st.download()
+        prog.close()
+    want = O.apply_ops_in_place(n, circ + circ, x.copy())
+    assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want))))
+    with q.HipState(n) as st:  # and eagerly the very same bits
+        st.upload(x)
+        st.apply_ops(circ + circ)
+        assert np.array_equal(st.download(), got)
 
 
 def test_program_outliving_its_state_is_inert():
