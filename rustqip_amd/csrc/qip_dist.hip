@@ -2,7 +2,8 @@
 // Uses the launch helpers of qip_launch.hip through qip_internal.h.
 //
 // Three layers, so that each can be tested where it can run:
-//   DistPlanner   pure host code: logical -> physical qubit map, which qubits go global at a remap (farthest next use),
+//   DistPlanner   pure host code: logical -> physical qubit map, which qubits go global at a remap (farthest next use; r4: by
+//                 modelled cost when that set would gather from inside a wave row),
 //                 the op each rank applies to its shard.  Emits a list of steps (local op / pack / exchange).
 //                 qip_hip_dist_debug_plan serialises it: the CPU tests replay it with the oracle as the shard and gloo
 //                 as the transport (tests/test_distributed_cpu.py).
