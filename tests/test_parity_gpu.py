@@ -2050,14 +2050,13 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
         leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
         # r4: wide tiles (13-bit register-resident tile, seven free positions per sweep): IEEE-equal in circuit order, also
         # with the qubits relabelled; the 1e-12 mode with commuting reorder
-        c2w = circuits.c2_random_circuit(n, 3 * 40, seed=33)
+        # (bench.py's parity block checks every wide leg it times at n = 30 — Clifford+T, Grover and the relabelled 1e-12 mode too;
+        # test_wide_tiles_… compares wide with narrow sweeps bit for bit at n = 18)
+        c2w = circuits.c2_random_circuit(n, 2 * 40, seed=33)
         leg(c2w[:40], True, tile=1, tile_jit=1, tile_wide=1)
         leg(c2w[40:80], True, tile=1, tile_jit=1, tile_wide=1, tile_relabel=2)
-        leg(c2w[80:120], False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_relabel=1)
         leg(circuits.c2_random_circuit(n, 40, seed=35), False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
         leg(circuits.c3_qft(n)[170:330], False, max_len=160, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
-        leg(circuits.c4_clifford_t(n, 48, seed=34), True, tile=1, tile_jit=1, tile_wide=1)
-        leg(circuits.c5_grover_iteration(n)[70:140], True, max_len=96, tile=1, tile_jit=1, tile_wide=1)
         twin.close()
         assert abs(st.norm_sqr() - 1) < 1e-9
 
@@ -2580,6 +2579,8 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
              "qft": circuits.c3_qft(n),
              "grover_k3": circuits.c5_grover_iteration(n, dense_k3=True),
              "mixed_items": circuits.c2_random_circuit(n, 40, seed=3) + extra}
+    if not f64:  # (the f32 generator differs from the f64 one in the element type only: three circuits keep the suite's time down)
+        cases = {k: cases[k] for k in ("c2", "qft", "mixed_items")}
     for name, ops in cases.items():
         want = O.apply_ops_in_place(n, ops, x.copy())
         for tile, relabel in ((1, 0), (1, 2), (2, 0), (2, 1)):
