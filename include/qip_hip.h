@@ -332,7 +332,8 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
 int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);
 
 /* Per-kernel-class timing, collected when option "profile" = 1.
- * classes: see qip_hip_kernel_class_name(). Resets with *_profile_reset. */
+ * classes: see qip_hip_kernel_class_name() — enumerate them, the list grows at the end (r4: "k_sparse_ell", "k_sparse_tile").
+ * Resets with *_profile_reset. */
 int qip_hip_kernel_class_count(void);
 const char* qip_hip_kernel_class_name(int cls);
 int qip_hip_state_profile_get(qip_hip_state* s, int cls, uint64_t* launches,
