@@ -91,6 +91,7 @@ extern "C" {
 
     pub fn qip_hip_tile_lane_assignment(dtype: c_int, pass_bits: *const u32, lanepos: *mut u64) -> c_int;
     pub fn qip_hip_debug_tile_plan(dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int) -> *const c_char;
+    pub fn qip_hip_debug_sparse_tile(dtype: c_int, n: u32, op: *const qip_op) -> *const c_char;
 
     pub fn qip_hip_state_set_option(s: *mut qip_hip_state, key: *const c_char, value: i64) -> c_int;
     pub fn qip_hip_kernel_class_count() -> c_int;

@@ -246,6 +246,12 @@ int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint64_t*
  * and checks the result against the CPU oracle, so the host half of the tile path is covered without a GPU. */
 const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode);
 
+/* Host-only test hook (r4): what the host decides about applying ONE SparseMatrix op in place through the LDS-staged tile
+ * kernel (k_sparse_tile) on a state of n qubits — the tile's positions, the block-base descriptor, the row table (entries per
+ * row, each stored column's place in the tile, the values) — as JSON, or {"applies":0} when the op takes another kernel.
+ * tests/test_tile_plan_cpu.py replays it with a numpy model of the kernel against the CPU oracle.  NULL on error. */
+const char* qip_hip_debug_sparse_tile(int dtype, uint32_t n, const qip_op* op);
+
 /* Number of index bits of a tile of the LDS-resident multi-gate sweeps (low 6 bits + the free positions). */
 int qip_hip_tile_bits(void);
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "qip_hip_plan_tiles": (_int, [_int, _u32, _opp, _u64, _int, C.POINTER(C.c_int64), _u64p]),
     "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "qip_hip_debug_tile_plan": (_cp, [_int, _u32, _opp, _u64, _int]),
+    "qip_hip_debug_sparse_tile": (_cp, [_int, _u32, _opp]),
     "qip_hip_tile_bits": (_int, []),
     "qip_hip_jit_cache_info": (_int, [_u64p, _u64p, _u64p]),
     "qip_hip_jit_stats": (_int, [_u64p, _dblp]),

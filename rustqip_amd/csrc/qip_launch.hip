@@ -996,12 +996,12 @@ static int launch_sparse_ell(qip_hip_state* s, const Plan& p, const FlatOp& f, b
 // wave row number 3..7: in place through k_sparse_tile (the group staged in LDS beside the row).  *done = false: not this shape.
 int64_t g_sparse_tile = 1;  // global option "sparse_tile": 0 = always the out-of-place gather (k_sparse_ell), for A/B runs
 // the shape test alone (program capture asks it too: an op that takes this form stays in place, so the program can be a graph)
-static bool sparse_tile_shape(const qip_hip_state* s, const Plan& p, const FlatOp& f, SparseTileDesc* dout, std::vector<uint32_t>* hp_out,
+static bool sparse_tile_shape(uint32_t n, int dtype, const Plan& p, const FlatOp& f, SparseTileDesc* dout, std::vector<uint32_t>* hp_out,
                               std::vector<uint32_t>* ctl_out_out, uint32_t* e_out) {
   if (!g_sparse_tile || f.inner->kind != QIP_OP_SPARSE || !f.distinct) return false;
   const uint32_t k = f.n_op;
-  if (k < (s->dtype == QIP_C64 ? 4u : 6u)) return false;  // (Complex<f32>, measured at n = 30: k = 5 one group per lane 67.6 % against 63.2 %; k = 4 even)
-  const uint32_t p5 = tile_p5(s->dtype, s->n);
+  if (k < (dtype == QIP_C64 ? 4u : 6u)) return false;  // (Complex<f32>, measured at n = 30: k = 5 one group per lane 67.6 % against 63.2 %; k = 4 even)
+  const uint32_t p5 = tile_p5(dtype, n);
   SparseTileDesc d;
   memset(&d, 0, sizeof d);
   d.p5 = p5;
@@ -1018,7 +1018,7 @@ static bool sparse_tile_shape(const qip_hip_state* s, const Plan& p, const FlatO
   d.kh = (uint32_t)hp.size();
   d.nlow = (uint32_t)__builtin_popcount(d.low_op);
   // 2^(6+kh) amplitudes per tile: up to 64 KiB (two blocks per CU) — Complex<f64> kh = 7 is one 128-KiB block of 1024 lanes per CU
-  if (d.kh < 3 || d.kh > 7 || s->n < 6 + d.kh + (uint32_t)ctl_out.size() + 2) return false;
+  if (d.kh < 3 || d.kh > 7 || n < 6 + d.kh + (uint32_t)ctl_out.size() + 2) return false;
   const uint64_t rows = 1ull << k;
   const uint64_t* rp = f.inner->sparse_rowptr;
   uint64_t widest = 0;
@@ -1032,17 +1032,26 @@ static bool sparse_tile_shape(const qip_hip_state* s, const Plan& p, const FlatO
   return true;
 }
 bool sparse_tile_applies(const qip_hip_state* s, const Plan& p, const FlatOp& f) {
-  return sparse_tile_shape(s, p, f, nullptr, nullptr, nullptr, nullptr);
+  return sparse_tile_shape(s->n, s->dtype, p, f, nullptr, nullptr, nullptr, nullptr);
 }
 
+// Everything the host decides about one k_sparse_tile launch — pure host code (qip_hip_debug_sparse_tile serialises it: the CPU
+// tests replay it with a numpy model of the kernel against the oracle, tests/test_tile_plan_cpu.py)
+template <typename T> struct SparseTilePlan {
+  SparseTileDesc d;
+  Ins ins;
+  uint64_t ntiles = 0;
+  uint32_t E = 1, threads = 0;
+  std::vector<uint32_t> nnz, slot;
+  std::vector<amp_t<T>> val;
+};
 template <typename T>
-static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
-  *done = false;
+static bool build_sparse_tile_plan(uint32_t n, int dtype, const Plan& p, const FlatOp& f, SparseTilePlan<T>* out) {
   const uint32_t k = f.n_op;
   SparseTileDesc d;
   std::vector<uint32_t> hp, ctl_out;
   uint32_t E = 1;
-  if (!sparse_tile_shape(s, p, f, &d, &hp, &ctl_out, &E)) return QIP_OK;
+  if (!sparse_tile_shape(n, dtype, p, f, &d, &hp, &ctl_out, &E)) return false;
   const uint32_t p5 = d.p5;
   const uint64_t rows = 1ull << k;
   const uint64_t* rp = f.inner->sparse_rowptr;
@@ -1060,8 +1069,11 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
     if (tile_is_low(p.opos[j], p5)) tbit[j] = tile_low_bit(p.opos[j]);
     else tbit[j] = 6u + (uint32_t)(std::find(hp.begin(), hp.end(), p.opos[j]) - hp.begin());
   }
-  std::vector<uint32_t> nnz(rows), slot(rows * E, 0);
-  std::vector<amp_t<T>> val(rows * E, mk<T>(0, 0));
+  std::vector<uint32_t>&nnz = out->nnz, &slot = out->slot;
+  std::vector<amp_t<T>>& val = out->val;
+  nnz.assign(rows, 0);
+  slot.assign(rows * E, 0);
+  val.assign(rows * E, mk<T>(0, 0));
   const amp_t<T>* sv = (const amp_t<T>*)f.inner->sparse_vals;
   for (uint64_t mp = 0; mp < rows; ++mp) {
     uint64_t m = 0;  // stored row: op index j is sub-index bit k-1-j (matrix_ops.rs:12-21)
@@ -1075,6 +1087,32 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
       val[mp * E + (q - rp[m])] = sv[q];
     }
   }
+  // the block base: the tile's high positions and the outside controls opened, the controls reading 1 (tile_block_base works in
+  // the space where p5 and 5 have traded places)
+  std::vector<uint32_t> opened = hp;
+  for (uint32_t c : ctl_out) opened.push_back(c);
+  uint64_t ones = 0;
+  for (uint32_t& o : opened)
+    if (o == 5u) o = p5;
+  for (uint32_t c : ctl_out) ones |= 1ull << (c == 5u ? p5 : c);
+  out->d = d;
+  out->ins = make_ins(opened, ones);
+  out->ntiles = 1ull << (n - 6 - d.kh - (uint32_t)ctl_out.size());
+  out->threads = 1u << (d.kh + 3);
+  out->E = E;
+  return true;
+}
+
+template <typename T>
+static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, bool* done) {
+  *done = false;
+  SparseTilePlan<T> sp;
+  if (!build_sparse_tile_plan<T>(s->n, s->dtype, p, f, &sp)) return QIP_OK;
+  const SparseTileDesc& d = sp.d;
+  const uint32_t E = sp.E;
+  const uint64_t rows = 1ull << f.n_op;
+  const std::vector<uint32_t>&nnz = sp.nnz, &slot = sp.slot;
+  const std::vector<amp_t<T>>& val = sp.val;
   const size_t b_nnz = rows * 4, b_slot = rows * E * 4, b_val = rows * E * sizeof(amp_t<T>);
   const size_t o_slot = (b_nnz + 15) & ~(size_t)15, o_val = (o_slot + b_slot + 15) & ~(size_t)15;
   QCHK(ensure_arena(s, o_val + b_val + 16));
@@ -1084,17 +1122,9 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
   const uint32_t* dn = (const uint32_t*)s->arena;
   const uint32_t* dslot = (const uint32_t*)((char*)s->arena + o_slot);
   const amp_t<T>* dval = (const amp_t<T>*)((char*)s->arena + o_val);
-  // the block base: the tile's high positions and the outside controls opened, the controls reading 1 (tile_block_base works in
-  // the space where p5 and 5 have traded places)
-  std::vector<uint32_t> opened = hp;
-  for (uint32_t c : ctl_out) opened.push_back(c);
-  uint64_t ones = 0;
-  for (uint32_t& o : opened)
-    if (o == 5u) o = p5;
-  for (uint32_t c : ctl_out) ones |= 1ull << (c == 5u ? p5 : c);
-  const Ins ins = make_ins(opened, ones);
-  const uint64_t ntiles = 1ull << (s->n - 6 - d.kh - (uint32_t)ctl_out.size());
-  const unsigned threads = 1u << (d.kh + 3);
+  const Ins ins = sp.ins;
+  const uint64_t ntiles = sp.ntiles;
+  const unsigned threads = sp.threads;
   const size_t lds = sizeof(amp_t<T>) << (6 + d.kh);
   const dim3 grid = grid2d(ntiles, 1);
   amp_t<T>* st = (amp_t<T>*)s->cur;
@@ -1118,6 +1148,52 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
   HIPCHK(hipGetLastError());
   *done = true;
   return QIP_OK;
+}
+
+// Host-only test hook (include/qip_hip.h): the k_sparse_tile plan of one op as JSON, "{\"applies\":0}" when the op takes another kernel
+template <typename T>
+static void sparse_tile_json(uint32_t n, int dtype, const Plan& p, const FlatOp& f, std::string* js) {
+  SparseTilePlan<T> sp;
+  if (!build_sparse_tile_plan<T>(n, dtype, p, f, &sp)) {
+    *js = "{\"applies\":0}";
+    return;
+  }
+  auto list = [&](const char* key, const std::vector<uint64_t>& v) {
+    *js += std::string(",\"") + key + "\":[";
+    for (size_t i = 0; i < v.size(); ++i) *js += (i ? "," : "") + std::to_string(v[i]);
+    *js += "]";
+  };
+  *js = "{\"applies\":1,\"n\":" + std::to_string(n) + ",\"kh\":" + std::to_string(sp.d.kh) + ",\"p5\":" + std::to_string(sp.d.p5) +
+        ",\"low_op\":" + std::to_string(sp.d.low_op) + ",\"nlow\":" + std::to_string(sp.d.nlow) + ",\"low_ctl\":" + std::to_string(sp.d.low_ctl) +
+        ",\"E\":" + std::to_string(sp.E) + ",\"threads\":" + std::to_string(sp.threads) + ",\"ntiles\":" + std::to_string(sp.ntiles) +
+        ",\"ins_ormask\":" + std::to_string(sp.ins.ormask);
+  list("hpos", std::vector<uint64_t>(sp.d.hpos, sp.d.hpos + sp.d.kh));
+  list("ins_pos", std::vector<uint64_t>(sp.ins.pos, sp.ins.pos + sp.ins.npos));
+  list("nnz", std::vector<uint64_t>(sp.nnz.begin(), sp.nnz.end()));
+  list("slot", std::vector<uint64_t>(sp.slot.begin(), sp.slot.end()));
+  *js += ",\"val\":[";
+  char buf[80];
+  for (size_t i = 0; i < sp.val.size(); ++i) {
+    snprintf(buf, sizeof buf, "%s[%.17g,%.17g]", i ? "," : "", (double)sp.val[i].x, (double)sp.val[i].y);
+    *js += buf;
+  }
+  *js += "]}";
+}
+extern "C" const char* qip_hip_debug_sparse_tile(int dtype, uint32_t n, const qip_op* op) {
+  static thread_local std::string json;
+  try {
+    if (!op || (dtype != QIP_C64 && dtype != QIP_C32)) return fail(QIP_ERR_INVALID, "null op or bad dtype"), nullptr;
+    FlatOp f;
+    if (flatten_op(n, op, false, &f) != QIP_OK) return nullptr;
+    Plan p;
+    if (make_plan(dtype, n, f, false, &p) != QIP_OK) return nullptr;
+    if (dtype == QIP_C64) sparse_tile_json<double>(n, dtype, p, f, &json);
+    else sparse_tile_json<float>(n, dtype, p, f, &json);
+    return json.c_str();
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  }
 }
 
 template <typename T>

@@ -281,6 +281,19 @@ def debug_tile_jit(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64) -> dic
             "first_source": (first.value or b"").decode()}
 
 
+def debug_sparse_tile(n: int, op, dtype: int = _ffi.QIP_C64) -> dict:
+    """Host-only test hook (qip_hip_debug_sparse_tile): what the host ships to k_sparse_tile for one SparseMatrix op, or
+    {"applies": 0} when the op takes another kernel."""
+    import json
+
+    cop = op.to_c(dtype)
+    arr = (_ffi.QipOp * 1)(cop)
+    txt = _ffi.lib.qip_hip_debug_sparse_tile(dtype, n, arr)
+    if not txt:
+        raise CircuitError(_ffi.last_error())
+    return json.loads(txt.decode() if isinstance(txt, bytes) else txt)
+
+
 def debug_tile_plan(n: int, ops, mode: int = 1, dtype: int = _ffi.QIP_C64) -> dict:
     """Host-only test hook (qip_hip_debug_tile_plan): the tile schedule plus every segment's passes and gate
     descriptors as shipped to the kernel, parsed from JSON."""

@@ -616,3 +616,115 @@ def test_wide_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode):
     assert any(st.get("wide") for st in plan["steps"])
     want = O.apply_ops_in_place(n, ops, x.copy())
     assert np.max(np.abs(got - want)) <= 1e-12, (name, mode)
+
+
+# ---- k_sparse_tile (r4): the host half of the in-place SparseMatrix kernel without a GPU ------------------------------------------
+def debug_sparse_tile(n, op, dtype=None):
+    from rustqip_amd import _ffi
+    from rustqip_amd.ops import debug_sparse_tile as hook
+
+    return hook(n, op, _ffi.QIP_C64 if dtype is None else dtype)
+
+
+def emulate_sparse_tile(state, n, plan):
+    """k_sparse_tile on a numpy vector, restated from the kernel: block -> tile base (tile_block_base: the block number spread over
+    the positions `ins` leaves open, in the space where position 5 and p5 have traded places, the controls outside the tile read 1),
+    lane -> the six row positions (0..4 and p5), tile row -> the op's other positions; every output row folds its stored entries
+    in stored order from 0 out of the staged tile; lanes whose in-row controls do not all read 1 keep their amplitudes."""
+    kh, p5, E = plan["kh"], plan["p5"], plan["E"]
+    hpos, low_op, low_ctl, nlow = plan["hpos"], plan["low_op"], plan["low_ctl"], plan["nlow"]
+    nnz = np.array(plan["nnz"], dtype=np.int64)
+    slot = np.array(plan["slot"], dtype=np.int64).reshape(-1, E)
+    val = np.array([complex(a, b) for a, b in plan["val"]], dtype=state.dtype).reshape(-1, E)
+    assert plan["threads"] == 1 << (kh + 3) and len(hpos) == kh and len(nnz) == 1 << (kh + nlow)
+    ins_pos, ormask = plan["ins_pos"], plan["ins_ormask"]
+    assert ins_pos == sorted(ins_pos)
+    lane = np.arange(64, dtype=np.int64)
+    lane_off = (lane & 31) | ((lane >> 5) << p5)
+    rows = np.arange(1 << kh, dtype=np.int64)
+    row_off = np.zeros_like(rows)
+    for j, hp in enumerate(hpos):
+        row_off |= ((rows >> j) & 1) << hp
+    ml = np.zeros(64, dtype=np.int64)  # the op's lane bits, packed
+    o = 0
+    for b in range(6):
+        if (low_op >> b) & 1:
+            ml |= ((lane >> b) & 1) << o
+            o += 1
+    assert o == nlow
+    keep = lane & ~low_op
+    active = (lane & low_ctl) == low_ctl
+    out = state.copy()
+    touched = np.zeros(1 << n, dtype=bool)
+    for blk in range(plan["ntiles"]):
+        w = blk << 6
+        for p in ins_pos:  # insert_bits: a zero at every listed position, ascending, then the ones
+            w = ((w >> p) << (p + 1)) | (w & ((1 << p) - 1))
+        w |= ormask
+        if p5 != 5:  # back from the traded space: the bit that stands at p5 belongs at 5
+            b = (w >> p5) & 1
+            w = (w & ~(1 << p5)) | (b << 5)
+        g = (w | row_off[:, None] | lane_off[None, :])  # (rows, lanes) global indices
+        assert not touched[g].any()
+        touched[g] = True
+        tile = state[g].reshape(-1)  # tile index = (row << 6) | lane
+        m = ml[None, :] | (rows[:, None] << nlow)
+        acc = np.zeros(g.shape, dtype=state.dtype)
+        for e in range(E):
+            v, xx = val[m, e], tile[slot[m, e] | keep[None, :]]
+            # num-complex's product, component by component (numpy's own complex multiply may fuse): cmul in qip_kernels.h
+            term = (v.real * xx.real - v.imag * xx.imag) + 1j * (v.real * xx.imag + v.imag * xx.real)
+            acc = np.where(e < nnz[m], acc + term.astype(state.dtype), acc)
+        out[g] = np.where(active[None, :], acc, state[g])
+    return out, touched
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_sparse_tile_plan_replayed_on_cpu_matches_the_oracle(dtype):
+    """r4: qip_hip_debug_sparse_tile exports what the host ships to k_sparse_tile (descriptor, block-base insert list, row table);
+    the numpy model above replays it and must reproduce the oracle bit for bit (same fold order) — op positions inside and outside
+    the wave row, the split position as an op bit and as a control, position 5, controls inside / outside, ragged rows, 1 / 2 / 4
+    entries per row, seven positions outside the row; and the shapes that must NOT take this kernel."""
+    from rustqip_amd import _ffi
+
+    n = 16
+    f64 = dtype == np.complex128
+    code = _ffi.QIP_C64 if f64 else _ffi.QIP_C32
+    rng = np.random.default_rng(16)
+    x = circuits.random_state(n, seed=4, dtype=dtype)
+
+    def rand_rows(k, width):
+        return [[(int(rng.integers(0, 1 << k)), complex(rng.standard_normal(), rng.standard_normal())) for _ in range(int(rng.integers(1, width + 1)))]
+                for _ in range(1 << k)]
+
+    perm = rng.permutation(1 << 8)
+    cases = {
+        "perm_phase8_kh7": q.make_sparse_matrix_op([15, 0, 9, 3, 11 if f64 else 12, 5, 1, 2], [[(int(perm[r]), complex(np.exp(0.1j * r)))] for r in range(256)]),
+        "two_per_row6": q.make_sparse_matrix_op([2, 15, 8, 0, 9, 5], rand_rows(6, 2)),
+        "four_per_row7_two_in_row": q.make_sparse_matrix_op([4, 1, 14, 9, 13, 0, 7], rand_rows(7, 4)),
+        "split_position_op_and_position5": q.make_sparse_matrix_op([4, 0, 10, 3, 9, 1], rand_rows(6, 3)),
+        "controls_in_and_out": q.make_control_op([13, 1, 11], q.make_sparse_matrix_op([0, 2, 4, 8, 6, 15], rand_rows(6, 2))),
+        "split_position_ctl": q.make_control_op([4, 10], q.make_sparse_matrix_op([0, 2, 5, 8, 7, 15], rand_rows(6, 2))),
+        "k5": q.make_sparse_matrix_op([0, 3, 6, 9, 1], rand_rows(5, 2)),
+    }
+    for name, op in cases.items():
+        plan = debug_sparse_tile(n, op, code)
+        if name == "k5" and not f64:
+            assert plan["applies"] == 0  # (Complex<f32>: k = 4, 5 stay with one group per lane)
+            continue
+        assert plan["applies"] == 1, name
+        got, touched = emulate_sparse_tile(x, n, plan)
+        want = O.apply_ops_in_place(n, [op], x.copy())
+        assert np.array_equal(got, want), name
+        # every amplitude inside the op's controlled sub-space is written exactly once, nothing outside the outside controls is read
+        nctl_out = n - 6 - plan["kh"] - int(math.log2(plan["ntiles"]))
+        assert int(touched.sum()) == (1 << n) >> nctl_out, name
+    # not this kernel: five entries in a row, only two positions outside the wave row, eight outside, a state too small, a dense op
+    for name, op, nn in (("five_per_row", q.make_sparse_matrix_op([2, 15, 8, 0, 9, 5], rand_rows(6, 5) + []), n),
+                         ("two_outside", q.make_sparse_matrix_op([15, 14, 13, 12, 11 if not f64 else 4, 0, 1], rand_rows(7, 2)), n),
+                         ("eight_outside", q.make_sparse_matrix_op([0, 1, 2, 3, 5, 6, 7, 8], [[(r, 1.0)] for r in range(256)]), n),
+                         ("small_state", q.make_sparse_matrix_op([0, 1, 2, 3, 4, 5], rand_rows(6, 2)), 10),
+                         ("dense", q.make_matrix_op([0, 9], np.eye(4).ravel()), n)):
+        if name == "five_per_row":
+            op = q.make_sparse_matrix_op([2, 15, 8, 0, 9, 5], [[(c, 1.0) for c in range(5)] for _ in range(64)])
+        assert debug_sparse_tile(nn, op, code)["applies"] == 0, name
