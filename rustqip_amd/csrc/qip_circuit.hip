@@ -639,8 +639,13 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
 // transposition costs its LDS traffic and two barriers per quarter, no register moves); the gates go through the same helpers
 // as the 11-bit sweeps (pass_dense, pass_scale, pass_swap, pass_dense2, pass_dense3w over 32 elements: the products and sums of
 // the gate-by-gate kernels in the same order — a circuit-order segment stays IEEE-equal to them).
+// `pin` (global option "tile_wide_pin", debug mode bit 256; r4, measured offline only — profiles/r04_wide_tiles.md): after every gate that
+// is applied under a block-uniform branch (a control / selector outside the tile) the 32 amplitudes pass through an empty asm with
+// "+v" constraints.  Semantically nothing; it stops the register allocator from keeping both versions of the tile alive across the join:
+// Clifford+T's first segment 175 VGPR spills -> 0 (9238 -> 8646 instructions), QFT's 32 -> 0; configs[1] (no spills) + 4 % instructions.
+int64_t g_tile_wide_pin = 0;
 template <typename T>
-static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false) {
+static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   constexpr uint32_t SW = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // tile_slot's fold width
   auto slot = [&](uint32_t t) { return t ^ ((t >> SW) & ((1u << SW) - 1u)); };
@@ -890,6 +895,11 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
       }
       if (g.omask) L("      if ((base & g.omask) == g.omask) { " + call + " }");
       else L("      { " + call + " }");
+      if (pin && (g.omask || call.compare(0, 9, "if ((base") == 0)) {
+        std::string pl = "     ";
+        for (int i = 0; i < 32; ++i) pl += " asm volatile(\"\" : \"+v\"(e[" + N(i) + "].x), \"+v\"(e[" + N(i) + "].y));";
+        L(pl);
+      }
       L("      __builtin_amdgcn_sched_barrier(0);");
       L("    }");
     }
@@ -1160,7 +1170,7 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   const bool parametrised = s->tile_jit != 3;
   std::vector<T> params;
   const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
-  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge);
+  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge, g_tile_wide_pin != 0);
   if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
   QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss before the timed region starts
   if (s->jit_prepare) return QIP_OK;
@@ -1276,7 +1286,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     if ((mode & 16) && n > (uint32_t)kWideBits) {  // mode bit 4: wide tiles
       WidePlan<T> wplan;
       QCHK(build_wide_segment<T>(n, seg, st.high, &wplan, mode & 3));
-      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0);
+      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0, (mode & 256) != 0);
       if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
     } else {
       TileSegmentPlan<T> plan;

@@ -2596,6 +2596,23 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
             if tile == 1 and relabel == 0 and f64 and name != "grover_k3":
                 assert np.array_equal(res[1][0], res[0][0]), (name, "wide and narrow circuit-order sweeps differ")
             assert res[1][1] <= res[0][1], (name, tile, relabel, res[0][1], res[1][1])  # never more sweeps than the narrow plan
+        if name == "c4" and f64:  # global option tile_wide_pin (register pins after block-uniform branches: no semantics): the very same bits
+            q.set_global_option("tile_wide_pin", 1)
+            try:
+                with q.HipState(n, dtype) as st:
+                    for k, v in (("tile", 1), ("tile_jit", 1), ("tile_wide", 1)):
+                        st.set_option(k, v)
+                    st.upload(x)
+                    st.apply_ops(ops)
+                    pinned = st.download()
+            finally:
+                q.set_global_option("tile_wide_pin", 0)
+            with q.HipState(n, dtype) as st:
+                for k, v in (("tile", 1), ("tile_jit", 1), ("tile_wide", 1)):
+                    st.set_option(k, v)
+                st.upload(x)
+                st.apply_ops(ops)
+                assert np.array_equal(pinned, st.download())
         if name in ("qft", "c4"):  # merged runs of diagonal gates + fused multiply-adds in the wide generator (1e-12 mode)
             with q.HipState(n, dtype) as st:
                 for k, v in (("tile", 2), ("tile_jit", 1), ("tile_wide", 1), ("tile_fma", 1), ("tile_merge", 1)):
