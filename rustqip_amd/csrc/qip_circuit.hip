@@ -639,11 +639,13 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
 // transposition costs its LDS traffic and two barriers per quarter, no register moves); the gates go through the same helpers
 // as the 11-bit sweeps (pass_dense, pass_scale, pass_swap, pass_dense2, pass_dense3w over 32 elements: the products and sums of
 // the gate-by-gate kernels in the same order — a circuit-order segment stays IEEE-equal to them).
-// `pin` (global option "tile_wide_pin", debug mode bit 256; r4, measured offline only — profiles/r04_wide_tiles.md): after every gate that
+// `pin` (global option "tile_wide_pin", debug mode bit 256; r4, profiles/r04_wide_tiles.md): after every gate that
 // is applied under a block-uniform branch (a control / selector outside the tile) the 32 amplitudes pass through an empty asm with
 // "+v" constraints.  Semantically nothing; it stops the register allocator from keeping both versions of the tile alive across the join:
 // Clifford+T's first segment 175 VGPR spills -> 0 (9238 -> 8646 instructions), QFT's 32 -> 0; configs[1] (no spills) + 4 % instructions.
-int64_t g_tile_wide_pin = 0;
+// On the GPU (tools/exp_wide_pin.py, n = 30, tile = 1, medians of 5): a 72-gate Clifford+T prefix 25.92 -> 23.90 ms (-7.8 %), a 60-gate
+// configs[1] prefix 17.42 -> 17.49 ms (noise); results bit-identical.  Default on.
+int64_t g_tile_wide_pin = 1;
 template <typename T>
 static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";

@@ -2596,8 +2596,8 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
             if tile == 1 and relabel == 0 and f64 and name != "grover_k3":
                 assert np.array_equal(res[1][0], res[0][0]), (name, "wide and narrow circuit-order sweeps differ")
             assert res[1][1] <= res[0][1], (name, tile, relabel, res[0][1], res[1][1])  # never more sweeps than the narrow plan
-        if name == "c4" and f64:  # global option tile_wide_pin (register pins after block-uniform branches: no semantics): the very same bits
-            q.set_global_option("tile_wide_pin", 1)
+        if name == "c4" and f64:  # global option tile_wide_pin (register pins after block-uniform branches: no semantics; default on): the very same bits without
+            q.set_global_option("tile_wide_pin", 0)
             try:
                 with q.HipState(n, dtype) as st:
                     for k, v in (("tile", 1), ("tile_jit", 1), ("tile_wide", 1)):
@@ -2606,7 +2606,7 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
                     st.apply_ops(ops)
                     pinned = st.download()
             finally:
-                q.set_global_option("tile_wide_pin", 0)
+                q.set_global_option("tile_wide_pin", 1)
             with q.HipState(n, dtype) as st:
                 for k, v in (("tile", 1), ("tile_jit", 1), ("tile_wide", 1)):
                     st.set_option(k, v)

@@ -595,8 +595,9 @@ def test_wide_tile_segments_plan_and_compile_without_a_gpu():
         assert "A e0[32];" in src and "__launch_bounds__(256, 2)" in src
     from rustqip_amd import _ffi
 
-    r = debug_tile_jit(n, ops, 1 | 16 | 64, _ffi.QIP_C32)
-    assert r["segments"] >= 1
+    for mode in (1 | 16 | 64, 1 | 16 | 64 | 256):
+        r = debug_tile_jit(n, ops, mode, _ffi.QIP_C32)
+        assert r["segments"] >= 1
 
 
 @pytest.mark.parametrize("mode", [1 | 16, 2 | 16, 1 | 4 | 8 | 16, 2 | 4 | 16])

@@ -33,10 +33,13 @@ def run(n, ops, pin, reps=0):
         return sorted(ts)[len(ts) // 2] * 1e3
 
 
-a = run(16, circuits.c4_clifford_t(16, 48, seed=32), 0)
-b = run(16, circuits.c4_clifford_t(16, 48, seed=32), 1)
-print("n=16 bit-identical:", bool(np.array_equal(a, b)))
-ops = circuits.c4_clifford_t(30, 256, seed=32)[:int(sys.argv[1]) if len(sys.argv) > 1 else 72]
+name = sys.argv[2] if len(sys.argv) > 2 else "c4"
+if name == "c4":
+    a = run(16, circuits.c4_clifford_t(16, 48, seed=32), 0)
+    b = run(16, circuits.c4_clifford_t(16, 48, seed=32), 1)
+    print("n=16 bit-identical:", bool(np.array_equal(a, b)))
+full = circuits.c4_clifford_t(30, 256, seed=32) if name == "c4" else circuits.c2_random_circuit(30, 256, seed=28)
+ops = full[:int(sys.argv[1]) if len(sys.argv) > 1 else 72]
 for pin in (0, 1):
-    print("n=30 Clifford+T prefix of %d gates, tile = 1 wide, pin = %d: %.2f ms (median of 5)" % (len(ops), pin, run(30, ops, pin, 5)))
-q.set_global_option("tile_wide_pin", 0)
+    print("n=30 %s prefix of %d gates, tile = 1 wide, pin = %d: %.2f ms (median of 5)" % (name, len(ops), pin, run(30, ops, pin, 5)))
+q.set_global_option("tile_wide_pin", 1)
