@@ -116,6 +116,8 @@ int qip_hip_abi_version(void);
  *   "tile_wide_pin"    1 (default) / 0: wide segments pass their 32 amplitudes through an empty register constraint after every gate
  *                      applied under a block-uniform branch — no semantics (bit-identical results), fewer spills in branch-heavy
  *                      segments (Clifford+T: 175 -> 0 VGPR spills, a 72-gate prefix at n = 30 25.9 -> 23.9 ms; configs[1] unchanged).
+ *   "tile_wide_dense3_inline"  0 (default): experimental — dense 3-qubit gates of wide segments written out group by group (offline: the
+ *                      528-byte stack object per lane disappears); compiled in the CPU suite, NOT yet run on a GPU: leave off.
  *   "sparse_tile"      1 (default): a SparseMatrix on k >= 6 qubits with <= 4 entries per row and 3..7 of its positions outside
  *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
  *                      gather (k_sparse_ell).  Same results bit for bit.

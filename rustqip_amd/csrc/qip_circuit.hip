@@ -646,8 +646,13 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
 // On the GPU (tools/exp_wide_pin.py, n = 30, tile = 1, medians of 5): a 72-gate Clifford+T prefix 25.92 -> 23.90 ms (-7.8 %), a 60-gate
 // configs[1] prefix 17.42 -> 17.49 ms (noise); results bit-identical.  Default on.
 int64_t g_tile_wide_pin = 1;
+// global option "tile_wide_dense3_inline" (debug mode bit 512; r4, OFF: compiled and register-checked without a GPU, never run on one):
+// dense 3-qubit gates of a wide segment written out group by group instead of through pass_dense3w — the dense-k3 Grover variant's first
+// wide segment: 528 B of stack per lane -> 0 (tools/jit_segment_resources.py, mode | 512).  The next round's first measurement.
+int64_t g_tile_wide_dense3_inline = 0;
 template <typename T>
-static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false) {
+static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false,
+                                   bool dense3_inline = false) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   constexpr uint32_t SW = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // tile_slot's fold width
   auto slot = [&](uint32_t t) { return t ^ ((t >> SW) & ((1u << SW) - 1u)); };
@@ -892,6 +897,28 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
         call = "pass_swap<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ">(e, c, g.cm_reg, " + lane_args + ");";
       } else if (g.kind == 3) {
         call = matrix(16) + "pass_dense2<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
+      } else if (g.kind == 4 && dense3_inline) {
+        // The same fold as pass_dense3w, written out for the (at most four) groups this gate really touches, every index a literal.
+        // pass_dense3w's loop over the 32 elements is not unrolled by the compiler at NE = 32: `e` is indexed at run time and the whole
+        // tile of the lane lives in a 528-byte stack object (profiles/r04_jit_segment_resources.txt: dense-k3 Grover on wide tiles).
+        const int JA = jof(g.b0), JB = jof(g.b1), JC = jof(g.tpos_out);
+        call = matrix(64);
+        for (int base = 0; base < 32; ++base) {
+          if (((base >> JA) & 1) || ((base >> JB) & 1) || ((base >> JC) & 1)) continue;
+          uint32_t cb = 0;
+          for (int j = 0; j < kWideRegBits; ++j)
+            if ((base >> j) & 1) cb |= 1u << ps.R[j];
+          if ((cb & g.cm_reg) != g.cm_reg) continue;
+          auto idx = [&](int r) { return base | (((r >> 2) & 1) << JA) | (((r >> 1) & 1) << JB) | ((r & 1) << JC); };
+          call += "{ const A x[8] = {";
+          for (int r = 0; r < 8; ++r) call += "e[" + N(idx(r)) + "]" + (r < 7 ? ", " : "}; ");
+          for (int r = 0; r < 8; ++r) {
+            call += "{ A acc = cmul(M[" + N(r * 8) + "], x[0]); ";
+            for (int c2 = 1; c2 < 8; ++c2) call += "acc = cadd(acc, cmul(M[" + N(r * 8 + c2) + "], x[" + N(c2) + "])); ";
+            call += "e[" + N(idx(r)) + "] = (g.cm_lane != 0u) ? tile_sel((tb & g.cm_lane) == g.cm_lane, acc, x[" + N(r) + "]) : acc; } __builtin_amdgcn_sched_barrier(0); ";
+          }
+          call += "} ";
+        }
       } else if (g.kind == 4) {
         call = matrix(64) + "pass_dense3w<T, " + N(jof(g.b0)) + ", " + N(jof(g.b1)) + ", " + N(jof(g.tpos_out)) + ">(M, e, c, g.cm_reg, " + lane_args + ");";
       }
@@ -1172,7 +1199,7 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   const bool parametrised = s->tile_jit != 3;
   std::vector<T> params;
   const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
-  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge, g_tile_wide_pin != 0);
+  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge, g_tile_wide_pin != 0, g_tile_wide_dense3_inline != 0);
   if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
   QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss before the timed region starts
   if (s->jit_prepare) return QIP_OK;
@@ -1288,7 +1315,7 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     if ((mode & 16) && n > (uint32_t)kWideBits) {  // mode bit 4: wide tiles
       WidePlan<T> wplan;
       QCHK(build_wide_segment<T>(n, seg, st.high, &wplan, mode & 3));
-      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0, (mode & 256) != 0);
+      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0, (mode & 256) != 0, (mode & 512) != 0);
       if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
     } else {
       TileSegmentPlan<T> plan;

@@ -68,6 +68,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
   if (key && !strcmp(key, "dist_plan_cost")) { g_dist_plan_cost = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "soft_measure_one_pass")) { g_soft_measure_one_pass = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_threads")) {

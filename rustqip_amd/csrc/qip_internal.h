@@ -65,7 +65,7 @@ extern int64_t g_single_via_tile, g_single_via_tile_f32;
 extern int64_t g_dist_fold_pack, g_dist_plan_cost;  // qip_dist.hip
 extern int64_t g_sparse_tile;  // qip_launch.hip
 extern int64_t g_soft_measure_one_pass;  // qip_measure.hip
-extern int64_t g_tile_wide_pin;  // qip_circuit.hip
+extern int64_t g_tile_wide_pin, g_tile_wide_dense3_inline;  // qip_circuit.hip
 extern int64_t g_jit_threads;     // qip_circuit.hip: host threads that compile a plan's new segments side by side
 extern int64_t g_force_k4_direct;  // tuning aid: dense k = 4 on the matrix cores reads its operands straight from HBM (k_gate_kq_mfma)  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 

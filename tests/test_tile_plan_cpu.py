@@ -588,14 +588,15 @@ def test_wide_tile_segments_plan_and_compile_without_a_gpu():
     u2, u3 = rand_unitary(2, rng), rand_unitary(3, rng)
     ops = circuits.c2_random_circuit(n, 60, seed=9) + [q.make_matrix_op([3, 12], u2.ravel()), q.make_matrix_op([15, 0, 7], u3.ravel()),
                                                         q.make_control_op([1, 14], q.make_matrix_op([9], circuits.H)), q.make_swap_op([2], [13])]
-    for mode in (1 | 16, 1 | 16 | 64, 2 | 16 | 32 | 64, 1 | 4 | 8 | 16 | 64, 2 | 16 | 32 | 64 | 128, 1 | 16 | 64 | 256):  # (bit 8: register pins after block-uniform branches)
+    # (bit 8: register pins after block-uniform branches; bit 9: dense 3-qubit gates written out group by group — literal and parametrised)
+    for mode in (1 | 16, 1 | 16 | 64, 2 | 16 | 32 | 64, 1 | 4 | 8 | 16 | 64, 2 | 16 | 32 | 64 | 128, 1 | 16 | 64 | 256, 1 | 16 | 512, 2 | 16 | 32 | 64 | 256 | 512):
         r = debug_tile_jit(n, ops, mode)
         assert r["segments"] >= 1 and r["code_bytes"] > 0, (mode, r)
         src = r["first_source"] if isinstance(r["first_source"], str) else r["first_source"].decode()
         assert "A e0[32];" in src and "__launch_bounds__(256, 2)" in src
     from rustqip_amd import _ffi
 
-    for mode in (1 | 16 | 64, 1 | 16 | 64 | 256):
+    for mode in (1 | 16 | 64, 1 | 16 | 64 | 256, 1 | 16 | 64 | 256 | 512):
         r = debug_tile_jit(n, ops, mode, _ffi.QIP_C32)
         assert r["segments"] >= 1
 

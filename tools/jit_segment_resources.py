@@ -1,7 +1,7 @@
 """Register use of a circuit's first run-time-compiled tile segment, without a GPU: the generated source
 (qip_hip_debug_tile_jit) compiled offline with the run-time flags and -Rpass-analysis=kernel-resource-usage.
     python tools/jit_segment_resources.py [n = 30] [c2,c4,grover,qft] [modes: 1|4|64, 2|4|64|128 ...]
-mode bits: 0-1 tile, 4 relabel, 64 numbers as kernel data, 128 merged diagonal runs."""
+mode bits: 0-1 tile, 4 relabel, 16 wide tiles, 64 numbers as kernel data, 128 merged diagonal runs, 256 register pins, 512 dense-3 gates written out."""
 import os
 import re
 import subprocess
@@ -20,7 +20,7 @@ def main():
     names = (sys.argv[2] if len(sys.argv) > 2 else "c2,c4,grover,qft").split(",")
     modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1 | 4 | 64, 2 | 4 | 64 | 128]
     cases = {"c2": circuits.c2_random_circuit(n, 256, seed=28), "c4": circuits.c4_clifford_t(n, 256, seed=32),
-             "grover": circuits.c5_grover_iteration(n), "qft": circuits.c3_qft(n)}
+             "grover": circuits.c5_grover_iteration(n), "groverk3": circuits.c5_grover_iteration(n, dense_k3=True), "qft": circuits.c3_qft(n)}
     for name in names:
         for mode in modes:
             r = debug_tile_jit(n, cases[name], mode)
