@@ -111,6 +111,9 @@ int qip_hip_abi_version(void);
  *   "dist_plan_cost"   1 (default): at a remap of a sharded state the leaving qubits are chosen by modelled cost — the count-optimal set
  *                      (farthest next use) unless the set that keeps the gather out of the wave rows is cheaper over the rest of the
  *                      circuit (exchange = shard / world bytes per link, free-standing gather = one copy of the shard); 0 = by count alone.
+ *                      EVERY RANK plans for itself: "dist_plan_cost", "dist_fold_pack" and "tile_row_split" must have the same value in
+ *                      every process of a sharded state.  A batch that contains an exchange compares a fingerprint of its communication
+ *                      steps across the ranks first (one 16-byte all-reduce) and is refused on all of them when they differ.
  *   "soft_measure_one_pass"  0 (default): soft_measure = chunk sums, host walk, crossing search in one chunk (two launches); 1 = one launch
  *                      whose last block does the walk and the search.  The same function of the sample; measured slower.
  *   "tile_wide_pin"    1 (default) / 0: wide segments pass their 32 amplitudes through an empty register constraint after every gate

@@ -1278,8 +1278,6 @@ int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg
   if (s->n < (uint32_t)kTileBits + (uint32_t)grid_ctl.size()) return QIP_OK;
   std::vector<const TileItem*> seg;
   for (const TileItem& t : parts) seg.push_back(&t);
-  const int64_t jit = s->tile_jit;
-  s->tile_jit = 0;  // one op does not repay a run-time compilation: the interpreter kernel
   // the free positions that pad the tile must not be control positions that left the grid
   if (!grid_ctl.empty()) {
     const uint32_t pad_from = std::min<uint32_t>((uint32_t)g_tile_pad_from, s->n > (uint32_t)kTileBits ? s->n - 5 : (uint32_t)kTileLow);
@@ -1289,6 +1287,8 @@ int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg
           hp.push_back(p);
     if (hp.size() != (size_t)kTileHigh) return QIP_OK;
   }
+  const int64_t jit = s->tile_jit;
+  s->tile_jit = 0;  // one op does not repay a run-time compilation: the interpreter kernel (no return between here and the restore)
   const int rc = launch_tile_segment<T>(s, seg, hp, p5, &grid_ctl, alg_bytes);
   s->tile_jit = jit;
   QCHK(rc);
@@ -1397,8 +1397,9 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   // gate-by-gate path: reported, not poisoned.
   bool moves_qubits = !sc.init_phys.empty() || sc.inserted > 0 || sc.absorbed > 0;
   for (const TileStep& st : sc.steps) moves_qubits = moves_qubits || !st.perm.empty();
-  s->layout.clear();
   const bool wide = (tile_mode_of(s) & 16) != 0;
+  // (the pre-compilation runs BEFORE the layout is cleared — a compiler failure here returns with the handle
+  // exactly as it was, still naming the layout the data is in)
   if (s->tile_jit && s->tile_passes && !s->capture_staging && !s->jit_prepare && g_jit_threads > 1) {
     // every segment of the plan that is not in the kernel cache yet, compiled side by side before anything runs
     std::vector<std::pair<std::string, bool>> jobs;
@@ -1417,10 +1418,17 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     QCHK(rc);
     QCHK(jit_compile_collected(s, jobs));
   }
+  s->layout.clear();
+  // The multi-GPU gather may ride in the last sweep's store phase only when that sweep addresses the CALLER's bit order: the
+  // request names caller-order positions (TileStorePerm.sel).  A plan that leaves the qubits relabelled (tile_relabel = 3 with
+  // a non-identity final layout) ends in physical positions that mean other qubits: no fold, the layout is settled and the
+  // gather runs as a sweep of its own (qip_dist.hip dist_run_steps).
+  bool ends_in_callers_order = true;
+  for (uint32_t p = 0; p < final_phys.size(); ++p) ends_in_callers_order = ends_in_callers_order && final_phys[p] == p;
   auto run_steps = [&]() -> int {
     size_t step_no = 0;
     for (const TileStep& st : sc.steps) {
-      s->fold_now = s->fold_request && ++step_no == sc.steps.size();  // (the batch's last step may store packed)
+      s->fold_now = s->fold_request && ends_in_callers_order && ++step_no == sc.steps.size();  // (the batch's last step may store packed)
       if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
         if (s->jit_prepare) continue;
         QCHK(launch_permute(s, st.perm.data()));

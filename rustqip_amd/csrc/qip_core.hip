@@ -452,8 +452,6 @@ extern "C" int qip_hip_state_destroy(qip_hip_state* s) try {
 extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
   STATE_ENTER_NOCHECK(s);
   if (index >= s->namps) return fail(QIP_ERR_INVALID, "basis index out of range");
-  s->layout.clear();  // whatever was there is overwritten: no need to restore its order first
-  s->poisoned = false;
   HIPCHK(hipMemsetAsync(s->cur, 0, s->namps * s->amp_bytes, s->stream));
   if (s->dtype == QIP_C64) {
     const double one[2] = {1.0, 0.0};
@@ -463,21 +461,30 @@ extern "C" int qip_hip_state_init_basis(qip_hip_state* s, uint64_t index) try {
     HIPCHK(hipMemcpyAsync((char*)s->cur + index * 8, one, 8, hipMemcpyHostToDevice, s->stream));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
+  s->layout.clear();  // whatever was there has been overwritten: no order of its own to restore, and a poisoned handle is
+  s->poisoned = false;  // healthy again — only now that the writes have landed
   return QIP_OK;
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_state_upload(qip_hip_state* s, const void* src, uint64_t offset, uint64_t len) try {
-  if (s && s->poisoned && offset == 0 && len == s->namps) {  // a full upload overwrites whatever a failed batch left
-    s->poisoned = false;
-    s->layout.clear();
+  // a full upload overwrites whatever a failed batch left: it is the one call (with init_basis) a poisoned handle accepts.
+  // The handle is declared healthy only AFTER the copy has landed: a null source or a failed copy leaves it poisoned.
+  const bool heals = s && s->poisoned && offset == 0 && len == s->namps && len != 0;
+  if (heals) {
+    STATE_ENTER_NOCHECK(s);
+  } else {
+    STATE_ENTER(s);
   }
-  STATE_ENTER(s);
   if (offset > s->namps || len > s->namps - offset) return fail(QIP_ERR_INVALID, "upload range out of bounds");
   if (len == 0) return QIP_OK;
   if (!src) return fail(QIP_ERR_INVALID, "null source");
   HIPCHK(hipMemcpyAsync((char*)s->cur + offset * s->amp_bytes, src, len * s->amp_bytes,
                         hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if (heals) {
+    s->poisoned = false;
+    s->layout.clear();
+  }
   return QIP_OK;
 } QIP_CATCH_ALL
 

@@ -886,8 +886,38 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
 
 // run a planned batch; on failure the handle is poisoned (see qip_hip_dist::poisoned)
 static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps);
+static int dist_all_reduce(qip_hip_dist* d, double* v, uint64_t count);
+// Every rank plans for itself, from its own copy of the circuit and of the process-global options the planner reads
+// (dist_plan_cost, tile_row_split through row_p5(), dist_fold_pack): these MUST be identical on all ranks (include/qip_hip.h).
+// Ranks whose plans differ would post different exchanges — a deadlock or a silently wrong all-to-all — so a batch
+// that contains an exchange first compares a fingerprint of its communication steps (which exchanges, which positions each
+// gather selects) across the ranks: one 16-byte all-reduce, and every rank sees the same verdict, so all of them refuse together.
+static int dist_plans_agree(qip_hip_dist* d, const std::vector<qipd::Step>& steps) {
+  if (d->pl.world <= 1) return QIP_OK;
+  uint64_t h = 1469598103934665603ull, comm_steps = 0;
+  auto mix = [&](uint64_t v) {
+    h ^= v;
+    h *= 1099511628211ull;
+  };
+  for (const qipd::Step& st : steps) {
+    if (st.kind == qipd::Step::LOCAL) continue;  // (local ops legitimately differ between ranks: controls on rank bits)
+    comm_steps += 1;
+    mix(st.kind == qipd::Step::PACK ? 0x50u : 0x45u);
+    for (uint32_t p : st.sel) mix(0x100u + p);
+  }
+  if (comm_steps == 0) return QIP_OK;
+  const double v = (double)((h ^ (h >> 20) ^ (h >> 40)) & 0xfffffull);  // 20 bits: v^2 * world stays exact in a double
+  double r[2] = {v, v * v};
+  QCHK(dist_all_reduce(d, r, 2));
+  const double w = (double)d->pl.world;
+  if (r[0] != w * v || r[1] != w * v * v)
+    return fail(QIP_ERR_INVALID, "the ranks planned different exchanges for this batch (do they see the same circuit and the same "
+                                 "global options dist_plan_cost / tile_row_split / dist_fold_pack?)");
+  return QIP_OK;
+}
 static int dist_run_or_poison(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
-  const int rc = dist_run_steps(d, steps);
+  int rc = dist_plans_agree(d, steps);
+  if (rc == QIP_OK) rc = dist_run_steps(d, steps);
   if (rc != QIP_OK) {
     d->poisoned = true;
     d->poison_msg = g_last_error;

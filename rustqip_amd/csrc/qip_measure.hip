@@ -63,13 +63,14 @@ extern "C" int qip_hip_state_copy_from(qip_hip_state* dst, qip_hip_state* src) t
   if (src->n != dst->n || src->dtype != dst->dtype) return fail(QIP_ERR_INVALID, "states differ in size or precision");
   if (src->device != dst->device) return fail(QIP_ERR_UNSUPPORTED, "states live on different devices");
   if (!src->layout.empty()) QCHK(state_settle(src));  // a relabelled source: the caller's order first
-  dst->layout.clear();                                // (the destination is overwritten: nothing of its own to restore)
-  dst->poisoned = false;
   HIPCHK(hipStreamSynchronize(src->stream));  // everything queued on the source has landed
   HIPCHK(hipMemcpyAsync(dst->cur, src->cur, dst->namps * dst->amp_bytes, hipMemcpyDeviceToDevice, dst->stream));
   // the two handles own separate non-blocking streams: the copy has READ the source before this call returns, so the
   // caller may queue the next gate on `src` at once (a 16-GiB copy is not hidden by host latency)
   HIPCHK(hipStreamSynchronize(dst->stream));
+  // only now is the destination a healthy state in the caller's order (not before the copy has succeeded)
+  dst->layout.clear();  // (the destination was overwritten: nothing of its own to restore)
+  dst->poisoned = false;
   return QIP_OK;
 } QIP_CATCH_ALL
 

@@ -170,27 +170,33 @@ def main():
         res = {}
         for fold in (0, 1):
             q.set_global_option("dist_fold_pack", fold)
-            for tile, jit in ((1, 0), (1, 1), (0, 0)):
+            # (1, 0, 3): shards with a PERSISTENT relabelling (tile_relabel = 3): a batch may leave its qubits relabelled, and then
+            # its last sweep addresses other qubits than the gather request names — no fold, the layout is settled first
+            for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3)):
                 sf = DistState(n, dist, 0, host_staged=True)
                 sf.set_option("tile", tile)
                 sf.set_option("tile_jit", jit)
+                if relabel:
+                    sf.set_option("tile_relabel", relabel)
                 sf.upload_global(x)
                 sf.apply_ops(ops)
-                res[(fold, tile, jit)] = (sf.download_global(), sf.comm_stats())
+                res[(fold, tile, jit, relabel)] = (sf.download_global(), sf.comm_stats())
                 sf.close()
         q.set_global_option("dist_fold_pack", 1)
         want = O.apply_ops_in_place(n, ops, x.copy())
         folded_total = 0
-        for tile, jit in ((1, 0), (1, 1), (0, 0)):
-            a, sa = res[(0, tile, jit)]
-            b, sb = res[(1, tile, jit)]
-            assert np.array_equal(a, b), (tile, jit)
+        for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3)):
+            a, sa = res[(0, tile, jit, relabel)]
+            b, sb = res[(1, tile, jit, relabel)]
+            assert np.array_equal(a, b), (tile, jit, relabel)
+            assert np.array_equal(b, res[(1, 1, 0, 0)][0]), (tile, jit, relabel)  # every form of the shard sweeps: the same amplitudes
             assert np.max(np.abs(b - want)) < 1e-12
             assert sa["packs_folded"] == 0 and sb["remaps"] == sa["remaps"]
             assert sb["pack_sweeps"] + sb["packs_folded"] == sa["pack_sweeps"], (sa, sb)
-            folded_total += sb["packs_folded"]
+            if not relabel:
+                folded_total += sb["packs_folded"]
             if rank == 0:
-                print(f"fold tile={tile} jit={jit}: remaps={sb['remaps']} pack_sweeps {sa['pack_sweeps']} -> {sb['pack_sweeps']} (folded {sb['packs_folded']})")
+                print(f"fold tile={tile} jit={jit} relabel={relabel}: remaps={sb['remaps']} pack_sweeps {sa['pack_sweeps']} -> {sb['pack_sweeps']} (folded {sb['packs_folded']})")
         assert folded_total >= 2, folded_total
         if rank == 0:
             print("ok fold: the remap's gather rides in the preceding tile sweep")
