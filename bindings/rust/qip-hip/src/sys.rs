@@ -141,6 +141,13 @@ extern "C" {
     pub fn qip_hip_tile_bits() -> c_int;
     pub fn qip_hip_jit_stats(kernels_compiled: *mut u64, compile_ms: *mut c_double) -> c_int;
     pub fn qip_hip_jit_cache_info(resident: *mut u64, evicted: *mut u64, cap: *mut u64) -> c_int;
+    /// (ABI 6) where run-time-compiled segments come from: disk cache, helper processes, this process.
+    pub fn qip_hip_jit_stats2(out: *mut qip_hip_jit_counters) -> c_int;
+    pub fn qip_hip_jit_set_cache_dir(dir: *const c_char) -> c_int;
+    pub fn qip_hip_jit_cache_dir() -> *const c_char;
+    pub fn qip_hip_jit_compile_file(src_path: *const c_char, fma: c_int, out_path: *const c_char) -> c_int;
+    /// host-only test hook: the descriptor of the bit-permutation sweep as JSON
+    pub fn qip_hip_debug_permute_plan(n: u32, pi: *const u32, row_bits: u32, fold_bits: u32) -> *const c_char;
     pub fn qip_hip_debug_tile_jit(
         dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int, segments: *mut u64,
         source_bytes: *mut u64, code_bytes: *mut u64, first_source: *mut *const c_char,
@@ -178,6 +185,22 @@ extern "C" {
 }
 
 pub const QIP_HIP_UNIQUE_ID_BYTES: usize = 128;
+
+/// `struct qip_hip_jit_counters` (ABI 6)
+#[repr(C)]
+#[derive(Default, Debug, Clone, Copy)]
+pub struct qip_hip_jit_counters {
+    pub kernels_resident_total: u64,
+    pub compiled: u64,
+    pub compiled_by_helpers: u64,
+    pub helper_processes: u64,
+    pub disk_hits: u64,
+    pub disk_stores: u64,
+    pub compile_ms: c_double,
+    pub disk_load_ms: c_double,
+    pub procs: i32,
+    pub disk_cache: i32,
+}
 
 #[repr(C)]
 pub struct qip_hip_dist {

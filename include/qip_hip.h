@@ -266,6 +266,34 @@ int qip_hip_tile_bits(void);
 /* Segment-specialised tile sweeps (option "tile_jit"): how many segment kernels this process has compiled with hiprtc
  * so far and the time that took (cache misses only; a segment met again costs nothing). */
 int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
+
+/* r5 (ABI 6): where those kernels come from.  A segment that is not resident in this process is looked up on disk first
+ * ($QIP_HIP_CACHE_DIR, default $XDG_CACHE_HOME/qip_hip or ~/.cache/qip_hip; "off" / "" disables; global option "jit_disk_cache"
+ * 0 / 1): code objects are stored under a 128-bit hash of compiler version + flags + the embedded kernel header + the source
+ * text, so a second process LOADS (~1 ms per segment) instead of compiling (~0.45 s per 11-bit segment, ~1.3 s per wide one).
+ * The segments of a plan that are new are compiled side by side in up to "jit_procs" helper PROCESSES (global option; 0 =
+ * automatic: the CPUs this process may use, at most 16, divided by the ranks of a sharded state; 1 = in this process only) —
+ * hiprtc serialises the compilations of one process, separate processes scale.  The helper is `qip_jitc` next to the library
+ * ($QIP_HIP_JITC overrides; absent = compile in process).  Results are bit-identical whichever way a kernel arrived. */
+typedef struct qip_hip_jit_counters {
+  uint64_t kernels_resident_total; /* kernels made resident in this process so far (= qip_hip_jit_stats' count)    */
+  uint64_t compiled;               /* hiprtc compilations on behalf of this process (here + in helpers)             */
+  uint64_t compiled_by_helpers;    /* ... of which in helper processes                                               */
+  uint64_t helper_processes;       /* helper processes spawned so far                                                */
+  uint64_t disk_hits, disk_stores; /* code objects loaded from / written to the disk cache                           */
+  double compile_ms;               /* wall time of the compilations (helpers run side by side: wall, not CPU time)   */
+  double disk_load_ms;             /* wall time spent reading code objects                                           */
+  int32_t procs;                   /* helper processes a plan may use right now                                      */
+  int32_t disk_cache;              /* 1 = a cache directory is in use                                                */
+} qip_hip_jit_counters;
+int qip_hip_jit_stats2(qip_hip_jit_counters* out);
+/* Cache directory: NULL = back to the default rule, "" = none.  qip_hip_jit_cache_dir: the directory in use ("" = none; the
+ * string is owned by the library until the calling thread's next call). */
+int qip_hip_jit_set_cache_dir(const char* dir);
+const char* qip_hip_jit_cache_dir(void);
+/* Host only (no device needed): compile the tile-segment source in `src_path` (contraction allowed when fma != 0) and leave the
+ * code object at `out_path` in the disk cache's file format.  What the helper processes run (tools/qip_jitc.c). */
+int qip_hip_jit_compile_file(const char* src_path, int fma, const char* out_path);
 /* The cache of those kernels is process-wide, guarded by a mutex (handles driven by different threads stay independent)
  * and bounded: beyond `cap` entries (qip_hip_set_global_option("jit_cache_cap", n), default 512) the least recently used
  * kernels are unloaded; programs recorded into a hipGraph re-record themselves when an eviction happened since.
@@ -336,7 +364,13 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *                    bits of the moment cost no LDS traffic; a transposition (four quarters through the buffer) brings in up to
  *                    three new register bits.  Same helpers, same gate order: "tile" = 1 stays IEEE-equal to the gate-by-gate
  *                    path.  "tile_fma" / "tile_merge" apply to wide segments of "tile" = 2 as they do to narrow ones.
- *                    0 (default) = the 11-bit LDS-resident tile.
+ *                    0 (default) = the 11-bit LDS-resident tile.  r5: also inside hipGraph programs.
+ *   "tile_auto"      1 (default, ABI 6): who compiles.  apply_ops on a state with "tile" >= 1 and "tile_jit" = 0 runs the interpreter
+ *                    kernel (a circuit that runs once does not repay seconds of compilation); a PROGRAM (qip_hip_program_create)
+ *                    created on such a state with n >= 22 is made to be replayed, so its own launches use run-time-compiled
+ *                    segments — wide ones ("tile_wide") unless the circuit holds dense 3-qubit gates — compiled once at creation
+ *                    (helper processes + disk cache, qip_hip_jit_stats2).  Same helpers, same order of operations: bit-identical
+ *                    to the interpreter for "tile" = 1.  0 = programs use the state's options as they are.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

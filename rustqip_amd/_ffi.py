@@ -58,6 +58,21 @@ _u64p = C.POINTER(C.c_uint64)
 _dblp = C.POINTER(C.c_double)
 _statep = C.c_void_p
 
+class QipJitCounters(C.Structure):
+    """struct qip_hip_jit_counters (include/qip_hip.h)"""
+    _fields_ = [("kernels_resident_total", C.c_uint64), ("compiled", C.c_uint64), ("compiled_by_helpers", C.c_uint64),
+                ("helper_processes", C.c_uint64), ("disk_hits", C.c_uint64), ("disk_stores", C.c_uint64),
+                ("compile_ms", C.c_double), ("disk_load_ms", C.c_double), ("procs", C.c_int32), ("disk_cache", C.c_int32)]
+
+
+def jit_counters() -> dict:
+    """Where the run-time-compiled tile segments of this process came from (qip_hip_jit_stats2)."""
+    c = QipJitCounters()
+    if lib.qip_hip_jit_stats2(C.byref(c)) != 0:
+        raise RuntimeError(last_error())
+    return {name: getattr(c, name) for name, _ in QipJitCounters._fields_}
+
+
 SIGNATURES = {
     "qip_hip_last_error": (_cp, []),
     "qip_hip_device_count": (_int, []),
@@ -94,6 +109,10 @@ SIGNATURES = {
     "qip_hip_tile_bits": (_int, []),
     "qip_hip_jit_cache_info": (_int, [_u64p, _u64p, _u64p]),
     "qip_hip_jit_stats": (_int, [_u64p, _dblp]),
+    "qip_hip_jit_stats2": (_int, [C.POINTER(QipJitCounters)]),
+    "qip_hip_jit_set_cache_dir": (_int, [_cp]),
+    "qip_hip_jit_cache_dir": (_cp, []),
+    "qip_hip_jit_compile_file": (_int, [_cp, _int, _cp]),
     "qip_hip_debug_tile_jit": (_int, [_int, _u32, _opp, _u64, _int, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p)]),
     "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
     "qip_hip_kernel_class_count": (_int, []),

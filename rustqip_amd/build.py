@@ -17,6 +17,8 @@ HEADERS = [os.path.join(CSRC, h) for h in ("qip_kernels.h", "qip_internal.h", "q
     os.path.join(HERE, "..", "include", "qip_hip.h")]
 OBJDIR = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "lib", "libqip_hip.so")
+JITC = os.path.join(HERE, "lib", "qip_jitc")
+JITC_SRC = os.path.join(CSRC, "qip_jitc.c")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc's SLP pass pairs f32 products into v_pk_mul_f32 / v_pk_add_f32, which need their operands in
 # aligned register pairs: in the f32 tile-sweep kernel that cost 180 VGPRs (2 waves per SIMD, 8.7 ms per sweep) against 90
@@ -48,7 +50,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(OUT, [os.path.join(CSRC, u + ".hip") for u in UNITS] + HEADERS + [os.path.join(CSRC, "exports.map")])
+    return _stale(OUT, [os.path.join(CSRC, u + ".hip") for u in UNITS] + HEADERS + [os.path.join(CSRC, "exports.map")]) or _stale(JITC, [JITC_SRC, OUT])
 
 
 def build(force: bool = False) -> str:
@@ -73,6 +75,12 @@ def build(force: bool = False) -> str:
     objs = [os.path.join(OBJDIR, u + ".o") for u in UNITS]
     if force or jobs or _stale(OUT, objs + [os.path.join(CSRC, "exports.map")]):
         cmd = [HIPCC, *LINK, "-o", OUT, *objs, *LIBS]
+        print("[rustqip_amd.build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    # the run-time compiler's helper process (plain C over the C ABI; found by the library next to itself)
+    if force or _stale(JITC, [JITC_SRC, OUT]):
+        cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-o", JITC, JITC_SRC, "-L" + os.path.dirname(OUT), "-lqip_hip",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
         print("[rustqip_amd.build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     return OUT

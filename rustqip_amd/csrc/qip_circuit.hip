@@ -5,6 +5,15 @@
 
 #include <mutex>
 
+#include <cerrno>
+#include <fcntl.h>
+#include <sched.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+extern char** environ;
+
 // ---------------------------------------------------------------------------------------
 // gate fusion: option "fuse" = K merges consecutive small gates into dense
 // gates on <= K qubits, applied in ONE sweep each.  The reference has no analogue (its apply_ops
@@ -274,6 +283,239 @@ static int hiprtc_compile(const std::string& src, bool fma, std::vector<char>* c
   return QIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// r5: code objects on disk, and a plan's new segments compiled in helper PROCESSES.
+//  * hiprtc costs ~0.45 s per 11-bit segment and ~1.3 s per wide one, and the code-object manager behind it serialises the
+//    compilations of one process (r4: 8 host threads bought nothing).  Separate processes do scale (measured on 8 cores: four
+//    processes compile four plans in the time of one), so the segments of a plan that are new are written out as source files,
+//    `qip_jitc` (a 30-line host program next to the library; it calls qip_hip_jit_compile_file below) is spawned up to
+//    "jit_procs" times, and the code objects come back through the disk cache.  No helper, one new segment, or jit_procs = 1:
+//    the compilation happens in this process as before.
+//  * every code object is kept under $QIP_HIP_CACHE_DIR (default $XDG_CACHE_HOME/qip_hip or ~/.cache/qip_hip; "off" or an
+//    empty value disables), named by a 128-bit hash of compiler version + flags + the embedded kernel header + the source text,
+//    written to a temporary name and renamed (readers never see half a file; two processes that compile the same segment just
+//    both succeed).  A second process loads instead of compiling: ~1 ms per segment.  The file carries the source length and the
+//    second hash word again, checked on load; anything odd is a miss, never an error.
+// ---------------------------------------------------------------------------------------
+int64_t g_jit_disk = 1;   // global option "jit_disk_cache"
+int64_t g_jit_procs = 0;  // global option "jit_procs": 0 = automatic (the CPUs this process may use, at most 16), 1 = in process only
+int64_t g_jit_world = 1;  // ranks that share this host's CPUs (set by qip_hip_dist_create): automatic jit_procs is divided by it
+static std::string g_jit_dir;           // resolved cache directory ("" = none)
+static bool g_jit_dir_resolved = false;
+static uint64_t g_jit_disk_hits = 0, g_jit_disk_stores = 0, g_jit_helper_procs = 0, g_jit_helper_segments = 0;
+static double g_jit_load_ms = 0;
+
+struct JitHash {
+  uint64_t a = 0, b = 0;
+};
+static uint64_t hash_fnv(const char* p, size_t n, uint64_t h) {
+  for (size_t i = 0; i < n; ++i) {
+    h ^= (unsigned char)p[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+static uint64_t hash_mix(const char* p, size_t n, uint64_t h) {  // an independent second word: 8 bytes at a time
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  for (; i < n; ++i) {
+    h = (h ^ (unsigned char)p[i]) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 31;
+  }
+  return h;
+}
+static const char* jit_flags_text(bool fma) {
+  return fma ? "gfx950 -O3 c++17 contract=fast no-slp" : "gfx950 -O3 c++17 contract=off no-slp";
+}
+static JitHash jit_hash(const std::string& src, bool fma) {
+  static JitHash base = [] {  // the embedded header and the compiler's version: once per process
+    JitHash h;
+    int major = 0, minor = 0;
+    (void)hiprtc_load();  // (the version is part of every key: always asked, so that keys do not depend on who hashes first)
+    if (g_rtc.handle) {
+      int (*ver)(int*, int*) = nullptr;
+      *(void**)(&ver) = dlsym(g_rtc.handle, "hiprtcVersion");
+      if (ver) (void)ver(&major, &minor);
+    }
+    char v[64];
+    snprintf(v, sizeof v, "qipjit1 hiprtc %d.%d ", major, minor);
+    h.a = hash_fnv(v, strlen(v), 1469598103934665603ull);
+    h.b = hash_mix(v, strlen(v), 0x243F6A8885A308D3ull);
+    h.a = hash_fnv(kKernelsHeaderSrc, sizeof kKernelsHeaderSrc, h.a);
+    h.b = hash_mix(kKernelsHeaderSrc, sizeof kKernelsHeaderSrc, h.b);
+    return h;
+  }();
+  JitHash h = base;
+  const char* f = jit_flags_text(fma);
+  h.a = hash_fnv(f, strlen(f), h.a);
+  h.b = hash_mix(f, strlen(f), h.b);
+  h.a = hash_fnv(src.data(), src.size(), h.a);
+  h.b = hash_mix(src.data(), src.size(), h.b);
+  return h;
+}
+static bool mkdir_p(const std::string& dir) {
+  struct stat st;
+  if (stat(dir.c_str(), &st) == 0) return S_ISDIR(st.st_mode);
+  const size_t slash = dir.find_last_of('/');
+  if (slash != std::string::npos && slash > 0 && !mkdir_p(dir.substr(0, slash))) return false;
+  return mkdir(dir.c_str(), 0700) == 0 || (stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode));
+}
+// under g_jit_mutex (or before any thread exists): where code objects are kept; "" = nowhere
+static const std::string& jit_dir_locked() {
+  if (g_jit_dir_resolved) return g_jit_dir;
+  g_jit_dir_resolved = true;
+  g_jit_dir.clear();
+  std::string dir;
+  if (const char* e = getenv("QIP_HIP_CACHE_DIR")) {
+    if (!*e || !strcmp(e, "off") || !strcmp(e, "0")) return g_jit_dir;
+    dir = e;
+  } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+    if (*x) dir = std::string(x) + "/qip_hip";
+  }
+  if (dir.empty()) {
+    const char* home = getenv("HOME");
+    if (!home || !*home) return g_jit_dir;
+    dir = std::string(home) + "/.cache/qip_hip";
+  }
+  if (mkdir_p(dir) && access(dir.c_str(), W_OK | X_OK) == 0) g_jit_dir = dir;
+  return g_jit_dir;
+}
+static std::string jit_disk_path(const std::string& dir, const JitHash& h) {
+  char name[48];
+  snprintf(name, sizeof name, "/%016llx%016llx.co", (unsigned long long)h.a, (unsigned long long)h.b);
+  return dir + name;
+}
+struct JitFileHeader {
+  char magic[8];
+  uint64_t src_len, hash_b, code_len;
+};
+static bool jit_disk_read(const std::string& path, size_t src_len, const JitHash& h, std::vector<char>* code) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  JitFileHeader hd;
+  bool ok = fread(&hd, sizeof hd, 1, f) == 1 && !memcmp(hd.magic, "QIPJIT1", 8) && hd.src_len == src_len && hd.hash_b == h.b &&
+            hd.code_len > 0 && hd.code_len < (1ull << 31);
+  if (ok) {
+    code->resize(hd.code_len);
+    ok = fread(code->data(), 1, hd.code_len, f) == hd.code_len && fgetc(f) == EOF;
+  }
+  fclose(f);
+  if (!ok) code->clear();
+  return ok;
+}
+static bool jit_disk_write(const std::string& path, size_t src_len, const JitHash& h, const std::vector<char>& code) {
+  char suffix[48];
+  snprintf(suffix, sizeof suffix, ".tmp.%ld.%llx", (long)getpid(), (unsigned long long)(uintptr_t)&code);
+  const std::string tmp = path + suffix;
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  JitFileHeader hd;
+  memcpy(hd.magic, "QIPJIT1", 8);
+  hd.src_len = src_len;
+  hd.hash_b = h.b;
+  hd.code_len = code.size();
+  bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = fclose(f) == 0 && ok;
+  if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+  if (!ok) (void)unlink(tmp.c_str());
+  return ok;
+}
+
+// Host only (no device): compile the segment source in `src_path` and leave the code object at `out_path` in the disk
+// cache's file format.  This is what the helper processes run (tools/qip_jitc.c).
+extern "C" int qip_hip_jit_compile_file(const char* src_path, int fma, const char* out_path) try {
+  if (!src_path || !out_path) return fail(QIP_ERR_INVALID, "null path");
+  FILE* f = fopen(src_path, "rb");
+  if (!f) return fail(QIP_ERR_INVALID, "cannot read %s", src_path);
+  std::string src;
+  char buf[1 << 16];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) src.append(buf, got);
+  fclose(f);
+  std::vector<char> code;
+  QCHK(hiprtc_compile(src, fma != 0, &code));
+  if (!jit_disk_write(out_path, src.size(), jit_hash(src, fma != 0), code)) return fail(QIP_ERR_DEVICE, "cannot write %s", out_path);
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// the CPUs this process may actually use: affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256 CPUs and grant 16)
+static int usable_cpus() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = atoll(q);
+      if (quota > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return n;
+}
+static int jit_procs_effective() {
+  if (g_jit_procs >= 1) return (int)std::min<int64_t>(g_jit_procs, 64);
+  static const int cpus = usable_cpus();
+  return std::max(1, std::min(16, cpus) / (int)std::max<int64_t>(1, g_jit_world));
+}
+// the helper program: $QIP_HIP_JITC, or `qip_jitc` next to this library
+static std::string jit_helper_path() {
+  if (const char* e = getenv("QIP_HIP_JITC")) return access(e, X_OK) == 0 ? std::string(e) : std::string();
+  Dl_info info;
+  if (!dladdr((void*)&qip_hip_jit_compile_file, &info) || !info.dli_fname) return std::string();
+  std::string pth = info.dli_fname;
+  const size_t slash = pth.find_last_of('/');
+  pth = (slash == std::string::npos ? std::string(".") : pth.substr(0, slash)) + "/qip_jitc";
+  return access(pth.c_str(), X_OK) == 0 ? pth : std::string();
+}
+// Compile jobs[todo[*]] in up to `procs` helper processes; results land at out_paths[*] (the disk cache).  Failures are not
+// reported from here: whatever is still missing afterwards is compiled in this process, which also produces the message.
+static void jit_compile_in_helpers(const std::string& helper, const std::string& dir, int procs,
+                                   const std::vector<std::pair<std::string, bool>>& jobs, const std::vector<size_t>& todo,
+                                   const std::vector<std::string>& out_paths) {
+  std::vector<std::string> src_paths(jobs.size());
+  std::vector<size_t> written;
+  for (size_t i : todo) {
+    char name[64];
+    snprintf(name, sizeof name, "/seg.%ld.%zu.hip", (long)getpid(), i);
+    src_paths[i] = dir + name;
+    FILE* f = fopen(src_paths[i].c_str(), "wb");
+    if (!f) continue;
+    const bool ok = fwrite(jobs[i].first.data(), 1, jobs[i].first.size(), f) == jobs[i].first.size();
+    if (fclose(f) == 0 && ok) written.push_back(i);
+  }
+  const size_t np = std::min<size_t>((size_t)procs, written.size());
+  std::vector<pid_t> pids;
+  for (size_t k = 0; k < np; ++k) {
+    std::vector<std::string> args = {helper};
+    for (size_t j = k; j < written.size(); j += np) {  // round robin: heavy and light segments alternate along a plan
+      const size_t i = written[j];
+      args.push_back(jobs[i].second ? "1" : "0");
+      args.push_back(src_paths[i]);
+      args.push_back(out_paths[i]);
+    }
+    std::vector<char*> argv;
+    for (std::string& a : args) argv.push_back(&a[0]);
+    argv.push_back(nullptr);
+    pid_t pid = 0;
+    if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) pids.push_back(pid);
+  }
+  for (pid_t pid : pids) {
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    }
+  }
+  for (size_t i : written) (void)unlink(src_paths[i].c_str());
+  g_jit_helper_procs += pids.size();
+}
+
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
@@ -286,8 +528,11 @@ struct JitKernel {
 // dangle, so programs hold the cache generation they were recorded under and re-record when it moved (qip_hip_program_run).
 static std::map<std::string, JitKernel> g_jit_cache;
 static uint64_t g_jit_clock = 0, g_jit_generation = 0;
+#include <set>
+static std::set<uint64_t> g_jit_warm_plans;  // fingerprints of plans whose segments have all been made resident (apply_ops_tiled)
+static uint64_t g_jit_warm_generation = 0;   // ... as long as nothing has been evicted since
 static int64_t g_jit_cache_cap = 512;
-static uint64_t g_jit_compiles = 0, g_jit_evictions = 0;
+static uint64_t g_jit_compiles = 0, g_jit_evictions = 0, g_jit_loaded = 0;  // (compiles: hiprtc runs of THIS process; loaded: kernels made resident)
 static double g_jit_compile_ms = 0;
 // Stream captures in progress in this process, on any handle (under g_jit_mutex).  Evicting synchronises the device and
 // unloads modules: neither may happen while ANY thread records a graph, not only the evicting handle's own capture.
@@ -299,10 +544,57 @@ static void jit_capture_scope(int delta) {
 
 extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
   std::lock_guard<std::mutex> lock(g_jit_mutex);
-  if (kernels_compiled) *kernels_compiled = g_jit_compiles;
-  if (compile_ms) *compile_ms = g_jit_compile_ms;
+  if (kernels_compiled) *kernels_compiled = g_jit_loaded;  // (cache misses of this process: compiled here, by a helper, or found on disk)
+  if (compile_ms) *compile_ms = g_jit_compile_ms + g_jit_load_ms;
   return QIP_OK;
 } QIP_CATCH_ALL
+
+extern "C" int qip_hip_jit_stats2(qip_hip_jit_counters* out) try {
+  if (!out) return fail(QIP_ERR_INVALID, "null output");
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  out->kernels_resident_total = g_jit_loaded;
+  out->compiled = g_jit_compiles;
+  out->compiled_by_helpers = g_jit_helper_segments;
+  out->helper_processes = g_jit_helper_procs;
+  out->disk_hits = g_jit_disk_hits;
+  out->disk_stores = g_jit_disk_stores;
+  out->compile_ms = g_jit_compile_ms;
+  out->disk_load_ms = g_jit_load_ms;
+  out->procs = jit_procs_effective();
+  out->disk_cache = (g_jit_disk && !jit_dir_locked().empty()) ? 1 : 0;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+// Where code objects are kept.  dir = NULL: back to the default ($QIP_HIP_CACHE_DIR, $XDG_CACHE_HOME/qip_hip, ~/.cache/qip_hip);
+// "" : nowhere.  A directory that cannot be created or written is an error and leaves the setting unchanged.
+extern "C" int qip_hip_jit_set_cache_dir(const char* dir) try {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  if (!dir) {
+    g_jit_dir_resolved = false;
+    (void)jit_dir_locked();
+    return QIP_OK;
+  }
+  if (!*dir) {
+    g_jit_dir.clear();
+    g_jit_dir_resolved = true;
+    return QIP_OK;
+  }
+  const std::string d = dir;
+  if (!mkdir_p(d) || access(d.c_str(), W_OK | X_OK) != 0) return fail(QIP_ERR_INVALID, "cache directory %s cannot be created or written", dir);
+  g_jit_dir = d;
+  g_jit_dir_resolved = true;
+  return QIP_OK;
+} QIP_CATCH_ALL
+extern "C" const char* qip_hip_jit_cache_dir(void) {
+  static thread_local std::string out;
+  try {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    out = g_jit_disk ? jit_dir_locked() : std::string();
+  } catch (...) {
+    return "";
+  }
+  return out.c_str();
+}
 
 extern "C" int qip_hip_jit_cache_info(uint64_t* resident, uint64_t* evicted, uint64_t* cap) try {
   std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -959,9 +1251,31 @@ static int jit_insert_locked(qip_hip_state* s, const std::string& key, const std
   }
   k.device = s->device;
   k.last_use = ++g_jit_clock;
-  g_jit_compiles += 1;
+  g_jit_loaded += 1;
   g_jit_cache[key] = k;
   if (fn) *fn = k.fn;
+  return QIP_OK;
+}
+// under g_jit_mutex: the code object of (src, fma) from the disk cache, or compiled here (and then stored there)
+static int jit_code_locked(const std::string& src, bool fma, std::vector<char>* code) {
+  const std::string dir = g_jit_disk ? jit_dir_locked() : std::string();
+  JitHash h;
+  std::string path;
+  if (!dir.empty()) {
+    h = jit_hash(src, fma);
+    path = jit_disk_path(dir, h);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (jit_disk_read(path, src.size(), h, code)) {
+      g_jit_disk_hits += 1;
+      g_jit_load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return QIP_OK;
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  QCHK(hiprtc_compile(src, fma, code));
+  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  g_jit_compiles += 1;
+  if (!dir.empty() && jit_disk_write(path, src.size(), h, *code)) g_jit_disk_stores += 1;
   return QIP_OK;
 }
 static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma, const std::function<int(hipFunction_t)>& launch) {
@@ -973,14 +1287,12 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
     it->second.last_use = ++g_jit_clock;
     fn = it->second.fn;
   } else if (!launch && s->jit_collect) {
-    s->jit_collect->push_back({src, fma});  // (the parallel pre-compilation of a plan: jit_compile_collected)
+    s->jit_collect->push_back({src, fma});  // (the pre-compilation of a plan: jit_compile_collected)
     return QIP_OK;
   } else {
-    const auto t0 = std::chrono::steady_clock::now();
     std::vector<char> code;
-    QCHK(hiprtc_compile(src, fma, &code));
+    QCHK(jit_code_locked(src, fma, &code));
     QCHK(jit_insert_locked(s, key, code, &fn));
-    g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   }
   return launch ? launch(fn) : QIP_OK;
@@ -1019,6 +1331,75 @@ static int hiprtc_compile_many(const std::vector<std::pair<std::string, bool>>& 
     if (rc[i] != QIP_OK) return fail(rc[i], "%s", msg[i].c_str());
   return QIP_OK;
 }
+// Device-free half: the code objects of `jobs` — from the disk cache, from helper processes, or compiled here.
+static int jit_obtain_code(const std::vector<std::pair<std::string, bool>>& jobs, std::vector<std::vector<char>>* code_out) {
+  const size_t nj = jobs.size();
+  std::vector<std::vector<char>>& code = *code_out;
+  code.assign(nj, std::vector<char>());
+  std::string dir, helper;
+  int procs = 1;
+  {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    if (g_jit_disk) dir = jit_dir_locked();
+    procs = jit_procs_effective();
+  }
+  // 1. what the disk cache already holds
+  std::vector<JitHash> hashes(nj);
+  std::vector<std::string> paths(nj);
+  std::vector<size_t> todo;
+  double load_ms = 0;
+  uint64_t hits = 0;
+  for (size_t i = 0; i < nj; ++i) {
+    if (!dir.empty()) {
+      hashes[i] = jit_hash(jobs[i].first, jobs[i].second);
+      paths[i] = jit_disk_path(dir, hashes[i]);
+      const auto t0 = std::chrono::steady_clock::now();
+      if (jit_disk_read(paths[i], jobs[i].first.size(), hashes[i], &code[i])) {
+        load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        hits += 1;
+        continue;
+      }
+    }
+    todo.push_back(i);
+  }
+  // 2. the rest: side by side in helper processes when there are several (and somewhere to put the results) ...
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t by_helpers = 0;
+  if (todo.size() >= 2 && procs > 1 && !dir.empty()) {
+    helper = jit_helper_path();
+    if (!helper.empty()) {
+      jit_compile_in_helpers(helper, dir, procs, jobs, todo, paths);
+      std::vector<size_t> still;
+      for (size_t i : todo) {
+        if (jit_disk_read(paths[i], jobs[i].first.size(), hashes[i], &code[i])) by_helpers += 1;
+        else still.push_back(i);
+      }
+      todo.swap(still);
+    }
+  }
+  // 3. ... and whatever is left (no helper, a single segment, a helper that failed: the message comes from here) in this process
+  uint64_t compiled_here = 0, stored = 0;
+  if (!todo.empty()) {
+    std::vector<std::pair<std::string, bool>> rest;
+    for (size_t i : todo) rest.push_back(jobs[i]);
+    std::vector<std::vector<char>> rest_code;
+    QCHK(hiprtc_compile_many(rest, &rest_code));
+    for (size_t j = 0; j < todo.size(); ++j) {
+      code[todo[j]].swap(rest_code[j]);
+      compiled_here += 1;
+      if (!dir.empty() && jit_disk_write(paths[todo[j]], jobs[todo[j]].first.size(), hashes[todo[j]], code[todo[j]])) stored += 1;
+    }
+  }
+  const double compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit_disk_hits += hits;
+  g_jit_load_ms += load_ms;
+  g_jit_helper_segments += by_helpers;
+  g_jit_compiles += compiled_here + by_helpers;
+  g_jit_disk_stores += stored + by_helpers;
+  if (compiled_here + by_helpers) g_jit_compile_ms += compile_ms;
+  return QIP_OK;
+}
 static int jit_compile_collected(qip_hip_state* s, std::vector<std::pair<std::string, bool>>& jobs) {
   {  // the same segment twice in one plan: once
     std::vector<std::pair<std::string, bool>> uniq;
@@ -1027,17 +1408,14 @@ static int jit_compile_collected(qip_hip_state* s, std::vector<std::pair<std::st
     jobs.swap(uniq);
   }
   if (jobs.empty()) return QIP_OK;
-  const auto t0 = std::chrono::steady_clock::now();
-  const size_t nj = jobs.size();
   std::vector<std::vector<char>> code;
-  QCHK(hiprtc_compile_many(jobs, &code));
+  QCHK(jit_obtain_code(jobs, &code));
   std::lock_guard<std::mutex> lock(g_jit_mutex);
-  for (size_t i = 0; i < nj; ++i) {
+  for (size_t i = 0; i < jobs.size(); ++i) {
     const std::string key = jit_key(s, jobs[i].first, jobs[i].second);
     if (g_jit_cache.find(key) != g_jit_cache.end()) continue;  // (another thread's handle got there first)
     QCHK(jit_insert_locked(s, key, code[i], nullptr));
   }
-  g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();
   return QIP_OK;
 }
@@ -1328,8 +1706,8 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     *src_bytes += src.size();
     jobs.push_back({src, (mode & 32) != 0});  // mode bit 5: fused multiply-adds
   }
-  std::vector<std::vector<char>> code;  // all segments side by side (g_jit_threads host threads), as apply_ops does
-  QCHK(hiprtc_compile_many(jobs, &code));
+  std::vector<std::vector<char>> code;  // as apply_ops obtains them: disk cache, helper processes, this process
+  QCHK(jit_obtain_code(jobs, &code));
   for (const auto& c : code) *code_bytes += c.size();
   return QIP_OK;
 }
@@ -1349,8 +1727,12 @@ extern "C" int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, 
 
 extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
+// option "tile_auto": from this size a program compiles its segments (below it a sweep is launch-bound and the interpreter, replayed
+// as a graph, is as fast: profiles/r01_small_n_launch_bound.md)
+constexpr int kAutoJitMinQubits = 22;
 static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
-  return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits && !s->capture_staging && !s->jit_for_capture;
+  // (r5: also inside a graph capture — the launch and its parameter upload are ordinary stream work like the 11-bit segments')
+  return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits;
 }
 static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = when it shortens the plan, 2 = always
   return (int)std::min<int64_t>(s->tile, 2) | (s->tile_relabel ? 4 : 0) | (s->tile_relabel == 2 ? 8 : 0) |  // (3 = persistent layout)
@@ -1400,23 +1782,61 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   const bool wide = (tile_mode_of(s) & 16) != 0;
   // (the pre-compilation runs BEFORE the layout is cleared — a compiler failure here returns with the handle
   // exactly as it was, still naming the layout the data is in)
-  if (s->tile_jit && s->tile_passes && !s->capture_staging && !s->jit_prepare && g_jit_threads > 1) {
-    // every segment of the plan that is not in the kernel cache yet, compiled side by side before anything runs
-    std::vector<std::pair<std::string, bool>> jobs;
-    s->jit_collect = &jobs;
-    s->jit_prepare = true;
-    int rc = QIP_OK;
+  // r5: every segment of the plan that is not resident yet is found FIRST (a compile-only pass that collects the sources), looked
+  // up in the disk cache, and the rest compiled side by side in helper processes (jit_compile_collected) before anything runs.
+  // A plan that has been through this once is remembered by a fingerprint of its structure, so the steady state (the same
+  // circuit applied again and again) does not generate every source twice.
+  if (s->tile_jit && s->tile_passes && !s->capture_staging) {
+    uint64_t fp = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+      fp ^= v;
+      fp *= 1099511628211ull;
+    };
+    mix(s->n); mix((uint64_t)s->dtype); mix((uint64_t)s->device); mix((uint64_t)tile_mode_of(s)); mix((uint64_t)s->tile_jit);
+    mix((uint64_t)(s->tile_fma != 0) | (uint64_t)(s->tile_merge != 0) << 1 | (uint64_t)(g_tile_wide_pin != 0) << 2 |
+        (uint64_t)(g_tile_wide_dense3_inline != 0) << 3 | (uint64_t)use_nt(s) << 4 | (uint64_t)g_tile_remap << 8);
     for (const TileStep& st : sc.steps) {
       if (st.ops.size() < 2 || !st.perm.empty()) continue;
-      std::vector<const TileItem*> seg;
-      for (uint64_t i : st.ops) seg.push_back(&items[i]);
-      rc = wide ? launch_wide_segment<T>(s, seg, st.high) : launch_tile_segment<T>(s, seg, st.high);
-      if (rc != QIP_OK) break;
+      mix(0xABCDu + st.ops.size());
+      for (uint32_t h : st.high) mix(h);
+      for (uint64_t i : st.ops) {
+        const TileItem& it = items[i];
+        mix((uint64_t)it.kind | (uint64_t)it.nz << 8 | (uint64_t)it.exact << 40);
+        mix(it.nd_mask);
+        mix(it.d_mask);
+        for (uint32_t c : it.cpos) mix(0x100u + c);
+        mix(it.t0 | (uint64_t)it.t1 << 8 | (uint64_t)it.t2 << 16);
+      }
     }
-    s->jit_prepare = false;
-    s->jit_collect = nullptr;
-    QCHK(rc);
-    QCHK(jit_compile_collected(s, jobs));
+    bool warm;
+    {
+      std::lock_guard<std::mutex> lock(g_jit_mutex);
+      warm = g_jit_warm_plans.count(fp) != 0 && g_jit_warm_generation == g_jit_generation;
+    }
+    if (!warm) {
+      std::vector<std::pair<std::string, bool>> jobs;
+      const bool outer_prepare = s->jit_prepare;
+      s->jit_collect = &jobs;
+      s->jit_prepare = true;
+      int rc = QIP_OK;
+      for (const TileStep& st : sc.steps) {
+        if (st.ops.size() < 2 || !st.perm.empty()) continue;
+        std::vector<const TileItem*> seg;
+        for (uint64_t i : st.ops) seg.push_back(&items[i]);
+        rc = wide ? launch_wide_segment<T>(s, seg, st.high) : launch_tile_segment<T>(s, seg, st.high);
+        if (rc != QIP_OK) break;
+      }
+      s->jit_prepare = outer_prepare;
+      s->jit_collect = nullptr;
+      QCHK(rc);
+      QCHK(jit_compile_collected(s, jobs));
+      std::lock_guard<std::mutex> lock(g_jit_mutex);
+      if (g_jit_warm_generation != g_jit_generation || g_jit_warm_plans.size() > 4096) {  // (an eviction may have dropped what a warm plan needs)
+        g_jit_warm_plans.clear();
+        g_jit_warm_generation = g_jit_generation;
+      }
+      g_jit_warm_plans.insert(fp);
+    }
   }
   s->layout.clear();
   // The multi-GPU gather may ride in the last sweep's store phase only when that sweep addresses the CALLER's bit order: the
@@ -1500,6 +1920,29 @@ struct qip_hip_program {
   uint64_t captured_jit_gen = 0;    // ... and run-time-compiled kernels the cache may since have unloaded
   std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
   int last_was_graph = 0;
+  // r5, option "tile_auto": a program is made to be replayed, so it repays a compilation — created on a state with tile >= 1 and
+  // tile_jit = 0 (the interpreter, what apply_ops keeps using) it runs its own launches with run-time-compiled segments, wide
+  // ones unless the circuit holds dense 3-qubit gates (which still lose on wide tiles).  Same arithmetic, same order: the
+  // results are bit-identical to the interpreter's (tile = 1) / within the mode's own bar (tile = 2).
+  bool auto_jit = false, auto_wide = false;
+};
+// the program's own options, in force while one of ITS launches (capture, replay, eager run) is issued
+struct ProgramOptions {
+  qip_hip_state* s;
+  int64_t jit, wide;
+  bool on;
+  explicit ProgramOptions(qip_hip_program* p) : s(p->s), jit(0), wide(0), on(p->s && p->auto_jit) {
+    if (!on) return;
+    jit = s->tile_jit;
+    wide = s->tile_wide;
+    s->tile_jit = 1;
+    s->tile_wide = p->auto_wide ? 1 : 0;
+  }
+  ~ProgramOptions() {
+    if (!on) return;
+    s->tile_jit = jit;
+    s->tile_wide = wide;
+  }
 };
 
 static void program_drop_graph(qip_hip_program* p);
@@ -1522,6 +1965,7 @@ static void program_drop_graph(qip_hip_program* p) {
 // Try to capture; on any obstacle leave the program in eager mode (exec == nullptr) and report success.
 static int program_capture(qip_hip_program* p) {
   qip_hip_state* s = p->s;
+  ProgramOptions scope(p);
   program_drop_graph(p);
   if (s->force_generic || g_force_generic || s->profile) return QIP_OK;
   // an op on the out-of-place path would swap the buffers under the graph: stay eager
@@ -1607,6 +2051,14 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
   p->s = s;
   p->ops = ops;
   p->count = count;
+  if (s->tile_auto && s->tile >= 1 && !s->tile_jit && s->tile_passes && s->n >= (uint32_t)kAutoJitMinQubits && !s->force_generic && !g_force_generic) {
+    p->auto_jit = true;
+    p->auto_wide = s->n > (uint32_t)kWideBits;
+    for (uint64_t i = 0; i < count && p->auto_wide; ++i) {
+      TileItem it;
+      if (classify_tile_item(s->dtype, s->n, &ops[i], &it) == QIP_OK && it.tileable && it.kind == 4) p->auto_wide = false;  // a dense 3-qubit item
+    }
+  }
   int rc = program_capture(p);
   if (rc != QIP_OK) {
     delete p;
@@ -1622,6 +2074,7 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) try {
   qip_hip_state* s = p->s;
   if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
   STATE_ENTER(s);
+  ProgramOptions scope(p);
   if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen ||
                   (s->tile_jit && p->captured_jit_gen != jit_cache_generation()) || s->profile || s->force_generic || g_force_generic)) {
     if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);

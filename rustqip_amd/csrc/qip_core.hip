@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 5; }  // 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
+extern "C" int qip_hip_abi_version(void) { return 6; }  // 6: + jit_stats2 / jit_set_cache_dir / jit_cache_dir / jit_compile_file, options jit_disk_cache / jit_procs / tile_auto; 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
@@ -71,6 +71,12 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "jit_disk_cache")) { g_jit_disk = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "jit_procs")) {
+    if (value < 0 || value > 64) return fail(QIP_ERR_INVALID, "jit_procs must be 0 (automatic) .. 64");
+    g_jit_procs = value;
+    return QIP_OK;
+  }
   if (key && !strcmp(key, "jit_threads")) {
     if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
     g_jit_threads = value;
@@ -545,6 +551,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
   else if (!strcmp(key, "tile_merge")) s->tile_merge = value;
   else if (!strcmp(key, "tile_wide")) s->tile_wide = value;
+  else if (!strcmp(key, "tile_auto")) s->tile_auto = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

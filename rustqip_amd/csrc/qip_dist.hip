@@ -984,6 +984,8 @@ extern "C" int qip_hip_dist_create(uint32_t n, int dtype, int device, int rank, 
     d->transport.all_to_all = qipd::rccl_all_to_all;
     d->transport.all_reduce_sum = qipd::rccl_all_reduce;
   }
+  // the ranks of one node share its CPUs: the run-time compiler's automatic helper-process count is divided by the world size
+  if (world > 1 && (int64_t)world > g_jit_world) g_jit_world = world;
   if (world > 1) {
     // every remap goes through the second 2^L buffer: get it now, so that a state too large for two buffers fails here and
     // not in the middle of a circuit, after local ops have already changed the shard

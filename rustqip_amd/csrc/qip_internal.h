@@ -66,6 +66,7 @@ extern int64_t g_dist_fold_pack, g_dist_plan_cost;  // qip_dist.hip
 extern int64_t g_sparse_tile;  // qip_launch.hip
 extern int64_t g_soft_measure_one_pass;  // qip_measure.hip
 extern int64_t g_tile_wide_pin, g_tile_wide_dense3_inline;  // qip_circuit.hip
+extern int64_t g_jit_disk, g_jit_procs, g_jit_world;  // qip_circuit.hip: code objects on disk, helper processes, ranks sharing the host
 extern int64_t g_jit_threads;     // qip_circuit.hip: host threads that compile a plan's new segments side by side
 extern int64_t g_force_k4_direct;  // tuning aid: dense k = 4 on the matrix cores reads its operands straight from HBM (k_gate_kq_mfma)  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 
@@ -184,6 +185,8 @@ struct qip_hip_state {
   int64_t tile_fma = 0;     // run-time-compiled segments of tile = 2: products may fuse into sums (1e-12 bar, not IEEE equality)
   int64_t tile_merge = 0;   // ... and runs of diagonal gates are applied as products of their factors
   int64_t tile_wide = 0;    // r4: run-time-compiled segments over a 13-bit register-resident tile (seven free positions per sweep)
+  int64_t tile_auto = 1;    // r5: programs (qip_hip_program_create) on a state with tile >= 1, tile_jit = 0 and n >= 22 compile their segments
+                            // (wide ones unless the circuit holds dense 3-qubit gates); apply_ops keeps the interpreter.  0 = never
   int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture; the parallel pre-compilation)
   bool jit_for_capture = false;  // ... on behalf of a graph capture: the plan must be the one the capture will record

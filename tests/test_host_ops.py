@@ -22,7 +22,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
         assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_ffi.SIGNATURES) == names
-    assert _ffi.lib.qip_hip_abi_version() == 5
+    assert _ffi.lib.qip_hip_abi_version() == 6
+    # the Rust binding a maintainer would compile (bindings/rust/qip-hip/src/sys.rs; no rustc in this image) declares exactly
+    # the same set: it cannot be type-checked here, so at least it cannot fall behind the header (67 of 68)
+    sys_rs = open(os.path.join(ROOT, "bindings", "rust", "qip-hip", "src", "sys.rs")).read()
+    assert set(re.findall(r"pub fn (qip_hip_[a-z0-9_]+)\s*\(", sys_rs)) == names
 
 
 def test_make_matrix_op_errors():
