@@ -1334,6 +1334,18 @@ static int hiprtc_compile_many(const std::vector<std::pair<std::string, bool>>& 
 // Device-free half: the code objects of `jobs` — from the disk cache, from helper processes, or compiled here.
 static int jit_obtain_code(const std::vector<std::pair<std::string, bool>>& jobs, std::vector<std::vector<char>>* code_out) {
   const size_t nj = jobs.size();
+  if (const char* dump = getenv("QIP_HIP_JIT_DUMP_DIR")) {  // debugging aid (tools/jit_segment_resources.py): every segment's source, numbered
+    static std::atomic<unsigned> serial{0};
+    if (*dump && mkdir_p(dump))
+      for (size_t i = 0; i < nj; ++i) {
+        char name[64];
+        snprintf(name, sizeof name, "/seg_%04u%s.hip", serial.fetch_add(1), jobs[i].second ? "_fma" : "");
+        if (FILE* f = fopen((std::string(dump) + name).c_str(), "wb")) {
+          (void)fwrite(jobs[i].first.data(), 1, jobs[i].first.size(), f);
+          fclose(f);
+        }
+      }
+  }
   std::vector<std::vector<char>>& code = *code_out;
   code.assign(nj, std::vector<char>());
   std::string dir, helper;
@@ -1433,15 +1445,26 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   TileSegmentPlan<T> plan;
   QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1, p5_override));
   const std::vector<uint32_t>& high = plan.high;
-  std::vector<TileGate<T>>& gates = plan.gates;
+  // r5: the interpreter kernel takes runs of diagonal gates as one loop over TileDiagItem steps (tile_merge_diag_runs: the same
+  // products in the same order, without the per-gate decoding); the plan itself stays what the generators and the CPU replay read
+  TileInterpPlan<T> interp;
+  const bool use_runs = g_tile_diag_runs && s->tile_passes && !s->tile_jit;
+  if (use_runs) tile_merge_diag_runs<T>(plan, &interp);
+  const bool has_runs = use_runs && interp.runs > 0;
+  std::vector<TileGate<T>>& gates = has_runs ? interp.gates : plan.gates;
   std::vector<amp_t<T>>& mats = plan.mats;
-  TilePassDesc& pd = plan.pd;
+  TilePassDesc& pd = has_runs ? interp.pd : plan.pd;
   const size_t gates_bytes = gates.size() * sizeof(TileGate<T>);
+  const size_t mats_bytes = mats.size() * sizeof(amp_t<T>);
+  const size_t items_bytes = has_runs ? interp.items.size() * sizeof(TileDiagItem<T>) : 0;
   static_assert(sizeof(TileGate<T>) % 16 == 0, "the matrix block behind the gate list stays 16-byte aligned");
+  static_assert(sizeof(amp_t<T>) * 16 % 16 == 0 && sizeof(TileDiagItem<T>) % 16 == 0, "... and the diagonal steps behind the matrices");
+  const size_t items_off = (gates_bytes + mats_bytes + 15) / 16 * 16;
   auto upload_gates = [&]() -> int {  // after the gates are final (k_tile_passes resolves them per pass first)
-    QCHK(ensure_arena(s, gates_bytes + mats.size() * sizeof(amp_t<T>)));  // one allocation: growing frees the old arena
+    QCHK(ensure_arena(s, items_off + items_bytes));  // one allocation: growing frees the old arena
     QCHK(arena_upload(s, gates.data(), gates_bytes, 0));
-    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats.size() * sizeof(amp_t<T>), gates_bytes));
+    if (!mats.empty()) QCHK(arena_upload(s, mats.data(), mats_bytes, gates_bytes));
+    if (items_bytes) QCHK(arena_upload(s, interp.items.data(), items_bytes, items_off));
     return QIP_OK;
   };
   TileDesc d;
@@ -1478,12 +1501,14 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const TileGate<T>* dg = nullptr;  // device addresses: valid only after the upload (the arena may grow / move)
   const amp_t<T>* dmats = nullptr;
+  const TileDiagItem<T>* ditems = nullptr;
   ProfRec rec;
   rec.cls = KC_TILE_GATES;
   auto begin = [&]() -> int {  // descriptors up, then the timed region starts
     QCHK(upload_gates());
     dg = (const TileGate<T>*)s->arena;
     dmats = (const amp_t<T>*)((const char*)s->arena + gates_bytes);
+    ditems = (const TileDiagItem<T>*)((const char*)s->arena + items_off);
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, sweep_bytes, &rec));
     return QIP_OK;
   };
@@ -1539,7 +1564,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
     QCHK(begin());
     if (folding) {
 #define TPF(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV, true>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
-                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)s->alt, *fold)
+                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)s->alt, *fold, ditems)
       if (use_nt(s)) TPF(true);
       else TPF(false);
 #undef TPF
@@ -1549,7 +1574,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       return QIP_OK;
     }
 #define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
-                                   (amp_t<T>*)s->cur, ins, pd, dg, dmats)
+                                   (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)nullptr, TileStorePerm(), ditems)
     if (use_nt(s)) TP(true);
     else TP(false);
 #undef TP

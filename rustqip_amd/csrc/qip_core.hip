@@ -7,7 +7,7 @@
 // (qip-iterators/src/matrix_ops.rs:62-152), and launches it on the handle's HIP stream.
 // There is NO CPU fallback: without a HIP device every compute entry point fails with
 // QIP_ERR_NO_DEVICE.
-#include "qip_internal.h"
+#include "qip_tile.h"
 
 thread_local std::string g_last_error;
 
@@ -71,6 +71,7 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "tile_diag_runs")) { g_tile_diag_runs = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_disk_cache")) { g_jit_disk = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_procs")) {
     if (value < 0 || value > 64) return fail(QIP_ERR_INVALID, "jit_procs must be 0 (automatic) .. 64");

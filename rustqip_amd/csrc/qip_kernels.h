@@ -1282,6 +1282,26 @@ enum TileOp : uint32_t {
   TOP_SWAP_01, TOP_SWAP_02, TOP_SWAP_12,
   // dense 3-qubit gate whose three targets ARE the pass's three bits: JA JB JC = pass-bit index of the sub-index MSB, middle, LSB
   TOP_DENSE3Q_012, TOP_DENSE3Q_021, TOP_DENSE3Q_102, TOP_DENSE3Q_120, TOP_DENSE3Q_201, TOP_DENSE3Q_210,
+  // r5: a RUN of consecutive diagonal gates of one pass, as TileDiagItem[b1] starting at item nz of the launch's item block
+  // (interpreter launches only: the host rewrites the pass's gate list, tile_merge_diag_runs; plans and generators never see it)
+  TOP_DIAG_RUN,
+};
+
+// One step of a diagonal run (r5).  Every diagonal tile gate — phase / controlled phase / Rz-like, target and controls on lane
+// bits, pass bits or outside the tile — is one or two of these: the amplitudes a lane holds in elements whose pass-bit
+// combination c satisfies (c & reg_mask) == reg_val are multiplied by F, where
+//     F = (tb & sel_mask) ? f1 : f0        (sel_mask = 0: F = f1)            the target's entry, when the target is a lane bit
+//     F = ((tb & lane_mask) == lane_val) ? F : (1, 0)                          lane-bit controls folded into the factor
+// provided the block's base index satisfies (base & omask) == oval (controls and targets outside the tile: wave-uniform).
+// These are operation for operation the products the per-op code paths above (TOP_DIAG_*) perform — same factor selection, same
+// multiplications by (1, 0) where a lane-bit control is 0, same elements, same order — so a run is bit-identical to its gates
+// one by one; what goes away is the per-gate decoding: a 128-byte descriptor, a jump table and the branches of five code paths
+// against 64 (Complex<f32>: 48) bytes and one loop (QFT's segments are runs of ~30 controlled phases per H).
+template <typename T> struct alignas(16) TileDiagItem {
+  amp_t<T> f0, f1;
+  uint32_t lane_mask, lane_val, reg_mask, reg_val;
+  uint64_t omask, oval;
+  uint32_t sel_mask, pad_[3];
 };
 
 struct TileDesc {
@@ -1669,7 +1689,8 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
                                                                               const TileGate<T>* __restrict__ gates,
                                                                               const amp_t<T>* __restrict__ mats,
                                                                               amp_t<T>* __restrict__ out = nullptr,
-                                                                              TileStorePerm sp = TileStorePerm()) {
+                                                                              TileStorePerm sp = TileStorePerm(),
+                                                                              const TileDiagItem<T>* __restrict__ diag = nullptr) {
   using A = amp_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
@@ -1721,6 +1742,32 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
       if ((base & g.omask) != g.omask) continue;  // an outside control is 0 for this whole tile
       const uint32_t cm_reg = g.cm_reg;
       switch (g.op) {
+        case TOP_DIAG_RUN: {
+          const TileDiagItem<T>* ip = diag + g.nz;
+          const TileDiagItem<T>* const iend = ip + g.b1;
+          for (; ip != iend; ++ip) {
+            const TileDiagItem<T> it = *ip;  // wave-uniform: scalar loads
+            if ((base & it.omask) != it.oval) continue;
+            A f = it.f1;
+            if (it.sel_mask != 0u) {
+              QIP_KEEP_BRANCH();
+              f = tile_sel((tb & it.sel_mask) != 0u, it.f1, it.f0);
+            }
+            if (it.lane_mask != 0u) {
+              QIP_KEEP_BRANCH();
+              const bool lane_ok = (tb & it.lane_mask) == it.lane_val;
+              f.x = lane_ok ? f.x : (T)1;
+              f.y = lane_ok ? f.y : (T)0;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if ((c[i] & it.reg_mask) == it.reg_val) {
+                QIP_KEEP_BRANCH();
+                e[i] = cmul(f, e[i]);
+              }
+          }
+          break;
+        }
         case TOP_DIAG_UNIFORM: {
           const A f = ((base >> g.tpos_out) & 1ull) ? g.m[1] : g.m[0];
           if (f.x == (T)1 && f.y == (T)0) break;  // unit entries leave the amplitude untouched

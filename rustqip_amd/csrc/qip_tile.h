@@ -37,6 +37,18 @@ template <typename T> struct TileSegmentPlan {
   std::vector<uint32_t> order; // gates[i] is the segment's order[i]-th op (build_tile_segment may reorder inside the segment)
 };
 
+// r5: what the INTERPRETER kernel (k_tile_passes) is handed for a segment: the plan's gate list with every run of >= 2
+// consecutive diagonal gates of a pass replaced by one TOP_DIAG_RUN entry + its TileDiagItem steps (qip_kernels.h).  The plan
+// itself — what the run-time generators, the CPU replay and the one-op sweeps consume — is unchanged.
+template <typename T> struct TileInterpPlan {
+  std::vector<TileGate<T>> gates;
+  std::vector<TileDiagItem<T>> items;
+  TilePassDesc pd;
+  uint32_t runs = 0, gates_in_runs = 0;
+};
+template <typename T> void tile_merge_diag_runs(const TileSegmentPlan<T>& plan, TileInterpPlan<T>* out, uint32_t min_run = 2);
+extern int64_t g_tile_diag_runs;  // global option "tile_diag_runs" (1 = on)
+
 // One step of a tiled schedule: a segment of >= 2 gates applied in one sweep, or a single op applied by
 // its own kernel (not tileable, or alone — a lone gate's own kernel touches only what can change).
 struct TileStep {

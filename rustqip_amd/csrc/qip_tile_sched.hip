@@ -513,6 +513,103 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
 
 
 // ---------------------------------------------------------------------------------------
+// r5: runs of diagonal gates for the interpreter kernel (qip_tile.h TileInterpPlan, qip_kernels.h TileDiagItem).  Each gate of a
+// run becomes the one or two steps that perform EXACTLY the products its own code path (TOP_DIAG_UNIFORM / _LANE / _LANE_CTL /
+// _REGJ in k_tile_passes) performs, in the same order:
+//   UNIFORM  (target outside, no lane-bit control): f = m[target bit of the base]; a unit f is skipped; the elements whose pass-bit
+//            controls are 1 are multiplied by f                       -> per non-unit half h: {f1 = m[h], outside: omask + target = h}
+//   LANE     (target on a lane bit):  F = lane's target bit ? m[1] : m[0], every element whose pass-bit controls are 1 is multiplied
+//            (also where F is the unit)                                -> {f0 = m[0], f1 = m[1], sel = target bit}
+//   LANE_CTL (lane-bit controls; target on a lane bit or outside): the same with F = (1, 0) on lanes whose controls are 0; with the
+//            target outside both halves are kept, units too (the op multiplies by whatever m[bit] is)
+//   REG J    (target = pass bit J): per non-unit half h, F = m[h] (or (1, 0) where a lane-bit control is 0) on the elements with
+//            bit J = h and the pass-bit controls 1                     -> {f1 = m[h], reg_mask += bit J, reg_val += h << J}
+// ---------------------------------------------------------------------------------------
+int64_t g_tile_diag_runs = 1;
+template <typename T>
+void tile_merge_diag_runs(const TileSegmentPlan<T>& plan, TileInterpPlan<T>* out, uint32_t min_run) {
+  out->gates.clear();
+  out->items.clear();
+  out->pd = plan.pd;
+  out->runs = out->gates_in_runs = 0;
+  auto unit = [](const amp_t<T>& a) { return a.x == (T)1 && a.y == (T)0; };
+  auto is_diag = [](const TileGate<T>& g) { return g.kind == 1 && g.op <= (uint32_t)TOP_DIAG_REG2; };
+  for (uint32_t pi = 0; pi < plan.pd.npasses; ++pi) {
+    const TilePass& ps = plan.pd.pass[pi];
+    TilePass& po = out->pd.pass[pi];
+    po.first = (uint32_t)out->gates.size();
+    uint32_t gi = ps.first;
+    const uint32_t gend = ps.first + ps.count;
+    while (gi < gend) {
+      uint32_t ge = gi;
+      while (ge < gend && is_diag(plan.gates[ge])) ++ge;
+      if (ge - gi < min_run) {  // not a run: the gate as it is (and the non-diagonal gate that ended the scan, if any)
+        const uint32_t upto = std::max(ge, gi + 1);
+        for (; gi < upto && gi < gend; ++gi) out->gates.push_back(plan.gates[gi]);
+        continue;
+      }
+      TileGate<T> run;
+      memset(&run, 0, sizeof run);
+      run.kind = 1;
+      run.op = TOP_DIAG_RUN;
+      run.b0 = kTileOutside;
+      run.nz = (uint32_t)out->items.size();
+      for (; gi < ge; ++gi) {
+        const TileGate<T>& g = plan.gates[gi];
+        TileDiagItem<T> it;
+        memset(&it, 0, sizeof it);
+        it.reg_mask = it.reg_val = g.cm_reg;
+        it.lane_mask = it.lane_val = g.cm_lane;
+        it.omask = it.oval = g.omask;
+        it.f0 = g.m[0];
+        it.f1 = g.m[1];
+        const bool outside = g.b0 == kTileOutside;
+        if (g.op == TOP_DIAG_UNIFORM || (outside && (g.op == TOP_DIAG_LANE || g.op == TOP_DIAG_LANE_CTL))) {
+          for (int h = 0; h < 2; ++h) {
+            if (g.op == TOP_DIAG_UNIFORM && unit(g.m[h])) continue;
+            TileDiagItem<T> t = it;
+            t.f1 = g.m[h];
+            t.f0 = g.m[h];
+            t.omask = g.omask | (1ull << g.tpos_out);
+            t.oval = g.omask | ((uint64_t)h << g.tpos_out);
+            out->items.push_back(t);
+          }
+        } else if (g.op == TOP_DIAG_LANE || g.op == TOP_DIAG_LANE_CTL) {
+          // F = (target bit ? m[1] : m[0]), then (1, 0) where a lane-bit control is 0.  When one entry IS the unit (phase gates) the
+          // target bit is just one more lane condition with the SAME F on every lane: (bit = h and controls) ? m[h] : (1, 0)
+          if (unit(g.m[0]) || unit(g.m[1])) {
+            const int h = unit(g.m[0]) ? 1 : 0;
+            it.f0 = it.f1 = g.m[h];
+            it.lane_mask |= 1u << g.b0;
+            it.lane_val |= (uint32_t)h << g.b0;
+          } else {
+            it.sel_mask = 1u << g.b0;
+          }
+          out->items.push_back(it);
+        } else {  // TOP_DIAG_REG0..2: the target is a pass bit
+          for (int h = 0; h < 2; ++h) {
+            if (unit(g.m[h])) continue;
+            TileDiagItem<T> t = it;
+            t.f1 = g.m[h];
+            t.f0 = g.m[h];
+            t.reg_mask = g.cm_reg | (1u << g.b0);
+            t.reg_val = g.cm_reg | ((uint32_t)h << g.b0);
+            out->items.push_back(t);
+          }
+        }
+        out->gates_in_runs += 1;
+      }
+      run.b1 = (uint32_t)out->items.size() - run.nz;
+      out->runs += 1;
+      if (run.b1) out->gates.push_back(run);  // (a run of identities has no step)
+    }
+    po.count = (uint32_t)out->gates.size() - po.first;
+  }
+}
+template void tile_merge_diag_runs<double>(const TileSegmentPlan<double>&, TileInterpPlan<double>*, uint32_t);
+template void tile_merge_diag_runs<float>(const TileSegmentPlan<float>&, TileInterpPlan<float>*, uint32_t);
+
+// ---------------------------------------------------------------------------------------
 // Wide tiles (r4): the plan of one segment for the register-resident 13-bit tile (qip_tile.h WidePlan).  Tile bits 0..5 = the
 // rows (positions 0..4 and p5), 6..12 = the seven high positions.  At load / store time the thread id fills tile bits 0..7
 // (rows, then the two wave positions) and a lane's 32 accesses walk tile bits 8..12: that is arrangement 0, and gates on
@@ -1462,6 +1559,35 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
       for (size_t e = 0; e < plan.mats.size(); ++e)
         js += std::string(e ? "," : "") + "[" + num((double)plan.mats[e].x) + "," + num((double)plan.mats[e].y) + "]";
       js += "]";
+      if (mode & 1024) {  // r5: what the interpreter kernel is handed instead — runs of diagonal gates as TileDiagItem steps
+        TileInterpPlan<T> ip;
+        tile_merge_diag_runs<T>(plan, &ip);
+        js += ",\"interp\":{\"runs\":" + std::to_string(ip.runs) + ",\"gates_in_runs\":" + std::to_string(ip.gates_in_runs) + ",\"passes\":[";
+        for (uint32_t pi = 0; pi < ip.pd.npasses; ++pi)
+          js += std::string(pi ? "," : "") + "[" + std::to_string(ip.pd.pass[pi].first) + "," + std::to_string(ip.pd.pass[pi].count) + "]";
+        js += "],\"gates\":[";
+        for (size_t gi = 0; gi < ip.gates.size(); ++gi) {
+          const TileGate<T>& g = ip.gates[gi];
+          if (gi) js += ",";
+          if (g.op == (uint32_t)TOP_DIAG_RUN) {
+            js += "{\"run\":[" + std::to_string(g.nz) + "," + std::to_string(g.b1) + "]}";
+          } else {
+            size_t src = 0;  // an unchanged gate: its index in the plan's list
+            for (; src < plan.gates.size(); ++src)
+              if (!memcmp(&plan.gates[src], &g, sizeof g)) break;
+            js += "{\"gate\":" + std::to_string(src) + "}";
+          }
+        }
+        js += "],\"items\":[";
+        for (size_t k = 0; k < ip.items.size(); ++k) {
+          const TileDiagItem<T>& it = ip.items[k];
+          js += std::string(k ? "," : "") + "{\"f0\":[" + num((double)it.f0.x) + "," + num((double)it.f0.y) + "],\"f1\":[" + num((double)it.f1.x) + "," +
+                num((double)it.f1.y) + "],\"lane\":[" + std::to_string(it.lane_mask) + "," + std::to_string(it.lane_val) + "],\"reg\":[" +
+                std::to_string(it.reg_mask) + "," + std::to_string(it.reg_val) + "],\"out\":[" + std::to_string(it.omask) + "," +
+                std::to_string(it.oval) + "],\"sel\":" + std::to_string(it.sel_mask) + "}";
+        }
+        js += "]}";
+      }
     }
     js += "}";
   }

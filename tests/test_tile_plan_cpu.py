@@ -12,7 +12,7 @@ import pytest
 
 import rustqip_amd as q
 from oracle import qip_oracle as O
-from rustqip_amd import circuits
+from rustqip_amd import _ffi, circuits
 from rustqip_amd.ops import TILE_BITS, TILE_LANE_BITS, debug_tile_plan
 
 TILE_LOW, OUTSIDE = 6, 0xFFFFFFFF
@@ -25,7 +25,7 @@ DENSE2Q = [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)]
 SWAPS = [(0, 1), (0, 2), (1, 2)]
 
 
-def emulate_segment(state, n, seg):
+def emulate_segment(state, n, seg, use_interp=False):
     """k_tile_passes on a numpy vector: one block per tile, 512 lanes, 8 elements per lane and pass."""
     high = seg["high"]
     # the six low tile bits = the lane id at load / store time: positions 0..4 and p5 (5: one contiguous 1-KiB row per wave-level
@@ -49,6 +49,8 @@ def emulate_segment(state, n, seg):
     mats = np.array([complex(a, b) for a, b in seg["mats"]], dtype=np.complex128)
     tid = np.arange(NLANES, dtype=np.int64)
     seen = 0
+    interp = seg.get("interp") if use_interp else None
+    pass_no = 0
     for ps in seg["passes"]:
         pb, lanepos = ps["pb"], ps["lanepos"]
         assert sorted(pb + lanepos) == list(range(TILE_BITS))  # lane bits + pass bits tile the tile bits exactly
@@ -61,7 +63,25 @@ def emulate_segment(state, n, seg):
         e = tile[:, te]  # (ntiles, lanes, 8)
         assert ps["first"] == seen
         seen += ps["count"]
-        for g in gates[ps["first"]: ps["first"] + ps["count"]]:
+        pass_gates = gates[ps["first"]: ps["first"] + ps["count"]]
+        if interp is not None:  # r5: what the interpreter kernel is handed — runs of diagonal gates as TileDiagItem steps
+            first, count = interp["passes"][pass_no]
+            pass_gates = interp["gates"][first: first + count]
+        pass_no += 1
+        for g in pass_gates:
+            if "run" in g:  # TOP_DIAG_RUN (qip_kernels.h): F = (tb & sel) ? f1 : f0; (1, 0) where a lane condition fails; elements by reg
+                for it in interp["items"][g["run"][0]: g["run"][0] + g["run"][1]]:
+                    tile_on = (base & np.uint64(it["out"][0])) == np.uint64(it["out"][1])
+                    f0, f1 = complex(*it["f0"]), complex(*it["f1"])
+                    f = np.where((tb & it["sel"]) != 0, f1, f0) if it["sel"] else np.full(NLANES, f1)
+                    if it["lane"][0]:
+                        f = np.where((tb & it["lane"][0]) == it["lane"][1], f, 1.0 + 0j)
+                    elem_ok = (c & it["reg"][0]) == it["reg"][1]
+                    mask = tile_on[:, None, None] & elem_ok[None, None, :]
+                    e = np.where(mask, f.astype(e.dtype)[None, :, None] * e, e)  # (the state's precision, like the scalar factors of the per-op paths)
+                continue
+            if "gate" in g:
+                g = gates[g["gate"]]
             passmask = sum(1 << b for b in pb)
             assert g["cm_reg"] == g["cmask"] & passmask and g["cm_lane"] == g["cmask"] & ~passmask
             m = [complex(a, b) for a, b in g["m"]]
@@ -250,7 +270,7 @@ def replay(n, ops, mode, x, dtype=None):
         else:
             assert len(step["high"]) == TILE_BITS - TILE_LOW and len(set(step["high"])) == TILE_BITS - TILE_LOW
             assert not set(step["high"]) & set(step["low"]) and step["low"][5] == (11 if n >= 12 and step["low"][5] != 5 else 5)
-            emulate_segment(st, n, step)
+            emulate_segment(st, n, step, use_interp=bool(mode & 1024))
         done += step["ops"]
     assert sorted(done) == list(range(len(ops)))
     return st, plan
@@ -320,6 +340,47 @@ def test_tile_plan_replayed_on_cpu_matches_the_oracle(name, mode, sched):
     if sched == 2:  # the search keeps the shortest of its plans, the first-come plan among them
         q.set_global_option("tile_sched", 0)
         assert len(plan["steps"]) <= len(debug_tile_plan(n, ops, mode)["steps"])
+
+
+def test_diagonal_runs_of_the_interpreter_are_the_same_products_in_the_same_order():
+    """r5: the interpreter kernel is handed every run of >= 2 consecutive diagonal gates of a pass as ONE entry + TileDiagItem
+    steps (qip_hip_debug_tile_plan mode bit 1024 exports that form).  Replayed with the numpy model: the state after every
+    circuit equals the plain plan's replay EXACTLY (same products, same order — numpy multiplies complex numbers the unfused
+    way on both sides) and the oracle to rounding; QFT's segments really are mostly runs."""
+    rng = np.random.default_rng(12)
+    n = 13
+    x = circuits.random_state(n, seed=4)
+    import cmath
+
+    extra = []
+    for _ in range(40):  # diagonal gates of every shape: phase / Rz-like / units on either entry, 0..3 controls anywhere
+        qs = [int(v) for v in rng.permutation(n)]
+        kind = int(rng.integers(0, 5))
+        d = {0: [1, 0, 0, cmath.rect(1, 0.3)], 1: [cmath.rect(1, -0.2), 0, 0, cmath.rect(1, 0.2)], 2: [cmath.rect(1, 0.9), 0, 0, 1],
+             3: [1, 0, 0, -1], 4: [1j, 0, 0, cmath.rect(1, 1.1)]}[kind]
+        nc = int(rng.integers(0, 4))
+        op = q.make_matrix_op([qs[0]], d)
+        extra.append(q.make_control_op(qs[1:1 + nc], op) if nc else op)
+        if rng.integers(0, 3) == 0:
+            extra.append(q.make_matrix_op([qs[5]], circuits.H))
+    cases = {"qft": circuits.c3_qft(n), "c4": circuits.c4_clifford_t(n, 120, seed=3),
+             "c2": circuits.h_layer(n) + circuits.c2_random_circuit(n, 100, seed=9), "diag_shapes": circuits.h_layer(n) + extra,
+             "grover": circuits.c5_grover_iteration(n)}
+    for name, ops in cases.items():
+        for mode in (1, 2):
+            plain = replay(n, ops, mode, x)[0]
+            runs = replay(n, ops, mode | 1024, x)[0]
+            assert np.array_equal(plain, runs), (name, mode)
+            assert np.max(np.abs(runs - O.apply_ops_in_place(n, ops, x.copy()))) < 1e-12, (name, mode)
+    plan = debug_tile_plan(n, cases["qft"], 1 | 1024)
+    segs = [s for s in plan["steps"] if "interp" in s]
+    in_runs = sum(s["interp"]["gates_in_runs"] for s in segs)
+    assert segs and in_runs >= 0.7 * sum(len(s["gates"]) for s in segs), in_runs
+    # Complex<f32> states: the same steps with f32 numbers
+    xf = x.astype(np.complex64)
+    # (held to f32 rounding, not equality: the numpy model of the per-op LANE path promotes its per-lane factor array to f64)
+    assert np.max(np.abs(replay(n, cases["diag_shapes"], 1, xf, _ffi.QIP_C32)[0] - replay(n, cases["diag_shapes"], 1 | 1024, xf, _ffi.QIP_C32)[0])) < 1e-6
+    assert np.array_equal(replay(n, cases["qft"], 1, xf, _ffi.QIP_C32)[0], replay(n, cases["qft"], 1 | 1024, xf, _ffi.QIP_C32)[0])
 
 
 def test_runs_of_swaps_become_one_permutation_sweep():
