@@ -242,12 +242,13 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     guard.check(st)
     legs = {}
 
-    def leg(name, ops, exact, gate_by_gate=False, seed=0, bases=2, max_len=64, **options):
+    def leg(name, ops, exact, gate_by_gate=False, seed=0, bases=2, max_len=64, state=None, **options):
+        st_, twin_ = (st, twin) if state is None else (state, None)
         for k, v in options.items():
-            st.set_option(k, v)
-        r = W.check_circuit(st, n, ops, O, gate_by_gate=gate_by_gate, seed=seed, bases_per_step=bases, twin=twin, max_len=max_len)
+            st_.set_option(k, v)
+        r = W.check_circuit(st_, n, ops, O, gate_by_gate=gate_by_gate, seed=seed, bases_per_step=bases, twin=twin_, max_len=max_len)
         for k in options:
-            st.set_option(k, 0)
+            st_.set_option(k, 0)
         r["options"] = options
         r["bar"] = "IEEE-equal" if exact else "1e-12"
         r.setdefault("whole_vector_compares", 0)
@@ -256,8 +257,8 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
         r["ok"] = bool((r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0) if exact
                        else (r["max_abs_delta"] <= 1e-12 and r["whole_vector_max_abs_delta"] <= 1e-12))
         r["ok"] = bool(r["ok"] and r["skipped"] == 0)
-        if not exact and twin is not None:
-            twin.resync()
+        if not exact and twin_ is not None:
+            twin_.resync()
         legs[name] = r
 
     # the headline, gate by gate; the state stays a product state: closed-form marginals after every gate
@@ -318,6 +319,15 @@ def parity_check(q, circuits, st, n, ops_headline, ops_mixed, gates):
     leg("configs2_qft_tile2_jit_fma_merge_wide", circuits.c3_qft(n)[200:400], False, seed=31, max_len=160, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
     leg("configs3_clifford_t_tile2_jit_fma_merge_wide_relabel", circuits.c4_clifford_t(n, gates, seed=33)[:64], False, seed=32,
         tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1, tile_relabel=1)
+    if twin is not None:  # (closed before the f32 state below is created: HBM holds st + its scratch + the f32 pair)
+        twin.close()
+        twin = None
+    # r5: the Complex<f32> leg that is timed on wide tiles (extras.complex64_n*.mixed_tile1_jit_wide) — a Complex<f32>
+    # state of the timed size against the f32 ORACLE on closed sub-cubes; both sides compute in unfused f32: bit equality
+    with q.HipState(n, np.complex64, device=st_device(st)) as s32:
+        s32.init_basis(0)
+        s32.apply_ops(ops0)
+        leg("complex64_mixed_tile1_jit_wide_chunks", ops_mixed[:64], True, seed=33, state=s32, tile=1, tile_jit=1, tile_wide=1)
     return finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0)
 
 
@@ -351,6 +361,97 @@ def finish_parity(q, st, n, legs, twin, ops0, a_ops, init_err, t0):
 
 def st_device(st):
     return getattr(st, "device", 0)
+
+
+def reference_bench_shapes(q, circuits, args):
+    """The reference's OWN benches (the only numbers its code defines: `cargo +nightly bench`), at the reference's sizes:
+    qip/benches/state_bench.rs:118-139 (n = 8, dense 8-qubit H^8), :141-155 (n = 24, H on qubit 0), :157-170 (n = 8, 7-control
+    identity), :172-202 (n = 16, 15-control identity, Complex<f64> and Complex<f32>), :380-393 (n = 16, 16-qubit sparse identity);
+    qip-iterators/benches/matmul_bench.rs:163-177 (n = 20, [1,1,1,1] on qubit 0; real f64 there, complex here).  One `apply_op`
+    per iteration there; here microseconds per op three ways — eager (one C-ABI call per op, one sync at the end), a hipGraph
+    program of 64 ops, the same program over tile sweeps (tile = 1) — on a resident state, beside the CPU restatement's
+    apply_op (accumulate, like the reference's bench loop) on the host's cores.  These states live in L2 / MALL: launch-bound."""
+    import numpy as np
+
+    from oracle import qip_oracle as O
+
+    isq = 1.0 / math.sqrt(2.0)
+    h = [isq, isq, isq, -isq]
+    h8 = np.array([[1.0]])
+    for _ in range(8):
+        h8 = np.kron(h8, np.array([[isq, isq], [isq, -isq]]))
+    shapes = [
+        ("state_bench.rs:118-139 bench_hadamard_larger", 8, np.complex128, q.make_matrix_op(list(range(8)), h8.ravel())),
+        ("state_bench.rs:141-155 bench_hadamard_larger_single", 24, np.complex128, q.make_matrix_op([0], h)),
+        ("state_bench.rs:157-170 bench_cidentity_larger", 8, np.complex128, q.make_control_op(list(range(7)), q.make_matrix_op([7], [1, 0, 0, 1]))),
+        ("state_bench.rs:172-186 bench_cidentity_giant", 16, np.complex128, q.make_control_op(list(range(15)), q.make_matrix_op([15], [1, 0, 0, 1]))),
+        ("state_bench.rs:188-202 bench_cidentity_giant_halfprec", 16, np.complex64, q.make_control_op(list(range(15)), q.make_matrix_op([15], [1, 0, 0, 1]))),
+        ("state_bench.rs:380-393 bench_identity_giant_sparse", 16, np.complex128, q.make_sparse_matrix_op(list(range(16)), [[(i, 1.0)] for i in range(1 << 16)])),
+        ("matmul_bench.rs:163-177 bench_large_ones_qip", 20, np.complex128, q.make_matrix_op([0], [1, 1, 1, 1])),
+    ]
+    out = {}
+    reps = 64
+    for name, n, dtype, op in shapes:
+        row = {"n": n, "dtype": "c64" if dtype == np.complex128 else "c32", "algorithmic_bytes_per_op": q.algorithmic_bytes(n, op, 0 if dtype == np.complex128 else 1)}
+        try:
+            with q.HipState(n, dtype) as s:
+                s.init_basis(0)
+                one = s.compile_ops([op])
+                s.apply_compiled(one)
+                s.sync()
+                ts = []
+                for _ in range(REPS):
+                    s.sync()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        s.apply_compiled(one)
+                    s.sync()
+                    ts.append((time.perf_counter() - t) / reps)
+                row["eager_us_per_op"] = 1e6 * statistics.median(ts)
+                for label, tile in (("hipgraph_program_us_per_op", 0), ("tiled_program_us_per_op", 1)):
+                    if tile and n < 11:
+                        continue  # (a tile is 2^11 amplitudes)
+                    s.set_option("tile", tile)
+                    prog = s.compile_program([op] * reps)
+                    prog.run()
+                    s.sync()
+                    ts = []
+                    for _ in range(REPS):
+                        s.sync()
+                        t = time.perf_counter()
+                        prog.run()
+                        s.sync()
+                        ts.append((time.perf_counter() - t) / reps)
+                    row[label] = 1e6 * statistics.median(ts)
+                    row[label.replace("_us_per_op", "_is_graph")] = bool(prog.is_graph)
+                    prog.close()
+                    s.set_option("tile", 0)
+        except Exception as exc:  # noqa: BLE001
+            row["error"] = repr(exc)
+        if not args.no_cpu_baseline:
+            # the CPU restatement on the same shape: out += op . in, as the reference's bench loop does (apply_op, matrix_ops.rs:98-123)
+            try:
+                import ctypes as C
+
+                x = np.zeros(1 << n, dtype=dtype)
+                y = np.zeros(1 << n, dtype=dtype)
+                cop = op.to_c(O._dt(y))  # (converted once: the descriptor of the 2^16-row sparse op takes longer to build than to apply)
+                fn = getattr(O._lib, f"qip_oracle_apply_op_{O._suf(y)}")
+                call = lambda: fn(n, C.byref(cop), x.ctypes.data, x.size, y.ctypes.data, y.size, 0, 0, 1, 0)  # noqa: E731
+                call()
+                k = max(1, min(64, int(2 ** (22 - n)))) if n < 22 else 2
+                ts = []
+                for _ in range(3):
+                    t = time.perf_counter()
+                    for _ in range(k):
+                        call()
+                    ts.append((time.perf_counter() - t) / k)
+                row["cpu_restatement_us_per_op"] = 1e6 * statistics.median(ts)
+                row["cpu_threads"] = O.max_threads()
+            except Exception as exc:  # noqa: BLE001
+                row["cpu_error"] = repr(exc)
+        out[name] = row
+    return out
 
 
 def main():
@@ -581,6 +682,9 @@ def main():
                 extras[cname]["tile2_jit_fma_merge_wide"] = leg(cops, "ops", tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
         extras["norm_sqr_end"] = st.norm_sqr()
         st.close()
+        # r5: where the run-time-compiled segments of this process came from (helper processes side by side, disk cache)
+        extras["jit"] = dict(_F.jit_counters(), cache_dir=_F.lib.qip_hip_jit_cache_dir().decode())
+        extras["reference_bench_shapes"] = reference_bench_shapes(q, circuits, args)
         # configs[1] exactly: n = 28
         n28 = 28
         ops28 = circuits.c2_random_circuit(n28, args.gates, seed=28)

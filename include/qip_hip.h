@@ -119,8 +119,9 @@ int qip_hip_abi_version(void);
  *   "tile_wide_pin"    1 (default) / 0: wide segments pass their 32 amplitudes through an empty register constraint after every gate
  *                      applied under a block-uniform branch — no semantics (bit-identical results), fewer spills in branch-heavy
  *                      segments (Clifford+T: 175 -> 0 VGPR spills, a 72-gate prefix at n = 30 25.9 -> 23.9 ms; configs[1] unchanged).
- *   "tile_wide_dense3_inline"  0 (default): experimental — dense 3-qubit gates of wide segments written out group by group (offline: the
- *                      528-byte stack object per lane disappears); compiled in the CPU suite, NOT yet run on a GPU: leave off.
+ *   "tile_wide_dense3_inline"  1 (default since r5) / 0: dense 3-qubit gates of wide segments written out group by group instead of through
+ *                      pass_dense3w's loop (whose run-time indexing put the lane's 32 amplitudes in a 528-byte stack object).  The same fold:
+ *                      bit-identical (tests); dense-k3 Grover at n = 30 on wide tiles 109.9 -> 77.5 ms (11-bit tiles: 88.2).
  *   "sparse_tile"      1 (default): a SparseMatrix on k >= 6 qubits with <= 4 entries per row and 3..7 of its positions outside
  *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
  *                      gather (k_sparse_ell).  Same results bit for bit.
@@ -368,9 +369,14 @@ int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t co
  *   "tile_auto"      1 (default, ABI 6): who compiles.  apply_ops on a state with "tile" >= 1 and "tile_jit" = 0 runs the interpreter
  *                    kernel (a circuit that runs once does not repay seconds of compilation); a PROGRAM (qip_hip_program_create)
  *                    created on such a state with n >= 22 is made to be replayed, so its own launches use run-time-compiled
- *                    segments — wide ones ("tile_wide") unless the circuit holds dense 3-qubit gates — compiled once at creation
+ *                    segments over wide tiles ("tile_wide"), compiled once at creation
  *                    (helper processes + disk cache, qip_hip_jit_stats2).  Same helpers, same order of operations: bit-identical
  *                    to the interpreter for "tile" = 1.  0 = programs use the state's options as they are.
+ *   "pair_floor"     1 (default, ABI 6): in the gate-by-gate path of apply_ops (n >= 22), a gate whose selectors — controls, the target of
+ *                    a phase-type diagonal — sit inside a 1-KiB wave row costs a sweep of the WHOLE vector for half / a quarter of the
+ *                    algorithmic bytes (the memory system moves whole lines: T on bit 0 41 %, CNOT with the control in a row 40 %); when it
+ *                    and the NEXT gate fit one tile, the two go as ONE two-item tile sweep (interpreter kernel, circuit order, the same
+ *                    unfused arithmetic: IEEE-equal) and the neighbour rides for free.  0 = always one launch per gate.
  *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
  *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
  *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)

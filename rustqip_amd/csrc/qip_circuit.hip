@@ -941,7 +941,7 @@ int64_t g_tile_wide_pin = 1;
 // global option "tile_wide_dense3_inline" (debug mode bit 512; r4, OFF: compiled and register-checked without a GPU, never run on one):
 // dense 3-qubit gates of a wide segment written out group by group instead of through pass_dense3w — the dense-k3 Grover variant's first
 // wide segment: 528 B of stack per lane -> 0 (tools/jit_segment_resources.py, mode | 512).  The next round's first measurement.
-int64_t g_tile_wide_dense3_inline = 0;
+int64_t g_tile_wide_dense3_inline = 1;  // r5: run on MI355X — bit-identical to pass_dense3w, dense-k3 Grover on wide tiles 109.9 -> 77.5 ms (narrow: 88.2): on
 template <typename T>
 static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false,
                                    bool dense3_inline = false) {
@@ -1755,6 +1755,7 @@ extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 // option "tile_auto": from this size a program compiles its segments (below it a sweep is launch-bound and the interpreter, replayed
 // as a graph, is as fast: profiles/r01_small_n_launch_bound.md)
 constexpr int kAutoJitMinQubits = 22;
+constexpr int kPairFloorMinQubits = 22;  // option "pair_floor": only where a sweep is HBM-bound (below, launches are)
 static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
   // (r5: also inside a graph capture — the launch and its parameter upload are ordinary stream work like the 11-bit segments')
   return s->tile_wide && s->tile_jit && s->tile_passes && s->n > (uint32_t)kWideBits;
@@ -1920,6 +1921,46 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
       return s->dtype == QIP_C64 ? apply_ops_fused<double>(s, ops, count, K) : apply_ops_fused<float>(s, ops, count, K);
   }
   for (uint64_t i = 0; i < count; ++i) {
+    // r5, option "pair_floor" (default 1): a gate whose selectors (controls, the target of a phase-type diagonal) sit inside a
+    // 1-KiB wave row sweeps the WHOLE vector for half / a quarter of the algorithmic bytes — the memory system moves whole lines
+    // (T on bit 0: 41 %, CNOT with its control inside a row: 40 %, profiles/r02_line_bits.md).  When such a gate and its
+    // neighbour fit one tile they go as ONE two-item tile sweep (interpreter kernel, circuit order: the same unfused arithmetic
+    // per amplitude, IEEE-equal to the two launches) — the neighbour rides for free.  Everything else stays one launch per gate.
+    if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_staging) {
+      bool floor_gate = false, both = true;
+      for (int j = 0; j < 2 && both; ++j) {
+        TileItem it;
+        if (classify_tile_item(s->dtype, s->n, &ops[i + j], &it) != QIP_OK || !it.tileable) {
+          both = false;
+          break;
+        }
+        double by = 0;
+        if ((it.d_mask & 63ull) && qip_hip_op_algorithmic_bytes(s->dtype, s->n, &ops[i + j], &by) == QIP_OK &&
+            by < 2.0 * (double)s->amp_bytes * (double)s->namps)
+          floor_gate = true;
+      }
+      if (both && floor_gate) {
+        TileSchedule sc;
+        if (make_tile_schedule(s->dtype, s->n, &ops[i], 2, 1, true, &sc) == QIP_OK && sc.steps.size() == 1 && sc.steps[0].ops.size() == 2 &&
+            sc.steps[0].perm.empty()) {
+          const int64_t tile = s->tile, jit = s->tile_jit, relabel = s->tile_relabel, wide = s->tile_wide;
+          s->tile = 1;
+          s->tile_jit = s->tile_relabel = s->tile_wide = 0;
+          const int rc = s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, &ops[i], 2, false) : apply_ops_tiled<float>(s, &ops[i], 2, false);
+          s->tile = tile;
+          s->tile_jit = jit;
+          s->tile_relabel = relabel;
+          s->tile_wide = wide;
+          if (rc != QIP_OK) {
+            std::string msg = g_last_error;
+            return fail(rc, "ops %llu, %llu: %s", (unsigned long long)i, (unsigned long long)i + 1, msg.c_str());
+          }
+          ++i;
+          continue;
+        }
+        (void)hipGetLastError();
+      }
+    }
     s->fold_now = s->fold_request && i + 1 == count;  // (a last op that runs as a one-op tile sweep may store packed)
     int rc = s->dtype == QIP_C64 ? apply_op_t<double>(s, &ops[i]) : apply_op_t<float>(s, &ops[i]);
     s->fold_now = false;
@@ -1946,8 +1987,8 @@ struct qip_hip_program {
   std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
   int last_was_graph = 0;
   // r5, option "tile_auto": a program is made to be replayed, so it repays a compilation — created on a state with tile >= 1 and
-  // tile_jit = 0 (the interpreter, what apply_ops keeps using) it runs its own launches with run-time-compiled segments, wide
-  // ones unless the circuit holds dense 3-qubit gates (which still lose on wide tiles).  Same arithmetic, same order: the
+  // tile_jit = 0 (the interpreter, what apply_ops keeps using) it runs its own launches with run-time-compiled wide segments.
+  // Same arithmetic, same order: the
   // results are bit-identical to the interpreter's (tile = 1) / within the mode's own bar (tile = 2).
   bool auto_jit = false, auto_wide = false;
 };
@@ -2078,11 +2119,7 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
   p->count = count;
   if (s->tile_auto && s->tile >= 1 && !s->tile_jit && s->tile_passes && s->n >= (uint32_t)kAutoJitMinQubits && !s->force_generic && !g_force_generic) {
     p->auto_jit = true;
-    p->auto_wide = s->n > (uint32_t)kWideBits;
-    for (uint64_t i = 0; i < count && p->auto_wide; ++i) {
-      TileItem it;
-      if (classify_tile_item(s->dtype, s->n, &ops[i], &it) == QIP_OK && it.tileable && it.kind == 4) p->auto_wide = false;  // a dense 3-qubit item
-    }
+    p->auto_wide = s->n > (uint32_t)kWideBits;  // (dense 3-qubit items included since they are written out group by group: tile_wide_dense3_inline)
   }
   int rc = program_capture(p);
   if (rc != QIP_OK) {

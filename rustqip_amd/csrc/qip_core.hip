@@ -553,6 +553,7 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   else if (!strcmp(key, "tile_merge")) s->tile_merge = value;
   else if (!strcmp(key, "tile_wide")) s->tile_wide = value;
   else if (!strcmp(key, "tile_auto")) s->tile_auto = value;
+  else if (!strcmp(key, "pair_floor")) s->pair_floor = value;
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

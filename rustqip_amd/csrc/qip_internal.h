@@ -187,6 +187,8 @@ struct qip_hip_state {
   int64_t tile_wide = 0;    // r4: run-time-compiled segments over a 13-bit register-resident tile (seven free positions per sweep)
   int64_t tile_auto = 1;    // r5: programs (qip_hip_program_create) on a state with tile >= 1, tile_jit = 0 and n >= 22 compile their segments
                             // (wide ones unless the circuit holds dense 3-qubit gates); apply_ops keeps the interpreter.  0 = never
+  int64_t pair_floor = 1;   // r5: gate-by-gate apply_ops pairs a gate whose selectors sit inside a wave row (a full sweep for half the bytes)
+                            // with its neighbour into one two-item tile sweep when both fit a tile (IEEE-equal); 0 = one launch per gate, always
   int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture; the parallel pre-compilation)
   bool jit_for_capture = false;  // ... on behalf of a graph capture: the plan must be the one the capture will record

@@ -81,6 +81,22 @@ template <typename A> __device__ __forceinline__ A cmul(A a, A b) {
   r.y = a.x * b.y + a.y * b.x;
   return r;
 }
+// e <- f * e IN PLACE: the four products and two sums of cmul(f, e), rounded one by one in the same way (v_add_f64 with a negated
+// operand IS the subtraction), written so that no result needs a copy: inside the diagonal-run loop of k_tile_passes the compiler's
+// own allocation of cmul spends two v_mov_b64 per element on moving the results back into the loop-carried registers (8 instead of
+// 6 vector instructions per product; the loop is bound by vector issue).
+__device__ __forceinline__ void cscale_inplace(amp_t<double> f, amp_t<double>& e) {
+  double t0, t1;
+  asm("v_mul_f64 %2, %4, %0\n\t"
+      "v_mul_f64 %3, %5, %1\n\t"
+      "v_mul_f64 %1, %4, %1\n\t"
+      "v_mul_f64 %0, %5, %0\n\t"
+      "v_add_f64 %1, %1, %0\n\t"
+      "v_add_f64 %0, %2, -%3"
+      : "+v"(e.x), "+v"(e.y), "=&v"(t0), "=&v"(t1)
+      : "v"(f.x), "v"(f.y));
+}
+__device__ __forceinline__ void cscale_inplace(amp_t<float> f, amp_t<float>& e) { e = cmul(f, e); }
 template <typename A> __device__ __forceinline__ A cadd(A a, A b) {
   A r;
   r.x = a.x + b.x;
@@ -1297,12 +1313,15 @@ enum TileOp : uint32_t {
 // multiplications by (1, 0) where a lane-bit control is 0, same elements, same order — so a run is bit-identical to its gates
 // one by one; what goes away is the per-gate decoding: a 128-byte descriptor, a jump table and the branches of five code paths
 // against 64 (Complex<f32>: 48) bytes and one loop (QFT's segments are runs of ~30 controlled phases per H).
+// `emask` (host-resolved against the item's pass): bit i = element i of the lane's eight satisfies the pass-bit condition, so the
+// kernel tests one bit per element; the condition itself (reg_mask / reg_val, tile-index space) is kept for the CPU replay.
+// Complex<f64>: 64 bytes = ONE scalar load per step (sel_mask travels in the top byte of `emask` as bit position + 1).
 template <typename T> struct alignas(16) TileDiagItem {
   amp_t<T> f0, f1;
-  uint32_t lane_mask, lane_val, reg_mask, reg_val;
   uint64_t omask, oval;
-  uint32_t sel_mask, pad_[3];
+  uint32_t lane_mask, lane_val, emask_sel, reg_pack;  // emask_sel = emask | (sel bit + 1) << 24; reg_pack = reg_mask | reg_val << 16
 };
+static_assert(sizeof(TileDiagItem<double>) == 64 && sizeof(TileDiagItem<float>) == 48, "one (f64) / two scalar loads per diagonal step");
 
 struct TileDesc {
   uint32_t ngates;
@@ -1745,13 +1764,17 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
         case TOP_DIAG_RUN: {
           const TileDiagItem<T>* ip = diag + g.nz;
           const TileDiagItem<T>* const iend = ip + g.b1;
-          for (; ip != iend; ++ip) {
-            const TileDiagItem<T> it = *ip;  // wave-uniform: scalar loads
+          TileDiagItem<T> nxt = *ip;  // wave-uniform: scalar loads, one step ahead of their use
+          for (; ip != iend;) {
+            const TileDiagItem<T> it = nxt;
+            ++ip;
+            if (ip != iend) nxt = *ip;
             if ((base & it.omask) != it.oval) continue;
             A f = it.f1;
-            if (it.sel_mask != 0u) {
+            const uint32_t selp = it.emask_sel >> 24;
+            if (selp != 0u) {
               QIP_KEEP_BRANCH();
-              f = tile_sel((tb & it.sel_mask) != 0u, it.f1, it.f0);
+              f = tile_sel(((tb >> (selp - 1u)) & 1u) != 0u, it.f1, it.f0);
             }
             if (it.lane_mask != 0u) {
               QIP_KEEP_BRANCH();
@@ -1761,9 +1784,9 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-              if ((c[i] & it.reg_mask) == it.reg_val) {
+              if ((it.emask_sel >> i) & 1u) {
                 QIP_KEEP_BRANCH();
-                e[i] = cmul(f, e[i]);
+                cscale_inplace(f, e[i]);
               }
           }
           break;

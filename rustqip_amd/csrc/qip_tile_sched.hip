@@ -554,47 +554,48 @@ void tile_merge_diag_runs(const TileSegmentPlan<T>& plan, TileInterpPlan<T>* out
       run.op = TOP_DIAG_RUN;
       run.b0 = kTileOutside;
       run.nz = (uint32_t)out->items.size();
+      // element i of a lane's eight holds the pass-bit combination c[i] (bit j of i on pass bit pb[j]): the pass-bit condition of a
+      // step is resolved here into one bit per element
+      uint32_t cbits[8];
+      for (int i = 0; i < 8; ++i) cbits[i] = ((uint32_t)(i & 1) << ps.pb[0]) | ((uint32_t)((i >> 1) & 1) << ps.pb[1]) | ((uint32_t)((i >> 2) & 1) << ps.pb[2]);
+      auto push = [&](amp_t<T> f0, amp_t<T> f1, uint32_t lane_mask, uint32_t lane_val, uint32_t reg_mask, uint32_t reg_val, uint64_t omask, uint64_t oval,
+                      uint32_t sel_bit_plus_1) {
+        TileDiagItem<T> t;
+        memset(&t, 0, sizeof t);
+        t.f0 = f0;
+        t.f1 = f1;
+        t.omask = omask;
+        t.oval = oval;
+        t.lane_mask = lane_mask;
+        t.lane_val = lane_val;
+        uint32_t emask = 0;
+        for (int i = 0; i < 8; ++i)
+          if ((cbits[i] & reg_mask) == reg_val) emask |= 1u << i;
+        t.emask_sel = emask | (sel_bit_plus_1 << 24);
+        t.reg_pack = reg_mask | (reg_val << 16);  // (tile-index bits: < 2^11 each)
+        out->items.push_back(t);
+      };
       for (; gi < ge; ++gi) {
         const TileGate<T>& g = plan.gates[gi];
-        TileDiagItem<T> it;
-        memset(&it, 0, sizeof it);
-        it.reg_mask = it.reg_val = g.cm_reg;
-        it.lane_mask = it.lane_val = g.cm_lane;
-        it.omask = it.oval = g.omask;
-        it.f0 = g.m[0];
-        it.f1 = g.m[1];
         const bool outside = g.b0 == kTileOutside;
         if (g.op == TOP_DIAG_UNIFORM || (outside && (g.op == TOP_DIAG_LANE || g.op == TOP_DIAG_LANE_CTL))) {
           for (int h = 0; h < 2; ++h) {
             if (g.op == TOP_DIAG_UNIFORM && unit(g.m[h])) continue;
-            TileDiagItem<T> t = it;
-            t.f1 = g.m[h];
-            t.f0 = g.m[h];
-            t.omask = g.omask | (1ull << g.tpos_out);
-            t.oval = g.omask | ((uint64_t)h << g.tpos_out);
-            out->items.push_back(t);
+            push(g.m[h], g.m[h], g.cm_lane, g.cm_lane, g.cm_reg, g.cm_reg, g.omask | (1ull << g.tpos_out), g.omask | ((uint64_t)h << g.tpos_out), 0u);
           }
         } else if (g.op == TOP_DIAG_LANE || g.op == TOP_DIAG_LANE_CTL) {
           // F = (target bit ? m[1] : m[0]), then (1, 0) where a lane-bit control is 0.  When one entry IS the unit (phase gates) the
           // target bit is just one more lane condition with the SAME F on every lane: (bit = h and controls) ? m[h] : (1, 0)
           if (unit(g.m[0]) || unit(g.m[1])) {
             const int h = unit(g.m[0]) ? 1 : 0;
-            it.f0 = it.f1 = g.m[h];
-            it.lane_mask |= 1u << g.b0;
-            it.lane_val |= (uint32_t)h << g.b0;
+            push(g.m[h], g.m[h], g.cm_lane | (1u << g.b0), g.cm_lane | ((uint32_t)h << g.b0), g.cm_reg, g.cm_reg, g.omask, g.omask, 0u);
           } else {
-            it.sel_mask = 1u << g.b0;
+            push(g.m[0], g.m[1], g.cm_lane, g.cm_lane, g.cm_reg, g.cm_reg, g.omask, g.omask, g.b0 + 1u);
           }
-          out->items.push_back(it);
         } else {  // TOP_DIAG_REG0..2: the target is a pass bit
           for (int h = 0; h < 2; ++h) {
             if (unit(g.m[h])) continue;
-            TileDiagItem<T> t = it;
-            t.f1 = g.m[h];
-            t.f0 = g.m[h];
-            t.reg_mask = g.cm_reg | (1u << g.b0);
-            t.reg_val = g.cm_reg | ((uint32_t)h << g.b0);
-            out->items.push_back(t);
+            push(g.m[h], g.m[h], g.cm_lane, g.cm_lane, g.cm_reg | (1u << g.b0), g.cm_reg | ((uint32_t)h << g.b0), g.omask, g.omask, 0u);
           }
         }
         out->gates_in_runs += 1;
@@ -1583,8 +1584,9 @@ static int tile_plan_json(int dtype, uint32_t n, const qip_op* ops, uint64_t cou
           const TileDiagItem<T>& it = ip.items[k];
           js += std::string(k ? "," : "") + "{\"f0\":[" + num((double)it.f0.x) + "," + num((double)it.f0.y) + "],\"f1\":[" + num((double)it.f1.x) + "," +
                 num((double)it.f1.y) + "],\"lane\":[" + std::to_string(it.lane_mask) + "," + std::to_string(it.lane_val) + "],\"reg\":[" +
-                std::to_string(it.reg_mask) + "," + std::to_string(it.reg_val) + "],\"out\":[" + std::to_string(it.omask) + "," +
-                std::to_string(it.oval) + "],\"sel\":" + std::to_string(it.sel_mask) + "}";
+                std::to_string(it.reg_pack & 0xffffu) + "," + std::to_string(it.reg_pack >> 16) + "],\"out\":[" + std::to_string(it.omask) + "," +
+                std::to_string(it.oval) + "],\"sel\":" + std::to_string((it.emask_sel >> 24) ? 1u << ((it.emask_sel >> 24) - 1u) : 0u) +
+                ",\"emask\":" + std::to_string(it.emask_sel & 0xffu) + "}";
         }
         js += "]}";
       }

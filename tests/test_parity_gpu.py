@@ -41,7 +41,7 @@ GATES_1Q = {
     "dense": [0.3 + 0.1j, -0.7j, 0.2, 0.9 - 0.4j],
 }
 PERMUTATIONS = {"X", "ident"}
-WIDE_DENSE3_INLINE_DEFAULT = 0  # the library's default of global option tile_wide_dense3_inline (restored after tests that flip it)
+WIDE_DENSE3_INLINE_DEFAULT = 1  # the library's default of global option tile_wide_dense3_inline (restored after tests that flip it)
 
 
 @pytest.fixture(scope="module")
@@ -1075,6 +1075,102 @@ def test_hipgraph_program_replay(O):
                 got = st.download()
             want = O.apply_ops_in_place(n, sp + sp, x.copy())
             assert np.max(np.abs(got - want)) <= TOL64 * max(1.0, float(np.max(np.abs(want)))), (n, width)
+
+
+def test_programs_compile_their_segments_automatically(O):
+    """r5, option tile_auto (default on): apply_ops on a state with tile = 1 and tile_jit = 0 keeps the interpreter kernel; a PROGRAM
+    created on that state (n >= 22) is made to be replayed and compiles its segments once at creation — wide ones, also inside
+    the hipGraph — through helper processes and the disk cache.  Same helpers, same order: bit-identical to the interpreter."""
+    from rustqip_amd import _ffi
+
+    n = 22
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 120, seed=28) + circuits.c3_qft(n)[:90]
+    x = circuits.random_state(n, seed=2)
+    with q.HipState(n) as ref:
+        ref.set_option("tile", 1)
+        ref.upload(x)
+        c0 = _ffi.jit_counters()
+        ref.apply_ops(ops)  # the interpreter: nothing is compiled for a circuit that runs once
+        assert _ffi.jit_counters()["kernels_resident_total"] == c0["kernels_resident_total"]
+        want = ref.download()
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.upload(x)
+        prog = st.compile_program(ops)
+        c1 = _ffi.jit_counters()
+        made = c1["kernels_resident_total"] - c0["kernels_resident_total"]
+        assert made >= 2, (c0, c1)  # its segments were made resident at creation (compiled here, by helpers, or found on disk)
+        assert c1["compiled"] - c0["compiled"] + c1["disk_hits"] - c0["disk_hits"] >= made
+        prog.run()
+        assert prog.is_graph
+        assert np.array_equal(st.download(), want)
+        st.upload(x)
+        prog.run()
+        prog.run()  # replays compile nothing
+        assert _ffi.jit_counters()["kernels_resident_total"] == c1["kernels_resident_total"]
+        assert np.array_equal(st.download(), ref_twice(n, ops, x))
+        # the state's own apply_ops still interprets (the program's options are its own)
+        st.upload(x)
+        st.apply_ops(ops)
+        assert _ffi.jit_counters()["kernels_resident_total"] == c1["kernels_resident_total"] and np.array_equal(st.download(), want)
+        prog.close()
+        st.set_option("tile_auto", 0)  # switched off: a program uses the state's options as they are
+        prog = st.compile_program(ops)
+        assert _ffi.jit_counters()["kernels_resident_total"] == c1["kernels_resident_total"]
+        st.upload(x)
+        prog.run()
+        assert prog.is_graph and np.array_equal(st.download(), want)
+        prog.close()
+    assert np.max(np.abs(want - O.apply_ops_in_place(n, ops, x.copy()))) == 0.0
+
+
+def ref_twice(n, ops, x):
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        st.apply_ops(ops)
+        return st.download()
+
+
+def test_gate_by_gate_pairs_a_line_floor_gate_with_its_neighbour(O):
+    """r5, option pair_floor (default on, n >= 22): in the gate-by-gate path a gate whose selectors sit inside a wave row (T / S /
+    controlled phase on a low bit, CNOT with a low control: a sweep of the whole vector for half the bytes) and the next gate go
+    as ONE two-item tile sweep when they fit a tile.  Same unfused arithmetic per amplitude: IEEE-equal to one launch per gate,
+    and fewer launches."""
+    n = 22
+    x = circuits.random_state(n, seed=6)
+    rng = np.random.default_rng(3)
+    low = []
+    for _ in range(40):  # every kind of line-floor gate next to every kind of neighbour
+        qs = [int(v) for v in rng.permutation(n)]
+        lo = n - 1 - int(rng.integers(0, 6))  # a qubit whose index bit lies inside a wave row
+        hi = [v for v in qs if v != lo]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            low.append(q.make_matrix_op([lo], circuits.T))
+        elif kind == 1:
+            low.append(q.make_control_op([lo], q.make_matrix_op([hi[0]], circuits.X)))
+        elif kind == 2:
+            low.append(q.make_control_op([hi[0]], q.make_matrix_op([lo], [1, 0, 0, cmath.rect(1, 0.4)])))
+        else:
+            low.append(q.make_control_op([lo, hi[0]], q.make_matrix_op([hi[1]], circuits.H)))
+        nb = int(rng.integers(0, 4))
+        low.append([q.make_matrix_op([hi[2]], circuits.H), q.make_matrix_op([hi[3]], circuits.rz(0.3)),
+                    q.make_control_op([hi[4]], q.make_matrix_op([hi[5]], circuits.X)), q.make_swap_op([hi[6]], [hi[7]])][nb])
+    for name, ops in (("c4", circuits.c4_clifford_t(n, 200, seed=32)), ("c2", circuits.c2_random_circuit(n, 200, seed=28)), ("low", low),
+                      ("qft", circuits.c3_qft(n)[:150])):
+        res = {}
+        for pair in (0, 1):
+            with q.HipState(n) as st:
+                st.set_option("pair_floor", pair)
+                st.set_option("profile", 1)
+                st.upload(x)
+                st.apply_ops(ops)
+                res[pair] = (st.download(), sum(v["launches"] for v in st.profile().values()))
+        assert np.array_equal(res[0][0], res[1][0]), name
+        assert res[1][1] < res[0][1], (name, res[0][1], res[1][1])  # pairs were formed
+        if name in ("c4", "low"):
+            assert np.array_equal(res[1][0], O.apply_ops_in_place(n, ops, x.copy())), name
 
 
 def test_program_with_a_sparse_op_on_six_qubits_is_a_graph(O):

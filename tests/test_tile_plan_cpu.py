@@ -77,6 +77,7 @@ def emulate_segment(state, n, seg, use_interp=False):
                     if it["lane"][0]:
                         f = np.where((tb & it["lane"][0]) == it["lane"][1], f, 1.0 + 0j)
                     elem_ok = (c & it["reg"][0]) == it["reg"][1]
+                    assert sum(1 << i for i in range(8) if elem_ok[i]) == it["emask"]  # what the kernel tests: the host-resolved element mask
                     mask = tile_on[:, None, None] & elem_ok[None, None, :]
                     e = np.where(mask, f.astype(e.dtype)[None, :, None] * e, e)  # (the state's precision, like the scalar factors of the per-op paths)
                 continue

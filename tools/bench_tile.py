@@ -46,10 +46,12 @@ def main():
     import numpy as np
 
     f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
-    for key in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32"):  # tuning aids (global options)
+    for key in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32", "tile_diag_runs",
+                "tile_wide_dense3_inline", "tile_wide_pin", "jit_procs"):  # tuning aids (global options)
         if os.environ.get("QIP_" + key.upper()):
             q.set_global_option(key, int(os.environ["QIP_" + key.upper()]))
-    tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32")}
+    tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32",
+                                                                "tile_diag_runs", "tile_wide_dense3_inline") if os.environ.get("QIP_" + k.upper())}
     with q.HipState(n, np.complex64 if f32 else np.complex128) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
@@ -62,6 +64,8 @@ def main():
                 st.set_option("tile_fma", int(os.environ.get("QIP_TILE_FMA", "0")) if mode else 0)
                 st.set_option("tile_merge", int(os.environ.get("QIP_TILE_MERGE", "0")) if mode else 0)
                 st.set_option("tile_wide", int(os.environ.get("QIP_TILE_WIDE", "0")) if mode else 0)
+                for kv in filter(None, os.environ.get("QIP_STATE_OPTS", "").split(",")):  # e.g. QIP_STATE_OPTS=pair_floor=0
+                    st.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                 cops = st.compile_ops(ops)
                 st.set_option("profile", 1)
                 st.profile_reset()
@@ -79,7 +83,7 @@ def main():
                 print(json.dumps({"circuit": name, "n": n, "tile": mode, "gates": len(ops), "sweeps": sweeps,
                                   "ms": round(1e3 * best, 2), "gates_per_s": round(len(ops) / best, 1),
                                   "ms_per_sweep": round(1e3 * best / sweeps, 3), "dtype": "f32" if f32 else "f64", "jit": os.environ.get("QIP_TILE_JIT", "0"), "relabel": os.environ.get("QIP_TILE_RELABEL", "0"), "fma": os.environ.get("QIP_TILE_FMA", "0"), "merge": os.environ.get("QIP_TILE_MERGE", "0"), "wide": os.environ.get("QIP_TILE_WIDE", "0"),
-                                  "tune": tune, "norm": st.norm_sqr()}), flush=True)
+                                  "tune": dict(tune, state_opts=os.environ.get("QIP_STATE_OPTS", "")), "norm": st.norm_sqr()}), flush=True)
         st.set_option("tile", 0)
         st.set_option("tile_jit", 0)
         st.set_option("tile_relabel", 0)
