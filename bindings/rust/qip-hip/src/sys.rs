@@ -160,6 +160,8 @@ extern "C" {
         transport: *const qip_hip_transport, out: *mut *mut qip_hip_dist,
     ) -> c_int;
     pub fn qip_hip_dist_destroy(d: *mut qip_hip_dist) -> c_int;
+    /// (ABI 6) a caller-supplied transport's slice entry point (the exchange overlapped with the neighbouring tile sweeps)
+    pub fn qip_hip_dist_set_slice_transport(d: *mut qip_hip_dist, f: qip_hip_all_to_all_slice_fn) -> c_int;
     pub fn qip_hip_dist_init_basis(d: *mut qip_hip_dist, logical_index: u64) -> c_int;
     pub fn qip_hip_dist_apply_op(d: *mut qip_hip_dist, op: *const qip_op) -> c_int;
     pub fn qip_hip_dist_apply_ops(d: *mut qip_hip_dist, ops: *const qip_op, count: u64) -> c_int;
@@ -179,12 +181,17 @@ extern "C" {
     pub fn qip_hip_dist_debug_pieces(
         rank: c_int, world: c_int, chunk_bytes: u64, piece_bytes: u64, cap: u64, peer: *mut i32, offset: *mut u64, length: *mut u64,
     ) -> i64;
+    pub fn qip_hip_dist_debug_overlap(
+        n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64, tile_mode: c_int, slices: c_int,
+    ) -> *const c_char;
     pub fn qip_hip_dist_debug_plan(
         n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64,
     ) -> *const c_char;
 }
 
 pub const QIP_HIP_UNIQUE_ID_BYTES: usize = 128;
+pub type qip_hip_all_to_all_slice_fn =
+    Option<unsafe extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, u64, u64, *mut c_void) -> c_int>;
 
 /// `struct qip_hip_jit_counters` (ABI 6)
 #[repr(C)]
@@ -229,4 +236,8 @@ pub struct qip_hip_dist_stats {
     /// (ABI 5) pack sweeps that took the LDS-tiled bit-permutation sweep; remaps whose gather rode in the preceding tile sweep
     pub packs_via_permute: u64,
     pub packs_folded: u64,
+    /// (ABI 6) remaps whose exchange ran in slices overlapped with the sweep before / also after them; slices issued
+    pub remaps_overlapped: u64,
+    pub remaps_overlapped_after: u64,
+    pub slices_overlapped: u64,
 }

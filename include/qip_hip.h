@@ -468,6 +468,12 @@ typedef struct qip_hip_transport {
   int (*all_reduce_sum)(void* ctx, double* values, uint64_t count);
 } qip_hip_transport;
 
+/* r5 (ABI 6), optional second transport entry point: the all-to-all restricted to bytes [slice_off, slice_off + slice_bytes) of
+ * every chunk, ordered on `stream` (the handle's communication stream, not the shard's).  With it (the built-in RCCL transport
+ * has one) and option "dist_overlap" = 2 / 4 / 8 a remap's exchange is cut into that many slices and overlapped with the tile
+ * sweeps either side of it (qip_hip_dist_stats.remaps_overlapped); without it every exchange is one all_to_all call as before. */
+typedef int (*qip_hip_all_to_all_slice_fn)(void* ctx, const void* send, void* recv, uint64_t chunk_bytes, uint64_t slice_off,
+                                           uint64_t slice_bytes, void* stream);
 /* 128 opaque bytes that identify one RCCL communicator (ncclGetUniqueId): rank 0 calls this and hands the bytes to
  * the other ranks by whatever channel the host has (the Rust side: the launcher's environment / a file / MPI). */
 #define QIP_HIP_UNIQUE_ID_BYTES 128
@@ -479,6 +485,8 @@ int qip_hip_dist_unique_id(void* id_out);
 int qip_hip_dist_create(uint32_t n, int dtype, int device, int rank, int world, const void* unique_id,
                         const qip_hip_transport* transport, qip_hip_dist** out);
 int qip_hip_dist_destroy(qip_hip_dist* d);
+/* (ABI 6) hand a caller-supplied transport's slice entry point to the handle (same ctx as its qip_hip_transport); NULL removes it */
+int qip_hip_dist_set_slice_transport(qip_hip_dist* d, qip_hip_all_to_all_slice_fn fn);
 
 /* state[i] = (i == logical_index) ? 1 : 0 over the whole sharded vector (builder.rs:406-421) */
 int qip_hip_dist_init_basis(qip_hip_dist* d, uint64_t logical_index);
@@ -489,7 +497,13 @@ int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op);
 int qip_hip_dist_apply_ops(qip_hip_dist* d, const qip_op* ops, uint64_t count);
 int qip_hip_dist_sync(qip_hip_dist* d);
 /* options: "tile", "fuse", "mfma", "profile", ... are forwarded to the shard (qip_hip_state_set_option); "piece_bytes"
- * (largest single ncclSend / ncclRecv) belongs to the built-in RCCL transport: QIP_ERR_UNSUPPORTED with a caller-supplied one */
+ * (largest single ncclSend / ncclRecv) belongs to the built-in RCCL transport: QIP_ERR_UNSUPPORTED with a caller-supplied one;
+ * "dist_overlap" (r5): 0 (default) / 1 = every exchange is one all-to-all on the shard's stream; 2 / 4 / 8 = a remap whose
+ * neighbouring local batches run as tile sweeps ("tile" >= 1) has its exchange cut into that many slices (the index positions right
+ * below the chunk-selecting ones), issued on a separate stream as soon as the LAST sweep before the remap — launched in as many
+ * parts — has stored them, and the FIRST sweep after it starts on each slice as soon as it has landed.  Same amplitudes bit for
+ * bit.  Costs a third shard-sized buffer when the remap's gather rides in that last sweep.  Default off for the built-in RCCL
+ * transport: no multi-GPU machine has been available to run it on. */
 int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value);
 
 /* measurement over the whole vector (measurement_ops.rs:11-13, 115-127, 190-269): local reductions + one all-reduce;
@@ -538,6 +552,9 @@ typedef struct qip_hip_dist_stats {
    * store phase of the tile sweep before them (`packs_folded`: counted in neither pack_sweeps nor pack_ms) */
   uint64_t packs_via_permute;
   uint64_t packs_folded;
+  /* (ABI 6) remaps whose exchange ran in slices on the communication stream, overlapped with the sweep before them, and how many
+   * of those were also overlapped with the sweep after them; slices issued in all (option "dist_overlap" per overlapped remap) */
+  uint64_t remaps_overlapped, remaps_overlapped_after, slices_overlapped;
 } qip_hip_dist_stats;
 /* counters since the previous call (they reset; rccl_ranks / rccl_rank / piece_bytes are properties, not counters) */
 int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);
@@ -548,6 +565,14 @@ int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);
  * (any may be NULL).  Test transports use the same list, so the loop is exercised without a second GPU. */
 int64_t qip_hip_dist_debug_pieces(int rank, int world, uint64_t chunk_bytes, uint64_t piece_bytes, uint64_t cap,
                                   int32_t* peer, uint64_t* offset, uint64_t* length);
+
+/* Host-only (r5): which of that plan's remaps the overlapped exchange (option "dist_overlap" = `slices`) serves when the local
+ * batches run as tile sweeps in scheduler mode `tile_mode` (1 / 2 = "tile", + 16 = wide tiles): JSON
+ * {"remaps":[{"pack":0|1,"before":0|1,"after":0|1,"batch_sweeps_before":k}, ...]} — "before": the batch's last sweep is cut into
+ * slices and the exchange starts beside it, "after": the next batch's first sweep awaits the slices one by one.  The predicate
+ * the executor itself applies; tools/model_scaling.py prices the overlap with it.  NULL on error. */
+const char* qip_hip_dist_debug_overlap(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count, int tile_mode,
+                                       int slices);
 
 /* Host-only test hook: what rank `rank` of `world` would do for this circuit on a fresh state, as a JSON string
  * (owned by the library, valid until the calling thread's next call; NULL on error): the steps

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqip_hip.so")
+# (QIP_HIP_LIB: another build of the same library — how tools/ A/B two kernel variants inside one GPU call)
+LIB_PATH = os.environ.get("QIP_HIP_LIB") or os.path.join(_HERE, "lib", "libqip_hip.so")
 
 QIP_C64, QIP_C32 = 0, 1
 QIP_OP_MATRIX, QIP_OP_SPARSE, QIP_OP_SWAP, QIP_OP_CONTROL = 0, 1, 2, 3
@@ -37,6 +38,7 @@ QIP_HIP_UNIQUE_ID_BYTES = 128
 # struct qip_hip_transport: the two callbacks a caller-supplied transport provides
 A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 ARS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
+A2AS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)  # qip_hip_all_to_all_slice_fn
 
 
 class QipTransport(C.Structure):
@@ -47,7 +49,8 @@ class QipDistStats(C.Structure):
     _fields_ = [("remaps", C.c_uint64), ("pack_sweeps", C.c_uint64), ("bytes_sent", C.c_uint64),
                 ("exchange_ms", C.c_double), ("pack_ms", C.c_double),
                 ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("pieces_sent", C.c_uint64), ("piece_bytes", C.c_uint64),
-                ("packs_via_permute", C.c_uint64), ("packs_folded", C.c_uint64)]
+                ("packs_via_permute", C.c_uint64), ("packs_folded", C.c_uint64),
+                ("remaps_overlapped", C.c_uint64), ("remaps_overlapped_after", C.c_uint64), ("slices_overlapped", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/qip_hip.h declares
@@ -131,6 +134,7 @@ SIGNATURES = {
     "qip_hip_dist_unique_id": (_int, [_vp]),
     "qip_hip_dist_create": (_int, [_u32, _int, _int, _int, _int, _vp, C.POINTER(QipTransport), C.POINTER(_vp)]),
     "qip_hip_dist_destroy": (_int, [_vp]),
+    "qip_hip_dist_set_slice_transport": (_int, [_vp, A2AS_FN]),
     "qip_hip_dist_init_basis": (_int, [_vp, _u64]),
     "qip_hip_dist_apply_op": (_int, [_vp, _opp]),
     "qip_hip_dist_apply_ops": (_int, [_vp, _opp, _u64]),
@@ -145,6 +149,7 @@ SIGNATURES = {
     "qip_hip_dist_soft_measure": (_int, [_vp, _u64p, _u32, _dbl, _u64p]),
     "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
     "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
+    "qip_hip_dist_debug_overlap": (_cp, [_u32, _int, _int, _int, _opp, _u64, _int, _int]),
     "qip_hip_dist_debug_pieces": (_i64, [_int, _int, _u64, _u64, _u64, C.POINTER(C.c_int32), _u64p, _u64p]),
 }
 

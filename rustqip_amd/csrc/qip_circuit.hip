@@ -659,7 +659,9 @@ template <typename T> static std::string fnum(T v) {
 // only a value that newly becomes (or stops being) 0 / +-1 changes the structure and compiles again.
 template <typename T>
 static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& ins, bool nt, int remap = 0, std::vector<T>* params = nullptr,
-                                   bool merge_diag = false, const TileStorePerm* fold = nullptr) {
+                                   bool merge_diag = false, const TileStorePerm* fold = nullptr, bool sliced = false) {
+  // `sliced` (r5): the sweep is launched in parts — `ins` has the slice positions opened too, and the kernel's second parameter
+  // is the part's bits at those positions (ORed into every block's base) instead of the unused tile count
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   std::string o;
   auto L = [&](const std::string& line) { o += line; o += "\n"; };
@@ -704,7 +706,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     L("  return x | top;");
     L("}");
   }
-  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
+  L(std::string("extern \"C\" __global__ __launch_bounds__(kTileBlock, 5) void qip_segment(A* __restrict__ st, uint64_t ") + (sliced ? "slice_or" : "ntiles") +
     (params ? ", const T* __restrict__ P" : "") + (fold && fold->g ? ", A* __restrict__ out" : "") + ") {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];");
   L("  A* tile = reinterpret_cast<A*>(tile_raw);");
@@ -722,7 +724,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     return U(off);
   };
   L("  A x[8];");
-  L("  (void)ntiles;");
+  if (!sliced) L("  (void)ntiles;");
   L("  uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;");
   // (tuning aid, global option "tile_remap": the 2^r blocks one XCD receives in a row take ADJACENT tiles; measured slower)
   if (remap == 2) L("  blk = (blk & ~31ull) | ((blk & 7ull) << 2) | ((blk >> 3) & 3ull);");
@@ -738,7 +740,7 @@ static std::string tile_jit_source(const TileSegmentPlan<T>& plan, const Ins& in
     const std::string J = std::to_string(remap - 16);
     L("  blk = ((blk >> 3) & ((1ull << " + J + ") - 1ull)) | ((blk & 7ull) << " + J + ") | (((blk >> 3) >> " + J + ") << (" + J + " + 3));");
   }
-  L("  const uint64_t base = tile_base(blk), wbase = base | wave_off;");
+  L(std::string("  const uint64_t base = tile_base(blk)") + (sliced ? " | slice_or" : "") + ", wbase = base | wave_off;");
   L("  const uint32_t lane_off = tile_lane_off(lane, " + std::to_string(d.p5) + "u);");
   for (int u = 0; u < 8; ++u) L("  x[" + std::to_string(u) + "] = ldg<NT>(st + (wbase | " + ub(u) + ") + lane_off);");
   L("  const uint32_t tidv = tid;");
@@ -944,7 +946,7 @@ int64_t g_tile_wide_pin = 1;
 int64_t g_tile_wide_dense3_inline = 1;  // r5: run on MI355X — bit-identical to pass_dense3w, dense-k3 Grover on wide tiles 109.9 -> 77.5 ms (narrow: 88.2): on
 template <typename T>
 static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool nt, std::vector<T>* params, bool merge_diag = false, bool pin = false,
-                                   bool dense3_inline = false) {
+                                   bool dense3_inline = false, bool sliced = false, const TileStorePerm* fold = nullptr) {
   const char* tname = std::is_same<T, double>::value ? "double" : "float";
   constexpr uint32_t SW = sizeof(amp_t<T>) == 16 ? 4u : 5u;  // tile_slot's fold width
   auto slot = [&](uint32_t t) { return t ^ ((t >> SW) & ((1u << SW) - 1u)); };
@@ -975,15 +977,28 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
   if (plan.p5 != 5u) L("  w = (w & ~(1ull << " + N(plan.p5) + ")) | (((w >> " + N(plan.p5) + ") & 1ull) << 5);");
   L("  return w;");
   L("}");
-  L(std::string("extern \"C\" __global__ __launch_bounds__(256, 2) void qip_segment(A* __restrict__ st, uint64_t ntiles") +
-    (params ? ", const T* __restrict__ P" : "") + ") {");
+  if (fold && fold->g) {
+    // r5: the tiles are stored elsewhere, packed for the multi-GPU exchange (TileStorePerm), exactly as the 11-bit sweeps do it: the
+    // map moves index bits, so it distributes over wave base | access bits | lane offset
+    L("__device__ __forceinline__ uint64_t dst_of(uint64_t x) {");
+    L("  uint64_t top = 0;");
+    for (uint32_t t = 0; t < fold->g; ++t) L("  top |= ((x >> " + N(fold->sel[t]) + ") & 1ull) << " + N(fold->Lg + t) + ";");
+    for (uint32_t t = 0; t < fold->g; ++t) {
+      const std::string p = N(fold->sel_desc[t]);
+      L("  x = ((x >> " + N(fold->sel_desc[t] + 1) + ") << " + p + ") | (x & ((1ull << " + p + ") - 1ull));");
+    }
+    L("  return x | top;");
+    L("}");
+  }
+  L(std::string("extern \"C\" __global__ __launch_bounds__(256, 2) void qip_segment(A* __restrict__ st, uint64_t ") + (sliced ? "slice_or" : "ntiles") +
+    (params ? ", const T* __restrict__ P" : "") + (fold && fold->g ? ", A* __restrict__ out" : "") + ") {");
   L("  extern __shared__ __attribute__((aligned(16))) unsigned char buf_raw[];");
   L("  A* buf = reinterpret_cast<A*>(buf_raw);");
   L(std::string("  constexpr bool NT = ") + (nt ? "true" : "false") + ";");
   L("  const uint32_t tid = threadIdx.x, lane = tid & 63u;");
   L("  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);");
-  L("  (void)ntiles;");
-  L("  const uint64_t base = tile_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x);");
+  if (!sliced) L("  (void)ntiles;");
+  L(std::string("  const uint64_t base = tile_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x)") + (sliced ? " | slice_or;" : ";"));
   L("  const uint64_t wbase = base | ((uint64_t)(wave & 1u) << " + N(plan.high[0]) + ") | ((uint64_t)(wave >> 1) << " + N(plan.high[1]) + ");");
   L("  const uint32_t lane_off = tile_lane_off(lane, " + N(plan.p5) + "u);");
   auto ub = [&](int u) {
@@ -1227,7 +1242,12 @@ static std::string wide_jit_source(const WidePlan<T>& plan, const Ins& ins, bool
     L("  }");
   }
   const std::string el = "e" + N(plan.passes.size() - 1);
-  for (int u = 0; u < 32; ++u) L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, " + el + "[" + N(u) + "]);");
+  if (fold && fold->g) {
+    L("  const uint64_t dlane = dst_of(lane_off);");
+    for (int u = 0; u < 32; ++u) L("  stg<NT>(out + dst_of(wbase | " + ub(u) + ") + dlane, " + el + "[" + N(u) + "]);");
+  } else {
+    for (int u = 0; u < 32; ++u) L("  stg<NT>(st + (wbase | " + ub(u) + ") + lane_off, " + el + "[" + N(u) + "]);");
+  }
   L("}");
   return o;
 }
@@ -1493,6 +1513,33 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   if (folding)
     for (uint32_t t = 0; t < fold->g; ++t) folding = folding && !tile_is_low(fold->sel[t], plan.p5);
   if (folding) QCHK(ensure_alt(s));
+  // r5: the sweep in 2^nbits parts (TileSlicing, qip_internal.h) — the slice positions must be block-index bits of this sweep
+  // (not tile positions, not positions taken off the grid), above the rows, and with `need_fold` the store must really be packed
+  TileSlicing* sl = (s->capture_staging || s->jit_prepare) ? nullptr : s->slice_now;
+  bool slicing = sl && sl->nbits >= 1 && sl->nbits <= 3 && s->tile_passes && (!grid_ctl || grid_ctl->empty()) && (!sl->need_fold || folding) &&
+                 !(sl->in_place_only && folding) && s->n >= (uint32_t)kTileBits + sl->nbits;
+  if (slicing)
+    for (uint32_t j = 0; j < sl->nbits; ++j) {
+      slicing = slicing && sl->pos[j] > 11u && sl->pos[j] < s->n && !tile_is_low(sl->pos[j], plan.p5) &&
+                std::find(high.begin(), high.end(), sl->pos[j]) == high.end();
+      for (uint32_t i = 0; i < j; ++i) slicing = slicing && sl->pos[i] != sl->pos[j];
+    }
+  Ins ins_sliced = ins;
+  if (slicing) {
+    std::vector<uint32_t> opened = high;
+    for (uint32_t& o : opened)
+      if (o == 5u) o = plan.p5;  // (as above: the space where p5 and 5 have traded places; slice positions are > 11)
+    for (uint32_t j = 0; j < sl->nbits; ++j) opened.push_back(sl->pos[j]);
+    ins_sliced = make_ins(opened, 0);
+  }
+  const uint32_t nparts = slicing ? 1u << sl->nbits : 1u;
+  auto slice_or = [&](uint32_t k) {
+    uint64_t v = 0;
+    for (uint32_t j = 0; slicing && j < sl->nbits; ++j) v |= (uint64_t)((k >> j) & 1u) << sl->pos[j];
+    return v;
+  };
+  if (sl && !slicing && sl->fallback) QCHK(sl->fallback());
+  if (sl) s->slice_now = nullptr;  // (consumed: by this step, sliced or not)
   auto folded_swap = [&]() {
     std::swap(s->cur, s->alt);
     std::swap(s->owns_cur, s->owns_alt);
@@ -1537,24 +1584,33 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       if (nb < 3) remap = 0;
       else remap = 16 + (int)std::min(J, nb - 3);
     }
-    const std::string src = tile_jit_source<T>(plan, ins, use_nt(s), remap, parametrised ? &params : nullptr, merge, folding ? fold : nullptr);
+    if (slicing) remap = 0;
+    const std::string src = tile_jit_source<T>(plan, slicing ? ins_sliced : ins, use_nt(s), remap, parametrised ? &params : nullptr, merge,
+                                               folding ? fold : nullptr, slicing);
     QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss BEFORE the timed region starts
     if (s->jit_prepare) return QIP_OK;
     if (parametrised && !params.empty()) QCHK(arena_upload(s, params.data(), params.size() * sizeof(T), 0));
     if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, sweep_bytes, &rec));
     void* st_ptr = s->cur;
-    uint64_t ntiles_arg = ntiles;
+    uint64_t ntiles_arg = ntiles;  // (a sliced kernel reads the part's slice bits here instead)
     void* params_ptr = s->arena;
     void* out_ptr = s->alt;
     // (a kernel without parameters has no third argument: the packed-store destination then comes third)
     void* args_p[] = {&st_ptr, &ntiles_arg, &params_ptr, &out_ptr};
     void* args_np[] = {&st_ptr, &ntiles_arg, &out_ptr};
     void** args = (parametrised || !folding) ? args_p : args_np;
-    const dim3 grid = grid2d(ntiles, 1);
-    QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
-      HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
-      return QIP_OK;
-    }));
+    const dim3 grid = grid2d(ntiles >> (slicing ? sl->nbits : 0), 1);
+    for (uint32_t k = 0; k < nparts; ++k) {
+      if (slicing && sl->before) QCHK(sl->before(k, folding));
+      if (slicing) ntiles_arg = slice_or(k);
+      QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
+        HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, kTileBlock, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+        return QIP_OK;
+      }));
+      if (slicing && sl->after) QCHK(sl->after(k, folding));
+      if (slicing) sl->parts_done += 1;
+    }
+    if (slicing) sl->folded = folding;
     if (s->profile) QCHK(prof_end(s, &rec));
     if (folding) folded_swap();
     return QIP_OK;
@@ -1562,22 +1618,34 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   if (s->jit_prepare) return QIP_OK;
   if (s->tile_passes) {
     QCHK(begin());
-    if (folding) {
-#define TPF(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV, true>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
-                                    (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)s->alt, *fold, ditems)
-      if (use_nt(s)) TPF(true);
-      else TPF(false);
+    const uint64_t ntiles_part = ntiles >> (slicing ? sl->nbits : 0);
+    for (uint32_t k = 0; k < nparts; ++k) {
+      Ins ins_k = slicing ? ins_sliced : ins;
+      ins_k.ormask |= slice_or(k);
+      if (slicing && sl->before) QCHK(sl->before(k, folding));
+      if (folding) {
+#define TPF(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV, true>), grid2d(ntiles_part, 1), dim3(kTileBlock), lds, s->stream, \
+                                    (amp_t<T>*)s->cur, ins_k, pd, dg, dmats, (amp_t<T>*)s->alt, *fold, ditems)
+        if (use_nt(s)) TPF(true);
+        else TPF(false);
 #undef TPF
+      } else {
+#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles_part, 1), dim3(kTileBlock), lds, s->stream, \
+                                   (amp_t<T>*)s->cur, ins_k, pd, dg, dmats, (amp_t<T>*)nullptr, TileStorePerm(), ditems)
+        if (use_nt(s)) TP(true);
+        else TP(false);
+#undef TP
+      }
       HIPCHK(hipGetLastError());
+      if (slicing && sl->after) QCHK(sl->after(k, folding));
+      if (slicing) sl->parts_done += 1;
+    }
+    if (slicing) sl->folded = folding;
+    if (folding) {
       if (s->profile) QCHK(prof_end(s, &rec));
       folded_swap();
       return QIP_OK;
     }
-#define TP(NTV) hipLaunchKernelGGL((k_tile_passes<T, NTV>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, \
-                                   (amp_t<T>*)s->cur, ins, pd, dg, dmats, (amp_t<T>*)nullptr, TileStorePerm(), ditems)
-    if (use_nt(s)) TP(true);
-    else TP(false);
-#undef TP
   } else {
     QCHK(begin());
     if (use_nt(s))
@@ -1602,7 +1670,35 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   const bool parametrised = s->tile_jit != 3;
   std::vector<T> params;
   const bool merge = s->tile_merge && s->tile >= 2;  // products of runs of diagonal gates: rounding differs (1e-12 mode only)
-  const std::string src = wide_jit_source<T>(plan, ins, use_nt(s), parametrised ? &params : nullptr, merge, g_tile_wide_pin != 0, g_tile_wide_dense3_inline != 0);
+  // r5: a packed store (the multi-GPU remap's gather rides in this sweep, TileStorePerm) under the same conditions as the 11-bit
+  // sweeps: none of the gathered positions is a lane position of the tile, the second buffer exists
+  const TileStorePerm* fold = (s->fold_now && s->fold_request && !s->fold_done) ? s->fold_request : nullptr;
+  bool folding = fold && fold->g && !s->capture_staging && !s->jit_prepare;
+  if (folding)
+    for (uint32_t t = 0; t < fold->g; ++t) folding = folding && !tile_is_low(fold->sel[t], plan.p5);
+  if (folding) QCHK(ensure_alt(s));
+  // r5: the sweep in parts (TileSlicing: the sharded state's exchange overlaps with it)
+  TileSlicing* sl = (s->capture_staging || s->jit_prepare) ? nullptr : s->slice_now;
+  bool slicing = sl && sl->nbits >= 1 && sl->nbits <= 3 && (!sl->need_fold || folding) && !(sl->in_place_only && folding) &&
+                 s->n >= (uint32_t)kWideBits + sl->nbits;
+  if (slicing)
+    for (uint32_t j = 0; j < sl->nbits; ++j) {
+      slicing = slicing && sl->pos[j] > 11u && sl->pos[j] < s->n && !tile_is_low(sl->pos[j], plan.p5) &&
+                std::find(plan.high.begin(), plan.high.end(), sl->pos[j]) == plan.high.end();
+      for (uint32_t i = 0; i < j; ++i) slicing = slicing && sl->pos[i] != sl->pos[j];
+    }
+  Ins ins_use = ins;
+  if (slicing) {
+    std::vector<uint32_t> opened = plan.high;
+    for (uint32_t& o : opened)
+      if (o == 5u) o = plan.p5;
+    for (uint32_t j = 0; j < sl->nbits; ++j) opened.push_back(sl->pos[j]);
+    ins_use = make_ins(opened, 0);
+  }
+  if (sl && !slicing && sl->fallback) QCHK(sl->fallback());
+  if (sl) s->slice_now = nullptr;
+  const std::string src = wide_jit_source<T>(plan, ins_use, use_nt(s), parametrised ? &params : nullptr, merge, g_tile_wide_pin != 0, g_tile_wide_dense3_inline != 0, slicing,
+                                             folding ? fold : nullptr);
   if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
   QCHK(jit_get_and_launch(s, src, fma, nullptr));  // compile on a miss before the timed region starts
   if (s->jit_prepare) return QIP_OK;
@@ -1611,16 +1707,39 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   rec.cls = KC_TILE_GATES;
   if (s->profile) QCHK(prof_begin(s, KC_TILE_GATES, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
   void* st_ptr = s->cur;
-  uint64_t ntiles = 1ull << (s->n - (uint32_t)kWideBits);
+  const uint64_t ntiles = (1ull << (s->n - (uint32_t)kWideBits)) >> (slicing ? sl->nbits : 0);
+  uint64_t second_arg = ntiles;  // (a sliced kernel reads the part's slice bits here)
   void* params_ptr = s->arena;
-  void* args[] = {&st_ptr, &ntiles, &params_ptr};
+  void* out_ptr = s->alt;
+  // (a kernel without parameters has no third argument: the packed-store destination then comes third)
+  void* args_p[] = {&st_ptr, &second_arg, &params_ptr, &out_ptr};
+  void* args_np[] = {&st_ptr, &second_arg, &out_ptr};
+  void** args = (parametrised || !folding) ? args_p : args_np;
   const dim3 grid = grid2d(ntiles, 1);
   const size_t lds = 2 * (sizeof(amp_t<T>) << kTileBits);  // the transposition buffer: two quarters of the tile
-  QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
-    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, 256, 1, 1, (unsigned)lds, s->stream, args, nullptr));
-    return QIP_OK;
-  }));
+  const uint32_t nparts = slicing ? 1u << sl->nbits : 1u;
+  for (uint32_t k = 0; k < nparts; ++k) {
+    if (slicing) {
+      second_arg = 0;
+      for (uint32_t j = 0; j < sl->nbits; ++j) second_arg |= (uint64_t)((k >> j) & 1u) << sl->pos[j];
+      if (sl->before) QCHK(sl->before(k, folding));
+    }
+    QCHK(jit_get_and_launch(s, src, fma, [&](hipFunction_t fn) -> int {
+      HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, 256, 1, 1, (unsigned)lds, s->stream, args, nullptr));
+      return QIP_OK;
+    }));
+    if (slicing) {
+      if (sl->after) QCHK(sl->after(k, folding));
+      sl->parts_done += 1;
+    }
+  }
+  if (slicing) sl->folded = folding;
   if (s->profile) QCHK(prof_end(s, &rec));
+  if (folding) {
+    std::swap(s->cur, s->alt);
+    std::swap(s->owns_cur, s->owns_alt);
+    s->fold_done = true;
+  }
   return QIP_OK;
 }
 
@@ -1765,6 +1884,8 @@ static int tile_mode_of(const qip_hip_state* s) {  // option tile_relabel: 1 = w
          (tile_wide_of(s) ? 16 : 0);
 }
 
+int state_tile_mode(const qip_hip_state* s) { return tile_mode_of(s); }  // (qip_dist.hip schedules the edge sweeps of a remap with it)
+
 template <typename T>
 static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t count, bool /*reorder*/) {
   TileSchedule sc;
@@ -1873,14 +1994,43 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   for (uint32_t p = 0; p < final_phys.size(); ++p) ends_in_callers_order = ends_in_callers_order && final_phys[p] == p;
   auto run_steps = [&]() -> int {
     size_t step_no = 0;
+    // a first-step request that no step can take (an empty plan; one step that already serves the last-step request) is settled
+    // BEFORE anything is enqueued: its fallback is what makes the data the batch reads complete
+    if (s->slice_first && !s->jit_prepare && !s->capture_staging && (sc.steps.empty() || (sc.steps.size() == 1 && s->slice_last && ends_in_callers_order))) {
+      TileSlicing* w = s->slice_first;
+      s->slice_first = nullptr;
+      if (w->fallback) QCHK(w->fallback());
+    }
     for (const TileStep& st : sc.steps) {
-      s->fold_now = s->fold_request && ends_in_callers_order && ++step_no == sc.steps.size();  // (the batch's last step may store packed)
+      ++step_no;
+      s->fold_now = s->fold_request && ends_in_callers_order && step_no == sc.steps.size();  // (the batch's last step may store packed)
+      // r5: the first / last step in parts (the sharded state's overlapped exchange); positions are caller-order positions, so
+      // only a plan that starts / ends in the caller's order may take the request.  A step that is not a multi-gate tile sweep
+      // (or a sweep that cannot be cut there) consumes it through its fallback.
+      TileSlicing* want = nullptr;
+      if (!s->jit_prepare && !s->capture_staging) {
+        if (step_no == sc.steps.size() && s->slice_last && ends_in_callers_order) want = s->slice_last;
+        else if (step_no == 1 && s->slice_first && sc.init_phys.empty() && sc.inserted == 0 && sc.absorbed == 0) want = s->slice_first;
+        else if (step_no == 1 && s->slice_first) {  // (a relabelled plan addresses other positions: settle the request unsliced)
+          TileSlicing* w = s->slice_first;
+          s->slice_first = nullptr;
+          if (w->fallback) QCHK(w->fallback());
+        }
+      }
+      s->slice_now = want;
+      auto unsliced = [&]() -> int {
+        TileSlicing* w = s->slice_now;
+        s->slice_now = nullptr;
+        return (w && w->fallback) ? w->fallback() : QIP_OK;
+      };
       if (!st.perm.empty()) {  // a run of Swap ops as one bit-permutation sweep
         if (s->jit_prepare) continue;
+        QCHK(unsliced());
         QCHK(launch_permute(s, st.perm.data()));
         continue;
       }
       if (st.ops.size() == 1) {
+        QCHK(unsliced());
         QCHK(apply_op_t<T>(s, &ops[st.ops[0]]));
         continue;
       }
@@ -1893,6 +2043,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   };
   const int rc_steps = run_steps();
   s->fold_now = false;
+  s->slice_now = nullptr;
   if (rc_steps != QIP_OK) {
     if (moves_qubits && !s->jit_prepare) {
       s->poisoned = true;
@@ -1914,6 +2065,11 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
   if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
     return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
                                : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
+  if (s->slice_first) {  // (only tile sweeps run in parts: every other path settles the request before its first launch)
+    TileSlicing* w = s->slice_first;
+    s->slice_first = nullptr;
+    if (w->fallback) QCHK(w->fallback());
+  }
   if (!s->layout.empty()) QCHK(state_settle(s));
   if (s->fuse >= 2 && !s->force_generic && !g_force_generic) {
     const uint32_t K = (uint32_t)std::min<int64_t>(s->fuse, kMaxMfmaK);  // both precisions have a matrix-core k = 5 kernel
@@ -1927,7 +2083,13 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     // neighbour fit one tile they go as ONE two-item tile sweep (interpreter kernel, circuit order: the same unfused arithmetic
     // per amplitude, IEEE-equal to the two launches) — the neighbour rides for free.  Everything else stays one launch per gate.
     if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_staging) {
+      // What the two launches move, in sweeps of the whole vector: a gate's algorithmic share, doubled for every selector
+      // inside a wave row (whole lines / rows travel whichever half is needed), at most 1.  One two-item sweep moves 1 (and runs
+      // a little slower than a bare sweep): worth it from 1.3 — T on a low bit + H (1 + 1), CNOT with a low control + anything;
+      // NOT two controlled phases of a QFT (1/4 doubled = 1/2 each: measured 946 -> 986 ms when they were paired).
       bool floor_gate = false, both = true;
+      double moved = 0;
+      const double full = 2.0 * (double)s->amp_bytes * (double)s->namps;
       for (int j = 0; j < 2 && both; ++j) {
         TileItem it;
         if (classify_tile_item(s->dtype, s->n, &ops[i + j], &it) != QIP_OK || !it.tileable) {
@@ -1935,11 +2097,16 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
           break;
         }
         double by = 0;
-        if ((it.d_mask & 63ull) && qip_hip_op_algorithmic_bytes(s->dtype, s->n, &ops[i + j], &by) == QIP_OK &&
-            by < 2.0 * (double)s->amp_bytes * (double)s->namps)
-          floor_gate = true;
+        if (qip_hip_op_algorithmic_bytes(s->dtype, s->n, &ops[i + j], &by) != QIP_OK) {
+          both = false;
+          break;
+        }
+        const int in_row = __builtin_popcountll(it.d_mask & 63ull);
+        const double phys = std::min(1.0, by / full * (double)(1u << in_row));
+        if (in_row && phys > by / full) floor_gate = true;
+        moved += phys;
       }
-      if (both && floor_gate) {
+      if (both && floor_gate && moved >= 1.3) {
         TileSchedule sc;
         if (make_tile_schedule(s->dtype, s->n, &ops[i], 2, 1, true, &sc) == QIP_OK && sc.steps.size() == 1 && sc.steps[0].ops.size() == 2 &&
             sc.steps[0].perm.empty()) {

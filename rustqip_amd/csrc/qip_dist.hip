@@ -671,6 +671,35 @@ static int rccl_all_to_all(void* ctx, const void* send, void* recv, uint64_t chu
                         hipMemcpyDeviceToDevice, st));
   return QIP_OK;
 }
+// r5: bytes [slice_off, slice_off + slice_bytes) of EVERY chunk — one group over all peers, so that all links run at once in every
+// slice (cutting the exchange by peer instead would use the links one after the other); the slices of one remap are issued in order
+// on the handle's communication stream and overlap with the tile sweeps on the shard's stream (dist_run_steps)
+static int rccl_all_to_all_slice(void* ctx, const void* send, void* recv, uint64_t chunk_bytes, uint64_t slice_off, uint64_t slice_bytes, void* stream) {
+  RcclTransport* t = static_cast<RcclTransport*>(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  if (slice_off > chunk_bytes || slice_bytes > chunk_bytes - slice_off) return fail(QIP_ERR_INVALID, "slice outside the chunk");
+  if (t->world > 1) {
+    int first = 0;
+    const char* what = "";
+    int r = g_rccl.GroupStart();
+    if (r != 0) return fail(QIP_ERR_DEVICE, "ncclGroupStart failed: %s", g_rccl.GetErrorString(r));
+    for (const Piece& pc : plan_pieces(t->rank, t->world, slice_bytes, t->piece_bytes)) {
+      const size_t at = (size_t)pc.peer * chunk_bytes + slice_off + pc.offset;
+      r = g_rccl.Send((const char*)send + at, (size_t)pc.length, Rccl::kUint8, pc.peer, t->comm, st);
+      if (r != 0 && first == 0) first = r, what = "ncclSend";
+      r = g_rccl.Recv((char*)recv + at, (size_t)pc.length, Rccl::kUint8, pc.peer, t->comm, st);
+      if (r != 0 && first == 0) first = r, what = "ncclRecv";
+      if (first != 0) break;
+      t->pieces_sent += 1;
+    }
+    r = g_rccl.GroupEnd();
+    if (first != 0) return fail(QIP_ERR_DEVICE, "%s failed inside the exchange group: %s", what, g_rccl.GetErrorString(first));
+    if (r != 0) return fail(QIP_ERR_DEVICE, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(r));
+  }
+  const size_t own = (size_t)t->rank * chunk_bytes + slice_off;
+  HIPCHK(hipMemcpyAsync((char*)recv + own, (const char*)send + own, slice_bytes, hipMemcpyDeviceToDevice, st));
+  return QIP_OK;
+}
 static int rccl_all_reduce(void* ctx, double* values, uint64_t count) {
   RcclTransport* t = static_cast<RcclTransport*>(ctx);
   if (count == 0) return QIP_OK;
@@ -736,11 +765,131 @@ struct qip_hip_dist {
   // computed from such a handle can be trusted: it is poisoned and every later call fails with the original message.
   bool poisoned = false;
   std::string poison_msg;
+  // r5: the exchange overlapped with the tile sweeps either side of it (dist_run_steps): cut into `overlap` slices (option
+  // "dist_overlap": 0 / 1 = off, 2 / 4 / 8), each issued on `comm_stream` as soon as the sweep before the remap has stored it,
+  // the sweep after the remap starting on a slice as soon as it has landed.  `third`: the receive buffer of a remap whose packed
+  // store and exchange are both in flight (source, packed copy and receive buffer are three different arrays then).
+  int64_t overlap = 0;
+  qip_hip_all_to_all_slice_fn slice_fn = nullptr;
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> ev_pre, ev_rx;
+  void* third = nullptr;
+  bool rx_pending = false;  // slices of the last overlapped exchange may still be landing: the shard's stream has not waited yet
+  uint32_t rx_slices = 0;
+  std::vector<uint32_t> rx_packed;  // the positions that cut it
+  bool rx_after = false;            // ... and whether the first sweep of the next batch can take them
 };
+
+
+// ---- r5: the overlapped exchange — what the tile sweeps either side of a remap look like, and where the exchange can be cut ----
+// The exchange is cut into 2^p slices by p index positions of the buffer that is exchanged ("packed" positions, below the g chunk-
+// selecting ones); a sweep can run slice by slice when NONE of those positions is a tile position of it.  The edge sweeps of the two
+// batches are found by scheduling them exactly as apply_ops will (host work, no device), then the p highest packed positions that the
+// LAST sweep before the remap leaves alone — preferring those the FIRST sweep after it leaves alone too — are taken.  A slice is then
+// 2^(L-g-p-q0) runs of 2^q0 consecutive amplitudes per chunk (q0 = the lowest chosen position, >= kSliceMinPos): one transport call
+// per run, every call a group over all peers.  Shared by the executor (dist_run_steps) and the host-only predicate
+// (qip_hip_dist_debug_overlap), so what the model prices is what runs.
+struct EdgeTile {
+  bool segment = false;          // the step is a multi-gate tile sweep
+  bool wide = false;
+  std::vector<uint32_t> high;    // its tile's positions above the rows
+  uint32_t p5 = 5;
+  bool ends_in_callers_order = false, starts_plain = false;
+  size_t nsteps = 0;
+};
+int state_tile_mode(const qip_hip_state* s);  // qip_circuit.hip
+template <typename T>
+static EdgeTile edge_tile_t(int dtype, uint32_t L, const qip_op* ops, uint64_t count, int tile_mode, bool last) {
+  EdgeTile e;
+  TileSchedule sc;
+  if (L < (uint32_t)kTileBits || make_tile_schedule(dtype, L, ops, count, tile_mode & (1 | 2 | 4 | 8 | 16), true, &sc) != QIP_OK || sc.steps.empty()) return e;
+  e.nsteps = sc.steps.size();
+  e.ends_in_callers_order = true;
+  for (uint32_t p = 0; p < sc.final_phys.size(); ++p) e.ends_in_callers_order = e.ends_in_callers_order && sc.final_phys[p] == p;
+  e.starts_plain = sc.init_phys.empty() && sc.inserted == 0 && sc.absorbed == 0;
+  const TileStep& st = last ? sc.steps.back() : sc.steps.front();
+  if (st.ops.size() < 2 || !st.perm.empty()) return e;
+  std::vector<const TileItem*> seg;
+  for (uint64_t i : st.ops) seg.push_back(&sc.items[i]);
+  if ((tile_mode & 16) && L > (uint32_t)kWideBits) {
+    WidePlan<T> plan;
+    if (build_wide_segment<T>(L, seg, st.high, &plan, tile_mode & 3) != QIP_OK) return e;
+    e.high = plan.high;
+    e.p5 = plan.p5;
+    e.wide = true;
+  } else {
+    TileSegmentPlan<T> plan;
+    if (build_tile_segment<T>(L, true, seg, st.high, &plan, tile_mode & 3) != QIP_OK) return e;
+    e.high = plan.high;
+    e.p5 = plan.p5;
+  }
+  e.segment = true;
+  return e;
+}
+static EdgeTile edge_tile(int dtype, uint32_t L, const qip_op* ops, uint64_t count, int tile_mode, bool last) {
+  (void)hipGetLastError();
+  return dtype == QIP_C64 ? edge_tile_t<double>(dtype, L, ops, count, tile_mode, last) : edge_tile_t<float>(dtype, L, ops, count, tile_mode, last);
+}
+constexpr uint32_t kSliceMinPos = 12;  // (slice positions lie above the rows and above the split-row position 11)
+// packed position q < L-g  <->  position of the buffer the sweep before the remap addresses (a gather in between moves it)
+static uint32_t packed_to_source(uint32_t q, const std::vector<uint32_t>* sel, uint32_t L) {
+  if (!sel) return q;
+  uint32_t seen = 0;
+  for (uint32_t pp = 0; pp < L; ++pp) {
+    if (std::find(sel->begin(), sel->end(), pp) != sel->end()) continue;
+    if (seen == q) return pp;
+    ++seen;
+  }
+  return L;
+}
+static bool in_tile(const EdgeTile& e, uint32_t pos) { return tile_is_low(pos, e.p5) || std::find(e.high.begin(), e.high.end(), pos) != e.high.end(); }
+// *packed = the p chosen packed positions (ascending); *after = the sweep after the remap can take them too
+static bool choose_slices(uint32_t L, uint32_t g, uint32_t pbits, const std::vector<uint32_t>* pack_sel, const EdgeTile& pre, const EdgeTile* post,
+                          std::vector<uint32_t>* packed, bool* after) {
+  packed->clear();
+  *after = false;
+  if (!pre.segment || !pre.ends_in_callers_order || L < g + pbits + kSliceMinPos) return false;
+  if (pack_sel) {  // the gather must ride in that sweep: a packed store, which needs the rows to survive
+    for (uint32_t p : *pack_sel)
+      if (tile_is_low(p, pre.p5)) return false;
+  }
+  const bool post_usable = post && post->segment && post->starts_plain;
+  for (int pass = post_usable ? 0 : 1; pass < 2 && packed->size() < pbits; ++pass) {
+    packed->clear();
+    for (uint32_t q = L - g; q-- > kSliceMinPos && packed->size() < pbits;) {
+      const uint32_t src = packed_to_source(q, pack_sel, L);
+      if (src >= L || src <= 11u || in_tile(pre, src)) continue;
+      if (pass == 0 && (q <= 11u || in_tile(*post, q))) continue;
+      packed->push_back(q);
+    }
+    if (packed->size() == pbits) *after = pass == 0;
+  }
+  if (packed->size() != pbits) return false;
+  std::sort(packed->begin(), packed->end());
+  return true;
+}
+// the byte runs of slice k inside ONE chunk: offsets (bytes) and the common run length
+static void slice_runs(uint32_t L, uint32_t g, const std::vector<uint32_t>& packed, uint32_t k, uint64_t amp_bytes, std::vector<uint64_t>* offsets,
+                       uint64_t* run_bytes) {
+  const uint32_t q0 = packed[0], top = L - g;
+  std::vector<uint32_t> free_bits;  // the chunk-offset bits above q0 that are not slice positions
+  for (uint32_t q = q0 + 1; q < top; ++q)
+    if (std::find(packed.begin(), packed.end(), q) == packed.end()) free_bits.push_back(q);
+  uint64_t fixed = 0;
+  for (size_t j = 0; j < packed.size(); ++j) fixed |= (uint64_t)((k >> j) & 1u) << packed[j];
+  offsets->clear();
+  for (uint64_t c = 0; c < (1ull << free_bits.size()); ++c) {
+    uint64_t off = fixed;
+    for (size_t b = 0; b < free_bits.size(); ++b) off |= ((c >> b) & 1ull) << free_bits[b];
+    offsets->push_back(off * amp_bytes);
+  }
+  *run_bytes = (1ull << q0) * amp_bytes;
+}
 
 static int dist_drain_events(qip_hip_dist* d) {
   qip_hip_state* s = d->shard;
   if (d->ev_exchange.empty() && d->ev_pack.empty()) return QIP_OK;
+  if (d->comm_stream) HIPCHK(hipStreamSynchronize(d->comm_stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   for (auto* list : {&d->ev_exchange, &d->ev_pack}) {
     for (auto& e : *list) {
@@ -775,7 +924,34 @@ template <typename F> static int dist_timed(qip_hip_dist* d, std::vector<std::pa
   return QIP_OK;
 }
 
+// the shard's stream waits for every slice of the last overlapped exchange that it has not waited for yet
+static int dist_wait_rx(qip_hip_dist* d) {
+  if (!d->rx_pending) return QIP_OK;
+  for (uint32_t k = 0; k < d->rx_slices; ++k) HIPCHK(hipStreamWaitEvent(d->shard->stream, d->ev_rx[k], 0));
+  d->rx_pending = false;
+  return QIP_OK;
+}
+static int dist_overlap_setup(qip_hip_dist* d, uint32_t P) {
+  if (!d->comm_stream) HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+  while (d->ev_pre.size() < P) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    d->ev_pre.push_back(a);
+    d->ev_rx.push_back(b);
+  }
+  return QIP_OK;
+}
+
+static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps);
 static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
+  const int rc = dist_run_steps_inner(d, steps);
+  // whatever comes next on the shard's stream (a download, a measurement, the next batch) is ordered after the last slices
+  if (rc == QIP_OK) return dist_wait_rx(d);
+  d->shard->slice_first = d->shard->slice_last = d->shard->slice_now = nullptr;
+  return rc;
+}
+static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
   qip_hip_state* s = d->shard;
   const uint32_t g = d->pl.g, L = d->pl.L;
   size_t i = 0;
@@ -807,19 +983,120 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
         s->fold_request = &sp;
         s->fold_done = false;
       }
+      // r5, option "dist_overlap": the exchange that follows this batch in P slices on the communication stream, slice k sent as
+      // soon as the batch's LAST tile sweep — launched in P parts — has stored it; and the slices of the exchange BEFORE this
+      // batch awaited one by one by its FIRST sweep (TileSlicing, qip_internal.h).  The slice bits are the index positions right
+      // below the chunk-selecting ones of the buffer that is exchanged: packed positions L-g-p .. L-g-1.
+      const uint32_t P = (d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && !s->force_generic && !g_force_generic) ? (uint32_t)d->overlap : 0u;
+      uint32_t pbits = 0;
+      while ((1u << pbits) < P) ++pbits;
+      TileSlicing sl_post, sl_pre;
+      const bool post = d->rx_pending && d->rx_after && P && d->rx_packed.size() == pbits;
+      if (post) {
+        sl_post.nbits = pbits;
+        sl_post.in_place_only = true;
+        for (uint32_t j = 0; j < pbits; ++j) sl_post.pos[j] = d->rx_packed[j];
+        sl_post.before = [d](uint32_t k, bool) -> int {
+          HIPCHK(hipStreamWaitEvent(d->shard->stream, d->ev_rx[k], 0));
+          return QIP_OK;
+        };
+        sl_post.fallback = [d]() -> int { return dist_wait_rx(d); };
+        s->slice_first = &sl_post;
+      } else {
+        QCHK(dist_wait_rx(d));
+      }
+      const size_t ex_at = jx + (jx < steps.size() && steps[jx].kind == qipd::Step::PACK ? 1 : 0);
+      const bool ex_next = ex_at < steps.size() && steps[ex_at].kind == qipd::Step::EXCHANGE;
+      const bool pack_in_plan = ex_next && ex_at != jx;
+      bool pre = P && ex_next && s->layout.empty() && (!pack_in_plan || pack_next);
+      const uint64_t chunk_bytes = (s->namps >> g) * s->amp_bytes;
+      std::vector<uint32_t> packed;
+      bool after_ok = false;
+      if (pre) {
+        // the sweeps either side, as apply_ops will schedule them (the batch after the remap is marshalled early for that)
+        const int mode = state_tile_mode(s);
+        const EdgeTile e_pre = edge_tile(s->dtype, L, m.flat.data(), m.flat.size(), mode, true);
+        EdgeTile e_post;
+        qipd::Marshalled m2;
+        {
+          std::vector<const qip_op*> p2;
+          for (size_t t = ex_at + 1; t < steps.size() && steps[t].kind == qipd::Step::LOCAL; ++t) p2.push_back(qipd::marshal_one(s->dtype, *steps[t].op, &m2));
+          for (const qip_op* q2 : p2) m2.flat.push_back(*q2);
+          if (!m2.flat.empty()) e_post = edge_tile(s->dtype, L, m2.flat.data(), m2.flat.size(), mode, false);
+        }
+        pre = choose_slices(L, g, pbits, pack_in_plan ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, &packed, &after_ok);
+      }
+      if (pre) {
+        if (dist_overlap_setup(d, P) != QIP_OK) pre = false;
+        if (pre && pack_in_plan && !d->third && hipMalloc(&d->third, s->namps * s->amp_bytes) != hipSuccess) {
+          (void)hipGetLastError();  // no room for the receive buffer: this remap runs the serial way
+          d->third = nullptr;
+          pre = false;
+        }
+        if (pre && !pack_in_plan && ensure_alt(s) != QIP_OK) pre = false;
+      }
+      if (pre) {
+        sl_pre.nbits = pbits;
+        sl_pre.need_fold = pack_in_plan;
+        for (uint32_t j = 0; j < pbits; ++j) sl_pre.pos[j] = packed_to_source(packed[j], pack_in_plan ? &steps[jx].sel : nullptr, L);
+        const uint64_t amp_bytes = s->amp_bytes;
+        sl_pre.after = [d, s, chunk_bytes, amp_bytes, pack_in_plan, packed, L, g](uint32_t k, bool folding) -> int {
+          if (folding != pack_in_plan) return fail(QIP_ERR_DEVICE, "internal: overlapped exchange and packed store disagree");
+          HIPCHK(hipEventRecord(d->ev_pre[k], s->stream));
+          HIPCHK(hipStreamWaitEvent(d->comm_stream, d->ev_pre[k], 0));
+          // (the part has been enqueued, the buffers have not been exchanged yet: a packed store went to `alt`)
+          const void* send = folding ? s->alt : s->cur;
+          void* recv = folding ? d->third : s->alt;
+          std::vector<uint64_t> offs;
+          uint64_t run_bytes = 0;
+          slice_runs(L, g, packed, k, amp_bytes, &offs, &run_bytes);
+          for (uint64_t off : offs) {
+            const int rc = d->slice_fn(d->transport.ctx, send, recv, chunk_bytes, off, run_bytes, (void*)d->comm_stream);
+            if (rc != 0) return g_last_error.empty() ? fail(QIP_ERR_DEVICE, "transport all_to_all_slice failed with status %d", rc) : QIP_ERR_DEVICE;
+          }
+          HIPCHK(hipEventRecord(d->ev_rx[k], d->comm_stream));
+          return QIP_OK;
+        };
+        s->slice_last = &sl_pre;
+      }
       const int rc_batch = qip_hip_state_apply_ops(s, m.flat.data(), m.flat.size());
       const bool folded = pack_next && s->fold_done;
       s->fold_request = nullptr;
       s->fold_done = false;
+      s->slice_first = s->slice_last = s->slice_now = nullptr;
       QCHK(rc_batch);
+      if (post) {
+        QCHK(dist_wait_rx(d));  // (a no-op in stream order when the first sweep has awaited every slice; otherwise the safety net)
+        if (sl_post.parts_done == P) d->stats.remaps_overlapped_after += 1;
+      }
       if (folded) {
         d->stats.packs_folded += 1;
         ++jx;  // the PACK step is done
+      }
+      if (pre && sl_pre.parts_done != 0) {
+        if (sl_pre.parts_done != P || sl_pre.folded != pack_in_plan) return fail(QIP_ERR_DEVICE, "internal: overlapped exchange left incomplete");
+        // every slice is on its way: the receive buffer becomes the shard (builder.rs:514 analogue), the EXCHANGE step is done
+        if (pack_in_plan) {
+          std::swap(s->cur, d->third);  // cur was the packed copy (folded_swap): it is what the communication stream still reads
+        } else {
+          std::swap(s->cur, s->alt);
+          std::swap(s->owns_cur, s->owns_alt);
+        }
+        d->rx_pending = true;
+        d->rx_slices = P;
+        d->rx_packed = packed;  // (after the exchange the packed positions ARE the shard's positions)
+        d->rx_after = after_ok;
+        d->stats.remaps += 1;
+        d->stats.remaps_overlapped += 1;
+        d->stats.slices_overlapped += P;
+        d->stats.bytes_sent += chunk_bytes * (uint64_t)(d->pl.world - 1);
+        jx = ex_at + 1;
       }
       // payload buffers of this batch die with `m`: the uploads above were staged by the runtime before returning
       i = jx;
       continue;
     }
+    QCHK(dist_wait_rx(d));  // (a gather or an exchange of its own reads the whole shard)
     if (!s->layout.empty()) QCHK(state_settle(s));  // (a shard with a persistent relabelling: the caller's order first)
     if (steps[i].kind == qipd::Step::PACK) {
       QCHK(ensure_alt(s));
@@ -945,8 +1222,20 @@ extern "C" int qip_hip_dist_destroy(qip_hip_dist* d) try {
     if (d->rccl->d_red) (void)hipFree(d->rccl->d_red);
     delete d->rccl;
   }
+  if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
+  for (hipEvent_t e : d->ev_pre) (void)hipEventDestroy(e);
+  for (hipEvent_t e : d->ev_rx) (void)hipEventDestroy(e);
+  if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
+  if (d->third) (void)hipFree(d->third);
   if (d->shard) qip_hip_state_destroy(d->shard);
   delete d;
+  return QIP_OK;
+} QIP_CATCH_ALL
+
+extern "C" int qip_hip_dist_set_slice_transport(qip_hip_dist* d, qip_hip_all_to_all_slice_fn fn) try {
+  if (!d) return fail(QIP_ERR_INVALID, "null dist handle");
+  if (d->rccl) return fail(QIP_ERR_UNSUPPORTED, "the built-in RCCL transport brings its own slice entry point");
+  d->slice_fn = fn;
   return QIP_OK;
 } QIP_CATCH_ALL
 
@@ -983,6 +1272,7 @@ extern "C" int qip_hip_dist_create(uint32_t n, int dtype, int device, int rank, 
     d->transport.ctx = d->rccl;
     d->transport.all_to_all = qipd::rccl_all_to_all;
     d->transport.all_reduce_sum = qipd::rccl_all_reduce;
+    d->slice_fn = qipd::rccl_all_to_all_slice;
   }
   // the ranks of one node share its CPUs: the run-time compiler's automatic helper-process count is divided by the world size
   if (world > 1 && (int64_t)world > g_jit_world) g_jit_world = world;
@@ -1032,6 +1322,11 @@ extern "C" int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t
     if (value < 16 || (value & 15)) return fail(QIP_ERR_INVALID, "piece_bytes must be a positive multiple of 16");
     if (!d->rccl) return fail(QIP_ERR_UNSUPPORTED, "piece_bytes belongs to the built-in RCCL transport; this handle uses caller-supplied callbacks");
     d->rccl->piece_bytes = (uint64_t)value;
+    return QIP_OK;
+  }
+  if (key && !strcmp(key, "dist_overlap")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(QIP_ERR_INVALID, "dist_overlap is 0, 1 (off), 2, 4 or 8 slices");
+    d->overlap = value;
     return QIP_OK;
   }
   return qip_hip_state_set_option(d->shard, key, value);
@@ -1266,6 +1561,72 @@ extern "C" int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, ui
   }
   return qip_hip_state_measure_state(s, loc_q.data(), (uint32_t)loc_q.size(), lm, p);
 } QIP_CATCH_ALL
+
+// Host-only (r5): which remaps of this rank's plan the overlapped exchange (option "dist_overlap") serves when the local batches run as
+// tile sweeps in scheduler mode `tile_mode` — decided by the very functions the executor uses (edge_tile, choose_slices).
+extern "C" const char* qip_hip_dist_debug_overlap(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count, int tile_mode,
+                                                  int slices) {
+  static thread_local std::string json;
+  try {
+    if (count && !ops) return fail(QIP_ERR_INVALID, "null op array"), nullptr;
+    if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype), nullptr;
+    if (slices != 2 && slices != 4 && slices != 8) return fail(QIP_ERR_INVALID, "slices is 2, 4 or 8"), nullptr;
+    qipd::DistPlanner pl;
+    if (pl.init(n, dtype, rank, world) != QIP_OK) return nullptr;
+    std::vector<qipd::Step> steps;
+    if (pl.plan(ops, count, &steps) != QIP_OK) return nullptr;
+    const uint32_t g = pl.g, L = pl.L;
+    uint32_t pbits = 0;
+    while ((1 << pbits) < slices) ++pbits;
+    json = "{\"n\":" + std::to_string(n) + ",\"slices\":" + std::to_string(slices) + ",\"remaps\":[";
+    bool first_entry = true;
+    auto batch = [&](size_t from, qipd::Marshalled* m) {
+      std::vector<const qip_op*> ptrs;
+      size_t t = from;
+      for (; t < steps.size() && steps[t].kind == qipd::Step::LOCAL; ++t) ptrs.push_back(qipd::marshal_one(dtype, *steps[t].op, m));
+      for (const qip_op* p : ptrs) m->flat.push_back(*p);
+      return t;
+    };
+    size_t i = 0;
+    while (i < steps.size()) {
+      qipd::Marshalled m;
+      const size_t jx = steps[i].kind == qipd::Step::LOCAL ? batch(i, &m) : i;
+      const size_t ex_at = jx + (jx < steps.size() && steps[jx].kind == qipd::Step::PACK ? 1 : 0);
+      if (!(ex_at < steps.size() && steps[ex_at].kind == qipd::Step::EXCHANGE)) {
+        i = jx > i ? jx : i + 1;
+        continue;
+      }
+      const bool pack = ex_at != jx;
+      bool pre = world > 1 && !m.flat.empty() && (!pack || g_dist_fold_pack), after = false;
+      std::vector<uint32_t> packed;
+      size_t sweeps = 0;
+      if (pre) {
+        const EdgeTile e_pre = edge_tile(dtype, L, m.flat.data(), m.flat.size(), tile_mode, true);
+        sweeps = e_pre.nsteps;
+        qipd::Marshalled m2;
+        batch(ex_at + 1, &m2);
+        EdgeTile e_post;
+        if (!m2.flat.empty()) e_post = edge_tile(dtype, L, m2.flat.data(), m2.flat.size(), tile_mode, false);
+        pre = choose_slices(L, g, pbits, pack ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, &packed, &after);
+        // (a one-sweep batch between two overlapped remaps serves the later one: apply_ops_tiled settles the first-step request unsliced)
+      }
+      json += std::string(first_entry ? "" : ",") + "{\"pack\":" + (pack ? "1" : "0") + ",\"before\":" + (pre ? "1" : "0") + ",\"after\":" +
+              (pre && after ? "1" : "0") + ",\"batch_sweeps_before\":" + std::to_string(sweeps) + ",\"positions\":[";
+      for (size_t j = 0; j < packed.size(); ++j) json += (j ? "," : "") + std::to_string(packed[j]);
+      json += "]}";
+      first_entry = false;
+      i = ex_at + 1;
+    }
+    json += "]}";
+    return json.c_str();
+  } catch (const std::exception& e) {
+    fail(QIP_ERR_INVALID, "internal error: %s", e.what());
+    return nullptr;
+  } catch (...) {
+    fail(QIP_ERR_INVALID, "internal error");
+    return nullptr;
+  }
+}
 
 extern "C" const char* qip_hip_dist_debug_plan(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count) {
   static thread_local std::string json;

@@ -179,6 +179,14 @@ struct qip_hip_state {
   // last step runs, `fold_done` reports that a sweep took the request.
   const TileStorePerm* fold_request = nullptr;
   bool fold_now = false, fold_done = false;
+  // r5: the FIRST / LAST tile sweep of a batch launched in 2^nbits parts, part k = the blocks whose base index reads k at `pos`
+  // (amplitude-index positions that are not tile positions of that sweep) — the sharded state's exchange is cut into the same
+  // slices and overlaps with these sweeps (qip_dist.hip): `after(k)` runs once part k is enqueued (the slice can be sent as soon
+  // as it is stored), `before(k)` before part k is enqueued (it may start as soon as the slice has landed).  `fallback` runs
+  // instead when the step turns out not to be sliceable.  See TileSlicing.
+  struct TileSlicing* slice_first = nullptr;
+  struct TileSlicing* slice_last = nullptr;
+  struct TileSlicing* slice_now = nullptr;
   int64_t swap_single = 0;  // 1 = one sweep per transposition (tuning aid; default groups them, k_swapn)
   int64_t tile_jit = 0;     // 1 (= 2) = tile segments run as kernels compiled at run time for that segment's STRUCTURE (hiprtc,
                             // cached), its numbers are kernel data (angles can change without recompiling); 3 = numbers as literals
@@ -208,6 +216,16 @@ struct qip_hip_state {
   double prof_bytes[KC_COUNT] = {0};
 };
 
+struct TileSlicing {
+  uint32_t nbits = 0;
+  uint32_t pos[3] = {0, 0, 0};  // slice k has bit j of k at amplitude-index position pos[j] (the state's order when the step runs)
+  bool need_fold = false;       // only valid together with a packed store (the slices are slices of the PACKED buffer)
+  bool in_place_only = false;   // never together with a packed store (the second buffer may still be read by the exchange)
+  std::function<int(uint32_t, bool)> before, after;  // (k, folding)
+  std::function<int()> fallback;                     // the step ran unsliced
+  uint32_t parts_done = 0;
+  bool folded = false;
+};
 int ensure_arena(qip_hip_state* s, size_t bytes);
 int ensure_partial(qip_hip_state* s, size_t count);
 int ensure_alt(qip_hip_state* s);

@@ -1764,11 +1764,24 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
         case TOP_DIAG_RUN: {
           const TileDiagItem<T>* ip = diag + g.nz;
           const TileDiagItem<T>* const iend = ip + g.b1;
+#ifndef QIP_DIAG_PREFETCH
+#define QIP_DIAG_PREFETCH 1
+#endif
+#ifndef QIP_DIAG_ASM
+#define QIP_DIAG_ASM 1
+#endif
+#if QIP_DIAG_PREFETCH
           TileDiagItem<T> nxt = *ip;  // wave-uniform: scalar loads, one step ahead of their use
+#endif
           for (; ip != iend;) {
+#if QIP_DIAG_PREFETCH
             const TileDiagItem<T> it = nxt;
             ++ip;
             if (ip != iend) nxt = *ip;
+#else
+            const TileDiagItem<T> it = *ip;
+            ++ip;
+#endif
             if ((base & it.omask) != it.oval) continue;
             A f = it.f1;
             const uint32_t selp = it.emask_sel >> 24;
@@ -1786,7 +1799,11 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
             for (int i = 0; i < 8; ++i)
               if ((it.emask_sel >> i) & 1u) {
                 QIP_KEEP_BRANCH();
+#if QIP_DIAG_ASM
                 cscale_inplace(f, e[i]);
+#else
+                e[i] = cmul(f, e[i]);
+#endif
               }
           }
           break;

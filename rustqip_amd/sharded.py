@@ -52,7 +52,32 @@ class HostStagedTransport:
         self._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self._a2a = _ffi.A2A_FN(self._all_to_all)
         self._ars = _ffi.ARS_FN(self._all_reduce)
+        self._a2as = _ffi.A2AS_FN(self._all_to_all_slice)
+        self.slices_moved = 0
         self.struct = _ffi.QipTransport(None, self._a2a, self._ars)
+
+    def _all_to_all_slice(self, ctx, send, recv, chunk_bytes, slice_off, slice_bytes, stream):
+        """qip_hip_all_to_all_slice_fn (r5): bytes [slice_off, slice_off + slice_bytes) of every chunk.  `stream` is the handle's
+        communication stream, which already waits for the sweep part that stores this slice; host-staged, so the host waits too
+        (no overlap here — the product transport is RCCL — but the same slices, the same buffers, the same order)."""
+        try:
+            world = self.dist.get_world_size()
+            chunk, off, ln = int(chunk_bytes), int(slice_off), int(slice_bytes)
+            h_send = self.torch.empty(ln * world, dtype=self.torch.uint8)
+            h_recv = self.torch.empty(ln * world, dtype=self.torch.uint8)
+            if self._hip.hipStreamSynchronize(C.c_void_p(stream)) != 0:
+                return 1
+            for c in range(world):
+                if self._hip.hipMemcpy(C.c_void_p(h_send.data_ptr() + c * ln), C.c_void_p(send + c * chunk + off), ln, 2) != 0:
+                    return 1
+            self.dist.all_to_all_single(h_recv, h_send)
+            for c in range(world):
+                if self._hip.hipMemcpy(C.c_void_p(recv + c * chunk + off), C.c_void_p(h_recv.data_ptr() + c * ln), ln, 1) != 0:
+                    return 1
+            self.slices_moved += 1
+            return 0
+        except Exception:  # noqa: BLE001
+            return 1
 
     def _all_to_all(self, ctx, send, recv, chunk_bytes, stream):
         try:
@@ -148,6 +173,7 @@ class DistState:
         if host_staged:
             _check(_ffi.lib.qip_hip_dist_create(self.n, self.dtype, device, self.rank, self.world, None,
                                                 C.byref(self._transport.struct), C.byref(self._h)))
+            _check(_ffi.lib.qip_hip_dist_set_slice_transport(self._h, self._transport._a2as))
         else:
             uid = _broadcast_unique_id(dist, self.rank)
             _check(_ffi.lib.qip_hip_dist_create(self.n, self.dtype, device, self.rank, self.world, uid, None, C.byref(self._h)))
@@ -302,7 +328,10 @@ class DistState:
                 # read back from the communicator (ncclCommCount / ncclCommUserRank); 0 / -1 with caller-supplied callbacks
                 "rccl_ranks": int(st.rccl_ranks), "rccl_rank": int(st.rccl_rank),
                 "pieces_sent": int(st.pieces_sent), "piece_bytes": int(st.piece_bytes),
-                "packs_via_permute_bits": int(st.packs_via_permute), "packs_folded": int(st.packs_folded)}
+                "packs_via_permute_bits": int(st.packs_via_permute), "packs_folded": int(st.packs_folded),
+                # r5, option "dist_overlap": remaps whose exchange ran in slices beside the sweep before them / also the one after
+                "remaps_overlapped": int(st.remaps_overlapped), "remaps_overlapped_after": int(st.remaps_overlapped_after),
+                "slices_overlapped": int(st.slices_overlapped)}
 
     def set_profile(self, v: int) -> None:
         self.shard.set_option("profile", int(v))
@@ -343,6 +372,16 @@ def debug_plan(n: int, rank: int, world: int, ops: Sequence[MatrixOp], dtype: in
     cops = [op.to_c(dtype) for op in ops]
     arr = (_ffi.QipOp * len(cops))(*cops)
     txt = _ffi.lib.qip_hip_dist_debug_plan(n, dtype, rank, world, arr, len(cops))
+    if not txt:
+        raise CircuitError(_ffi.last_error())
+    return json.loads(txt.decode() if isinstance(txt, bytes) else txt)
+
+
+def debug_overlap(n: int, rank: int, world: int, ops: Sequence[MatrixOp], tile_mode: int = 1, slices: int = 4, dtype: int = _ffi.QIP_C64) -> dict:
+    """qip_hip_dist_debug_overlap parsed: which remaps of `rank`'s plan the overlapped exchange serves (host only)"""
+    cops = [op.to_c(dtype) for op in ops]
+    arr = (_ffi.QipOp * len(cops))(*cops)
+    txt = _ffi.lib.qip_hip_dist_debug_overlap(n, dtype, rank, world, arr, len(cops), tile_mode, slices)
     if not txt:
         raise CircuitError(_ffi.last_error())
     return json.loads(txt.decode() if isinstance(txt, bytes) else txt)

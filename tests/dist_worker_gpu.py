@@ -200,6 +200,45 @@ def main():
         assert folded_total >= 2, folded_total
         if rank == 0:
             print("ok fold: the remap's gather rides in the preceding tile sweep")
+    if not use_nccl and world > 1:
+        # r5, option dist_overlap: the exchange in P slices on the communication stream, each sent as soon as the LAST tile sweep
+        # before the remap (launched in P parts, packed store included) has stored it, the FIRST sweep after the remap starting
+        # on each slice as soon as it has landed.  Same amplitudes bit for bit as the serial remap, for every form of the sweeps.
+        n = 21
+        x = circuits.random_state(n, n)
+        ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 200, seed=13) + circuits.c4_clifford_t(n, 120, seed=7) + circuits.c3_qft(n)[:150]
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        base = None
+        seen_overlap = seen_after = 0
+        for slices, tile, jit, wide in ((0, 1, 0, 0), (4, 1, 0, 0), (2, 1, 0, 0), (4, 1, 1, 0), (4, 1, 1, 1), (8, 2, 1, 0)):
+            so = DistState(n, dist, 0, host_staged=True)
+            so.set_option("tile", tile)
+            so.set_option("tile_jit", jit)
+            so.set_option("tile_wide", wide)
+            so.set_option("dist_overlap", slices)
+            so.upload_global(x)
+            so.apply_ops(ops)
+            got = so.download_global()
+            cs = so.comm_stats()
+            assert abs(so.norm_sqr() - 1) < 1e-12
+            so.close()
+            assert np.max(np.abs(got - want)) < 1e-12, (slices, tile, jit, wide)
+            if slices == 0:
+                base = (got, cs)
+                assert cs["remaps_overlapped"] == 0 and cs["slices_overlapped"] == 0
+            else:
+                if tile == 1:
+                    assert np.array_equal(got, base[0]), (slices, tile, jit, wide)  # IEEE-equal sweeps: the very same bits
+                assert cs["remaps"] == base[1]["remaps"], (cs, base[1])
+                assert cs["slices_overlapped"] == slices * cs["remaps_overlapped"]
+                seen_overlap += cs["remaps_overlapped"]
+                seen_after += cs["remaps_overlapped_after"]
+            if rank == 0:
+                print(f"overlap slices={slices} tile={tile} jit={jit} wide={wide}: remaps={cs['remaps']} overlapped={cs['remaps_overlapped']} "
+                      f"(after too: {cs['remaps_overlapped_after']}) folded={cs['packs_folded']} pack_sweeps={cs['pack_sweeps']}")
+        assert seen_overlap >= 3 and seen_after >= 1, (seen_overlap, seen_after)
+        if rank == 0:
+            print("ok overlap: the exchange in slices beside the neighbouring tile sweeps changes nothing")
     # f32 shards
     n = 11
     xf = circuits.random_state(n, 3, np.complex64)

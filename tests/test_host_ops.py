@@ -348,7 +348,10 @@ int main(void) {
   qip_op inner = {QIP_OP_MATRIX, 1, idx + 1, 0, x, 0, 0, 0, 0};
   qip_op cnot = {QIP_OP_CONTROL, 2, idx, 1, 0, 0, 0, 0, &inner};
   qip_hip_transport t = {0, a2a, ars};
-  qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0, 0, -1, 0, 0, 0, 0};
+  qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0, 0, -1, 0, 0, 0, 0, 0, 0, 0};
+  qip_hip_jit_counters jc = {0, 0, 0, 0, 0, 0, 0.0, 0.0, 0, 0};
+  qip_hip_all_to_all_slice_fn slice = 0;
+  (void)jc; (void)slice;
   char id[QIP_HIP_UNIQUE_ID_BYTES];
   (void)id; (void)st; (void)t;
   return qip_hip_validate_op(2, &cnot) == QIP_OK && qip_hip_abi_version() >= 1 ? 0 : 1;

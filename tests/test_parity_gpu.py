@@ -1856,6 +1856,7 @@ def test_sharded_virtual_shards_on_one_gpu():
     assert out.count("ok n=") == 4
     assert "ok fault: a failed exchange poisons the handle" in out and "ok pieces:" in out
     assert "ok fold: the remap's gather rides in the preceding tile sweep" in out
+    assert "ok overlap: the exchange in slices beside the neighbouring tile sweeps changes nothing" in out
     assert out.count("samples differ from the reference's scan") == 2
 
 
