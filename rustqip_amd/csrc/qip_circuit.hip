@@ -1834,16 +1834,40 @@ static int debug_jit_t(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
     for (uint64_t i : st.ops) seg.push_back(&items[i]);
     std::vector<T> params;  // mode bit 6: parametrised (numbers as kernel data)
     std::string src;
+    // mode bit 11 (2048): the SLICED + PACKED-STORE variant the sharded state's overlapped exchange launches (r5) — one position that is
+    // not a tile position is gathered on top, another cuts the sweep in two parts: generated and compiled here, run on the GPU by
+    // tests/dist_worker_gpu.py
+    auto variant = [&](const std::vector<uint32_t>& high, uint32_t p5, Ins* ins, TileStorePerm* sp) {
+      std::vector<uint32_t> spare;
+      for (uint32_t pp = n; pp-- > 12u && spare.size() < 2;)
+        if (!tile_is_low(pp, p5) && std::find(high.begin(), high.end(), pp) == high.end()) spare.push_back(pp);
+      if (spare.size() < 2) return false;
+      memset(sp, 0, sizeof *sp);
+      sp->g = 1;
+      sp->Lg = n - 1;
+      sp->sel[0] = sp->sel_desc[0] = spare[0];
+      std::vector<uint32_t> opened = high;
+      for (uint32_t& o : opened)
+        if (o == 5u) o = p5;
+      opened.push_back(spare[1]);
+      *ins = make_ins(opened, 0);
+      return true;
+    };
     if ((mode & 16) && n > (uint32_t)kWideBits) {  // mode bit 4: wide tiles
       WidePlan<T> wplan;
       QCHK(build_wide_segment<T>(n, seg, st.high, &wplan, mode & 3));
-      src = wide_jit_source<T>(wplan, tile_ins(wplan.high, wplan.p5), true, (mode & 64) ? &params : nullptr, (mode & 128) != 0, (mode & 256) != 0, (mode & 512) != 0);
+      Ins ins = tile_ins(wplan.high, wplan.p5);
+      TileStorePerm sp;
+      const bool var = (mode & 2048) && variant(wplan.high, wplan.p5, &ins, &sp);
+      src = wide_jit_source<T>(wplan, ins, true, (mode & 64) ? &params : nullptr, (mode & 128) != 0, (mode & 256) != 0, (mode & 512) != 0, var, var ? &sp : nullptr);
       if (src.empty()) return fail(QIP_ERR_INVALID, "internal: wide segment source");
     } else {
       TileSegmentPlan<T> plan;
       QCHK(build_tile_segment<T>(n, true, seg, st.high, &plan, mode & 3));
       Ins ins = tile_ins(plan.high, plan.p5);
-      src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0);  // bit 7: merged diagonal runs
+      TileStorePerm sp;
+      const bool var = (mode & 2048) && variant(plan.high, plan.p5, &ins, &sp);
+      src = tile_jit_source<T>(plan, ins, true, 0, (mode & 64) ? &params : nullptr, (mode & 128) != 0, var ? &sp : nullptr, var);  // bit 7: merged diagonal runs
     }
     if (*nseg == 0 && first) *first = src;
     *nseg += 1;

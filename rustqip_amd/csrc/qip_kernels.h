@@ -1764,8 +1764,11 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
         case TOP_DIAG_RUN: {
           const TileDiagItem<T>* ip = diag + g.nz;
           const TileDiagItem<T>* const iend = ip + g.b1;
+// Measured on MI355X (QFT n = 30 through the interpreter, tools/build_variants.sh A/B inside one GPU call, two rounds each, ms):
+//   per-gate code paths 125.3 | runs 90.3 | + in-place products (QIP_DIAG_ASM) 85.1 | + descriptor one step ahead (QIP_DIAG_PREFETCH) 96.4
+// the prefetch costs more scalar moves than the load latency it hides (five waves per SIMD already cover it): off.
 #ifndef QIP_DIAG_PREFETCH
-#define QIP_DIAG_PREFETCH 1
+#define QIP_DIAG_PREFETCH 0
 #endif
 #ifndef QIP_DIAG_ASM
 #define QIP_DIAG_ASM 1

@@ -172,11 +172,14 @@ def main():
             q.set_global_option("dist_fold_pack", fold)
             # (1, 0, 3): shards with a PERSISTENT relabelling (tile_relabel = 3): a batch may leave its qubits relabelled, and then
             # its last sweep addresses other qubits than the gather request names — no fold, the layout is settled first
-            for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3)):
+            # (1, 1, 16): run-time-compiled WIDE segments (r5: they have the packed store too)
+            for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3), (1, 1, 16)):
                 sf = DistState(n, dist, 0, host_staged=True)
                 sf.set_option("tile", tile)
                 sf.set_option("tile_jit", jit)
-                if relabel:
+                if relabel == 16:
+                    sf.set_option("tile_wide", 1)
+                elif relabel:
                     sf.set_option("tile_relabel", relabel)
                 sf.upload_global(x)
                 sf.apply_ops(ops)
@@ -185,7 +188,7 @@ def main():
         q.set_global_option("dist_fold_pack", 1)
         want = O.apply_ops_in_place(n, ops, x.copy())
         folded_total = 0
-        for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3)):
+        for tile, jit, relabel in ((1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 0, 3), (1, 1, 16)):
             a, sa = res[(0, tile, jit, relabel)]
             b, sb = res[(1, tile, jit, relabel)]
             assert np.array_equal(a, b), (tile, jit, relabel)
@@ -193,6 +196,8 @@ def main():
             assert np.max(np.abs(b - want)) < 1e-12
             assert sa["packs_folded"] == 0 and sb["remaps"] == sa["remaps"]
             assert sb["pack_sweeps"] + sb["packs_folded"] == sa["pack_sweeps"], (sa, sb)
+            if relabel == 16:
+                assert sb["packs_folded"] >= 1, sb  # the wide sweeps really took the gather
             if not relabel:
                 folded_total += sb["packs_folded"]
             if rank == 0:

@@ -561,6 +561,25 @@ def test_parametrised_segments_keep_their_source_when_angles_change():
     assert d["segments"] >= 1 and d["code_bytes"] > 0
 
 
+def test_sliced_and_packed_store_variants_of_segments_compile():
+    """r5: the variants of a run-time-compiled segment that the sharded state's overlapped exchange launches — the sweep in parts
+    (an extra opened position + the part's bits as a kernel argument) with the remap's gather riding in the store (dst_of) — for
+    11-bit and wide tiles, both precisions: generated and compiled for gfx950 here, run on the GPU by tests/dist_worker_gpu.py."""
+    from rustqip_amd.ops import debug_tile_jit
+
+    n = 24  # (room for two positions above 11 outside a 13-bit tile)
+    ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 60, seed=5)
+    for dtype in (_ffi.QIP_C64, _ffi.QIP_C32):
+        for mode in (1 | 64, 1 | 16 | 64 | 256, 2 | 16 | 32 | 64 | 128):
+            plain = debug_tile_jit(n, ops, mode, dtype)
+            var = debug_tile_jit(n, ops, mode | 2048, dtype)
+            src = var["first_source"]
+            src = src if isinstance(src, str) else src.decode()
+            assert var["segments"] == plain["segments"] and var["code_bytes"] > 0
+            assert "slice_or" in src and "dst_of(" in src and "A* __restrict__ out" in src
+            assert "slice_or" not in (plain["first_source"] if isinstance(plain["first_source"], str) else plain["first_source"].decode())
+
+
 def test_merged_diagonal_runs_are_generated_and_compile():
     """option tile_merge (host hook: mode bit 7, with tile = 2 and contraction bit 5): a run of >= 3 consecutive diagonal gates
     becomes products of factors per element set — outside-the-tile controls stay uniform branches, lane-bit conditions selects —
