@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline steps (profiling passes: no parity check, mixed circuit, extras or CPU baseline)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--dist-overlap", type=int, default=0,
+                    help="N > 1 only: add legs with the exchange cut into this many slices and overlapped with the neighbouring tile sweeps "
+                         "(option dist_overlap; off by default: RCCL on two streams has never run on real multi-GPU hardware here)")
     return ap.parse_args()
 
 
@@ -658,6 +661,20 @@ def main():
         # ... and the 1e-12 mode over wide tiles, with fused multiply-adds and merged runs of diagonal gates (without relabelling:
         # seven positions per sweep leave little for it to win, and its in-tile swaps and closing sweep cost more than they save)
         extras["tiled_mode2_jit_fma_merge_wide"] = leg(ops_mixed, tile=2, tile_jit=1, tile_fma=1, tile_merge=1, tile_wide=1)
+        # r5: a PROGRAM created on a tile = 1 state (option tile_auto): compiled once at creation, replayed as one hipGraph
+        try:
+            st.set_option("tile", 1)
+            t_c = time.perf_counter()
+            prog = st.compile_program(ops_mixed)
+            create_s = time.perf_counter() - t_c
+            dt, ts = median_time(prog.run, st.sync)
+            extras["program_tile_auto"] = {"gates": len(ops_mixed), "ms": 1e3 * dt, "gates_per_s": len(ops_mixed) / dt, "is_graph": bool(prog.is_graph),
+                                           "create_s_once": create_s, "reps": REPS}
+            prog.close()
+        except Exception as exc:  # noqa: BLE001
+            extras["program_tile_auto"] = {"error": repr(exc)}
+        finally:
+            st.set_option("tile", 0)
         # the other BASELINE configs on the same resident state size
         for cname, cops in (("configs2_qft_n%d" % n, circuits.c3_qft(n)),
                             ("configs3_clifford_t_n%d" % n, circuits.c4_clifford_t(n, args.gates, seed=32)),
@@ -722,8 +739,11 @@ def main():
         # BASELINE configs[3] (Clifford+T) and configs[4] (Grover iteration, plain and dense k = 3) on the sharded
         # state, and the headline circuit with the local runs between remaps applied as tile sweeps (tile = 1:
         # IEEE-equal).  Guarded: nothing here can take the bench line down.  Median of REPS, max over ranks.
-        def dist_leg(cops, tile=0):
+        def dist_leg(cops, tile=0, jit=0, wide=0, overlap=0):
             st.set_option("tile", tile)
+            st.set_option("tile_jit", jit)
+            st.set_option("tile_wide", wide)
+            st.set_option("dist_overlap", overlap)
             cc = st.compile_ops(cops)
             st.apply_compiled(cc)
             sync()
@@ -736,7 +756,8 @@ def main():
                 sync()
                 barrier()
                 ts.append(max_over_ranks(time.perf_counter() - t))
-            st.set_option("tile", 0)
+            for key in ("tile", "tile_jit", "tile_wide", "dist_overlap"):
+                st.set_option(key, 0)
             dt = statistics.median(ts)
             cs = st.comm_stats()
             return {"ops": len(cops), "ms": 1e3 * dt, "ops_per_s": len(cops) / dt, "algorithmic_GBps": circuit_bytes(q, n, cops) / dt / 1e9,
@@ -748,7 +769,16 @@ def main():
                                 ("configs1_mixed_n%d" % n, ops_mixed, {}),
                                 ("configs3_clifford_t_tiled_mode1", circuits.c4_clifford_t(n, args.gates, seed=32), {"tile": 1}),
                                 ("configs1_mixed_tiled_mode1", ops_mixed, {"tile": 1}),
-                                ("headline_tiled_mode1", ops, {"tile": 1})):
+                                ("headline_tiled_mode1", ops, {"tile": 1}),
+                                # r5: the compiled sweeps (wide tiles; the remap's gather rides in their store) ...
+                                ("configs1_mixed_tiled_mode1_jit_wide", ops_mixed, {"tile": 1, "jit": 1, "wide": 1}),
+                                ("configs3_clifford_t_tiled_mode1_jit_wide", circuits.c4_clifford_t(n, args.gates, seed=32), {"tile": 1, "jit": 1, "wide": 1})) + (
+                                # ... and, on request, with the exchange overlapped with the sweeps either side of it
+                                (("configs1_mixed_tiled_mode1_jit_wide_overlap", ops_mixed, {"tile": 1, "jit": 1, "wide": 1, "overlap": args.dist_overlap}),
+                                 ("configs3_clifford_t_tiled_mode1_jit_wide_overlap", circuits.c4_clifford_t(n, args.gates, seed=32),
+                                  {"tile": 1, "jit": 1, "wide": 1, "overlap": args.dist_overlap}),
+                                 ("configs1_mixed_tiled_mode1_overlap", ops_mixed, {"tile": 1, "overlap": args.dist_overlap}))
+                                if args.dist_overlap >= 2 else ()):
             try:
                 extras[cname] = dist_leg(cops, **kw)
             except Exception as exc:  # noqa: BLE001

@@ -2106,7 +2106,8 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     // (T on bit 0: 41 %, CNOT with its control inside a row: 40 %, profiles/r02_line_bits.md).  When such a gate and its
     // neighbour fit one tile they go as ONE two-item tile sweep (interpreter kernel, circuit order: the same unfused arithmetic
     // per amplitude, IEEE-equal to the two launches) — the neighbour rides for free.  Everything else stays one launch per gate.
-    if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_staging) {
+    if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_staging && !s->force_generic &&
+        !g_force_generic) {
       // What the two launches move, in sweeps of the whole vector: a gate's algorithmic share, doubled for every selector
       // inside a wave row (whole lines / rows travel whichever half is needed), at most 1.  One two-item sweep moves 1 (and runs
       // a little slower than a bare sweep): worth it from 1.3 — T on a low bit + H (1 + 1), CNOT with a low control + anything;
@@ -2137,7 +2138,16 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
           const int64_t tile = s->tile, jit = s->tile_jit, relabel = s->tile_relabel, wide = s->tile_wide;
           s->tile = 1;
           s->tile_jit = s->tile_relabel = s->tile_wide = 0;
+          // the sharded state's requests belong to the BATCH's last step, not to this pair's: a pair in the middle of the batch
+          // must not store packed (the gates after it would run on the packed buffer) — only the batch's last two ops may
+          const TileStorePerm* fold_req = s->fold_request;
+          TileSlicing *sf = s->slice_first, *sl = s->slice_last;
+          if (i + 2 < count) s->fold_request = nullptr;
+          s->slice_first = s->slice_last = nullptr;
           const int rc = s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, &ops[i], 2, false) : apply_ops_tiled<float>(s, &ops[i], 2, false);
+          s->fold_request = fold_req;
+          s->slice_first = sf;
+          s->slice_last = sl;
           s->tile = tile;
           s->tile_jit = jit;
           s->tile_relabel = relabel;

@@ -136,7 +136,7 @@ def main():
                 st4.upload_global(x)
                 st4.apply_ops(ops[:30])
                 srng = np.random.default_rng(99)
-                samples = srng.uniform(0, 1, 2000)
+                samples = srng.uniform(0, 1, 400 if use_nccl else 2000)  # (the world-1 RCCL plumbing run repeats this for the transport only)
                 idx = [3, 0, n - 1, 6]
                 differ = sum(1 for r_u in samples if st4.soft_measure(idx, float(r_u) if rank == 0 else 0.5) != O.soft_measure(n, idx, ref, float(r_u)))
                 assert differ == 0, (name, differ)
@@ -205,6 +205,26 @@ def main():
         assert folded_total >= 2, folded_total
         if rank == 0:
             print("ok fold: the remap's gather rides in the preceding tile sweep")
+    if not use_nccl and world > 1:
+        # r5: gate-by-gate shards at a size where pair_floor is active (n_local = 22): a pair in the MIDDLE of a batch that a remap
+        # follows must not take the batch's packed-store request (found by the n = 29 twin: the gates after it ran on the packed buffer)
+        n = 23
+        x = circuits.random_state(n, n)
+        ops = circuits.h_layer(n)[:6] + circuits.c4_clifford_t(n, 90, seed=32) + circuits.c2_random_circuit(n, 60, seed=28)
+        want = O.apply_ops_in_place(n, ops, x.copy())
+        got = {}
+        for pair in (1, 0):
+            sp = DistState(n, dist, 0, host_staged=True)
+            sp.set_option("pair_floor", pair)
+            sp.set_option("profile", 1)
+            sp.upload_global(x)
+            sp.apply_ops(ops)
+            got[pair] = (sp.download_global(), sum(v["launches"] for v in sp.take_profile().values()), sp.comm_stats())
+            sp.close()
+        assert np.array_equal(got[1][0], got[0][0]) and np.max(np.abs(got[1][0] - want)) < 1e-12
+        assert got[1][1] < got[0][1] and got[1][2]["remaps"] >= 1, (got[1][1], got[0][1], got[1][2])
+        if rank == 0:
+            print(f"ok pair_floor on shards: {got[0][1]} -> {got[1][1]} launches, {got[1][2]['remaps']} remaps, folded {got[1][2]['packs_folded']}")
     if not use_nccl and world > 1:
         # r5, option dist_overlap: the exchange in P slices on the communication stream, each sent as soon as the LAST tile sweep
         # before the remap (launched in P parts, packed store included) has stored it, the FIRST sweep after the remap starting

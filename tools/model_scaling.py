@@ -2,69 +2,107 @@
 """The MODELLED weak-scaling table of DESIGN.md §5 (no multi-GPU hardware has been available in any round: this is host arithmetic
 over the planner's own plans, not a measurement).
 
-  python tools/model_scaling.py [n_local]        (default 30: the bench's shard size)
+  python tools/model_scaling.py [bench line file = newest profiles/r0*_bench_n1.json] [n_local = 30]
 
-Per circuit and world size N: the planner's plan for rank 0 at n = n_local + log2 N (qip_hip_dist_debug_plan: exchanges, gathers,
-which of them select a position inside a wave row), priced with the plan's own model (exchange = shard / N bytes over each of the N - 1
-xGMI links at 153 GB/s; a gather that cannot ride in a tile sweep = one copy of the shard at 6.2 TB/s) and the MEASURED single-GPU time
-per gate at this shard size (profiles/r04_bench_n1.json: gate by gate 5.27 ms; as tile sweeps from the bench line's medians)."""
+Per circuit and world size N: the planner's plan for rank 0 at n = n_local + log2 N (qip_hip_dist_debug_plan: exchanges, gathers, which of
+them select a position inside a wave row), priced with the plan's own model (exchange = shard / N bytes over each of the N - 1 xGMI links at
+153 GB/s; a gather that cannot ride in a tile sweep = one copy of the shard at 6.2 TB/s) and the MEASURED single-GPU times of the bench line.
+
+r5: the overlapped exchange (option "dist_overlap", P = 4 slices).  Which remaps it serves comes from the library's own predicate
+(qip_hip_dist_debug_overlap: the edge sweeps of the two batches scheduled as apply_ops schedules them); a served remap is priced as a
+pipeline of P slices through (sweep part, exchange slice[, sweep part]):  T = a + b [+ a'] + (P - 1) * max(a, b[, a']),  a = C * S / P,
+b = E / P, with S the mode's measured time per sweep, E the modelled exchange and C = 1.25 for the HBM bandwidth the exchange takes from a
+sweep that runs beside it (N = 8: 2 x 7 x 153 GB/s = 2.1 of ~6.5 TB/s).  What the overlap hides is (S + E [+ S']) - T."""
+import glob
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import rustqip_amd as q  # noqa: E402
+import rustqip_amd as q  # noqa: E402,F401
 from rustqip_amd import circuits, sharded  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, CONTENTION = 4, 1.25
+
+
+def hidden(E, S, before, after):
+    """milliseconds of (sweep + exchange [+ sweep]) that the P-slice pipeline hides"""
+    if not before:
+        return 0.0
+    a, b = CONTENTION * S / P, E / P
+    if after:
+        return max(0.0, (S + E + S) - (a + b + a + (P - 1) * max(a, b)))
+    return max(0.0, (S + E) - (a + b + (P - 1) * max(a, b)))
 
 
 def main():
-    nl = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")).read().strip().splitlines()[-1])
+    args = [a for a in sys.argv[1:]]
+    path = args[0] if args and os.path.exists(args[0]) else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_n1.json")))[-1]
+    nl = int(args[-1]) if args and args[-1].isdigit() else 30
+    line = json.loads(open(path).read().strip().splitlines()[-1])
     ex = line["extras"]
-    t_gate = line["ms_per_step"] / line["config"]["gates_per_step"]  # ms per gate, gate by gate, n = 30
-    # measured single-GPU medians (ms) for the whole circuit: gate by gate / best IEEE-equal sweeps / best 1e-12 sweeps
-    single = {
-        "headline (256 H / X / Rz)": (line["ms_per_step"], None, None),
-        "configs[1] mix (256)": (line["mixed_circuit"]["ms"], ex["tiled_mode1_jit_wide_relabel"]["ms"], ex["tiled_mode2_jit_fma_merge_wide"]["ms"]),
-        "Clifford+T (256)": (ex["configs3_clifford_t_n30"]["ms"], ex["configs3_clifford_t_n30"]["tile1_jit_wide_relabel"]["ms"],
-                             ex["configs3_clifford_t_n30"]["tile2_jit_fma_merge_wide_relabel"]["ms"]),
-        "Grover iteration (182)": (ex["configs4_grover_iteration_n30"]["ms"], ex["configs4_grover_iteration_n30"]["tile1_jit_wide"]["ms"], None),
-        "QFT (480)": (ex["configs2_qft_n30"]["ms"], ex["configs2_qft_n30"]["tile1_jit"]["ms"], ex["configs2_qft_n30"]["tile2_jit_fma_merge_wide"]["ms"]),
+    t_gate = line["ms_per_step"] / line["config"]["gates_per_step"]
+
+    def leg(d):  # (ms of the whole circuit, ms per sweep)
+        return (d["ms"], d["ms"] / max(1, d["launches"])) if d else None
+
+    c3, c4g, qft = ex["configs3_clifford_t_n30"], ex["configs4_grover_iteration_n30"], ex["configs2_qft_n30"]
+    # mode -> (scheduler mode bits for the predicate, {circuit: (ms, ms per sweep)})
+    modes = {
+        "interpreter sweeps (tile = 1)": (1, {"configs[1] mix (256)": leg(ex["tiled_mode1"]), "Clifford+T (256)": leg(c3["tile1"]),
+                                              "Grover iteration (182)": leg(c4g["tile1"]), "QFT (480)": leg(qft["tile1"])}),
+        "compiled wide sweeps (tile = 1, IEEE-equal)": (1 | 16, {"configs[1] mix (256)": leg(ex["tiled_mode1_jit_wide"]), "Clifford+T (256)": leg(c3.get("tile1_jit_wide")),
+                                                                   "Grover iteration (182)": leg(c4g.get("tile1_jit_wide")), "QFT (480)": leg(qft["tile1_jit"])}),
+        "compiled wide sweeps, 1e-12 mode (tile = 2, fma, merged runs)": (2 | 16, {"configs[1] mix (256)": leg(ex["tiled_mode2_jit_fma_merge_wide"]),
+                                                                                     "Clifford+T (256)": leg(c3.get("tile2_jit_fma_merge_wide_relabel")),
+                                                                                     "QFT (480)": leg(qft.get("tile2_jit_fma_merge_wide"))}),
     }
-    print(f"MODEL, not a measurement.  n_local = {nl}; single-GPU times measured at n = 30 (profiles/r04_bench_n1.json, {t_gate:.2f} ms per gate gate by gate).\n")
-    print("| circuit | N | n | exchanges | gathers (from a row position) | modelled comm ms | gate by gate: ms, per-GPU efficiency | IEEE-equal sweeps | 1e-12 sweeps |")
-    print("|---|---|---|---|---|---|---|---|---|")
-    for name, gen in (("headline (256 H / X / Rz)", lambda n: circuits.c2_random_circuit(n, 256, seed=28, single_only=True)),
-                      ("configs[1] mix (256)", lambda n: circuits.c2_random_circuit(n, 256, seed=28)),
-                      ("Clifford+T (256)", lambda n: circuits.c4_clifford_t(n, 256, seed=32)),
-                      ("Grover iteration (182)", lambda n: circuits.c5_grover_iteration(n)),
-                      ("QFT (480)", lambda n: circuits.c3_qft(n))):
+    gens = (("headline (256 H / X / Rz)", lambda n: circuits.c2_random_circuit(n, 256, seed=28, single_only=True)),
+            ("configs[1] mix (256)", lambda n: circuits.c2_random_circuit(n, 256, seed=28)),
+            ("Clifford+T (256)", lambda n: circuits.c4_clifford_t(n, 256, seed=32)),
+            ("Grover iteration (182)", lambda n: circuits.c5_grover_iteration(n)),
+            ("QFT (480)", lambda n: circuits.c3_qft(n)))
+    gbg = {"headline (256 H / X / Rz)": line["ms_per_step"], "configs[1] mix (256)": line["mixed_circuit"]["ms"], "Clifford+T (256)": c3["ms"],
+           "Grover iteration (182)": c4g["ms"], "QFT (480)": qft["ms"]}
+    print(f"MODEL, not a measurement.  n_local = {nl}; single-GPU times measured at n = 30 ({os.path.relpath(path, ROOT)}, {t_gate:.2f} ms per gate gate by gate).  "
+          f"Overlap: P = {P} slices, contention factor {CONTENTION}.\n")
+    print("### gate by gate (the BASELINE metric)\n")
+    print("| circuit | N | n | exchanges | gathers (from a row position) | modelled comm ms | ms, per-GPU efficiency |")
+    print("|---|---|---|---|---|---|---|")
+    plans = {}
+    for name, gen in gens:
         for world in (1, 2, 4, 8):
             g = world.bit_length() - 1
             n = nl + g
-            ops = gen(n)
             if world == 1:
-                exch = packs = rows = 0
-                comm_lo = comm_hi = 0.0
+                m = {"exchanges": 0, "packs": 0, "packs_from_row_positions": 0, "exchange_ms": 0.0, "pack_ms": 0.0}
             else:
-                m = sharded.debug_plan(n, 0, world, ops)["model"]
-                exch, packs, rows = m["exchanges"], m["packs"], m["packs_from_row_positions"]
-                comm_lo = exch * m["exchange_ms"] + rows * m["pack_ms"]   # every other gather rides in a tile sweep
-                comm_hi = exch * m["exchange_ms"] + packs * m["pack_ms"]  # gate by gate: every gather is a sweep of its own
-            # local work per rank does not grow with N in this weak scaling (a gate sweeps the 2^n_local shard; gates whose
-            # exchanging target sits on a rank bit are served after a remap)
-            cols = []
-            for idx, comm in ((0, comm_hi), (1, comm_lo), (2, comm_lo)):
-                t1 = single[name][idx]
-                if t1 is None:
-                    cols.append("—")
-                else:
-                    # n_local = 30 scaling of the measured n = 30 time: proportional to the shard size
-                    t1s = t1 * (2.0 ** (nl - 30))
-                    cols.append(f"{t1s + comm:.0f} ms, {100 * t1s / (t1s + comm):.0f} %")
-            print(f"| {name} | {world} | {n} | {exch} | {packs} ({rows}) | {comm_lo:.0f} – {comm_hi:.0f} | " + " | ".join(cols) + " |")
+                m = sharded.debug_plan(n, 0, world, gen(n))["model"]
+            plans[(name, world)] = m
+            comm = m["exchanges"] * m["exchange_ms"] + m["packs"] * m["pack_ms"]  # gate by gate: every gather is a sweep of its own
+            t1 = gbg[name] * 2.0 ** (nl - 30)
+            print(f"| {name} | {world} | {n} | {m['exchanges']} | {m['packs']} ({m['packs_from_row_positions']}) | {comm:.0f} | {t1 + comm:.0f} ms, {100 * t1 / (t1 + comm):.0f} % |")
+    for mode_name, (bits, single) in modes.items():
+        print(f"\n### {mode_name}\n")
+        print("| circuit | N | remaps: served before / also after | comm ms serial (gathers ride in the sweeps) | ms, per-GPU efficiency serial | hidden by the overlap, ms | ms, per-GPU efficiency overlapped |")
+        print("|---|---|---|---|---|---|---|")
+        for name, gen in gens:
+            if not single.get(name):
+                continue
+            t1, per_sweep = single[name]
+            t1 *= 2.0 ** (nl - 30)
+            per_sweep *= 2.0 ** (nl - 30)
+            for world in (2, 4, 8):
+                g = world.bit_length() - 1
+                n = nl + g
+                m = plans[(name, world)]
+                ov = sharded.debug_overlap(n, 0, world, gen(n), bits, P)["remaps"]
+                comm = m["exchanges"] * m["exchange_ms"] + m["packs_from_row_positions"] * m["pack_ms"]
+                hid = sum(hidden(m["exchange_ms"], per_sweep, r["before"], r["after"]) for r in ov)
+                nb, na = sum(r["before"] for r in ov), sum(r["after"] for r in ov)
+                print(f"| {name} | {world} | {nb} / {na} of {len(ov)} | {comm:.0f} | {t1 + comm:.0f} ms, {100 * t1 / (t1 + comm):.0f} % | {hid:.0f} | "
+                      f"{t1 + comm - hid:.0f} ms, {100 * t1 / (t1 + comm - hid):.0f} % |")
 
 
 if __name__ == "__main__":
