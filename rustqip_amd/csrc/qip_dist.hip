@@ -700,8 +700,14 @@ static int rccl_all_to_all_slice(void* ctx, const void* send, void* recv, uint64
   HIPCHK(hipMemcpyAsync((char*)recv + own, (const char*)send + own, slice_bytes, hipMemcpyDeviceToDevice, st));
   return QIP_OK;
 }
+static int rccl_all_reduce_on(RcclTransport* t, double* values, uint64_t count, hipStream_t stream);
 static int rccl_all_reduce(void* ctx, double* values, uint64_t count) {
   RcclTransport* t = static_cast<RcclTransport*>(ctx);
+  return rccl_all_reduce_on(t, values, count, t->stream);
+}
+// (r5: the ranks' agreement on where an overlapped exchange is cut runs on the COMMUNICATION stream — waiting for it does not drain
+// the sweeps queued on the shard's stream)
+static int rccl_all_reduce_on(RcclTransport* t, double* values, uint64_t count, hipStream_t stream) {
   if (count == 0) return QIP_OK;
   if (count > t->red_cap) {
     if (t->d_red) HIPCHK(hipFree(t->d_red));
@@ -711,10 +717,10 @@ static int rccl_all_reduce(void* ctx, double* values, uint64_t count) {
     HIPCHK(hipMalloc((void**)&t->d_red, cap * sizeof(double)));
     t->red_cap = cap;
   }
-  HIPCHK(hipMemcpyAsync(t->d_red, values, count * sizeof(double), hipMemcpyHostToDevice, t->stream));
-  NCHK(g_rccl.AllReduce(t->d_red, t->d_red, count, Rccl::kFloat64, Rccl::kSum, t->comm, t->stream));
-  HIPCHK(hipMemcpyAsync(values, t->d_red, count * sizeof(double), hipMemcpyDeviceToHost, t->stream));
-  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipMemcpyAsync(t->d_red, values, count * sizeof(double), hipMemcpyHostToDevice, stream));
+  NCHK(g_rccl.AllReduce(t->d_red, t->d_red, count, Rccl::kFloat64, Rccl::kSum, t->comm, stream));
+  HIPCHK(hipMemcpyAsync(values, t->d_red, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
   return QIP_OK;
 }
 
@@ -776,6 +782,7 @@ struct qip_hip_dist {
   void* third = nullptr;
   bool rx_pending = false;  // slices of the last overlapped exchange may still be landing: the shard's stream has not waited yet
   uint32_t rx_slices = 0;
+  size_t agreed_for = (size_t)-1;   // index of the EXCHANGE step the ranks have already voted on (dist_run_steps)
   std::vector<uint32_t> rx_packed;  // the positions that cut it
   bool rx_after = false;            // ... and whether the first sweep of the next batch can take them
 };
@@ -843,26 +850,38 @@ static uint32_t packed_to_source(uint32_t q, const std::vector<uint32_t>* sel, u
   return L;
 }
 static bool in_tile(const EdgeTile& e, uint32_t pos) { return tile_is_low(pos, e.p5) || std::find(e.high.begin(), e.high.end(), pos) != e.high.end(); }
-// *packed = the p chosen packed positions (ascending); *after = the sweep after the remap can take them too
-static bool choose_slices(uint32_t L, uint32_t g, uint32_t pbits, const std::vector<uint32_t>* pack_sel, const EdgeTile& pre, const EdgeTile* post,
-                          std::vector<uint32_t>* packed, bool* after) {
-  packed->clear();
-  *after = false;
-  if (!pre.segment || !pre.ends_in_callers_order || L < g + pbits + kSliceMinPos) return false;
-  if (pack_sel) {  // the gather must ride in that sweep: a packed store, which needs the rows to survive
-    for (uint32_t p : *pack_sel)
-      if (tile_is_low(p, pre.p5)) return false;
-  }
+// EVERY rank must cut a remap's exchange at the same positions, but the ranks' local batches differ (a control on a rank bit drops
+// the op on half of them), so their edge sweeps hold different tiles: each rank states what it could live with — v[0] = "my last
+// sweep can run in parts at all", v[1 + q] = "packed position q is outside its tile", v[1 + W + q] = "... and outside my first
+// sweep's after the remap" — the vectors are summed over the ranks, and the choice is made from what ALL of them accept (identical
+// input on every rank, so identical output): the p highest positions, preferring those the sweeps after the remap accept too.
+static void slice_votes(uint32_t L, uint32_t g, const std::vector<uint32_t>* pack_sel, const EdgeTile& pre, const EdgeTile* post, bool usable,
+                        std::vector<double>* v) {
+  const uint32_t W = L - g;
+  v->assign(1 + 2 * (size_t)W, 0.0);
+  bool ok = usable && pre.segment && pre.ends_in_callers_order;
+  if (ok && pack_sel)  // the gather must ride in that sweep: a packed store, which needs the rows to survive
+    for (uint32_t p : *pack_sel) ok = ok && !tile_is_low(p, pre.p5);
+  if (!ok) return;
+  (*v)[0] = 1.0;
   const bool post_usable = post && post->segment && post->starts_plain;
-  for (int pass = post_usable ? 0 : 1; pass < 2 && packed->size() < pbits; ++pass) {
+  for (uint32_t q = kSliceMinPos; q < W; ++q) {
+    const uint32_t src = packed_to_source(q, pack_sel, L);
+    if (src >= L || src <= 11u || in_tile(pre, src)) continue;
+    (*v)[1 + q] = 1.0;
+    if (post_usable && !in_tile(*post, q)) (*v)[1 + W + q] = 1.0;
+  }
+}
+// from the summed votes of `world` ranks: *packed = the p chosen packed positions (ascending); false = this remap runs the serial way
+static bool choose_slices(uint32_t L, uint32_t g, uint32_t pbits, const std::vector<double>& sum, int world, std::vector<uint32_t>* packed) {
+  const uint32_t W = L - g;
+  packed->clear();
+  if (sum.size() != 1 + 2 * (size_t)W || sum[0] != (double)world || W < pbits + kSliceMinPos) return false;
+  for (int pass = 0; pass < 2; ++pass) {
     packed->clear();
-    for (uint32_t q = L - g; q-- > kSliceMinPos && packed->size() < pbits;) {
-      const uint32_t src = packed_to_source(q, pack_sel, L);
-      if (src >= L || src <= 11u || in_tile(pre, src)) continue;
-      if (pass == 0 && (q <= 11u || in_tile(*post, q))) continue;
-      packed->push_back(q);
-    }
-    if (packed->size() == pbits) *after = pass == 0;
+    for (uint32_t q = W; q-- > kSliceMinPos && packed->size() < pbits;)
+      if (sum[1 + (pass == 0 ? W : 0) + q] == (double)world) packed->push_back(q);
+    if (packed->size() == pbits) break;
   }
   if (packed->size() != pbits) return false;
   std::sort(packed->begin(), packed->end());
@@ -931,6 +950,17 @@ static int dist_wait_rx(qip_hip_dist* d) {
   d->rx_pending = false;
   return QIP_OK;
 }
+// sum over the ranks, without touching the shard's stream (RCCL: on the communication stream; a caller's transport: its host reduction)
+static int dist_overlap_setup(qip_hip_dist* d, uint32_t P);
+static int dist_agree(qip_hip_dist* d, std::vector<double>* v) {
+  if (d->rccl) {
+    QCHK(dist_overlap_setup(d, 1));
+    return qipd::rccl_all_reduce_on(d->rccl, v->data(), v->size(), d->comm_stream);
+  }
+  const int rc = d->transport.all_reduce_sum(d->transport.ctx, v->data(), v->size());
+  if (rc != 0) return g_last_error.empty() ? fail(QIP_ERR_DEVICE, "transport all_reduce_sum failed with status %d", rc) : QIP_ERR_DEVICE;
+  return QIP_OK;
+}
 static int dist_overlap_setup(qip_hip_dist* d, uint32_t P) {
   if (!d->comm_stream) HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
   while (d->ev_pre.size() < P) {
@@ -945,6 +975,7 @@ static int dist_overlap_setup(qip_hip_dist* d, uint32_t P) {
 
 static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps);
 static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
+  d->agreed_for = (size_t)-1;
   const int rc = dist_run_steps_inner(d, steps);
   // whatever comes next on the shard's stream (a download, a measurement, the next batch) is ordered after the last slices
   if (rc == QIP_OK) return dist_wait_rx(d);
@@ -1011,20 +1042,28 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
       bool pre = P && ex_next && s->layout.empty() && (!pack_in_plan || pack_next);
       const uint64_t chunk_bytes = (s->namps >> g) * s->amp_bytes;
       std::vector<uint32_t> packed;
-      bool after_ok = false;
-      if (pre) {
-        // the sweeps either side, as apply_ops will schedule them (the batch after the remap is marshalled early for that)
-        const int mode = state_tile_mode(s);
-        const EdgeTile e_pre = edge_tile(s->dtype, L, m.flat.data(), m.flat.size(), mode, true);
-        EdgeTile e_post;
-        qipd::Marshalled m2;
-        {
+      if (P && ex_next) {
+        // the sweeps either side, as apply_ops will schedule them (the batch after the remap is marshalled early for that); the vote
+        // is cast for EVERY exchange of the plan, feasible here or not: the agreement is a collective
+        std::vector<double> votes;
+        if (pre) {
+          const int mode = state_tile_mode(s);
+          const EdgeTile e_pre = edge_tile(s->dtype, L, m.flat.data(), m.flat.size(), mode, true);
+          EdgeTile e_post;
+          qipd::Marshalled m2;
           std::vector<const qip_op*> p2;
           for (size_t t = ex_at + 1; t < steps.size() && steps[t].kind == qipd::Step::LOCAL; ++t) p2.push_back(qipd::marshal_one(s->dtype, *steps[t].op, &m2));
           for (const qip_op* q2 : p2) m2.flat.push_back(*q2);
           if (!m2.flat.empty()) e_post = edge_tile(s->dtype, L, m2.flat.data(), m2.flat.size(), mode, false);
+          slice_votes(L, g, pack_in_plan ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, true, &votes);
+        } else {
+          slice_votes(L, g, nullptr, EdgeTile(), nullptr, false, &votes);
         }
-        pre = choose_slices(L, g, pbits, pack_in_plan ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, &packed, &after_ok);
+        QCHK(dist_agree(d, &votes));
+        d->agreed_for = ex_at;
+        pre = pre && choose_slices(L, g, pbits, votes, d->pl.world, &packed);
+      } else {
+        pre = false;
       }
       if (pre) {
         if (dist_overlap_setup(d, P) != QIP_OK) pre = false;
@@ -1085,7 +1124,7 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
         d->rx_pending = true;
         d->rx_slices = P;
         d->rx_packed = packed;  // (after the exchange the packed positions ARE the shard's positions)
-        d->rx_after = after_ok;
+        d->rx_after = true;     // (whether the next batch's first sweep can take them is decided when it is launched: fallback = full wait)
         d->stats.remaps += 1;
         d->stats.remaps_overlapped += 1;
         d->stats.slices_overlapped += P;
@@ -1097,6 +1136,16 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
       continue;
     }
     QCHK(dist_wait_rx(d));  // (a gather or an exchange of its own reads the whole shard)
+    {  // an exchange this rank reaches without a local batch before it: the other ranks may have one and vote — vote "no" with them
+      const size_t ex_here = i + (steps[i].kind == qipd::Step::PACK ? 1 : 0);
+      const bool votes_held = d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && !s->force_generic && !g_force_generic;
+      if (votes_held && ex_here < steps.size() && steps[ex_here].kind == qipd::Step::EXCHANGE && d->agreed_for != ex_here) {
+        std::vector<double> votes;
+        slice_votes(L, g, nullptr, EdgeTile(), nullptr, false, &votes);
+        QCHK(dist_agree(d, &votes));
+        d->agreed_for = ex_here;
+      }
+    }
     if (!s->layout.empty()) QCHK(state_settle(s));  // (a shard with a persistent relabelling: the caller's order first)
     if (steps[i].kind == qipd::Step::PACK) {
       QCHK(ensure_alt(s));
@@ -1562,8 +1611,9 @@ extern "C" int qip_hip_dist_measure(qip_hip_dist* d, const uint64_t* indices, ui
   return qip_hip_state_measure_state(s, loc_q.data(), (uint32_t)loc_q.size(), lm, p);
 } QIP_CATCH_ALL
 
-// Host-only (r5): which remaps of this rank's plan the overlapped exchange (option "dist_overlap") serves when the local batches run as
-// tile sweeps in scheduler mode `tile_mode` — decided by the very functions the executor uses (edge_tile, choose_slices).
+// Host-only (r5): which remaps the overlapped exchange (option "dist_overlap") serves when the local batches run as tile sweeps in
+// scheduler mode `tile_mode` — decided by the very functions the executor uses (edge_tile, slice_votes, choose_slices), with the votes of
+// ALL ranks (each rank's plan is made here, their votes summed as the executor's all-reduce sums them); "after" is `rank`'s own view.
 extern "C" const char* qip_hip_dist_debug_overlap(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count, int tile_mode,
                                                   int slices) {
   static thread_local std::string json;
@@ -1571,51 +1621,77 @@ extern "C" const char* qip_hip_dist_debug_overlap(uint32_t n, int dtype, int ran
     if (count && !ops) return fail(QIP_ERR_INVALID, "null op array"), nullptr;
     if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype), nullptr;
     if (slices != 2 && slices != 4 && slices != 8) return fail(QIP_ERR_INVALID, "slices is 2, 4 or 8"), nullptr;
-    qipd::DistPlanner pl;
-    if (pl.init(n, dtype, rank, world) != QIP_OK) return nullptr;
-    std::vector<qipd::Step> steps;
-    if (pl.plan(ops, count, &steps) != QIP_OK) return nullptr;
-    const uint32_t g = pl.g, L = pl.L;
+    if (rank < 0 || rank >= world) return fail(QIP_ERR_INVALID, "rank %d of %d", rank, world), nullptr;
     uint32_t pbits = 0;
     while ((1 << pbits) < slices) ++pbits;
-    json = "{\"n\":" + std::to_string(n) + ",\"slices\":" + std::to_string(slices) + ",\"remaps\":[";
-    bool first_entry = true;
-    auto batch = [&](size_t from, qipd::Marshalled* m) {
-      std::vector<const qip_op*> ptrs;
-      size_t t = from;
-      for (; t < steps.size() && steps[t].kind == qipd::Step::LOCAL; ++t) ptrs.push_back(qipd::marshal_one(dtype, *steps[t].op, m));
-      for (const qip_op* p : ptrs) m->flat.push_back(*p);
-      return t;
-    };
-    size_t i = 0;
-    while (i < steps.size()) {
-      qipd::Marshalled m;
-      const size_t jx = steps[i].kind == qipd::Step::LOCAL ? batch(i, &m) : i;
-      const size_t ex_at = jx + (jx < steps.size() && steps[jx].kind == qipd::Step::PACK ? 1 : 0);
-      if (!(ex_at < steps.size() && steps[ex_at].kind == qipd::Step::EXCHANGE)) {
-        i = jx > i ? jx : i + 1;
-        continue;
-      }
-      const bool pack = ex_at != jx;
-      bool pre = world > 1 && !m.flat.empty() && (!pack || g_dist_fold_pack), after = false;
-      std::vector<uint32_t> packed;
+    struct Remap {
+      bool pack = false, after = false;
       size_t sweeps = 0;
-      if (pre) {
-        const EdgeTile e_pre = edge_tile(dtype, L, m.flat.data(), m.flat.size(), tile_mode, true);
-        sweeps = e_pre.nsteps;
+      std::vector<double> votes;
+    };
+    std::vector<std::vector<Remap>> per_rank((size_t)world);
+    uint32_t g = 0, L = 0;
+    for (int r = 0; r < world; ++r) {
+      qipd::DistPlanner pl;
+      if (pl.init(n, dtype, r, world) != QIP_OK) return nullptr;
+      std::vector<qipd::Step> steps;
+      if (pl.plan(ops, count, &steps) != QIP_OK) return nullptr;
+      g = pl.g;
+      L = pl.L;
+      auto batch = [&](size_t from, qipd::Marshalled* m) {
+        std::vector<const qip_op*> ptrs;
+        size_t t = from;
+        for (; t < steps.size() && steps[t].kind == qipd::Step::LOCAL; ++t) ptrs.push_back(qipd::marshal_one(dtype, *steps[t].op, m));
+        for (const qip_op* p : ptrs) m->flat.push_back(*p);
+        return t;
+      };
+      size_t i = 0;
+      while (i < steps.size()) {
+        qipd::Marshalled m;
+        const size_t jx = steps[i].kind == qipd::Step::LOCAL ? batch(i, &m) : i;
+        const size_t ex_at = jx + (jx < steps.size() && steps[jx].kind == qipd::Step::PACK ? 1 : 0);
+        if (!(ex_at < steps.size() && steps[ex_at].kind == qipd::Step::EXCHANGE)) {
+          i = jx > i ? jx : i + 1;
+          continue;
+        }
+        Remap rm;
+        rm.pack = ex_at != jx;
+        const bool usable = world > 1 && !m.flat.empty() && (!rm.pack || g_dist_fold_pack);
+        EdgeTile e_pre, e_post;
         qipd::Marshalled m2;
         batch(ex_at + 1, &m2);
-        EdgeTile e_post;
-        if (!m2.flat.empty()) e_post = edge_tile(dtype, L, m2.flat.data(), m2.flat.size(), tile_mode, false);
-        pre = choose_slices(L, g, pbits, pack ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, &packed, &after);
-        // (a one-sweep batch between two overlapped remaps serves the later one: apply_ops_tiled settles the first-step request unsliced)
+        if (usable) {
+          e_pre = edge_tile(dtype, L, m.flat.data(), m.flat.size(), tile_mode, true);
+          rm.sweeps = e_pre.nsteps;
+          if (!m2.flat.empty()) e_post = edge_tile(dtype, L, m2.flat.data(), m2.flat.size(), tile_mode, false);
+        }
+        slice_votes(L, g, rm.pack ? &steps[jx].sel : nullptr, e_pre, m2.flat.empty() ? nullptr : &e_post, usable, &rm.votes);
+        rm.after = !m2.flat.empty() && e_post.segment && e_post.starts_plain;  // (refined below against the chosen positions)
+        if (rm.after) {
+          // remember the first sweep's tile through the votes' second half: position q acceptable <=> votes[1 + W + q] on THIS rank
+        }
+        per_rank[(size_t)r].push_back(std::move(rm));
+        i = ex_at + 1;
       }
-      json += std::string(first_entry ? "" : ",") + "{\"pack\":" + (pack ? "1" : "0") + ",\"before\":" + (pre ? "1" : "0") + ",\"after\":" +
-              (pre && after ? "1" : "0") + ",\"batch_sweeps_before\":" + std::to_string(sweeps) + ",\"positions\":[";
+    }
+    json = "{\"n\":" + std::to_string(n) + ",\"slices\":" + std::to_string(slices) + ",\"remaps\":[";
+    const size_t nrem = per_rank[0].size();
+    for (int r = 1; r < world; ++r)
+      if (per_rank[(size_t)r].size() != nrem) return fail(QIP_ERR_INVALID, "internal: the ranks plan different numbers of exchanges"), nullptr;
+    const uint32_t W = L - g;
+    for (size_t k = 0; k < nrem; ++k) {
+      std::vector<double> sum(1 + 2 * (size_t)W, 0.0);
+      for (int r = 0; r < world; ++r)
+        for (size_t t = 0; t < sum.size(); ++t) sum[t] += per_rank[(size_t)r][k].votes[t];
+      std::vector<uint32_t> packed;
+      const bool pre = choose_slices(L, g, pbits, sum, world, &packed);
+      const Remap& mine = per_rank[(size_t)rank][k];
+      bool after = pre && mine.after;
+      for (uint32_t q : packed) after = after && mine.votes[1 + W + q] == 1.0;
+      json += std::string(k ? "," : "") + "{\"pack\":" + (mine.pack ? "1" : "0") + ",\"before\":" + (pre ? "1" : "0") + ",\"after\":" + (after ? "1" : "0") +
+              ",\"batch_sweeps_before\":" + std::to_string(mine.sweeps) + ",\"positions\":[";
       for (size_t j = 0; j < packed.size(); ++j) json += (j ? "," : "") + std::to_string(packed[j]);
       json += "]}";
-      first_entry = false;
-      i = ex_at + 1;
     }
     json += "]}";
     return json.c_str();

@@ -40,7 +40,8 @@ def main():
     assert np.array_equal(sm.download(1 << 9, 1 << 10), full[1 << 9:(1 << 9) + (1 << 10)])
     sm.close()
 
-    res = W.sharded_parity(lambda: DistState(n, dist, 0, np.complex128, host_staged=True), dist, n, O, q, circuits, gates=256)
+    # (--quick: the gate-by-gate legs at a third of their length — the tile-sweep legs, the remaps and the k_permute_bits pack stay as they are)
+    res = W.sharded_parity(lambda: DistState(n, dist, 0, np.complex128, host_staged=True), dist, n, O, q, circuits, gates=256, quick="--quick" in sys.argv)
     if rank == 0:
         brief = {k: v for k, v in res.items() if k != "legs"}
         brief["legs"] = {k: {kk: vv for kk, vv in v.items() if kk in ("gates", "rows", "max_abs_delta", "bit_equal", "ok", "comm", "skipped",

@@ -152,3 +152,36 @@ def test_logical_windows_of_a_sharded_state_index_math():
                 assert np.all(owner == rank) and np.array_equal(local, np.arange(1 << L, dtype=np.uint64))
                 seen[logical.astype(np.int64)] += 1
             assert np.all(seen == 1)  # the shards tile the logical index space exactly once
+
+
+def test_overlapped_exchange_is_cut_where_every_rank_can_cut_it():
+    """r5, option dist_overlap: the positions that cut a remap's exchange into slices must be the same on every rank although the ranks'
+    local batches — and so the tiles of their edge sweeps — differ.  The host-only predicate (qip_hip_dist_debug_overlap: every rank's plan,
+    votes summed as the executor's all-reduce sums them) answers alike whichever rank asks, picks positions below the chunk-selecting ones
+    and above the rows, and `after` implies `before`.  Bench circuits at bench size (n = 32 / 33 over 4 / 8 ranks): the model's input."""
+    import math
+
+    from rustqip_amd import circuits, sharded
+
+    seen_before = seen_after = 0
+    for name, gen in (("c2", lambda n: circuits.c2_random_circuit(n, 256, seed=28)), ("c4", lambda n: circuits.c4_clifford_t(n, 256, seed=32)),
+                      ("grover", lambda n: circuits.c5_grover_iteration(n)), ("qft", lambda n: circuits.c3_qft(n))):
+        for world, slices, mode in ((4, 4, 1), (8, 4, 1 | 16), (2, 2, 2), (8, 8, 1)):
+            g = int(math.log2(world))
+            n = 30 + g
+            ops = gen(n)
+            plans = [sharded.debug_overlap(n, r, world, ops, mode, slices)["remaps"] for r in ((0, world - 1) if world > 2 else (0, 1))]
+            exchanges = sharded.debug_plan(n, 0, world, ops)["model"]["exchanges"]
+            assert all(len(p) == exchanges for p in plans), (name, world)
+            for a, b in zip(plans[0], plans[1]):
+                assert (a["pack"], a["before"], a["positions"]) == (b["pack"], b["before"], b["positions"]), (name, world, a, b)
+                if a["before"]:
+                    assert len(a["positions"]) == int(math.log2(slices)) and a["positions"] == sorted(set(a["positions"]))
+                    assert all(12 <= q < n - 2 * g for q in a["positions"]), a
+                else:
+                    assert not a["positions"] and not a["after"]
+                for x in (a, b):
+                    assert not x["after"] or x["before"]
+                seen_before += a["before"]
+                seen_after += a["after"]
+    assert seen_before >= 12 and seen_after >= 8, (seen_before, seen_after)

@@ -1157,8 +1157,8 @@ def test_gate_by_gate_pairs_a_line_floor_gate_with_its_neighbour(O):
         nb = int(rng.integers(0, 4))
         low.append([q.make_matrix_op([hi[2]], circuits.H), q.make_matrix_op([hi[3]], circuits.rz(0.3)),
                     q.make_control_op([hi[4]], q.make_matrix_op([hi[5]], circuits.X)), q.make_swap_op([hi[6]], [hi[7]])][nb])
-    for name, ops in (("c4", circuits.c4_clifford_t(n, 200, seed=32)), ("c2", circuits.c2_random_circuit(n, 200, seed=28)), ("low", low),
-                      ("qft", circuits.c3_qft(n)[:150])):
+    for name, ops in (("c4", circuits.c4_clifford_t(n, 120, seed=32)), ("c2", circuits.c2_random_circuit(n, 120, seed=28)), ("low", low),
+                      ("qft", circuits.c3_qft(n)[:100])):
         res = {}
         for pair in (0, 1):
             with q.HipState(n) as st:
@@ -1869,7 +1869,7 @@ def test_sharded_state_against_the_oracle_at_bench_shard_size():
     amplitudes after every step and closed-form marginals through qip_hip_dist_measure_probs (tests/dist_worker_parity_gpu.py)."""
     import json
 
-    out = _run_dist(2, ["--n-local", "28"], worker="dist_worker_parity_gpu.py", timeout=1800)
+    out = _run_dist(2, ["--n-local", "28", "--quick"], worker="dist_worker_parity_gpu.py", timeout=1800)
     res = json.loads([l for l in out.splitlines() if l.startswith("SHARDED_PARITY ")][-1][len("SHARDED_PARITY "):])
     assert res["all_legs_ok"] and res["n"] == 29 and res["rows_checked"] >= 10**7, res
     assert res["whole_vector"]["amplitudes_not_equal_in_IEEE_legs"] == 0 and res["bit_equal"], res
@@ -2133,7 +2133,7 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
 
     ops0, vecs = W.product_state_ops(n, seed=n)
     c2s = circuits.c2_random_circuit(n, 16, seed=28, single_only=True)
-    c2 = circuits.c2_random_circuit(n, 5 * 24, seed=29)
+    c2 = circuits.c2_random_circuit(n, 5 * 16, seed=29)
     with q.HipState(n) as st:
         st.init_basis(0)
         st.apply_ops(ops0)
@@ -2160,12 +2160,12 @@ def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
                 twin.resync()
             return r
 
-        leg(c2[:24], True, tile=1)
-        leg(c2[24:48], True, tile=1, tile_jit=1)
-        leg(c2[48:72], True, tile=1, tile_jit=1, tile_relabel=2)
-        leg(c2[72:96], False, tile=2, tile_jit=1)
-        leg(c2[96:120], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
-        leg(circuits.c2_random_circuit(n, 24, seed=31), False, fuse=5)
+        leg(c2[:16], True, tile=1)
+        leg(c2[16:32], True, tile=1, tile_jit=1)
+        leg(c2[32:48], True, tile=1, tile_jit=1, tile_relabel=2)
+        leg(c2[48:64], False, tile=2, tile_jit=1)
+        leg(c2[64:80], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c2_random_circuit(n, 16, seed=31), False, fuse=5)
         r = leg(circuits.c3_qft(n)[:120], True, max_len=160, tile=1, tile_jit=1)  # the first 5 H with all their controlled phases
         assert r["steps"] <= 2  # chunks as large as the timed segments (5-6 H and their controlled phases each)
         leg(circuits.c4_clifford_t(n, 48, seed=32), True, tile=1, tile_jit=1)

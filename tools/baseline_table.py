@@ -125,4 +125,36 @@ for f in sorted(glob.glob(P(f"{tag}_bench_2ranks_one_gpu*.json"))):
     for k, v in b.get("extras", {}).items():
         if isinstance(v, dict) and "comm_over_reps" in v:
             c = v["comm_over_reps"]
-            L(f"  * `{k}`: {c['remaps']} remaps, {c['pack_sweeps']} gathers as sweeps of their own, **{c['packs_folded']} folded into the preceding tile sweep**, {c['packs_via_permute_bits']} through `k_permute_bits`")
+            L(f"  * `{k}`: {c['remaps']} remaps, {c['pack_sweeps']} gathers as sweeps of their own, **{c['packs_folded']} folded into the preceding tile sweep**, {c['packs_via_permute_bits']} through `k_permute_bits`"
+              + (f"; exchange overlapped with the sweep before it in {c['remaps_overlapped']} remaps ({c['remaps_overlapped_after']} also with the sweep after), {c['slices_overlapped']} slices" if c.get("remaps_overlapped") is not None and "overlap" in k else ""))
+
+
+# ---- r5: who compiled what, programs, and the reference's own bench shapes (printed after the main table) -------------------------------
+if "jit" in ex:
+    j = ex["jit"]
+    L("")
+    L(f"Run-time compiler over the whole bench process (`extras.jit`): {j['kernels_resident_total']} segment kernels made resident, {j['compiled']} compiled "
+      f"({j['compiled_by_helpers']} of them in {j['helper_processes']} helper processes, at most {j['procs']} side by side), {j['disk_hits']} loaded from the disk cache, "
+      f"{j['compile_ms'] / 1e3:.1f} s of wall time compiling in all, {j['disk_load_ms']:.1f} ms reading code objects.")
+    for key in ("tiled_mode1_jit",):
+        if "compile_ms_once" in ex.get(key, {}):
+            L(f"`{key}`: {ex[key]['segments_compiled']} segments, `compile_ms_once` = {ex[key]['compile_ms_once']:.0f} ms.")
+    sp = P(f"{tag}_bench_n1_second_process.json")
+    if os.path.exists(sp):
+        b2 = json.loads(open(sp).read().strip().splitlines()[-1])
+        j2 = b2["extras"]["jit"]
+        L(f"A SECOND process of the same command on the same box (`{os.path.basename(sp)}`): {j2['compiled']} compiled, {j2['disk_hits']} loaded from disk in {j2['disk_load_ms']:.1f} ms; "
+          f"`tiled_mode1_jit.compile_ms_once` = {b2['extras']['tiled_mode1_jit']['compile_ms_once']:.1f} ms.")
+if "program_tile_auto" in ex and "ms" in ex["program_tile_auto"]:
+    pa = ex["program_tile_auto"]
+    L(f"A program created on a `tile` = 1 state (`tile_auto`): {pa['ms']:.1f} ms per replay of configs[1] ({pa['gates_per_s']:.0f} gates/s), hipGraph = {pa['is_graph']}, created in {pa['create_s_once']:.2f} s (compilation included).")
+if "reference_bench_shapes" in ex:
+    L("")
+    L("### The reference's own benches, at the reference's sizes (`extras.reference_bench_shapes`; microseconds per `apply_op`)")
+    L("")
+    L("| reference bench | n | element | eager (one C-ABI call per op) | hipGraph program of 64 | tiled program of 64 | CPU restatement (`apply_op`, accumulate) | algorithmic bytes per op |")
+    L("|---|---|---|---|---|---|---|---|")
+    for name, r in ex["reference_bench_shapes"].items():
+        f = lambda k: (f"{r[k]:.2f}" if k in r else "—")  # noqa: E731
+        L(f"| `{name}` | {r['n']} | {r['dtype']} | {f('eager_us_per_op')} | {f('hipgraph_program_us_per_op')} | {f('tiled_program_us_per_op')} | "
+          f"{f('cpu_restatement_us_per_op')} ({r.get('cpu_threads', '?')} threads) | {r['algorithmic_bytes_per_op']:.3g} |")

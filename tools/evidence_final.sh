@@ -16,7 +16,7 @@ timeout 560 python bench.py --steps 20 --warmup 5 > $F/bench_n1.json 2> $F/bench
 echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee $F/bench_wall.txt
 # a second process of the same command: every segment comes from the disk cache (extras.jit of that line)
 S=$(date +%s)
-timeout 560 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $F/bench_n1_second_process.json 2> $F/bench_n1_second_process.err
+timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $F/bench_n1_second_process.json 2> $F/bench_n1_second_process.err
 echo "second bench rc=$? wall=$(( $(date +%s) - S ))s" | tee -a $F/bench_wall.txt
 timeout 200 python tools/bench_ops.py 30 all > $O/ops_table.md 2> $O/ops_table.err
 timeout 200 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32.md 2> $O/ops_table_f32.err
@@ -32,4 +32,8 @@ for leg in "c2 1 1" "c4 1 1" "c2 2 0"; do
   python $R/tools/pmc_jit_segments.py $O/pmc_${T}_FETCH_SIZE $O/pmc_${T}_WRITE_SIZE "$1, tile = $2, wide tiles, relabel = $3" >> $O/jit_segments_pmc.md 2>> $O/jit_segments_pmc.err
 done
 cd $R
+# two ranks on the one GPU (host-staged transport): plumbing + parity + the overlapped exchange's counters, not a throughput figure
+QIP_BENCH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --n-local 24 --steps 3 --warmup 1 --dist-overlap 4 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
+timeout 900 python -m pytest tests -m gpu -q --durations=6 -k "sharded_virtual or bench_multi_rank or programs_compile" > $O/gpu_tests_subset.txt 2>&1
+tail -8 $O/gpu_tests_subset.txt
 tail -c 400 $F/bench_n1.json
