@@ -126,15 +126,8 @@ def median_time(fn, sync, reps=REPS):
     return statistics.median(ts), ts
 
 
-def cpu_baseline(q, circuits, args):
-    """Time the oracle on a bounded sample of the same workload at n = 28 (SURVEY.md §8(d)): the first gates of the same
-    seeded single-qubit circuit, as many as fit the budget (>= 4), median of 3 repetitions, all usable cores; plus the same
-    loop on ONE thread at n = 22, so that the scaling over threads is visible.  Both buffers are first touched inside the
-    OpenMP region (two untimed gates write them in parallel with the static split the timed gates use)."""
-    import numpy as np
-
-    from oracle import qip_oracle as O
-
+def host_threads(O):
+    """(OpenMP's default count, CPUs usable by affinity, the cgroup CPU quota or None, the thread count the CPU legs use = the smallest)"""
     omp_threads = O.max_threads()
     try:
         usable = len(os.sched_getaffinity(0))
@@ -147,7 +140,19 @@ def cpu_baseline(q, circuits, args):
             quota = None if qv == "max" else float(qv) / float(per)
     except Exception:
         pass
-    threads = max(1, min(omp_threads, usable, int(quota) if quota and quota >= 1 else omp_threads))
+    return omp_threads, usable, quota, max(1, min(omp_threads, usable, int(quota) if quota and quota >= 1 else omp_threads))
+
+
+def cpu_baseline(q, circuits, args):
+    """Time the oracle on a bounded sample of the same workload at n = 28 (SURVEY.md §8(d)): the first gates of the same
+    seeded single-qubit circuit, as many as fit the budget (>= 4), median of 3 repetitions, all usable cores; plus the same
+    loop on ONE thread at n = 22, so that the scaling over threads is visible.  Both buffers are first touched inside the
+    OpenMP region (two untimed gates write them in parallel with the static split the timed gates use)."""
+    import numpy as np
+
+    from oracle import qip_oracle as O
+
+    omp_threads, usable, quota, threads = host_threads(O)
 
     def run(n, ops, reps, nthreads):
         O.set_num_threads(nthreads)
@@ -441,16 +446,20 @@ def reference_bench_shapes(q, circuits, args):
                 cop = op.to_c(O._dt(y))  # (converted once: the descriptor of the 2^16-row sparse op takes longer to build than to apply)
                 fn = getattr(O._lib, f"qip_oracle_apply_op_{O._suf(y)}")
                 call = lambda: fn(n, C.byref(cop), x.ctypes.data, x.size, y.ctypes.data, y.size, 0, 0, 1, 0)  # noqa: E731
-                call()
+                omp_default, _, _, threads = host_threads(O)
                 k = max(1, min(64, int(2 ** (22 - n)))) if n < 22 else 2
-                ts = []
-                for _ in range(3):
-                    t = time.perf_counter()
-                    for _ in range(k):
-                        call()
-                    ts.append((time.perf_counter() - t) / k)
-                row["cpu_restatement_us_per_op"] = 1e6 * statistics.median(ts)
-                row["cpu_threads"] = O.max_threads()
+                for label, nt in (("cpu_restatement_us_per_op", threads), ("cpu_restatement_one_thread_us_per_op", 1)):
+                    O.set_num_threads(nt)  # (the cgroup's CPU quota, not the 128+ threads OpenMP would start; and one thread: at n = 8 the fork costs more than the work)
+                    call()
+                    ts = []
+                    for _ in range(3):
+                        t = time.perf_counter()
+                        for _ in range(k):
+                            call()
+                        ts.append((time.perf_counter() - t) / k)
+                    row[label] = 1e6 * statistics.median(ts)
+                O.set_num_threads(omp_default)
+                row["cpu_threads"] = threads
             except Exception as exc:  # noqa: BLE001
                 row["cpu_error"] = repr(exc)
         out[name] = row

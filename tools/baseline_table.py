@@ -152,9 +152,9 @@ if "reference_bench_shapes" in ex:
     L("")
     L("### The reference's own benches, at the reference's sizes (`extras.reference_bench_shapes`; microseconds per `apply_op`)")
     L("")
-    L("| reference bench | n | element | eager (one C-ABI call per op) | hipGraph program of 64 | tiled program of 64 | CPU restatement (`apply_op`, accumulate) | algorithmic bytes per op |")
+    L("| reference bench | n | element | eager (one C-ABI call per op) | hipGraph program of 64 | tiled program of 64 | CPU restatement (`apply_op`, accumulate): all granted threads / one thread | algorithmic bytes per op |")
     L("|---|---|---|---|---|---|---|---|")
     for name, r in ex["reference_bench_shapes"].items():
         f = lambda k: (f"{r[k]:.2f}" if k in r else "—")  # noqa: E731
         L(f"| `{name}` | {r['n']} | {r['dtype']} | {f('eager_us_per_op')} | {f('hipgraph_program_us_per_op')} | {f('tiled_program_us_per_op')} | "
-          f"{f('cpu_restatement_us_per_op')} ({r.get('cpu_threads', '?')} threads) | {r['algorithmic_bytes_per_op']:.3g} |")
+          f"{f('cpu_restatement_us_per_op')} ({r.get('cpu_threads', '?')} threads) / {f('cpu_restatement_one_thread_us_per_op')} | {r['algorithmic_bytes_per_op']:.3g} |")
