@@ -114,6 +114,11 @@ int qip_hip_abi_version(void);
  *                      EVERY RANK plans for itself: "dist_plan_cost", "dist_fold_pack" and "tile_row_split" must have the same value in
  *                      every process of a sharded state.  A batch that contains an exchange compares a fingerprint of its communication
  *                      steps across the ranks first (one 16-byte all-reduce) and is refused on all of them when they differ.
+ *   "tile_diag_runs"   1 (default, r5): the interpreter kernel of the tile sweeps (k_tile_passes) walks every run of >= 2 consecutive diagonal
+ *                      gates of a pass as ONE loop over 64-byte steps (factor, lane condition, host-resolved element mask, outside condition)
+ *                      instead of decoding each gate — the same products in the same order: bit-identical; QFT at n = 30 through the
+ *                      interpreter 125.3 -> 85.1 ms.  0 = every gate through its own code path (rounds 1-4).
+ *   "jit_disk_cache"   1 (default) / 0, "jit_procs" 0 (automatic) .. 64: see qip_hip_jit_stats2 below.
  *   "soft_measure_one_pass"  0 (default): soft_measure = chunk sums, host walk, crossing search in one chunk (two launches); 1 = one launch
  *                      whose last block does the walk and the search.  The same function of the sample; measured slower.
  *   "tile_wide_pin"    1 (default) / 0: wide segments pass their 32 amplitudes through an empty register constraint after every gate
