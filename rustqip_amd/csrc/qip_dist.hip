@@ -1018,7 +1018,7 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
       // soon as the batch's LAST tile sweep — launched in P parts — has stored it; and the slices of the exchange BEFORE this
       // batch awaited one by one by its FIRST sweep (TileSlicing, qip_internal.h).  The slice bits are the index positions right
       // below the chunk-selecting ones of the buffer that is exchanged: packed positions L-g-p .. L-g-1.
-      const uint32_t P = (d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && !s->force_generic && !g_force_generic) ? (uint32_t)d->overlap : 0u;
+      const uint32_t P = (d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && s->tile_passes && !s->force_generic && !g_force_generic) ? (uint32_t)d->overlap : 0u;
       uint32_t pbits = 0;
       while ((1u << pbits) < P) ++pbits;
       TileSlicing sl_post, sl_pre;
@@ -1046,6 +1046,14 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
         // the sweeps either side, as apply_ops will schedule them (the batch after the remap is marshalled early for that); the vote
         // is cast for EVERY exchange of the plan, feasible here or not: the agreement is a collective
         std::vector<double> votes;
+        // everything that can fail on ONE rank only is settled BEFORE the vote and goes into it: a rank that found out afterwards
+        // that it cannot follow would leave the others in a sliced exchange it never joins
+        if (pre && (dist_overlap_setup(d, P) != QIP_OK || ensure_alt(s) != QIP_OK)) pre = false;
+        if (pre && pack_in_plan && !d->third && hipMalloc(&d->third, s->namps * s->amp_bytes) != hipSuccess) {
+          (void)hipGetLastError();  // no room for the receive buffer: this rank votes no, every rank runs the remap the serial way
+          d->third = nullptr;
+          pre = false;
+        }
         if (pre) {
           const int mode = state_tile_mode(s);
           const EdgeTile e_pre = edge_tile(s->dtype, L, m.flat.data(), m.flat.size(), mode, true);
@@ -1064,15 +1072,6 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
         pre = pre && choose_slices(L, g, pbits, votes, d->pl.world, &packed);
       } else {
         pre = false;
-      }
-      if (pre) {
-        if (dist_overlap_setup(d, P) != QIP_OK) pre = false;
-        if (pre && pack_in_plan && !d->third && hipMalloc(&d->third, s->namps * s->amp_bytes) != hipSuccess) {
-          (void)hipGetLastError();  // no room for the receive buffer: this remap runs the serial way
-          d->third = nullptr;
-          pre = false;
-        }
-        if (pre && !pack_in_plan && ensure_alt(s) != QIP_OK) pre = false;
       }
       if (pre) {
         sl_pre.nbits = pbits;
@@ -1112,7 +1111,10 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
         d->stats.packs_folded += 1;
         ++jx;  // the PACK step is done
       }
-      if (pre && sl_pre.parts_done != 0) {
+      // (the ranks AGREED to cut this exchange: a sweep that ran uncut here would leave the peers in slices this rank never sends —
+      // fail loudly instead of falling back to the serial exchange alone)
+      if (pre && sl_pre.parts_done == 0) return fail(QIP_ERR_DEVICE, "internal: the sweep before an exchange the ranks agreed to cut ran uncut on rank %d", d->pl.rank);
+      if (pre) {
         if (sl_pre.parts_done != P || sl_pre.folded != pack_in_plan) return fail(QIP_ERR_DEVICE, "internal: overlapped exchange left incomplete");
         // every slice is on its way: the receive buffer becomes the shard (builder.rs:514 analogue), the EXCHANGE step is done
         if (pack_in_plan) {
@@ -1138,7 +1140,7 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
     QCHK(dist_wait_rx(d));  // (a gather or an exchange of its own reads the whole shard)
     {  // an exchange this rank reaches without a local batch before it: the other ranks may have one and vote — vote "no" with them
       const size_t ex_here = i + (steps[i].kind == qipd::Step::PACK ? 1 : 0);
-      const bool votes_held = d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && !s->force_generic && !g_force_generic;
+      const bool votes_held = d->overlap >= 2 && d->slice_fn && d->pl.world > 1 && s->tile >= 1 && s->tile_passes && !s->force_generic && !g_force_generic;
       if (votes_held && ex_here < steps.size() && steps[ex_here].kind == qipd::Step::EXCHANGE && d->agreed_for != ex_here) {
         std::vector<double> votes;
         slice_votes(L, g, nullptr, EdgeTile(), nullptr, false, &votes);
