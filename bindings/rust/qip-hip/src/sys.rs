@@ -1,4 +1,4 @@
-//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 5).
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 6: 74 entry points; `tests/test_host_ops.py` compares the two sets).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 

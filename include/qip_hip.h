@@ -131,6 +131,9 @@ int qip_hip_abi_version(void);
  *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
  *                      gather (k_sparse_ell).  Same results bit for bit.
  *   "tile_row_split_f32"  5 (default) / 12: the same choice for Complex<f32> states (measured: no gain, profiles/r04_summary.md).
+ *   "debug_slice_sweeps"  0 (default) / 2 / 4 / 8 (r5, measuring aid): every multi-gate tile sweep is launched in that many parts, cut at the
+ *                      highest index positions its tile leaves alone — the sliced launches of the overlapped exchange ("dist_overlap") without
+ *                      any exchange: what cutting a sweep costs by itself.  Same results bit for bit.
  *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
  *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
  *                      (profiles/r02_*.md, r03_tile_skeleton.md). */

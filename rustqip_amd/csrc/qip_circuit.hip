@@ -1897,6 +1897,7 @@ extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 
 // option "tile_auto": from this size a program compiles its segments (below it a sweep is launch-bound and the interpreter, replayed
 // as a graph, is as fast: profiles/r01_small_n_launch_bound.md)
+int64_t g_debug_slice_sweeps = 0;  // global option "debug_slice_sweeps" (measuring aid, see apply_ops_tiled)
 constexpr int kAutoJitMinQubits = 22;
 constexpr int kPairFloorMinQubits = 22;  // option "pair_floor": only where a sweep is HBM-bound (below, launches are)
 static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
@@ -2040,6 +2041,17 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
           s->slice_first = nullptr;
           if (w->fallback) QCHK(w->fallback());
         }
+      }
+      TileSlicing dbg;
+      if (!want && g_debug_slice_sweeps >= 2 && !s->jit_prepare && !s->capture_staging && st.perm.empty() && st.ops.size() >= 2) {
+        // measuring aid (global option "debug_slice_sweeps" = 2 / 4 / 8): EVERY multi-gate sweep in that many parts, cut at the highest
+        // index positions its tile leaves alone — what a sliced launch costs by itself, at full size on one GPU, without any exchange
+        uint32_t pb = 0;
+        while ((1 << pb) < g_debug_slice_sweeps) ++pb;
+        dbg.nbits = 0;
+        for (uint32_t pp = s->n; pp-- > 12u && dbg.nbits < pb;)
+          if (std::find(st.high.begin(), st.high.end(), pp) == st.high.end()) dbg.pos[dbg.nbits++] = pp;
+        if (dbg.nbits == pb) want = &dbg;
       }
       s->slice_now = want;
       auto unsliced = [&]() -> int {

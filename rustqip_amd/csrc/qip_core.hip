@@ -71,6 +71,11 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
   if (key && !strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
+  if (key && !strcmp(key, "debug_slice_sweeps")) {
+    if (value != 0 && value != 2 && value != 4 && value != 8) return fail(QIP_ERR_INVALID, "debug_slice_sweeps is 0, 2, 4 or 8");
+    g_debug_slice_sweeps = value;
+    return QIP_OK;
+  }
   if (key && !strcmp(key, "tile_diag_runs")) { g_tile_diag_runs = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_disk_cache")) { g_jit_disk = value != 0; return QIP_OK; }
   if (key && !strcmp(key, "jit_procs")) {

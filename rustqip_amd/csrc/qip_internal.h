@@ -67,6 +67,7 @@ extern int64_t g_sparse_tile;  // qip_launch.hip
 extern int64_t g_soft_measure_one_pass;  // qip_measure.hip
 extern int64_t g_tile_wide_pin, g_tile_wide_dense3_inline;  // qip_circuit.hip
 extern int64_t g_jit_disk, g_jit_procs, g_jit_world;  // qip_circuit.hip: code objects on disk, helper processes, ranks sharing the host
+extern int64_t g_debug_slice_sweeps;  // qip_circuit.hip
 extern int64_t g_jit_threads;     // qip_circuit.hip: host threads that compile a plan's new segments side by side
 extern int64_t g_force_k4_direct;  // tuning aid: dense k = 4 on the matrix cores reads its operands straight from HBM (k_gate_kq_mfma)  // 0 = never, 1 = single dense k = 2, 3 / Swap ops with a bit inside a row go as a one-item tile sweep, 2 = every dense k = 2, 3  // tuning aids of the tile sweeps (qip_hip_set_global_option)
 

@@ -47,11 +47,11 @@ def main():
 
     f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
     for key in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32", "tile_diag_runs",
-                "tile_wide_dense3_inline", "tile_wide_pin", "jit_procs"):  # tuning aids (global options)
+                "tile_wide_dense3_inline", "tile_wide_pin", "jit_procs", "debug_slice_sweeps"):  # tuning aids (global options)
         if os.environ.get("QIP_" + key.upper()):
             q.set_global_option(key, int(os.environ["QIP_" + key.upper()]))
     tune = {k: os.environ.get("QIP_" + k.upper(), "") for k in ("tile_pad_from", "tile_wave_rule", "tile_remap", "tile_sched", "tile_row_split", "tile_row_split_f32",
-                                                                "tile_diag_runs", "tile_wide_dense3_inline") if os.environ.get("QIP_" + k.upper())}
+                                                                "tile_diag_runs", "tile_wide_dense3_inline", "debug_slice_sweeps") if os.environ.get("QIP_" + k.upper())}
     with q.HipState(n, np.complex64 if f32 else np.complex128) as st:
         st.init_basis(0)
         st.apply_ops(circuits.h_layer(n))
