@@ -98,6 +98,7 @@ enum KernelClass {
   KC_PERMUTE,
   KC_SPARSE_ELL,
   KC_SPARSE_TILE,
+  KC_TILE_PARTS,  // (r5) not a kernel: `launches` counts the PARTS of tile sweeps that were launched in slices (TileSlicing); no time, no bytes
   KC_COUNT
 };
 
