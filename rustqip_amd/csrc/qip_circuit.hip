@@ -1609,7 +1609,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       }));
       if (slicing && sl->after) QCHK(sl->after(k, folding));
       if (slicing) sl->parts_done += 1;
-      if (s->profile) s->prof_launches[KC_TILE_PARTS] += 1;
+      if (slicing && s->profile) s->prof_launches[KC_TILE_PARTS] += 1;
     }
     if (slicing) sl->folded = folding;
     if (s->profile) QCHK(prof_end(s, &rec));
@@ -1640,7 +1640,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
       HIPCHK(hipGetLastError());
       if (slicing && sl->after) QCHK(sl->after(k, folding));
       if (slicing) sl->parts_done += 1;
-      if (s->profile) s->prof_launches[KC_TILE_PARTS] += 1;
+      if (slicing && s->profile) s->prof_launches[KC_TILE_PARTS] += 1;
     }
     if (slicing) sl->folded = folding;
     if (folding) {
