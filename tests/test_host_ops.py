@@ -363,3 +363,20 @@ int main(void) {
                     str(src), "-o", str(exe), "-L", lib_dir, "-lqip_hip", "-Wl,-rpath," + lib_dir], check=True)
     env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     assert subprocess.run([str(exe)], env=env).returncode == 0  # validate_op is host code: runs without a GPU
+
+
+def test_r5_options_and_profile_classes_exist_without_a_gpu():
+    """host-only surface added in round 5: global options are validated, the profile class list grew at the end"""
+    names = [_ffi.lib.qip_hip_kernel_class_name(i).decode() for i in range(_ffi.lib.qip_hip_kernel_class_count())]
+    assert names[-1] == "tile_sweep_parts" and names.index("k_tile_passes") == 8  # (existing indices unchanged)
+    for key, good, bad in (("debug_slice_sweeps", 4, 3), ("jit_procs", 2, 65), ("tile_diag_runs", 0, None), ("jit_disk_cache", 0, None)):
+        q.set_global_option(key, good)
+        if bad is not None:
+            with pytest.raises(q.CircuitError):
+                q.set_global_option(key, bad)
+    q.set_global_option("debug_slice_sweeps", 0)
+    q.set_global_option("jit_procs", 0)
+    q.set_global_option("tile_diag_runs", 1)
+    q.set_global_option("jit_disk_cache", 1)
+    c = _ffi.jit_counters()
+    assert c["procs"] >= 1 and c["disk_cache"] in (0, 1)
