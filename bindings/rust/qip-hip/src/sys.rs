@@ -1,4 +1,5 @@
-//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 6: 74 entry points; `tests/test_host_ops.py` compares the two sets).
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 7: 66 entry points; `tests/test_host_ops.py` compares the two sets).
+//! The host-only test hooks of `include/qip_hip_debug.h` are not part of the binding contract and are not mirrored here.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
@@ -89,10 +90,6 @@ extern "C" {
         step_of_op: *mut i64, n_steps: *mut u64,
     ) -> c_int;
 
-    pub fn qip_hip_tile_lane_assignment(dtype: c_int, pass_bits: *const u32, lanepos: *mut u64) -> c_int;
-    pub fn qip_hip_debug_tile_plan(dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int) -> *const c_char;
-    pub fn qip_hip_debug_sparse_tile(dtype: c_int, n: u32, op: *const qip_op) -> *const c_char;
-
     pub fn qip_hip_state_set_option(s: *mut qip_hip_state, key: *const c_char, value: i64) -> c_int;
     pub fn qip_hip_kernel_class_count() -> c_int;
     pub fn qip_hip_kernel_class_name(cls: c_int) -> *const c_char;
@@ -146,12 +143,6 @@ extern "C" {
     pub fn qip_hip_jit_set_cache_dir(dir: *const c_char) -> c_int;
     pub fn qip_hip_jit_cache_dir() -> *const c_char;
     pub fn qip_hip_jit_compile_file(src_path: *const c_char, fma: c_int, out_path: *const c_char) -> c_int;
-    /// host-only test hook: the descriptor of the bit-permutation sweep as JSON
-    pub fn qip_hip_debug_permute_plan(n: u32, pi: *const u32, row_bits: u32, fold_bits: u32) -> *const c_char;
-    pub fn qip_hip_debug_tile_jit(
-        dtype: c_int, n: u32, ops: *const qip_op, count: u64, mode: c_int, segments: *mut u64,
-        source_bytes: *mut u64, code_bytes: *mut u64, first_source: *mut *const c_char,
-    ) -> c_int;
 
     // ---- the state sharded over several GPUs (one process per GPU) ------------------------------------------
     pub fn qip_hip_dist_unique_id(id_out: *mut c_void) -> c_int; // QIP_HIP_UNIQUE_ID_BYTES = 128
@@ -178,22 +169,13 @@ extern "C" {
     pub fn qip_hip_dist_layout(d: *mut qip_hip_dist, phys: *mut u32) -> c_int;
     pub fn qip_hip_dist_rank_flip(d: *mut qip_hip_dist, mask: *mut u32) -> c_int;
     pub fn qip_hip_dist_take_stats(d: *mut qip_hip_dist, out: *mut qip_hip_dist_stats) -> c_int;
-    pub fn qip_hip_dist_debug_pieces(
-        rank: c_int, world: c_int, chunk_bytes: u64, piece_bytes: u64, cap: u64, peer: *mut i32, offset: *mut u64, length: *mut u64,
-    ) -> i64;
-    pub fn qip_hip_dist_debug_overlap(
-        n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64, tile_mode: c_int, slices: c_int,
-    ) -> *const c_char;
-    pub fn qip_hip_dist_debug_plan(
-        n: u32, dtype: c_int, rank: c_int, world: c_int, ops: *const qip_op, count: u64,
-    ) -> *const c_char;
 }
 
 pub const QIP_HIP_UNIQUE_ID_BYTES: usize = 128;
 pub type qip_hip_all_to_all_slice_fn =
     Option<unsafe extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, u64, u64, *mut c_void) -> c_int>;
 
-/// `struct qip_hip_jit_counters` (ABI 6)
+/// `struct qip_hip_jit_counters` (ABI 7)
 #[repr(C)]
 #[derive(Default, Debug, Clone, Copy)]
 pub struct qip_hip_jit_counters {
@@ -207,6 +189,8 @@ pub struct qip_hip_jit_counters {
     pub disk_load_ms: c_double,
     pub procs: i32,
     pub disk_cache: i32,
+    pub background_segments: u64,
+    pub disk_trimmed: u64,
 }
 
 #[repr(C)]

@@ -90,53 +90,34 @@ const char* qip_hip_last_error(void);
 int qip_hip_device_count(void);
 /* ABI version of this header (bumped when entry points or options are added or changed). */
 int qip_hip_abi_version(void);
-/* Process-wide options.
- *   "force_generic"    1 routes every op (including the host twin below) through the literal gather kernel; used by the
- *                      parity tests to check both the specialised kernels and the fallback against the oracle.
- *   "single_via_tile"  which single ops run as a ONE-op tile sweep (whole rows on both global sides whatever the target bits;
- *                      the arithmetic of the dedicated VALU kernels, IEEE-equal): 0 = none, 1 = dense k = 2, 3 and Swap ops with
- *                      a bit inside a 1-KiB row, 2 = every dense k = 2, 3, 3 (default) = uncontrolled single-qubit gates on a
- *                      position >= 6 as well.  "single_via_tile_f32": the same switch for Complex<f32> states (default 3).
- *   "jit_cache_cap"    bound of the run-time compiler's kernel cache (default 512, see qip_hip_jit_cache_info).
- *   "tile_sched"       the tile scheduler's host-side decisions: 1 (default) = gates inside a segment are ordered for the fewest
- *                      LDS passes (tile = 1: only across gates that commute exactly, the result stays IEEE-equal to circuit
- *                      order) and, with tile = 2 from n = 24, the five positions of a segment are claimed by what they buy
- *                      (shortest of three plans); 0 = first come, circuit order inside segments; 2 = search at every size (tests).
- *   "tile_row_split"   11 (default): every wave-level access of a tile sweep is two 512-byte halves 32 KiB apart (the tile's six
- *                      low index positions are 0..4 and 11; Complex<f64>, n >= 12), 5: one contiguous 1-KiB row (rounds 1-3).
- *                      Same results bit for bit; which address bits travel together is what sets a sweep's HBM rate
- *                      (profiles/r04_tile_rows.md).
- *   "dist_fold_pack"   1 (default): the gather of a sharded state's remap rides in the store phase of the tile sweep before
- *                      it where it can (qip_hip_dist_stats.packs_folded); 0 = always a sweep of its own.
- *   "dist_plan_cost"   1 (default): at a remap of a sharded state the leaving qubits are chosen by modelled cost — the count-optimal set
- *                      (farthest next use) unless the set that keeps the gather out of the wave rows is cheaper over the rest of the
- *                      circuit (exchange = shard / world bytes per link, free-standing gather = one copy of the shard); 0 = by count alone.
- *                      EVERY RANK plans for itself: "dist_plan_cost", "dist_fold_pack" and "tile_row_split" must have the same value in
- *                      every process of a sharded state.  A batch that contains an exchange compares a fingerprint of its communication
- *                      steps across the ranks first (one 16-byte all-reduce) and is refused on all of them when they differ.
- *   "tile_diag_runs"   1 (default, r5): the interpreter kernel of the tile sweeps (k_tile_passes) walks every run of >= 2 consecutive diagonal
- *                      gates of a pass as ONE loop over 64-byte steps (factor, lane condition, host-resolved element mask, outside condition)
- *                      instead of decoding each gate — the same products in the same order: bit-identical; QFT at n = 30 through the
- *                      interpreter 125.3 -> 85.1 ms.  0 = every gate through its own code path (rounds 1-4).
- *   "jit_disk_cache"   1 (default) / 0, "jit_procs" 0 (automatic) .. 64: see qip_hip_jit_stats2 below.
- *   "soft_measure_one_pass"  0 (default): soft_measure = chunk sums, host walk, crossing search in one chunk (two launches); 1 = one launch
- *                      whose last block does the walk and the search.  The same function of the sample; measured slower.
- *   "tile_wide_pin"    1 (default) / 0: wide segments pass their 32 amplitudes through an empty register constraint after every gate
- *                      applied under a block-uniform branch — no semantics (bit-identical results), fewer spills in branch-heavy
- *                      segments (Clifford+T: 175 -> 0 VGPR spills, a 72-gate prefix at n = 30 25.9 -> 23.9 ms; configs[1] unchanged).
- *   "tile_wide_dense3_inline"  1 (default since r5) / 0: dense 3-qubit gates of wide segments written out group by group instead of through
- *                      pass_dense3w's loop (whose run-time indexing put the lane's 32 amplitudes in a 528-byte stack object).  The same fold:
- *                      bit-identical (tests); dense-k3 Grover at n = 30 on wide tiles 109.9 -> 77.5 ms (11-bit tiles: 88.2).
- *   "sparse_tile"      1 (default): a SparseMatrix on k >= 6 qubits with <= 4 entries per row and 3..7 of its positions outside
- *                      the wave row is applied IN PLACE with its group staged in LDS (k_sparse_tile); 0 = always the out-of-place
- *                      gather (k_sparse_ell).  Same results bit for bit.
- *   "tile_row_split_f32"  5 (default) / 12: the same choice for Complex<f32> states (measured: no gain, profiles/r04_summary.md).
- *   "debug_slice_sweeps"  0 (default) / 2 / 4 / 8 (r5, measuring aid): every multi-gate tile sweep is launched in that many parts, cut at the
- *                      highest index positions its tile leaves alone — the sliced launches of the overlapped exchange ("dist_overlap") without
- *                      any exchange: what cutting a sweep costs by itself.  Same results bit for bit.
- *   tuning aids        "perm_rows" (0 / 5 / 6), "line_bits" (0..3), "tile_pad_from" (11), "tile_wave_rule" (1), "tile_remap" (0; 4 = XCD-aware
- *                      block -> tile order in run-time-compiled segments), "k4_direct" (0): measured alternatives kept switchable
- *                      (profiles/r02_*.md, r03_tile_skeleton.md). */
+/* Process-wide options (every key the product build accepts; unknown keys are QIP_ERR_INVALID).
+ *   "force_generic"        1: every op (the host twins below included) runs through the literal out-of-place gather kernel —
+ *                          the path the parity tests hold the specialised kernels against.  Default 0.
+ *   "single_via_tile"      which single ops run as a ONE-op tile sweep (whole wave rows on both global sides whatever the
+ *                          target bits; the arithmetic of the dedicated VALU kernels, IEEE-equal): 0 none, 1 dense k = 2, 3 and
+ *                          Swap ops with a bit inside a 1-KiB row, 2 every dense k = 2, 3, 3 (default) also uncontrolled
+ *                          single-qubit gates on a position >= 6.
+ *   "tile_sched"           the tile scheduler's host-side search: 1 (default) orders the gates of a segment for the fewest LDS
+ *                          passes ("tile" = 1: only across gates that commute exactly) and, for "tile" = 2 from n = 24, picks
+ *                          the shortest of three position-claiming plans; 0 first come, circuit order; 2 search at every size.
+ *   "jit_cache_cap"        bound of the in-process cache of run-time-compiled kernels (default 512; qip_hip_jit_cache_info).
+ *   "jit_disk_cache"       1 (default) / 0: keep code objects on disk (qip_hip_jit_stats2).
+ *   "jit_disk_cap_mb"      bound of that directory in MiB; oldest files go first (default -1 = $QIP_HIP_CACHE_MAX_MB or 1024;
+ *                          0 = unbounded).
+ *   "jit_procs"            helper processes a plan's new segments are compiled in: 0 (default) automatic, 1 in this process
+ *                          only, up to 64.
+ *   "dist_fold_pack"       1 (default): the gather of a sharded state's remap rides in the store phase of the tile sweep
+ *                          before it where it can (qip_hip_dist_stats.packs_folded); 0 always a sweep of its own.
+ *   "dist_plan_cost"       1 (default): at a remap the leaving qubits are chosen by modelled cost (count-optimal set unless
+ *                          keeping the gather out of the wave rows is cheaper over the rest of the circuit); 0 by count alone.
+ *   "collective_timeout_s" seconds a rank of a sharded state waits for queued work that contains an exchange or an all-reduce
+ *                          before the call FAILS (and the handle is unusable) instead of hanging: a peer died or issued other
+ *                          calls.  Default 120; 0 waits for ever.
+ * Every rank plans for itself: "dist_plan_cost", "dist_fold_pack" and the per-handle options "tile" / "dist_overlap" must agree
+ * across the processes of a sharded state.  A batch that contains an exchange compares a fingerprint of its communication
+ * steps and of those options across the ranks first (one 16-byte all-reduce) and is refused on all of them when they differ.
+ * (The measured alternatives of earlier rounds — row layouts, unroll factors, one-pass variants — are fixed at the values that
+ * won; a -DQIP_HIP_TUNING build of the library makes them options again for tools/bench_*.py.  profiles/ holds the runs.) */
 int qip_hip_set_global_option(const char* key, int64_t value);
 
 /* ---- op validation ------------------------------------------------------
@@ -219,8 +200,6 @@ int qip_hip_state_sync(qip_hip_state* s);
  * amplitudes without arithmetic, so the composition is bit-identical to applying them one by one); the tile scheduler
  * uses it for runs of swaps (QFT's closing bit reversal) and the multi-GPU remap for its gather.  Uses the scratch buffer. */
 int qip_hip_state_permute_bits(qip_hip_state* s, const uint32_t* pi);
-/* Host-only test hook: the descriptor of that sweep as JSON (tile bit positions, LDS swizzle), NULL on error. */
-const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi, uint32_t row_bits, uint32_t fold_bits);
 
 /* state <- op · state.  Equivalent to apply_op_overwrite(n, op, state, arena, 0, 0)
  * followed by the buffer swap (builder.rs:499,514). */
@@ -249,25 +228,8 @@ int qip_hip_program_destroy(qip_hip_program* p);
 int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode,
                        int64_t* step_of_op, uint64_t* n_steps);
 
-/* Host-only: how one pass of a tile sweep lays the thread id over the tile.  pass_bits = the pass's three exchange
- * bits (tile-index space 0..10, ascending); *lanepos gets nibble k = tile-index bit filled by bit k of the 8-bit
- * thread id.  The tile is stored in LDS at slot(t) = t ^ ((t >> S) & (2^S - 1)), S = 4 (QIP_C64) / 5 (QIP_C32);
- * together the two make every pass free of LDS bank conflicts unless it holds both bits of a pair (j, j+S).  Exposed
- * so the claim can be checked without a GPU (tests/test_host_ops.py). */
-int qip_hip_tile_lane_assignment(int dtype, const uint32_t* pass_bits, uint64_t* lanepos);
 
-/* Host-only test hook: the complete tile plan of a circuit as a JSON string (owned by the library, valid until
- * the calling thread's next call; NULL on error): the schedule of qip_hip_plan_tiles and, for every multi-gate
- * step, the free bit positions, the passes (exchange bits, lane-bit assignment) and the gate descriptors exactly
- * as they are shipped to k_tile_passes.  tests/test_tile_plan_cpu.py replays it with a numpy model of the kernel
- * and checks the result against the CPU oracle, so the host half of the tile path is covered without a GPU. */
-const char* qip_hip_debug_tile_plan(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode);
 
-/* Host-only test hook (r4): what the host decides about applying ONE SparseMatrix op in place through the LDS-staged tile
- * kernel (k_sparse_tile) on a state of n qubits — the tile's positions, the block-base descriptor, the row table (entries per
- * row, each stored column's place in the tile, the values) — as JSON, or {"applies":0} when the op takes another kernel.
- * tests/test_tile_plan_cpu.py replays it with a numpy model of the kernel against the CPU oracle.  NULL on error. */
-const char* qip_hip_debug_sparse_tile(int dtype, uint32_t n, const qip_op* op);
 
 /* Number of index bits of a tile of the LDS-resident multi-gate sweeps (low 6 bits + the free positions). */
 int qip_hip_tile_bits(void);
@@ -294,6 +256,8 @@ typedef struct qip_hip_jit_counters {
   double disk_load_ms;             /* wall time spent reading code objects                                           */
   int32_t procs;                   /* helper processes a plan may use right now                                      */
   int32_t disk_cache;              /* 1 = a cache directory is in use                                                */
+  uint64_t background_segments;    /* (ABI 7) segments handed to background helpers by one-shot apply_ops ("tile_auto") */
+  uint64_t disk_trimmed;           /* (ABI 7) code objects removed to keep the cache under "jit_disk_cap_mb"            */
 } qip_hip_jit_counters;
 int qip_hip_jit_stats2(qip_hip_jit_counters* out);
 /* Cache directory: NULL = back to the default rule, "" = none.  qip_hip_jit_cache_dir: the directory in use ("" = none; the
@@ -309,87 +273,41 @@ int qip_hip_jit_compile_file(const char* src_path, int fma, const char* out_path
  * Any output may be NULL. */
 int qip_hip_jit_cache_info(uint64_t* resident, uint64_t* evicted, uint64_t* cap);
 
-/* Host-only test hook: generate AND compile (hiprtc cross-compiles for gfx950 without a device) the run-time source
- * of every multi-gate step of the circuit's tile schedule.  *first_source (may be NULL) points at the first segment's
- * source text, owned by the library until the calling thread's next call. */
-int qip_hip_debug_tile_jit(int dtype, uint32_t n, const qip_op* ops, uint64_t count, int mode, uint64_t* segments,
-                           uint64_t* source_bytes, uint64_t* code_bytes, const char** first_source);
 
-/* Options: key is one of
- *   "force_generic"  1 = route every op through the literal gather kernel
- *   "profile"        1 = bracket every kernel with HIP events (see *_profile_*)
- *   "lowbit_shuffle" 1 = cross-lane variant of the 1-qubit kernel for low bit positions (default 1)
- *   "mfma"           1 = matrix-core kernels: dense k = 3..5 where they win (f64 and f32 forms), k = 6..8 (f64,
- *                    A operand streamed through LDS); 0 = VALU register kernels (k <= 4) / the literal kernel (default 1)
- *   "fuse"           K >= 2: qip_hip_state_apply_ops merges consecutive gates into dense gates on
- *                    <= K qubits (K <= 5) and applies each in one sweep; results
- *                    then match the gate-by-gate path to rounding (1e-12 bar), not bit for bit.
- *                    0 (default) = one sweep per gate, bit-faithful to the reference's fold order.
- *   "tile"           1: qip_hip_state_apply_ops cuts the circuit into segments of gates (1-qubit gates with any
- *                    controls, dense 2-qubit gates, bit swaps) whose exchanging bits live on index bits 0..5
- *                    plus five free higher bits and applies each segment in ONE sweep
- *                    through an LDS-resident tile, in circuit order up to exact commutations of rounding-free gates
- *                    (IEEE-equal to the gate-by-gate path; a dense 3-qubit gate rides along as the unfused register fold,
- *                    i.e. equal to its gate-by-gate form under "mfma" = 0 — on the matrix cores it is an fma chain);
- *                    2: additionally hoists gates over skipped gates they commute with (1e-12 bar). 0 = off.
- *   "tile_jit"       1: every tile segment runs as a kernel compiled at run time for that segment's STRUCTURE (hiprtc; op
- *                    codes, bit positions, control masks, zero / unit / real shapes become constants of the code: no descriptor
- *                    fetch, no dispatch left), cached per process by its source.  The segment's NUMBERS — every matrix component
- *                    that is not exactly 0 or +-1 — are kernel data (scalar loads from the arena), so new rotation angles reuse
- *                    the compiled kernel: a variational loop compiles once.  Bit-identical to the interpreter (same helpers,
- *                    same order).  Pays ~0.3-1 s per NEW structure: for circuits that are replayed (programs, loops), not for
- *                    one-shot runs.  2: same as 1 (kept for round-3 callers).  3 (tuning aid): numbers as literals in the
- *                    source (every new angle is a new kernel).  0 (default) = the interpreter kernel.
- *   "tile_relabel"   1: the tile scheduler keeps a logical -> physical map of the qubits: at the end of every segment
- *                    in-tile bit swaps (riding along in the same sweep) put the qubits whose next amplitude-exchanging use
- *                    comes soonest on index bits 0..5, so the next segment spends its five free positions on five OTHER
- *                    qubits; uncontrolled Swap ops become label exchanges (no sweep at all); one bit-permutation sweep at
- *                    the end restores the order.  Only moves are added and no gate changes its place in the plain schedule's
- *                    order: bit-identical to "tile" = 1 without it (for "tile" = 2 the hoists depend on which gates share a
- *                    physical tile, so the two plans agree to the 1e-12 bar of that mode only; a dense 3-qubit gate that rides
- *                    in a segment in one plan and runs alone on the matrix cores in the other likewise differs by rounding).
- *                    The plan is only used when it is shorter than the plain
- *                    one (random circuits: 19 -> 14 sweeps for configs[1]; layered ones like QFT / Grover keep the plain
- *                    plan).  2 = use it unconditionally (tests).  3 = as 1, and the layout PERSISTS across apply_ops calls: a
- *                    batch starts from the layout the previous one left and does not pay the restoring sweep; the caller's
- *                    order is restored (one sweep) by the first call that needs it — download / upload / measurement /
- *                    device_ptr / a batch without relabelling / a program capture.  A circuit applied in chunks (a
- *                    variational loop, a host that streams its ops) then costs what it costs in one piece.
- *                    0 (default) = off.  Needs the scratch buffer (a state too large for it keeps the plain plan).  A relabelled
- *                    batch that fails half way (a launch, an allocation, the run-time compiler) leaves the buffer in an order
- *                    nobody can name: the handle then refuses every call that reads or computes from the amplitudes, with the
- *                    original message, until qip_hip_state_init_basis / a full upload / copy_from overwrites them (ABI 5).
- *   "tile_fma"       1: run-time-compiled segments of "tile" = 2 are compiled with multiply-add contraction (v_fma_f64: a complex
- *                    product is 4 instead of 6 vector instructions; QFT at n = 30: 57 -> 50 ms).  Ignored for "tile" = 1, which
- *                    promises IEEE equality with the gate-by-gate path.  0 (default) = off.
- *   "tile_merge"     1: in run-time-compiled segments of "tile" = 2, a run of consecutive diagonal gates (they all commute) is
- *                    applied as PRODUCTS: each gate's factor joins the running product of the set of a lane's elements it acts on,
- *                    each element then takes the product of its sets (QFT: ~33 complex products per lane after each H instead of
- *                    116).  Rounding differs from the sequential products (1e-12 bar).  Ignored for "tile" = 1.  0 (default) = off.
- *   "tile_wide"      1 (ABI 5; needs "tile_jit"): the segments run over a WIDE tile — 2^13 amplitudes per block held in registers
- *                    (32 per lane = five register bits; 256 lanes), LDS only as a transposition buffer — so a segment claims
- *                    SEVEN free positions instead of five and the circuit needs fewer sweeps (configs[1] in circuit order:
- *                    18 -> 13, relabelled 14 -> 10; a light sweep costs the same 5.2 - 5.8 ms).  Gates on the five register
- *                    bits of the moment cost no LDS traffic; a transposition (four quarters through the buffer) brings in up to
- *                    three new register bits.  Same helpers, same gate order: "tile" = 1 stays IEEE-equal to the gate-by-gate
- *                    path.  "tile_fma" / "tile_merge" apply to wide segments of "tile" = 2 as they do to narrow ones.
- *                    0 (default) = the 11-bit LDS-resident tile.  r5: also inside hipGraph programs.
- *   "tile_auto"      1 (default, ABI 6): who compiles.  apply_ops on a state with "tile" >= 1 and "tile_jit" = 0 runs the interpreter
- *                    kernel (a circuit that runs once does not repay seconds of compilation); a PROGRAM (qip_hip_program_create)
- *                    created on such a state with n >= 22 is made to be replayed, so its own launches use run-time-compiled
- *                    segments over wide tiles ("tile_wide"), compiled once at creation
- *                    (helper processes + disk cache, qip_hip_jit_stats2).  Same helpers, same order of operations: bit-identical
- *                    to the interpreter for "tile" = 1.  0 = programs use the state's options as they are.
- *   "pair_floor"     1 (default, ABI 6): in the gate-by-gate path of apply_ops (n >= 22), a gate whose selectors — controls, the target of
- *                    a phase-type diagonal — sit inside a 1-KiB wave row costs a sweep of the WHOLE vector for half / a quarter of the
- *                    algorithmic bytes (the memory system moves whole lines: T on bit 0 41 %, CNOT with the control in a row 40 %); when it
- *                    and the NEXT gate fit one tile, the two go as ONE two-item tile sweep (interpreter kernel, circuit order, the same
- *                    unfused arithmetic: IEEE-equal) and the neighbour rides for free.  0 = always one launch per gate.
- *   "swap_single"    1 = one sweep per transposition of a Swap (tuning aid; default: groups of transpositions per sweep)
- *   "tile_passes"    1 (default): tile sweeps keep each lane's 8-element group in registers across a pass of
- *                    gates (one LDS round trip per pass); 0: one LDS round trip per gate (tuning aid)
- *   "packed_f32"     1 (default): f32 states are swept as 16-B elements of two amplitudes where possible
- *   "unroll"         1 = one item per iteration in the matrix-core kernel (tuning aid)
+/* Per-handle options (unknown keys are QIP_ERR_INVALID).  Defaults in brackets.
+ *   "force_generic" [0]  1: this handle's ops run through the literal gather kernel.
+ *   "profile"       [0]  1: every kernel is bracketed with HIP events (qip_hip_state_profile_get); programs run eagerly.
+ *   "mfma"          [1]  matrix-core kernels for dense k = 3..5 where they win, k = 6..10 always; 0: VALU register kernels
+ *                        (k <= 4, the bit-faithful fold) / the literal kernel.
+ *   "fuse"          [0]  K = 2..5: qip_hip_state_apply_ops merges consecutive gates into dense gates on <= K qubits, one sweep
+ *                        each; results match the gate-by-gate path to the 1e-12 bar, not bit for bit.
+ *   "tile"          [0]  1: apply_ops cuts the circuit into segments (1-qubit gates with any controls, dense 2- / 3-qubit
+ *                        gates, bit swaps) whose exchanging bits fit index bits 0..5 plus five free higher positions, and applies
+ *                        each segment in ONE sweep through an LDS-resident tile, in circuit order up to exact commutations:
+ *                        IEEE-equal to the gate-by-gate path (a dense 3-qubit gate rides as the unfused register fold, i.e.
+ *                        equal to its "mfma" = 0 form).  2: also hoists gates over gates they commute with (1e-12 bar).
+ *   "tile_jit"      [0]  1: every segment runs as a kernel compiled at run time (hiprtc) for the segment's STRUCTURE — op codes,
+ *                        positions, masks, zero / unit / real shapes are constants; matrix entries other than 0 / +-1 are kernel
+ *                        data, so new angles reuse the kernel.  Bit-identical to the interpreter.  ~0.4 - 1.3 s per new
+ *                        structure, compiled side by side in helper processes and kept on disk (qip_hip_jit_stats2).
+ *   "tile_wide"     [0]  1 (needs "tile_jit"): segments over a 13-bit tile held in registers, seven free positions per sweep;
+ *                        same helpers and gate order as the 11-bit tile (configs[1]: 18 -> 13 sweeps).
+ *   "tile_relabel"  [0]  1: the scheduler keeps a logical -> physical qubit map: in-tile swaps at the end of a segment put the
+ *                        soonest-needed qubits on bits 0..5, uncontrolled Swap ops become label exchanges, one permutation sweep
+ *                        at the end restores the order; used when the plan gets shorter; only moves are added (bit-identical
+ *                        for "tile" = 1).  2: always.  3: as 1 and the layout PERSISTS across apply_ops calls — the first call
+ *                        that needs the caller's order (download, measurement, device_ptr, a program) restores it with one sweep.
+ *                        A relabelled batch that fails half way leaves an order nobody can name: the handle refuses every call
+ *                        that reads amplitudes until init_basis / a full upload / copy_from overwrites them.
+ *   "tile_fma"      [0]  1: compiled segments of "tile" = 2 may contract products into sums (1e-12 bar; ignored for "tile" = 1).
+ *   "tile_merge"    [0]  1: compiled segments of "tile" = 2 apply a run of diagonal gates as products of their factors.
+ *   "tile_auto"     [1]  who pays for compilation when "tile" >= 1 and "tile_jit" = 0 (n >= 22): a PROGRAM compiles its
+ *                        segments (wide tiles) at creation; apply_ops uses compiled wide sweeps only when EVERY segment of
+ *                        the plan is already resident or in the disk cache, otherwise the interpreter now and the missing
+ *                        segments in background helper processes for the next call or process.  0: the state's options as set.
+ *   "pair_floor"    [1]  gate-by-gate apply_ops (n >= 22): a gate whose selectors sit inside a 1-KiB wave row (a sweep of the
+ *                        whole vector for half / a quarter of the bytes) goes with its neighbour as ONE two-item tile sweep when
+ *                        both fit a tile (IEEE-equal).  0: one launch per gate.
  */
 int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);
 
@@ -505,14 +423,13 @@ int qip_hip_dist_apply_op(qip_hip_dist* d, const qip_op* op);
  * go to the shard as one qip_hip_state_apply_ops batch (so option "tile" applies to them) */
 int qip_hip_dist_apply_ops(qip_hip_dist* d, const qip_op* ops, uint64_t count);
 int qip_hip_dist_sync(qip_hip_dist* d);
-/* options: "tile", "fuse", "mfma", "profile", ... are forwarded to the shard (qip_hip_state_set_option); "piece_bytes"
- * (largest single ncclSend / ncclRecv) belongs to the built-in RCCL transport: QIP_ERR_UNSUPPORTED with a caller-supplied one;
- * "dist_overlap" (r5): 0 (default) / 1 = every exchange is one all-to-all on the shard's stream; 2 / 4 / 8 = a remap whose
- * neighbouring local batches run as tile sweeps ("tile" >= 1) has its exchange cut into that many slices (the index positions right
- * below the chunk-selecting ones), issued on a separate stream as soon as the LAST sweep before the remap — launched in as many
- * parts — has stored them, and the FIRST sweep after it starts on each slice as soon as it has landed.  Same amplitudes bit for
- * bit.  Costs a third shard-sized buffer when the remap's gather rides in that last sweep.  Default off for the built-in RCCL
- * transport: no multi-GPU machine has been available to run it on. */
+/* Per-handle options of a sharded state: the keys of qip_hip_state_set_option are forwarded to the shard, plus
+ *   "piece_bytes"   largest single ncclSend / ncclRecv of the built-in RCCL transport (default 1 GiB; QIP_ERR_UNSUPPORTED with a
+ *                   caller-supplied transport).
+ *   "dist_overlap"  EXPERIMENTAL, default 0: 2 / 4 / 8 cut a remap's exchange into that many slices on a second stream,
+ *                   overlapped with the tile sweeps either side of it ("tile" >= 1; same amplitudes bit for bit; a third
+ *                   shard-sized buffer when the gather rides in the sweep before).  Has only ever run over the host-staged test
+ *                   transport: no multi-GPU machine was available. */
 int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t value);
 
 /* measurement over the whole vector (measurement_ops.rs:11-13, 115-127, 190-269): local reductions + one all-reduce;
@@ -568,29 +485,8 @@ typedef struct qip_hip_dist_stats {
 /* counters since the previous call (they reset; rccl_ranks / rccl_rank / piece_bytes are properties, not counters) */
 int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out);
 
-/* Host-only: how one rank's all-to-all of `chunk_bytes` per peer is cut into sends of at most `piece_bytes` — the list the
- * built-in RCCL transport walks inside ONE ncclGroupStart / ncclGroupEnd (peer, byte offset inside the chunk, length; the
- * matching receive has the same three numbers).  Returns the number of pieces; fills at most `cap` entries of each array
- * (any may be NULL).  Test transports use the same list, so the loop is exercised without a second GPU. */
-int64_t qip_hip_dist_debug_pieces(int rank, int world, uint64_t chunk_bytes, uint64_t piece_bytes, uint64_t cap,
-                                  int32_t* peer, uint64_t* offset, uint64_t* length);
 
-/* Host-only (r5): which of that plan's remaps the overlapped exchange (option "dist_overlap" = `slices`) serves when the local
- * batches run as tile sweeps in scheduler mode `tile_mode` (1 / 2 = "tile", + 16 = wide tiles): JSON
- * {"remaps":[{"pack":0|1,"before":0|1,"after":0|1,"batch_sweeps_before":k}, ...]} — "before": the batch's last sweep is cut into
- * slices and the exchange starts beside it, "after": the next batch's first sweep awaits the slices one by one.  The predicate
- * the executor itself applies; tools/model_scaling.py prices the overlap with it.  NULL on error. */
-const char* qip_hip_dist_debug_overlap(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count, int tile_mode,
-                                       int slices);
 
-/* Host-only test hook: what rank `rank` of `world` would do for this circuit on a fresh state, as a JSON string
- * (owned by the library, valid until the calling thread's next call; NULL on error): the steps
- *   {"t":"local","op":{...}}   the op this rank applies to its shard, in LOCAL qubit indices
- *   {"t":"pack","sel":[...]}   gather these local bit positions into the top g positions (in this order)
- *   {"t":"exchange"}           all-to-all of the top g local bits with the g rank bits
- * and the final layout.  tests/test_distributed_cpu.py replays it with the CPU oracle as the shard and gloo as the
- * transport, so the planner and the per-rank localisation are covered without a GPU. */
-const char* qip_hip_dist_debug_plan(uint32_t n, int dtype, int rank, int world, const qip_op* ops, uint64_t count);
 
 #ifdef __cplusplus
 }

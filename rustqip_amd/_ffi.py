@@ -65,7 +65,8 @@ class QipJitCounters(C.Structure):
     """struct qip_hip_jit_counters (include/qip_hip.h)"""
     _fields_ = [("kernels_resident_total", C.c_uint64), ("compiled", C.c_uint64), ("compiled_by_helpers", C.c_uint64),
                 ("helper_processes", C.c_uint64), ("disk_hits", C.c_uint64), ("disk_stores", C.c_uint64),
-                ("compile_ms", C.c_double), ("disk_load_ms", C.c_double), ("procs", C.c_int32), ("disk_cache", C.c_int32)]
+                ("compile_ms", C.c_double), ("disk_load_ms", C.c_double), ("procs", C.c_int32), ("disk_cache", C.c_int32),
+                ("background_segments", C.c_uint64), ("disk_trimmed", C.c_uint64)]
 
 
 def jit_counters() -> dict:
@@ -98,7 +99,6 @@ SIGNATURES = {
     "qip_hip_state_swap_buffers": (_int, [_statep]),
     "qip_hip_state_sync": (_int, [_statep]),
     "qip_hip_state_permute_bits": (_int, [_statep, C.POINTER(C.c_uint32)]),
-    "qip_hip_debug_permute_plan": (_cp, [_u32, C.POINTER(C.c_uint32), _u32, _u32]),
     "qip_hip_state_apply_op": (_int, [_statep, _opp]),
     "qip_hip_state_apply_ops": (_int, [_statep, _opp, _u64]),
     "qip_hip_program_create": (_int, [_statep, _opp, _u64, C.POINTER(C.c_void_p)]),
@@ -106,9 +106,6 @@ SIGNATURES = {
     "qip_hip_program_is_graph": (_int, [C.c_void_p]),
     "qip_hip_program_destroy": (_int, [C.c_void_p]),
     "qip_hip_plan_tiles": (_int, [_int, _u32, _opp, _u64, _int, C.POINTER(C.c_int64), _u64p]),
-    "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
-    "qip_hip_debug_tile_plan": (_cp, [_int, _u32, _opp, _u64, _int]),
-    "qip_hip_debug_sparse_tile": (_cp, [_int, _u32, _opp]),
     "qip_hip_tile_bits": (_int, []),
     "qip_hip_jit_cache_info": (_int, [_u64p, _u64p, _u64p]),
     "qip_hip_jit_stats": (_int, [_u64p, _dblp]),
@@ -116,7 +113,6 @@ SIGNATURES = {
     "qip_hip_jit_set_cache_dir": (_int, [_cp]),
     "qip_hip_jit_cache_dir": (_cp, []),
     "qip_hip_jit_compile_file": (_int, [_cp, _int, _cp]),
-    "qip_hip_debug_tile_jit": (_int, [_int, _u32, _opp, _u64, _int, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p)]),
     "qip_hip_state_set_option": (_int, [_statep, _cp, _i64]),
     "qip_hip_kernel_class_count": (_int, []),
     "qip_hip_kernel_class_name": (_cp, [_int]),
@@ -148,6 +144,15 @@ SIGNATURES = {
     "qip_hip_dist_rank_flip": (_int, [_vp, C.POINTER(C.c_uint32)]),
     "qip_hip_dist_soft_measure": (_int, [_vp, _u64p, _u32, _dbl, _u64p]),
     "qip_hip_dist_take_stats": (_int, [_vp, C.POINTER(QipDistStats)]),
+}
+
+# the host-only test hooks of include/qip_hip_debug.h (not part of the binding contract: bindings do not mirror them)
+DEBUG_SIGNATURES = {
+    "qip_hip_debug_permute_plan": (_cp, [_u32, C.POINTER(C.c_uint32), _u32, _u32]),
+    "qip_hip_tile_lane_assignment": (_int, [_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "qip_hip_debug_tile_plan": (_cp, [_int, _u32, _opp, _u64, _int]),
+    "qip_hip_debug_sparse_tile": (_cp, [_int, _u32, _opp]),
+    "qip_hip_debug_tile_jit": (_int, [_int, _u32, _opp, _u64, _int, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p)]),
     "qip_hip_dist_debug_plan": (_cp, [_u32, _int, _int, _int, _opp, _u64]),
     "qip_hip_dist_debug_overlap": (_cp, [_u32, _int, _int, _int, _opp, _u64, _int, _int]),
     "qip_hip_dist_debug_pieces": (_i64, [_int, _int, _u64, _u64, _u64, C.POINTER(C.c_int32), _u64p, _u64p]),
@@ -161,7 +166,7 @@ def _load() -> C.CDLL:
             "(hipcc --offload-arch=gfx950). rustqip_amd has no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

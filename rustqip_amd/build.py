@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 # only exports are the C ABI (csrc/exports.map)
 UNITS = ["qip_core", "qip_launch", "qip_tile_sched", "qip_circuit", "qip_host", "qip_measure", "qip_dist"]
 HEADERS = [os.path.join(CSRC, h) for h in ("qip_kernels.h", "qip_internal.h", "qip_tile.h")] + [
-    os.path.join(HERE, "..", "include", "qip_hip.h")]
+    os.path.join(HERE, "..", "include", "qip_hip.h"), os.path.join(HERE, "..", "include", "qip_hip_debug.h")]
 OBJDIR = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "lib", "libqip_hip.so")
 JITC = os.path.join(HERE, "lib", "qip_jitc")
@@ -24,6 +24,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # aligned register pairs: in the f32 tile-sweep kernel that cost 180 VGPRs (2 waves per SIMD, 8.7 ms per sweep) against 90
 # without it; the kernels are bound by HBM or by instruction issue, never by f32 flops (profiles/r02_slp.md)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+# QIP_HIP_TUNING=1 at build time: the measured alternatives that the product build fixes at their defaults become options again
+# (csrc/qip_core.hip, "tuning options"): what tools/bench_ops.py, bench_tile.py, bench_permute.py switch for A/B runs
+if os.environ.get("QIP_HIP_TUNING"):
+    FLAGS.append("-DQIP_HIP_TUNING")
 LINK = ["--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
 LIBS = ["-ldl"]  # librccl and libhiprtc are dlopen-ed on first use (qip_dist.hip, qip_circuit.hip): no link-time dependency
 

@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include <cerrno>
+#include <dirent.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <spawn.h>
@@ -295,8 +296,16 @@ static int hiprtc_compile(const std::string& src, bool fma, std::vector<char>* c
 //  * every code object is kept under $QIP_HIP_CACHE_DIR (default $XDG_CACHE_HOME/qip_hip or ~/.cache/qip_hip; "off" or an
 //    empty value disables), named by a 128-bit hash of compiler version + flags + the embedded kernel header + the source text,
 //    written to a temporary name and renamed (readers never see half a file; two processes that compile the same segment just
-//    both succeed).  A second process loads instead of compiling: ~1 ms per segment.  The file carries the source length and the
-//    second hash word again, checked on load; anything odd is a miss, never an error.
+//    both succeed).  A second process loads instead of compiling: ~1 ms per segment.
+//  * r6, what is TRUSTED: a code object found on disk ends up on the GPU, so the cache only ever reads what this user wrote.
+//    The directory must be owned by the effective uid and writable by nobody else (an existing directory that is not: no disk
+//    cache — the default rule falls back to "none", qip_hip_jit_set_cache_dir reports the reason); a file must be a regular
+//    file (no symlink), owned by the uid, not group/world-writable; its header carries the source length, the second word of
+//    the key and a hash of the CODE BYTES, all checked on load.  Anything odd is a miss (and a recompilation that overwrites
+//    the file), never an error, never a load.  The key names the compiler by everything that can be asked of it at run time:
+//    hiprtc's version, the HIP runtime's version, the sizes of libhiprtc / libamd_comgr as loaded.
+//  * r6, bounded: after a store the directory is trimmed to "jit_disk_cap_mb" (global option; $QIP_HIP_CACHE_MAX_MB; default
+//    1024) — oldest modification time first (a hit refreshes it), stale temporaries with them.
 // ---------------------------------------------------------------------------------------
 int64_t g_jit_disk = 1;   // global option "jit_disk_cache"
 int64_t g_jit_procs = 0;  // global option "jit_procs": 0 = automatic (the CPUs this process may use, at most 16), 1 = in process only
@@ -305,6 +314,7 @@ static std::string g_jit_dir;           // resolved cache directory ("" = none)
 static bool g_jit_dir_resolved = false;
 static uint64_t g_jit_disk_hits = 0, g_jit_disk_stores = 0, g_jit_helper_procs = 0, g_jit_helper_segments = 0;
 static double g_jit_load_ms = 0;
+static uint64_t g_jit_background_segments = 0;  // segments handed to background helpers (option tile_auto, one-shot callers)
 
 struct JitHash {
   uint64_t a = 0, b = 0;
@@ -333,20 +343,39 @@ static uint64_t hash_mix(const char* p, size_t n, uint64_t h) {  // an independe
 static const char* jit_flags_text(bool fma) {
   return fma ? "gfx950 -O3 c++17 contract=fast no-slp" : "gfx950 -O3 c++17 contract=off no-slp";
 }
-static JitHash jit_hash(const std::string& src, bool fma) {
-  static JitHash base = [] {  // the embedded header and the compiler's version: once per process
-    JitHash h;
-    int major = 0, minor = 0;
-    (void)hiprtc_load();  // (the version is part of every key: always asked, so that keys do not depend on who hashes first)
-    if (g_rtc.handle) {
-      int (*ver)(int*, int*) = nullptr;
-      *(void**)(&ver) = dlsym(g_rtc.handle, "hiprtcVersion");
-      if (ver) (void)ver(&major, &minor);
+// everything about the compiler that can be asked at run time: hiprtc's version, the HIP runtime's version, and the byte sizes
+// of the two shared objects that do the work as this process has them loaded (an updated ROCm changes at least one of them)
+static std::string jit_compiler_identity() {
+  int major = 0, minor = 0, rt = 0;
+  long long sz_rtc = 0, sz_comgr = 0;
+  (void)hiprtc_load();  // (part of every key: always asked, so that keys do not depend on who hashes first)
+  if (g_rtc.handle) {
+    int (*ver)(int*, int*) = nullptr;
+    *(void**)(&ver) = dlsym(g_rtc.handle, "hiprtcVersion");
+    if (ver) (void)ver(&major, &minor);
+    Dl_info info;
+    struct stat st;
+    if (ver && dladdr((void*)ver, &info) && info.dli_fname && stat(info.dli_fname, &st) == 0) sz_rtc = (long long)st.st_size;
+    // (loaded here if hiprtc has not done so yet — it does lazily, at its first compilation: the key must not depend on that)
+    for (const char* name : {"libamd_comgr.so", "libamd_comgr.so.3", "/opt/rocm/lib/libamd_comgr.so"}) {
+      void* comgr = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (!comgr) continue;
+      void* sym = dlsym(comgr, "amd_comgr_get_version");
+      if (sym && dladdr(sym, &info) && info.dli_fname && stat(info.dli_fname, &st) == 0) sz_comgr = (long long)st.st_size;
+      break;  // (stays loaded: hiprtc needs it anyway)
     }
-    char v[64];
-    snprintf(v, sizeof v, "qipjit1 hiprtc %d.%d ", major, minor);
-    h.a = hash_fnv(v, strlen(v), 1469598103934665603ull);
-    h.b = hash_mix(v, strlen(v), 0x243F6A8885A308D3ull);
+  }
+  (void)hipRuntimeGetVersion(&rt);
+  char v[160];
+  snprintf(v, sizeof v, "qipjit2 hiprtc %d.%d runtime %d libhiprtc %lld comgr %lld ", major, minor, rt, sz_rtc, sz_comgr);
+  return v;
+}
+static JitHash jit_hash(const std::string& src, bool fma) {
+  static JitHash base = [] {  // the embedded header and the compiler's identity: once per process
+    JitHash h;
+    const std::string v = jit_compiler_identity();
+    h.a = hash_fnv(v.data(), v.size(), 1469598103934665603ull);
+    h.b = hash_mix(v.data(), v.size(), 0x243F6A8885A308D3ull);
     h.a = hash_fnv(kKernelsHeaderSrc, sizeof kKernelsHeaderSrc, h.a);
     h.b = hash_mix(kKernelsHeaderSrc, sizeof kKernelsHeaderSrc, h.b);
     return h;
@@ -366,6 +395,23 @@ static bool mkdir_p(const std::string& dir) {
   if (slash != std::string::npos && slash > 0 && !mkdir_p(dir.substr(0, slash))) return false;
   return mkdir(dir.c_str(), 0700) == 0 || (stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode));
 }
+// A cache directory is used only when it belongs to this user and nobody else can write to it: what it holds is loaded onto the GPU.
+static bool jit_dir_trusted(const std::string& dir, std::string* why) {
+  struct stat st;
+  if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) {
+    if (why) *why = "not a directory";
+    return false;
+  }
+  if (st.st_uid != geteuid()) {
+    if (why) *why = "not owned by this user";
+    return false;
+  }
+  if (st.st_mode & (S_IWGRP | S_IWOTH)) {
+    if (why) *why = "writable by group or others";
+    return false;
+  }
+  return access(dir.c_str(), W_OK | X_OK) == 0 || ((why ? (void)(*why = "not writable") : (void)0), false);
+}
 // under g_jit_mutex (or before any thread exists): where code objects are kept; "" = nowhere
 static const std::string& jit_dir_locked() {
   if (g_jit_dir_resolved) return g_jit_dir;
@@ -383,7 +429,7 @@ static const std::string& jit_dir_locked() {
     if (!home || !*home) return g_jit_dir;
     dir = std::string(home) + "/.cache/qip_hip";
   }
-  if (mkdir_p(dir) && access(dir.c_str(), W_OK | X_OK) == 0) g_jit_dir = dir;
+  if (mkdir_p(dir) && jit_dir_trusted(dir, nullptr)) g_jit_dir = dir;
   return g_jit_dir;
 }
 static std::string jit_disk_path(const std::string& dir, const JitHash& h) {
@@ -393,38 +439,116 @@ static std::string jit_disk_path(const std::string& dir, const JitHash& h) {
 }
 struct JitFileHeader {
   char magic[8];
-  uint64_t src_len, hash_b, code_len;
+  uint64_t src_len, hash_b, code_len, code_hash;
 };
+static uint64_t jit_code_hash(const char* p, size_t n) { return hash_mix(p, n, 0x13198A2E03707344ull ^ (uint64_t)n); }
 static bool jit_disk_read(const std::string& path, size_t src_len, const JitHash& h, std::vector<char>* code) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
   JitFileHeader hd;
-  bool ok = fread(&hd, sizeof hd, 1, f) == 1 && !memcmp(hd.magic, "QIPJIT1", 8) && hd.src_len == src_len && hd.hash_b == h.b &&
-            hd.code_len > 0 && hd.code_len < (1ull << 31);
+  auto read_all = [&](void* dst, size_t n) {
+    char* q = (char*)dst;
+    while (n) {
+      const ssize_t got = read(fd, q, n);
+      if (got < 0 && errno == EINTR) continue;
+      if (got <= 0) return false;
+      q += got;
+      n -= (size_t)got;
+    }
+    return true;
+  };
+  ok = ok && read_all(&hd, sizeof hd) && !memcmp(hd.magic, "QIPJIT2", 8) && hd.src_len == src_len && hd.hash_b == h.b && hd.code_len > 0 &&
+       hd.code_len < (1ull << 31) && (uint64_t)st.st_size == sizeof hd + hd.code_len;
   if (ok) {
     code->resize(hd.code_len);
-    ok = fread(code->data(), 1, hd.code_len, f) == hd.code_len && fgetc(f) == EOF;
+    ok = read_all(code->data(), hd.code_len) && jit_code_hash(code->data(), code->size()) == hd.code_hash;
   }
-  fclose(f);
+  if (ok) (void)futimens(fd, nullptr);  // a hit refreshes the modification time: the trim below drops the oldest first
+  close(fd);
   if (!ok) code->clear();
   return ok;
 }
+static std::atomic<unsigned> g_jit_tmp_serial{0};  // temporaries of one process never share a name (two handles may compile side by side)
+static int64_t g_jit_disk_cap_mb = -1;             // global option "jit_disk_cap_mb"; -1 = $QIP_HIP_CACHE_MAX_MB or 1024
+static uint64_t g_jit_disk_trimmed = 0;
 static bool jit_disk_write(const std::string& path, size_t src_len, const JitHash& h, const std::vector<char>& code) {
-  char suffix[48];
-  snprintf(suffix, sizeof suffix, ".tmp.%ld.%llx", (long)getpid(), (unsigned long long)(uintptr_t)&code);
+  char suffix[64];
+  snprintf(suffix, sizeof suffix, ".tmp.%ld.%u", (long)getpid(), g_jit_tmp_serial.fetch_add(1));
   const std::string tmp = path + suffix;
-  FILE* f = fopen(tmp.c_str(), "wb");
-  if (!f) return false;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return false;
   JitFileHeader hd;
-  memcpy(hd.magic, "QIPJIT1", 8);
+  memcpy(hd.magic, "QIPJIT2", 8);
   hd.src_len = src_len;
   hd.hash_b = h.b;
   hd.code_len = code.size();
-  bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
-  ok = fclose(f) == 0 && ok;
+  hd.code_hash = jit_code_hash(code.data(), code.size());
+  auto write_all = [&](const void* src, size_t n) {
+    const char* q = (const char*)src;
+    while (n) {
+      const ssize_t put = write(fd, q, n);
+      if (put < 0 && errno == EINTR) continue;
+      if (put <= 0) return false;
+      q += put;
+      n -= (size_t)put;
+    }
+    return true;
+  };
+  bool ok = write_all(&hd, sizeof hd) && write_all(code.data(), code.size());
+  ok = close(fd) == 0 && ok;
   if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
   if (!ok) (void)unlink(tmp.c_str());
   return ok;
+}
+// Keep the directory under its bound: code objects by modification time, oldest first, until 90 % of the bound is left; and the
+// temporaries (sources handed to helpers, half-written objects) that a killed process left behind more than an hour ago.
+static void jit_disk_trim(const std::string& dir) {
+  int64_t cap_mb = g_jit_disk_cap_mb;
+  if (cap_mb < 0) {
+    const char* e = getenv("QIP_HIP_CACHE_MAX_MB");
+    cap_mb = e && *e ? atoll(e) : 1024;
+  }
+  if (cap_mb <= 0 || dir.empty()) return;
+  DIR* d = opendir(dir.c_str());
+  if (!d) return;
+  struct Ent {
+    std::string name;
+    int64_t mtime_ns;
+    uint64_t size;
+  };
+  std::vector<Ent> objs;
+  uint64_t total = 0;
+  const time_t now = time(nullptr);
+  while (struct dirent* de = readdir(d)) {
+    const std::string name = de->d_name;
+    struct stat st;
+    if (name == "." || name == ".." || lstat((dir + "/" + name).c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+    const bool obj = name.size() > 3 && name.compare(name.size() - 3, 3, ".co") == 0;
+    if (obj) {
+      objs.push_back({name, (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec, (uint64_t)st.st_size});
+      total += (uint64_t)st.st_size;
+    } else if ((name.find(".co.tmp.") != std::string::npos || name.compare(0, 4, "seg.") == 0) && now - st.st_mtime > 3600) {
+      (void)unlink((dir + "/" + name).c_str());
+    }
+  }
+  closedir(d);
+  const uint64_t cap = (uint64_t)cap_mb << 20;
+  if (total <= cap) return;
+  std::sort(objs.begin(), objs.end(), [](const Ent& a, const Ent& b) { return a.mtime_ns < b.mtime_ns; });
+  for (const Ent& e : objs) {
+    if (total <= cap / 10 * 9) break;
+    if (unlink((dir + "/" + e.name).c_str()) == 0) {
+      total -= e.size;
+      g_jit_disk_trimmed += 1;
+    }
+  }
+}
+int jit_set_disk_cap_mb(int64_t mb) {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit_disk_cap_mb = mb;
+  return QIP_OK;
 }
 
 // Host only (no device): compile the segment source in `src_path` and leave the code object at `out_path` in the disk
@@ -484,7 +608,7 @@ static void jit_compile_in_helpers(const std::string& helper, const std::string&
   std::vector<size_t> written;
   for (size_t i : todo) {
     char name[64];
-    snprintf(name, sizeof name, "/seg.%ld.%zu.hip", (long)getpid(), i);
+    snprintf(name, sizeof name, "/seg.%ld.%u.%zu.hip", (long)getpid(), g_jit_tmp_serial.fetch_add(1), i);
     src_paths[i] = dir + name;
     FILE* f = fopen(src_paths[i].c_str(), "wb");
     if (!f) continue;
@@ -562,6 +686,8 @@ extern "C" int qip_hip_jit_stats2(qip_hip_jit_counters* out) try {
   out->disk_load_ms = g_jit_load_ms;
   out->procs = jit_procs_effective();
   out->disk_cache = (g_jit_disk && !jit_dir_locked().empty()) ? 1 : 0;
+  out->background_segments = g_jit_background_segments;
+  out->disk_trimmed = g_jit_disk_trimmed;
   return QIP_OK;
 } QIP_CATCH_ALL
 
@@ -580,7 +706,9 @@ extern "C" int qip_hip_jit_set_cache_dir(const char* dir) try {
     return QIP_OK;
   }
   const std::string d = dir;
-  if (!mkdir_p(d) || access(d.c_str(), W_OK | X_OK) != 0) return fail(QIP_ERR_INVALID, "cache directory %s cannot be created or written", dir);
+  std::string why = "cannot be created";
+  if (!mkdir_p(d) || !jit_dir_trusted(d, &why))
+    return fail(QIP_ERR_INVALID, "cache directory %s is not used: %s (code objects found there are loaded onto the GPU: the directory must belong to this user and be writable by nobody else)", dir, why.c_str());
   g_jit_dir = d;
   g_jit_dir_resolved = true;
   return QIP_OK;
@@ -1295,7 +1423,10 @@ static int jit_code_locked(const std::string& src, bool fma, std::vector<char>* 
   QCHK(hiprtc_compile(src, fma, code));
   g_jit_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   g_jit_compiles += 1;
-  if (!dir.empty() && jit_disk_write(path, src.size(), h, *code)) g_jit_disk_stores += 1;
+  if (!dir.empty() && jit_disk_write(path, src.size(), h, *code)) {
+    g_jit_disk_stores += 1;
+    jit_disk_trim(dir);
+  }
   return QIP_OK;
 }
 static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma, const std::function<int(hipFunction_t)>& launch) {
@@ -1313,7 +1444,7 @@ static int jit_get_and_launch(qip_hip_state* s, const std::string& src, bool fma
     std::vector<char> code;
     QCHK(jit_code_locked(src, fma, &code));
     QCHK(jit_insert_locked(s, key, code, &fn));
-    if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
+    if (!s->capture_pool && g_jit_captures_in_progress == 0) jit_evict_locked();  // (never the entry just inserted: it is the most recently used)
   }
   return launch ? launch(fn) : QIP_OK;
 }
@@ -1430,7 +1561,131 @@ static int jit_obtain_code(const std::vector<std::pair<std::string, bool>>& jobs
   g_jit_compiles += compiled_here + by_helpers;
   g_jit_disk_stores += stored + by_helpers;
   if (compiled_here + by_helpers) g_jit_compile_ms += compile_ms;
+  if (stored + by_helpers) jit_disk_trim(dir);
   return QIP_OK;
+}
+
+// ---- r6: compiled sweeps for one-shot callers, when they are free (option "tile_auto") -------------------------------------
+// apply_ops on a state with tile >= 1 and tile_jit = 0 is what a `calculate_state` caller issues (HipBuilder): once.  It does not
+// repay seconds of compilation — but a plan whose segments are ALL already resident or in the disk cache costs milliseconds to
+// load and runs 1.5x faster than the interpreter.  So such a call LOOKS its wide plan up (jit_load_only): all hits -> compiled
+// sweeps (bit-identical to the interpreter for tile = 1); any miss -> the interpreter runs now, and the missing segments are
+// handed to helper processes nobody waits for (jit_compile_in_background): the next call, or the next process, finds them.
+static constexpr int kJitMiss = -1001;  // internal status of a lookup-only pass (never crosses the ABI)
+static std::map<std::string, std::chrono::steady_clock::time_point> g_jit_inflight;  // object paths handed to background helpers
+static std::map<uint64_t, std::chrono::steady_clock::time_point> g_jit_cold_plans;   // plan fingerprints last seen incomplete
+
+// the jobs that are resident or on disk become resident; the others are returned in `misses` (nothing is compiled)
+static int jit_load_only(qip_hip_state* s, std::vector<std::pair<std::string, bool>>& jobs, std::vector<std::pair<std::string, bool>>* misses) {
+  {
+    std::vector<std::pair<std::string, bool>> uniq;
+    for (auto& j : jobs)
+      if (std::find(uniq.begin(), uniq.end(), j) == uniq.end()) uniq.push_back(std::move(j));
+    jobs.swap(uniq);
+  }
+  std::string dir;
+  {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    if (g_jit_disk) dir = jit_dir_locked();
+  }
+  std::vector<std::vector<char>> code(jobs.size());
+  std::vector<char> hit(jobs.size(), 0);
+  uint64_t hits = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < jobs.size() && !dir.empty(); ++i) {
+    const JitHash h = jit_hash(jobs[i].first, jobs[i].second);
+    if (jit_disk_read(jit_disk_path(dir, h), jobs[i].first.size(), h, &code[i])) {
+      hit[i] = 1;
+      hits += 1;
+    }
+  }
+  const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (size_t i = 0; i < jobs.size(); ++i)
+    if (!hit[i]) misses->push_back(jobs[i]);
+  if (!misses->empty()) return QIP_OK;  // (a partial plan is of no use: nothing is loaded onto the device)
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit_disk_hits += hits;
+  g_jit_load_ms += load_ms;
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    const std::string key = jit_key(s, jobs[i].first, jobs[i].second);
+    if (g_jit_cache.find(key) != g_jit_cache.end()) continue;
+    QCHK(jit_insert_locked(s, key, code[i], nullptr));
+  }
+  if (!s->capture_pool && g_jit_captures_in_progress == 0) jit_evict_locked();
+  return QIP_OK;
+}
+
+// Hand `jobs` to helper processes and return at once.  The helpers write the code objects into the disk cache and remove their
+// own source files (qip_jitc -u); a detached thread reaps them (it touches nothing of this library).  Jobs handed out less than
+// two minutes ago are not handed out again.
+static void jit_compile_in_background(const std::vector<std::pair<std::string, bool>>& jobs) {
+  std::string dir, helper;
+  int procs = 1;
+  std::vector<size_t> todo;
+  std::vector<std::string> out_paths(jobs.size());
+  {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    if (g_jit_disk) dir = jit_dir_locked();
+    if (dir.empty()) return;  // nowhere to leave the results
+    procs = jit_procs_effective();
+    const auto now = std::chrono::steady_clock::now();
+    for (auto it = g_jit_inflight.begin(); it != g_jit_inflight.end();)
+      it = now - it->second > std::chrono::seconds(120) ? g_jit_inflight.erase(it) : std::next(it);
+    for (size_t i = 0; i < jobs.size(); ++i) {
+      out_paths[i] = jit_disk_path(dir, jit_hash(jobs[i].first, jobs[i].second));
+      if (g_jit_inflight.count(out_paths[i])) continue;
+      g_jit_inflight[out_paths[i]] = now;
+      todo.push_back(i);
+    }
+    g_jit_background_segments += todo.size();
+  }
+  if (todo.empty()) return;
+  helper = jit_helper_path();
+  if (helper.empty()) return;
+  std::vector<std::string> src_paths(jobs.size());
+  std::vector<size_t> written;
+  for (size_t i : todo) {
+    char name[64];
+    snprintf(name, sizeof name, "/seg.%ld.%u.%zu.hip", (long)getpid(), g_jit_tmp_serial.fetch_add(1), i);
+    src_paths[i] = dir + name;
+    const int fd = open(src_paths[i].c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) continue;
+    const bool ok = write(fd, jobs[i].first.data(), jobs[i].first.size()) == (ssize_t)jobs[i].first.size();
+    if (close(fd) == 0 && ok) written.push_back(i);
+    else (void)unlink(src_paths[i].c_str());
+  }
+  // (half of the usual share: the caller's own sweeps are running on this host's cores' attention too)
+  const size_t np = std::min<size_t>((size_t)std::max(1, procs / 2), written.size());
+  std::vector<pid_t> pids;
+  for (size_t k = 0; k < np; ++k) {
+    std::vector<std::string> args = {helper, "-u"};
+    for (size_t j = k; j < written.size(); j += np) {
+      const size_t i = written[j];
+      args.push_back(jobs[i].second ? "1" : "0");
+      args.push_back(src_paths[i]);
+      args.push_back(out_paths[i]);
+    }
+    std::vector<char*> argv;
+    for (std::string& a : args) argv.push_back(&a[0]);
+    argv.push_back(nullptr);
+    pid_t pid = 0;
+    if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) pids.push_back(pid);
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    g_jit_helper_procs += pids.size();
+  }
+  if (pids.empty()) {
+    for (size_t i : written) (void)unlink(src_paths[i].c_str());
+    return;
+  }
+  std::thread([pids]() {
+    for (pid_t pid : pids) {
+      int status = 0;
+      while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+      }
+    }
+  }).detach();
 }
 static int jit_compile_collected(qip_hip_state* s, std::vector<std::pair<std::string, bool>>& jobs) {
   {  // the same segment twice in one plan: once
@@ -1448,7 +1703,7 @@ static int jit_compile_collected(qip_hip_state* s, std::vector<std::pair<std::st
     if (g_jit_cache.find(key) != g_jit_cache.end()) continue;  // (another thread's handle got there first)
     QCHK(jit_insert_locked(s, key, code[i], nullptr));
   }
-  if (!s->capture_staging && g_jit_captures_in_progress == 0) jit_evict_locked();
+  if (!s->capture_pool && g_jit_captures_in_progress == 0) jit_evict_locked();
   return QIP_OK;
 }
 
@@ -1462,6 +1717,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   // `grid_ctl` (one-op sweeps): control positions OUTSIDE the tile that are taken off the grid — only the blocks whose base
   // reads 1 there are launched, so a controlled gate sweeps half / a quarter of the vector like the dedicated kernels do
   // (the kernel's own test of `omask` against the block's base then always passes).  `alg_bytes`: what the profile credits.
+  arena_begin_group(s);
   TileSegmentPlan<T> plan;
   QCHK(build_tile_segment<T>(s->n, s->tile_passes != 0, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1, p5_override));
   const std::vector<uint32_t>& high = plan.high;
@@ -1509,13 +1765,13 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
   // the gathered positions is a lane position of this tile) and the second buffer; otherwise the sweep runs as usual and the
   // remap gathers by itself
   if (!fold && s->fold_now && s->fold_request && !s->fold_done) fold = s->fold_request;
-  bool folding = fold && fold->g && s->tile_passes && (!grid_ctl || grid_ctl->empty()) && !s->capture_staging && !s->jit_prepare;
+  bool folding = fold && fold->g && s->tile_passes && (!grid_ctl || grid_ctl->empty()) && !s->capture_pool && !s->jit_prepare;
   if (folding)
     for (uint32_t t = 0; t < fold->g; ++t) folding = folding && !tile_is_low(fold->sel[t], plan.p5);
   if (folding) QCHK(ensure_alt(s));
   // r5: the sweep in 2^nbits parts (TileSlicing, qip_internal.h) — the slice positions must be block-index bits of this sweep
   // (not tile positions, not positions taken off the grid), above the rows, and with `need_fold` the store must really be packed
-  TileSlicing* sl = (s->capture_staging || s->jit_prepare) ? nullptr : s->slice_now;
+  TileSlicing* sl = (s->capture_pool || s->jit_prepare) ? nullptr : s->slice_now;
   bool slicing = sl && sl->nbits >= 1 && sl->nbits <= 3 && s->tile_passes && (!grid_ctl || grid_ctl->empty()) && (!sl->need_fold || folding) &&
                  !(sl->in_place_only && folding) && s->n >= (uint32_t)kTileBits + sl->nbits;
   if (slicing)
@@ -1665,6 +1921,7 @@ static int launch_tile_segment(qip_hip_state* s, const std::vector<const TileIte
 // a multi-gate step of a wide plan (option "tile_wide"): always its own run-time-compiled kernel
 template <typename T>
 static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileItem*>& seg, std::vector<uint32_t> high_in) {
+  arena_begin_group(s);
   WidePlan<T> plan;
   QCHK(build_wide_segment<T>(s->n, seg, std::move(high_in), &plan, s->tile >= 2 ? 2 : 1));
   const Ins ins = tile_ins(plan.high, plan.p5);
@@ -1675,12 +1932,12 @@ static int launch_wide_segment(qip_hip_state* s, const std::vector<const TileIte
   // r5: a packed store (the multi-GPU remap's gather rides in this sweep, TileStorePerm) under the same conditions as the 11-bit
   // sweeps: none of the gathered positions is a lane position of the tile, the second buffer exists
   const TileStorePerm* fold = (s->fold_now && s->fold_request && !s->fold_done) ? s->fold_request : nullptr;
-  bool folding = fold && fold->g && !s->capture_staging && !s->jit_prepare;
+  bool folding = fold && fold->g && !s->capture_pool && !s->jit_prepare;
   if (folding)
     for (uint32_t t = 0; t < fold->g; ++t) folding = folding && !tile_is_low(fold->sel[t], plan.p5);
   if (folding) QCHK(ensure_alt(s));
   // r5: the sweep in parts (TileSlicing: the sharded state's exchange overlaps with it)
-  TileSlicing* sl = (s->capture_staging || s->jit_prepare) ? nullptr : s->slice_now;
+  TileSlicing* sl = (s->capture_pool || s->jit_prepare) ? nullptr : s->slice_now;
   bool slicing = sl && sl->nbits >= 1 && sl->nbits <= 3 && (!sl->need_fold || folding) && !(sl->in_place_only && folding) &&
                  s->n >= (uint32_t)kWideBits + sl->nbits;
   if (slicing)
@@ -1920,7 +2177,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   // tile_relabel = 3: the qubit layout persists across calls — the plan starts from the layout the previous call left and
   // does not close with the restoring sweep (that happens once, when somebody needs the caller's order: state_settle).
   // Not inside a graph capture or a compile-only pass: a recorded program must start and end in the caller's order.
-  const bool persist = s->tile_relabel >= 3 && !s->capture_staging && !s->jit_prepare;
+  const bool persist = s->tile_relabel >= 3 && !s->capture_pool && !s->jit_prepare;
   if (!persist && !s->layout.empty()) QCHK(state_settle(s));
   sc.init_phys = s->layout;
   sc.keep_layout = persist;
@@ -1961,7 +2218,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
   // up in the disk cache, and the rest compiled side by side in helper processes (jit_compile_collected) before anything runs.
   // A plan that has been through this once is remembered by a fingerprint of its structure, so the steady state (the same
   // circuit applied again and again) does not generate every source twice.
-  if (s->tile_jit && s->tile_passes && !s->capture_staging) {
+  if (s->tile_jit && s->tile_passes && !s->capture_pool) {
     uint64_t fp = 1469598103934665603ull;
     auto mix = [&](uint64_t v) {
       fp ^= v;
@@ -1987,6 +2244,10 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     {
       std::lock_guard<std::mutex> lock(g_jit_mutex);
       warm = g_jit_warm_plans.count(fp) != 0 && g_jit_warm_generation == g_jit_generation;
+      if (!warm && s->jit_lookup_only) {  // a plan seen incomplete a moment ago: its segments are still being compiled, do not look again yet
+        auto it = g_jit_cold_plans.find(fp);
+        if (it != g_jit_cold_plans.end() && std::chrono::steady_clock::now() - it->second < std::chrono::milliseconds(1500)) return kJitMiss;
+      }
     }
     if (!warm) {
       std::vector<std::pair<std::string, bool>> jobs;
@@ -2004,7 +2265,19 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
       s->jit_prepare = outer_prepare;
       s->jit_collect = nullptr;
       QCHK(rc);
-      QCHK(jit_compile_collected(s, jobs));
+      if (s->jit_lookup_only) {
+        std::vector<std::pair<std::string, bool>> misses;
+        QCHK(jit_load_only(s, jobs, &misses));
+        if (!misses.empty()) {
+          jit_compile_in_background(misses);
+          std::lock_guard<std::mutex> lock(g_jit_mutex);
+          if (g_jit_cold_plans.size() > 1024) g_jit_cold_plans.clear();
+          g_jit_cold_plans[fp] = std::chrono::steady_clock::now();
+          return kJitMiss;  // (nothing has run, the layout is untouched)
+        }
+      } else {
+        QCHK(jit_compile_collected(s, jobs));
+      }
       std::lock_guard<std::mutex> lock(g_jit_mutex);
       if (g_jit_warm_generation != g_jit_generation || g_jit_warm_plans.size() > 4096) {  // (an eviction may have dropped what a warm plan needs)
         g_jit_warm_plans.clear();
@@ -2024,7 +2297,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
     size_t step_no = 0;
     // a first-step request that no step can take (an empty plan; one step that already serves the last-step request) is settled
     // BEFORE anything is enqueued: its fallback is what makes the data the batch reads complete
-    if (s->slice_first && !s->jit_prepare && !s->capture_staging && (sc.steps.empty() || (sc.steps.size() == 1 && s->slice_last && ends_in_callers_order))) {
+    if (s->slice_first && !s->jit_prepare && !s->capture_pool && (sc.steps.empty() || (sc.steps.size() == 1 && s->slice_last && ends_in_callers_order))) {
       TileSlicing* w = s->slice_first;
       s->slice_first = nullptr;
       if (w->fallback) QCHK(w->fallback());
@@ -2036,7 +2309,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
       // only a plan that starts / ends in the caller's order may take the request.  A step that is not a multi-gate tile sweep
       // (or a sweep that cannot be cut there) consumes it through its fallback.
       TileSlicing* want = nullptr;
-      if (!s->jit_prepare && !s->capture_staging) {
+      if (!s->jit_prepare && !s->capture_pool) {
         if (step_no == sc.steps.size() && s->slice_last && ends_in_callers_order) want = s->slice_last;
         else if (step_no == 1 && s->slice_first && sc.init_phys.empty() && sc.inserted == 0 && sc.absorbed == 0) want = s->slice_first;
         else if (step_no == 1 && s->slice_first) {  // (a relabelled plan addresses other positions: settle the request unsliced)
@@ -2046,7 +2319,7 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
         }
       }
       TileSlicing dbg;
-      if (!want && g_debug_slice_sweeps >= 2 && !s->jit_prepare && !s->capture_staging && st.perm.empty() && st.ops.size() >= 2) {
+      if (!want && g_debug_slice_sweeps >= 2 && !s->jit_prepare && !s->capture_pool && st.perm.empty() && st.ops.size() >= 2) {
         // measuring aid (global option "debug_slice_sweeps" = 2 / 4 / 8): EVERY multi-gate sweep in that many parts, cut at the highest
         // index positions its tile leaves alone — what a sliced launch costs by itself, at full size on one GPU, without any exchange
         uint32_t pb = 0;
@@ -2101,9 +2374,26 @@ static int apply_ops_tiled(qip_hip_state* s, const qip_op* ops_in, uint64_t coun
 extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint64_t count) try {
   STATE_ENTER_RAW(s);  // (a relabelled state stays relabelled for a relabelling batch: apply_ops_tiled decides)
   if (count && !ops) return fail(QIP_ERR_INVALID, "null op array");
-  if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits)
+  if (s->tile >= 1 && !s->force_generic && !g_force_generic && s->n >= (uint32_t)kTileBits) {
+    // r6, option "tile_auto" for one-shot callers: the compiled (wide) sweeps when every segment of the plan is already resident
+    // or in the disk cache; otherwise the interpreter now, the misses compiled in the background for the next call.  Not for the
+    // batches of a sharded state that carry a fold / slice request (their last sweep is chosen by the exchange), not while a
+    // program records or pre-compiles (it compiles for itself).
+    if (s->tile_auto && !s->tile_jit && s->tile_passes && s->n >= (uint32_t)kAutoJitMinQubits && count >= 2 && !s->capture_pool && !s->jit_prepare &&
+        !s->fold_request && !s->slice_first && !s->slice_last && !s->profile && g_jit_disk) {
+      const int64_t wide0 = s->tile_wide;
+      s->tile_jit = 1;
+      s->tile_wide = s->n > (uint32_t)kWideBits ? 1 : 0;
+      s->jit_lookup_only = true;
+      const int rc = s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2) : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
+      s->jit_lookup_only = false;
+      s->tile_jit = 0;
+      s->tile_wide = wide0;
+      if (rc != kJitMiss) return rc;
+    }
     return s->dtype == QIP_C64 ? apply_ops_tiled<double>(s, ops, count, s->tile >= 2)
                                : apply_ops_tiled<float>(s, ops, count, s->tile >= 2);
+  }
   if (s->slice_first) {  // (only tile sweeps run in parts: every other path settles the request before its first launch)
     TileSlicing* w = s->slice_first;
     s->slice_first = nullptr;
@@ -2121,7 +2411,7 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     // (T on bit 0: 41 %, CNOT with its control inside a row: 40 %, profiles/r02_line_bits.md).  When such a gate and its
     // neighbour fit one tile they go as ONE two-item tile sweep (interpreter kernel, circuit order: the same unfused arithmetic
     // per amplitude, IEEE-equal to the two launches) — the neighbour rides for free.  Everything else stays one launch per gate.
-    if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_staging && !s->force_generic &&
+    if (s->pair_floor && i + 1 < count && s->n >= (uint32_t)kPairFloorMinQubits && s->tile_passes && !s->capture_pool && !s->force_generic &&
         !g_force_generic) {
       // What the two launches move, in sweeps of the whole vector: a gate's algorithmic share, doubled for every selector
       // inside a wave row (whole lines / rows travel whichever half is needed), at most 1.  One two-item sweep moves 1 (and runs
@@ -2189,18 +2479,27 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
 } QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
-// programs: a circuit captured once into a hipGraph and replayed with one launch
+// programs: a circuit PREPARED once — every op's tables packed and resident in device memory the program owns — and
+// recorded into a hipGraph: a run is one graph launch of kernel nodes only (nothing is packed, uploaded or decided again).
+// Ops that write the second buffer (the literal gather, k_sparse_ell, bit-permutation sweeps) are recorded like the rest:
+// the ping-pong is deterministic, so a program keeps one recording per starting buffer (at most two) and follows the
+// buffers on the host after every launch, the way the reference swaps `state` and `arena` (builder.rs:514).
 // ---------------------------------------------------------------------------------------
+struct ProgRecording {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  void *start_cur = nullptr, *start_alt = nullptr;  // the buffers the recording reads first / writes first
+  bool swaps = false;                                // an odd number of out-of-place launches: the buffers end exchanged
+  bool uses_alt = false;                             // some launch writes the second buffer
+  ProgPool pool;                                     // the device copy of the ops' payloads
+  uint64_t jit_gen = 0;                              // run-time-compiled kernels the cache may since have unloaded
+};
 struct qip_hip_program {
   qip_hip_state* s = nullptr;
   const qip_op* ops = nullptr;
   uint64_t count = 0;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  void* captured_cur = nullptr;
-  uint64_t captured_arena_gen = 0;  // the graph's memcpy / kernel nodes hold arena addresses
-  uint64_t captured_jit_gen = 0;    // ... and run-time-compiled kernels the cache may since have unloaded
-  std::deque<std::vector<char>> staging;  // payloads the graph's memcpy nodes read at every replay
+  ProgRecording rec[2];
+  bool capture_failed = false;  // an obstacle that will not go away (profile / force_generic aside): stay eager, do not retry every run
   int last_was_graph = 0;
   // r5, option "tile_auto": a program is made to be replayed, so it repays a compilation — created on a state with tile >= 1 and
   // tile_jit = 0 (the interpreter, what apply_ops keeps using) it runs its own launches with run-time-compiled wide segments.
@@ -2227,7 +2526,15 @@ struct ProgramOptions {
   }
 };
 
-static void program_drop_graph(qip_hip_program* p);
+static void recording_drop(ProgRecording* r) {
+  if (r->exec) (void)hipGraphExecDestroy(r->exec);
+  if (r->graph) (void)hipGraphDestroy(r->graph);
+  if (r->pool.base) (void)hipFree(r->pool.base);
+  *r = ProgRecording();
+}
+static void program_drop_graph(qip_hip_program* p) {
+  for (ProgRecording& r : p->rec) recording_drop(&r);
+}
 void programs_orphan(qip_hip_state* s) {
   for (qip_hip_program* p : s->programs) {
     program_drop_graph(p);
@@ -2236,38 +2543,36 @@ void programs_orphan(qip_hip_state* s) {
   s->programs.clear();
 }
 
-static void program_drop_graph(qip_hip_program* p) {
-  if (p->exec) (void)hipGraphExecDestroy(p->exec);
-  if (p->graph) (void)hipGraphDestroy(p->graph);
-  p->exec = nullptr;
-  p->graph = nullptr;
-  p->staging.clear();
-}
-
-// Try to capture; on any obstacle leave the program in eager mode (exec == nullptr) and report success.
-static int program_capture(qip_hip_program* p) {
+// Record the program for the state's CURRENT buffers into `r`; on any obstacle leave `r` empty (the run is eager then) and report
+// success — only a real descriptor error is returned.
+static int program_capture(qip_hip_program* p, ProgRecording* r) {
   qip_hip_state* s = p->s;
   ProgramOptions scope(p);
-  program_drop_graph(p);
+  recording_drop(r);
   if (s->force_generic || g_force_generic || s->profile) return QIP_OK;
-  // an op on the out-of-place path would swap the buffers under the graph: stay eager
-  for (uint64_t i = 0; i < p->count; ++i) {
+  if (!s->stream) return QIP_OK;  // (the legacy default stream of a wrapped state cannot be captured)
+  // the second buffer must exist BEFORE the recording starts (no allocation inside a stream capture): ask for it when any launch
+  // of the plan writes out of place; a state too large for it stays eager (and fails there with the allocation's own message)
+  bool out_of_place = false;
+  for (uint64_t i = 0; i < p->count && !out_of_place; ++i) {
     FlatOp f;
     QCHK(flatten_op(s->n, &p->ops[i], false, &f));
     Plan pl;
     QCHK(make_plan(s->dtype, s->n, f, false, &pl));
-    const bool f64 = s->dtype == QIP_C64;
     const uint32_t k = f.n_op;
-    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxBigK && s->n >= f.k_all + 4));  // (k = 9, 10 upload 8 - 32 MiB of fragments and synchronise: eager)
-    (void)f64;
-    if (pl.cls == KC_GATHER_GENERIC && sparse_tile_applies(s, pl, f)) continue;  // (r4: in place through k_sparse_tile)
-    if (pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma)) return QIP_OK;
+    const bool reg_or_mfma = pl.cls == KC_GATE_KQ && (k <= kMaxRegK || (s->mfma && k <= kMaxHugeK && s->n >= f.k_all + 4));
+    if (pl.cls == KC_GATHER_GENERIC && sparse_tile_applies(s, pl, f)) continue;  // (in place through k_sparse_tile)
+    out_of_place = pl.cls == KC_GATHER_GENERIC || (pl.cls == KC_GATE_KQ && !reg_or_mfma);
   }
-  if (s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too
+  if (!out_of_place && s->tile >= 1 && s->n >= (uint32_t)kTileBits) {  // a bit-permutation sweep is out of place too
     TileSchedule sc;
     QCHK(make_tile_schedule(s->dtype, s->n, p->ops, p->count, tile_mode_of(s), s->tile_passes != 0, &sc));
-    for (const TileStep& st : sc.steps)
-      if (!st.perm.empty()) return QIP_OK;
+    for (const TileStep& st : sc.steps) out_of_place = out_of_place || !st.perm.empty();
+  }
+  if (out_of_place && !s->alt && ensure_alt(s) != QIP_OK) {
+    (void)hipGetLastError();
+    p->capture_failed = true;
+    return QIP_OK;
   }
   if (s->tile >= 1 && s->tile_jit) {  // run-time compilation cannot happen inside a stream capture: do it now
     s->jit_prepare = s->jit_for_capture = true;
@@ -2275,46 +2580,82 @@ static int program_capture(qip_hip_program* p) {
     s->jit_prepare = s->jit_for_capture = false;
     QCHK(rc);
   }
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    s->capture_arena_need = 0;
+  void* const arena0 = s->arena;
+  const size_t arena_cap0 = s->arena_cap;
+  void *const cur0 = s->cur, *const alt0 = s->alt;
+  const bool owns_cur0 = s->owns_cur, owns_alt0 = s->owns_alt;
+  ProgPool& pool = r->pool;
+  int result = QIP_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (!pool.base) {
+      pool.cap = std::max<size_t>(pool.cap, 1 << 16);
+      if (hipMalloc(&pool.base, pool.cap) != hipSuccess) {
+        (void)hipGetLastError();
+        pool = ProgPool();
+        p->capture_failed = true;
+        break;
+      }
+    }
+    pool.used = 0;
+    pool.overflow = false;
+    pool.image.clear();
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
       (void)hipGetLastError();
-      return QIP_OK;
+      p->capture_failed = true;
+      break;
     }
-    s->capture_staging = &p->staging;
+    s->capture_pool = &pool;
     jit_capture_scope(+1);
-    int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
-    s->capture_staging = nullptr;
+    const int rc = qip_hip_state_apply_ops(s, p->ops, p->count);
+    s->capture_pool = nullptr;
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s->stream, &g);
     jit_capture_scope(-1);
-    if (rc == QIP_OK && e == hipSuccess && g) {
-      if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) == hipSuccess) {
-        p->graph = g;
-        p->captured_cur = s->cur;
-        p->captured_arena_gen = s->arena_gen;
-        p->captured_jit_gen = jit_cache_generation();
+    // the recording ISSUED nothing: the host's view of the buffers goes back to where it was (the launch will move it)
+    const bool swapped = s->cur != cur0;
+    s->cur = cur0;
+    s->alt = alt0;
+    s->owns_cur = owns_cur0;
+    s->owns_alt = owns_alt0;
+    s->arena = arena0;
+    s->arena_cap = arena_cap0;
+    if (rc == QIP_OK && e == hipSuccess && g && !pool.overflow) {
+      bool ok = true;
+      if (pool.used) {
+        pool.image.resize(pool.used);
+        ok = hipMemcpy(pool.base, pool.image.data(), pool.used, hipMemcpyHostToDevice) == hipSuccess;
+      }
+      pool.image.clear();
+      pool.image.shrink_to_fit();
+      if (ok && hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+        r->graph = g;
+        r->start_cur = cur0;
+        r->start_alt = alt0;
+        r->swaps = swapped;
+        r->uses_alt = out_of_place;
+        r->jit_gen = jit_cache_generation();
         return QIP_OK;
       }
       (void)hipGetLastError();
       (void)hipGraphDestroy(g);
-      p->exec = nullptr;
-      p->staging.clear();
-      return QIP_OK;
+      r->exec = nullptr;
+      p->capture_failed = true;
+      break;
     }
     if (g) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
-    p->staging.clear();
-    if (s->capture_arena_need > s->arena_cap) {  // grow outside the capture, then retry
-      const size_t need = s->capture_arena_need;
-      s->capture_arena_need = 0;
-      QCHK(ensure_arena(s, need));
+    if (rc == QIP_OK && e == hipSuccess && pool.overflow) {  // the sizing pass: now the pool's size is known — once more
+      (void)hipFree(pool.base);
+      pool.base = nullptr;
+      pool.cap = pool.used + 4096;
       continue;
     }
-    if (rc != QIP_OK && rc != QIP_ERR_UNSUPPORTED) return rc;  // a real descriptor error
-    return QIP_OK;
+    if (rc != QIP_OK && rc != QIP_ERR_UNSUPPORTED) result = rc;  // a real descriptor error
+    else p->capture_failed = true;
+    break;
   }
-  return QIP_OK;
+  recording_drop(r);
+  return result;
 }
 
 extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint64_t count,
@@ -2337,8 +2678,17 @@ extern "C" int qip_hip_program_create(qip_hip_state* s, const qip_op* ops, uint6
     p->auto_jit = true;
     p->auto_wide = s->n > (uint32_t)kWideBits;  // (dense 3-qubit items included since they are written out group by group: tile_wide_dense3_inline)
   }
-  int rc = program_capture(p);
+  int rc = program_capture(p, &p->rec[0]);
+  if (rc != QIP_OK && p->auto_jit) {
+    // the automatic choice must not turn a compiler problem (libhiprtc missing, a hiprtc error on one segment) into a
+    // failed program_create — without it the interpreter would have served.  Drop the automatic options and record again with the
+    // state's own; only options the CALLER set propagate their errors.
+    p->auto_jit = p->auto_wide = false;
+    p->capture_failed = false;
+    rc = program_capture(p, &p->rec[0]);
+  }
   if (rc != QIP_OK) {
+    program_drop_graph(p);
     delete p;
     return rc;
   }
@@ -2353,31 +2703,41 @@ extern "C" int qip_hip_program_run(qip_hip_program* p) try {
   if (!s) return fail(QIP_ERR_INVALID, "the state this program was recorded against has been destroyed");
   STATE_ENTER(s);
   ProgramOptions scope(p);
-  if (p->exec && (p->captured_cur != s->cur || p->captured_arena_gen != s->arena_gen ||
-                  (s->tile_jit && p->captured_jit_gen != jit_cache_generation()) || s->profile || s->force_generic || g_force_generic)) {
-    if (s->profile || s->force_generic || g_force_generic) program_drop_graph(p);
-    else QCHK(program_capture(p));  // the state moved to its other buffer, or the arena was re-allocated (an eager op
-                                    // needed a larger payload): the recorded addresses are stale, re-record
+  if (s->profile || s->force_generic || g_force_generic) {  // (profiling brackets every kernel with events; the literal kernel is a test route)
+    p->last_was_graph = 0;
+    return qip_hip_state_apply_ops(s, p->ops, p->count);
   }
-  if (p->exec) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // the recording made for the buffers as they are now; none yet (the previous run left the state on its other buffer, an eager
+    // op exchanged them): record into the free slot, or over the one that does not start here
+    ProgRecording* r = nullptr;
+    for (ProgRecording& c : p->rec)
+      if (c.exec && c.start_cur == s->cur && (!c.uses_alt || c.start_alt == s->alt)) r = &c;
+    if (!r) {
+      if (p->capture_failed) break;
+      ProgRecording* slot = !p->rec[0].exec ? &p->rec[0] : (!p->rec[1].exec ? &p->rec[1] : (p->rec[0].start_cur == s->alt ? &p->rec[1] : &p->rec[0]));
+      QCHK(program_capture(p, slot));
+      if (!slot->exec) break;
+      r = slot;
+    }
     // generation check and launch in ONE critical section: an eviction on another thread between the two would unload a
     // module this graph names.  Enqueueing is asynchronous: the section is microseconds.
     bool stale = false;
     {
       std::lock_guard<std::mutex> lock(g_jit_mutex);
-      stale = s->tile_jit && p->captured_jit_gen != g_jit_generation;
-      if (!stale) HIPCHK(hipGraphLaunch(p->exec, s->stream));
+      stale = s->tile_jit && r->jit_gen != g_jit_generation;
+      if (!stale) HIPCHK(hipGraphLaunch(r->exec, s->stream));
     }
-    if (!stale) {
-      p->last_was_graph = 1;
-      return QIP_OK;
+    if (stale) {
+      recording_drop(r);
+      continue;
     }
-    QCHK(program_capture(p));
-    if (p->exec) {
-      HIPCHK(hipGraphLaunch(p->exec, s->stream));
-      p->last_was_graph = 1;
-      return QIP_OK;
+    if (r->swaps) {  // builder.rs:514
+      std::swap(s->cur, s->alt);
+      std::swap(s->owns_cur, s->owns_alt);
     }
+    p->last_was_graph = 1;
+    return QIP_OK;
   }
   p->last_was_graph = 0;
   return qip_hip_state_apply_ops(s, p->ops, p->count);
@@ -2397,4 +2757,3 @@ extern "C" int qip_hip_program_destroy(qip_hip_program* p) try {
   delete p;
   return QIP_OK;
 } QIP_CATCH_ALL
-

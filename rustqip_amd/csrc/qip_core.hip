@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 6; }  // 6: + jit_stats2 / jit_set_cache_dir / jit_cache_dir / jit_compile_file, options jit_disk_cache / jit_procs / tile_auto; 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
+extern "C" int qip_hip_abi_version(void) { return 7; }  // 7: programs own device-resident payloads and record out-of-place ops (one graph per buffer parity), jit counters + background_segments / disk_trimmed, option jit_disk_cap_mb, debug hooks in qip_hip_debug.h; 6: + jit_stats2 / jit_set_cache_dir / jit_cache_dir / jit_compile_file, options jit_disk_cache / jit_procs / tile_auto; 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {
@@ -47,64 +47,74 @@ int64_t g_tile_pad_from = 11, g_tile_wave_rule = 1, g_tile_remap = 0, g_tile_sch
 // split form brings EVERY choice of the five high positions to 5.3 - 5.9 ms per light sweep at n = 30 (contiguous: 5.3 - 8.6).
 int64_t g_tile_row_split = 11, g_tile_row_split_f32 = 5;
 int64_t g_single_via_tile = 3, g_single_via_tile_f32 = 3;
-int64_t g_force_k4_direct = 0;  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+int64_t g_force_k4_direct = 0;
+int64_t g_collective_timeout_s = 120;  // global option "collective_timeout_s" (qip_dist.hip: how long a rank waits for an exchange)  // row bits of k_permute_bits for 16-byte elements: 0 = by the permutation, 5 / 6 = forced (tuning aid)
+// Options (include/qip_hip.h lists the product's).  The measured alternatives of earlier rounds — each one a code path that lost
+// its A/B run (profiles/r0*_*.md) — are fixed at their defaults in the product build; a build with -DQIP_HIP_TUNING
+// (QIP_HIP_TUNING=1 python -m rustqip_amd.build) makes them switchable again for the tools/ bench scripts.
 extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
-  if (key && !strcmp(key, "force_generic")) {
-    g_force_generic = value;
-    return QIP_OK;
-  }
-  if (key && !strcmp(key, "perm_rows")) {
-    if (value != 0 && value != 5 && value != 6) return fail(QIP_ERR_INVALID, "perm_rows must be 0 (automatic), 5 or 6");
-    g_perm_rows = value;
-    return QIP_OK;
-  }
-  if (key && !strcmp(key, "line_bits")) {  // tuning aid (tools/bench_ops.py): 0..3
-    if (value < 0 || value > 3) return fail(QIP_ERR_INVALID, "line_bits must be 0..3");
-    g_line_bits = (uint32_t)value;
-    return QIP_OK;
-  }
-  if (key && !strcmp(key, "jit_cache_cap")) return jit_set_cache_cap(value);
-  if (key && !strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
-  if (key && !strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
-  if (key && !strcmp(key, "dist_plan_cost")) { g_dist_plan_cost = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "soft_measure_one_pass")) { g_soft_measure_one_pass = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "debug_slice_sweeps")) {
-    if (value != 0 && value != 2 && value != 4 && value != 8) return fail(QIP_ERR_INVALID, "debug_slice_sweeps is 0, 2, 4 or 8");
-    g_debug_slice_sweeps = value;
-    return QIP_OK;
-  }
-  if (key && !strcmp(key, "tile_diag_runs")) { g_tile_diag_runs = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "jit_disk_cache")) { g_jit_disk = value != 0; return QIP_OK; }
-  if (key && !strcmp(key, "jit_procs")) {
+  if (!key) return fail(QIP_ERR_INVALID, "null option key");
+  if (!strcmp(key, "force_generic")) { g_force_generic = value; return QIP_OK; }
+  if (!strcmp(key, "jit_cache_cap")) return jit_set_cache_cap(value);
+  if (!strcmp(key, "jit_disk_cap_mb")) return jit_set_disk_cap_mb(value);
+  if (!strcmp(key, "jit_disk_cache")) { g_jit_disk = value != 0; return QIP_OK; }
+  if (!strcmp(key, "jit_procs")) {
     if (value < 0 || value > 64) return fail(QIP_ERR_INVALID, "jit_procs must be 0 (automatic) .. 64");
     g_jit_procs = value;
     return QIP_OK;
   }
-  if (key && !strcmp(key, "jit_threads")) {
+  if (!strcmp(key, "tile_sched")) { g_tile_sched = value; return QIP_OK; }
+  if (!strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
+  if (!strcmp(key, "dist_fold_pack")) { g_dist_fold_pack = value; return QIP_OK; }
+  if (!strcmp(key, "dist_plan_cost")) { g_dist_plan_cost = value != 0; return QIP_OK; }
+  if (!strcmp(key, "collective_timeout_s")) {
+    if (value < 0) return fail(QIP_ERR_INVALID, "collective_timeout_s must be >= 0 (0 = wait for ever)");
+    g_collective_timeout_s = value;
+    return QIP_OK;
+  }
+#ifdef QIP_HIP_TUNING
+  if (!strcmp(key, "perm_rows")) {
+    if (value != 0 && value != 5 && value != 6) return fail(QIP_ERR_INVALID, "perm_rows must be 0 (automatic), 5 or 6");
+    g_perm_rows = value;
+    return QIP_OK;
+  }
+  if (!strcmp(key, "line_bits")) {
+    if (value < 0 || value > 3) return fail(QIP_ERR_INVALID, "line_bits must be 0..3");
+    g_line_bits = (uint32_t)value;
+    return QIP_OK;
+  }
+  if (!strcmp(key, "tile_pad_from")) { g_tile_pad_from = value; return QIP_OK; }
+  if (!strcmp(key, "soft_measure_one_pass")) { g_soft_measure_one_pass = value != 0; return QIP_OK; }
+  if (!strcmp(key, "tile_wide_dense3_inline")) { g_tile_wide_dense3_inline = value != 0; return QIP_OK; }
+  if (!strcmp(key, "tile_wide_pin")) { g_tile_wide_pin = value != 0; return QIP_OK; }
+  if (!strcmp(key, "sparse_tile")) { g_sparse_tile = value != 0; return QIP_OK; }
+  if (!strcmp(key, "debug_slice_sweeps")) {
+    if (value != 0 && value != 2 && value != 4 && value != 8) return fail(QIP_ERR_INVALID, "debug_slice_sweeps is 0, 2, 4 or 8");
+    g_debug_slice_sweeps = value;
+    return QIP_OK;
+  }
+  if (!strcmp(key, "tile_diag_runs")) { g_tile_diag_runs = value != 0; return QIP_OK; }
+  if (!strcmp(key, "jit_threads")) {
     if (value < 1 || value > 64) return fail(QIP_ERR_INVALID, "jit_threads must be 1..64");
     g_jit_threads = value;
     return QIP_OK;
   }
-  if (key && !strcmp(key, "tile_row_split_f32")) {
+  if (!strcmp(key, "tile_row_split_f32")) {
     if (value != 5 && value != 12) return fail(QIP_ERR_INVALID, "tile_row_split_f32 is 12 (split rows) or 5 (contiguous rows)");
     g_tile_row_split_f32 = value;
     return QIP_OK;
   }
-  if (key && !strcmp(key, "tile_row_split")) {
+  if (!strcmp(key, "tile_row_split")) {
     if (value != 5 && value != 11) return fail(QIP_ERR_INVALID, "tile_row_split is 11 (split rows) or 5 (contiguous rows)");
     g_tile_row_split = value;
     return QIP_OK;
   }
-  if (key && !strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
-  if (key && !strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
-  if (key && !strcmp(key, "tile_sched")) { g_tile_sched = value; return QIP_OK; }
-  if (key && !strcmp(key, "single_via_tile")) { g_single_via_tile = value; return QIP_OK; }
-  if (key && !strcmp(key, "k4_direct")) { g_force_k4_direct = value; return QIP_OK; }
-  if (key && !strcmp(key, "single_via_tile_f32")) { g_single_via_tile_f32 = value; return QIP_OK; }
-  return fail(QIP_ERR_INVALID, "unknown global option '%s'", key ? key : "(null)");
+  if (!strcmp(key, "tile_wave_rule")) { g_tile_wave_rule = value; return QIP_OK; }
+  if (!strcmp(key, "tile_remap")) { g_tile_remap = value; return QIP_OK; }
+  if (!strcmp(key, "k4_direct")) { g_force_k4_direct = value; return QIP_OK; }
+  if (!strcmp(key, "single_via_tile_f32")) { g_single_via_tile_f32 = value; return QIP_OK; }
+#endif
+  return fail(QIP_ERR_INVALID, "unknown global option '%s'", key);
 } QIP_CATCH_ALL
 
 // ---------------------------------------------------------------------------------------
@@ -341,11 +351,18 @@ extern "C" int qip_hip_op_algorithmic_bytes(int dtype, uint32_t n, const qip_op*
 // ---------------------------------------------------------------------------------------
 
 int ensure_arena(qip_hip_state* s, size_t bytes) {
-  if (bytes <= s->arena_cap) return QIP_OK;
-  if (s->capture_staging) {  // no malloc / sync inside a stream capture: ask the caller to grow and retry
-    s->capture_arena_need = std::max(s->capture_arena_need, bytes);
-    return fail(QIP_ERR_UNSUPPORTED, "arena too small during graph capture");
+  if (s->capture_pool) {  // a program records: a region of its device pool per launch group (arena_begin_group)
+    ProgPool* pp = s->capture_pool;
+    if (s->arena && bytes <= s->arena_cap) return QIP_OK;
+    if (s->arena) return fail(QIP_ERR_UNSUPPORTED, "internal: a launch group's payload region grew while a program was recorded");
+    const size_t off = (pp->used + 255) & ~(size_t)255;
+    pp->used = off + bytes;
+    if (pp->used > pp->cap) pp->overflow = true;  // sizing pass: no malloc inside a stream capture — the caller grows the pool and records again
+    s->arena = pp->overflow ? pp->base : (void*)((char*)pp->base + off);
+    s->arena_cap = bytes;
+    return QIP_OK;
   }
+  if (bytes <= s->arena_cap) return QIP_OK;
   if (s->arena) {
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipFree(s->arena));
@@ -544,21 +561,28 @@ extern "C" int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64
   if (!s || !key) return fail(QIP_ERR_INVALID, "null argument");
   if (!strcmp(key, "force_generic")) s->force_generic = value;
   else if (!strcmp(key, "profile")) s->profile = value;
-  else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
   else if (!strcmp(key, "mfma")) s->mfma = value;
   else if (!strcmp(key, "fuse")) s->fuse = value;
-  else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
   else if (!strcmp(key, "tile")) s->tile = value;
-  else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
-  else if (!strcmp(key, "unroll")) s->unroll = value;
-  else if (!strcmp(key, "swap_single")) s->swap_single = value;
-  else if (!strcmp(key, "tile_jit")) s->tile_jit = value;
+  else if (!strcmp(key, "tile_jit")) {
+#ifndef QIP_HIP_TUNING
+    if (value != 0 && value != 1) return fail(QIP_ERR_INVALID, "tile_jit is 0 or 1");
+#endif
+    s->tile_jit = value;
+  }
   else if (!strcmp(key, "tile_relabel")) s->tile_relabel = value;
   else if (!strcmp(key, "tile_fma")) s->tile_fma = value;
   else if (!strcmp(key, "tile_merge")) s->tile_merge = value;
   else if (!strcmp(key, "tile_wide")) s->tile_wide = value;
   else if (!strcmp(key, "tile_auto")) s->tile_auto = value;
   else if (!strcmp(key, "pair_floor")) s->pair_floor = value;
+#ifdef QIP_HIP_TUNING
+  else if (!strcmp(key, "lowbit_shuffle")) s->lowbit_shuffle = value;
+  else if (!strcmp(key, "packed_f32")) s->packed_f32 = value;
+  else if (!strcmp(key, "tile_passes")) s->tile_passes = value;
+  else if (!strcmp(key, "unroll")) s->unroll = value;
+  else if (!strcmp(key, "swap_single")) s->swap_single = value;
+#endif
   else return fail(QIP_ERR_INVALID, "unknown option '%s'", key);
   return QIP_OK;
 } QIP_CATCH_ALL

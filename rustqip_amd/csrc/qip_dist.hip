@@ -20,6 +20,7 @@
 // exchange is the cheapest one on this topology, and it buys g fresh local qubits instead of one.  What used to cost
 // extra — up to g local swap sweeps to bring the outgoing qubits to the top positions — is now one pack sweep.
 #include "qip_tile.h"
+#include <unistd.h>
 #include <dlfcn.h>
 
 #include <map>
@@ -30,6 +31,27 @@ int64_t g_dist_plan_cost = 1;  // global option "dist_plan_cost": 0 = the leavin
 int64_t g_dist_fold_pack = 1;  // global option "dist_fold_pack": 0 = the remap always gathers with a sweep of its own
 
 namespace qipd {
+
+// r6, the collective watchdog: a rank whose peers never arrive (one of them died, or issued different calls) must FAIL, not hang
+// the launcher.  Every place where the host waits for work that may contain an exchange or an all-reduce waits through this:
+// poll the stream, and give up after "collective_timeout_s" seconds (global option, default 120; 0 = plain hipStreamSynchronize).
+static int wait_stream(hipStream_t stream, int rank, int world, const char* what) {
+  if (world <= 1 || g_collective_timeout_s <= 0) {
+    HIPCHK(hipStreamSynchronize(stream));
+    return QIP_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(stream);
+    if (e == hipSuccess) return QIP_OK;
+    if (e != hipErrorNotReady) return fail(QIP_ERR_DEVICE, "hipStreamQuery failed: %s (rank %d, %s)", hipGetErrorString(e), rank, what);
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > (double)g_collective_timeout_s)
+      return fail(QIP_ERR_DEVICE, "rank %d of %d: %s did not complete within %lld s — a peer is missing, hung, or issued different calls "
+                  "(global option collective_timeout_s)", rank, world, what, (long long)g_collective_timeout_s);
+    if (waited > 2e-4) usleep(waited > 0.05 ? 1000 : 50);  // (spin for the first 200 us: a wait that short must not pay a sleep quantum)
+  }
+}
 
 // ---- ops owned by the planner (the localized op of a rank) -------------------------------------------------------------
 struct LocalOp {
@@ -720,8 +742,7 @@ static int rccl_all_reduce_on(RcclTransport* t, double* values, uint64_t count, 
   HIPCHK(hipMemcpyAsync(t->d_red, values, count * sizeof(double), hipMemcpyHostToDevice, stream));
   NCHK(g_rccl.AllReduce(t->d_red, t->d_red, count, Rccl::kFloat64, Rccl::kSum, t->comm, stream));
   HIPCHK(hipMemcpyAsync(values, t->d_red, count * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
-  return QIP_OK;
+  return wait_stream(stream, t->rank, t->world, "an all-reduce");
 }
 
 }  // namespace qipd
@@ -908,8 +929,8 @@ static void slice_runs(uint32_t L, uint32_t g, const std::vector<uint32_t>& pack
 static int dist_drain_events(qip_hip_dist* d) {
   qip_hip_state* s = d->shard;
   if (d->ev_exchange.empty() && d->ev_pack.empty()) return QIP_OK;
-  if (d->comm_stream) HIPCHK(hipStreamSynchronize(d->comm_stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
+  if (d->comm_stream) QCHK(qipd::wait_stream(d->comm_stream, d->pl.rank, d->pl.world, "the exchange on the communication stream"));
+  QCHK(qipd::wait_stream(s->stream, d->pl.rank, d->pl.world, "the queued batch (sweeps + exchange)"));
   for (auto* list : {&d->ev_exchange, &d->ev_pack}) {
     for (auto& e : *list) {
       float ms = 0;
@@ -979,7 +1000,10 @@ static int dist_run_steps(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
   const int rc = dist_run_steps_inner(d, steps);
   // whatever comes next on the shard's stream (a download, a measurement, the next batch) is ordered after the last slices
   if (rc == QIP_OK) return dist_wait_rx(d);
+  // (the requests point at objects of the failed batch's frame — none may outlive it)
   d->shard->slice_first = d->shard->slice_last = d->shard->slice_now = nullptr;
+  d->shard->fold_request = nullptr;
+  d->shard->fold_now = d->shard->fold_done = false;
   return rc;
 }
 static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
@@ -1039,7 +1063,9 @@ static int dist_run_steps_inner(qip_hip_dist* d, std::vector<qipd::Step>& steps)
       const size_t ex_at = jx + (jx < steps.size() && steps[jx].kind == qipd::Step::PACK ? 1 : 0);
       const bool ex_next = ex_at < steps.size() && steps[ex_at].kind == qipd::Step::EXCHANGE;
       const bool pack_in_plan = ex_next && ex_at != jx;
-      bool pre = P && ex_next && s->layout.empty() && (!pack_in_plan || pack_next);
+      // (with a PERSISTENT relabelling, tile_relabel = 3, the batch is scheduled from and to layouts edge_tile does not
+      // model — the prediction "ends in the caller's order" could be wrong on every rank alike: such states vote no)
+      bool pre = P && ex_next && s->layout.empty() && s->tile_relabel < 3 && (!pack_in_plan || pack_next);
       const uint64_t chunk_bytes = (s->namps >> g) * s->amp_bytes;
       std::vector<uint32_t> packed;
       if (P && ex_next) {
@@ -1234,13 +1260,18 @@ static int dist_plans_agree(qip_hip_dist* d, const std::vector<qipd::Step>& step
     for (uint32_t p : st.sel) mix(0x100u + p);
   }
   if (comm_steps == 0) return QIP_OK;
+  // (whether the slice votes of an overlapped exchange are held — collectives too — follows from per-handle options:
+  // ranks that differ in them must be refused here, not hang in a different number of all-reduces)
+  mix(0x4f00u + (uint64_t)d->overlap);
+  mix(0x5400u + (uint64_t)(d->shard->tile >= 1) + 2 * (uint64_t)(d->shard->tile_passes != 0) + 4 * (uint64_t)(d->shard->force_generic != 0) +
+      8 * (uint64_t)(d->shard->tile_relabel >= 3));
   const double v = (double)((h ^ (h >> 20) ^ (h >> 40)) & 0xfffffull);  // 20 bits: v^2 * world stays exact in a double
   double r[2] = {v, v * v};
   QCHK(dist_all_reduce(d, r, 2));
   const double w = (double)d->pl.world;
   if (r[0] != w * v || r[1] != w * v * v)
     return fail(QIP_ERR_INVALID, "the ranks planned different exchanges for this batch (do they see the same circuit and the same "
-                                 "global options dist_plan_cost / tile_row_split / dist_fold_pack?)");
+                                 "options dist_plan_cost / dist_fold_pack / dist_overlap / tile?)");
   return QIP_OK;
 }
 static int dist_run_or_poison(qip_hip_dist* d, std::vector<qipd::Step>& steps) {
@@ -1385,7 +1416,13 @@ extern "C" int qip_hip_dist_set_option(qip_hip_dist* d, const char* key, int64_t
 
 extern "C" int qip_hip_dist_sync(qip_hip_dist* d) try {
   DIST_ENTER(d);
-  return qip_hip_state_sync(d->shard);
+  if (d->comm_stream) QCHK(qipd::wait_stream(d->comm_stream, d->pl.rank, d->pl.world, "the exchange on the communication stream"));
+  const int rc = qipd::wait_stream(d->shard->stream, d->pl.rank, d->pl.world, "the queued batch (sweeps + exchange)");
+  if (rc != QIP_OK) {  // what is queued behind a collective that never completes can never run: the handle is done
+    d->poisoned = true;
+    d->poison_msg = g_last_error;
+  }
+  return rc;
 } QIP_CATCH_ALL
 
 extern "C" int qip_hip_dist_take_stats(qip_hip_dist* d, qip_hip_dist_stats* out) try {

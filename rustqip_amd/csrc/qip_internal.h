@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/qip_hip.h"
+#include "../../include/qip_hip_debug.h"
 #include "qip_kernels.h"
 
 using namespace qipk;
@@ -63,6 +64,7 @@ extern int64_t g_perm_rows;
 extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap, g_tile_sched;
 extern int64_t g_single_via_tile, g_single_via_tile_f32;
 extern int64_t g_dist_fold_pack, g_dist_plan_cost;  // qip_dist.hip
+extern int64_t g_collective_timeout_s;             // qip_core.hip: seconds a rank waits for an exchange before it fails (0 = for ever)
 extern int64_t g_sparse_tile;  // qip_launch.hip
 extern int64_t g_soft_measure_one_pass;  // qip_measure.hip
 extern int64_t g_tile_wide_pin, g_tile_wide_dense3_inline;  // qip_circuit.hip
@@ -202,12 +204,14 @@ struct qip_hip_state {
   int num_cus = 256;        // compute units of the device
   bool jit_prepare = false; // compile the segments' kernels but launch nothing (before a graph capture; the parallel pre-compilation)
   bool jit_for_capture = false;  // ... on behalf of a graph capture: the plan must be the one the capture will record
+  bool jit_lookup_only = false;  // r6 (option tile_auto, one-shot callers): the plan's segments are only LOOKED UP (memory, disk cache); a miss
+                                 // hands them to background helpers and the batch returns kJitMiss before anything has run
   // r4: apply_ops collects the sources of a plan's segments that are not in the kernel cache yet (source text, contraction flag)
   // and compiles them on several host threads before the first launch (hiprtc: ~0.35 s per 11-bit segment, ~1.4 s per wide one)
   std::vector<std::pair<std::string, bool>>* jit_collect = nullptr;
-  // program capture (hipGraph): payload staging that must outlive the graph, and arena growth request
-  std::deque<std::vector<char>>* capture_staging = nullptr;
-  size_t capture_arena_need = 0;
+  // program capture (hipGraph): non-null while a program records its launches.  Op payloads then go to the PROGRAM's own
+  // device pool instead of the arena (ProgPool below): the graph holds kernel nodes only and replays nothing from the host.
+  struct ProgPool* capture_pool = nullptr;
   std::vector<struct qip_hip_program*> programs;  // graphs recorded against this state's buffers  // f32: sweep two amplitudes per 16-B element when bit 0 is not involved  // 0 = gate by gate; K >= 2 = fuse into dense gates on <= K qubits
   int64_t unroll = 0;  // 0 = default per kernel
   // profiling
@@ -218,6 +222,16 @@ struct qip_hip_state {
   double prof_bytes[KC_COUNT] = {0};
 };
 
+// Device memory a recorded program owns for the payloads of its ops (dense tables, matrix-core fragments, CSR / ELL rows, tile
+// descriptors, the numbers of run-time-compiled segments): packed ONCE while the program is recorded, one region per launch
+// group, uploaded in one copy when the recording has succeeded.  While a program records (qip_hip_state::capture_pool),
+// ensure_arena hands out regions of this pool and arena_upload writes the host image instead of enqueueing a copy.
+struct ProgPool {
+  void* base = nullptr;
+  size_t cap = 0, used = 0;
+  bool overflow = false;        // a sizing pass: `used` keeps counting, nothing is stored, the recording is thrown away
+  std::vector<char> image;      // host image of [0, used)
+};
 struct TileSlicing {
   uint32_t nbits = 0;
   uint32_t pos[3] = {0, 0, 0};  // slice k has bit j of k at amplitude-index position pos[j] (the state's order when the step runs)
@@ -229,10 +243,18 @@ struct TileSlicing {
   bool folded = false;
 };
 int ensure_arena(qip_hip_state* s, size_t bytes);
+// start of a launch group (one op, one tile segment): while a program records, its payload gets a region of its own
+static inline void arena_begin_group(qip_hip_state* s) {
+  if (s->capture_pool) {
+    s->arena = nullptr;
+    s->arena_cap = 0;
+  }
+}
 int ensure_partial(qip_hip_state* s, size_t count);
 int ensure_alt(qip_hip_state* s);
 void programs_orphan(qip_hip_state* s);  // qip_circuit.hip
 int jit_set_cache_cap(int64_t cap);      // qip_circuit.hip (global option "jit_cache_cap")
+int jit_set_disk_cap_mb(int64_t mb);     // qip_circuit.hip (global option "jit_disk_cap_mb")
 uint64_t jit_cache_generation();
 // qip_circuit.hip: `op` as a one-item tile sweep; *done = false when it is not a tile item (nothing launched)
 template <typename T> int tile_apply_single(qip_hip_state* s, const qip_op* op, bool* done, double alg_bytes = 0);

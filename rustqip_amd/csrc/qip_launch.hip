@@ -22,14 +22,17 @@ static uint64_t mask_of(const std::vector<uint32_t>& pos) {
 
 
 // Stream-ordered copy of an op payload into the device arena.  Eagerly the (pageable) source is staged by
-// the runtime before the call returns; under graph capture the source must live as long as the graph, so
-// it is first copied into storage owned by the program.
+// the runtime before the call returns.  While a program records, the bytes go into the host image of the program's
+// device pool instead (ProgPool): one upload when the recording is done, nothing from the host at replay.
 int arena_upload(qip_hip_state* s, const void* src, size_t bytes, size_t arena_off) {
   if (bytes == 0) return QIP_OK;
   QCHK(ensure_arena(s, arena_off + bytes));
-  if (s->capture_staging) {
-    s->capture_staging->emplace_back((const char*)src, (const char*)src + bytes);
-    src = s->capture_staging->back().data();
+  if (ProgPool* pp = s->capture_pool) {
+    if (pp->overflow) return QIP_OK;
+    const size_t at = (size_t)((char*)s->arena - (char*)pp->base) + arena_off;
+    if (pp->image.size() < at + bytes) pp->image.resize(at + bytes);
+    memcpy(pp->image.data() + at, src, bytes);
+    return QIP_OK;
   }
   HIPCHK(hipMemcpyAsync((char*)s->arena + arena_off, src, bytes, hipMemcpyHostToDevice, s->stream));
   return QIP_OK;
@@ -697,7 +700,7 @@ static int launch_huge_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
         for (size_t e = 0; e < 2; ++e) a2[((rb * KP + pr) * 64 + l) * 2 + e] = (T)afrag[(rb * KS + 2 * pr + e) * 64 + l];
   QCHK(ensure_arena(s, a2.size() * sizeof(T)));
   QCHK(arena_upload(s, a2.data(), a2.size() * sizeof(T), 0));
-  HIPCHK(hipStreamSynchronize(s->stream));  // (the staging vector dies with this frame; 8 - 32 MiB once per gate)
+  if (!s->capture_pool) HIPCHK(hipStreamSynchronize(s->stream));  // (the staging vector dies with this frame; 8 - 32 MiB once per gate)
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
   Ins ins = make_ins(pos, mask_of(p.cpos));
@@ -1200,6 +1203,7 @@ template <typename T>
 int apply_op_t(qip_hip_state* s, const qip_op* op) {
   if (s->jit_prepare) return QIP_OK;  // compiling a program's segment kernels: single ops have nothing to prepare
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
+  arena_begin_group(s);
   FlatOp f;
   QCHK(flatten_op(s->n, op, false, &f));
   Plan p;
@@ -1315,12 +1319,10 @@ int apply_op_t(qip_hip_state* s, const qip_op* op) {
           rec.cls = KC_SPARSE_TILE;
           break;
         }
-        if (!s->capture_staging) {  // out of place: the buffers trade places, which a recorded graph cannot follow
-          rc = launch_sparse_ell<T>(s, p, f, &done);
-          if (rc != QIP_OK || done) {
-            rec.cls = KC_SPARSE_ELL;
-            break;
-          }
+        rc = launch_sparse_ell<T>(s, p, f, &done);  // out of place (a recorded program follows the buffers: one graph per parity)
+        if (rc != QIP_OK || done) {
+          rec.cls = KC_SPARSE_ELL;
+          break;
         }
       }
       QCHK(ensure_alt(s));

@@ -36,3 +36,27 @@ def oracle():
     from oracle import qip_oracle
 
     return qip_oracle
+
+
+def has_tuning_options() -> bool:
+    """True when libqip_hip.so was built with -DQIP_HIP_TUNING (QIP_HIP_TUNING=1 python -m rustqip_amd.build): the measured
+    alternatives of earlier rounds are switchable again.  The product build fixes them at their defaults; the A/B tests of
+    those alternatives skip there (`needs_tuning`)."""
+    import ctypes
+
+    from rustqip_amd import _ffi
+
+    return _ffi.lib.qip_hip_set_global_option(b"tile_diag_runs", ctypes.c_int64(1)) == 0
+
+
+def needs_tuning():
+    if not has_tuning_options():
+        pytest.skip("an A/B test of a measured alternative: needs a -DQIP_HIP_TUNING build of libqip_hip.so")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """the CPU oracle (the checker), under the name the GPU parity tests use"""
+    from oracle import qip_oracle
+
+    return qip_oracle

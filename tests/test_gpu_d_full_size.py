@@ -1,0 +1,363 @@
+"""SURVEY.md §8 rows c/d at the timed sizes: size-independent properties and oracle windows at n = 24..33, bench.py's failure path.
+Split out of the former tests/test_parity_gpu.py (a `-x` failure now names the row).  Everything goes through the
+C ABI (ctypes -> libqip_hip.so -> HIP kernels); helpers and bars: tests/gpu_common.py."""
+from gpu_common import *  # noqa: F401,F403
+from gpu_common import _ansatz, _jit_info, _permuted, _run_dist, _special_gates  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("n", [28])
+def test_full_size_properties(n):
+    """n = 28 (4 GiB): permutations round-trip bit-exactly, a random circuit followed by its
+    inverse returns to the start, the norm is preserved."""
+    inv = {"H": "H", "X": "X"}
+    with q.HipState(n) as st:
+        st.init_basis(5)
+        st.apply_ops(circuits.h_layer(n))
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        probe0 = st.download(12345, 4096)
+        assert np.allclose(np.abs(probe0), 2 ** (-n / 2), atol=1e-15)
+        # X, CNOT, SWAP twice = identity, bit-exact on a window
+        rng = np.random.default_rng(0)
+        st.apply_ops([q.make_matrix_op([t], circuits.rz(0.1 * (t + 1))) for t in range(n)])  # make amplitudes distinct
+        before = st.download(1 << 20, 1 << 16)
+        perms = []
+        for t in (0, 1, n // 2, n - 7, n - 2, n - 1):
+            perms.append(q.make_matrix_op([t], circuits.X))
+        perms.append(q.make_control_op([0], q.make_matrix_op([n - 1], circuits.X)))
+        perms.append(q.make_control_op([n - 1], q.make_matrix_op([3], circuits.X)))
+        perms.append(q.make_swap_op([0], [n - 1]))
+        perms.append(q.make_swap_op([2, 3], [n - 3, n - 2]))
+        st.apply_ops(perms + perms[::-1])
+        assert np.array_equal(st.download(1 << 20, 1 << 16), before)
+        # random circuit and its inverse
+        ops = circuits.c2_random_circuit(n, 48, seed=n)
+        inverse = []
+        for op in reversed(ops):
+            if op.kind == "Control":
+                inverse.append(op)
+            else:
+                d = op.data
+                inverse.append(q.make_matrix_op(op.indices, np.conj(d.reshape(2, 2).T).ravel()))
+        st.apply_ops(ops)
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        st.apply_ops(inverse)
+        after = st.download(1 << 20, 1 << 16)
+        assert np.max(np.abs(after - before)) < 1e-12
+        assert abs(st.norm_sqr() - 1) < 1e-10
+
+
+@pytest.mark.slow
+def test_full_size_qft_and_grover_properties():
+    """BASELINE configs[2] and [4] at n = 28 on one GPU, checked by size-independent properties:
+    QFT of a basis state has the closed form N^-1/2 exp(2 pi i j k / N); QFT followed by its inverse is
+    the identity; one Grover iteration takes the marked amplitude to sin(3 theta)."""
+    n = 28
+    N = 1 << n
+    j = 0b1011001110001111000011111010  # 28-bit basis state
+    qft = circuits.c3_qft(n)
+    with q.HipState(n) as st:
+        st.init_basis(j)
+        st.apply_ops(qft)
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        for k0 in (0, 1, 12345, N // 2 + 77, N - 4096):
+            got = st.download(k0, 4096)
+            k = np.arange(k0, k0 + 4096, dtype=np.int64)
+            phase = ((j * k) % N).astype(np.float64)  # j*k < 2^56 is exact in int64
+            want = np.exp(2j * np.pi * phase / N) / math.sqrt(N)
+            assert np.max(np.abs(got - want)) < 1e-13, k0  # amplitudes are 2^-14
+        inverse = []
+        for op in reversed(qft):
+            if op.kind == "Swap":
+                inverse.append(op)
+            elif op.kind == "Control":
+                d = op.inner.data
+                inverse.append(q.make_control_op(op.indices[:1], q.make_matrix_op(op.indices[1:], np.conj(d))))
+            else:
+                inverse.append(op)  # H
+        st.apply_ops(inverse)
+        back = st.download(j - 5, 16)
+        expect = np.zeros(16, dtype=np.complex128)
+        expect[5] = 1
+        assert np.max(np.abs(back - expect)) < 1e-10
+        assert abs(st.norm_sqr() - 1) < 1e-10
+    theta = math.asin(2 ** (-n / 2))
+    for dense_k3 in (False, True):
+        with q.HipState(n) as st:
+            st.init_basis(0)
+            st.apply_ops(circuits.h_layer(n) + circuits.c5_grover_iteration(n, dense_k3=dense_k3))
+            a0 = st.download(0, 2)
+            assert abs(abs(a0[0]) - math.sin(3 * theta)) < 1e-12
+            assert abs(abs(a0[1]) - math.cos(3 * theta) / math.sqrt(N - 1)) < 1e-12
+            assert abs(st.norm_sqr() - 1) < 1e-10
+
+
+@pytest.mark.slow
+def test_full_size_qft_through_tile_sweeps_and_the_permutation_sweep():
+    """configs[2] at n = 28 with tile = 1 (run-time-compiled segments): closed form of QFT|j>, then QFT^-1 back to |j>."""
+    n = 28
+    N = 1 << n
+    j = 0b0110100111000111100001111101
+    qft = circuits.c3_qft(n)
+    with q.HipState(n) as st:
+        st.set_option("tile", 1)
+        st.set_option("tile_jit", 1)
+        st.init_basis(j)
+        st.apply_ops(qft)
+        for k0 in (0, 3, 54321, N // 2 + 99, N - 4096):
+            got = st.download(k0, 4096)
+            k = np.arange(k0, k0 + 4096, dtype=np.int64)
+            want = np.exp(2j * np.pi * ((j * k) % N).astype(np.float64) / N) / math.sqrt(N)
+            assert np.max(np.abs(got - want)) < 1e-13, k0
+        inverse = []
+        for op in reversed(qft):
+            if op.kind == "Control":
+                inverse.append(q.make_control_op(op.indices[:1], q.make_matrix_op(op.indices[1:], np.conj(op.inner.data))))
+            else:
+                inverse.append(op)
+        st.apply_ops(inverse)  # starts with the run of swaps: one permutation sweep
+        back = st.download(j - 5, 16)
+        expect = np.zeros(16, dtype=np.complex128)
+        expect[5] = 1
+        assert np.max(np.abs(back - expect)) < 1e-10
+        assert abs(st.norm_sqr() - 1) < 1e-10
+
+
+@pytest.mark.slow
+def test_full_size_tile_relabel_saves_sweeps_and_changes_nothing():
+    """configs[1] at n = 28: the relabelled plan needs fewer sweeps (profile) and leaves the very same state, compared
+    on windows of two resident states (bottom, top and places in between)."""
+    n = 28
+    N = 1 << n
+    ops = circuits.c2_random_circuit(n, 256, seed=28)
+    init = circuits.h_layer(n) + [q.make_matrix_op([t], circuits.rz(0.1 + 0.37 * t)) for t in range(n)]
+    with q.HipState(n) as a, q.HipState(n) as b:
+        launches = []
+        for st, relabel in ((a, 0), (b, 1)):
+            st.init_basis(5)
+            st.apply_ops(init)
+            st.set_option("tile", 1)
+            st.set_option("tile_relabel", relabel)
+            st.set_option("profile", 1)
+            st.profile_reset()
+            st.apply_ops(ops)
+            prof = st.profile()
+            st.set_option("profile", 0)
+            launches.append(sum(v["launches"] for v in prof.values()))
+            if relabel:
+                assert prof.get("k_permute_bits", {}).get("launches", 0) == 1, prof
+        assert launches[1] < launches[0], launches
+        for off in (0, 1 << 16, 123456789 & ~0xFFFF, N // 2 - (1 << 15), N - (1 << 16)):
+            assert np.array_equal(a.download(off, 1 << 16), b.download(off, 1 << 16)), off
+        assert abs(b.norm_sqr() - 1) < 1e-10
+
+
+def test_window_compare_at_n24(O):
+    """Full-vector compare against the oracle at n = 24 on a prefix of configs[1]."""
+    n = 24
+    ops = circuits.h_layer(n)[:6] + circuits.c2_random_circuit(n, 10, seed=28)
+    x = rand_state(n, 24)
+    with q.HipState(n) as st:
+        st.upload(x)
+        st.apply_ops(ops)
+        got = st.download()
+    want = O.apply_ops_in_place(n, ops, x.copy())
+    assert np.max(np.abs(got - want)) <= TOL64
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("n", [30, 32])  # (r5: n = 28 dropped — 30 is the timed size, 32 the first 2-D grids; the suite's time limit)
+def test_full_size_oracle_windows(O, n):
+    """The benchmarked sizes (n = 30 is bench.py's workload; n = 32 is where streaming launches first need a second
+    grid dimension) compared with the ORACLE, gate by gate, on a seeded product state whose amplitudes are pairwise
+    distinct: >= 4 closed sub-cubes of >= 2^16 rows per gate, always including the bottom and the top of the index
+    space.  f64 gate-by-gate kernels are bit-equal (array_equal); matrix-core gates are held to 1e-12."""
+    from oracle import window_parity as W
+
+    rng = np.random.default_rng(n)
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    c2 = circuits.c2_random_circuit(n, 256, seed=28)
+    N = 1 << n
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        for off in (0, 12345, N // 2 - 777, N - (1 << 16)):
+            got = st.download(off, 1 << 16)
+            want = W.product_state_window(n, vecs, off, 1 << 16)
+            assert np.allclose(got, want, rtol=1e-12, atol=0), off
+        assert abs(st.norm_sqr() - 1) < 1e-10
+        # the first gates of the benchmarked circuit, one launch per gate
+        n_gbg = 40 if n <= 30 else 32
+        agg = W.check_circuit(st, n, c2[:n_gbg], O, gate_by_gate=True, seed=1)
+        assert agg["gates"] == n_gbg and agg["skipped"] == 0 and agg["rows"] >= n_gbg * 4 * (1 << 16)
+        assert agg["bit_equal"] and agg["max_abs_delta"] == 0.0, agg
+        for name, op, exact in _special_gates(n, rng):
+            r = W.check_ops(st, n, [op], O, bases=W.default_bases(n, seed=zlib.crc32(name.encode()) % 1000))
+            assert r is not None, name
+            if exact:
+                assert r["bit_equal"], (name, r)
+            else:
+                assert r["max_abs_delta"] <= TOL64, (name, r)
+        # LDS-resident multi-gate sweeps (tile = 1: IEEE-equal) on the following gates of the same circuit, in
+        # chunks whose sub-cubes stay small; the chunk is what the tile scheduler sees
+        st.set_option("tile", 1)
+        st.set_option("profile", 1)
+        st.profile_reset()
+        n_tile = 96 if n <= 30 else 48
+        agg = W.check_circuit(st, n, c2[40:40 + n_tile], O, gate_by_gate=False, seed=2, bases_per_step=2)
+        prof = st.profile()
+        assert agg["gates"] == n_tile and agg["skipped"] == 0
+        assert prof.get("k_tile_passes", {}).get("launches", 0) >= 3, prof  # multi-gate sweeps really ran
+        assert agg["max_abs_delta"] == 0.0, agg  # only a -0 may differ from the gate-by-gate path
+        if n == 30:
+            # the same sweeps as kernels compiled at run time for each segment (option tile_jit): still IEEE-equal
+            st.set_option("tile_jit", 1)
+            agg = W.check_circuit(st, n, c2[136:200], O, gate_by_gate=False, seed=4, bases_per_step=2)
+            st.set_option("tile_jit", 0)
+            assert agg["gates"] == 64 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+            # the scheduler relabelling the qubits (option tile_relabel = 2: unconditionally, so every chunk goes through
+            # in-tile swaps, label exchanges and the closing bit-permutation sweep): still IEEE-equal to the oracle
+            st.set_option("tile_relabel", 2)
+            qswap = [q.make_swap_op([3], [n - 2]), q.make_swap_op([n - 9], [0])]
+            agg = W.check_circuit(st, n, c2[200:232] + qswap + c2[232:256], O, gate_by_gate=False, seed=5, bases_per_step=2)
+            st.set_option("tile_relabel", 0)
+            assert agg["gates"] == 58 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+            assert st.profile().get("k_permute_bits", {}).get("launches", 0) >= 1
+            # configs[4], dense k = 3 variant (the 8x8 gates ride in the sweeps as passes of their own three bits), with
+            # dense k = 5 / k = 4 gates in between: matrix-core launches mixed with tile sweeps
+            g = circuits.c5_grover_iteration(n, dense_k3=True)
+            k5 = q.make_matrix_op([n - 1, n - 2, 3, n - 4, n - 5], rand_unitary(5, rng).ravel())
+            k4 = q.make_matrix_op([n - 1, n - 3, 2, n - 6], rand_unitary(4, rng).ravel())
+            g = g[:40] + [k5] + g[40:100] + [k4] + g[100:]
+            st.profile_reset()
+            agg = W.check_circuit(st, n, g, O, gate_by_gate=False, seed=3, bases_per_step=2)
+            assert agg["gates"] >= len(g) - 2 and agg["max_abs_delta"] <= TOL64, agg
+            assert st.profile().get("k_gate_kq_mfma", {}).get("launches", 0) >= 2, st.profile()
+        st.set_option("tile", 0)
+        st.set_option("profile", 0)
+        assert abs(st.norm_sqr() - 1) < 1e-9
+
+
+@pytest.mark.slow
+def test_full_size_oracle_windows_n33(O):
+    """n = 33 on ONE GPU (128 GiB: the size BASELINE configs[4] shards over 8; VERDICT r3 weak item 3: until now only its
+    norm was checked): gate by gate and through tile sweeps against the oracle on closed sub-cubes, bottom and top of the
+    2^33 index space included.  There is no room for a twin state; the whole-vector guard is the closed-form marginals of
+    the seeded product state (single-qubit gates keep it a product state).  Nothing here may take the out-of-place path."""
+    from oracle import window_parity as W
+
+    n = 33
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    head = circuits.c2_random_circuit(n, 64, seed=28, single_only=True)
+    c2 = circuits.c2_random_circuit(n, 128, seed=28)
+    N = 1 << n
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        for off in (0, N // 3, N - (1 << 16)):
+            assert np.allclose(st.download(off, 1 << 16), W.product_state_window(n, vecs, off, 1 << 16), rtol=1e-12, atol=0), off
+        guard = W.ProductGuard(n, vecs)
+        assert guard.check(st) <= 1e-11
+        agg = W.check_circuit(st, n, head[:16], O, gate_by_gate=True, seed=1)
+        assert agg["gates"] == 16 and agg["skipped"] == 0 and agg["bit_equal"] and agg["rows"] >= 16 * 4 * (1 << 16), agg
+        for op in head[:16]:
+            guard.apply(op)
+        assert guard.check(st) <= 1e-11, guard.worst_rel
+        st.set_option("tile", 1)
+        agg = W.check_circuit(st, n, head[16:64], O, gate_by_gate=False, seed=2, bases_per_step=2)
+        assert agg["gates"] == 48 and agg["skipped"] == 0 and agg["max_abs_delta"] == 0.0, agg
+        for op in head[16:64]:
+            guard.apply(op)
+        assert guard.check(st) <= 1e-11, guard.worst_rel
+        # the configs[1] mix (CNOTs: half sweeps whose controls sit on every kind of position), gate by gate and as sweeps
+        agg = W.check_circuit(st, n, c2[:16], O, gate_by_gate=True, seed=3, bases_per_step=2)
+        st.set_option("tile", 0)
+        agg2 = W.check_circuit(st, n, c2[16:32], O, gate_by_gate=True, seed=4, bases_per_step=2)
+        assert agg["skipped"] == 0 and agg2["skipped"] == 0 and agg["max_abs_delta"] == 0.0 and agg2["bit_equal"], (agg, agg2)
+        assert abs(st.norm_sqr() - 1) < 1e-9
+
+
+@pytest.mark.slow
+def test_bench_fails_when_parity_fails(tmp_path):
+    """a parity failure must be fatal — rc != 0, value null, parity_ok false at top level.  The failure is
+    provoked through the checker's side only (QIP_BENCH_SABOTAGE_PARITY perturbs what the ORACLE is fed), never the product."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--n-local", "20", "--gates", "64",
+           "--no-extras", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, QIP_BENCH_SABOTAGE_PARITY="1"))
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert res.returncode != 0 and line["value"] is None and line["parity_ok"] is False, (res.returncode, line["value"], line["parity_ok"])
+    assert "PARITY FAILED" in res.stderr
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert res.returncode == 0 and line["value"] > 0 and line["parity_ok"] is True
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("n", [26])
+def test_full_size_every_timed_leg_with_whole_vector_guard(O, n):
+    """What bench.py's parity block does at n = 30, as a test at n = 26 (r5: was 28 — the n = 30 version runs inside every
+    bench.py run, and the suite has to stay well inside the driver's time limit): every mode the bench times — tile sweeps
+    (interpreted, run-time-compiled, relabelled), the 1e-12 modes (tile = 2, fused multiply-adds, dense fusion) and the other
+    BASELINE circuits (QFT, Clifford+T, Grover) through run-time-compiled sweeps — against the oracle on closed sub-cubes, with
+    a twin state that goes gate by gate through the literal kernel compared over ALL 2^n amplitudes after every step, and
+    closed-form marginals while the state is a product state."""
+    from oracle import window_parity as W
+
+    ops0, vecs = W.product_state_ops(n, seed=n)
+    c2s = circuits.c2_random_circuit(n, 16, seed=28, single_only=True)
+    c2 = circuits.c2_random_circuit(n, 5 * 16, seed=29)
+    with q.HipState(n) as st:
+        st.init_basis(0)
+        st.apply_ops(ops0)
+        twin = W.Twin(st, lambda: q.HipState(n))
+        guard = W.ProductGuard(n, vecs)
+        assert guard.check(st) < 1e-12
+        agg = W.check_circuit(st, n, c2s, O, gate_by_gate=True, seed=1, twin=twin)
+        assert agg["bit_equal"] and agg["whole_vector_amplitudes_not_equal"] == 0 and agg["whole_vector_compares"] == 16, agg
+        for op in c2s:
+            guard.apply(op)
+        assert guard.check(st) < 1e-11, guard.worst_rel
+
+        def leg(ops, exact, max_len=64, **options):
+            for k, v in options.items():
+                st.set_option(k, v)
+            r = W.check_circuit(st, n, ops, O, gate_by_gate=False, seed=len(ops), bases_per_step=2, twin=twin, max_len=max_len)
+            for k in options:
+                st.set_option(k, 0)
+            assert r["skipped"] == 0 and r["gates"] == len(ops), (options, r)
+            if exact:
+                assert r["bit_equal"] and r["whole_vector_amplitudes_not_equal"] == 0, (options, r)
+            else:
+                assert r["max_abs_delta"] <= TOL64 and r["whole_vector_max_abs_delta"] <= TOL64, (options, r)
+                twin.resync()
+            return r
+
+        leg(c2[:16], True, tile=1)
+        leg(c2[16:32], True, tile=1, tile_jit=1)
+        leg(c2[32:48], True, tile=1, tile_jit=1, tile_relabel=2)
+        leg(c2[48:64], False, tile=2, tile_jit=1)
+        leg(c2[64:80], False, tile=2, tile_jit=1, tile_fma=1, tile_relabel=1)
+        leg(circuits.c2_random_circuit(n, 16, seed=31), False, fuse=5)
+        r = leg(circuits.c3_qft(n)[:120], True, max_len=160, tile=1, tile_jit=1)  # the first 5 H with all their controlled phases
+        assert r["steps"] <= 2  # chunks as large as the timed segments (5-6 H and their controlled phases each)
+        leg(circuits.c4_clifford_t(n, 48, seed=32), True, tile=1, tile_jit=1)
+        leg(circuits.c5_grover_iteration(n)[:70], True, max_len=96, tile=1, tile_jit=1)  # X / H walls and the 27-control Z
+        # r4: wide tiles (13-bit register-resident tile, seven free positions per sweep): IEEE-equal in circuit order, also
+        # with the qubits relabelled; the 1e-12 mode with commuting reorder
+        # (bench.py's parity block checks every wide leg it times at n = 30 — Clifford+T, Grover and the relabelled 1e-12 mode too;
+        # test_wide_tiles_… compares wide with narrow sweeps bit for bit at n = 18)
+        # (r5: two wide legs here — the relabelled and the QFT ones are bench.py parity legs at n = 30 and test_wide_tiles_… cases)
+        c2w = circuits.c2_random_circuit(n, 40, seed=33)
+        leg(c2w, True, tile=1, tile_jit=1, tile_wide=1)
+        leg(circuits.c2_random_circuit(n, 40, seed=35), False, tile=2, tile_jit=1, tile_wide=1, tile_fma=1, tile_merge=1)
+        twin.close()
+        assert abs(st.norm_sqr() - 1) < 1e-9

@@ -3,6 +3,7 @@
 export, and that compute entry points fail loudly without a GPU."""
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -13,18 +14,32 @@ from rustqip_amd import _ffi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "qip_hip.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(qip_hip_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 25
-    for name in sorted(names):
+    return set(re.findall(r"\b(qip_hip_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared("qip_hip.h")          # the binding contract
+    debug = _declared("qip_hip_debug.h")    # host-only test hooks: exported, not part of the contract
+    assert 25 <= len(names) <= 66 and len(debug) == 8 and not (names & debug)
+    for name in sorted(names | debug):
         assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
-        assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
-    assert set(_ffi.SIGNATURES) == names
-    assert _ffi.lib.qip_hip_abi_version() == 6
+    assert set(_ffi.SIGNATURES) == names and set(_ffi.DEBUG_SIGNATURES) == debug
+    assert _ffi.lib.qip_hip_abi_version() == 7
+    # nothing else is exported, and the test hooks sit under their own version-script node
+    out = subprocess.run(["nm", "-D", "--defined-only", "--with-symbol-versions", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {}
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) >= 3 and parts[1] in "TW" and parts[2].startswith("qip_hip_"):
+            sym, _, node = parts[2].partition("@@")
+            exported[sym] = node
+    assert set(exported) == names | debug
+    assert all(exported[s] == "QIP_HIP_DEBUG" for s in debug) and all(exported[s] == "QIP_HIP" for s in names)
     # the Rust binding a maintainer would compile (bindings/rust/qip-hip/src/sys.rs; no rustc in this image) declares exactly
-    # the same set: it cannot be type-checked here, so at least it cannot fall behind the header (67 of 68)
+    # the contract: it cannot be type-checked here, so at least it cannot fall behind the header (67 of 68)
     sys_rs = open(os.path.join(ROOT, "bindings", "rust", "qip-hip", "src", "sys.rs")).read()
     assert set(re.findall(r"pub fn (qip_hip_[a-z0-9_]+)\s*\(", sys_rs)) == names
 
@@ -349,7 +364,7 @@ int main(void) {
   qip_op cnot = {QIP_OP_CONTROL, 2, idx, 1, 0, 0, 0, 0, &inner};
   qip_hip_transport t = {0, a2a, ars};
   qip_hip_dist_stats st = {0, 0, 0, 0.0, 0.0, 0, -1, 0, 0, 0, 0, 0, 0, 0};
-  qip_hip_jit_counters jc = {0, 0, 0, 0, 0, 0, 0.0, 0.0, 0, 0};
+  qip_hip_jit_counters jc = {0, 0, 0, 0, 0, 0, 0.0, 0.0, 0, 0, 0, 0};
   qip_hip_all_to_all_slice_fn slice = 0;
   (void)jc; (void)slice;
   char id[QIP_HIP_UNIQUE_ID_BYTES];
@@ -365,18 +380,37 @@ int main(void) {
     assert subprocess.run([str(exe)], env=env).returncode == 0  # validate_op is host code: runs without a GPU
 
 
-def test_r5_options_and_profile_classes_exist_without_a_gpu():
-    """host-only surface added in round 5: global options are validated, the profile class list grew at the end"""
+PRODUCT_GLOBAL_OPTIONS = ("force_generic", "jit_cache_cap", "jit_disk_cap_mb", "jit_disk_cache", "jit_procs", "tile_sched", "single_via_tile",
+                          "dist_fold_pack", "dist_plan_cost", "collective_timeout_s")
+TUNING_ONLY_OPTIONS = ("perm_rows", "line_bits", "tile_pad_from", "soft_measure_one_pass", "tile_wide_dense3_inline", "tile_wide_pin", "sparse_tile",
+                       "debug_slice_sweeps", "tile_diag_runs", "jit_threads", "tile_row_split_f32", "tile_row_split", "tile_wave_rule", "tile_remap",
+                       "k4_direct", "single_via_tile_f32")
+
+
+def test_option_surface_without_a_gpu():
+    """r6: the product build knows the options include/qip_hip.h documents and nothing else — the measured alternatives of
+    earlier rounds exist only in a -DQIP_HIP_TUNING build (conftest.has_tuning_options)."""
     names = [_ffi.lib.qip_hip_kernel_class_name(i).decode() for i in range(_ffi.lib.qip_hip_kernel_class_count())]
     assert names[-1] == "tile_sweep_parts" and names.index("k_tile_passes") == 8  # (existing indices unchanged)
-    for key, good, bad in (("debug_slice_sweeps", 4, 3), ("jit_procs", 2, 65), ("tile_diag_runs", 0, None), ("jit_disk_cache", 0, None)):
+    for key, good, bad in (("jit_procs", 2, 65), ("jit_disk_cache", 0, None), ("collective_timeout_s", 30, -1), ("jit_disk_cap_mb", 64, None)):
         q.set_global_option(key, good)
         if bad is not None:
             with pytest.raises(q.CircuitError):
                 q.set_global_option(key, bad)
-    q.set_global_option("debug_slice_sweeps", 0)
     q.set_global_option("jit_procs", 0)
-    q.set_global_option("tile_diag_runs", 1)
     q.set_global_option("jit_disk_cache", 1)
+    q.set_global_option("collective_timeout_s", 120)
+    q.set_global_option("jit_disk_cap_mb", -1)
+    from conftest import has_tuning_options
+
+    if not has_tuning_options():
+        for key in TUNING_ONLY_OPTIONS:
+            with pytest.raises(q.CircuitError, match="unknown global option"):
+                q.set_global_option(key, 0)
+    # every option the header documents is accepted, every accepted one is documented
+    hdr = open(os.path.join(ROOT, "include", "qip_hip.h")).read()
+    for key in PRODUCT_GLOBAL_OPTIONS:
+        assert '"%s"' % key in hdr, key
+    assert len(set(re.findall(r'^ \*   "([a-z0-9_]+)"', hdr, flags=re.M))) <= 25
     c = _ffi.jit_counters()
     assert c["procs"] >= 1 and c["disk_cache"] in (0, 1)

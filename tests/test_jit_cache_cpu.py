@@ -94,3 +94,103 @@ def test_compile_file_reports_errors(tmp_path):
     p = subprocess.run([helper, "0", str(bad), str(tmp_path / "bad.co")], capture_output=True, text=True)
     assert p.returncode == 1 and "qip_jitc:" in p.stderr
     assert subprocess.run([helper], capture_output=True).returncode == 64
+
+
+def test_cache_trusts_only_what_this_user_wrote(tmp_path):
+    """r6: a code object found on disk ends up on the GPU, so anything odd about it is a MISS and a
+    recompilation, never a load: a flipped byte in the code (the header's hash of the CODE bytes), a truncated-then-padded file,
+    a planted file with a valid-looking header, a symlink, a group/world-writable file or directory."""
+    d = str(tmp_path / "c")
+    n, mode = 15, 1 | 64
+    r1 = run(n, mode, 1, {"QIP_HIP_CACHE_DIR": d})
+    segs = r1["segments"]
+    assert r1["compiled"] == segs and len(files(d)) == segs and segs >= 3
+    assert oct(os.stat(d).st_mode & 0o777) == "0o700" and all(oct(os.stat(os.path.join(d, f)).st_mode & 0o777) == "0o600" for f in files(d))
+    names = files(d)
+    good = {f: open(os.path.join(d, f), "rb").read() for f in names}
+
+    def second(expect_compiled, expect_hits):
+        r = run(n, mode, 1, {"QIP_HIP_CACHE_DIR": d})
+        assert (r["compiled"], r["disk_hits"]) == (expect_compiled, expect_hits), r
+        for f in names:  # whatever was damaged has been replaced by a good object
+            assert open(os.path.join(d, f), "rb").read() == good[f], f
+            assert not os.path.islink(os.path.join(d, f))
+
+    victim = os.path.join(d, names[0])
+    # one flipped byte in the middle of the code: same length, same header
+    b = bytearray(good[names[0]])
+    b[len(b) // 2] ^= 0x40
+    open(victim, "wb").write(bytes(b))
+    second(1, segs - 1)
+    # truncated, then padded back to its length with zeros
+    open(victim, "wb").write(good[names[0]][: len(b) // 2] + bytes(len(b) - len(b) // 2))
+    second(1, segs - 1)
+    # another entry's (valid) object planted under this name: the key's second word in the header does not match
+    open(victim, "wb").write(good[names[1]])
+    second(1, segs - 1)
+    # a symlink to a valid object is not followed
+    os.unlink(victim)
+    os.symlink(os.path.join(d, names[1]), victim)
+    second(1, segs - 1)
+    # a file others may write is not trusted
+    os.chmod(victim, 0o666)
+    second(1, segs - 1)
+    os.chmod(victim, 0o600)
+    second(0, segs)
+    # a directory others may write is not used at all (no loads, no stores); explicit selection reports why
+    os.chmod(d, 0o777)
+    r = run(n, mode, 1, {"QIP_HIP_CACHE_DIR": d})
+    assert r["dir"] == "" and r["disk_cache"] == 0 and r["compiled"] == segs and r["disk_hits"] == 0 and r["disk_stores"] == 0
+    import rustqip_amd  # noqa: F401
+    from rustqip_amd import _ffi
+
+    assert _ffi.lib.qip_hip_jit_set_cache_dir(d.encode()) != 0 and "writable by group or others" in _ffi.last_error()
+    os.chmod(d, 0o700)
+    assert _ffi.lib.qip_hip_jit_set_cache_dir(d.encode()) == 0
+    assert _ffi.lib.qip_hip_jit_set_cache_dir(None) == 0
+
+
+def test_cache_directory_is_bounded(tmp_path):
+    """r6: after a store the directory is trimmed to its bound, oldest modification time first; a hit refreshes the time"""
+    d = str(tmp_path / "c")
+    mode = 1 | 64
+    r1 = run(15, mode, 1, {"QIP_HIP_CACHE_DIR": d})
+    first = files(d)
+    total = sum(os.path.getsize(os.path.join(d, f)) for f in first)
+    assert r1["disk_trimmed"] == 0 and total > 0
+    old = 1_000_000_000
+    for i, f in enumerate(first):  # age them, the first file least
+        os.utime(os.path.join(d, f), (old + 100 - i, old + 100 - i))
+    # a second plan under a bound of 1 MiB: the new objects stay, the oldest of the first plan go
+    r2 = run(16, mode, 1, {"QIP_HIP_CACHE_DIR": d, "QIP_HIP_CACHE_MAX_MB": "1"})
+    now = files(d)
+    kept_total = sum(os.path.getsize(os.path.join(d, f)) for f in now)
+    if total + r2["compiled"] * 1 > 0 and r2["disk_trimmed"]:
+        assert kept_total <= (1 << 20)
+        gone = [f for f in first if f not in now]
+        assert gone and gone == first[len(first) - len(gone):]  # the oldest (highest index: aged most) went first
+    else:  # (the two plans together fit one MiB on this compiler: nothing to trim)
+        assert kept_total <= (1 << 20)
+    # stale temporaries of a killed process are swept with a store; fresh ones are left alone
+    stale, fresh = os.path.join(d, "seg.1.2.3.hip"), os.path.join(d, "seg.4.5.6.hip")
+    open(stale, "w").write("x")
+    open(fresh, "w").write("x")
+    os.utime(stale, (old, old))
+    run(17, mode, 1, {"QIP_HIP_CACHE_DIR": d})
+    assert not os.path.exists(stale) and os.path.exists(fresh)
+
+
+def test_helper_removes_its_sources_when_asked(tmp_path):
+    """the background jobs of one-shot callers (option tile_auto): qip_jitc -u leaves the code object and removes the source"""
+    import rustqip_amd  # noqa: F401
+    from rustqip_amd import circuits
+    from rustqip_amd.ops import debug_tile_jit
+
+    src = debug_tile_jit(14, circuits.h_layer(14) + circuits.c2_random_circuit(14, 40, seed=3), 1 | 64)["first_source"]
+    f = tmp_path / "seg.hip"
+    f.write_text(src)
+    helper = os.path.join(ROOT, "rustqip_amd", "lib", "qip_jitc")
+    p = subprocess.run([helper, "-u", "0", str(f), str(tmp_path / "seg.co")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert not f.exists() and (tmp_path / "seg.co").stat().st_size > 1000
+    assert subprocess.run([helper, "-u"], capture_output=True).returncode == 64
