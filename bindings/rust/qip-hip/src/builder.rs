@@ -89,11 +89,14 @@ pub struct HipBuilder<P: HipPrecision = f64> {
     pub device: i32,
     /// option "tile" of the library: 1 = several gates per sweep, IEEE-equal to one sweep per gate (default)
     pub tile: i64,
+    /// option "tile_relabel": 1 = the scheduler may relabel the qubits when that shortens the plan (bit-identical for `tile` = 1;
+    /// uses the second buffer, as the reference's run loop does with `arena`, `builder.rs:406-407`) (default)
+    pub tile_relabel: i64,
 }
 
 impl<P: HipPrecision> Default for HipBuilder<P> {
     fn default() -> Self {
-        Self { local: LocalBuilder::default(), measurements: 0, device: 0, tile: 1 }
+        Self { local: LocalBuilder::default(), measurements: 0, device: 0, tile: 1, tile_relabel: 1 }
     }
 }
 
@@ -171,6 +174,7 @@ impl<P: HipPrecision> HipBuilder<P> {
         let n = self.local.n();
         let mut st = HipState::<P>::new(n, self.device)?;
         st.set_option("tile", self.tile)?;
+        st.set_option("tile_relabel", if self.tile >= 1 { self.tile_relabel } else { 0 })?;
         st.init_basis(initial_index(n, it))?;
         let pipeline = self.local.make_subcircuit().expect("LocalBuilder::make_subcircuit is infallible");
         let mut measurements = HipMeasurements { measurements: Vec::new() };
@@ -345,7 +349,7 @@ impl<P: HipPrecision> Invertable for HipBuilder<P> {
     type SimilarBuilder = Self;
 
     fn new_similar(&self) -> Self {
-        Self { device: self.device, tile: self.tile, ..Self::default() }
+        Self { device: self.device, tile: self.tile, tile_relabel: self.tile_relabel, ..Self::default() }
     }
     fn invert_subcircuit(sc: Self::Subcircuit) -> CircuitResult<Self::Subcircuit> {
         LocalBuilder::<P>::invert_subcircuit(sc)

@@ -313,7 +313,8 @@ int qip_hip_state_set_option(qip_hip_state* s, const char* key, int64_t value);
 
 /* Per-kernel-class timing, collected when option "profile" = 1.
  * classes: see qip_hip_kernel_class_name() — enumerate them, the list grows at the end (r4: "k_sparse_ell", "k_sparse_tile";
- * r5: "tile_sweep_parts" — not a kernel: its launch count is the number of PARTS of tile sweeps that ran in slices, no time, no bytes).
+ * r5: "tile_sweep_parts" — not a kernel: its launch count is the number of PARTS of tile sweeps that ran in slices, no time, no bytes;
+ * r6: "k_dense_small").
  * Resets with *_profile_reset. */
 int qip_hip_kernel_class_count(void);
 const char* qip_hip_kernel_class_name(int cls);

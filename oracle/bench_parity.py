@@ -125,8 +125,11 @@ def cpu_shape(n, dtype, op):
     return row
 
 
+OPTION_DEFAULTS = {"tile_auto": 1, "pair_floor": 1, "mfma": 1}  # (every other per-handle option defaults to 0)
+
+
 class _Sabotaged:
-    """TEST HOOK (QIP_BENCH_SABOTAGE_PARITY, tests/test_parity_gpu.py): the CHECKER is made to disagree — the oracle's output
+    """TEST HOOK (QIP_BENCH_SABOTAGE_PARITY, tests/test_gpu_d_full_size.py): the CHECKER is made to disagree — the oracle's output
     is perturbed on one row — so that bench.py's failure path (parity_ok false, value null, exit status 1) can be exercised.
     The product is not touched."""
 
@@ -175,7 +178,7 @@ class Parity:
             r = W.check_circuit(st_, self.n, ops, self.O, gate_by_gate=gate_by_gate, seed=seed, bases_per_step=bases, twin=twin_, max_len=max_len)
         finally:
             for k in options:
-                st_.set_option(k, 0)
+                st_.set_option(k, OPTION_DEFAULTS.get(k, 0))
         r["options"] = options
         r["bar"] = "IEEE-equal" if exact else "1e-12"
         r.setdefault("whole_vector_compares", 0)

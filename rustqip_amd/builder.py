@@ -107,9 +107,13 @@ def lower_to_matrix_op(entry: PipelineEntry) -> Optional[MatrixOp]:
 class HipBuilder:
     """Drop-in for the LocalBuilder<P> call sequence of the reference, GPU-backed."""
 
-    def __init__(self, dtype=np.complex128, device: int = 0, tile: int = 1):
+    def __init__(self, dtype=np.complex128, device: int = 0, tile: int = 1, tile_relabel: int = 1):
         self.dtype = np.dtype(dtype)
         self.device = device
+        # tile_relabel = 1: the scheduler may relabel the qubits when that shortens the plan (only moves are added: bit-identical
+        # for tile = 1).  It uses the second buffer — the reference's run loop holds `state` and `arena` as well
+        # (builder.rs:406-407); a state too large for it keeps the plain plan.
+        self.tile_relabel = tile_relabel
         # tile = 1: runs of gates between measurements are applied as LDS-resident multi-gate sweeps in circuit
         # order — IEEE-equal to one sweep per gate, several times fewer passes over HBM.  0 = one sweep per
         # gate, 2 = also hoist gates over gates they commute with (1e-12 instead of bit equality).
@@ -305,6 +309,7 @@ class HipBuilder:
         forced = list(forced_measurements or [])
         state = HipState(n, self.dtype, self.device)
         state.set_option("tile", self.tile)
+        state.set_option("tile_relabel", self.tile_relabel if self.tile >= 1 else 0)
         state.init_basis(self.initial_index(init))
         results: List[tuple] = []
         batch: List[MatrixOp] = []

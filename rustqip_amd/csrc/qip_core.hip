@@ -224,7 +224,7 @@ extern "C" int qip_hip_validate_op(uint32_t n, const qip_op* op) try {
 static const char* kKernelClassNames[KC_COUNT] = {
     "k_gate1q_pair", "k_gate1q_xlane", "k_phase",          "k_diag",           "k_diag1q",
     "k_swap_bits",   "k_gate_kq",      "k_gate_kq_mfma",   "k_tile_passes",    "k_gather_generic",
-    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits", "k_sparse_ell", "k_sparse_tile", "tile_sweep_parts"};
+    "noop_identity", "k_sparse_kq", "k_gate_big_mfma", "k_permute_bits", "k_sparse_ell", "k_sparse_tile", "tile_sweep_parts", "k_dense_small"};
 
 extern "C" int qip_hip_kernel_class_count(void) { return KC_COUNT; }
 extern "C" const char* qip_hip_kernel_class_name(int cls) {

@@ -101,6 +101,7 @@ enum KernelClass {
   KC_SPARSE_ELL,
   KC_SPARSE_TILE,
   KC_TILE_PARTS,  // (r5) not a kernel: `launches` counts the PARTS of tile sweeps that were launched in slices (TileSlicing); no time, no bytes
+  KC_DENSE_SMALL, // (r6) dense k = 5..10 on a state with fewer than 16 groups (k_dense_small)
   KC_COUNT
 };
 

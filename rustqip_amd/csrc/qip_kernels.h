@@ -2012,6 +2012,50 @@ __device__ __forceinline__ amp_t<T> g_term(const GatherDesc& d, uint64_t row, ui
   return cmul(val, in[vecrow]);
 }
 
+// ---- dense k = 5..10 on a state too small for the matrix-core kernels (fewer than 16 groups: n < k + controls + 4) ----------
+// The reference's own bench shape (qip/benches/state_bench.rs:118-139: n = 8, one dense 8-qubit gate) is ONE 256 x 256 complex
+// matrix-vector product.  The literal kernel runs it as 256 lanes x 256 sequential terms with the reference's index loops per
+// term (172 us); the matrix-core kernels need 16 groups per wave.  Here a block of 256 lanes owns 16 rows of one group: lane
+// (chunk, r) folds the columns [chunk * S/16, (chunk + 1) * S/16) of row 16 * rb + r in increasing column order — the group's
+// amplitudes staged in LDS, the matrix read TRANSPOSED (mt[c * S + row]: 16 consecutive rows = 256 contiguous bytes) — and lane
+// (0, r) adds the 16 partial sums in chunk order.  Out of place (in -> out); rows outside the control subspace are copied by
+// the launcher first.  Products and sums are unfused; the order of the additions differs from the reference's single fold:
+// the 1e-12 bar of dense k >= 3 gates, not bit equality (option force_generic keeps the literal fold).
+struct DenseSmallDesc {
+  uint32_t k;
+  uint32_t tpos[10];  // tpos[b] = index position of sub-index bit b (bit 0 = the LAST op index, matrix_ops.rs:12-21)
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dense_small(const amp_t<T>* __restrict__ in, amp_t<T>* __restrict__ out, Ins ins,
+                                                        DenseSmallDesc d, const amp_t<T>* __restrict__ mt) {
+  using A = amp_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dense_small_lds[];
+  A* x = reinterpret_cast<A*>(dense_small_lds);  // [S]
+  const uint32_t S = 1u << d.k;
+  A* partial = x + S;                            // [16][16]
+  const uint32_t tid = threadIdx.x, r = tid & 15u, chunk = tid >> 4;
+  const uint64_t base = insert_bits<-1>((uint64_t)blockIdx.y, ins);
+  auto spread = [&](uint32_t c) {
+    uint64_t o = 0;
+    for (uint32_t b = 0; b < d.k; ++b) o |= (uint64_t)((c >> b) & 1u) << d.tpos[b];
+    return o;
+  };
+  for (uint32_t c = tid; c < S; c += kBlock) x[c] = in[base | spread(c)];
+  __syncthreads();
+  const uint32_t row = 16u * blockIdx.x + r, per = S >> 4, c0 = chunk * per;
+  A acc = czero<A>();
+  const A* col = mt + (size_t)c0 * S + row;
+#pragma unroll 4
+  for (uint32_t j = 0; j < per; ++j) acc = cadd(acc, cmul(col[(size_t)j * S], x[c0 + j]));
+  partial[chunk * 16u + r] = acc;
+  __syncthreads();
+  if (chunk == 0) {
+    A tot = partial[r];
+    for (uint32_t ch = 1; ch < 16u; ++ch) tot = cadd(tot, partial[ch * 16u + r]);
+    out[base | spread(row)] = tot;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gather_generic(const amp_t<T>* __restrict__ in,
                                                            amp_t<T>* __restrict__ out, GatherDesc d,

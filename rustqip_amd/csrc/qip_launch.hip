@@ -728,6 +728,40 @@ static int launch_huge_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   return QIP_OK;
 }
 
+// dense k = 5..10 on a state with fewer than 16 groups (n < k + controls + 4): one block per 16 rows of a group (k_dense_small),
+// cur -> alt.  *done = false when the op does not qualify.
+template <typename T>
+static int launch_dense_small(qip_hip_state* s, const Plan& p, bool* done) {
+  *done = false;
+  const uint32_t k = (uint32_t)p.opos.size();
+  if (k < 5 || k > 10 || p.table.size() != ((size_t)2 << (2 * k))) return QIP_OK;
+  QCHK(ensure_alt(s));
+  const size_t S = (size_t)1 << k;
+  std::vector<amp_t<T>> mt(S * S);  // transposed: mt[c * S + row]
+  for (size_t row = 0; row < S; ++row)
+    for (size_t c = 0; c < S; ++c) mt[c * S + row] = mk<T>(p.table[2 * (row * S + c)], p.table[2 * (row * S + c) + 1]);
+  QCHK(arena_upload(s, mt.data(), mt.size() * sizeof(amp_t<T>), 0));
+  if (!s->capture_pool && mt.size() * sizeof(amp_t<T>) > (1u << 20)) HIPCHK(hipStreamSynchronize(s->stream));  // (pageable staging of a large table dies with this frame)
+  DenseSmallDesc d;
+  memset(&d, 0, sizeof d);
+  d.k = k;
+  for (uint32_t b = 0; b < k; ++b) d.tpos[b] = p.opos[k - 1 - b];
+  std::vector<uint32_t> pos = p.cpos;
+  for (uint32_t t : p.opos) pos.push_back(t);
+  const Ins ins = make_ins(pos, mask_of(p.cpos));
+  const uint32_t groups = 1u << (s->n - (uint32_t)pos.size());
+  // rows the controls leave alone are the identity: they travel to the second buffer as they are
+  if (!p.cpos.empty()) HIPCHK(hipMemcpyAsync(s->alt, s->cur, s->namps * s->amp_bytes, hipMemcpyDeviceToDevice, s->stream));
+  const size_t lds = (S + 256) * sizeof(amp_t<T>);
+  hipLaunchKernelGGL((k_dense_small<T>), dim3((unsigned)(S / 16), groups), dim3(kBlock), lds, s->stream, (const amp_t<T>*)s->cur, (amp_t<T>*)s->alt, ins, d,
+                     (const amp_t<T>*)s->arena);
+  HIPCHK(hipGetLastError());
+  std::swap(s->cur, s->alt);  // builder.rs:514
+  std::swap(s->owns_cur, s->owns_alt);
+  *done = true;
+  return QIP_OK;
+}
+
 template <typename T>
 static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_cls, const FlatOp& f) {
   const uint32_t k = (uint32_t)p.opos.size();
@@ -766,6 +800,14 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
   if (s->mfma && k > kMaxBigK && k <= kMaxHugeK && s->n >= used + 4) {
     *actual_cls = KC_GATE_KQ_BIG;
     return launch_huge_mfma<T>(s, p, st);
+  }
+  if (k > kMaxRegK && s->mfma && f.distinct) {  // a state too small for the matrix-core kernels: the small dense kernel (1e-12 bar, like them)
+    bool done = false;
+    QCHK(launch_dense_small<T>(s, p, &done));
+    if (done) {
+      *actual_cls = KC_DENSE_SMALL;
+      return QIP_OK;
+    }
   }
   if (k > kMaxRegK) {  // no register form: literal kernel, out of place
     *actual_cls = KC_GATHER_GENERIC;

@@ -76,6 +76,9 @@ def rand_unitary(k, rng):
 
 
 def hip_apply(n, op, x, **options):
+    """op . x through a fresh handle with the given per-handle options (a measured alternative that only a tuning build knows
+    is dropped on the product build: the call then runs the default path once more)"""
+    options = {k: v for k, v in options.items() if k not in TUNING_STATE_KEYS or tuning()}
     with q.HipState(n, x.dtype) as st:
         for k, v in options.items():
             st.set_option(k, v)

@@ -428,7 +428,9 @@ def test_dense_8_qubit_reference_bench_shape(O):
     # qip/benches/state_bench.rs:118-139: dense 8-qubit matrix on an 8-qubit state
     rng = np.random.default_rng(8)
     u = rand_unitary(8, rng)
-    check(O, 8, q.make_matrix_op(list(range(8)), u.ravel()), paths=("fast",))
+    op = q.make_matrix_op(list(range(8)), u.ravel())
+    check(O, 8, op, bitwise=False, paths=("fast",))  # (r6: k_dense_small — partial sums of 16 columns: the 1e-12 bar of dense k >= 3)
+    check(O, 8, op, paths=("generic",))               # the literal fold stays bit-equal
 
 
 def test_diagonal_gates(O):
@@ -787,3 +789,37 @@ def test_one_op_tile_sweeps_controlled_dense_and_both_row_shapes(O, row_split):
     finally:
         if tuning():
             q.set_global_option("tile_row_split", 11)
+
+
+def test_dense_gate_on_a_state_too_small_for_the_matrix_cores(O):
+    """r6: dense k = 5..10 with fewer than 16 groups (n < k + controls + 4) — the reference's own bench shape, state_bench.rs:118-139
+    (n = 8, one dense 8-qubit gate) — runs through k_dense_small (16 rows of a group per block, partial sums of S/16 columns) instead
+    of the literal kernel: the 1e-12 bar of dense k >= 3 gates; force_generic keeps the literal fold (bit-equal)."""
+    rng = np.random.default_rng(8)
+    for k in (5, 6, 8, 10):
+        for extra, nc in ((0, 0), (1, 0), (3, 0), (2, 1), (3, 2)):
+            n = k + extra
+            perm = [int(v) for v in rng.permutation(n)]
+            op = q.make_matrix_op(perm[:k], rand_unitary(k, rng).ravel())
+            if nc:
+                op = q.make_control_op(perm[k:k + nc], op)
+            for dtype, tol in ((np.complex128, TOL64), (np.complex64, TOL32)):
+                x = rand_state(n, 3 * k + extra, dtype)
+                want = oracle_apply(O, n, op, x)
+                with q.HipState(n, dtype) as st:
+                    st.set_option("profile", 1)
+                    st.upload(x)
+                    st.apply_op(op)
+                    got = st.download()
+                    prof = st.profile()
+                assert float(np.max(np.abs(got - want))) <= tol, (k, n, nc, dtype)
+                assert "k_dense_small" in prof and "k_gather_generic" not in prof, (k, n, nc, prof)
+                if dtype == np.complex128:
+                    assert np.array_equal(hip_apply(n, op, x, force_generic=1), want), (k, n, nc)
+    # zero rows / zero columns and exact 0 / 1 entries survive (a permutation matrix stays exact: every sum has one non-zero term)
+    k, n = 8, 9
+    pm = np.zeros((256, 256))
+    pm[np.arange(256), rng.permutation(256)] = 1.0
+    op = q.make_matrix_op([8, 1, 2, 3, 4, 5, 6, 7], pm.ravel())
+    x = rand_state(n, 5)
+    assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x))

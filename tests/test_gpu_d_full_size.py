@@ -292,13 +292,21 @@ def test_bench_fails_when_parity_fails(tmp_path):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--n-local", "20", "--gates", "64",
            "--no-extras", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["QIP_BENCH_DETAIL"] = str(tmp_path / "bench_detail.json")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, QIP_BENCH_SABOTAGE_PARITY="1"))
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    last = res.stdout.rstrip().splitlines()[-1]
+    line = json.loads(last)  # (the LAST line of stdout is the contract line)
+    assert len(last) < 4096
     assert res.returncode != 0 and line["value"] is None and line["parity_ok"] is False, (res.returncode, line["value"], line["parity_ok"])
+    assert line["value_withheld"] > 0 and line["parity"]["legs_failed"]
     assert "PARITY FAILED" in res.stderr
+    detail = json.load(open(tmp_path / "bench_detail.json"))
+    assert detail["parity"]["all_legs_ok"] is False and any(not leg["ok"] for leg in detail["parity"]["legs"].values())
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert res.returncode == 0 and line["value"] > 0 and line["parity_ok"] is True
+    last = res.stdout.rstrip().splitlines()[-1]
+    line = json.loads(last)
+    assert res.returncode == 0 and line["value"] > 0 and line["parity_ok"] is True and len(last) < 4096
+    assert line["roofline"]["frac"] > 0 and line["parity"]["whole_vector_compares"] >= 64 and line["stage"] == "final"
 
 
 @pytest.mark.slow

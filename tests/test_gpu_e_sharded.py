@@ -48,26 +48,37 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    detail_path = os.path.join(tempfile.mkdtemp(), "bench_detail.json")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--n-local", "20", "--gates", "64", "--dist-overlap", "4"]
+           "--n-local", "20", "--gates", "64", "--dist-overlap", "4", "--budget-s", "800"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
-                         env=dict(env, QIP_BENCH_DIST_BACKEND="gloo"))
+                         env=dict(env, QIP_BENCH_DIST_BACKEND="gloo", QIP_BENCH_DETAIL=detail_path))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak"
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    # r6: the compact contract line comes three times — after the headline (parity pending), after the sharded parity check, at the end
+    assert len(lines) == 3 and all(len(json.dumps(l)) < 4096 for l in lines), [len(json.dumps(l)) for l in lines]
+    assert lines[0]["parity_ok"] is None and lines[0]["value"] > 0 and lines[1]["parity_ok"] is True and lines[0]["value"] == lines[2]["value"]
+    line = lines[-1]
+    assert res.stdout.rstrip().splitlines()[-1].startswith("{")  # ... and it is the LAST line of stdout
+    assert line["n_gpus"] == 2 and line["config"]["n_qubits"] == 21 and line["scaling"] == "weak" and line["stage"] == "final"
     assert abs(line["norm_sqr_after"] - 1) < 1e-10
     # (the look-ahead keeps the qubit whose next H is farthest on the rank bit, and X gates there only rename the ranks:
     # a short headline circuit may need no exchange at all — the legs below and the parity leg do)
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_") and line["comm"]["remaps"] >= 0
-    ex = line["extras"]
+    assert line["rccl_ranks"] == 0  # (the host-staged test transport: RCCL saw nobody)
+    detail = json.load(open(detail_path))
+    ex = detail["extras"]
+    assert not detail.get("extras_skipped"), detail.get("extras_skipped")
     for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs4_grover_dense_k3_n21",
                  "configs1_mixed_n21", "headline_tiled_mode1", "configs3_clifford_t_tiled_mode1", "configs1_mixed_tiled_mode1",
                  "configs1_mixed_tiled_mode1_jit_wide", "configs1_mixed_tiled_mode1_jit_wide_overlap", "configs1_mixed_tiled_mode1_overlap"):
         assert "error" not in ex[name] and ex[name]["ops_per_s"] > 0, (name, ex[name])
     assert sum(ex[name]["comm_over_reps"]["remaps"] for name in ("configs3_clifford_t_n21", "configs4_grover_iteration_n21", "configs1_mixed_n21")) >= 1
     assert abs(ex["norm_sqr_end"] - 1) < 1e-9
-    par = line["parity"]  # the sharded path against the oracle, inside the bench run itself
+    par = detail["parity"]  # the sharded path against the oracle, inside the bench run itself
     assert "error" not in par and par["world"] == 2 and par["remaps_exercised"] >= 1 and par["max_abs_delta"] <= 1e-12, par
     # r4: the sharded state is checked at the size it was timed at (sub-cubes through the layout + twin + marginals), and the
     # verdict is a top-level field the run's exit status follows

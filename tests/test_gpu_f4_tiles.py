@@ -958,7 +958,10 @@ def test_programs_own_their_payloads_and_record_out_of_place_ops(O):
                 got = st.download()
                 prog.close()
             want = O.apply_ops_in_place(n, [op] * runs, x.copy())
-            assert np.array_equal(got, want), (name, reps, float(np.max(np.abs(got - want))))
+            if name.startswith("dense"):  # (k_dense_small: partial sums of 16 columns, the 1e-12 bar of dense k >= 3 gates)
+                assert float(np.max(np.abs(got - want))) <= TOL64 * max(1.0, float(np.max(np.abs(want)))), (name, reps)
+            else:
+                assert np.array_equal(got, want), (name, reps, float(np.max(np.abs(got - want))))
     # the payload lives on the device: the host table may change after the program was created (a graph replays nothing from the host)
     n = 12
     x = rand_state(n, 12)

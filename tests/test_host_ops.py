@@ -391,7 +391,7 @@ def test_option_surface_without_a_gpu():
     """r6: the product build knows the options include/qip_hip.h documents and nothing else — the measured alternatives of
     earlier rounds exist only in a -DQIP_HIP_TUNING build (conftest.has_tuning_options)."""
     names = [_ffi.lib.qip_hip_kernel_class_name(i).decode() for i in range(_ffi.lib.qip_hip_kernel_class_count())]
-    assert names[-1] == "tile_sweep_parts" and names.index("k_tile_passes") == 8  # (existing indices unchanged)
+    assert names[-2:] == ["tile_sweep_parts", "k_dense_small"] and names.index("k_tile_passes") == 8  # (existing indices unchanged)
     for key, good, bad in (("jit_procs", 2, 65), ("jit_disk_cache", 0, None), ("collective_timeout_s", 30, -1), ("jit_disk_cap_mb", 64, None)):
         q.set_global_option(key, good)
         if bad is not None:

@@ -1,5 +1,5 @@
 """The flat circuit-replay format "qipc 1" (SURVEY.md §8 row f2): Python writer/reader, C++ reader + CLI.
-Host logic only — no amplitudes are touched here; the GPU replay is in test_parity_gpu.py."""
+Host logic only — no amplitudes are touched here; the GPU replay is in test_gpu_b_boundary.py."""
 import cmath
 import os
 import subprocess
@@ -107,7 +107,7 @@ def test_cpp_reader_rejects_what_python_rejects(cli, tmp_path):
 def test_cpp_reader_accepts_the_python_writer_and_needs_a_gpu(cli, tmp_path):
     """Without a device the CLI parses the whole file, then fails loudly at state creation: no CPU fallback."""
     if q.device_count() > 0:
-        pytest.skip("a GPU is present: the replay itself is checked in test_parity_gpu.py")
+        pytest.skip("a GPU is present: the replay itself is checked in test_gpu_b_boundary.py")
     p = tmp_path / "ok.qipc"
     replay.dump(str(p), sample_circuit())
     r = subprocess.run([cli, str(p)], capture_output=True, text=True)

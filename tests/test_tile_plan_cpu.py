@@ -487,7 +487,7 @@ def test_run_time_compiled_segments_build_without_a_gpu():
     """option tile_jit: every multi-gate segment is written out as straight-line HIP source (one pass_* helper call per
     gate, descriptors as constexpr values) and compiled with hiprtc.  hiprtc cross-compiles for gfx950 without a device,
     so the generator is exercised here for every gate shape a segment can hold, in both precisions; that the compiled
-    kernels compute the interpreter's results bit for bit is the GPU test's job (tests/test_parity_gpu.py)."""
+    kernels compute the interpreter's results bit for bit is the GPU test's job (tests/test_gpu_f4_tiles.py)."""
     from rustqip_amd import _ffi
     from rustqip_amd.ops import debug_tile_jit
 
@@ -654,7 +654,7 @@ def test_wide_tile_segments_plan_and_compile_without_a_gpu():
     positions — fewer sweeps for the same circuit, every op still in exactly one step — and their generated source (32-element
     register arrays, LDS transpositions in four quarters) compiles with hiprtc for gfx950 without a device, also in the
     parametrised form and with contraction allowed.  (What the compiled kernels compute is checked on the GPU against the
-    narrow sweeps bit for bit and against the oracle: tests/test_parity_gpu.py::test_wide_tiles_...)"""
+    narrow sweeps bit for bit and against the oracle: tests/test_gpu_f4_tiles.py::test_wide_tiles_...)"""
     from rustqip_amd.ops import debug_tile_jit, plan_tiles
 
     n = 30

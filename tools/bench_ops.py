@@ -14,6 +14,19 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rustqip_amd as q  # noqa: E402
+
+
+def _known(fn, key, value):
+    """set an option; the measured alternatives exist only in a tuning build of the library (QIP_HIP_TUNING=1 python -m rustqip_amd.build):
+    on the product build they are skipped — returns False then, and the row that needed it is left out"""
+    try:
+        fn(key, value)
+        return True
+    except q.CircuitError as exc:
+        if "unknown" in str(exc):
+            return False
+        raise
+
 from rustqip_amd import circuits  # noqa: E402
 
 
@@ -112,11 +125,11 @@ def main():
     if os.environ.get("QIP_SINGLE_VIA_TILE"):  # tuning aid: 0 = dedicated kernels only, 1 (default) / 2 = one-item tile sweeps
         q.set_global_option("single_via_tile", int(os.environ["QIP_SINGLE_VIA_TILE"]))
     if os.environ.get("QIP_TILE_ROW_SPLIT"):  # 11 (default): split rows in the tile sweeps, 5: contiguous rows
-        q.set_global_option("tile_row_split", int(os.environ["QIP_TILE_ROW_SPLIT"]))
+        _known(q.set_global_option, "tile_row_split", int(os.environ["QIP_TILE_ROW_SPLIT"]))
     if os.environ.get("QIP_K4_DIRECT"):
-        q.set_global_option("k4_direct", int(os.environ["QIP_K4_DIRECT"]))
+        _known(q.set_global_option, "k4_direct", int(os.environ["QIP_K4_DIRECT"]))
     if os.environ.get("QIP_SINGLE_VIA_TILE_F32"):
-        q.set_global_option("single_via_tile_f32", int(os.environ["QIP_SINGLE_VIA_TILE_F32"]))
+        _known(q.set_global_option, "single_via_tile_f32", int(os.environ["QIP_SINGLE_VIA_TILE_F32"]))
     print(f"| op (n={n}, Complex<{'f32' if f32 else 'f64'}>) | kernel | ms | algorithmic GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
     with q.HipState(n, dtype) as st:
         st.init_basis(0)
@@ -125,11 +138,13 @@ def main():
             if only and only not in name:
                 continue
             for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32", "swap_single"):
-                st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
-            q.set_global_option("sparse_tile", opts.get("_sparse_tile", 1))
+                _known(st.set_option, k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
+            ok = _known(q.set_global_option, "sparse_tile", opts.get("_sparse_tile", 1)) or opts.get("_sparse_tile", 1) == 1
             for k, v in opts.items():
                 if not k.startswith("_"):
-                    st.set_option(k, v)
+                    ok = _known(st.set_option, k, v) and ok
+            if not ok:
+                continue  # (a row of a measured alternative: needs a tuning build)
             comp = st.compile_ops([op] * reps)
             st.set_option("profile", 0)
             st.apply_compiled(st.compile_ops([op]))
@@ -147,8 +162,8 @@ def main():
             print(f"| {name} | `{kern}` | {dt*1e3:.3f} | {by/dt/1e9:.0f} | {100*by/dt/1e9/8000:.1f} |")
         st.set_option("profile", 0)
         for k in ("lowbit_shuffle", "mfma", "force_generic", "unroll", "packed_f32", "swap_single"):  # (the last row's options must not leak into the reductions)
-            st.set_option(k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
-        q.set_global_option("sparse_tile", 1)
+            _known(st.set_option, k, {"lowbit_shuffle": 1, "mfma": 1, "force_generic": 0, "unroll": 0, "packed_f32": 1, "swap_single": 0}[k])
+        _known(q.set_global_option, "sparse_tile", 1)
         for name, fn, by in (("norm_sqr", st.norm_sqr, amp * 2**n), ("measure_probs k=1", lambda: st.measure_probs([mid]), amp * 2**n),
                              ("measure_probs k=3", lambda: st.measure_probs([hi, mid, lo]), amp * 2**n),
                              ("measure_probs k=12 top bits", lambda: st.measure_probs(list(range(12))), amp * 2**n),
@@ -157,8 +172,8 @@ def main():
                              ("measure_probs k=16", lambda: st.measure_probs(list(range(2, 18))), amp * 2**n),
                              ("soft_measure (2 passes)", lambda: st.soft_measure([0, mid, lo], 0.4321), amp * 2**n),
                              ("soft_measure (one launch: chunk sums + last block's walk; measured alternative)",
-                              lambda: (q.set_global_option("soft_measure_one_pass", 1), st.soft_measure([0, mid, lo], 0.4321),
-                                       q.set_global_option("soft_measure_one_pass", 0)), amp * 2**n)):
+                              lambda: (_known(q.set_global_option, "soft_measure_one_pass", 1), st.soft_measure([0, mid, lo], 0.4321),
+                                       _known(q.set_global_option, "soft_measure_one_pass", 0)), amp * 2**n)):
             fn()
             t0 = time.perf_counter()
             for _ in range(3):

@@ -311,6 +311,61 @@ __global__ __launch_bounds__(256, BPC) void k_v13(A* __restrict__ st, Hp7 hp, A 
   for (int u = 0; u < 32; ++u) stg<true>(st + (w | off(u)) + lane_off, x[u]);
 }
 
+// r6 experiment (kill criterion first): the same 13-bit tile with 16 amplitudes per lane (FOUR register bits) and 512
+// lanes per block — half the registers per lane, twice the waves: 2 blocks per CU are 4 waves per SIMD (<= 128 VGPRs), 3 blocks per CU 6 waves
+// per SIMD (<= 84 VGPRs, 64 of them amplitudes).  LDS again only a 32-KiB transposition buffer: a pass moves the tile through it in four rounds
+// of 4 elements per lane.  Keep only if a light sweep is <= 5.2 ms at >= 3 blocks per CU AND the loaded shapes (P = 3, 4) beat k_v13.
+template <int P, int G, int BPC>
+__global__ __launch_bounds__(512, BPC) void k_v13w(A* __restrict__ st, Hp7 hp, A f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  A* buf = reinterpret_cast<A*>(raw);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7: three tile bits
+  uint64_t w = (uint64_t)blockIdx.x << 6;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const uint32_t p = hp.sorted[j];
+    w = ((w >> p) << (p + 1)) | (w & ((1ull << p) - 1ull));
+  }
+  if (hp.p5 != 5u) {
+    const uint64_t b = (w >> hp.p5) & 1ull;
+    w = (w & ~(1ull << hp.p5)) | (b << 5);
+  }
+  w |= ((uint64_t)(wave & 1u) << hp.h[0]) | ((uint64_t)((wave >> 1) & 1u) << hp.h[1]) | ((uint64_t)(wave >> 2) << hp.h[2]);
+  const uint32_t lane_off = (lane & 31u) | ((lane >> 5) << hp.p5);
+  A x[16];
+  auto off = [&](int u) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) o |= (uint64_t)((u >> b) & 1) << hp.h[3 + b];
+    return o;
+  };
+#pragma unroll
+  for (int u = 0; u < 16; ++u) x[u] = ldg<true>(st + (w | off(u)) + lane_off);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {  // 4 elements per lane x 512 lanes = 2^11 amplitudes = the 32-KiB buffer
+      const uint32_t slot_w = tile_slot<A>(tid);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) buf[slot_w ^ tile_slot<A>((uint32_t)i << 9)] = x[4 * qd + i];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const uint32_t tr = ((tid & 15u) << 5) | (tid >> 4);  // another lane -> tile-bit assignment
+      const uint32_t slot_r = tile_slot<A>(tr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[4 * qd + i] = buf[slot_r ^ tile_slot<A>((uint32_t)i << 9)];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = cmul(f, x[i]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) stg<true>(st + (w | off(u)) + lane_off, x[u]);
+}
+
 __global__ void k_init(A* st, uint64_t n) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     A v;
@@ -578,6 +633,41 @@ int main(int argc, char** argv) {
       V13(3, 8, 3);
     }
 #undef V13
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "v13w")) {
+    // r6: 512 lanes x 16 amplitudes against 256 lanes x 32, same tile, same positions, light and loaded shapes
+    const uint32_t N = (uint32_t)n;
+    const uint64_t ntiles = g_n >> 13;
+    A f;
+    f.x = 0.6;
+    f.y = 0.8;
+    auto mk7 = [&](std::vector<uint32_t> h, uint32_t p5) {
+      Hp7 hp;
+      for (int j = 0; j < 7; ++j) hp.h[j] = h[j];
+      std::vector<uint32_t> sp = h;
+      for (uint32_t& v : sp) if (v == 5u) v = p5;
+      std::sort(sp.begin(), sp.end());
+      for (int j = 0; j < 7; ++j) hp.sorted[j] = sp[j];
+      hp.p5 = p5;
+      return hp;
+    };
+    struct { std::vector<uint32_t> h; uint32_t p5; const char* name; } sets[] = {
+        {{12, 13, 14, 15, 16, 17, 18}, 11, "split 12..18"},
+        {{N - 7, N - 6, N - 5, N - 4, N - 3, N - 2, N - 1}, 11, "split top7"},
+        {{12, 14, 17, 20, 22, 24, N - 1}, 11, "split scattered"},
+        {{5, 6, 7, 8, 9, 10, 12}, 11, "split low"}};
+#define V13(P, G, BPC) run("V13  256x32 " #BPC "/CU", P, G, s.name, [&] { hipLaunchKernelGGL((k_v13<P, G, BPC>), dim3((unsigned)ntiles), dim3(256), 32768, 0, g_st, hp, f); })
+#define V13W(P, G, BPC) run("V13W 512x16 " #BPC "/CU", P, G, s.name, [&] { hipLaunchKernelGGL((k_v13w<P, G, BPC>), dim3((unsigned)ntiles), dim3(512), 32768, 0, g_st, hp, f); })
+    for (auto& s : sets) {
+      const Hp7 hp = mk7(s.h, s.p5);
+      V13(1, 2, 2);  V13W(1, 2, 2);  V13W(1, 2, 3);
+      V13(3, 8, 2);  V13W(3, 8, 2);  V13W(3, 8, 3);
+      V13(4, 16, 2); V13W(4, 16, 2); V13W(4, 16, 3);
+    }
+#undef V13
+#undef V13W
     CK(hipFree(g_st));
     return 0;
   }
