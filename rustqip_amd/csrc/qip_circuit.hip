@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include <cerrno>
+#include <climits>
 #include <dirent.h>
 #include <fcntl.h>
 #include <sched.h>
@@ -302,8 +303,9 @@ static int hiprtc_compile(const std::string& src, bool fma, std::vector<char>* c
 //    cache — the default rule falls back to "none", qip_hip_jit_set_cache_dir reports the reason); a file must be a regular
 //    file (no symlink), owned by the uid, not group/world-writable; its header carries the source length, the second word of
 //    the key and a hash of the CODE BYTES, all checked on load.  Anything odd is a miss (and a recompilation that overwrites
-//    the file), never an error, never a load.  The key names the compiler by everything that can be asked of it at run time:
-//    hiprtc's version, the HIP runtime's version, the sizes of libhiprtc / libamd_comgr as loaded.
+//    the file), never an error, never a load.  The key names the compiler by the ROCm installation the helper processes use
+//    ($ROCM_PATH or /opt/rocm: its release and the sizes of its libhiprtc / libamd_comgr — see jit_compiler_identity; a host
+//    program that has another ROCm's libraries loaded, PyTorch for one, hands even single segments to a helper).
 //  * r6, bounded: after a store the directory is trimmed to "jit_disk_cap_mb" (global option; $QIP_HIP_CACHE_MAX_MB; default
 //    1024) — oldest modification time first (a hit refreshes it), stale temporaries with them.
 // ---------------------------------------------------------------------------------------
@@ -343,9 +345,33 @@ static uint64_t hash_mix(const char* p, size_t n, uint64_t h) {  // an independe
 static const char* jit_flags_text(bool fma) {
   return fma ? "gfx950 -O3 c++17 contract=fast no-slp" : "gfx950 -O3 c++17 contract=off no-slp";
 }
-// everything about the compiler that can be asked at run time: hiprtc's version, the HIP runtime's version, and the byte sizes
-// of the two shared objects that do the work as this process has them loaded (an updated ROCm changes at least one of them)
+// The compiler a key names.  New segments are compiled by helper processes (qip_jitc): fresh processes that load the system's
+// ROCm — whatever THIS process has loaded.  A host program that imported PyTorch first carries PyTorch's own bundled libhiprtc /
+// libamd_comgr / HIP runtime (another ROCm release), so "as loaded here" named a different compiler than the one that wrote the
+// files: the helpers' objects failed the header check and every segment was compiled a second time in process (r6: bench.py's
+// 207 segments, 93 s instead of 31), and a process without PyTorch never found what a process with PyTorch had cached.
+// So the identity is that of the INSTALLATION the helpers use, read from its files: $ROCM_PATH or /opt/rocm — the release
+// (.info/version) and the byte sizes of libhiprtc / libamd_comgr there (an updated ROCm changes at least one of the three).
+// Only when no such installation is found does the key fall back to what this process has loaded (hiprtc's version, the HIP
+// runtime's version, the sizes of the two shared objects as loaded).
+static std::string g_jit_canonical_hiprtc;  // real path of the installation's libhiprtc ("" = fell back to as-loaded)
 static std::string jit_compiler_identity() {
+  for (const char* root : {(const char*)getenv("ROCM_PATH"), "/opt/rocm"}) {
+    if (!root || !*root) continue;
+    const std::string r = root;
+    struct stat st_rtc, st_comgr;
+    if (stat((r + "/lib/libhiprtc.so").c_str(), &st_rtc) != 0 || stat((r + "/lib/libamd_comgr.so").c_str(), &st_comgr) != 0) continue;
+    char release[64] = "?";
+    if (FILE* f = fopen((r + "/.info/version").c_str(), "r")) {
+      if (fscanf(f, "%63s", release) != 1) strcpy(release, "?");
+      fclose(f);
+    }
+    char real[PATH_MAX];
+    if (realpath((r + "/lib/libhiprtc.so").c_str(), real)) g_jit_canonical_hiprtc = real;
+    char v[224];
+    snprintf(v, sizeof v, "qipjit3 rocm %s libhiprtc %lld comgr %lld ", release, (long long)st_rtc.st_size, (long long)st_comgr.st_size);
+    return v;
+  }
   int major = 0, minor = 0, rt = 0;
   long long sz_rtc = 0, sz_comgr = 0;
   (void)hiprtc_load();  // (part of every key: always asked, so that keys do not depend on who hashes first)
@@ -369,6 +395,20 @@ static std::string jit_compiler_identity() {
   char v[160];
   snprintf(v, sizeof v, "qipjit2 hiprtc %d.%d runtime %d libhiprtc %lld comgr %lld ", major, minor, rt, sz_rtc, sz_comgr);
   return v;
+}
+// true when a compilation in THIS process would use another libhiprtc than the one the keys name (a host program that brought its
+// own ROCm libraries): such a process sends even a single new segment to a helper, so that a file is what its name says
+static bool jit_foreign_hiprtc_loaded() {
+  static const bool foreign = [] {
+    if (g_jit_canonical_hiprtc.empty() || hiprtc_load() != QIP_OK) return false;
+    int (*ver)(int*, int*) = nullptr;
+    *(void**)(&ver) = dlsym(g_rtc.handle, "hiprtcVersion");
+    Dl_info info;
+    char real[PATH_MAX];
+    if (!ver || !dladdr((void*)ver, &info) || !info.dli_fname || !realpath(info.dli_fname, real)) return false;
+    return g_jit_canonical_hiprtc != real;
+  }();
+  return foreign;
 }
 static JitHash jit_hash(const std::string& src, bool fma) {
   static JitHash base = [] {  // the embedded header and the compiler's identity: once per process
@@ -564,7 +604,20 @@ extern "C" int qip_hip_jit_compile_file(const char* src_path, int fma, const cha
   fclose(f);
   std::vector<char> code;
   QCHK(hiprtc_compile(src, fma != 0, &code));
-  if (!jit_disk_write(out_path, src.size(), jit_hash(src, fma != 0), code)) return fail(QIP_ERR_DEVICE, "cannot write %s", out_path);
+  // The requester named the file by ITS key (<32 hex digits>.co): the header repeats the key's second word so that the requester's
+  // own check passes — the name is the contract, whatever this process would have computed.  Any other name: this process's key.
+  JitHash h = jit_hash(src, fma != 0);
+  {
+    const char* base = strrchr(out_path, '/');
+    base = base ? base + 1 : out_path;
+    unsigned long long a = 0, b = 0;
+    int used = 0;
+    if (strlen(base) == 35 && sscanf(base, "%16llx%16llx%n", &a, &b, &used) == 2 && used == 32 && !strcmp(base + 32, ".co")) {
+      h.a = a;
+      h.b = b;
+    }
+  }
+  if (!jit_disk_write(out_path, src.size(), h, code)) return fail(QIP_ERR_DEVICE, "cannot write %s", out_path);
   return QIP_OK;
 } QIP_CATCH_ALL
 
@@ -1528,7 +1581,7 @@ static int jit_obtain_code(const std::vector<std::pair<std::string, bool>>& jobs
   // 2. the rest: side by side in helper processes when there are several (and somewhere to put the results) ...
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t by_helpers = 0;
-  if (todo.size() >= 2 && procs > 1 && !dir.empty()) {
+  if (!todo.empty() && !dir.empty() && ((todo.size() >= 2 && procs > 1) || jit_foreign_hiprtc_loaded())) {
     helper = jit_helper_path();
     if (!helper.empty()) {
       jit_compile_in_helpers(helper, dir, procs, jobs, todo, paths);

@@ -36,7 +36,6 @@ extern "C" int qip_hip_device_count(void) try {
 int64_t g_force_generic = 0;
 // Selector bits below this position stay in the grid as a per-lane predicate (whole lines are swept); see kLineBits.
 uint32_t g_line_bits = qipk::kLineBits;
-int64_t g_perm_rows = 0;
 // Tile sweeps, measured on MI355X at n = 30 (tools/tune_tile.hip, profiles/r03_tile_skeleton.md): the time of a light sweep is set
 // by WHICH five high positions the tile holds — 5.2 ms for {11..15}, 6.3 ms for {6..10}, 6.7 ms for the top five — not by the
 // block structure (persistent / prefetching variants are no faster).  Free positions a segment does not need are therefore
@@ -73,11 +72,6 @@ extern "C" int qip_hip_set_global_option(const char* key, int64_t value) try {
     return QIP_OK;
   }
 #ifdef QIP_HIP_TUNING
-  if (!strcmp(key, "perm_rows")) {
-    if (value != 0 && value != 5 && value != 6) return fail(QIP_ERR_INVALID, "perm_rows must be 0 (automatic), 5 or 6");
-    g_perm_rows = value;
-    return QIP_OK;
-  }
   if (!strcmp(key, "line_bits")) {
     if (value < 0 || value > 3) return fail(QIP_ERR_INVALID, "line_bits must be 0..3");
     g_line_bits = (uint32_t)value;

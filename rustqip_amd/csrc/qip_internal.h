@@ -60,7 +60,6 @@ int fail(int code, const char* fmt, ...);
 
 extern int64_t g_force_generic;
 extern uint32_t g_line_bits;
-extern int64_t g_perm_rows;
 extern int64_t g_tile_pad_from, g_tile_wave_rule, g_tile_remap, g_tile_sched;
 extern int64_t g_single_via_tile, g_single_via_tile_f32;
 extern int64_t g_dist_fold_pack, g_dist_plan_cost;  // qip_dist.hip

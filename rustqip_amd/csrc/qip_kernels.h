@@ -535,19 +535,23 @@ __global__ __launch_bounds__(kBlock) void k_swapn(E* __restrict__ st, uint64_t n
 // out[j] = in[src(j)] where bit pi[d] of src(j) is bit d of j: the composition of any run of Swap ops (each one a
 // product of bit transpositions, qubit_iterators.rs:208-218; pure moves, so the composition is bit-identical to the
 // ops applied one after the other), the gather of a multi-GPU remap, a qubit relabelling.
-// A block moves a tile of 2^(2R) elements chosen so that BOTH sides stream whole rows of 2^R elements (512 B): the
-// tile's destination bits are the R row bits of the destination plus the R destination bits that are fed by the
-// source's row bits (padded with the next lowest bits when the two sets overlap).  Rows are read in source order,
-// parked in LDS at their destination coordinate and written in destination order.  The LDS slot is the tile coordinate
-// with up to FB of its higher bits XOR-folded into the low FB bits (FB = 3 for 16-byte elements, 4 for 8-byte ones:
-// the lanes of one ds_write / ds_read bank group then hit distinct banks on both sides, MI355X_MICROARCH.md §LDS).
+// A block moves a tile of 2^TB elements chosen so that BOTH sides stream whole rows: the tile's destination bits are the R
+// row bits of the destination, the destination bits that are fed by the source's row bits, and (r6, "split rows") index
+// position 11 on both sides — thread bit 5, the upper half of a wave, is position 11, so a wave-level access is two 512-byte
+// halves 32 KiB apart on the read side AND on the write side (byte-address bit 15: the r4 finding of the tile sweeps,
+// profiles/r04_tile_rows.md, measured for this sweep in profiles/r06_permute.md: every permutation 5.2 - 5.9 ms at n = 30
+// against 5.4 - 6.7 with contiguous rows).  Rows are read in source order, parked in LDS at their destination coordinate and
+// written in destination order.  The LDS slot is the tile coordinate with up to FB of its higher bits XOR-folded into the low
+// FB bits (FB = 3 for 16-byte elements, 4 for 8-byte ones: the lanes of one ds_write / ds_read bank group then hit distinct
+// banks on both sides, MI355X_MICROARCH.md §LDS).
 constexpr int kPermMaxTile = 12;
 struct PermDesc {
-  uint32_t tbits[kPermMaxTile];  // destination positions of the tile bits, ascending (tbits[i] = i for i < R)
-  uint32_t sbits[kPermMaxTile];  // source positions the tile covers, ascending (sbits[i] = i for i < R)
-  uint32_t u2c[kPermMaxTile];    // bit i of the source-side coordinate is bit u2c[i] of the tile (destination) coordinate
+  uint32_t tbits[kPermMaxTile];    // destination position of tile-coordinate bit i (tbits[i] = i for i < R; thread bits 0..7, element bits 8..)
+  uint32_t sbits[kPermMaxTile];    // source position of source-side coordinate bit i (sbits[i] = i for i < R)
+  uint32_t u2c[kPermMaxTile];      // bit i of the source-side coordinate is bit u2c[i] of the tile (destination) coordinate
+  uint32_t tsorted[kPermMaxTile];  // the tile's destination positions ascending (the block index fills the others)
   uint32_t nfold, fold_from[4], fold_to[4];
-  uint32_t n_outer;              // destination positions outside the tile and the source position each one feeds
+  uint32_t n_outer;                // destination positions outside the tile and the source position each one feeds
   unsigned char outer_dst[64], outer_src[64];
 };
 __device__ __forceinline__ uint32_t perm_fold(uint32_t c, const PermDesc& d) {
@@ -555,18 +559,10 @@ __device__ __forceinline__ uint32_t perm_fold(uint32_t c, const PermDesc& d) {
   for (uint32_t i = 0; i < d.nfold; ++i) f ^= ((c >> d.fold_from[i]) & 1u) << d.fold_to[i];
   return c ^ f;
 }
-template <typename A, int R, bool NT>
+template <typename A, int R, int TB, bool NT, int PIPE>
 __global__ __launch_bounds__(kBlock) void k_permute_bits(const A* __restrict__ in, A* __restrict__ out, PermDesc d) {
-  constexpr int TB = 2 * R, E = (1 << TB) / kBlock, EB = TB - 8;  // elements per thread; coordinate bits 8.. come from e
+  constexpr int E = (1 << TB) / kBlock, EB = TB - 8;  // elements per thread; coordinate bits 8.. come from e
   __shared__ __attribute__((aligned(16))) A tile[1 << TB];
-  uint64_t dbase = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
-#pragma unroll
-  for (int i = 0; i < TB; ++i) {
-    const uint32_t p = d.tbits[i];
-    dbase = ((dbase >> p) << (p + 1)) | (dbase & ((1ull << p) - 1ull));
-  }
-  uint64_t sbase = 0;
-  for (uint32_t i = 0; i < d.n_outer; ++i) sbase |= ((dbase >> d.outer_dst[i]) & 1ull) << d.outer_src[i];
   const uint32_t t = threadIdx.x;
   // thread part of: source offset, tile coordinate reached from the source side, destination offset
   uint64_t s_t = t & ((1u << R) - 1u), d_t = t & ((1u << R) - 1u);
@@ -581,28 +577,54 @@ __global__ __launch_bounds__(kBlock) void k_permute_bits(const A* __restrict__ i
     }
   }
   const uint32_t slot_ld = perm_fold(c_t, d), slot_st = perm_fold(t, d);  // the fold is linear: e's part is XOR-ed in below
+  // a block moves PIPE consecutive tiles; the loads of tile p + 1 are in flight while tile p is read back from LDS and stored
+  const uint64_t first = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) * PIPE;
+  uint64_t dbase, sbase;
+  auto bases = [&](uint64_t b) {
+    dbase = b;
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const uint32_t p = d.tsorted[i];
+      dbase = ((dbase >> p) << (p + 1)) | (dbase & ((1ull << p) - 1ull));
+    }
+    sbase = 0;
+    for (uint32_t i = 0; i < d.n_outer; ++i) sbase |= ((dbase >> d.outer_dst[i]) & 1ull) << d.outer_src[i];
+  };
   A x[E];
+  auto load = [&]() {
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    uint64_t s_e = 0;
+    for (int e = 0; e < E; ++e) {
+      uint64_t s_e = 0;
 #pragma unroll
-    for (int i = 0; i < EB; ++i) s_e |= (uint64_t)((e >> i) & 1) << d.sbits[8 + i];
-    x[e] = ldg<NT>(in + (sbase | s_t | s_e));
-  }
+      for (int i = 0; i < EB; ++i) s_e |= (uint64_t)((e >> i) & 1) << d.sbits[8 + i];
+      x[e] = ldg<NT>(in + (sbase | s_t | s_e));
+    }
+  };
+  bases(first);
+  load();
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    uint32_t c_e = 0;
+  for (int p = 0; p < PIPE; ++p) {
 #pragma unroll
-    for (int i = 0; i < EB; ++i) c_e |= (uint32_t)((e >> i) & 1) << d.u2c[8 + i];
-    tile[slot_ld ^ perm_fold(c_e, d)] = x[e];
-  }
-  __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      uint32_t c_e = 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    uint64_t d_e = 0;
+      for (int i = 0; i < EB; ++i) c_e |= (uint32_t)((e >> i) & 1) << d.u2c[8 + i];
+      tile[slot_ld ^ perm_fold(c_e, d)] = x[e];
+    }
+    __syncthreads();
+    const uint64_t dcur = dbase;
+    if (p + 1 < PIPE) {
+      bases(first + p + 1);
+      load();
+    }
 #pragma unroll
-    for (int i = 0; i < EB; ++i) d_e |= (uint64_t)((e >> i) & 1) << d.tbits[8 + i];
-    stg<NT>(out + (dbase | d_t | d_e), tile[slot_st ^ perm_fold((uint32_t)e << 8, d)]);
+    for (int e = 0; e < E; ++e) {
+      uint64_t d_e = 0;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) d_e |= (uint64_t)((e >> i) & 1) << d.tbits[8 + i];
+      stg<NT>(out + (dcur | d_t | d_e), tile[slot_st ^ perm_fold((uint32_t)e << 8, d)]);
+    }
+    if (p + 1 < PIPE) __syncthreads();
   }
 }
 // states smaller than one tile: one element per thread, the source index bit by bit
@@ -1881,93 +1903,125 @@ __global__ __launch_bounds__(kTileBlock, 5) void k_tile_passes(amp_t<T>* __restr
   }
 }
 
-// ---- dense 4-qubit gate on the matrix cores through an LDS-resident tile -------------------------------------------------
+// ---- dense 4- / 5-qubit gate on the matrix cores through an LDS-resident tile ----------------------------------------------
 // k_gate_kq_mfma reads its operands where they lie: 16 groups x 4 sub-indices per load instruction = four 256-B runs, 65 %
-// of peak for k = 4 whatever the target bits.  Here a block stages the tile the one-op sweeps use — index bits 0..5 + the
-// gate's targets above them + free positions from 11 upwards, whole 1-KiB rows on both global sides — and the wave takes
-// its matrix-core operands from LDS: same lane mapping (lane = (group j, q), c~ = 4 m + q over the targets in ascending
-// position order), same host-built A fragments (16 values per lane for k = 4), same fma chains (1e-12 bar), results written
-// back over the operands in LDS, then the tile is stored row by row.  The tile holds 2^7 groups = 8 items of 16: two per wave.
+// of peak for k = 4 and k = 5 whatever the target bits.  Here a block stages the tile the one-op sweeps use — index bits 0..5
+// + the gate's targets above them + free positions from 11 upwards, whole (split) rows on both global sides — and the wave
+// takes its matrix-core operands from LDS: same lane mapping (lane = (group j, q), c~ = 4 m + q over the targets in ascending
+// position order), same host-built A fragments (16 values per lane for k = 4, 64 for k = 5), same fma chains (1e-12 bar),
+// results written back over the operands in LDS, then the tile is stored row by row.  The tile holds 2^(11-k) groups: eight
+// items of 16 for k = 4 (two per wave), four for k = 5 (one per wave).  Row blocks go through the matrix pipe two at a time
+// (two independent accumulator chains over the same B operands).
+// k = 5 (r6, Complex<f64>; profiles/r06_dense_k5.md): 8 flop/B — at the HBM rate the f64 matrix pipe is 67 % busy (64 matrix
+// instructions = 1.7 us per tile and SIMD against 2.5 us of HBM time per tile and CU), and with 128 registers of A per lane only
+// two blocks fit a CU.  One tile per block ran 8.4 ms at n = 30 (load, barrier, 1.7 us of matrix pipe, barrier, store: nothing
+// overlaps; the direct kernel: 6.6).  LOOP: a block walks `pipe` consecutive tiles with the NEXT tile's rows in flight (in
+// registers) while the current one is in the matrix pipe: 8 tiles 6.0 ms, 32 5.7, 256 5.6 = 76 % of 8 TB/s (direct: 63 - 65 %).
 struct TileMfmaDesc {
   uint32_t hpos[kTileHigh];  // amplitude-index positions of tile bits 6..10 (ascending)
-  uint32_t tb[4];            // tile-bit index of the targets, ascending
-  uint32_t nb[kTileBits - 4];  // the other tile bits, ascending: nb[0..3] = group, nb[4..6] = item
+  uint32_t tb[5];            // tile-bit index of the targets, ascending
+  uint32_t nb[kTileBits - 4];  // the other tile bits, ascending: nb[0..3] = group, the rest = item
   uint32_t p5;                 // amplitude-index position of tile bit 5 (see tile_block_base)
 };
 
-template <typename T, bool NT>
-__global__ __launch_bounds__(kTileBlock, 5) void k_gate_k4_tile_mfma(amp_t<T>* __restrict__ st, Ins ins, TileMfmaDesc d,
-                                                                    const T* __restrict__ afrag) {
+template <typename T, int K, bool NT, bool LOOP>
+__global__ __launch_bounds__(kTileBlock, K == 4 ? 5 : 2) void k_gate_tile_mfma(amp_t<T>* __restrict__ st, Ins ins, TileMfmaDesc d,
+                                                                              const T* __restrict__ afrag, uint32_t pipe) {
+  const uint32_t PIPE = LOOP ? pipe : 1u;  // tiles per block
   using A = amp_t<T>;
   using V4 = typename Acc4<T>::type;
-  constexpr int K = 4, S = 16, TT = S / 8, KS = S / 2, NA = S / 4;
+  constexpr int S = 1 << K, TT = S / 8, KS = S / 2, NA = S / 4;
+  constexpr int IB = kTileBits - K - 4;          // item bits of the tile
+  constexpr int IPW = (1 << IB) / (kTileBlock / 64);  // items per wave
+  static_assert(IPW >= 1 && TT % 2 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   A* tile = reinterpret_cast<A*>(tile_raw);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint64_t wbase = tile_block_base(blockIdx.x + (uint64_t)blockIdx.y * gridDim.x, ins, d.p5);
+  const uint64_t first = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) * PIPE;
+  auto base_of = [&](uint64_t t) {
+    uint64_t w = tile_block_base(t, ins, d.p5);
 #pragma unroll
-  for (int j = 0; j < kTileWaveBits; ++j) wbase |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
+    for (int j = 0; j < kTileWaveBits; ++j) w |= (uint64_t)((wave >> j) & 1u) << d.hpos[j];
+    return w;
+  };
+  auto row_of = [&](int u) {
+    return ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) | ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
+  };
   const uint32_t slot_tid = tile_slot<A>(tid);
   const uint32_t lane_off = tile_lane_off(lane, d.p5);
+  uint64_t wbase = base_of(first);
+  A r[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) r[u] = ldg<NT>(st + (wbase | row_of(u)) + lane_off);
   // the gate's fragments while the rows are on their way
   T a[TT][KS];
 #pragma unroll
   for (int rb = 0; rb < TT; ++rb)
 #pragma unroll
     for (int s = 0; s < KS; ++s) a[rb][s] = afrag[(rb * KS + s) * 64 + lane];
-  {
-    A x[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
-                          ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-      x[u] = ldg<NT>(st + ub + lane_off);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = x[u];
-  }
-  __syncthreads();
   // lane = (group j, q): j fills the four lowest non-target tile bits, q the two lowest targets
   const uint32_t j = lane & 15u, q = lane >> 4;
   uint32_t t_lane = ((q & 1u) << d.tb[0]) | ((q >> 1) << d.tb[1]);
 #pragma unroll
   for (int b = 0; b < 4; ++b) t_lane |= ((j >> b) & 1u) << d.nb[b];
   const uint32_t slot_lane = tile_slot<A>(t_lane);
+  // a block moves PIPE consecutive tiles: the rows of tile p + 1 are in flight while tile p goes through the matrix pipe
+#pragma unroll 1
+  for (uint32_t p = 0; p < PIPE; ++p) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const uint32_t item = wave * 2u + (uint32_t)it;  // (wave-uniform)
-    uint32_t t_item = 0;
+    for (int u = 0; u < 8; ++u) tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)] = r[u];
+    __syncthreads();
+    const uint64_t wcur = wbase;
+    if (p + 1 < PIPE) {
+      wbase = base_of(first + (uint64_t)p + 1);
 #pragma unroll
-    for (int b = 0; b < kTileBits - 4 - 4; ++b) t_item |= ((item >> b) & 1u) << d.nb[4 + b];
-    uint32_t slot[NA];
-    A x[NA];
-#pragma unroll
-    for (int m = 0; m < NA; ++m) {
-      const uint32_t t_m = t_item | (((uint32_t)m & 1u) << d.tb[2]) | (((uint32_t)m >> 1) << d.tb[3]);
-      slot[m] = slot_lane ^ tile_slot<A>(t_m);
-      x[m] = tile[slot[m]];
+      for (int u = 0; u < 8; ++u) r[u] = ldg<NT>(st + (wbase | row_of(u)) + lane_off);
     }
 #pragma unroll
-    for (int rb = 0; rb < TT; ++rb) {
-      V4 acc = {(T)0, (T)0, (T)0, (T)0};
+    for (int it = 0; it < IPW; ++it) {
+      const uint32_t item = wave * (uint32_t)IPW + (uint32_t)it;  // (wave-uniform)
+      uint32_t t_item = 0;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = mfma16(a[rb][s], (s & 1) ? x[s >> 1].y : x[s >> 1].x, acc);
-      A y0, y1;
-      y0.x = acc[0];
-      y0.y = acc[1];
-      y1.x = acc[2];
-      y1.y = acc[3];
-      tile[slot[2 * rb]] = y0;      // every amplitude of the tile belongs to exactly one lane: in place
-      tile[slot[2 * rb + 1]] = y1;
+      for (int b = 0; b < IB; ++b) t_item |= ((item >> b) & 1u) << d.nb[4 + b];
+      uint32_t slot[NA];
+      A x[NA];
+#pragma unroll
+      for (int m = 0; m < NA; ++m) {
+        uint32_t t_m = t_item;
+#pragma unroll
+        for (int b = 0; b < K - 2; ++b) t_m |= (((uint32_t)m >> b) & 1u) << d.tb[2 + b];
+        slot[m] = slot_lane ^ tile_slot<A>(t_m);
+        x[m] = tile[slot[m]];
+      }
+#pragma unroll
+      for (int rb = 0; rb < TT; rb += 2) {
+        V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const T b = (s & 1) ? x[s >> 1].y : x[s >> 1].x;
+          acc0 = mfma16(a[rb][s], b, acc0);
+          acc1 = mfma16(a[rb + 1][s], b, acc1);
+        }
+        A y0, y1, y2, y3;
+        y0.x = acc0[0];
+        y0.y = acc0[1];
+        y1.x = acc0[2];
+        y1.y = acc0[3];
+        y2.x = acc1[0];
+        y2.y = acc1[1];
+        y3.x = acc1[2];
+        y3.y = acc1[3];
+        tile[slot[2 * rb]] = y0;      // every amplitude of the tile belongs to exactly one lane: in place
+        tile[slot[2 * rb + 1]] = y1;
+        tile[slot[2 * rb + 2]] = y2;
+        tile[slot[2 * rb + 3]] = y3;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint64_t ub = wbase | ((uint64_t)(u & 1) << d.hpos[kTileWaveBits]) | ((uint64_t)((u >> 1) & 1) << d.hpos[kTileWaveBits + 1]) |
-                        ((uint64_t)((u >> 2) & 1) << d.hpos[kTileWaveBits + 2]);
-    stg<NT>(st + ub + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+    for (int u = 0; u < 8; ++u) stg<NT>(st + (wcur | row_of(u)) + lane_off, tile[slot_tid ^ tile_slot<A>((uint32_t)u << kTileLaneBits)]);
+    if (p + 1 < PIPE) __syncthreads();
   }
 }
 

@@ -338,32 +338,50 @@ static int launch_swap(qip_hip_state* s, uint32_t n, const Plan& p, E* st) {
 // ---- any permutation of the index bits in one out-of-place sweep (k_permute_bits) ---------------------------------
 // pi[d] = source bit position that destination bit position d takes its value from: out[j] = in[src(j)], bit pi[d] of
 // src(j) = bit d of j.  Pure host code; exported through qip_hip_debug_permute_plan for the CPU tests.
-static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t fold_bits, PermDesc* out) {
-  const uint32_t TB = 2 * R;
-  if (n < TB || TB > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "internal: permutation tile does not fit n = %u", n);
+// `split` (0 = none): an index position that is made thread bit 5 — the upper half of a wave — on BOTH sides (11 for 16-byte
+// elements: byte-address bit 15, "split rows"); the tile then holds the R row bits, the destination bits fed by the source's row
+// bits, `split` and the destination bit fed by source position `split`: 11 or 12 bits (*tile_bits_out).  Without it: 2 R bits.
+static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t fold_bits, uint32_t split, PermDesc* out, uint32_t* tile_bits_out) {
+  if (split && (split < R || split >= n || R != 5u)) return fail(QIP_ERR_INVALID, "internal: split rows need R = 5 and a position >= 5 below n");
   PermDesc& d = *out;
   memset(&d, 0, sizeof d);
   std::vector<char> in_tile(n, 0);
   for (uint32_t b = 0; b < R; ++b) in_tile[b] = 1;             // the destination's row bits
   for (uint32_t b = 0; b < n; ++b)
     if (pi[b] < R) in_tile[b] = 1;                              // destination bits fed by the source's row bits
+  if (split) {
+    in_tile[split] = 1;
+    for (uint32_t b = 0; b < n; ++b)
+      if (pi[b] == split) in_tile[b] = 1;
+  }
   uint32_t cnt = 0;
   for (uint32_t b = 0; b < n; ++b) cnt += in_tile[b];
+  const uint32_t TB = split ? (cnt <= 11u ? 11u : 12u) : 2 * R;
+  if (n < TB || TB > (uint32_t)kPermMaxTile || cnt > TB) return fail(QIP_ERR_INVALID, "internal: permutation tile does not fit n = %u", n);
   for (uint32_t b = 0; b < n && cnt < TB; ++b)                  // pad with the lowest positions left
     if (!in_tile[b]) {
       in_tile[b] = 1;
       ++cnt;
     }
-  std::vector<uint32_t> tb, sb;
+  // coordinate order on each side: the rows, then the split position, then the rest ascending
+  std::vector<uint32_t> tb, sb, srcs;
+  for (uint32_t b = 0; b < R; ++b) tb.push_back(b), sb.push_back(b);
+  if (split) tb.push_back(split), sb.push_back(split);
   for (uint32_t b = 0; b < n; ++b)
     if (in_tile[b]) {
-      tb.push_back(b);
-      sb.push_back(pi[b]);
+      srcs.push_back(pi[b]);
+      if (b >= R && b != split) tb.push_back(b);
     }
-  std::sort(sb.begin(), sb.end());
+  std::sort(srcs.begin(), srcs.end());
+  for (uint32_t sp : srcs)
+    if (sp >= R && sp != split) sb.push_back(sp);
+  if (tb.size() != TB || sb.size() != TB) return fail(QIP_ERR_INVALID, "internal: permutation tile is not closed");
+  std::vector<uint32_t> ts = tb;
+  std::sort(ts.begin(), ts.end());
   for (uint32_t i = 0; i < TB; ++i) {
     d.tbits[i] = tb[i];
     d.sbits[i] = sb[i];
+    d.tsorted[i] = ts[i];
   }
   for (uint32_t i = 0; i < TB; ++i) {  // source coordinate bit i is source position sb[i] = pi[tb[k]] -> tile bit k
     uint32_t k = 0;
@@ -391,6 +409,7 @@ static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t f
       d.outer_src[d.n_outer] = (unsigned char)pi[b];
       d.n_outer += 1;
     }
+  if (tile_bits_out) *tile_bits_out = TB;
   return QIP_OK;
 }
 
@@ -420,17 +439,17 @@ int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
     n -= 1;
   }
   const bool wide = s->dtype == QIP_C64 || packed;   // 16-byte elements
-  // 16-byte elements: 512-B rows in 16-KiB tiles (8 blocks per CU) unless two or more of the source's row bits feed
-  // destination bits far above the rows — then the tile's rows are scattered on the source side and 1-KiB rows in
-  // 64-KiB tiles pay (measured at n = 30: random permutation 7.2 -> 6.5 ms, three transpositions 7.3 -> 5.9, while a
-  // single transposition is better off with the small tile: 5.9 vs 6.2 ms; profiles/r02_permute.md)
-  uint32_t scattered = 0;
-  for (uint32_t b = 10; b < n; ++b) scattered += pi[b] < 5u;
-  const uint32_t R = !wide ? 6u : (g_perm_rows ? (uint32_t)g_perm_rows : (scattered >= 2 && n >= 12 ? 6u : 5u)), TB = 2 * R;
+  // 16-byte elements: 512-byte rows with SPLIT wave accesses — thread bit 5 is index position 11 on both sides, so every
+  // wave-level read and write is two 512-byte halves 32 KiB apart (r6; measured on every permutation of tools/bench_permute.py:
+  // profiles/r06_permute.md) — in tiles of 2^11 or 2^12 elements (32 / 64 KiB of LDS).  A state below 2^12 elements keeps
+  // contiguous rows in 2^10-element tiles; 8-byte elements (an unpacked Complex<f32> view) keep 512-byte rows of 64 elements.
+  // (8-byte elements with the same split — two 256-byte pieces per wave access — measured slower: profiles/r06_permute.md)
+  const uint32_t R = wide ? 5u : 6u;
+  const uint32_t split = (wide && n >= 12u) ? 11u : 0u;
   ProfRec rec;
   if (s->profile) QCHK(prof_begin(s, KC_PERMUTE, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
   const bool nt = use_nt(s);
-  if (n < TB) {
+  if (n < (split ? 12u : 2 * R)) {
     PermSmall ps;
     memset(&ps, 0, sizeof ps);
     ps.n = n;
@@ -445,19 +464,27 @@ int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
       hipLaunchKernelGGL((k_permute_bits_small<amp_t<float>>), grid, block, 0, s->stream, (const amp_t<float>*)s->cur, (amp_t<float>*)s->alt, count, ps);
   } else {
     PermDesc d;
-    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, &d));  // (fold width follows the element size, not R)
-    const dim3 grid = grid2d(1ull << (n - TB), 1), block(kBlock);
-#define PB(A, RR)                                                                                                        \
-  do {                                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_permute_bits<A, RR, true>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);  \
-    else hipLaunchKernelGGL((k_permute_bits<A, RR, false>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);    \
+    uint32_t TB = 0;
+    QCHK(make_perm_desc(n, pi.data(), R, wide ? 3u : 4u, split, &d, &TB));  // (fold width follows the element size, not R)
+    // a 2^12-element tile of 16-byte elements is 64 KiB of LDS = two blocks per CU: such a block moves TWO tiles, the second one's
+    // loads in flight while the first is stored (three transpositions 5.99 -> 5.74 ms, random 5.75 -> 5.55; no gain for 2^11 tiles)
+    const uint32_t pipe = (wide && TB == 12 && n >= TB + 1) ? 2u : 1u;
+    const dim3 grid = grid2d((1ull << (n - TB)) / pipe, 1), block(kBlock);
+#define PB2(A, RR, TT, PP)                                                                                                         \
+  do {                                                                                                                             \
+    if (nt) hipLaunchKernelGGL((k_permute_bits<A, RR, TT, true, PP>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);  \
+    else hipLaunchKernelGGL((k_permute_bits<A, RR, TT, false, PP>), grid, block, 0, s->stream, (const A*)s->cur, (A*)s->alt, d);    \
   } while (0)
-    if (s->dtype == QIP_C64 && R == 5) PB(amp_t<double>, 5);
-    else if (s->dtype == QIP_C64) PB(amp_t<double>, 6);
-    else if (packed && R == 5) PB(f32x4, 5);
-    else if (packed) PB(f32x4, 6);
-    else PB(amp_t<float>, 6);
-#undef PB
+    if (s->dtype == QIP_C64 && TB == 10) PB2(amp_t<double>, 5, 10, 1);
+    else if (s->dtype == QIP_C64 && TB == 11) PB2(amp_t<double>, 5, 11, 1);
+    else if (s->dtype == QIP_C64 && pipe == 2) PB2(amp_t<double>, 5, 12, 2);
+    else if (s->dtype == QIP_C64) PB2(amp_t<double>, 5, 12, 1);
+    else if (packed && TB == 10) PB2(f32x4, 5, 10, 1);
+    else if (packed && TB == 11) PB2(f32x4, 5, 11, 1);
+    else if (packed && pipe == 2) PB2(f32x4, 5, 12, 2);
+    else if (packed) PB2(f32x4, 5, 12, 1);
+    else PB2(amp_t<float>, 6, 12, 1);
+#undef PB2
   }
   HIPCHK(hipGetLastError());
   if (s->profile) QCHK(prof_end(s, &rec));
@@ -492,11 +519,14 @@ extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi
     if (check_bit_permutation(n, pi, &identity) != QIP_OK) return nullptr;
     // an exported entry point: the two shape arguments index fixed-size tables of the descriptor, so they are checked here
     // (the library itself only ever passes 5 / 6 and 3 / 4)
-    if (row_bits < 1 || 2 * row_bits > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "row_bits must be 1..%d", kPermMaxTile / 2), nullptr;
+    // row_bits = 0: the shape the library picks for 16-byte elements (512-byte rows, split at position 11 when n >= 12)
+    const uint32_t split = (row_bits == 0 && n >= 12) ? 11u : 0u;
+    if (row_bits == 0) row_bits = 5;
+    if (row_bits < 1 || 2 * row_bits > (uint32_t)kPermMaxTile) return fail(QIP_ERR_INVALID, "row_bits must be 0 (the library's choice) or 1..%d", kPermMaxTile / 2), nullptr;
     if (fold_bits > 4 || fold_bits > 2 * row_bits) return fail(QIP_ERR_INVALID, "fold_bits must be <= min(4, 2 * row_bits)"), nullptr;
     PermDesc d;
-    if (make_perm_desc(n, pi, row_bits, fold_bits, &d) != QIP_OK) return nullptr;
-    const uint32_t TB = 2 * row_bits;
+    uint32_t TB = 0;
+    if (make_perm_desc(n, pi, row_bits, fold_bits, split, &d, &TB) != QIP_OK) return nullptr;
     auto arr = [&](const char* key, const uint32_t* v, uint32_t cnt) {
       std::string a = std::string("\"") + key + "\":[";
       for (uint32_t i = 0; i < cnt; ++i) a += (i ? "," : "") + std::to_string(v[i]);
@@ -507,7 +537,8 @@ extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi
       od[i] = d.outer_dst[i];
       os[i] = d.outer_src[i];
     }
-    json = "{\"n\":" + std::to_string(n) + ",\"row_bits\":" + std::to_string(row_bits) + "," + arr("tbits", d.tbits, TB) + "," +
+    json = "{\"n\":" + std::to_string(n) + ",\"row_bits\":" + std::to_string(row_bits) + ",\"tile_bits\":" + std::to_string(TB) + ",\"split\":" + std::to_string(split) + "," +
+           arr("tsorted", d.tsorted, TB) + "," + arr("tbits", d.tbits, TB) + "," +
            arr("sbits", d.sbits, TB) + "," + arr("u2c", d.u2c, TB) + "," + arr("fold_from", d.fold_from, d.nfold) + "," +
            arr("fold_to", d.fold_to, d.nfold) + "," + arr("outer_dst", od, d.n_outer) + "," + arr("outer_src", os, d.n_outer) + "}";
     return json.c_str();
@@ -549,12 +580,16 @@ static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::ve
       }
 }
 
-// dense k = 4 through the LDS-staged matrix-core kernel (k_gate_k4_tile_mfma).  *done = false when the op does not qualify:
-// controls inside a row, more than five positions above the rows, a state below one tile.
+// dense k = 4, 5 through the LDS-staged matrix-core kernel (k_gate_tile_mfma).  *done = false when the op does not qualify:
+// controls inside a row, a state below one tile.
 template <typename T>
-static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool* done) {
+static int launch_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool* done) {
   *done = false;
-  if (p.opos.size() != 4 || s->n < (uint32_t)kTileBits + 6) return QIP_OK;
+  const uint32_t k = (uint32_t)p.opos.size();
+  if ((k != 4 && k != 5) || s->n < (uint32_t)kTileBits + 6) return QIP_OK;
+  // k = 5: Complex<f64> only (Complex<f32> measured even with the direct kernel: 3.41 vs 3.47 ms at n = 30), and only where a block
+  // gets at least 8 tiles with two blocks on every CU: 2^12 tiles (n >= 23 + controls); below that the direct kernel is faster
+  if (k == 5 && (!std::is_same<T, double>::value || s->n < (uint32_t)kTileBits + 12 + (uint32_t)p.cpos.size())) return QIP_OK;
   const uint32_t p5 = tile_p5_of<T>(s->n);  // the rows' sixth bit (qip_tile.h): 11 = split rows
   for (uint32_t c : p.cpos)
     if (tile_is_low(c, p5)) return QIP_OK;
@@ -579,7 +614,7 @@ static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bo
   d.p5 = p5;
   auto tile_bit = [&](uint32_t pos) { return tile_is_low(pos, p5) ? tile_low_bit(pos) : (uint32_t)kTileLow + (uint32_t)(std::find(high.begin(), high.end(), pos) - high.begin()); };
   uint32_t is_target = 0;
-  for (int b = 0; b < 4; ++b) {
+  for (uint32_t b = 0; b < k; ++b) {
     d.tb[b] = tile_bit(tau[b]);
     is_target |= 1u << d.tb[b];
   }
@@ -601,8 +636,19 @@ static int launch_k4_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bo
   const uint64_t ntiles = 1ull << (s->n - (uint32_t)kTileBits - (uint32_t)p.cpos.size());
   const size_t lds = sizeof(amp_t<T>) << kTileBits;
   const T* af = (const T*)s->arena;
-  if (use_nt(s)) hipLaunchKernelGGL((k_gate_k4_tile_mfma<T, true>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af);
-  else hipLaunchKernelGGL((k_gate_k4_tile_mfma<T, false>), grid2d(ntiles, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af);
+  const bool nt = use_nt(s);
+  // k = 5: a block walks `pipe` consecutive tiles (the next tile's rows in flight during the matrix instructions): at least 8
+  // tiles each, 512 - 2048 blocks (two per CU, one to four rounds); n = 30: 256 tiles per block
+  const uint32_t pipe = k == 5 ? (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, ntiles / 1024)) : 1u;  // (powers of two)
+#define TM(KK, LL)                                                                                                                                       \
+  do {                                                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, true, LL>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);    \
+    else hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, false, LL>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);      \
+  } while (0)
+  if (k == 4) TM(4, false);
+  else if constexpr (std::is_same<T, double>::value) TM(5, true);
+  else return fail(QIP_ERR_UNSUPPORTED, "internal: the tile form of dense k = 5 is a Complex<f64> kernel");
+#undef TM
   HIPCHK(hipGetLastError());
   *done = true;
   return QIP_OK;
@@ -785,9 +831,9 @@ static int launch_kq(qip_hip_state* s, const Plan& p, amp_t<T>* st, int* actual_
                            (k == 4 && s->n >= (uint32_t)kTileBits + 6 && !g_force_k4_direct);
     if (s->mfma && want_mfma && k >= 3 && k <= kMaxMfmaK && s->n >= used + 4) {
       *actual_cls = KC_GATE_KQ_MFMA;
-      if (k == 4 && s->unroll == 0 && !g_force_k4_direct) {  // operands through an LDS-resident tile: whole rows on both global sides
+      if ((k == 4 || k == 5) && s->unroll == 0 && !g_force_k4_direct) {  // operands through an LDS-resident tile: whole rows on both global sides
         bool done = false;
-        QCHK(launch_k4_tile_mfma<T>(s, p, st, &done));
+        QCHK(launch_tile_mfma<T>(s, p, st, &done));
         if (done) return QIP_OK;
       }
       return launch_kq_mfma<T>(s, p, st);

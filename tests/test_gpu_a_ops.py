@@ -734,6 +734,48 @@ def test_dense4_on_the_matrix_cores_through_an_lds_tile(O, dtype, tol):
         assert np.array_equal(st.download(), O.apply_ops_in_place(n, [q.make_matrix_op([18, 17, 0, 1], perm01.ravel())], x.copy()))
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, TOL64), (np.complex64, TOL32)])
+def test_dense5_on_the_matrix_cores_through_an_lds_tile(O, dtype, tol):
+    """k_gate_tile_mfma<K = 5> (r6): a dense 5-qubit gate of a Complex<f64> state of >= 23 qubits with its operands staged through
+    the one-op sweeps' tile — one item of 16 groups per wave, a block walking 8+ consecutive tiles with the next tile's rows in
+    flight.  Every placement of the targets (inside the rows, above them, mixed, on the split position 11 and on position 5, all
+    five above the rows), controls above the rows (one control: 8 tiles per block at n = 24), the fall-backs to the direct
+    kernel (a control inside a row, smaller states, Complex<f32>) — against the oracle (fma chains: 1e-12 / 1e-5), against the
+    direct-from-HBM kernel (same fragments: identical) in a tuning build; a 0/1 matrix stays exact."""
+    rng = np.random.default_rng(23)
+    u = rand_unitary(5, rng)
+    perm01 = np.eye(32)[rng.permutation(32)]
+    for n in (23, 24, 19):
+        x = circuits.random_state(n, seed=n, dtype=dtype)
+        P = lambda *pos: [n - 1 - p for p in pos]  # noqa: E731  (position p <-> qubit n-1-p)
+        cases = []
+        if n != 24:
+            for tg in (P(0, 1, 2, 3, 4), P(11, 5, 0, 1, 2), P(n - 1, n - 2, n - 3, n - 4, n - 5), P(n - 1, 3, 11, 7, 5), P(6, 7, 8, 9, 10), P(12, 0, n - 1, 5, 13), P(4, 11, 12, 13, 14)):
+                cases.append((f"targets at positions {[n - 1 - t for t in tg]}", q.make_matrix_op(tg, u.ravel())))
+            cases.append(("0/1 permutation matrix", q.make_matrix_op(P(n - 1, 1, 5, 11, 8), perm01.ravel())))
+        if n != 23:
+            cases.append(("controlled, a control above the rows", q.make_control_op(P(15), q.make_matrix_op(P(n - 1, 0, 5, 11, 13), u.ravel()))))
+            cases.append(("controlled, a control inside a row (direct kernel)", q.make_control_op(P(2), q.make_matrix_op(P(n - 1, 0, 5, 11, 13), u.ravel()))))
+        with q.HipState(n, dtype) as st, q.HipState(n, dtype) as direct:
+            for name, op in cases:
+                st.upload(x)
+                st.apply_op(op)
+                got = st.download()
+                want = O.apply_ops_in_place(n, [op], x.copy())
+                if name.startswith("0/1"):
+                    assert np.array_equal(got, want), (n, name)
+                else:
+                    assert float(np.max(np.abs(got - want))) <= tol, (n, name)
+                if tuning():
+                    q.set_global_option("k4_direct", 1)
+                    try:
+                        direct.upload(x)
+                        direct.apply_op(op)
+                    finally:
+                        q.set_global_option("k4_direct", 0)
+                    assert np.array_equal(got, direct.download()), (n, name)
+
+
 @pytest.mark.parametrize("row_split", [11, 5])
 def test_one_op_tile_sweeps_controlled_dense_and_both_row_shapes(O, row_split):
     """r4: (a) a CONTROLLED dense k = 2 / 3 gate runs as a one-op tile sweep too — controls above the rows come off the grid

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r"""
 import json, os, sys, time
+if os.environ.get("QIP_TEST_IMPORT_TORCH_FIRST"):
+    import torch  # brings PyTorch's own bundled libhiprtc / libamd_comgr / HIP runtime into the process
 sys.path.insert(0, %(root)r)
 from rustqip_amd import circuits, _ffi
 from rustqip_amd.ops import debug_tile_jit
@@ -65,6 +67,36 @@ def test_second_process_loads_from_disk_and_helpers_make_the_same_code(tmp_path)
     open(victim, "wb").write(good[: len(good) // 2])
     r4 = run(n, mode, -1, {"QIP_HIP_CACHE_DIR": a})
     assert r4["compiled"] == 1 and r4["disk_hits"] == r4["segments"] - 1
+    assert open(victim, "rb").read() == good
+
+
+def test_a_host_program_with_its_own_rocm_libraries_shares_the_cache(tmp_path):
+    """r6: bench.py imports torch, whose wheel carries another ROCm release's libhiprtc / comgr / runtime.  The key used to name the
+    compiler "as loaded in this process": the helpers' (system ROCm) objects then failed the requester's header check and every
+    segment was compiled twice (compiled_by_helpers = 0 in the driver's bench), and a process without torch never found what one
+    with torch had cached.  The key names the installation the helpers use: same file names either way, helpers' work accepted,
+    hits across the two kinds of process; a single new segment of such a process goes to a helper too."""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    n, mode = 16, 1 | 64
+    with_torch = {"QIP_TEST_IMPORT_TORCH_FIRST": "1"}
+    r1 = run(n, mode, -1, dict(with_torch, QIP_HIP_CACHE_DIR=a))
+    assert r1["compiled"] == r1["segments"] >= 3 and r1["disk_hits"] == 0
+    if r1["procs"] > 1:
+        assert r1["compiled_by_helpers"] == r1["segments"], r1
+    r2 = run(n, mode, -1, {"QIP_HIP_CACHE_DIR": b})
+    assert files(a) == files(b)
+    for f in files(a):
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
+    r3 = run(n, mode, -1, {"QIP_HIP_CACHE_DIR": a})  # no torch, reads what the torch process left
+    assert r3["compiled"] == 0 and r3["disk_hits"] == r3["segments"] == r1["segments"]
+    r4 = run(n, mode, -1, dict(with_torch, QIP_HIP_CACHE_DIR=b))  # and the other way round
+    assert r4["compiled"] == 0 and r4["disk_hits"] == r4["segments"]
+    # one damaged entry = ONE new segment: in a process that has a foreign libhiprtc loaded it is still a helper that compiles it
+    victim = os.path.join(a, files(a)[0])
+    good = open(victim, "rb").read()
+    open(victim, "wb").write(good[:100])
+    r5 = run(n, mode, -1, dict(with_torch, QIP_HIP_CACHE_DIR=a))
+    assert r5["compiled"] == 1 and r5["compiled_by_helpers"] == 1 and r5["helper_processes"] == 1, r5
     assert open(victim, "rb").read() == good
 
 

@@ -38,12 +38,12 @@ def fold(c, d):
 
 
 def replay(n, d, x):
-    """numpy model of k_permute_bits<A, R>: returns (out, slots of the load side [u], slots of the store side [c])"""
+    """numpy model of k_permute_bits<A, R, TB>: returns (out, slots of the load side [u], slots of the store side [c])"""
     R = d["row_bits"]
-    TB = 2 * R
+    TB = d["tile_bits"]
     nblk = 1 << (n - TB)
     dbase = np.arange(nblk, dtype=np.uint64)
-    for p in d["tbits"]:
+    for p in d["tsorted"]:
         low = dbase & np.uint64((1 << p) - 1)
         dbase = ((dbase >> np.uint64(p)) << np.uint64(p + 1)) | low
     sbase = np.zeros_like(dbase)
@@ -72,10 +72,13 @@ def want_of(n, pi, x):
     return x[src.astype(np.int64)]
 
 
-@pytest.mark.parametrize("row_bits,fold_bits", [(5, 3), (6, 4)])
+@pytest.mark.parametrize("row_bits,fold_bits", [(5, 3), (6, 4), (0, 3)])
 def test_descriptor_replayed_with_numpy(row_bits, fold_bits):
+    """(0, 3) is the shape the library launches for 16-byte elements: 512-byte rows, thread bit 5 = index position 11 on both sides"""
     rng = np.random.default_rng(7)
-    TB = 2 * row_bits
+    split = row_bits == 0
+    TB = 12 if split else 2 * row_bits
+    row_bits = row_bits or 5
     cases = []
     for n in (TB, TB + 1, TB + 3):
         cases.append((n, list(range(n))[::-1]))                      # bit reversal (QFT's closing swaps)
@@ -89,8 +92,14 @@ def test_descriptor_replayed_with_numpy(row_bits, fold_bits):
         cases.append((n, list(range(row_bits)) + [int(v) for v in rng.permutation(hi)]))
     group = 8 if fold_bits == 3 else 16
     for n, pi in cases:
-        d = plan(n, pi, row_bits, fold_bits)
+        d = plan(n, pi, 0 if split else row_bits, fold_bits)
         assert d["tbits"][:row_bits] == list(range(row_bits)) and d["sbits"][:row_bits] == list(range(row_bits))
+        if split:
+            assert d["split"] == 11 and d["tbits"][5] == 11 and d["sbits"][5] == 11 and d["tile_bits"] in (11, 12)
+            assert d["tile_bits"] == 11 or sum(1 for b in range(n) if b < 5 or b == 11 or pi[b] < 5 or pi[b] == 11) == 12
+        else:
+            assert d["split"] == 0 and d["tile_bits"] == TB
+        TB = d["tile_bits"]
         x = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
         got, slot_ld, slot_st = replay(n, d, x)
         assert np.array_equal(got, want_of(n, pi, x)), (n, pi)
@@ -121,17 +130,17 @@ def test_run_of_swaps_composes_to_one_permutation():
     assert np.array_equal(want_of(n, pi, x), want)
 
 
-@pytest.mark.parametrize("n,row_bits,fold_bits", [(30, 5, 3), (33, 5, 3), (34, 6, 4), (40, 5, 3)])
+@pytest.mark.parametrize("n,row_bits,fold_bits", [(30, 5, 3), (33, 5, 3), (34, 6, 4), (40, 5, 3), (30, 0, 3), (33, 0, 3), (40, 0, 3)])
 def test_descriptor_at_bench_sizes_on_sampled_elements(n, row_bits, fold_bits):
     """no state: for sampled (block, element) pairs the source index the load side computes and the destination index the
     store side computes satisfy dst bit d = src bit pi[d] (block ids above 2^32 blocks included: the 2-D grid of n >= 38)"""
     rng = np.random.default_rng(n)
-    TB = 2 * row_bits
     for pi in (list(range(n))[::-1], [int(v) for v in rng.permutation(n)], list(range(1, n)) + [0]):
         d = plan(n, pi, row_bits, fold_bits)
+        TB, row_bits = d["tile_bits"], d["row_bits"]
         blocks = np.concatenate([np.array([0, (1 << (n - TB)) - 1], dtype=np.uint64), rng.integers(0, 1 << (n - TB), size=200, dtype=np.uint64)])
         dbase = blocks.copy()
-        for p in d["tbits"]:
+        for p in d["tsorted"]:
             low = dbase & np.uint64((1 << p) - 1)
             dbase = ((dbase >> np.uint64(p)) << np.uint64(p + 1)) | low
         sbase = np.zeros_like(dbase)
@@ -154,7 +163,8 @@ def test_plan_hook_rejects_shapes_its_tables_cannot_hold():
     n = 16
     arr = (C.c_uint32 * n)(*range(n))
     arr[0], arr[9] = 9, 0
-    for row_bits, fold_bits in ((0, 0), (7, 3), (5, 5), (1, 3), (40, 2)):
+    for row_bits, fold_bits in ((7, 3), (5, 5), (1, 3), (40, 2), (0, 5)):
         assert not _ffi.lib.qip_hip_debug_permute_plan(n, arr, row_bits, fold_bits), (row_bits, fold_bits)
         assert "must be" in _ffi.last_error() or "does not fit" in _ffi.last_error()
     assert _ffi.lib.qip_hip_debug_permute_plan(n, arr, 5, 3)
+    assert _ffi.lib.qip_hip_debug_permute_plan(n, arr, 0, 3)  # row_bits = 0: the library's own choice (split rows)

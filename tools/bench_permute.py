@@ -16,8 +16,6 @@ from rustqip_amd import circuits  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     f32 = len(sys.argv) > 2 and sys.argv[2] == "f32"
-    if os.environ.get("QIP_PERM_ROWS"):
-        q.set_global_option("perm_rows", int(os.environ["QIP_PERM_ROWS"]))
     amp = 8.0 if f32 else 16.0
     rng = np.random.default_rng(1)
     ident = list(range(n))

@@ -10,12 +10,14 @@ if [ "$2" != "quick" ]; then
   timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $O/gpu_tests.txt 2>&1
   tail -18 $O/gpu_tests.txt
 fi
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
+QIP_BENCH_DETAIL=$O/bench_detail.json timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 echo "bench rc=$?"; tail -2 $O/bench_n1.err
-QIP_BENCH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --n-local 24 --steps 3 --warmup 1 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
+QIP_BENCH_DETAIL=$O/bench_detail_2ranks.json QIP_BENCH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --n-local 24 --steps 3 --warmup 1 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
 tail -2 $O/bench_2ranks_one_gpu.err
 timeout 600 python tools/bench_ops.py 30 all > $O/ops_table.md 2> $O/ops_table.err
 timeout 600 python tools/bench_ops.py 30 all f32 > $O/ops_table_f32.md 2> $O/ops_table_f32.err
+timeout 300 python tools/bench_permute.py 30 > $O/permute_f64.md 2>&1
+timeout 300 python tools/bench_permute.py 30 f32 > $O/permute_f32.md 2>&1
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 cd $R
 if [ "$2" = "quick" ]; then  # the tests that cover what changed since the last full run of the suite (kept beside it under profiles/)
@@ -25,12 +27,13 @@ fi
 python - <<PY
 import json
 d=json.loads(open("$O/bench_n1.json").read().strip().splitlines()[-1])
-print({k:d[k] for k in ("value","ms_per_step","gates_per_s","parity_ok")}, d["roofline"]["kernel"], d["roofline"]["frac"], d["parity"]["all_legs_ok"], d["parity"]["seconds"])
+print({k:d[k] for k in ("value","ms_per_step","gates_per_s","parity_ok","wall_s")}, d["roofline"]["kernel"], d["roofline"]["frac"], d["parity"]["legs_failed"], d["parity"]["seconds"])
 print(d["cpu_baseline"])
-for k,v in d["extras"].items():
+x=json.load(open("$O/bench_detail.json"))
+for k,v in x.get("extras",{}).items():
     if isinstance(v,dict) and "ms" in v: print(k, round(v["ms"],1), v.get("launches"), round(v.get("per_launch_GBps",0)))
     elif isinstance(v,dict):
         print(k, {a:(round(b["ms"],1) if isinstance(b,dict) and "ms" in b else None) for a,b in v.items() if isinstance(b,dict)})
 d=json.loads(open("$O/bench_2ranks_one_gpu.json").read().strip().splitlines()[-1])
-print("2 ranks:", {k:d[k] for k in ("value","parity_ok")}, {k:(v.get("comm_over_reps") if isinstance(v,dict) else v) for k,v in d["extras"].items()})
+print("2 ranks:", {k:d.get(k) for k in ("value","parity_ok","rccl_ranks","per_gpu_efficiency")})
 PY

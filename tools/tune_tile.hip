@@ -255,6 +255,47 @@ __global__ __launch_bounds__(256, 8) void k_probe(A* __restrict__ st, Tp tp, A f
   for (int u = 0; u < 8; ++u) stg<true>(st + a[u], cmul(f, x[u]));
 }
 
+// r6 probe for the out-of-place bit-permutation sweep: TB tile positions on the SOURCE side (S[0..5] lane, S[6..7] wave, S[8..] a lane's
+// back-to-back loads) and TB on the DESTINATION side, two buffers; the block index drives the other positions ascending on both sides.
+// No LDS and no data consistency (what is timed is the DRAM address pattern of a tile's reads and writes, which is what set the r4 finding).
+template <int TB> struct Tp2 { uint32_t s[TB], d[TB], ss[TB], ds[TB]; };
+template <int TB>
+__global__ __launch_bounds__(256, TB >= 12 ? 2 : (TB == 11 ? 4 : 8)) void k_probe2(const A* __restrict__ in, A* __restrict__ out, Tp2<TB> tp) {
+  constexpr int E = (1 << TB) / 256;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t ws = blockIdx.x, wd = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    const uint32_t p = tp.ss[j], q = tp.ds[j];
+    ws = ((ws >> p) << (p + 1)) | (ws & ((1ull << p) - 1ull));
+    wd = ((wd >> q) << (q + 1)) | (wd & ((1ull << q) - 1ull));
+  }
+  uint64_t os = 0, od = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    os |= (uint64_t)((lane >> k) & 1u) << tp.s[k];
+    od |= (uint64_t)((lane >> k) & 1u) << tp.d[k];
+  }
+  os |= ((uint64_t)(wave & 1u) << tp.s[6]) | ((uint64_t)(wave >> 1) << tp.s[7]);
+  od |= ((uint64_t)(wave & 1u) << tp.d[6]) | ((uint64_t)(wave >> 1) << tp.d[7]);
+  A x[E];
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    uint64_t a = ws | os;
+#pragma unroll
+    for (int b = 0; b < TB - 8; ++b) a |= (uint64_t)((u >> b) & 1) << tp.s[8 + b];
+    x[u] = ldg<true>(in + a);
+  }
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    uint64_t a = wd | od;
+#pragma unroll
+    for (int b = 0; b < TB - 8; ++b) a |= (uint64_t)((u >> b) & 1) << tp.d[8 + b];
+    stg<true>(out + a, x[u]);
+  }
+}
+
 // r4 experiment (with a kill criterion): a 13-bit tile held in REGISTERS — 32 amplitudes per lane (five
 // register bits), 256 lanes per block, seven free positions per sweep instead of five — with LDS only as a 32-KiB transposition
 // buffer: a pass moves the tile through it in four quarters.  Keep only if a light sweep stays <= 6.5 ms at >= 2 blocks per CU.
@@ -713,6 +754,66 @@ int main(int argc, char** argv) {
       CK(hipEventDestroy(e0));
       CK(hipEventDestroy(e1));
     }
+    CK(hipFree(g_st));
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "probe2")) {
+    // `<tag> <TB> <s0> ... <s(TB-1)> <d0> ... <d(TB-1)>` lines on stdin -> one timing each (out of place: a second 2^n buffer)
+    A* out2 = nullptr;
+    CK(hipMalloc(&out2, g_n * sizeof(A)));
+    k_init<<<4096, 256>>>(g_st, g_n);
+    CK(hipDeviceSynchronize());
+    char line[512];
+    while (fgets(line, sizeof line, stdin)) {
+      char tag[64];
+      int TB = 0, used = 0;
+      if (sscanf(line, "%63s %d%n", tag, &TB, &used) != 2 || (TB != 10 && TB != 11 && TB != 12)) continue;
+      uint32_t v[24];
+      const char* p = line + used;
+      bool ok = true;
+      for (int j = 0; j < 2 * TB && ok; ++j) {
+        int adv = 0;
+        ok = sscanf(p, "%u%n", &v[j], &adv) == 1;
+        p += adv;
+      }
+      if (!ok) { printf("probe2 %s bad\n", tag); continue; }
+      auto timeit = [&](auto tp, int tb) {
+        for (int j = 0; j < tb; ++j) { tp.s[j] = v[j]; tp.d[j] = v[tb + j]; tp.ss[j] = v[j]; tp.ds[j] = v[tb + j]; }
+        std::sort(tp.ss, tp.ss + tb);
+        std::sort(tp.ds, tp.ds + tb);
+        for (int j = 0; j < tb; ++j)
+          if (tp.ss[j] >= (uint32_t)n || tp.ds[j] >= (uint32_t)n || (j && (tp.ss[j] == tp.ss[j - 1] || tp.ds[j] == tp.ds[j - 1]))) return -1.0f;
+        const unsigned blocks = (unsigned)(g_n >> tb);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        float best = 1e9f;
+        for (int r = 0; r <= g_reps; ++r) {
+          CK(hipEventRecord(e0));
+          if (tb == 10) hipLaunchKernelGGL(k_probe2<10>, dim3(blocks), dim3(256), 0, 0, g_st, out2, *(Tp2<10>*)&tp);
+          else if (tb == 11) hipLaunchKernelGGL(k_probe2<11>, dim3(blocks), dim3(256), 0, 0, g_st, out2, *(Tp2<11>*)&tp);
+          else hipLaunchKernelGGL(k_probe2<12>, dim3(blocks), dim3(256), 0, 0, g_st, out2, *(Tp2<12>*)&tp);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (r) best = std::min(best, ms);
+        }
+        CK(hipGetLastError());
+        CK(hipEventDestroy(e0));
+        CK(hipEventDestroy(e1));
+        return best;
+      };
+      float ms = -1;
+      if (TB == 10) { Tp2<10> tp; ms = timeit(tp, 10); }
+      else if (TB == 11) { Tp2<11> tp; ms = timeit(tp, 11); }
+      else { Tp2<12> tp; ms = timeit(tp, 12); }
+      printf("probe2 %-40s TB=%d %.3f ms %6.0f GB/s |", tag, TB, ms, ms > 0 ? 32.0 * (double)g_n / ms / 1e6 : 0.0);
+      for (int j = 0; j < 2 * TB; ++j) printf("%s%u", j == TB ? " -> " : " ", v[j]);
+      printf("\n");
+      fflush(stdout);
+    }
+    CK(hipFree(out2));
     CK(hipFree(g_st));
     return 0;
   }
