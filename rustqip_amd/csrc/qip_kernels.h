@@ -754,6 +754,65 @@ template <typename T> struct Acc4;
 template <> struct Acc4<double> { using type = v4f64; };
 template <> struct Acc4<float> { using type = v4f32; };
 
+// ---- r6: three real products instead of four for k >= 5 (and two for a real matrix) ---------------------------------------
+// From k = 5 up the sweeps are bound by (k = 5: close to) the matrix pipe, so the real form above — four S x S real products
+// per complex one — is replaced by three (Gauss): with Xs = X_re + X_im
+//     K1 = G_re Xs,   Y_re = K1 - (G_re + G_im) X_im,   Y_im = K1 + (G_im - G_re) X_re
+// as accumulator chains: acc = P Xs (S/4 steps of 16 complex rows x 4 columns), then re = acc + R X_im and im = acc + Q X_re
+// with P = G_re, R = -(G_re + G_im), Q = G_im - G_re built on the host in double: 3 S^2 / 64 matrix instructions per item of
+// 16 groups instead of S^2 / 16.  A matrix with no imaginary part needs P only: re = P X_re, im = P X_im, S^2 / 32 — and
+// keeps a 0/1 matrix exact (every sum is one amplitude plus zeros), which the three-product form would not ((a + b) - b).
+// Fragments: frag[((rb * NP + part) * (S/4) + s) * 64 + lane], NP = 3 (parts P, R, Q) or 1; 16 COMPLEX rows per block rb.
+// C/D layout as above: a lane ends up with re (chain `re`) and im (chain `im`) of the amplitudes c~' = 16 rb + 4 reg + q, i.e.
+// its own amplitudes m' = 4 rb + reg.  Rounding: a few ulp from the unfused fold (1e-12 bar), like every matrix-core form.
+template <typename T, int K, int NP>
+__device__ __forceinline__ void mfma3_item(const T (&a)[(1 << K) / 16][NP][(1 << K) / 4], const amp_t<T> (&x)[(1 << K) / 4],
+                                           amp_t<T> (&y)[(1 << K) / 4]) {
+  using V4 = typename Acc4<T>::type;
+  constexpr int S = 1 << K, RB = S / 16, KS3 = S / 4;
+  static_assert(RB % 2 == 0 && (NP == 1 || NP == 3), "shape");
+#pragma unroll
+  for (int rb = 0; rb < RB; rb += 2) {  // two row blocks at a time: independent chains over the same B operands
+    V4 re0, im0, re1, im1;
+    if constexpr (NP == 3) {
+      V4 k0 = {(T)0, (T)0, (T)0, (T)0}, k1 = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+      for (int s = 0; s < KS3; ++s) {
+        const T b = x[s].x + x[s].y;
+        k0 = mfma16(a[rb][0][s], b, k0);
+        k1 = mfma16(a[rb + 1][0][s], b, k1);
+      }
+      re0 = k0;
+      im0 = k0;
+      re1 = k1;
+      im1 = k1;
+#pragma unroll
+      for (int s = 0; s < KS3; ++s) {
+        re0 = mfma16(a[rb][1][s], x[s].y, re0);
+        im0 = mfma16(a[rb][2][s], x[s].x, im0);
+        re1 = mfma16(a[rb + 1][1][s], x[s].y, re1);
+        im1 = mfma16(a[rb + 1][2][s], x[s].x, im1);
+      }
+    } else {
+      re0 = im0 = re1 = im1 = V4{(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+      for (int s = 0; s < KS3; ++s) {
+        re0 = mfma16(a[rb][0][s], x[s].x, re0);
+        im0 = mfma16(a[rb][0][s], x[s].y, im0);
+        re1 = mfma16(a[rb + 1][0][s], x[s].x, re1);
+        im1 = mfma16(a[rb + 1][0][s], x[s].y, im1);
+      }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      y[4 * rb + reg].x = re0[reg];
+      y[4 * rb + reg].y = im0[reg];
+      y[4 * rb + 4 + reg].x = re1[reg];
+      y[4 * rb + 4 + reg].y = im1[reg];
+    }
+  }
+}
+
 template <typename T, int K, int WU, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<T>* __restrict__ st,
                                                          uint64_t nitems, Ins ins, MfmaDesc d,
@@ -822,33 +881,37 @@ __global__ __launch_bounds__(kBlock) void k_gate_kq_mfma(amp_t<T>* __restrict__ 
   }
 }
 
-// ---- dense k-qubit gate on the f64 matrix cores, k = 6, 7, 8: the gate matrix streams through LDS ------------------
-// Same real-form product and the same lane mapping as k_gate_kq_mfma (a lane loads whole amplitudes with 16-B accesses,
-// ends up with re AND im of exactly those amplitudes and stores them back in place), but the A operand — (2S)^2 doubles
-// = 128 KiB / 512 KiB / 2 MiB for k = 6 / 7 / 8 — no longer fits a wave's registers.  It is read from the host-arranged
-// fragment array (afrag[(rb * KS + s) * 64 + lane], L2-resident) one 16-row block `rb` at a time into LDS, shared by
-// the block's four waves (each wave works on its own 16 groups) and double-buffered through registers: the loads of
-// block rb + 1 are issued before the KS matrix instructions of block rb and land in the other LDS half after them, one
-// barrier per row block.  X stays in registers for the whole item (S / 4 amplitudes per lane), so outputs can be
-// written over the inputs as each row block finishes.
-// Roofline: 8 * 2^k flop per amplitude against 32 B — 16 / 32 / 64 flop/B for k = 6 / 7 / 8, at or past the f64
-// matrix-core ridge (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 2048 flop / 64 clk * 1024 SIMDs * 2.4 GHz
-// = 78.6 TFLOP/s, ridge 9.8 flop/B at 8 TB/s): these sweeps are bound by the matrix pipe, not by HBM.
-// Two accumulator chains per row block (even / odd K-steps) keep the pipe busy without a second wave on the SIMD.
-template <typename T, int K, bool NT>
-__global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<T>* __restrict__ st, uint64_t nitems, Ins ins,
+// ---- dense k-qubit gate on the matrix cores, k = 6, 7, 8: the gate matrix streams through LDS --------------------------
+// Same lane mapping as k_gate_kq_mfma (a lane loads whole amplitudes with 16-B accesses, ends up with re AND im of exactly
+// those amplitudes and stores them back in place), but the A operand no longer fits a wave's registers.  r6: the products are
+// the three of mfma3_item's header (or the two of a matrix without an imaginary part): per block `rb` of 16 complex rows the
+// parts P, R, Q (NP = 3; P alone for NP = 1), each S/4 K-steps = one chunk of the host-arranged fragment array
+// (frag[((rb * NP + part) * (S/4) + s) * 64 + lane], L2-resident; 8 / 16 / 32 KiB per chunk in f64 for k = 6 / 7 / 8) —
+// brought into LDS one chunk at a time, shared by the block's four waves (each on its own 16 groups) and double-buffered through
+// registers: the loads of the next chunk are issued before the matrix instructions of this one and land in the other LDS half
+// after them, one barrier per chunk.  X stays in registers for the whole item (S/4 amplitudes per lane); the four amplitudes a
+// lane owns of a row block are written over the inputs when the block's last part is done.
+// Roofline: 6 * 2^k flop per amplitude executed (8 * 2^k nominal; 4 * 2^k for a real matrix) against 32 B: at or past the f64
+// matrix-core ridge (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 2048 flop / 64 clk * 1024 SIMDs * 2.4 GHz =
+// 78.6 TFLOP/s, ridge 9.8 flop/B at 8 TB/s), and the A stream out of L2 (3 * 2^(2k) values per 64 groups) next in line at k = 8.
+// Two accumulator chains per part (even / odd K-steps).  Measured at n = 30 (profiles/r06_dense_k5.md): k = 6 9.98 -> 8.68 ms,
+// k = 7 18.4 -> 15.2, k = 8 38.2 -> 34.6; a real matrix: k = 6 7.3 ms, k = 8 18.4 ms.
+template <typename T, int K, bool NT, int NP>
+__global__ __launch_bounds__(kBlock, (K <= 7 || sizeof(T) == 4) ? 2 : 1) void k_gate_big_mfma(amp_t<T>* __restrict__ st, uint64_t nitems, Ins ins,
                                                           MfmaDesc d, const T* __restrict__ afrag) {
   using A = amp_t<T>;
   using V4 = typename Acc4<T>::type;
   constexpr int S = 1 << K;
-  constexpr int TT = S / 8;        // 16-row blocks of the (2S x 2S) real matrix
-  constexpr int KS = S / 2;        // K-steps of 4
+  constexpr int RB = S / 16;       // blocks of 16 complex rows
+  constexpr int KS3 = S / 4;       // K-steps of one part
   constexpr int NA = S / 4;        // amplitudes per lane per item
-  constexpr int CH = KS * 64;      // values per row-block chunk of A
+  constexpr int CH = KS3 * 64;     // values per chunk (one part of one row block)
+  constexpr int NCH = RB * NP;     // chunks per item
   constexpr int PV = 16 / sizeof(T);     // values per 16-byte piece
   constexpr int PF = CH / (kBlock * PV); // 16-byte pieces per thread per chunk
+  static_assert(PF >= 1 && (NP == 1 || NP == 3), "shape");
   typedef T v2f64 __attribute__((ext_vector_type(16 / sizeof(T))));  // one 16-byte piece of A
-  __shared__ __attribute__((aligned(16))) T lds[2 * CH];  // two chunks: 32 / 64 / 128 KiB in f64 (static: no 64-KiB dynamic cap)
+  __shared__ __attribute__((aligned(16))) T lds[2 * CH];  // two chunks
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t j = lane & 15u, q = lane >> 4;
@@ -866,6 +929,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<T>* __restrict__
   for (int p = 0; p < PF; ++p) lds2[p * kBlock + tid] = af2[p * kBlock + tid];
   __syncthreads();
   uint32_t buf = 0;
+  const V4 zero = {(T)0, (T)0, (T)0, (T)0};
   const uint64_t nwg = (nitems + 3) / 4;
   for (uint64_t it = blockIdx.x; it < nwg; it += gridDim.x) {
     const uint64_t w = it * 4 + wave;
@@ -880,27 +944,63 @@ __global__ __launch_bounds__(kBlock) void k_gate_big_mfma(amp_t<T>* __restrict__
 #pragma unroll
       for (int m = 0; m < NA; ++m) x[m] = czero<A>();
     }
-    for (int rb = 0; rb < TT; ++rb) {
-      // next row block of A (wrapping to block 0 for the next item) -> registers, in flight across the MFMAs
-      const int nrb = rb + 1 == TT ? 0 : rb + 1;
+    V4 re = zero, im = zero;
+    for (int c = 0; c < NCH; ++c) {
+      // the next chunk of A (wrapping to chunk 0 for the next item) -> registers, in flight across the matrix instructions
+      const int nc = c + 1 == NCH ? 0 : c + 1;
       v2f64 pre[PF];
 #pragma unroll
-      for (int p = 0; p < PF; ++p) pre[p] = af2[(size_t)nrb * (CH / PV) + p * kBlock + tid];
+      for (int p = 0; p < PF; ++p) pre[p] = af2[(size_t)nc * (CH / PV) + p * kBlock + tid];
       const T* a = lds + buf * CH + lane;
-      V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
+      const int part = NP == 1 ? 0 : c % NP;  // (wave-uniform)
+      if (NP == 1) {
+        V4 r0 = zero, i0 = zero;
 #pragma unroll
-      for (int s = 0; s < KS; s += 2) {
-        acc0 = mfma16(a[s * 64], x[s >> 1].x, acc0);
-        acc1 = mfma16(a[(s + 1) * 64], x[s >> 1].y, acc1);
+        for (int s = 0; s < KS3; ++s) {
+          r0 = mfma16(a[s * 64], x[s].x, r0);
+          i0 = mfma16(a[s * 64], x[s].y, i0);
+          if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (keeps the LDS operand loads from being hoisted en bloc: registers)
+        }
+        re = r0;
+        im = i0;
+      } else if (part == 0) {  // K1 = P (X_re + X_im): two chains (even / odd K-steps)
+        V4 k0 = zero, k1 = zero;
+#pragma unroll
+        for (int s = 0; s < KS3; s += 2) {
+          k0 = mfma16(a[s * 64], x[s].x + x[s].y, k0);
+          k1 = mfma16(a[(s + 1) * 64], x[s + 1].x + x[s + 1].y, k1);
+          if ((s & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+        }
+        re = k0 + k1;
+        im = re;
+      } else if (part == 1) {  // re = K1 + R X_im
+        V4 k1 = zero;
+#pragma unroll
+        for (int s = 0; s < KS3; s += 2) {
+          re = mfma16(a[s * 64], x[s].y, re);
+          k1 = mfma16(a[(s + 1) * 64], x[s + 1].y, k1);
+          if ((s & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+        }
+        re = re + k1;
+      } else {                 // im = K1 + Q X_re
+        V4 k1 = zero;
+#pragma unroll
+        for (int s = 0; s < KS3; s += 2) {
+          im = mfma16(a[s * 64], x[s].x, im);
+          k1 = mfma16(a[(s + 1) * 64], x[s + 1].x, k1);
+          if ((s & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+        }
+        im = im + k1;
       }
-      if (active) {
-        A y0, y1;
-        y0.x = acc0[0] + acc1[0];
-        y0.y = acc0[1] + acc1[1];
-        y1.x = acc0[2] + acc1[2];
-        y1.y = acc0[3] + acc1[3];
-        stg<NT>(st + (base | offm(2u * (uint32_t)rb)), y0);
-        stg<NT>(st + (base | offm(2u * (uint32_t)rb + 1u)), y1);
+      if (active && (NP == 1 || part == 2)) {  // the row block is complete: its four amplitudes of this lane, over the inputs
+        const uint32_t rb = (uint32_t)(c / NP);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          A y;
+          y.x = re[reg];
+          y.y = im[reg];
+          stg<NT>(st + (base | offm(4u * rb + (uint32_t)reg)), y);
+        }
       }
 #pragma unroll
       for (int p = 0; p < PF; ++p) lds2[(buf ^ 1u) * (CH / PV) + p * kBlock + tid] = pre[p];
@@ -1924,7 +2024,7 @@ struct TileMfmaDesc {
   uint32_t p5;                 // amplitude-index position of tile bit 5 (see tile_block_base)
 };
 
-template <typename T, int K, bool NT, bool LOOP>
+template <typename T, int K, bool NT, bool LOOP, int NP>  // NP = 0: the four-product real form (k = 4); 3 / 1: mfma3_item (k = 5)
 __global__ __launch_bounds__(kTileBlock, K == 4 ? 5 : 2) void k_gate_tile_mfma(amp_t<T>* __restrict__ st, Ins ins, TileMfmaDesc d,
                                                                               const T* __restrict__ afrag, uint32_t pipe) {
   const uint32_t PIPE = LOOP ? pipe : 1u;  // tiles per block
@@ -1955,11 +2055,22 @@ __global__ __launch_bounds__(kTileBlock, K == 4 ? 5 : 2) void k_gate_tile_mfma(a
 #pragma unroll
   for (int u = 0; u < 8; ++u) r[u] = ldg<NT>(st + (wbase | row_of(u)) + lane_off);
   // the gate's fragments while the rows are on their way
-  T a[TT][KS];
+  constexpr int NPA = NP ? NP : 1, RB3 = NP ? S / 16 : 1, KS3 = NP ? S / 4 : 1;
+  T a[NP ? 1 : TT][NP ? 1 : KS];
+  T a3[RB3][NPA][KS3];
+  if constexpr (NP == 0) {
 #pragma unroll
-  for (int rb = 0; rb < TT; ++rb)
+    for (int rb = 0; rb < TT; ++rb)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a[rb][s] = afrag[(rb * KS + s) * 64 + lane];
+      for (int s = 0; s < KS; ++s) a[rb][s] = afrag[(rb * KS + s) * 64 + lane];
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < RB3; ++rb)
+#pragma unroll
+      for (int pt = 0; pt < NPA; ++pt)
+#pragma unroll
+        for (int s = 0; s < KS3; ++s) a3[rb][pt][s] = afrag[((rb * NPA + pt) * KS3 + s) * 64 + lane];
+  }
   // lane = (group j, q): j fills the four lowest non-target tile bits, q the two lowest targets
   const uint32_t j = lane & 15u, q = lane >> 4;
   uint32_t t_lane = ((q & 1u) << d.tb[0]) | ((q >> 1) << d.tb[1]);
@@ -1994,28 +2105,35 @@ __global__ __launch_bounds__(kTileBlock, K == 4 ? 5 : 2) void k_gate_tile_mfma(a
         slot[m] = slot_lane ^ tile_slot<A>(t_m);
         x[m] = tile[slot[m]];
       }
+      if constexpr (NP != 0) {
+        A y[NA];
+        mfma3_item<T, K, NPA>(a3, x, y);
 #pragma unroll
-      for (int rb = 0; rb < TT; rb += 2) {
-        V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
+        for (int m = 0; m < NA; ++m) tile[slot[m]] = y[m];  // every amplitude of the tile belongs to exactly one lane: in place
+      } else {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const T b = (s & 1) ? x[s >> 1].y : x[s >> 1].x;
-          acc0 = mfma16(a[rb][s], b, acc0);
-          acc1 = mfma16(a[rb + 1][s], b, acc1);
+        for (int rb = 0; rb < TT; rb += 2) {
+          V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const T b = (s & 1) ? x[s >> 1].y : x[s >> 1].x;
+            acc0 = mfma16(a[rb][s], b, acc0);
+            acc1 = mfma16(a[rb + 1][s], b, acc1);
+          }
+          A y0, y1, y2, y3;
+          y0.x = acc0[0];
+          y0.y = acc0[1];
+          y1.x = acc0[2];
+          y1.y = acc0[3];
+          y2.x = acc1[0];
+          y2.y = acc1[1];
+          y3.x = acc1[2];
+          y3.y = acc1[3];
+          tile[slot[2 * rb]] = y0;      // every amplitude of the tile belongs to exactly one lane: in place
+          tile[slot[2 * rb + 1]] = y1;
+          tile[slot[2 * rb + 2]] = y2;
+          tile[slot[2 * rb + 3]] = y3;
         }
-        A y0, y1, y2, y3;
-        y0.x = acc0[0];
-        y0.y = acc0[1];
-        y1.x = acc0[2];
-        y1.y = acc0[3];
-        y2.x = acc1[0];
-        y2.y = acc1[1];
-        y3.x = acc1[2];
-        y3.y = acc1[3];
-        tile[slot[2 * rb]] = y0;      // every amplitude of the tile belongs to exactly one lane: in place
-        tile[slot[2 * rb + 1]] = y1;
-        tile[slot[2 * rb + 2]] = y2;
-        tile[slot[2 * rb + 3]] = y3;
       }
     }
     __syncthreads();

@@ -580,6 +580,44 @@ static void build_afrag(const Plan& p, const std::vector<uint32_t>& tau, std::ve
       }
 }
 
+// A operands of mfma3_item (qip_kernels.h; k >= 5): 16 COMPLEX rows per block, parts P = G_re, R = -(G_re + G_im), Q = G_im - G_re
+// (computed in double, rounded once to the state's precision by the caller); a matrix without an imaginary part gets P only
+// (*real_only).  Index ((rb * NP + part) * (S/4) + s) * 64 + lane; lane l = (row i = l & 15 of the block, column kk = l >> 4 of the
+// K-step); C row i belongs to lane q = i & 3 as its reg = i >> 2 (f64 layout) or to lane q = i >> 2 as reg = i & 3 (f32 layout),
+// i.e. to the amplitude c~' = 16 rb + 4 reg + q; column c~ = 4 s + kk.
+static void build_afrag3(const Plan& p, const std::vector<uint32_t>& tau, std::vector<double>* out, bool f32_layout, bool* real_only) {
+  const uint32_t k = (uint32_t)p.opos.size();
+  const uint32_t S = 1u << k, RB = S / 16, KS3 = S / 4;
+  uint32_t perm_bit[12];  // c~ bit b (b-th lowest target position) -> sub-index bit of the reference
+  for (uint32_t b = 0; b < k; ++b)
+    for (uint32_t j = 0; j < k; ++j)
+      if (p.opos[j] == tau[b]) perm_bit[b] = k - 1 - j;
+  auto c_of = [&](uint32_t ct) {
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < k; ++b) c |= ((ct >> b) & 1u) << perm_bit[b];
+    return c;
+  };
+  bool real = true;
+  for (size_t e = 0; e < (size_t)S * S && real; ++e) real = p.table[2 * e + 1] == 0.0;
+  *real_only = real;
+  const uint32_t NP = real ? 1u : 3u;
+  out->assign((size_t)RB * NP * KS3 * 64, 0.0);
+  for (uint32_t rb = 0; rb < RB; ++rb)
+    for (uint32_t s = 0; s < KS3; ++s)
+      for (uint32_t l = 0; l < 64; ++l) {
+        const uint32_t i = l & 15, kk = l >> 4;
+        const uint32_t qp = f32_layout ? i >> 2 : i & 3, reg = f32_layout ? i & 3 : i >> 2;
+        const uint32_t ctp = 16 * rb + 4 * reg + qp, ct = 4 * s + kk;
+        const size_t e = (size_t)c_of(ctp) * S + c_of(ct);
+        const double re = p.table[2 * e], im = p.table[2 * e + 1];
+        (*out)[(((size_t)rb * NP + 0) * KS3 + s) * 64 + l] = re;
+        if (!real) {
+          (*out)[(((size_t)rb * NP + 1) * KS3 + s) * 64 + l] = -(re + im);
+          (*out)[(((size_t)rb * NP + 2) * KS3 + s) * 64 + l] = im - re;
+        }
+      }
+}
+
 // dense k = 4, 5 through the LDS-staged matrix-core kernel (k_gate_tile_mfma).  *done = false when the op does not qualify:
 // controls inside a row, a state below one tile.
 template <typename T>
@@ -622,7 +660,12 @@ static int launch_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool*
   for (uint32_t b = 0; b < (uint32_t)kTileBits; ++b)
     if (!((is_target >> b) & 1u)) d.nb[nn++] = b;
   std::vector<double> afrag;
-  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  // k = 5: a matrix without an imaginary part takes the two-product form (mfma3_item, NP = 1: half the matrix instructions, a 0/1
+  // matrix stays exact); a complex one keeps the four-product real form — the three-product form measured no faster here
+  // (5.62 vs 5.63 ms at n = 30: the pipelined tile kernel is no longer bound by the matrix pipe) and rounds worse
+  bool real_only = false;
+  if (k == 5) build_afrag3(p, tau, &afrag, std::is_same<T, float>::value, &real_only);
+  if (!real_only) build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
   std::vector<T> af_t(afrag.begin(), afrag.end());
   QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
   // (tile_block_base: positions in the space where p5 and 5 have traded places; the kernel exchanges the two bits back)
@@ -640,14 +683,16 @@ static int launch_tile_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st, bool*
   // k = 5: a block walks `pipe` consecutive tiles (the next tile's rows in flight during the matrix instructions): at least 8
   // tiles each, 512 - 2048 blocks (two per CU, one to four rounds); n = 30: 256 tiles per block
   const uint32_t pipe = k == 5 ? (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, ntiles / 1024)) : 1u;  // (powers of two)
-#define TM(KK, LL)                                                                                                                                       \
-  do {                                                                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, true, LL>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);    \
-    else hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, false, LL>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);      \
+#define TM(KK, LL, PP)                                                                                                                                       \
+  do {                                                                                                                                                       \
+    if (nt) hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, true, LL, PP>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);    \
+    else hipLaunchKernelGGL((k_gate_tile_mfma<T, KK, false, LL, PP>), grid2d(ntiles / pipe, 1), dim3(kTileBlock), lds, s->stream, st, ins, d, af, pipe);      \
   } while (0)
-  if (k == 4) TM(4, false);
-  else if constexpr (std::is_same<T, double>::value) TM(5, true);
-  else return fail(QIP_ERR_UNSUPPORTED, "internal: the tile form of dense k = 5 is a Complex<f64> kernel");
+  if (k == 4) TM(4, false, 0);
+  else if constexpr (std::is_same<T, double>::value) {
+    if (real_only) TM(5, true, 1);
+    else TM(5, true, 0);
+  } else return fail(QIP_ERR_UNSUPPORTED, "internal: the tile form of dense k = 5 is a Complex<f64> kernel");
 #undef TM
   HIPCHK(hipGetLastError());
   *done = true;
@@ -698,8 +743,10 @@ static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   std::vector<uint32_t> tau = p.opos;
   std::sort(tau.begin(), tau.end());
   std::vector<double> afrag;
-  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
+  bool real_only = false;
+  build_afrag3(p, tau, &afrag, std::is_same<T, float>::value, &real_only);
   std::vector<T> af_t(afrag.begin(), afrag.end());
+  QCHK(ensure_arena(s, af_t.size() * sizeof(T)));
   QCHK(arena_upload(s, af_t.data(), af_t.size() * sizeof(T), 0));
   std::vector<uint32_t> pos = p.cpos;
   for (uint32_t t : p.opos) pos.push_back(t);
@@ -713,10 +760,15 @@ static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const dim3 grid(blocks), block(kBlock);
   const T* af = (const T*)s->arena;
   const bool nt = use_nt(s);
-#define BM(K)                                                                                                        \
-  do {                                                                                                               \
-    if (nt) hipLaunchKernelGGL((k_gate_big_mfma<T, K, true>), grid, block, 0, s->stream, st, nitems, ins, d, af);    \
-    else hipLaunchKernelGGL((k_gate_big_mfma<T, K, false>), grid, block, 0, s->stream, st, nitems, ins, d, af);      \
+#define BM(K)                                                                                                                    \
+  do {                                                                                                                           \
+    if (real_only) {                                                                                                             \
+      if (nt) hipLaunchKernelGGL((k_gate_big_mfma<T, K, true, 1>), grid, block, 0, s->stream, st, nitems, ins, d, af);           \
+      else hipLaunchKernelGGL((k_gate_big_mfma<T, K, false, 1>), grid, block, 0, s->stream, st, nitems, ins, d, af);             \
+    } else {                                                                                                                     \
+      if (nt) hipLaunchKernelGGL((k_gate_big_mfma<T, K, true, 3>), grid, block, 0, s->stream, st, nitems, ins, d, af);           \
+      else hipLaunchKernelGGL((k_gate_big_mfma<T, K, false, 3>), grid, block, 0, s->stream, st, nitems, ins, d, af);             \
+    }                                                                                                                            \
   } while (0)
   switch (k) {
     case 6: BM(6); break;

@@ -339,6 +339,14 @@ def test_dense_big_k_streamed_matrix_core_kernel(O, k):
     pm[np.arange(1 << k), perm] = 1
     op = q.make_matrix_op([int(v) for v in rng.permutation(n)[:k]], pm.ravel())
     assert np.array_equal(hip_apply(n, op, x), oracle_apply(O, n, op, x))
+    if k <= 8:  # r6: a matrix without an imaginary part goes through the two-product form (k = 6..8), a complex one through three
+        orth = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0]
+        for idx in (list(range(n - k, n)), [int(v) for v in rng.permutation(n)[:k]]):
+            op = q.make_matrix_op(idx, orth.ravel())
+            assert np.max(np.abs(hip_apply(n, op, x) - oracle_apply(O, n, op, x))) <= TOL64, (k, idx)
+            opf = q.make_matrix_op(idx, orth.astype(np.complex64).ravel())
+            xf32 = rand_state(n, 6, np.complex64)
+            assert np.max(np.abs(hip_apply(n, opf, xf32) - oracle_apply(O, n, opf, xf32))) <= TOL32, (k, idx)
     op = q.make_matrix_op(list(range(k)), u.ravel())
     assert np.array_equal(hip_apply(n, op, x, mfma=0), oracle_apply(O, n, op, x))  # literal kernel: bit-equal
     # the f32 form of the same kernel (v_mfma_f32_16x16x4_f32)
@@ -753,6 +761,12 @@ def test_dense5_on_the_matrix_cores_through_an_lds_tile(O, dtype, tol):
             for tg in (P(0, 1, 2, 3, 4), P(11, 5, 0, 1, 2), P(n - 1, n - 2, n - 3, n - 4, n - 5), P(n - 1, 3, 11, 7, 5), P(6, 7, 8, 9, 10), P(12, 0, n - 1, 5, 13), P(4, 11, 12, 13, 14)):
                 cases.append((f"targets at positions {[n - 1 - t for t in tg]}", q.make_matrix_op(tg, u.ravel())))
             cases.append(("0/1 permutation matrix", q.make_matrix_op(P(n - 1, 1, 5, 11, 8), perm01.ravel())))
+            # a matrix without an imaginary part takes the two-product form (P = G only): a real orthogonal matrix, H on five qubits
+            cases.append(("real orthogonal matrix", q.make_matrix_op(P(n - 2, 0, 11, 6, 14), np.linalg.qr(rng.standard_normal((32, 32)))[0].ravel())))
+            h5 = np.array([[1.0]])
+            for _ in range(5):
+                h5 = np.kron(h5, np.array([[1.0, 1.0], [1.0, -1.0]]) / math.sqrt(2.0))
+            cases.append(("H on five qubits", q.make_matrix_op(P(n - 1, n - 3, 4, 5, 12), h5.ravel())))
         if n != 23:
             cases.append(("controlled, a control above the rows", q.make_control_op(P(15), q.make_matrix_op(P(n - 1, 0, 5, 11, 13), u.ravel()))))
             cases.append(("controlled, a control inside a row (direct kernel)", q.make_control_op(P(2), q.make_matrix_op(P(n - 1, 0, 5, 11, 13), u.ravel()))))

@@ -36,6 +36,13 @@ def rand_unitary(k, rng):
     return u
 
 
+def hk(k):
+    m = np.array([[1.0]])
+    for _ in range(k):
+        m = np.kron(m, np.array([[1.0, 1.0], [1.0, -1.0]]) / math.sqrt(2.0))
+    return m
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "all" else None
@@ -92,6 +99,9 @@ def main():
         ("dense k=6 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {}),
         ("dense k=7 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11], rand_unitary(7, rng).ravel()), {}),
         ("dense k=8 (MFMA f64, A streamed)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13], rand_unitary(8, rng).ravel()), {}),
+        ("dense k=5, real matrix (H on five qubits: two real products)", q.make_matrix_op([hi, mid, 5, 7, lo], hk(5).ravel()), {}),
+        ("dense k=6, real matrix (H on six qubits)", q.make_matrix_op([hi, mid, 5, 7, 9, lo], hk(6).ravel()), {}),
+        ("dense k=8, real matrix (H on eight qubits: state_bench.rs:118-139's gate)", q.make_matrix_op([hi, mid, 5, 7, 9, 11, 13, lo], hk(8).ravel()), {}),
         ("dense k=9 (MFMA f64, X in LDS, A from L2)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17], rand_unitary(9, rng).ravel()), {}),
         ("dense k=10 (MFMA f64, X in LDS in two K phases, A from L2)", q.make_matrix_op([hi, mid, 5, 7, lo, 9, 11, 13, 17, 19], rand_unitary(10, rng).ravel()), {}),
         ("dense k=6 (literal gather)", q.make_matrix_op([hi, mid, 5, 7, lo, 9], rand_unitary(6, rng).ravel()), {"mfma": 0}),
