@@ -544,13 +544,13 @@ __global__ __launch_bounds__(kBlock) void k_swapn(E* __restrict__ st, uint64_t n
 // written in destination order.  The LDS slot is the tile coordinate with up to FB of its higher bits XOR-folded into the low
 // FB bits (FB = 3 for 16-byte elements, 4 for 8-byte ones: the lanes of one ds_write / ds_read bank group then hit distinct
 // banks on both sides, MI355X_MICROARCH.md §LDS).
-constexpr int kPermMaxTile = 12;
+constexpr int kPermMaxTile = 13;  // (13: the pair form of 8-byte elements, k_permute_pairs)
 struct PermDesc {
   uint32_t tbits[kPermMaxTile];    // destination position of tile-coordinate bit i (tbits[i] = i for i < R; thread bits 0..7, element bits 8..)
   uint32_t sbits[kPermMaxTile];    // source position of source-side coordinate bit i (sbits[i] = i for i < R)
   uint32_t u2c[kPermMaxTile];      // bit i of the source-side coordinate is bit u2c[i] of the tile (destination) coordinate
   uint32_t tsorted[kPermMaxTile];  // the tile's destination positions ascending (the block index fills the others)
-  uint32_t nfold, fold_from[4], fold_to[4];
+  uint32_t nfold, fold_from[6], fold_to[6];
   uint32_t n_outer;                // destination positions outside the tile and the source position each one feeds
   unsigned char outer_dst[64], outer_src[64];
 };
@@ -623,6 +623,88 @@ __global__ __launch_bounds__(kBlock) void k_permute_bits(const A* __restrict__ i
 #pragma unroll
       for (int i = 0; i < EB; ++i) d_e |= (uint64_t)((e >> i) & 1) << d.tbits[8 + i];
       stg<NT>(out + (dcur | d_t | d_e), tile[slot_st ^ perm_fold((uint32_t)e << 8, d)]);
+    }
+    if (p + 1 < PIPE) __syncthreads();
+  }
+}
+// ---- the same sweep for 8-byte elements whose index bit 0 MOVES (Complex<f32>, unpacked view; r6) -------------------------
+// k_permute_bits would read such a state in 512-byte wave rows of 64 elements, and the split that pays for 16-byte elements is two
+// 256-byte pieces there (measured slower, profiles/r06_permute.md).  Here both global sides move 16-byte PAIRS — two elements
+// that differ in index position 0 on that side — with thread bits 0..4 = positions 1..5 and thread bit 5 = position 12 (byte
+// address bit 15) on the read side AND on the write side: the access pattern of the 16-byte kernel.  The 8-byte transposition
+// happens inside LDS: a loaded pair is parked as two 8-byte elements at their destination coordinates (they differ in tile bit
+// u2c[0]), a stored pair is one 16-byte LDS read (tile bit 0 = destination position 0; the slot's bit 0 is never folded).
+// Tile = positions {0..5, 12} on both sides: 12 or 13 bits (32 / 64 KiB); a permutation that needs 14 stays with k_permute_bits.
+// Coordinate bit 0 = the pair bit, bits 1..8 = the thread id, bits 9.. = the E units a thread moves.  PIPE as above.
+template <int TB, bool NT, int PIPE>
+__global__ __launch_bounds__(kBlock) void k_permute_pairs(const f32x4* __restrict__ in, f32x4* __restrict__ out, PermDesc d) {
+  using A8 = amp_t<float>;
+  constexpr int EB = TB - 9, E = 1 << EB;  // 16-byte units per thread
+  __shared__ __attribute__((aligned(16))) A8 tile[1 << TB];
+  const uint32_t t = threadIdx.x;
+  uint64_t s_t = 0, d_t = 0;
+  uint32_t c_t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t bit = (t >> i) & 1u;
+    c_t |= bit << d.u2c[i + 1];
+    s_t |= (uint64_t)bit << d.sbits[i + 1];
+    d_t |= (uint64_t)bit << d.tbits[i + 1];
+  }
+  const uint32_t slot_ld = perm_fold(c_t, d), slot_hi = perm_fold(1u << d.u2c[0], d), slot_st = perm_fold(t << 1, d);
+  const uint64_t first = (blockIdx.x + (uint64_t)blockIdx.y * gridDim.x) * PIPE;
+  uint64_t dbase, sbase;
+  auto bases = [&](uint64_t b) {
+    dbase = b;
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const uint32_t p = d.tsorted[i];
+      dbase = ((dbase >> p) << (p + 1)) | (dbase & ((1ull << p) - 1ull));
+    }
+    sbase = 0;
+    for (uint32_t i = 0; i < d.n_outer; ++i) sbase |= ((dbase >> d.outer_dst[i]) & 1ull) << d.outer_src[i];
+  };
+  f32x4 x[E];
+  auto load = [&]() {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      uint64_t s_e = 0;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) s_e |= (uint64_t)((e >> i) & 1) << d.sbits[9 + i];
+      x[e] = ldg<NT>(in + ((sbase | s_t | s_e) >> 1));
+    }
+  };
+  bases(first);
+  load();
+#pragma unroll
+  for (int p = 0; p < PIPE; ++p) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      uint32_t c_e = 0;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) c_e |= (uint32_t)((e >> i) & 1) << d.u2c[9 + i];
+      const uint32_t sl = slot_ld ^ perm_fold(c_e, d);
+      A8 lo, hi;
+      lo.x = x[e].x;
+      lo.y = x[e].y;
+      hi.x = x[e].z;
+      hi.y = x[e].w;
+      tile[sl] = lo;
+      tile[sl ^ slot_hi] = hi;
+    }
+    __syncthreads();
+    const uint64_t dcur = dbase;
+    if (p + 1 < PIPE) {
+      bases(first + p + 1);
+      load();
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      uint64_t d_e = 0;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) d_e |= (uint64_t)((e >> i) & 1) << d.tbits[9 + i];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[slot_st ^ perm_fold((uint32_t)e << 9, d)]);
+      stg<NT>(out + ((dcur | d_t | d_e) >> 1), v);
     }
     if (p + 1 < PIPE) __syncthreads();
   }

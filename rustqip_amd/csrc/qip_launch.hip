@@ -413,6 +413,75 @@ static int make_perm_desc(uint32_t n, const uint32_t* pi, uint32_t R, uint32_t f
   return QIP_OK;
 }
 
+// The pair form for 8-byte elements whose index bit 0 moves (k_permute_pairs): tile = positions {0..5, 12} on both sides, 12 or 13
+// bits; *fits = false when the permutation needs 14.  Coordinate order on each side: position 0 (the pair bit), 1..5, 12, the rest
+// ascending.  Folds: the source-side lane bits (coordinates 1..5) that land on tile bits above 5 are XOR-ed into free slot bits
+// 1..5 (never bit 0: a stored pair is one aligned 16-byte LDS read), so that a wave's 8-byte writes spread over the banks.
+static int make_perm_pairs_desc(uint32_t n, const uint32_t* pi, PermDesc* out, uint32_t* tile_bits_out, bool* fits) {
+  *fits = false;
+  if (n < 14u) return QIP_OK;
+  PermDesc& d = *out;
+  memset(&d, 0, sizeof d);
+  auto special = [](uint32_t p) { return p <= 5u || p == 12u; };
+  std::vector<char> in_tile(n, 0);
+  for (uint32_t b = 0; b < n; ++b)
+    if (special(b) || special(pi[b])) in_tile[b] = 1;
+  uint32_t cnt = 0;
+  for (uint32_t b = 0; b < n; ++b) cnt += in_tile[b];
+  if (cnt > 13u) return QIP_OK;
+  const uint32_t TB = cnt <= 12u ? 12u : 13u;
+  for (uint32_t b = 0; b < n && cnt < TB; ++b)  // pad with the lowest positions left
+    if (!in_tile[b]) {
+      in_tile[b] = 1;
+      ++cnt;
+    }
+  std::vector<uint32_t> tb = {0, 1, 2, 3, 4, 5, 12}, sb = tb, srcs;
+  for (uint32_t b = 0; b < n; ++b)
+    if (in_tile[b]) {
+      srcs.push_back(pi[b]);
+      if (!special(b)) tb.push_back(b);
+    }
+  std::sort(srcs.begin(), srcs.end());
+  for (uint32_t sp : srcs)
+    if (!special(sp)) sb.push_back(sp);
+  if (tb.size() != TB || sb.size() != TB) return fail(QIP_ERR_INVALID, "internal: permutation tile is not closed");
+  std::vector<uint32_t> ts = tb;
+  std::sort(ts.begin(), ts.end());
+  for (uint32_t i = 0; i < TB; ++i) {
+    d.tbits[i] = tb[i];
+    d.sbits[i] = sb[i];
+    d.tsorted[i] = ts[i];
+  }
+  for (uint32_t i = 0; i < TB; ++i) {
+    uint32_t k = 0;
+    while (k < TB && pi[tb[k]] != sb[i]) ++k;
+    if (k == TB) return fail(QIP_ERR_INVALID, "internal: permutation tile is not closed");
+    d.u2c[i] = k;
+  }
+  char taken[6] = {1, 0, 0, 0, 0, 0};  // slot bits 0..5; bit 0 is never a target
+  for (uint32_t i = 1; i <= 5; ++i)
+    if (d.u2c[i] >= 1 && d.u2c[i] <= 5) taken[d.u2c[i]] = 1;
+  uint32_t slot = 1;
+  for (uint32_t i = 1; i <= 5; ++i) {
+    if (d.u2c[i] <= 5) continue;  // (0: the lanes already differ in the slot's bit 0; 1..5: in place)
+    while (slot <= 5 && taken[slot]) ++slot;
+    if (slot > 5) break;
+    taken[slot] = 1;
+    d.fold_from[d.nfold] = d.u2c[i];
+    d.fold_to[d.nfold] = slot;
+    d.nfold += 1;
+  }
+  for (uint32_t b = 0; b < n; ++b)
+    if (!in_tile[b]) {
+      d.outer_dst[d.n_outer] = (unsigned char)b;
+      d.outer_src[d.n_outer] = (unsigned char)pi[b];
+      d.n_outer += 1;
+    }
+  *tile_bits_out = TB;
+  *fits = true;
+  return QIP_OK;
+}
+
 static int check_bit_permutation(uint32_t n, const uint32_t* pi, bool* identity) {
   uint64_t seen = 0;
   *identity = true;
@@ -442,13 +511,18 @@ int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
   // 16-byte elements: 512-byte rows with SPLIT wave accesses — thread bit 5 is index position 11 on both sides, so every
   // wave-level read and write is two 512-byte halves 32 KiB apart (r6; measured on every permutation of tools/bench_permute.py:
   // profiles/r06_permute.md) — in tiles of 2^11 or 2^12 elements (32 / 64 KiB of LDS).  A state below 2^12 elements keeps
-  // contiguous rows in 2^10-element tiles; 8-byte elements (an unpacked Complex<f32> view) keep 512-byte rows of 64 elements.
-  // (8-byte elements with the same split — two 256-byte pieces per wave access — measured slower: profiles/r06_permute.md)
+  // contiguous rows in 2^10-element tiles.  8-byte elements (Complex<f32> whose index bit 0 moves): 16-byte PAIRS on both global
+  // sides with the same split and the 8-byte transposition inside LDS (k_permute_pairs) when positions {0..5, 12} of both sides fit
+  // 13 tile bits, else 512-byte rows of 64 elements (the same split for 8-byte accesses — two 256-byte pieces — measured slower).
   const uint32_t R = wide ? 5u : 6u;
   const uint32_t split = (wide && n >= 12u) ? 11u : 0u;
   ProfRec rec;
   if (s->profile) QCHK(prof_begin(s, KC_PERMUTE, 2.0 * (double)s->amp_bytes * (double)s->namps, &rec));
   const bool nt = use_nt(s);
+  PermDesc dp;
+  bool pairs_fit = false;
+  uint32_t pairs_tb = 0;
+  if (!wide) QCHK(make_perm_pairs_desc(n, pi.data(), &dp, &pairs_tb, &pairs_fit));  // (n >= 14 and at most 13 tile bits)
   if (n < (split ? 12u : 2 * R)) {
     PermSmall ps;
     memset(&ps, 0, sizeof ps);
@@ -462,6 +536,19 @@ int launch_permute(qip_hip_state* s, const uint32_t* pi_in) {
       hipLaunchKernelGGL((k_permute_bits_small<f32x4>), grid, block, 0, s->stream, (const f32x4*)s->cur, (f32x4*)s->alt, count, ps);
     else
       hipLaunchKernelGGL((k_permute_bits_small<amp_t<float>>), grid, block, 0, s->stream, (const amp_t<float>*)s->cur, (amp_t<float>*)s->alt, count, ps);
+  } else if (pairs_fit) {  // 8-byte elements, index bit 0 moves, the pair tile fits: 16-byte pairs on both global sides
+    const dim3 block(kBlock);
+    const f32x4* src = (const f32x4*)s->cur;
+    f32x4* dst = (f32x4*)s->alt;
+    if (pairs_tb == 12) {
+      const dim3 grid = grid2d(1ull << (n - 12), 1);
+      if (nt) hipLaunchKernelGGL((k_permute_pairs<12, true, 1>), grid, block, 0, s->stream, src, dst, dp);
+      else hipLaunchKernelGGL((k_permute_pairs<12, false, 1>), grid, block, 0, s->stream, src, dst, dp);
+    } else {  // 64 KiB of LDS: two tiles per block, the second in flight (as k_permute_bits does for its 2^12 tiles)
+      const dim3 grid = grid2d((1ull << (n - 13)) / 2, 1);
+      if (nt) hipLaunchKernelGGL((k_permute_pairs<13, true, 2>), grid, block, 0, s->stream, src, dst, dp);
+      else hipLaunchKernelGGL((k_permute_pairs<13, false, 2>), grid, block, 0, s->stream, src, dst, dp);
+    }
   } else {
     PermDesc d;
     uint32_t TB = 0;
@@ -519,6 +606,27 @@ extern "C" const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi
     if (check_bit_permutation(n, pi, &identity) != QIP_OK) return nullptr;
     // an exported entry point: the two shape arguments index fixed-size tables of the descriptor, so they are checked here
     // (the library itself only ever passes 5 / 6 and 3 / 4)
+    if (row_bits == 100) {  // the pair form of 8-byte elements (k_permute_pairs); "fits": false when the tile would need 14 bits
+      PermDesc d;
+      uint32_t TB = 0;
+      bool fits = false;
+      if (make_perm_pairs_desc(n, pi, &d, &TB, &fits) != QIP_OK) return nullptr;
+      if (!fits) return (json = "{\"fits\":false}").c_str();
+      auto arr = [&](const char* key, const uint32_t* v, uint32_t cnt) {
+        std::string a = std::string("\"") + key + "\":[";
+        for (uint32_t i = 0; i < cnt; ++i) a += (i ? "," : "") + std::to_string(v[i]);
+        return a + "]";
+      };
+      uint32_t od[64], os[64];
+      for (uint32_t i = 0; i < d.n_outer; ++i) {
+        od[i] = d.outer_dst[i];
+        os[i] = d.outer_src[i];
+      }
+      json = "{\"fits\":true,\"n\":" + std::to_string(n) + ",\"tile_bits\":" + std::to_string(TB) + "," + arr("tsorted", d.tsorted, TB) + "," +
+             arr("tbits", d.tbits, TB) + "," + arr("sbits", d.sbits, TB) + "," + arr("u2c", d.u2c, TB) + "," + arr("fold_from", d.fold_from, d.nfold) + "," +
+             arr("fold_to", d.fold_to, d.nfold) + "," + arr("outer_dst", od, d.n_outer) + "," + arr("outer_src", os, d.n_outer) + "}";
+      return json.c_str();
+    }
     // row_bits = 0: the shape the library picks for 16-byte elements (512-byte rows, split at position 11 when n >= 12)
     const uint32_t split = (row_bits == 0 && n >= 12) ? 11u : 0u;
     if (row_bits == 0) row_bits = 5;

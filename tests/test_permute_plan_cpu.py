@@ -168,3 +168,76 @@ def test_plan_hook_rejects_shapes_its_tables_cannot_hold():
         assert "must be" in _ffi.last_error() or "does not fit" in _ffi.last_error()
     assert _ffi.lib.qip_hip_debug_permute_plan(n, arr, 5, 3)
     assert _ffi.lib.qip_hip_debug_permute_plan(n, arr, 0, 3)  # row_bits = 0: the library's own choice (split rows)
+
+
+def replay_pairs(n, d, x):
+    """numpy model of k_permute_pairs<TB>: 8-byte elements, 16-byte pairs on both global sides, the 8-byte transposition in LDS.
+    Returns (out, LDS slots written by the load side [unit, half], LDS slot pairs read by the store side)."""
+    TB = d["tile_bits"]
+    nblk = 1 << (n - TB)
+    dbase = np.arange(nblk, dtype=np.uint64)
+    for p in d["tsorted"]:
+        low = dbase & np.uint64((1 << p) - 1)
+        dbase = ((dbase >> np.uint64(p)) << np.uint64(p + 1)) | low
+    sbase = np.zeros_like(dbase)
+    for a, b in zip(d["outer_dst"], d["outer_src"]):
+        sbase |= ((dbase >> np.uint64(a)) & np.uint64(1)) << np.uint64(b)
+    u = np.arange(1 << (TB - 1), dtype=np.uint64) << np.uint64(1)  # a unit's coordinate: (e, thread) above the pair bit
+    s_off = spread(u, d["sbits"])          # element offset of the unit's first element on the source side
+    d_off = spread(u, d["tbits"])
+    assert not np.any(s_off & np.uint64(1)) and not np.any(d_off & np.uint64(1))  # units are 16-byte aligned on both sides
+    c_lo = spread(u, d["u2c"])
+    slot_lo = fold(c_lo, d)
+    slot_hi = slot_lo ^ fold(np.uint64(1) << np.uint64(d["u2c"][0]), d)
+    slot_st = fold(u, d)
+    assert not np.any(slot_st & np.uint64(1))  # a stored pair is one aligned 16-byte LDS read
+    assert fold(np.uint64(1), d) == np.uint64(1)
+    out = np.empty_like(x)
+    for b in range(nblk):
+        lds = np.empty(1 << TB, dtype=x.dtype)
+        src = (sbase[b] | s_off).astype(np.int64)
+        lds[slot_lo.astype(np.int64)] = x[src]
+        lds[slot_hi.astype(np.int64)] = x[src + 1]
+        dst = (dbase[b] | d_off).astype(np.int64)
+        out[dst] = lds[slot_st.astype(np.int64)]
+        out[dst + 1] = lds[slot_st.astype(np.int64) + 1]
+    return out, np.stack([slot_lo, slot_hi]), slot_st
+
+
+def test_pair_form_for_8_byte_elements_replayed_with_numpy():
+    """r6, k_permute_pairs (Complex<f32> when index bit 0 moves): the host's descriptor replayed — every element lands where
+    new[j] = old[src(j)] says, the LDS slots are a bijection, a wave's 32-lane halves spread their 8-byte writes over >= 16 of the
+    32 bank pairs (the sweep is HBM-bound by a factor of ten: two-way conflicts cost nothing, 32-way ones would), and the
+    permutations that need 14 tile bits are left to k_permute_bits."""
+    rng = np.random.default_rng(11)
+    fitted = 0
+    for n in (14, 15, 17):
+        cases = [[n - 1] + list(range(1, n - 1)) + [0],                     # bit 0 <-> the top bit
+                 list(range(1, n)) + [0],                                   # rotation
+                 [1, 0] + list(range(2, n)),                                # inside the pair / lane bits
+                 [12] + list(range(1, 12)) + [0] + list(range(13, n)),      # bit 0 <-> the split position
+                 list(range(n))[::-1]]
+        cases += [[int(v) for v in rng.permutation(n)] for _ in range(10)]
+        for pi in cases:
+            d = plan(n, pi, 100, 0)
+            special = [b for b in range(n) if b <= 5 or b == 12 or pi[b] <= 5 or pi[b] == 12]
+            assert d["fits"] == (len(special) <= 13), (n, pi)
+            if not d["fits"]:
+                continue
+            fitted += 1
+            TB = d["tile_bits"]
+            assert TB == (12 if len(special) <= 12 else 13)
+            assert d["tbits"][:7] == [0, 1, 2, 3, 4, 5, 12] and d["sbits"][:7] == [0, 1, 2, 3, 4, 5, 12]
+            assert all(1 <= t <= 5 for t in d["fold_to"]) and all(f >= 6 for f in d["fold_from"])
+            x = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+            got, slots_ld, slot_st = replay_pairs(n, d, x)
+            assert np.array_equal(got, want_of(n, pi, x)), (n, pi)
+            assert len(set(slots_ld.ravel().tolist())) == 1 << TB
+            assert len(set(slot_st.tolist()) | set((slot_st + np.uint64(1)).tolist())) == 1 << TB
+            for half in slots_ld:  # 32 consecutive lanes of one write instruction
+                g = (half % np.uint64(32)).reshape(-1, 32)
+                assert min(len(set(r.tolist())) for r in g) >= 16, (n, pi)
+    assert fitted >= 20
+    assert plan(20, list(range(20))[::-1], 100, 0)["fits"] is False  # the reversal needs 14 positions
+    n = 13
+    assert plan(n, list(range(1, n)) + [0], 100, 0)["fits"] is False  # below 14 qubits: k_permute_bits
