@@ -240,8 +240,11 @@ int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
 
 /* r5 (ABI 6): where those kernels come from.  A segment that is not resident in this process is looked up on disk first
  * ($QIP_HIP_CACHE_DIR, default $XDG_CACHE_HOME/qip_hip or ~/.cache/qip_hip; "off" / "" disables; global option "jit_disk_cache"
- * 0 / 1): code objects are stored under a 128-bit hash of compiler version + flags + the embedded kernel header + the source
+ * 0 / 1): code objects are stored under a 128-bit hash of the compiler + flags + the embedded kernel header + the source
  * text, so a second process LOADS (~1 ms per segment) instead of compiling (~0.45 s per 11-bit segment, ~1.3 s per wide one).
+ * "The compiler" is the ROCm installation the helper processes use ($ROCM_PATH or /opt/rocm: its release and the sizes of its
+ * libhiprtc / libamd_comgr), not whatever copy of those libraries the host program happens to have loaded: processes with and
+ * without e.g. PyTorch's bundled ROCm share one cache, and the former hand even a single new segment to a helper.
  * The segments of a plan that are new are compiled side by side in up to "jit_procs" helper PROCESSES (global option; 0 =
  * automatic: the CPUs this process may use, at most 16, divided by the ranks of a sharded state; 1 = in this process only) —
  * hiprtc serialises the compilations of one process, separate processes scale.  The helper is `qip_jitc` next to the library
