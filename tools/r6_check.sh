@@ -1,13 +1,10 @@
 #!/bin/bash
-# the final tree once more: the full GPU suite, then the default-shaped bench run with the committed PMC traffic of the same kernels
-out=gpurun_out/${1:-r06y}
+# (1) the data fixtures of tests/golden through the HIP path; (2) a -DQIP_HIP_TUNING build on the box: the GPU suite once more with the
+# measured alternatives as options, which switches on the A/B identity asserts (tile form == direct form, row shapes, ...)
+out=gpurun_out/${1:-r06x}
 mkdir -p $out
-( time timeout 1500 python -m pytest tests -m gpu -q --durations=12 ) > $out/gpu_tests.txt 2>&1
-echo "rc=$?" >> $out/gpu_tests.txt
-tail -n 22 $out/gpu_tests.txt
-export QIP_BENCH_DETAIL=$out/bench_detail.json
-( time timeout 900 python bench.py --steps 20 --warmup 5 ) > $out/bench_n1.json 2> $out/bench_n1.err
-tail -n 1 $out/bench_n1.json | cut -c1-300
-grep -v amdgpu.ids $out/bench_n1.err | tail -n 6
-( time timeout 600 python bench.py ) > $out/bench_default.json 2> $out/bench_default.err
-tail -n 1 $out/bench_default.json | cut -c1-200; grep real $out/bench_default.err
+timeout 600 python -m pytest tests/test_golden_fixtures.py -m gpu -q 2>&1 | tail -n 3
+QIP_HIP_TUNING=1 python -m rustqip_amd.build > $out/tuning_build.log 2>&1; tail -n 1 $out/tuning_build.log | cut -c1-200
+( time timeout 1700 python -m pytest tests -m gpu -q --durations=5 ) > $out/gpu_tests_tuning_build.txt 2>&1
+echo "rc=$?" >> $out/gpu_tests_tuning_build.txt
+tail -n 25 $out/gpu_tests_tuning_build.txt | cut -c1-300
