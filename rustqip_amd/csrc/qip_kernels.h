@@ -1366,14 +1366,22 @@ struct SparseTileDesc {
   uint32_t low_ctl;   // lane bits that are controls (all must read 1 for the row to be touched)
 };
 
-template <typename T, int E, bool NT>
+// TL (r6): the op's table — `rows` x E (slot, value) entries + the row counts — is copied into LDS behind the tile by the block and
+// read from there.  With wider rows a lane issues 8 x (1 + 2 E) table loads per tile through the vector memory path, which, not
+// HBM, then bounds the sweep (Complex<f32>, k = 7, four entries per row: 36 % of the HBM peak; profiles/r06_sparse_tile.md); from
+// LDS they cost a fraction.  Used for Complex<f32> rows of four entries when the table is at most 16 KiB (the launcher's comment
+// has the cases where it measured no better).
+template <typename T, int E, bool NT, bool TL>
 __global__ void k_sparse_tile(amp_t<T>* __restrict__ st, uint64_t ntiles, Ins ins, SparseTileDesc d,
                               const uint32_t* __restrict__ nnz, const uint32_t* __restrict__ slot,
-                              const amp_t<T>* __restrict__ val) {
+                              const amp_t<T>* __restrict__ val, uint32_t rows) {
   using A = amp_t<T>;
   constexpr int R = 8;  // rows of the tile per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char sparse_tile_raw[];
   A* tile = reinterpret_cast<A*>(sparse_tile_raw);
+  A* lval = tile + ((size_t)64 << d.kh);                          // TL: rows * E values ...
+  uint32_t* lslot = reinterpret_cast<uint32_t*>(lval + (size_t)rows * E);  // ... their slots ...
+  uint32_t* lnnz = lslot + (size_t)rows * E;                      // ... and the rows' counts
   const uint64_t blk = blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (blk >= ntiles) return;
   const uint32_t lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
@@ -1412,19 +1420,26 @@ __global__ void k_sparse_tile(amp_t<T>* __restrict__ st, uint64_t ntiles, Ins in
       v[i][0] = val[m];
     }
   }
+  if constexpr (TL) {  // (the table does not depend on the tile: it arrives while the tile's loads are in flight)
+    for (uint32_t i = threadIdx.x; i < rows * (uint32_t)E; i += blockDim.x) {
+      lval[i] = val[i];
+      lslot[i] = slot[i];
+    }
+    for (uint32_t i = threadIdx.x; i < rows; i += blockDim.x) lnnz[i] = nnz[i];
+  }
 #pragma unroll
   for (int i = 0; i < R; ++i) tile[(((uint32_t)i * nw + wave) << 6) | lane] = x[i];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const uint32_t m = ml | (((uint32_t)i * nw + wave_v) << d.nlow);
-    if constexpr (!PRE) cnt[i] = nnz[m];
+    if constexpr (!PRE) cnt[i] = TL ? lnnz[m] : nnz[m];
     A acc = czero<A>();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       if constexpr (!PRE) {
-        sl[i][e] = slot[m * E + e];  // (slots beyond a row's count hold 0: a harmless read, not added)
-        v[i][e] = val[m * E + e];
+        sl[i][e] = TL ? lslot[m * E + e] : slot[m * E + e];  // (slots beyond a row's count hold 0: a harmless read, not added)
+        v[i][e] = TL ? lval[m * E + e] : val[m * E + e];
       }
       const A xx = tile[sl[i][e] | keep];
       if ((uint32_t)e < cnt[i]) acc = cadd(acc, cmul(v[i][e], xx));

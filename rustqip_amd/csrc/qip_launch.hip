@@ -1376,25 +1376,37 @@ static int launch_sparse_tile(qip_hip_state* s, const Plan& p, const FlatOp& f, 
   const Ins ins = sp.ins;
   const uint64_t ntiles = sp.ntiles;
   const unsigned threads = sp.threads;
-  const size_t lds = sizeof(amp_t<T>) << (6 + d.kh);
+  // r6: Complex<f32> rows of four entries read their table from LDS (copied behind the tile by every block) when it is small: a
+  // lane's 8 x (1 + 2 E) = 72 table loads per tile through the vector memory path bound that sweep, not HBM (k = 7: 5.98 -> 3.23 ms =
+  // 36 -> 67 % of 8 TB/s).  Measured and left alone: Complex<f64> E = 4 (6.81 -> 6.99 ms: its HBM time is twice as long and hides the
+  // loads), E = 2 in both precisions (f64 k = 6: 5.69 -> 6.22 ms, f32: 3.74 -> 3.79); profiles/r06_sparse_tile.md
+  const size_t tile_bytes = sizeof(amp_t<T>) << (6 + d.kh);
+  const size_t table_bytes = (size_t)rows * E * (sizeof(amp_t<T>) + 4) + (size_t)rows * 4;
+  const bool tl = E == 4 && std::is_same<T, float>::value && table_bytes <= 16 * 1024 && tile_bytes + table_bytes <= 160 * 1024;
+  const size_t lds = tile_bytes + (tl ? table_bytes : 0);
   const dim3 grid = grid2d(ntiles, 1);
   amp_t<T>* st = (amp_t<T>*)s->cur;
   const bool nt = use_nt(s);
-#define SPT2(EE, NTV)                                                                                                             \
-  do {                                                                                                                             \
-    if (lds > 64 * 1024)                                                                                                           \
-      HIPCHK(hipFuncSetAttribute((const void*)k_sparse_tile<T, EE, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-    hipLaunchKernelGGL((k_sparse_tile<T, EE, NTV>), grid, dim3(threads), lds, s->stream, st, ntiles, ins, d, dn, dslot, dval);    \
+#define SPT3(EE, NTV, TLV)                                                                                                                 \
+  do {                                                                                                                                      \
+    if (lds > 64 * 1024)                                                                                                                    \
+      HIPCHK(hipFuncSetAttribute((const void*)k_sparse_tile<T, EE, NTV, TLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    hipLaunchKernelGGL((k_sparse_tile<T, EE, NTV, TLV>), grid, dim3(threads), lds, s->stream, st, ntiles, ins, d, dn, dslot, dval, (uint32_t)rows); \
   } while (0)
-#define SPT(EE)                  \
-  do {                           \
-    if (nt) SPT2(EE, true);      \
-    else SPT2(EE, false);        \
+#define SPT(EE)                        \
+  do {                                 \
+    if (nt) SPT3(EE, true, false);     \
+    else SPT3(EE, false, false);       \
   } while (0)
   if (E == 1) SPT(1);
   else if (E == 2) SPT(2);
-  else SPT(4);
-#undef SPT2
+  else if (tl) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (nt) SPT3(4, true, true);
+      else SPT3(4, false, true);
+    }
+  } else SPT(4);
+#undef SPT3
 #undef SPT
   HIPCHK(hipGetLastError());
   *done = true;
