@@ -382,7 +382,7 @@ int main(void) {
 
 PRODUCT_GLOBAL_OPTIONS = ("force_generic", "jit_cache_cap", "jit_disk_cap_mb", "jit_disk_cache", "jit_procs", "tile_sched", "single_via_tile",
                           "dist_fold_pack", "dist_plan_cost", "collective_timeout_s")
-TUNING_ONLY_OPTIONS = ("perm_rows", "line_bits", "tile_pad_from", "soft_measure_one_pass", "tile_wide_dense3_inline", "tile_wide_pin", "sparse_tile",
+TUNING_ONLY_OPTIONS = ("line_bits", "tile_pad_from", "soft_measure_one_pass", "tile_wide_dense3_inline", "tile_wide_pin", "sparse_tile",
                        "debug_slice_sweeps", "tile_diag_runs", "jit_threads", "tile_row_split_f32", "tile_row_split", "tile_wave_rule", "tile_remap",
                        "k4_direct", "single_via_tile_f32")
 
