@@ -919,6 +919,51 @@ def test_wide_tiles_match_the_narrow_sweeps_and_the_oracle(O, dtype):
             assert float(np.max(np.abs(got - want))) <= tol, (nn, tile)
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, TOL64), (np.complex64, TOL32)])
+def test_programs_with_this_rounds_kernels(O, dtype, tol):
+    """r6: the kernels added this round inside a PROGRAM (tables packed once into the program's own device pool, launches recorded
+    into a hipGraph) on a state of 23 qubits, where the pipelined k = 5 tile kernel applies: dense k = 5 complex (four products) and
+    real (two), dense k = 6 complex (three products) and real (two), a Swap run that composes to a bit permutation with index bit 0
+    moving (k_permute_bits for Complex<f64>, k_permute_pairs for Complex<f32>), a SparseMatrix on seven qubits with four entries per
+    row (Complex<f32>: the table in LDS) — replayed twice, against the same ops applied one call at a time and against the oracle."""
+    n = 23
+    rng = np.random.default_rng(66)
+    P = lambda *pos: [n - 1 - p for p in pos]  # noqa: E731
+    rows7 = []
+    for r in range(128):
+        cols = [int(c) for c in rng.permutation(128)[:4]]
+        rows7.append([(c, complex(rng.standard_normal(), rng.standard_normal()) * 0.5) for c in cols])
+    ops = [
+        q.make_matrix_op(P(22, 3, 11, 7, 5), rand_unitary(5, rng).ravel()),
+        q.make_matrix_op(P(20, 0, 12, 6, 14), np.linalg.qr(rng.standard_normal((32, 32)))[0].ravel()),
+        q.make_matrix_op(P(21, 1, 5, 11, 8, 15), rand_unitary(6, rng).ravel()),
+        q.make_matrix_op(P(2, 9, 13, 17, 19, 22), np.linalg.qr(rng.standard_normal((64, 64)))[0].ravel()),
+        q.make_swap_op(P(0, 13), P(22, 4)),
+        q.make_sparse_matrix_op(P(22, 18, 16, 14, 9, 3, 1), rows7),
+        q.make_control_op(P(15), q.make_matrix_op(P(22, 0, 5, 11, 13), rand_unitary(5, rng).ravel())),
+    ]
+    x = circuits.random_state(n, seed=9, dtype=dtype)
+    with q.HipState(n, dtype) as st, q.HipState(n, dtype) as eager:
+        st.upload(x)
+        prog = st.compile_program(ops)  # (ops carry complex128 tables; the binding converts them per state dtype)
+        prog.run()
+        prog.run()
+        assert prog.is_graph
+        got = st.download()
+        prog.close()
+        eager.upload(x)
+        eager.set_option("profile", 1)
+        for _ in range(2):
+            for o in ops:
+                eager.apply_op(o)
+        prof = eager.profile()
+        assert np.array_equal(got, eager.download())  # the same kernels with the same tables: identical
+        assert prof.get("k_gate_kq_mfma", {}).get("launches", 0) >= 6 and prof.get("k_gate_big_mfma", {}).get("launches", 0) == 4, prof
+    want = O.apply_ops_in_place(n, ops + ops, x.copy())
+    scale = max(1.0, float(np.max(np.abs(want))))  # (the sparse op is not unitary: amplitudes grow)
+    assert float(np.max(np.abs(got - want))) <= 8 * tol * scale
+
+
 def test_programs_own_their_payloads_and_record_out_of_place_ops(O):
     """r6 (VERDICT r5 item 2): a program packs every op's tables ONCE into device memory it owns and records kernel nodes only;
     ops that write the second buffer are recorded too — one recording per starting buffer, the host follows the ping-pong
