@@ -16,7 +16,9 @@ extern "C" {
 
 /* Host-only test hook: the descriptor of that sweep as JSON (tile bit positions, LDS swizzle), NULL on error.
  * row_bits = 0 asks for the shape the library launches for 16-byte elements (512-byte rows, thread bit 5 = index position 11
- * on both sides when n >= 12: "tile_bits" 11 or 12); row_bits = 5 / 6 the contiguous-row shapes of 2 * row_bits tile bits. */
+ * on both sides when n >= 12: "tile_bits" 11 or 12); row_bits = 5 / 6 the contiguous-row shapes of 2 * row_bits tile bits;
+ * row_bits = 100 the pair form of 8-byte elements whose index bit 0 moves (k_permute_pairs: "fits" false when the tile would
+ * need 14 bits or n < 14; fold_bits is ignored). */
 const char* qip_hip_debug_permute_plan(uint32_t n, const uint32_t* pi, uint32_t row_bits, uint32_t fold_bits);
 
 /* Host-only: how one pass of a tile sweep lays the thread id over the tile.  pass_bits = the pass's three exchange
