@@ -1101,30 +1101,35 @@ __global__ __launch_bounds__(kBlock, (K <= 7 || sizeof(T) == 4) ? 2 : 1) void k_
 // exactly one wave and goes from the L2-resident fragment array straight into registers (16-byte loads holding two
 // consecutive K-steps, eight pairs prefetched ahead of the matrix instructions), never through LDS.  The results stay in
 // registers (2 amplitudes per lane per row block) until the item's last row block is done — X in LDS is never overwritten —
-// and are then stored over the inputs.  Same real-form product, lane mapping and host-built fragments (re-ordered in pairs)
-// as k_gate_kq_mfma.  Where 16 groups x 2^k amplitudes exceed the LDS (Complex<f64>, k = 10: 256 KiB) the K dimension is
-// walked in two phases, each with half of X in LDS, the running sums of a wave's row blocks carried in registers.
-// Roofline: 8 * 2^k flop per amplitude = 128 / 256 flop/B: bound by the f64 matrix pipe (78.6 TFLOP/s), with the A stream
-// (2^(k+1) bytes of L2 traffic per amplitude: every block walks the whole 8- / 32-MiB fragment array per item) next in line.
+// and are then stored over the inputs.  Same lane mapping as k_gate_kq_mfma; the products and the host-built fragments are those
+// of mfma3_item (three real products per complex one, two for a real matrix; fragments re-ordered in pairs of K-steps).  Where
+// 16 groups x 2^k amplitudes exceed the LDS (Complex<f64>, k = 10: 256 KiB) the K dimension is walked in two phases, each with
+// half of X in LDS, the running sums of a wave's row blocks carried in registers.
+// Roofline: 6 * 2^k flop per amplitude executed (8 * 2^k nominal) against 32 B: bound by the f64 matrix pipe (78.6 TFLOP/s), with
+// the A stream (1.5 * 2^(k+1) bytes of L2 traffic per amplitude: every block walks the whole 6- / 24-MiB fragment array per item)
+// next in line.  n = 30 (profiles/r06_dense_k5.md): k = 9 79 -> 59 ms, k = 10 162 - 188 -> 129 ms.
 struct HugeDesc {
   uint32_t tau[12];  // target bit positions, ascending
 };
-template <typename T, int K, int NPH, bool NT>
+// r6: the products are the three of mfma3_item's header (NP = 3: parts P, R, Q; NP = 1: P alone for a matrix without an imaginary
+// part), per block of 16 COMPLEX rows: three independent accumulator chains (K1, re, im) over the item's K-steps, re += K1 and
+// im += K1 at the end of a phase.  Fragments in pairs of consecutive K-steps: frag[(((rb * (S/8) + sp) * NP + part) * 64 + lane) * 2 + e].
+template <typename T, int K, int NPH, bool NT, int NP>
 __global__ __launch_bounds__(512) void k_gate_huge_mfma(amp_t<T>* __restrict__ st, uint64_t nitems, Ins ins, HugeDesc d,
                                                        const T* __restrict__ afrag2) {
   using A = amp_t<T>;
   using V4 = typename Acc4<T>::type;
   constexpr int NG = 16;        // groups per item (the 16 columns of the matrix instruction)
   constexpr int S = 1 << K;
-  constexpr int TT = S / 8;     // 16-row blocks of the (2S x 2S) real matrix
-  constexpr int KP = S / 4;     // K-step PAIRS (one amplitude of X each)
+  constexpr int RB = S / 16;    // blocks of 16 complex rows
+  constexpr int KP = S / 8;     // K-step PAIRS per part (two amplitudes of X each)
   constexpr int KPH = KP / NPH; // ... per phase: NPH > 1 when 16 x 2^K amplitudes exceed the LDS (Complex<f64>, K = 10) — the
                                 // K dimension is walked in NPH phases, each with its share of X in LDS, the row blocks'
                                 // running sums carried in registers from phase to phase
   constexpr int NW = 8;         // waves per block
-  constexpr int RBW = TT / NW;  // row blocks per wave
-  constexpr int PF = 8;         // K-step pairs of A in flight ahead of the matrix instructions
-  static_assert(KPH % PF == 0 && TT % NW == 0 && KP % NPH == 0, "shape");
+  constexpr int RBW = RB / NW;  // row blocks per wave
+  constexpr int PF = (NPH > 1 || NP == 1) ? 2 : 4;  // K-step pairs of A in flight ahead of the matrix instructions (registers: the carried sums of NPH > 1)
+  static_assert(KPH % PF == 0 && RB % NW == 0 && KP % NPH == 0 && (NP == 1 || NP == 3), "shape");
   __shared__ __attribute__((aligned(16))) A xl[(S / NPH) * NG];  // xl[(c~ - first c~ of the phase) * NG + group]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1138,62 +1143,79 @@ __global__ __launch_bounds__(512) void k_gate_huge_mfma(amp_t<T>* __restrict__ s
   };
   typedef T pair_t __attribute__((ext_vector_type(2)));  // A values of K-steps 2p and 2p + 1
   const pair_t* __restrict__ a2 = reinterpret_cast<const pair_t*>(afrag2);
+  const V4 zero = {(T)0, (T)0, (T)0, (T)0};
+  constexpr int KSPH = (S / 4) / NPH;  // amplitudes of X per lane and phase
   for (uint64_t w = blockIdx.x; w < nitems; w += gridDim.x) {
     const uint64_t base = insert_bits<-1>(w * NG + j, ins) | offq;
-    V4 y[RBW];  // the row blocks' sums so far; statically indexed (a rolled loop picks its slot by comparison): registers
+    V4 yre[RBW], yim[RBW];  // the row blocks' sums so far; statically indexed (a rolled loop picks its slot by comparison): registers
 #pragma unroll
-    for (int r = 0; r < RBW; ++r) y[r] = V4{(T)0, (T)0, (T)0, (T)0};
+    for (int r = 0; r < RBW; ++r) yre[r] = yim[r] = zero;
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
       if (ph) __syncthreads();  // every wave is done with the previous phase's share of X
       // X -> LDS: wave v brings the sub-indices c~ = 4 m + q with m = first + v, first + v + NW, ...
 #pragma unroll 4
-      for (uint32_t m = wave; m < (uint32_t)KPH; m += NW)
-        xl[(4u * m + q) * NG + j] = ldg<NT>(st + (base | offm((uint32_t)ph * KPH + m)));
+      for (uint32_t m = wave; m < (uint32_t)KSPH; m += NW)
+        xl[(4u * m + q) * NG + j] = ldg<NT>(st + (base | offm((uint32_t)ph * KSPH + m)));
       __syncthreads();
 #pragma unroll 1
       for (int rbi = 0; rbi < RBW; ++rbi) {
         const uint32_t rb = wave + (uint32_t)rbi * NW;
-        const pair_t* ap = a2 + ((size_t)rb * KP + (size_t)ph * KPH) * 64 + lane;
-        V4 acc0 = {(T)0, (T)0, (T)0, (T)0}, acc1 = {(T)0, (T)0, (T)0, (T)0};
-        if (NPH > 1) {
+        const pair_t* ap = a2 + (((size_t)rb * KP + (size_t)ph * KPH) * NP) * 64 + lane;  // + (sp * NP + part) * 64
+        V4 k1 = zero, re = zero, im = zero;
+        pair_t cur[PF][NP], nxt[PF][NP];
 #pragma unroll
-          for (int r = 0; r < RBW; ++r)
-            if (r == rbi) acc0 = y[r];
-        }
-        pair_t cur[PF], nxt[PF];
+        for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int u = 0; u < PF; ++u) cur[u] = ap[(size_t)u * 64];
+          for (int pt = 0; pt < NP; ++pt) cur[u][pt] = ap[(size_t)(u * NP + pt) * 64];
 #pragma unroll 1
         for (int p0 = 0; p0 < KPH; p0 += PF) {
           if (p0 + PF < KPH) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) nxt[u] = ap[(size_t)(p0 + PF + u) * 64];
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+              for (int pt = 0; pt < NP; ++pt) nxt[u][pt] = ap[(size_t)((p0 + PF + u) * NP + pt) * 64];
           }
 #pragma unroll
           for (int u = 0; u < PF; ++u) {
-            const A xb = xl[(4u * (uint32_t)(p0 + u) + q) * NG + j];
-            acc0 = mfma16(cur[u].x, xb.x, acc0);
-            acc1 = mfma16(cur[u].y, xb.y, acc1);
+            const A xa = xl[(4u * (uint32_t)(2 * (p0 + u)) + q) * NG + j], xb = xl[(4u * (uint32_t)(2 * (p0 + u) + 1) + q) * NG + j];
+            if constexpr (NP == 3) {
+              k1 = mfma16(cur[u][0].x, xa.x + xa.y, k1);
+              re = mfma16(cur[u][1].x, xa.y, re);
+              im = mfma16(cur[u][2].x, xa.x, im);
+              k1 = mfma16(cur[u][0].y, xb.x + xb.y, k1);
+              re = mfma16(cur[u][1].y, xb.y, re);
+              im = mfma16(cur[u][2].y, xb.x, im);
+            } else {
+              re = mfma16(cur[u][0].x, xa.x, re);
+              im = mfma16(cur[u][0].x, xa.y, im);
+              re = mfma16(cur[u][0].y, xb.x, re);
+              im = mfma16(cur[u][0].y, xb.y, im);
+            }
           }
 #pragma unroll
-          for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+          for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt) cur[u][pt] = nxt[u][pt];
         }
 #pragma unroll
         for (int r = 0; r < RBW; ++r)
-          if (r == rbi) y[r] = acc0 + acc1;
+          if (r == rbi) {
+            yre[r] = yre[r] + (NP == 3 ? re + k1 : re);
+            yim[r] = yim[r] + (NP == 3 ? im + k1 : im);
+          }
       }
     }
 #pragma unroll
     for (int r = 0; r < RBW; ++r) {
       const uint32_t rb = wave + (uint32_t)r * NW;
-      A y0, y1;
-      y0.x = y[r][0];
-      y0.y = y[r][1];
-      y1.x = y[r][2];
-      y1.y = y[r][3];
-      stg<NT>(st + (base | offm(2u * rb)), y0);
-      stg<NT>(st + (base | offm(2u * rb + 1u)), y1);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        A y;
+        y.x = yre[r][reg];
+        y.y = yim[r][reg];
+        stg<NT>(st + (base | offm(4u * rb + (uint32_t)reg)), y);
+      }
     }
     __syncthreads();  // every wave is done reading this item's X before the next item overwrites it
   }

@@ -896,14 +896,16 @@ static int launch_huge_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   std::vector<uint32_t> tau = p.opos;
   std::sort(tau.begin(), tau.end());
   std::vector<double> afrag;
-  build_afrag(p, tau, &afrag, std::is_same<T, float>::value);
-  // pairs of consecutive K-steps side by side, so a lane fetches both with one 16-byte (f32: 8-byte) load
-  const size_t S = (size_t)1 << k, TT = S / 8, KS = S / 2, KP = S / 4;
+  bool real_only = false;
+  build_afrag3(p, tau, &afrag, std::is_same<T, float>::value, &real_only);
+  // pairs of consecutive K-steps side by side, so a lane fetches both with one 16-byte (f32: 8-byte) load; the parts of one pair adjacent
+  const size_t S = (size_t)1 << k, RB = S / 16, KS3 = S / 4, KP = S / 8, NP = real_only ? 1 : 3;
   std::vector<T> a2(afrag.size());
-  for (size_t rb = 0; rb < TT; ++rb)
-    for (size_t pr = 0; pr < KP; ++pr)
-      for (size_t l = 0; l < 64; ++l)
-        for (size_t e = 0; e < 2; ++e) a2[((rb * KP + pr) * 64 + l) * 2 + e] = (T)afrag[(rb * KS + 2 * pr + e) * 64 + l];
+  for (size_t rb = 0; rb < RB; ++rb)
+    for (size_t sp = 0; sp < KP; ++sp)
+      for (size_t pt = 0; pt < NP; ++pt)
+        for (size_t l = 0; l < 64; ++l)
+          for (size_t e = 0; e < 2; ++e) a2[((((rb * KP + sp) * NP + pt) * 64 + l) * 2) + e] = (T)afrag[((rb * NP + pt) * KS3 + 2 * sp + e) * 64 + l];
   QCHK(ensure_arena(s, a2.size() * sizeof(T)));
   QCHK(arena_upload(s, a2.data(), a2.size() * sizeof(T), 0));
   if (!s->capture_pool) HIPCHK(hipStreamSynchronize(s->stream));  // (the staging vector dies with this frame; 8 - 32 MiB once per gate)
@@ -918,10 +920,15 @@ static int launch_huge_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   const unsigned blocks = (unsigned)std::min<uint64_t>(nitems, (uint64_t)s->num_cus);  // one 128-KiB block per CU
   const T* af = (const T*)s->arena;
   const bool nt = use_nt(s);
-#define HM(K, NPH)                                                                                                            \
-  do {                                                                                                                        \
-    if (nt) hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, true>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);  \
-    else hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, false>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);    \
+#define HM(K, NPH)                                                                                                                       \
+  do {                                                                                                                                   \
+    if (real_only) {                                                                                                                     \
+      if (nt) hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, true, 1>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);  \
+      else hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, false, 1>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);    \
+    } else {                                                                                                                             \
+      if (nt) hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, true, 3>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);  \
+      else hipLaunchKernelGGL((k_gate_huge_mfma<T, K, NPH, false, 3>), dim3(blocks), dim3(512), 0, s->stream, st, nitems, ins, d, af);    \
+    }                                                                                                                                    \
   } while (0)
   // (16 groups x 2^10 Complex<f64> amplitudes are 256 KiB: two phases of 128 KiB)
   if (k == 9) HM(9, 1);
