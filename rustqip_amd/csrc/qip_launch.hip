@@ -863,7 +863,8 @@ static int launch_big_mfma(qip_hip_state* s, const Plan& p, amp_t<T>* st) {
   memset(&d, 0, sizeof d);
   for (uint32_t b = 0; b < k; ++b) d.tau[b] = tau[b];
   const uint64_t nitems = 1ull << (s->n - (uint32_t)pos.size() - 4);  // waves' worth of 16 groups
-  const unsigned per_cu = k <= 7 ? 2u : 1u;  // resident blocks per CU (registers: 2 waves per SIMD up to k = 7; LDS: 128 KiB at k = 8 in f64)
+  // resident blocks per CU = the kernel's launch bound: two waves per SIMD, except Complex<f64> at k = 8 (X alone is 256 registers per lane)
+  const unsigned per_cu = (k <= 7 || std::is_same<T, float>::value) ? 2u : 1u;
   const unsigned blocks = (unsigned)std::min<uint64_t>((nitems + 3) / 4, 256ull * per_cu);
   const dim3 grid(blocks), block(kBlock);
   const T* af = (const T*)s->arena;
