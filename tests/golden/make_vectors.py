@@ -82,6 +82,8 @@ cases.append({"id": "B7.readme_cswap", "ref": "README.md:26-63", "check": "cswap
               "amplitudes": {"4": 0.5, "32": 0.5, "68": 0.5, "96": -0.5}, "tolerance": 1e-12})
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
-with open(out, "w") as f:
-    json.dump({"source": "Renmusxd/RustQIP (qip 1.5.0, qip-iterators): constants of its own tests, transcribed; see make_vectors.py", "cases": cases}, f, indent=1)
+with open(out, "w") as f:  # one case per line
+    f.write('{"source": "Renmusxd/RustQIP (qip 1.5.0, qip-iterators): constants of its own tests, transcribed; see make_vectors.py",\n "cases": [\n')
+    f.write(",\n".join("  " + json.dumps(c) for c in cases))
+    f.write("\n ]}\n")
 print(out, len(cases), "cases")
