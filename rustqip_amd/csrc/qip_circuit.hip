@@ -1581,7 +1581,8 @@ static int jit_obtain_code(const std::vector<std::pair<std::string, bool>>& jobs
   // 2. the rest: side by side in helper processes when there are several (and somewhere to put the results) ...
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t by_helpers = 0;
-  if (!todo.empty() && !dir.empty() && ((todo.size() >= 2 && procs > 1) || jit_foreign_hiprtc_loaded())) {
+  // (a process with a foreign libhiprtc sends single segments out too — unless "jit_procs" = 1 asks for this process only)
+  if (!todo.empty() && !dir.empty() && ((todo.size() >= 2 && procs > 1) || (g_jit_procs != 1 && jit_foreign_hiprtc_loaded()))) {
     helper = jit_helper_path();
     if (!helper.empty()) {
       jit_compile_in_helpers(helper, dir, procs, jobs, todo, paths);
