@@ -304,10 +304,11 @@ int qip_hip_jit_cache_info(uint64_t* resident, uint64_t* evicted, uint64_t* cap)
  *                        that reads amplitudes until init_basis / a full upload / copy_from overwrites them.
  *   "tile_fma"      [0]  1: compiled segments of "tile" = 2 may contract products into sums (1e-12 bar; ignored for "tile" = 1).
  *   "tile_merge"    [0]  1: compiled segments of "tile" = 2 apply a run of diagonal gates as products of their factors.
- *   "tile_auto"     [1]  who pays for compilation when "tile" >= 1 and "tile_jit" = 0 (n >= 22): a PROGRAM compiles its
- *                        segments (wide tiles) at creation; apply_ops uses compiled wide sweeps only when EVERY segment of
- *                        the plan is already resident or in the disk cache, otherwise the interpreter now and the missing
- *                        segments in background helper processes for the next call or process.  0: the state's options as set.
+ *   "tile_auto"     [1]  who pays for compilation when "tile" >= 1 and "tile_jit" = 0: a PROGRAM (n >= 22) compiles its
+ *                        segments (wide tiles) at creation; apply_ops (n >= 24: below, looking the plan up costs more host
+ *                        time than the compiled sweeps save) uses compiled wide sweeps only when EVERY segment of the plan
+ *                        is already resident or in the disk cache, otherwise the interpreter now and the missing segments
+ *                        in background helper processes for the next call or process.  0: the state's options as set.
  *   "pair_floor"    [1]  gate-by-gate apply_ops (n >= 22): a gate whose selectors sit inside a 1-KiB wave row (a sweep of the
  *                        whole vector for half / a quarter of the bytes) goes with its neighbour as ONE two-item tile sweep when
  *                        both fit a tile (IEEE-equal).  0: one launch per gate.

@@ -2213,6 +2213,10 @@ extern "C" int qip_hip_tile_bits(void) { return kTileBits; }
 // as a graph, is as fast: profiles/r01_small_n_launch_bound.md)
 int64_t g_debug_slice_sweeps = 0;  // global option "debug_slice_sweeps" (measuring aid, see apply_ops_tiled)
 constexpr int kAutoJitMinQubits = 22;
+// ... and from this size a one-shot apply_ops looks its wide plan up (r6).  The lookup plans twice and fingerprints every segment:
+// ~3.5 us of host time per gate, which at n = 22 makes the compiled path host-bound and SLOWER than the interpreter (2000 gates:
+// 7.4 against 6.2 ms); from n = 24 it wins (10.0 against 15.4 ms; n = 26: 36 against 57 ms).
+constexpr int kAutoOneShotMinQubits = 24;
 constexpr int kPairFloorMinQubits = 22;  // option "pair_floor": only where a sweep is HBM-bound (below, launches are)
 static bool tile_wide_of(const qip_hip_state* s) {  // wide tiles: run-time-compiled segments only, a state above one wide tile
   // (r5: also inside a graph capture — the launch and its parameter upload are ordinary stream work like the 11-bit segments')
@@ -2433,7 +2437,7 @@ extern "C" int qip_hip_state_apply_ops(qip_hip_state* s, const qip_op* ops, uint
     // or in the disk cache; otherwise the interpreter now, the misses compiled in the background for the next call.  Not for the
     // batches of a sharded state that carry a fold / slice request (their last sweep is chosen by the exchange), not while a
     // program records or pre-compiles (it compiles for itself).
-    if (s->tile_auto && !s->tile_jit && s->tile_passes && s->n >= (uint32_t)kAutoJitMinQubits && count >= 2 && !s->capture_pool && !s->jit_prepare &&
+    if (s->tile_auto && !s->tile_jit && s->tile_passes && s->n >= (uint32_t)kAutoOneShotMinQubits && count >= 2 && !s->capture_pool && !s->jit_prepare &&
         !s->fold_request && !s->slice_first && !s->slice_last && !s->profile && g_jit_disk) {
       const int64_t wide0 = s->tile_wide;
       s->tile_jit = 1;

@@ -292,9 +292,12 @@ int build_tile_segment(uint32_t n, bool passes, const std::vector<const TileItem
       }
     }
     // B: pass by pass, the three tile bits whose closure — every gate that becomes ready and exchanges only across them —
-    // is largest (gates that compute count 1, diagonal ones, which fit any pass, a little)
+    // is largest (gates that compute count 1, diagonal ones, which fit any pass, a little).  165 triples x a closure scan per
+    // pass: ~5 us of host time per gate (r6: measured 320 us per 55-gate segment), which a saved pass — one LDS round trip of
+    // the tile, 0.5 ms per sweep at n = 30, 8 us at n = 24, 0.5 us at n = 20 — repays only on large states: below 2^24
+    // amplitudes the run loop was host-bound by this search (2000 gates at n = 12: 12.4 ms, of which 11.6 here), so it is skipped.
     std::vector<size_t> order_b;
-    {
+    if (n >= 24u) {
       Set placed{0, 0, 0, 0};
       auto closure = [&](uint32_t tri, Set pl, std::vector<size_t>* emit) {
         double w = 0;

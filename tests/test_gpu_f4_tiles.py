@@ -1037,7 +1037,7 @@ def test_one_shot_apply_ops_takes_compiled_sweeps_only_when_they_are_free(O, tmp
 
     from rustqip_amd import _ffi
 
-    n = 22
+    n = 24  # (the smallest state whose one-shot apply_ops looks its plan up: below, the lookup costs more than the sweeps save)
     ops = circuits.h_layer(n) + circuits.c2_random_circuit(n, 96, seed=41)
     x = circuits.random_state(n, seed=4)
     assert _ffi.lib.qip_hip_jit_set_cache_dir(str(tmp_path / "cache").encode()) == 0
