@@ -444,9 +444,8 @@ def run_extras(q, circuits, st, n, args, ops, ops_mixed, par, em, budget, res):
         return par.leg(name, cops, exact, seed=seed, max_len=max_len, **options)
 
     def jit_stats():
-        k, ms = _C.c_uint64(), _C.c_double()
-        _F.lib.qip_hip_jit_stats(_C.byref(k), _C.byref(ms))
-        return int(k.value), ms.value
+        c = _F.jit_counters()  # (cache misses of this process: compiled here, by a helper, or found on disk)
+        return int(c["kernels_resident_total"]), c["compile_ms"] + c["disk_load_ms"]
 
     def timed_mode(dst, key, cops, label_ops, exact, seed, chunk, max_len=64, **options):
         """check `chunk` (a slice of the circuit at the timed size) through the mode, then time the whole circuit in it"""

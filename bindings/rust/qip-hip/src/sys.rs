@@ -1,10 +1,14 @@
-//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 7: 66 entry points; `tests/test_host_ops.py` compares the two sets).
+//! Raw bindings: one declaration per entry point of `include/qip_hip.h` (ABI version 8: 66 entry points; `tests/test_host_ops.py` compares the two sets).
 //! The host-only test hooks of `include/qip_hip_debug.h` are not part of the binding contract and are not mirrored here.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
 pub const QIP_C64: c_int = 0; // Complex<f64>
 pub const QIP_C32: c_int = 1; // Complex<f32>
+pub const QIP_F64: c_int = 2; // f64  (real / integer P: slice-level calls only)
+pub const QIP_F32: c_int = 3; // f32
+pub const QIP_I64: c_int = 4; // i64 (wrapping)
+pub const QIP_I32: c_int = 5; // i32 (wrapping)
 
 pub const QIP_OP_MATRIX: i32 = 0;
 pub const QIP_OP_SPARSE: i32 = 1;
@@ -57,6 +61,13 @@ extern "C" {
     pub fn qip_hip_apply_op_host(
         dtype: c_int, n: u32, op: *const qip_op,
         input: *const c_void, in_len: u64, output: *mut c_void, out_len: u64,
+        in_off: u64, out_off: u64, accumulate: c_int,
+    ) -> c_int;
+
+    /// The same on device slices, for any `P` of `qip_dtype` (matrix_ops.rs:98-107 is generic over `P`).
+    pub fn qip_hip_apply_op_device(
+        dtype: c_int, device: c_int, stream: *mut c_void, n: u32, op: *const qip_op,
+        d_in: *const c_void, in_len: u64, d_out: *mut c_void, out_len: u64,
         in_off: u64, out_off: u64, accumulate: c_int,
     ) -> c_int;
 
@@ -136,7 +147,6 @@ extern "C" {
     ) -> c_int;
 
     pub fn qip_hip_tile_bits() -> c_int;
-    pub fn qip_hip_jit_stats(kernels_compiled: *mut u64, compile_ms: *mut c_double) -> c_int;
     pub fn qip_hip_jit_cache_info(resident: *mut u64, evicted: *mut u64, cap: *mut u64) -> c_int;
     /// (ABI 6) where run-time-compiled segments come from: disk cache, helper processes, this process.
     pub fn qip_hip_jit_stats2(out: *mut qip_hip_jit_counters) -> c_int;

@@ -35,7 +35,13 @@ extern "C" {
 typedef struct { double re, im; } qip_c64; /* Complex<f64>  (qip/src/types.rs:6-13) */
 typedef struct { float re, im; } qip_c32;  /* Complex<f32> */
 
-enum qip_dtype { QIP_C64 = 0, QIP_C32 = 1 };
+/* Element type `P` of a call.  A device-resident STATE is always complex (QIP_C64 / QIP_C32: the `qip` crate's states are
+ * Complex<P>, qip/src/types.rs:6-13).  The real and integer types are the other instances of the generic `P` of
+ * qip-iterators' kernel (matrix_ops.rs:98-107 `apply_op<P>`: its own tests run it on i32, matrix_ops.rs:271-374, its benches
+ * on f64, qip-iterators/benches/matmul_bench.rs:19-33,163-177): they are accepted by the slice-level calls
+ * qip_hip_apply_op_host, qip_hip_apply_op_row_host and qip_hip_apply_op_device, where op payloads (`dense`, `sparse_vals`)
+ * and both vectors hold plain `P` values.  Integer arithmetic wraps (two's complement), as Rust's does in release builds. */
+enum qip_dtype { QIP_C64 = 0, QIP_C32 = 1, QIP_F64 = 2, QIP_F32 = 3, QIP_I64 = 4, QIP_I32 = 5 };
 
 /* MatrixOp<P> variants (qip-iterators/src/iterators/ops.rs:11-20). */
 enum qip_op_kind {
@@ -51,7 +57,7 @@ enum qip_op_kind {
  *                indices first, then the inner op's indices (ops.rs:19,84-91).
  *                SWAP: the A half then the B half (ops.rs:66-79).
  *   dense        MATRIX only: 4^k entries, row-major, element type chosen by the
- *                `dtype` argument of the call (qip_c64 or qip_c32).
+ *                `dtype` argument of the call (qip_c64, qip_c32, or plain P).
  *   sparse_*     SPARSE only: CSR flattening of Vec<Vec<(usize, P)>>; row r is
  *                entries [rowptr[r], rowptr[r+1]); stored order is preserved and
  *                nothing is filtered (qubit_iterators.rs:87-101).
@@ -146,8 +152,19 @@ int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op,
                           void* out, uint64_t out_len,
                           uint64_t in_off, uint64_t out_off, int accumulate);
 
+/* The same two functions on DEVICE slices, for any `P` of enum qip_dtype: `d_in` / `d_out` are device pointers to in_len /
+ * out_len elements (not aliasing), `stream` a hipStream_t (NULL: the null stream) on `device`.  Every output row is the
+ * reference's literal fold (one lane per row, columns in iterator order), so the result is bit-equal to the reference's for
+ * every op kind, window and `P`.  A dense op on k <= 4 qubits (with or without controls) and Swap travel in the kernel
+ * arguments: the call only launches and returns without synchronising; larger dense tables and SparseMatrix rows are
+ * uploaded per call and the call synchronises `stream` before it returns.  A complex amplitude vector that takes many ops
+ * belongs in a state (qip_hip_state_wrap adopts device memory): that is where the specialised kernels are. */
+int qip_hip_apply_op_device(int dtype, int device, void* stream, uint32_t n, const qip_op* op,
+                            const void* d_in, uint64_t in_len, void* d_out, uint64_t out_len,
+                            uint64_t in_off, uint64_t out_off, int accumulate);
+
 /* apply_op_row (matrix_ops.rs:38-59): the single value (op . input)[output_offset + outputrow], same window rules.
- * `out_value` points at one qip_c64 / qip_c32.  Host pointers; for parity tests. */
+ * `out_value` points at one element of `dtype`.  Host pointers; for parity tests. */
 int qip_hip_apply_op_row_host(int dtype, uint32_t n, const qip_op* op, const void* in, uint64_t in_len,
                               uint64_t outputrow, uint64_t in_off, uint64_t out_off, void* out_value);
 
@@ -234,11 +251,7 @@ int qip_hip_plan_tiles(int dtype, uint32_t n, const qip_op* ops, uint64_t count,
 /* Number of index bits of a tile of the LDS-resident multi-gate sweeps (low 6 bits + the free positions). */
 int qip_hip_tile_bits(void);
 
-/* Segment-specialised tile sweeps (option "tile_jit"): how many segment kernels this process has compiled with hiprtc
- * so far and the time that took (cache misses only; a segment met again costs nothing). */
-int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
-
-/* r5 (ABI 6): where those kernels come from.  A segment that is not resident in this process is looked up on disk first
+/* Segment-specialised tile sweeps (option "tile_jit"): where the segment kernels of this process come from.  A segment that is not resident in this process is looked up on disk first
  * ($QIP_HIP_CACHE_DIR, default $XDG_CACHE_HOME/qip_hip or ~/.cache/qip_hip; "off" / "" disables; global option "jit_disk_cache"
  * 0 / 1): code objects are stored under a 128-bit hash of the compiler + flags + the embedded kernel header + the source
  * text, so a second process LOADS (~1 ms per segment) instead of compiling (~0.45 s per 11-bit segment, ~1.3 s per wide one).
@@ -250,7 +263,7 @@ int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms);
  * hiprtc serialises the compilations of one process, separate processes scale.  The helper is `qip_jitc` next to the library
  * ($QIP_HIP_JITC overrides; absent = compile in process).  Results are bit-identical whichever way a kernel arrived. */
 typedef struct qip_hip_jit_counters {
-  uint64_t kernels_resident_total; /* kernels made resident in this process so far (= qip_hip_jit_stats' count)    */
+  uint64_t kernels_resident_total; /* kernels made resident in this process so far (cache misses only: a segment met again costs nothing) */
   uint64_t compiled;               /* hiprtc compilations on behalf of this process (here + in helpers)             */
   uint64_t compiled_by_helpers;    /* ... of which in helper processes                                               */
   uint64_t helper_processes;       /* helper processes spawned so far                                                */

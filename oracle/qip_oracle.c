@@ -123,6 +123,29 @@ uint64_t qip_oracle_sub_to_full(uint32_t n, const uint64_t* mat_indices, uint32_
 #undef FN
 #undef SQRT
 
+/* ---- real / integer P (the generic `P` of qip-iterators' apply_op) --------- */
+
+#define RT double
+#define FN(x) x##_f64
+#include "qip_oracle_real_impl.h"
+#undef RT
+#undef FN
+#define RT float
+#define FN(x) x##_f32
+#include "qip_oracle_real_impl.h"
+#undef RT
+#undef FN
+#define RT uint64_t
+#define FN(x) x##_i64
+#include "qip_oracle_real_impl.h"
+#undef RT
+#undef FN
+#define RT uint32_t
+#define FN(x) x##_i32
+#include "qip_oracle_real_impl.h"
+#undef RT
+#undef FN
+
 int qip_oracle_max_threads(void) { return omp_get_max_threads(); }
 /* the CPU-baseline leg times the same loop with 1 thread and with all of them (bench.py) */
 void qip_oracle_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }

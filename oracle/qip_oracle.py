@@ -26,7 +26,7 @@ _LIB = os.path.join(_HERE, "libqip_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("qip_oracle.c", "qip_oracle_impl.h")]
+    src = [os.path.join(_HERE, f) for f in ("qip_oracle.c", "qip_oracle_impl.h", "qip_oracle_real_impl.h")]
     src.append(os.path.join(_HERE, "..", "include", "qip_hip.h"))
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
         subprocess.run(["make", "-C", _HERE, "-B", "libqip_oracle.so"], check=True, stdout=subprocess.DEVNULL)
@@ -77,6 +77,16 @@ for suf, cplx, real in (("c64", _C64, C.c_double), ("c32", _C32, C.c_float)):
     f.argtypes = [C.c_uint32, _u64p, C.c_uint32, C.c_uint64, real, C.c_void_p, C.c_uint64, C.c_void_p,
                   C.c_uint64, C.c_uint64, C.c_uint64]
 
+# real / integer P (qip_oracle_real_impl.h): apply_op / apply_op_overwrite / apply_op_row only
+for suf, elem in (("f64", C.c_double), ("f32", C.c_float), ("i64", C.c_int64), ("i32", C.c_int32)):
+    f = getattr(_lib, f"qip_oracle_apply_op_{suf}")
+    f.restype = None
+    f.argtypes = [C.c_uint32, _opp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                  C.c_int, C.c_int]
+    f = getattr(_lib, f"qip_oracle_apply_op_row_{suf}")
+    f.restype = elem
+    f.argtypes = [C.c_uint32, _opp, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+
 for name, res, args in (
     ("qip_oracle_get_flat_index", C.c_uint64, [C.c_uint32, C.c_uint64, C.c_uint64]),
     ("qip_oracle_flip_bits", C.c_uint64, [C.c_uint32, C.c_uint64]),
@@ -97,16 +107,20 @@ def _u64(values: Sequence[int]):
     return (C.c_uint64 * len(values))(*[int(v) for v in values])
 
 
+_ELEM = {np.dtype(np.complex128): ("c64", _pffi.QIP_C64), np.dtype(np.complex64): ("c32", _pffi.QIP_C32),
+         np.dtype(np.float64): ("f64", _pffi.QIP_F64), np.dtype(np.float32): ("f32", _pffi.QIP_F32),
+         np.dtype(np.int64): ("i64", _pffi.QIP_I64), np.dtype(np.int32): ("i32", _pffi.QIP_I32)}
+
+
 def _suf(arr: np.ndarray) -> str:
-    if arr.dtype == np.complex128:
-        return "c64"
-    if arr.dtype == np.complex64:
-        return "c32"
-    raise TypeError(f"oracle supports complex128/complex64, got {arr.dtype}")
+    try:
+        return _ELEM[arr.dtype][0]
+    except KeyError:
+        raise TypeError(f"oracle supports complex128/64, float64/32, int64/32, got {arr.dtype}") from None
 
 
 def _dt(arr: np.ndarray) -> int:
-    return _pffi.QIP_C64 if arr.dtype == np.complex128 else _pffi.QIP_C32
+    return _ELEM[arr.dtype][1]
 
 
 # ---- bit utilities -------------------------------------------------------------------
@@ -143,12 +157,12 @@ def apply_op_overwrite(n, op, input, output, input_offset=0, output_offset=0, *,
 
 
 def apply_op_row(n: int, op: MatrixOp, input: np.ndarray, outputrow: int, input_offset: int = 0,
-                 output_offset: int = 0) -> complex:
-    """apply_op_row (matrix_ops.rs:38-59)"""
+                 output_offset: int = 0):
+    """apply_op_row (matrix_ops.rs:38-59): a complex for a complex vector, a float / int for a real / integer one"""
     cop = op.to_c(_dt(input))
     r = getattr(_lib, f"qip_oracle_apply_op_row_{_suf(input)}")(
         n, C.byref(cop), input.ctypes.data, input.size, outputrow, input_offset, output_offset)
-    return complex(r.re, r.im)
+    return complex(r.re, r.im) if np.iscomplexobj(input) else r
 
 
 def make_op_matrix(n: int, op: MatrixOp, dtype=np.complex128) -> np.ndarray:

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QIP_HIP_LIB") or os.path.join(_HERE, "lib", "libqip_hip.so")
 
 QIP_C64, QIP_C32 = 0, 1
+QIP_F64, QIP_F32, QIP_I64, QIP_I32 = 2, 3, 4, 5  # real / integer P of the slice-level calls (include/qip_hip.h, enum qip_dtype)
 QIP_OP_MATRIX, QIP_OP_SPARSE, QIP_OP_SWAP, QIP_OP_CONTROL = 0, 1, 2, 3
 QIP_OK, QIP_ERR_INVALID, QIP_ERR_DEVICE, QIP_ERR_NO_DEVICE, QIP_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "qip_hip_op_algorithmic_bytes": (_int, [_int, _u32, _opp, _dblp]),
     "qip_hip_apply_op_host": (_int, [_int, _u32, _opp, _vp, _u64, _vp, _u64, _u64, _u64, _int]),
     "qip_hip_apply_op_row_host": (_int, [_int, _u32, _opp, _vp, _u64, _u64, _u64, _u64, _vp]),
+    "qip_hip_apply_op_device": (_int, [_int, _int, _vp, _u32, _opp, _vp, _u64, _vp, _u64, _u64, _u64, _int]),
     "qip_hip_measure_probs_host": (_int, [_int, _u32, _u64p, _u32, _vp, _u64, _u64, _dblp]),
     "qip_hip_measure_prob_host": (_int, [_int, _u32, _u64, _u64p, _u32, _vp, _u64, _u64, _dblp]),
     "qip_hip_state_create": (_int, [_u32, _int, _int, C.POINTER(_statep)]),
@@ -108,7 +110,6 @@ SIGNATURES = {
     "qip_hip_plan_tiles": (_int, [_int, _u32, _opp, _u64, _int, C.POINTER(C.c_int64), _u64p]),
     "qip_hip_tile_bits": (_int, []),
     "qip_hip_jit_cache_info": (_int, [_u64p, _u64p, _u64p]),
-    "qip_hip_jit_stats": (_int, [_u64p, _dblp]),
     "qip_hip_jit_stats2": (_int, [C.POINTER(QipJitCounters)]),
     "qip_hip_jit_set_cache_dir": (_int, [_cp]),
     "qip_hip_jit_cache_dir": (_cp, []),

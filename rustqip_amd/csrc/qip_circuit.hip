@@ -719,13 +719,6 @@ static void jit_capture_scope(int delta) {
   g_jit_captures_in_progress += delta;
 }
 
-extern "C" int qip_hip_jit_stats(uint64_t* kernels_compiled, double* compile_ms) try {
-  std::lock_guard<std::mutex> lock(g_jit_mutex);
-  if (kernels_compiled) *kernels_compiled = g_jit_loaded;  // (cache misses of this process: compiled here, by a helper, or found on disk)
-  if (compile_ms) *compile_ms = g_jit_compile_ms + g_jit_load_ms;
-  return QIP_OK;
-} QIP_CATCH_ALL
-
 extern "C" int qip_hip_jit_stats2(qip_hip_jit_counters* out) try {
   if (!out) return fail(QIP_ERR_INVALID, "null output");
   std::lock_guard<std::mutex> lock(g_jit_mutex);

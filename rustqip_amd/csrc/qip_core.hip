@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 
 extern "C" const char* qip_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int qip_hip_abi_version(void) { return 7; }  // 7: programs own device-resident payloads and record out-of-place ops (one graph per buffer parity), jit counters + background_segments / disk_trimmed, option jit_disk_cap_mb, debug hooks in qip_hip_debug.h; 6: + jit_stats2 / jit_set_cache_dir / jit_cache_dir / jit_compile_file, options jit_disk_cache / jit_procs / tile_auto; 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
+extern "C" int qip_hip_abi_version(void) { return 8; }  // 8: + qip_hip_apply_op_device and the real / integer element types QIP_F64 / F32 / I64 / I32 of the slice-level calls, jit_stats folded into jit_stats2; 7: programs own device-resident payloads and record out-of-place ops (one graph per buffer parity), jit counters + background_segments / disk_trimmed, option jit_disk_cap_mb, debug hooks in qip_hip_debug.h; 6: + jit_stats2 / jit_set_cache_dir / jit_cache_dir / jit_compile_file, options jit_disk_cache / jit_procs / tile_auto; 5: + state_download_indices, copy_from completes before it returns; 4: + state_copy_from, state_max_abs_diff, dist stats v2 (rccl_ranks), options tile_fma / jit cache bound
 extern "C" int qip_hip_device_count(void) try {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) {

@@ -64,12 +64,343 @@ static int apply_op_host_t(int dtype, uint32_t n, const qip_op* op, const void* 
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------
+// apply_op / apply_op_overwrite on DEVICE slices for any P (qip_hip_apply_op_device)
+// ---------------------------------------------------------------------------------------
+// qip-iterators' kernel is generic over P (matrix_ops.rs:98-107): a real or integer vector takes the same row fold as a
+// complex one — acc = P::zero(); acc += val * input[col] over the iterator's columns (matrix_ops.rs:62-94, std::iter::Sum),
+// then `+=` or `=` into the output row (:110 / :139).  One lane per output row, the reference's loops verbatim (index maps
+// g_full_to_sub / g_sub_to_full of the complex literal kernel, the Control threshold of qubit_iterators.rs:130-169, the
+// zero-skip of MatrixOpIterator :49 only), products and sums unfused (the build has -ffp-contract=off): bit-equal to the
+// reference for every P.  Integers are computed in the unsigned type of their width (wrapping; the bits are two's complement).
+// Algorithmic bytes per output row: sizeof(P) x (1 read of the input + 1 write, + 1 read when accumulating).
+template <typename R> struct RealTab {  // a dense op on k <= 4 qubits inside the kernel arguments: no upload, no table to own
+  R v[256];
+};
+
+template <typename R>
+__device__ __forceinline__ R r_term(const GatherDesc& d, uint64_t row, uint64_t col, R val, const R* __restrict__ in) {
+  const uint64_t colbits = g_sub_to_full(d, col, row);  // matrix_ops.rs:79
+  if (colbits < d.in_off) return (R)0;                   // :80-81
+  const uint64_t vecrow = colbits - d.in_off;            // :83
+  if (vecrow >= d.in_len) return (R)0;                   // :84-85
+  return val * in[vecrow];                               // :87
+}
+
+template <typename R, bool TAB>
+__global__ __launch_bounds__(kBlock) void k_gather_real(const R* __restrict__ in, R* __restrict__ out, GatherDesc d,
+                                                        RealTab<R> tab, const R* __restrict__ dense,
+                                                        const uint64_t* __restrict__ rowptr, const uint64_t* __restrict__ cols,
+                                                        const R* __restrict__ vals) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < d.out_len; r += stride) {
+    const uint64_t row = d.out_off + r;
+    const uint64_t matrow = g_full_to_sub(d, row);
+    R acc = (R)0;
+    uint64_t shift = 0, irow = matrow;
+    bool identity_row = false;
+    if (d.n_control > 0) {
+      const uint64_t thr = (1ull << (d.n_control + d.n_op)) - (1ull << d.n_op);
+      if (matrow >= thr) {
+        shift = thr;
+        irow = matrow - thr;
+      } else {
+        identity_row = true;
+      }
+    }
+    if (identity_row) {
+      acc = acc + r_term<R>(d, row, matrow, (R)1, in);
+    } else if (d.inner_kind == 0) {  // MATRIX
+      const uint64_t side = 1ull << d.n_op;
+      for (uint64_t c = 0; c < side; ++c) {
+        const R v = TAB ? tab.v[irow * side + c] : dense[irow * side + c];
+        if (!(v == (R)0)) acc = acc + r_term<R>(d, row, c + shift, v, in);
+      }
+    } else if (d.inner_kind == 1) {  // SPARSE
+      for (uint64_t p = rowptr[irow]; p < rowptr[irow + 1]; ++p) acc = acc + r_term<R>(d, row, cols[p] + shift, vals[p], in);
+    } else {  // SWAP
+      const uint32_t half_n = d.n_op >> 1;
+      const uint64_t lower_mask = ~(~0ull << half_n);
+      const uint64_t col = ((irow & lower_mask) << half_n) + (irow >> half_n);
+      acc = acc + r_term<R>(d, row, col + shift, (R)1, in);
+    }
+    out[r] = d.accumulate ? (R)(out[r] + acc) : acc;
+  }
+}
+
+// ---- the whole vector (both windows [0, 2^n)), a dense op or Swap on distinct qubits with k_all <= 4 indices ------------------
+// One lane owns V = 16 / sizeof(P) consecutive rows of every one of the 2^K rows of a group (K = controls + op qubits; the V
+// rows differ only in index bits below every op / control position): it reads each of the group's 2^K input vectors ONCE
+// (16-byte accesses), folds every output row exactly as the literal kernel does — acc = 0; acc += m[row][c] * x[c] for c
+// ascending, entries equal to zero skipped (the matrix sits in the kernel arguments: the skip is a scalar branch); a row outside
+// the control subspace or of a Swap is 0 + 1 * x[col] — and writes 2^K output vectors.  Bit-equal to the literal kernel; HBM
+// traffic = the algorithmic bytes (the literal kernel reads every input line 2^k_op times, from different lanes).
+// An op with an index bit below log2(V) takes V = 1 (8- / 4-byte accesses).
+struct RealGroupDesc {
+  uint64_t nitems;      // 2^n / (2^K * V)
+  uint64_t off[16];     // off[m] = the index bits of sub-index m (bit K-1-j of m at position pos[j]), in units of V rows
+  int32_t accumulate;
+};
+
+template <typename R, int V> struct RVec { using type = R __attribute__((ext_vector_type(V))); };
+template <typename R> struct RVec<R, 1> { using type = R; };
+
+template <typename R, int V, int K, int NC, bool SWAP, bool NT>
+__global__ __launch_bounds__(kBlock) void k_real_groups(const R* __restrict__ in, R* __restrict__ out, Ins ins, RealGroupDesc d,
+                                                        RealTab<R> tab) {
+  using X = typename RVec<R, V>::type;
+  constexpr int M = 1 << K, KOP = K - NC, SIDE = 1 << KOP, THR = M - SIDE;
+  const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= d.nitems) return;
+  const uint64_t base = insert_bits<K>(w, ins);
+  const X* inv = reinterpret_cast<const X*>(in);
+  X* outv = reinterpret_cast<X*>(out);
+  X x[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = ldg<NT>(inv + (base | d.off[m]));
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    X acc = (X)(R)0;
+    if (m < THR) {  // outside the control subspace: exactly one (row, 1)  (qubit_iterators.rs:160-169)
+      acc = acc + (X)(R)1 * x[m];
+    } else if constexpr (SWAP) {
+      constexpr int HALF = KOP >> 1;
+      const int irow = m - THR;
+      const int col = ((irow & ((1 << HALF) - 1)) << HALF) + (irow >> HALF);
+      acc = acc + (X)(R)1 * x[col + THR];
+    } else {
+#pragma unroll
+      for (int c = 0; c < SIDE; ++c) {
+        const R v = tab.v[(m - THR) * SIDE + c];
+        if (!(v == (R)0)) acc = acc + (X)v * x[c + THR];
+      }
+    }
+    const uint64_t at = base | d.off[m];
+    stg<NT>(outv + at, d.accumulate ? (X)(ldg<NT>(outv + at) + acc) : acc);
+  }
+}
+
+template <typename R, int V, int K, bool NT>
+static int launch_real_groups_k(const FlatOp& f, const R* d_in, R* d_out, const Ins& ins, const RealGroupDesc& d, const RealTab<R>& tab,
+                                hipStream_t stream) {
+  const dim3 grid((unsigned)((d.nitems + kBlock - 1) / kBlock)), block(kBlock);
+  const bool swap = f.inner->kind == QIP_OP_SWAP;
+#define RG(NC, SW)                                                                                                       \
+  hipLaunchKernelGGL((k_real_groups<R, V, K, NC, SW, NT>), grid, block, 0, stream, d_in, d_out, ins, d, tab)
+  const int nc = (int)f.n_control;
+  if (swap) {
+    if constexpr (K == 2) { RG(0, true); }
+    else if constexpr (K == 3) { RG(1, true); }
+    else if constexpr (K == 4) { if (nc == 0) RG(0, true); else RG(2, true); }
+  } else {
+    if constexpr (K == 1) { RG(0, false); }
+    else if constexpr (K == 2) { if (nc == 0) RG(0, false); else RG(1, false); }
+    else if constexpr (K == 3) { if (nc == 0) RG(0, false); else if (nc == 1) RG(1, false); else RG(2, false); }
+    else { if (nc == 0) RG(0, false); else if (nc == 1) RG(1, false); else if (nc == 2) RG(2, false); else RG(3, false); }
+  }
+#undef RG
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
+// true (and launched) when the op qualifies; false: the literal kernel takes it
+template <typename R>
+static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_out, int accumulate, hipStream_t stream, bool* done) {
+  *done = false;
+  const uint32_t K = f.k_all;
+  if (!f.distinct || K > 4 || K >= n || g_force_generic) return QIP_OK;
+  if (f.inner->kind == QIP_OP_SPARSE) return QIP_OK;
+  if (f.inner->kind == QIP_OP_SWAP && (f.n_op & 1u)) return QIP_OK;
+  constexpr int VMAX = 16 / (int)sizeof(R);
+  constexpr uint32_t LOGV = sizeof(R) == 8 ? 1u : 2u;
+  std::vector<uint32_t> pos(K);
+  uint32_t lowest = 64;
+  for (uint32_t j = 0; j < K; ++j) {
+    pos[j] = (uint32_t)(n - 1 - f.outer->indices[j]);
+    lowest = std::min(lowest, pos[j]);
+  }
+  const bool vec = lowest >= LOGV && n >= K + LOGV && ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0);
+  const uint32_t lv = vec ? LOGV : 0u;
+  RealGroupDesc d;
+  memset(&d, 0, sizeof d);
+  d.nitems = 1ull << (n - K - lv);
+  d.accumulate = accumulate;
+  for (uint32_t m = 0; m < (1u << K); ++m)
+    for (uint32_t j = 0; j < K; ++j) d.off[m] |= (uint64_t)((m >> (K - 1 - j)) & 1u) << (pos[j] - lv);
+  std::vector<uint32_t> sorted(K);
+  for (uint32_t j = 0; j < K; ++j) sorted[j] = pos[j] - lv;
+  const Ins ins = make_ins(sorted, 0);
+  RealTab<R> tab;
+  memset(&tab, 0, sizeof tab);
+  if (f.inner->kind == QIP_OP_MATRIX) memcpy(tab.v, f.inner->dense, sizeof(R) << (2 * f.n_op));
+  *done = true;
+  // a vector far beyond the caches streams (non-temporal accesses, as the state kernels' sweeps do); V = 1 is the rare shape
+  const bool nt = vec && (sizeof(R) << n) >= (64ull << 20);
+#define RK(KK)                                                                                                   \
+  return !vec ? launch_real_groups_k<R, 1, KK, false>(f, d_in, d_out, ins, d, tab, stream)                       \
+         : nt ? launch_real_groups_k<R, VMAX, KK, true>(f, d_in, d_out, ins, d, tab, stream)                     \
+              : launch_real_groups_k<R, VMAX, KK, false>(f, d_in, d_out, ins, d, tab, stream)
+  switch (K) {
+    case 1: RK(1);
+    case 2: RK(2);
+    case 3: RK(3);
+    default: RK(4);
+  }
+#undef RK
+}
+
+template <typename R>
+static int apply_op_real_device(uint32_t n, const qip_op* op, const R* d_in, uint64_t in_len, R* d_out, uint64_t out_len,
+                                uint64_t in_off, uint64_t out_off, int accumulate, hipStream_t stream) {
+  FlatOp f;
+  QCHK(flatten_op(n, op, false, &f));
+  if (out_len == 0) return QIP_OK;
+  GatherDesc d;
+  memset(&d, 0, sizeof d);
+  d.n = n;
+  d.k_all = f.k_all;
+  d.n_control = f.n_control;
+  d.n_op = f.n_op;
+  d.inner_kind = f.inner->kind;
+  d.accumulate = accumulate;
+  d.in_len = in_len;
+  d.out_len = out_len;
+  d.in_off = in_off;
+  d.out_off = out_off;
+  for (uint32_t j = 0; j < f.k_all; ++j) d.pos[j] = (uint32_t)(n - 1 - f.outer->indices[j]);
+  if (in_off == 0 && out_off == 0 && in_len == (1ull << n) && out_len == in_len) {  // the whole vector: each input read once
+    bool done = false;
+    QCHK(launch_real_groups<R>(n, f, d_in, d_out, accumulate, stream, &done));
+    if (done) return QIP_OK;
+  }
+  const dim3 grid(grid_stride(out_len)), block(kBlock);
+  if (f.inner->kind == QIP_OP_SWAP || (f.inner->kind == QIP_OP_MATRIX && f.n_op <= 4)) {
+    RealTab<R> tab;
+    memset(&tab, 0, sizeof tab);
+    if (f.inner->kind == QIP_OP_MATRIX) memcpy(tab.v, f.inner->dense, sizeof(R) << (2 * f.n_op));
+    hipLaunchKernelGGL((k_gather_real<R, true>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)nullptr,
+                       (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const R*)nullptr);
+    HIPCHK(hipGetLastError());
+    return QIP_OK;
+  }
+  // a payload too large for the kernel arguments: one device buffer for this call
+  size_t b_dense = 0, b_rp = 0, b_cols = 0, b_vals = 0, o_cols = 0, o_vals = 0;
+  if (f.inner->kind == QIP_OP_MATRIX) {
+    b_dense = sizeof(R) << (2 * f.n_op);
+  } else {
+    const uint64_t rows = 1ull << f.n_op;
+    const uint64_t nnz = f.inner->sparse_rowptr[rows];
+    b_rp = (rows + 1) * 8;
+    b_cols = nnz * 8;
+    b_vals = nnz * sizeof(R);
+    o_cols = (b_rp + 15) & ~(size_t)15;
+    o_vals = (o_cols + b_cols + 15) & ~(size_t)15;
+  }
+  char* buf = nullptr;
+  HIPCHK(hipMalloc((void**)&buf, std::max<size_t>(b_dense + o_vals + b_vals, 16)));
+  auto body = [&]() -> int {
+    if (b_dense) HIPCHK(hipMemcpyAsync(buf, f.inner->dense, b_dense, hipMemcpyHostToDevice, stream));
+    if (b_rp) HIPCHK(hipMemcpyAsync(buf, f.inner->sparse_rowptr, b_rp, hipMemcpyHostToDevice, stream));
+    if (b_cols) HIPCHK(hipMemcpyAsync(buf + o_cols, f.inner->sparse_cols, b_cols, hipMemcpyHostToDevice, stream));
+    if (b_vals) HIPCHK(hipMemcpyAsync(buf + o_vals, f.inner->sparse_vals, b_vals, hipMemcpyHostToDevice, stream));
+    RealTab<R> tab;
+    memset(&tab, 0, sizeof tab);
+    hipLaunchKernelGGL((k_gather_real<R, false>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)buf, (const uint64_t*)buf,
+                       (const uint64_t*)(buf + o_cols), (const R*)(buf + o_vals));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    return QIP_OK;
+  };
+  const int rc = body();
+  if (rc != QIP_OK) (void)hipStreamSynchronize(stream);
+  (void)hipFree(buf);
+  return rc;
+}
+
+// complex P on device slices: the literal kernel of the state path (k_gather_generic) through a handle that adopts the caller's
+// stream and owns only the payload arena
+template <typename T>
+static int apply_op_complex_device(int dtype, int device, hipStream_t stream, uint32_t n, const qip_op* op, const void* d_in,
+                                   uint64_t in_len, void* d_out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
+                                   int accumulate) {
+  FlatOp f;
+  QCHK(flatten_op(n, op, false, &f));
+  if (out_len == 0) return QIP_OK;
+  qip_hip_state* s = nullptr;
+  QCHK(qip_hip_state_wrap(n, dtype, device, d_out, nullptr, (void*)stream, &s));
+  int rc = launch_gather<T>(s, f, (const amp_t<T>*)d_in, in_len, (amp_t<T>*)d_out, out_len, in_off, out_off, accumulate);
+  std::string keep = g_last_error;
+  qip_hip_state_destroy(s);  // (synchronises the stream: the payload arena dies with the handle)
+  if (rc != QIP_OK) g_last_error = keep;
+  return rc;
+}
+
+static size_t elem_bytes(int dtype) {
+  switch (dtype) {
+    case QIP_C64: return 16;
+    case QIP_C32: case QIP_F64: case QIP_I64: return 8;
+    case QIP_F32: case QIP_I32: return 4;
+    default: return 0;
+  }
+}
+
+extern "C" int qip_hip_apply_op_device(int dtype, int device, void* stream, uint32_t n, const qip_op* op, const void* d_in,
+                                       uint64_t in_len, void* d_out, uint64_t out_len, uint64_t in_off, uint64_t out_off,
+                                       int accumulate) try {
+  if (!elem_bytes(dtype)) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if ((in_len && !d_in) || (out_len && !d_out)) return fail(QIP_ERR_INVALID, "null buffer");
+  if (n == 0 || n > 40) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 40]", n);
+  if (qip_hip_device_count() <= device || device < 0)
+    return fail(QIP_ERR_NO_DEVICE, "no HIP device %d visible: qip_hip has no CPU fallback", device);
+  HIPCHK(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case QIP_C64: return apply_op_complex_device<double>(dtype, device, st, n, op, d_in, in_len, d_out, out_len, in_off, out_off, accumulate);
+    case QIP_C32: return apply_op_complex_device<float>(dtype, device, st, n, op, d_in, in_len, d_out, out_len, in_off, out_off, accumulate);
+    case QIP_F64: return apply_op_real_device<double>(n, op, (const double*)d_in, in_len, (double*)d_out, out_len, in_off, out_off, accumulate, st);
+    case QIP_F32: return apply_op_real_device<float>(n, op, (const float*)d_in, in_len, (float*)d_out, out_len, in_off, out_off, accumulate, st);
+    case QIP_I64: return apply_op_real_device<uint64_t>(n, op, (const uint64_t*)d_in, in_len, (uint64_t*)d_out, out_len, in_off, out_off, accumulate, st);
+    default: return apply_op_real_device<uint32_t>(n, op, (const uint32_t*)d_in, in_len, (uint32_t*)d_out, out_len, in_off, out_off, accumulate, st);
+  }
+} QIP_CATCH_ALL
+
+// host slices of a real / integer P: upload, the device call above, download
+static int apply_op_real_host(int dtype, uint32_t n, const qip_op* op, const void* in, uint64_t in_len, void* out,
+                              uint64_t out_len, uint64_t in_off, uint64_t out_off, int accumulate) {
+  FlatOp f;
+  QCHK(flatten_op(n, op, false, &f));  // (argument errors before any device work, as the complex twin reports them)
+  if (out_len == 0) return QIP_OK;
+  if (qip_hip_device_count() <= 0) return fail(QIP_ERR_NO_DEVICE, "no HIP device visible: qip_hip has no CPU fallback");
+  HIPCHK(hipSetDevice(0));
+  const size_t eb = elem_bytes(dtype);
+  void *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_in, std::max<size_t>(in_len * eb, 16)));
+  hipError_t e = hipMalloc(&d_out, out_len * eb);
+  if (e != hipSuccess) {
+    (void)hipFree(d_in);
+    return fail(QIP_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  auto body = [&]() -> int {
+    if (in_len) HIPCHK(hipMemcpy(d_in, in, in_len * eb, hipMemcpyHostToDevice));
+    if (accumulate) HIPCHK(hipMemcpy(d_out, out, out_len * eb, hipMemcpyHostToDevice));
+    QCHK(qip_hip_apply_op_device(dtype, 0, nullptr, n, op, d_in, in_len, d_out, out_len, in_off, out_off, accumulate));
+    HIPCHK(hipMemcpy(out, d_out, out_len * eb, hipMemcpyDeviceToHost));  // (null stream: ordered behind the kernel)
+    return QIP_OK;
+  };
+  const int rc = body();
+  (void)hipDeviceSynchronize();
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
 extern "C" int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op, const void* in,
                                      uint64_t in_len, void* out, uint64_t out_len, uint64_t in_off,
                                      uint64_t out_off, int accumulate) try {
-  if (dtype != QIP_C64 && dtype != QIP_C32) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
+  if (!elem_bytes(dtype)) return fail(QIP_ERR_INVALID, "bad dtype %d", dtype);
   if ((in_len && !in) || (out_len && !out)) return fail(QIP_ERR_INVALID, "null buffer");
   if (n == 0 || n > 40) return fail(QIP_ERR_INVALID, "n = %u out of range [1, 40]", n);
+  if (dtype != QIP_C64 && dtype != QIP_C32) return apply_op_real_host(dtype, n, op, in, in_len, out, out_len, in_off, out_off, accumulate);
   return dtype == QIP_C64
              ? apply_op_host_t<double>(dtype, n, op, in, in_len, out, out_len, in_off, out_off, accumulate)
              : apply_op_host_t<float>(dtype, n, op, in, in_len, out, out_len, in_off, out_off, accumulate);

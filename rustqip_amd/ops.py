@@ -30,8 +30,31 @@ class Representation(Enum):
     LittleEndian = 1
 
 
+_NP_OF_DTYPE = {_ffi.QIP_C64: np.complex128, _ffi.QIP_C32: np.complex64, _ffi.QIP_F64: np.float64, _ffi.QIP_F32: np.float32,
+                _ffi.QIP_I64: np.int64, _ffi.QIP_I32: np.int32}
+
+
 def complex_dtype(dtype: int):
     return np.complex128 if dtype == _ffi.QIP_C64 else np.complex64
+
+
+def element_dtype(dtype: int):
+    """numpy type of one element `P` of enum qip_dtype (complex for a state; real / integer for the slice-level calls)"""
+    return _NP_OF_DTYPE[dtype]
+
+
+def _payload(values, dtype: int) -> np.ndarray:
+    """op payload (Matrix data / SparseMatrix values) as `P`: a real or integer `P` takes no imaginary part and no fraction"""
+    et = element_dtype(dtype)
+    a = np.asarray(values)
+    if not np.issubdtype(et, np.complexfloating):
+        if np.iscomplexobj(a):
+            if np.any(a.imag != 0):
+                raise CircuitError("op payload has an imaginary part but the vectors are real")
+            a = a.real
+        if np.issubdtype(et, np.integer) and np.any(a != np.floor(a)):
+            raise CircuitError("op payload has a fractional part but the vectors are integers")
+    return np.ascontiguousarray(a, dtype=et)
 
 
 def flip_bits(n: int, num: int) -> int:
@@ -86,7 +109,6 @@ class MatrixOp:
     # ---- marshalling ------------------------------------------------------------
     def to_c(self, dtype: int = _ffi.QIP_C64) -> _ffi.QipOp:
         """Build the `struct qip_op` tree; the returned object keeps every buffer alive."""
-        cdt = complex_dtype(dtype)
         op = _ffi.QipOp()
         keep: list = []
         idx = np.ascontiguousarray(self.indices, dtype=np.uint64)
@@ -100,7 +122,7 @@ class MatrixOp:
                 raise CircuitError(
                     f"Matrix data has {0 if self.data is None else self.data.size} entries versus expected 2^2*{k}"
                 )
-            dat = np.ascontiguousarray(self.data, dtype=cdt)
+            dat = _payload(self.data, dtype)
             keep.append(dat)
             op.dense = dat.ctypes.data
         elif self.kind == "SparseMatrix":
@@ -119,7 +141,7 @@ class MatrixOp:
                     vals.append(v)
                 rowptr[r + 1] = len(cols)
             cols_a = np.ascontiguousarray(cols, dtype=np.uint64)
-            vals_a = np.ascontiguousarray(vals, dtype=cdt)
+            vals_a = _payload(vals, dtype)
             keep += [rowptr, cols_a, vals_a]
             op.sparse_rowptr = rowptr.ctypes.data_as(C.POINTER(C.c_uint64))
             op.sparse_cols = cols_a.ctypes.data_as(C.POINTER(C.c_uint64))

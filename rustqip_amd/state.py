@@ -47,11 +47,23 @@ def _dtype_of(arr: np.ndarray) -> int:
     raise CircuitError(f"unsupported amplitude dtype {arr.dtype}; use complex128 or complex64")
 
 
+_SLICE_DTYPES = {np.dtype(np.complex128): _ffi.QIP_C64, np.dtype(np.complex64): _ffi.QIP_C32, np.dtype(np.float64): _ffi.QIP_F64,
+                 np.dtype(np.float32): _ffi.QIP_F32, np.dtype(np.int64): _ffi.QIP_I64, np.dtype(np.int32): _ffi.QIP_I32}
+
+
+def _slice_dtype_of(arr) -> int:
+    """element type `P` of a slice-level call (apply_op<P> is generic, matrix_ops.rs:98-107): complex, real or integer"""
+    try:
+        return _SLICE_DTYPES[np.dtype(arr.dtype)]
+    except (KeyError, TypeError):
+        raise CircuitError(f"unsupported element dtype {arr.dtype}; use complex128/64, float64/32 or int64/32") from None
+
+
 def _apply_host(n, op, input, output, input_offset, output_offset, accumulate):
     if not (isinstance(input, np.ndarray) and isinstance(output, np.ndarray)):
         raise TypeError("input and output must be numpy arrays")
-    dtype = _dtype_of(output)
-    if _dtype_of(input) != dtype:
+    dtype = _slice_dtype_of(output)
+    if _slice_dtype_of(input) != dtype:
         raise CircuitError("input and output precision differ")
     if not (input.flags.c_contiguous and output.flags.c_contiguous and output.flags.writeable):
         raise CircuitError("input/output must be contiguous, output writeable")
@@ -79,14 +91,52 @@ def apply_op_overwrite(n: int, op: MatrixOp, input: np.ndarray, output: np.ndarr
 
 
 def apply_op_row(n: int, op: MatrixOp, input: np.ndarray, outputrow: int, input_offset: int = 0,
-                 output_offset: int = 0) -> complex:
-    """apply_op_row (matrix_ops.rs:38-59): the value of row output_offset + outputrow."""
-    dtype = _dtype_of(input)
+                 output_offset: int = 0):
+    """apply_op_row (matrix_ops.rs:38-59): the value of row output_offset + outputrow (a `P`: complex, float or int)."""
+    dtype = _slice_dtype_of(input)
     cop = op.to_c(dtype)
     out = np.zeros(1, dtype=input.dtype)
     _check(_ffi.lib.qip_hip_apply_op_row_host(dtype, n, C.byref(cop), input.ctypes.data, input.size, int(outputrow),
                                               int(input_offset), int(output_offset), out.ctypes.data))
-    return complex(out[0])
+    return out[0].item()
+
+
+class DeviceSlice:
+    """`&[P]` / `&mut [P]` in device memory: a raw pointer to `length` elements of numpy type `dtype` on GPU `device`
+    (from hipMalloc, a torch tensor's data_ptr(), HipState.as_slice(...))"""
+
+    def __init__(self, ptr: int, length: int, dtype, device: int = 0):
+        self.ptr, self.length, self.dtype, self.device = int(ptr), int(length), np.dtype(dtype), int(device)
+
+
+def _as_slice(t) -> DeviceSlice:
+    if isinstance(t, DeviceSlice):
+        return t
+    dt = _TORCH_DTYPES.get(str(t.dtype))  # a torch tensor (device memory and streams are torch's job; no torch types in the C ABI)
+    if dt is None or not (t.is_cuda and t.is_contiguous()):
+        raise CircuitError(f"unsupported element dtype {t.dtype}, or not a contiguous tensor on a GPU")
+    return DeviceSlice(t.data_ptr() if t.numel() else 0, t.numel(), dt, t.device.index or 0)
+
+
+_TORCH_DTYPES = {"torch.complex128": np.complex128, "torch.complex64": np.complex64, "torch.float64": np.float64,
+                 "torch.float32": np.float32, "torch.int64": np.int64, "torch.int32": np.int32}
+
+
+def apply_op_device(n: int, op: MatrixOp, input, output, input_offset: int = 0, output_offset: int = 0, *,
+                    accumulate: bool = True, stream: int = 0) -> None:
+    """apply_op (accumulate) / apply_op_overwrite on DEVICE slices for any `P` (qip_hip_apply_op_device): `input` / `output`
+    are DeviceSlice objects or contiguous 1-D torch tensors on one GPU, `stream` a raw hipStream_t (0 = null stream).  Nothing
+    is copied to the host; with a dense op on k <= 4 qubits or a Swap the call only launches."""
+    i, o = _as_slice(input), _as_slice(output)
+    if i.dtype != o.dtype or i.device != o.device:
+        raise CircuitError(f"input and output differ in element dtype or device ({i.dtype} on {i.device}, {o.dtype} on {o.device})")
+    dtype = _slice_dtype_of(o)
+    eb = o.dtype.itemsize
+    if i.length and o.length and i.ptr < o.ptr + o.length * eb and o.ptr < i.ptr + i.length * eb:
+        raise CircuitError("input and output must not alias (&[P] vs &mut [P])")
+    cop = op.to_c(dtype)
+    _check(_ffi.lib.qip_hip_apply_op_device(dtype, o.device, stream or None, n, C.byref(cop), i.ptr or None, i.length,
+                                            o.ptr or None, o.length, int(input_offset), int(output_offset), int(accumulate)))
 
 
 def measure_probs(n: int, indices: Sequence[int], input: np.ndarray, input_offset: int = 0) -> np.ndarray:
@@ -105,7 +155,7 @@ def measure_prob(n: int, measured: int, indices: Sequence[int], input: np.ndarra
     return out.value
 
 
-def make_op_matrix(n: int, op: MatrixOp, dtype=np.complex128) -> np.ndarray:
+def make_op_matrix(n: int, op: MatrixOp, dtype=np.complex128) -> np.ndarray:  # (any `P`: the reference's tests use i32)
     """Full 2^n x 2^n matrix of `op`, column by column through apply_op on basis vectors —
     the reference's test/debug helper (qip/src/state_ops/matrix_ops.rs:246-257,
     qip-iterators/src/matrix_ops.rs:229-255).  Returns M with M[r, c] = <r|op|c>."""
@@ -205,6 +255,16 @@ class HipState:
         p = C.c_void_p()
         _check(_ffi.lib.qip_hip_state_device_ptr(self._h, C.byref(p)))
         return int(p.value or 0)
+
+    def as_slice(self, dtype=None, offset: int = 0, length: Optional[int] = None) -> DeviceSlice:
+        """the amplitude buffer seen as elements of `dtype` (default: the state's own), [offset, offset + length) of them:
+        the device memory of a slice-level call (apply_op_device)"""
+        dt = np.dtype(dtype or self.np_dtype)
+        total = (len(self) * self.np_dtype.itemsize) // dt.itemsize
+        length = total - offset if length is None else length
+        if offset < 0 or length < 0 or offset + length > total:
+            raise CircuitError("slice outside the state's buffer")
+        return DeviceSlice(self.device_ptr() + offset * dt.itemsize, length, dt, self.device)
 
     def scratch_ptr(self) -> int:
         p = C.c_void_p()

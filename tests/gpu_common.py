@@ -181,8 +181,7 @@ def _jit_info():
 
     from rustqip_amd import _ffi
 
-    k, ms = C.c_uint64(), C.c_double()
-    assert _ffi.lib.qip_hip_jit_stats(C.byref(k), C.byref(ms)) == 0
+    k = C.c_uint64(_ffi.jit_counters()["kernels_resident_total"])
     res, ev, cap = C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert _ffi.lib.qip_hip_jit_cache_info(C.byref(res), C.byref(ev), C.byref(cap)) == 0
     return {"compiled": int(k.value), "resident": int(res.value), "evicted": int(ev.value), "cap": int(cap.value)}

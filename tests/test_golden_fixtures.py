@@ -15,6 +15,9 @@ FIXTURE = json.load(open(os.path.join(HERE, "golden", "reference_vectors.json"))
 CASES = FIXTURE["cases"]
 
 
+ELEMENT_TYPES = (np.complex128, np.int32, np.int64, np.float64, np.float32, np.complex64)
+
+
 def op_of(d):
     if d["kind"] == "matrix":
         return MatrixOp.new_matrix(d["indices"], d["data"])
@@ -34,8 +37,8 @@ class OracleBackend:
 
         self.O = O
 
-    def op_matrix(self, n, op):
-        return self.O.make_op_matrix(n, op)
+    def op_matrix(self, n, op, dtype=np.complex128):
+        return self.O.make_op_matrix(n, op, dtype=dtype)
 
     def apply_op(self, n, op, x):
         out = np.zeros_like(x)
@@ -69,8 +72,8 @@ class HipBackend:
 
         self.q = q
 
-    def op_matrix(self, n, op):
-        return self.q.make_op_matrix(n, op)
+    def op_matrix(self, n, op, dtype=np.complex128):
+        return self.q.make_op_matrix(n, op, dtype=dtype)  # (apply_op's host-pointer twin on basis vectors, whatever the element type)
 
     def apply_op(self, n, op, x):
         out = np.zeros_like(x)
@@ -107,12 +110,16 @@ def replay(case, B):
     n = case["n"]
     kind = case["check"]
     if kind in ("op_matrix", "op_matrix_differs"):
-        got = B.op_matrix(n, op_of(case["op"]))
-        want = np.array(case["matrix"], dtype=np.complex128)
-        assert np.array_equal(got, want) == (kind == "op_matrix"), case["id"]
+        # qip-iterators' own tests: the reference runs them with P = i32 (integer literals); apply_op is generic over P
+        # (matrix_ops.rs:98-107), so the same vectors are replayed in that type and in every other element type of the ABI
+        for dtype in ELEMENT_TYPES:
+            got = B.op_matrix(n, op_of(case["op"]), dtype)
+            want = np.array(case["matrix"], dtype=np.complex128).real.astype(dtype) if dtype != np.complex128 else np.array(case["matrix"], dtype=dtype)
+            assert got.dtype == dtype and np.array_equal(got, want) == (kind == "op_matrix"), (case["id"], dtype)
     elif kind == "row_columns":
-        m = B.op_matrix(n, op_of(case["op"]))
-        assert [list(np.nonzero(m[r])[0]) for r in range(1 << n)] == case["columns"] and np.all(m[m != 0] == 1), case["id"]
+        for dtype in ELEMENT_TYPES:
+            m = B.op_matrix(n, op_of(case["op"]), dtype)
+            assert [list(np.nonzero(m[r])[0]) for r in range(1 << n)] == case["columns"] and np.all(m[m != 0] == 1), (case["id"], dtype)
     elif kind == "apply_op":
         got = B.apply_op(n, op_of(case["op"]), np.array(case["input"], dtype=np.complex128))
         assert np.array_equal(got, np.array(case["output"], dtype=np.complex128)), case["id"]

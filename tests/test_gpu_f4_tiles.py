@@ -144,9 +144,8 @@ def test_tile_segments_compiled_at_run_time_are_bit_identical(O):
     from rustqip_amd import _ffi
 
     def jit_count():
-        k, ms = C.c_uint64(), C.c_double()
-        assert _ffi.lib.qip_hip_jit_stats(C.byref(k), C.byref(ms)) == 0
-        return int(k.value), ms.value
+        c = _ffi.jit_counters()
+        return int(c["kernels_resident_total"]), c["compile_ms"] + c["disk_load_ms"]
 
     rng = np.random.default_rng(77)
     for n, dtype in ((13, np.complex128), (16, np.complex128), (14, np.complex64)):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(names | debug):
         assert hasattr(_ffi.lib, name), f"libqip_hip.so does not export {name}"
     assert set(_ffi.SIGNATURES) == names and set(_ffi.DEBUG_SIGNATURES) == debug
-    assert _ffi.lib.qip_hip_abi_version() == 7
+    assert _ffi.lib.qip_hip_abi_version() == 8
     # nothing else is exported, and the test hooks sit under their own version-script node
     out = subprocess.run(["nm", "-D", "--defined-only", "--with-symbol-versions", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {}

@@ -259,3 +259,71 @@ def test_oracle_f32_matches_f64_loosely():
     O.apply_op(n, op, x.astype(np.complex128), o64)
     O.apply_op(n, op, x.astype(np.complex64), o32)
     assert np.allclose(o32, o64, atol=1e-5)
+
+
+# ---- generic P: a real / integer vector (matrix_ops.rs:98-107; the reference's own B1 / B2 tests run on i32) ----------------------
+REAL_TYPES = (np.float64, np.float32, np.int64, np.int32)
+
+
+def random_real_ops(n, rng, integer):
+    """one op of every kind (and their Controls) with real payloads; integer = small whole numbers (exact in every P)"""
+    def vals(count):
+        return rng.integers(-3, 4, size=count).astype(float) if integer else rng.standard_normal(count)
+
+    pick = lambda k: [int(v) for v in rng.permutation(n)[:k]]  # noqa: E731
+    ops = []
+    for k in (1, 2, 3, 5):
+        ops.append(MatrixOp.new_matrix(pick(k), vals(4**k)))
+    idx = pick(3)
+    ops.append(MatrixOp.new_sparse(idx, [[(int(c), float(v)) for c, v in zip(rng.integers(0, 8, size=2), vals(2))] for _ in range(8)]))
+    ab = pick(4)
+    ops.append(MatrixOp.new_swap(ab[:2], ab[2:]))
+    c = pick(4)
+    ops.append(MatrixOp.new_control(c[:2], c[2:], MatrixOp.new_matrix(c[2:], vals(16))))
+    c = pick(5)
+    ops.append(MatrixOp.new_control(c[:1], c[1:], MatrixOp.new_control(c[1:3], c[3:], MatrixOp.new_swap(c[3:4], c[4:]))))  # nested, uncollapsed
+    c = pick(4)
+    ops.append(MatrixOp.new_control(c[:1], c[1:], MatrixOp.new_sparse(c[1:], [[(int(j ^ 5), float(v))] for j, v in enumerate(vals(8))])))
+    return ops
+
+
+@pytest.mark.parametrize("dtype", REAL_TYPES)
+def test_real_p_equals_the_real_part_of_the_complex_fold(dtype):
+    """the complex oracle is pinned on the reference's vectors; with no imaginary part anywhere a complex fold IS the real fold
+    ((a + 0i)(b + 0i) = ab - 0, 0; sums componentwise), so the real restatement must agree bit for bit — windows, accumulate and
+    every op kind included"""
+    n = 7
+    rng = np.random.default_rng(5)
+    integer = np.issubdtype(dtype, np.integer)
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    for op in random_real_ops(n, rng, integer):
+        x = rng.integers(-4, 5, size=1 << n).astype(dtype) if integer else rng.standard_normal(1 << n).astype(dtype)
+        y0 = rng.integers(-4, 5, size=1 << n).astype(dtype) if integer else rng.standard_normal(1 << n).astype(dtype)
+        for (io, il, oo, ol) in ((0, 1 << n, 0, 1 << n), (16, 80, 8, 100), (0, 0, 3, 5), (100, 28, 0, 128)):
+            for acc in (True, False):
+                got = y0[:ol].copy()
+                O.apply_op(n, op, np.ascontiguousarray(x[io:io + il]), got, io, oo, accumulate=acc)
+                want = y0[:ol].astype(cdt)
+                O.apply_op(n, op, np.ascontiguousarray(x[io:io + il]).astype(cdt), want, io, oo, accumulate=acc)
+                assert np.all(want.imag == 0) and np.array_equal(got, want.real.astype(dtype)), (op, dtype, io, il, oo, ol, acc)
+                if ol and not acc:  # apply_op_row (matrix_ops.rs:38-59) = one row of apply_op_overwrite
+                    r = int(rng.integers(0, ol))
+                    assert O.apply_op_row(n, op, np.ascontiguousarray(x[io:io + il]), r, io, oo) == got[r]
+
+
+def test_integer_p_wraps():
+    """i32 arithmetic is two's complement (Rust release builds): 2^30 * 4 = 0, 2^31 - 1 + 1 = -2^31"""
+    x = np.array([1 << 30, (1 << 31) - 1], dtype=np.int32)
+    out = np.array([0, 1], dtype=np.int32)
+    O.apply_op(1, MatrixOp.new_matrix([0], [4, 0, 0, 1]), x, out)
+    assert list(out) == [0, -(1 << 31)]
+
+
+def test_real_payload_must_be_real():
+    from rustqip_amd import CircuitError
+
+    x = np.ones(2)
+    with pytest.raises(CircuitError, match="imaginary"):
+        O.apply_op(1, MatrixOp.new_matrix([0], [1j, 0, 0, 1]), x, np.zeros(2))
+    with pytest.raises(CircuitError, match="fractional"):
+        O.apply_op(1, MatrixOp.new_matrix([0], [0.5, 0, 0, 1]), x.astype(np.int64), np.zeros(2, dtype=np.int64))

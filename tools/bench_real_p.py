@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""apply_op<P> for a REAL P on device slices (qip_hip_apply_op_device): the reference's own f64 bench shapes
+(qip-iterators/benches/matmul_bench.rs:19-33 n = 12, :163-177 n = 20: a 2 x 2 matrix of ones on qubit 0, ones in, accumulate)
+and the same op at HBM sizes, against the CPU oracle on this box's cores.  Algorithmic bytes per row: sizeof(P) x (input read +
+output write, + output read when accumulating).  HIP events on the stream the kernel is launched on (torch's current = null stream)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustqip_amd as q  # noqa: E402
+from oracle import qip_oracle as O  # noqa: E402  (the CPU column only)
+from rustqip_amd.ops import MatrixOp  # noqa: E402
+
+
+def gpu_time(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def main():
+    threads = O.max_threads()
+    print(f"| n | P | op | accumulate | GPU us / call | algorithmic GB/s | of 8 TB/s | CPU oracle us / call ({threads} threads) | check |\n|---|---|---|---|---|---|---|---|---|")
+    ones = [1.0, 1.0, 1.0, 1.0]
+    shapes = [(12, np.float64, "ones on qubit 0 (matmul_bench.rs:19-33)", MatrixOp.new_matrix([0], ones), True),
+              (20, np.float64, "ones on qubit 0 (matmul_bench.rs:163-177)", MatrixOp.new_matrix([0], ones), True)]
+    rng = np.random.default_rng(3)
+    for n in (26, 28):
+        for dt in (np.float64, np.float32):
+            shapes += [(n, dt, "ones on qubit 0", MatrixOp.new_matrix([0], ones), True),
+                       (n, dt, "dense on qubit n-1", MatrixOp.new_matrix([n - 1], rng.standard_normal(4)), False),
+                       (n, dt, "dense on qubits 3, n-2", MatrixOp.new_matrix([3, n - 2], rng.standard_normal(16)), False),
+                       (n, dt, "CNOT(5 -> 20)", MatrixOp.new_control([5], [20], MatrixOp.new_matrix([20], [0, 1, 1, 0])), False),
+                       (n, dt, "Swap(1, n-1)", MatrixOp.new_swap([1], [n - 1]), False)]
+    for n, dt, name, op, acc in shapes:
+        N = 1 << n
+        x = np.ones(N, dtype=dt) if "ones" in name else rng.standard_normal(N).astype(dt)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros(N, dtype=d_in.dtype, device="cuda")
+        sec = gpu_time(lambda: q.apply_op_device(n, op, d_in, d_out, accumulate=acc), 200 if n <= 20 else 20)
+        by = np.dtype(dt).itemsize * N * (3 if acc else 2)
+        # check: one more call from a known output against the oracle (bit-equal)
+        d_out.zero_()
+        q.apply_op_device(n, op, d_in, d_out, accumulate=acc)
+        torch.cuda.synchronize()
+        want = np.zeros(N, dtype=dt)
+        O.apply_op(n, op, x, want, accumulate=acc)
+        ok = np.array_equal(d_out.cpu().numpy(), want)
+        reps = 20 if n <= 20 else 2
+        t = time.perf_counter()
+        for _ in range(reps):
+            O.apply_op(n, op, x, want, accumulate=acc)
+        cpu = (time.perf_counter() - t) / reps
+        print(f"| {n} | {np.dtype(dt).name} | {name} | {int(acc)} | {sec*1e6:.1f} | {by/sec/1e9:.0f} | {by/sec/8e12*100:.1f} % | {cpu*1e6:.0f} | {'bit-equal' if ok else 'DIFFERS'} |")
+        del d_in, d_out
+
+
+if __name__ == "__main__":
+    main()
