@@ -485,6 +485,43 @@ def run_extras(q, circuits, st, n, args, ops, ops_mixed, par, em, budget, res):
             from oracle.bench_parity import cpu_shape
         extras["reference_bench_shapes"] = reference_bench_shapes(q, circuits, cpu_shape)
 
+    def sec_generic_p():
+        # the kernel's generic element type (matrix_ops.rs:98-107): apply_op<P> for a REAL P on device slices — the reference's own
+        # f64 bench shapes (qip-iterators/benches/matmul_bench.rs:19-33 n = 12, :163-177 n = 20: a 2 x 2 matrix of ones on qubit 0,
+        # ones in, accumulate) and the same op at an HBM size; every row bit-equal to the oracle's real restatement or the leg fails
+        import torch
+
+        rows = []
+        ones = q.MatrixOp.new_matrix([0], [1.0, 1.0, 1.0, 1.0])
+        for n_, dt, reps in ((12, np.float64, 200), (20, np.float64, 200), (26, np.float64, 20), (26, np.float32, 20)):
+            x = np.ones(1 << n_, dtype=dt)
+            d_in = torch.from_numpy(x).cuda(st_device(st))
+            d_out = torch.zeros(1 << n_, dtype=d_in.dtype, device=d_in.device)
+            row = {"n": n_, "P": np.dtype(dt).name, "op": "Matrix([0], ones), accumulate", "ref": "matmul_bench.rs:%s" % ("19-33" if n_ == 12 else "163-177" if n_ == 20 else "- (HBM size)")}
+            if par is not None:
+                from oracle import qip_oracle as _O  # (the checker)
+                want = np.zeros(1 << n_, dtype=dt)
+                for _ in range(2):
+                    _O.apply_op(n_, ones, x, want)
+                    q.apply_op_device(n_, ones, d_in, d_out)
+                torch.cuda.synchronize()
+                row["bit_equal_to_oracle"] = par.record("generic_p__%s_n%d" % (row["P"], n_), d_out.cpu().numpy(), want, gates=2)
+            cop = ones.to_c(_F.QIP_F64 if dt == np.float64 else _F.QIP_F32)  # (the reference builds its op once, outside b.iter)
+            q.apply_op_device(n_, cop, d_in, d_out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # (the call launches on the null stream = torch's current stream here)
+            for _ in range(reps):
+                q.apply_op_device(n_, cop, d_in, d_out)
+            e1.record()
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / reps
+            by = np.dtype(dt).itemsize * 3 * (1 << n_)  # input read + output read + output write
+            row.update({"us_per_call": 1e6 * sec, "algorithmic_GBps": by / sec / 1e9, "frac_of_8TBps": by / sec / 1e9 / HBM_PEAK_GBPS})
+            rows.append(row)
+            del d_in, d_out
+        extras["generic_p_real_vectors"] = rows
+
     def sec_builder():
         # What a `calculate_state` caller gets — HipBuilder's run loop: ONE apply_ops batch on a fresh handle with tile = 1 and
         # tile_relabel = 1, no program object (qip/src/builder.rs:499 is the call being replaced).  Option tile_auto: the interpreter
@@ -611,6 +648,7 @@ def run_extras(q, circuits, st, n, args, ops, ops_mixed, par, em, budget, res):
     sections = [
         ("mixed", 6, sec_mixed),
         ("shapes", 12, sec_shapes),
+        ("generic_p", 6, sec_generic_p),
         ("builder", 25, sec_builder),
         ("tiled", 30, sec_tiled),
         # (QFT's controlled phases only TEST their bits: a chunk is closed over its H targets alone and holds what a timed segment holds;

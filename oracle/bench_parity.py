@@ -222,6 +222,14 @@ class Parity:
         self.legs["single_qubit_gate_by_gate"] = single
         self.leg("mixed_gate_by_gate", ops_mixed[:32], True, gate_by_gate=True, seed=12, bases=4)
 
+    def record(self, name, got, want, gates=1):
+        """a leg checked outside the state machinery (the slice-level calls on real vectors): every element of `got` against the
+        oracle's `want`, bar = bit equality"""
+        differ = int(np.count_nonzero(got != want))
+        self.legs[name] = {"ok": differ == 0, "bar": "IEEE-equal", "max_abs_delta": float(np.max(np.abs(got - want), initial=0.0)) if differ else 0.0,
+                           "gates": gates, "rows": int(got.size), "whole_vector_compares": 1, "whole_vector_amplitudes_not_equal": differ}
+        return differ == 0
+
     def reset_state(self):
         """back to the seeded product state advanced by the checked headline gates (the checked circuits entangled it): a
         non-uniform state, which is what gets timed"""

