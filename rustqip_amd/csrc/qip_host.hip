@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_real(const R* __restrict__ in
 // ascending, entries equal to zero skipped (the matrix sits in the kernel arguments: the skip is a scalar branch); a row outside
 // the control subspace or of a Swap is 0 + 1 * x[col] — and writes 2^K output vectors.  Bit-equal to the literal kernel; HBM
 // traffic = the algorithmic bytes (the literal kernel reads every input line 2^k_op times, from different lanes).
-// An op with an index bit below log2(V) takes V = 1 (8- / 4-byte accesses).
+// An op with an index bit below log2(V) takes V = 1 (8- / 4-byte accesses; a 4-byte P whose lowest index bit is position 1: V = 2).
 struct RealGroupDesc {
   uint64_t nitems;      // 2^n / (2^K * V)
   uint64_t off[16];     // off[m] = the index bits of sub-index m (bit K-1-j of m at position pos[j]), in units of V rows
@@ -219,8 +219,11 @@ static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_o
     pos[j] = (uint32_t)(n - 1 - f.outer->indices[j]);
     lowest = std::min(lowest, pos[j]);
   }
-  const bool vec = lowest >= LOGV && n >= K + LOGV && ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0);
-  const uint32_t lv = vec ? LOGV : 0u;
+  const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0);
+  const bool vec = lowest >= LOGV && n >= K + LOGV && aligned;
+  // a 4-byte P with its lowest index bit at position 1: pairs of rows (8-byte accesses) instead of single ones
+  const bool half = !vec && sizeof(R) == 4 && lowest == 1 && n >= K + 1 && aligned;
+  const uint32_t lv = vec ? LOGV : half ? 1u : 0u;
   RealGroupDesc d;
   memset(&d, 0, sizeof d);
   d.nitems = 1ull << (n - K - lv);
@@ -239,6 +242,8 @@ static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_o
   // n = 28, f64, a dense op on qubits 3 and n-2 — 16-byte runs — 785 us with cached accesses, 1448 us with non-temporal ones)
   const bool nt = vec && (sizeof(R) << n) >= (64ull << 20) && lowest - lv >= 3;
 #define RK(KK)                                                                                                   \
+  if constexpr (sizeof(R) == 4)                                                                                  \
+    if (half) return launch_real_groups_k<R, 2, KK, false>(f, d_in, d_out, ins, d, tab, stream);                 \
   return !vec ? launch_real_groups_k<R, 1, KK, false>(f, d_in, d_out, ins, d, tab, stream)                       \
          : nt ? launch_real_groups_k<R, VMAX, KK, true>(f, d_in, d_out, ins, d, tab, stream)                     \
               : launch_real_groups_k<R, VMAX, KK, false>(f, d_in, d_out, ins, d, tab, stream)

@@ -175,6 +175,19 @@ def test_no_gpu_fails_loudly():
     out = np.zeros(2, dtype=np.complex128)
     with pytest.raises(q.QipHipError, match="no CPU fallback"):
         q.apply_op(1, q.make_matrix_op([0], [0, 1, 1, 0]), inp, out)
+    # the real / integer element types of the slice-level calls: the same answer, for host and for device slices
+    for dt in (np.float64, np.float32, np.int64, np.int32):
+        with pytest.raises(q.QipHipError, match="no CPU fallback"):
+            q.apply_op(1, q.MatrixOp.new_matrix([0], [0, 1, 1, 0]), np.ones(2, dtype=dt), np.zeros(2, dtype=dt))
+        with pytest.raises(q.QipHipError, match="no CPU fallback"):
+            q.apply_op_device(1, q.MatrixOp.new_matrix([0], [0, 1, 1, 0]), q.DeviceSlice(4096, 2, dt), q.DeviceSlice(8192, 2, dt))
+    # ... and argument errors are reported before any device work (a state is Complex<P>; payloads of a real P are real)
+    with pytest.raises(q.CircuitError, match="out of range"):
+        q.apply_op(1, q.MatrixOp.new_matrix([3], [0, 1, 1, 0]), np.ones(2), np.zeros(2))
+    with pytest.raises(q.CircuitError, match="imaginary"):
+        q.apply_op(1, q.MatrixOp.new_matrix([0], [0, 1j, 1, 0]), np.ones(2), np.zeros(2))
+    with pytest.raises(q.CircuitError, match="unsupported"):
+        q.apply_op(1, q.MatrixOp.new_matrix([0], [0, 1, 1, 0]), np.ones(2, dtype=np.int16), np.zeros(2, dtype=np.int16))
 
 
 def test_product_never_imports_oracle():
