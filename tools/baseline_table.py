@@ -98,6 +98,17 @@ for name, r in ex.get("reference_bench_shapes", {}).items():
     L(f"| {name} | {r['n']} ({r['dtype']}) | {r.get('eager_us_per_op', float('nan')):.2f} | {r.get('hipgraph_program_us_per_op', float('nan')):.2f} ({r.get('hipgraph_program_is_graph')}) | "
       f"{r.get('tiled_program_us_per_op', float('nan')):.2f} | {r.get('one_shot_us_per_op', float('nan')):.1f} | {r.get('cpu_restatement_us_per_op', float('nan')):.1f} ({r.get('cpu_threads')}) | "
       f"{r.get('cpu_restatement_one_thread_us_per_op', float('nan')):.1f} |")
+gp = ex.get("generic_p_real_vectors")
+if gp:
+    L("")
+    L("`apply_op<P>` for a REAL `P` on device slices (`qip_hip_apply_op_device`; the reference's f64 bench shapes, `qip-iterators/benches/matmul_bench.rs`; op built once, "
+      "algorithmic bytes = `sizeof(P)` × 3 × 2^n for an accumulating call; more shapes: `profiles/" + tag + "_real_p.md`):")
+    L("")
+    L("| n | P | op | reference bench | µs per call | GB/s | % of 8 TB/s | vs the oracle (every row) |")
+    L("|---|---|---|---|---|---|---|---|")
+    for r in gp:
+        L(f"| {r['n']} | {r['P']} | {r['op']} | `{r['ref']}` | {r['us_per_call']:.1f} | {r['algorithmic_GBps']:.0f} | {100 * r['frac_of_8TBps']:.1f} | "
+          f"{'bit-equal' if r.get('bit_equal_to_oracle') else 'not checked' if 'bit_equal_to_oracle' not in r else 'DIFFERS'} |")
 ops = ops_rows(P(f"{tag}_ops_table.md"))
 if ops:
     L("")
