@@ -52,37 +52,38 @@ inline size_t flip_bits(size_t n, size_t num) {
   return out;
 }
 
-/// MatrixOp<P> (ops.rs:11-20).  P is the real precision; amplitudes are std::complex<P>, which is
-/// layout-compatible with qip_c64 / qip_c32 and with num_complex::Complex<P>.
-template <typename P> class MatrixOp {
+/// MatrixOp<E> of qip-iterators (ops.rs:11-20), E the ELEMENT type of the vectors it applies to: the reference's enum is
+/// generic (its kernel runs on i32 in its tests, on f64 in its benches).  std::complex<P> is layout-compatible with
+/// qip_c64 / qip_c32 and with num_complex::Complex<P>; a real / integer E is passed as is (enum qip_dtype).
+template <typename E> class BasicMatrixOp {
  public:
-  using C = std::complex<P>;
+  using C = E;
   using SparseRows = std::vector<std::vector<std::pair<size_t, C>>>;
   enum class Kind { Matrix, SparseMatrix, Swap, Control };
 
-  static MatrixOp new_matrix(std::vector<size_t> indices, std::vector<C> data) {
-    MatrixOp op(Kind::Matrix, std::move(indices));
+  static BasicMatrixOp new_matrix(std::vector<size_t> indices, std::vector<C> data) {
+    BasicMatrixOp op(Kind::Matrix, std::move(indices));
     op.data_ = std::move(data);
     return op;
   }
-  static MatrixOp new_sparse(std::vector<size_t> indices, SparseRows rows) {
-    MatrixOp op(Kind::SparseMatrix, std::move(indices));
+  static BasicMatrixOp new_sparse(std::vector<size_t> indices, SparseRows rows) {
+    BasicMatrixOp op(Kind::SparseMatrix, std::move(indices));
     op.rows_ = std::move(rows);
     return op;
   }
-  static MatrixOp new_swap(std::vector<size_t> a, const std::vector<size_t>& b) {
+  static BasicMatrixOp new_swap(std::vector<size_t> a, const std::vector<size_t>& b) {
     const size_t h = a.size();
     a.insert(a.end(), b.begin(), b.end());
-    MatrixOp op(Kind::Swap, std::move(a));
+    BasicMatrixOp op(Kind::Swap, std::move(a));
     op.half_ = h;
     return op;
   }
-  static MatrixOp new_control(std::vector<size_t> c, const std::vector<size_t>& r, MatrixOp inner) {
+  static BasicMatrixOp new_control(std::vector<size_t> c, const std::vector<size_t>& r, BasicMatrixOp inner) {
     const size_t nc = c.size();
     c.insert(c.end(), r.begin(), r.end());
-    MatrixOp op(Kind::Control, std::move(c));
+    BasicMatrixOp op(Kind::Control, std::move(c));
     op.n_controls_ = nc;
-    op.inner_ = std::make_shared<MatrixOp>(std::move(inner));
+    op.inner_ = std::make_shared<BasicMatrixOp>(std::move(inner));
     return op;
   }
 
@@ -92,11 +93,11 @@ template <typename P> class MatrixOp {
   size_t n_controls() const { return n_controls_; }
   const std::vector<C>& data() const { return data_; }
   const SparseRows& rows() const { return rows_; }
-  const MatrixOp* inner() const { return inner_.get(); }
-  std::shared_ptr<MatrixOp> inner_ptr() const { return inner_; }
+  const BasicMatrixOp* inner() const { return inner_.get(); }
+  std::shared_ptr<BasicMatrixOp> inner_ptr() const { return inner_; }
 
   /// The `struct qip_op` tree for the C ABI.  It owns every buffer it points into (including a copy
-  /// of the matrix data), so it stays valid after the MatrixOp it was made from is gone.
+  /// of the matrix data), so it stays valid after the BasicMatrixOp it was made from is gone.
   struct CView {
     qip_op op{};
     std::vector<uint64_t> idx, rowptr, cols;
@@ -149,14 +150,26 @@ template <typename P> class MatrixOp {
   }
 
  private:
-  MatrixOp(Kind k, std::vector<size_t> idx) : kind_(k), indices_(std::move(idx)) {}
+  BasicMatrixOp(Kind k, std::vector<size_t> idx) : kind_(k), indices_(std::move(idx)) {}
   Kind kind_;
   std::vector<size_t> indices_;
   std::vector<C> data_;
   SparseRows rows_;
   size_t half_ = 0, n_controls_ = 0;
-  std::shared_ptr<MatrixOp> inner_;
+  std::shared_ptr<BasicMatrixOp> inner_;
 };
+
+/// The `qip` crate's MatrixOp<Complex<P>> (what LocalBuilder lowers gates to): P is the real precision of the amplitudes.
+template <typename P> using MatrixOp = BasicMatrixOp<std::complex<P>>;
+
+/// enum qip_dtype of an element type
+template <typename E> struct element_dtype;
+template <> struct element_dtype<std::complex<double>> { static constexpr int value = QIP_C64; };
+template <> struct element_dtype<std::complex<float>> { static constexpr int value = QIP_C32; };
+template <> struct element_dtype<double> { static constexpr int value = QIP_F64; };
+template <> struct element_dtype<float> { static constexpr int value = QIP_F32; };
+template <> struct element_dtype<int64_t> { static constexpr int value = QIP_I64; };
+template <> struct element_dtype<int32_t> { static constexpr int value = QIP_I32; };
 
 /// get_index (matrix_ops.rs:33-35)
 template <typename P> size_t get_index(const MatrixOp<P>& op, size_t i) { return op.indices()[i]; }
@@ -231,6 +244,46 @@ void apply_op_overwrite(size_t n, const MatrixOp<P>& op, const std::vector<std::
   check(qip_hip_apply_op_host(dtype_of<P>::value, (uint32_t)n, &c->op, input.data(), input.size(), output.data(),
                               output.size(), input_offset, output_offset, 0));
 }
+
+// ---- qip_iterators::matrix_ops for ANY element type (matrix_ops.rs:38-59,98-152 are generic over P) ---------------------
+// `qip::iterators::apply_op(n, op, input, output, input_offset, output_offset)` is the reference's signature with
+// &[P] / &mut [P] as std::vector<E>: E = std::complex<double / float>, double, float, int64_t, int32_t.  Integer
+// arithmetic wraps.  Host vectors (the call uploads, runs the HIP kernels, downloads); `apply_op_device` takes device
+// pointers and a hipStream_t and copies nothing.
+namespace iterators {
+template <typename E>
+void apply_op(size_t n, const BasicMatrixOp<E>& op, const std::vector<E>& input, std::vector<E>& output, size_t input_offset,
+              size_t output_offset) {
+  auto c = op.to_c();
+  check(qip_hip_apply_op_host(element_dtype<E>::value, (uint32_t)n, &c->op, input.data(), input.size(), output.data(),
+                              output.size(), input_offset, output_offset, 1));
+}
+template <typename E>
+void apply_op_overwrite(size_t n, const BasicMatrixOp<E>& op, const std::vector<E>& input, std::vector<E>& output,
+                        size_t input_offset, size_t output_offset) {
+  auto c = op.to_c();
+  check(qip_hip_apply_op_host(element_dtype<E>::value, (uint32_t)n, &c->op, input.data(), input.size(), output.data(),
+                              output.size(), input_offset, output_offset, 0));
+}
+template <typename E>
+E apply_op_row(size_t n, const BasicMatrixOp<E>& op, const std::vector<E>& input, size_t outputrow, size_t input_offset,
+               size_t output_offset) {
+  auto c = op.to_c();
+  E value{};
+  check(qip_hip_apply_op_row_host(element_dtype<E>::value, (uint32_t)n, &c->op, input.data(), input.size(), outputrow,
+                                  input_offset, output_offset, &value));
+  return value;
+}
+/// device slices: d_in / d_out point at in_len / out_len elements on `device`; asynchronous on `stream` for a dense op on
+/// <= 4 qubits or a Swap (include/qip_hip.h: qip_hip_apply_op_device)
+template <typename E>
+void apply_op_device(size_t n, const BasicMatrixOp<E>& op, const E* d_in, size_t in_len, E* d_out, size_t out_len,
+                     size_t input_offset, size_t output_offset, bool accumulate = true, int device = 0, void* stream = nullptr) {
+  auto c = op.to_c();
+  check(qip_hip_apply_op_device(element_dtype<E>::value, device, stream, (uint32_t)n, &c->op, d_in, in_len, d_out, out_len,
+                                input_offset, output_offset, accumulate ? 1 : 0));
+}
+}  // namespace iterators
 
 // ---- outer seam: device-resident state ---------------------------------------------------------------
 template <typename P> class HipState {

@@ -4,6 +4,8 @@
 // Usage: test_host_mirror cpu   -> host-only checks (constructors, errors, marshalling, validator)
 //        test_host_mirror gpu   -> also runs the HIP path and compares with the CPU oracle (linked
 //                                  in as the checker: oracle/libqip_oracle.so)
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -13,6 +15,11 @@
 extern "C" void qip_oracle_apply_op_c64(uint32_t n, const qip_op* op, const qip_c64* input, uint64_t in_len,
                                         qip_c64* output, uint64_t out_len, uint64_t in_off, uint64_t out_off,
                                         int accumulate, int nthreads);
+
+extern "C" void qip_oracle_apply_op_f64(uint32_t n, const qip_op* op, const double* input, uint64_t in_len, double* output,
+                                        uint64_t out_len, uint64_t in_off, uint64_t out_off, int accumulate, int nthreads);
+extern "C" void qip_oracle_apply_op_i32(uint32_t n, const qip_op* op, const int32_t* input, uint64_t in_len, int32_t* output,
+                                        uint64_t out_len, uint64_t in_off, uint64_t out_off, int accumulate, int nthreads);
 
 using qip::CircuitError;
 using C = std::complex<double>;
@@ -41,6 +48,10 @@ static std::vector<C> from_reals(std::initializer_list<double> v) {
   for (double x : v) out.emplace_back(x, 0.0);
   return out;
 }
+
+static_assert(qip::element_dtype<std::complex<double>>::value == QIP_C64 && qip::element_dtype<double>::value == QIP_F64 &&
+              qip::element_dtype<float>::value == QIP_F32 && qip::element_dtype<int64_t>::value == QIP_I64 &&
+              qip::element_dtype<int32_t>::value == QIP_I32, "enum qip_dtype");
 
 static void host_checks() {
   // test_get_index_simple / _condition / _swap
@@ -84,7 +95,74 @@ static void host_checks() {
   EXPECT(b.pipeline().size() == 3 && b.pipeline()[1].indices[0] == 1);
 }
 
+// qip-iterators' own unit tests run apply_op on i32 (matrix_ops.rs:271-374), its benches on f64: the generic element type
+static void generic_element_checks() {
+  namespace it = qip::iterators;
+  using IOp = qip::BasicMatrixOp<int32_t>;
+  using ROp = qip::BasicMatrixOp<double>;
+  {
+    // test_counting (matrix_ops.rs:337-348): [1, 2, 3, 4] on qubit 0 of 3 = kron(mat, I4); make_op_matrix as the reference builds it
+    const size_t n = 3, N = 8;
+    const std::vector<int32_t> data{1, 2, 3, 4};
+    auto op = IOp::new_matrix({0}, data);
+    for (size_t i = 0; i < N; ++i) {
+      std::vector<int32_t> in(N, 0), out(N, 0);
+      in[i] = 1;
+      it::apply_op(n, op, in, out, 0, 0);
+      for (size_t r = 0; r < N; ++r) EXPECT(out[r] == ((r & 3) == (i & 3) ? data[(r >> 2) * 2 + (i >> 2)] : 0));
+    }
+    // test_counting_order / _flipped (:350-374)
+    std::vector<int32_t> d16(16);
+    for (int i = 0; i < 16; ++i) d16[i] = i;
+    bool same01 = true, same10 = true;
+    for (size_t i = 0; i < 4; ++i) {
+      std::vector<int32_t> in(4, 0), a(4, 0), b(4, 0);
+      in[i] = 1;
+      it::apply_op(2, IOp::new_matrix({0, 1}, d16), in, a, 0, 0);
+      it::apply_op(2, IOp::new_matrix({1, 0}, d16), in, b, 0, 0);
+      for (size_t r = 0; r < 4; ++r) {
+        same01 = same01 && a[r] == d16[r * 4 + i];
+        same10 = same10 && b[r] == d16[r * 4 + i];
+      }
+    }
+    EXPECT(same01 && !same10);
+  }
+  {
+    // random real ops against the oracle's real restatement: whole vector (group kernel), a window (literal kernel), a row
+    const size_t n = 10, N = size_t(1) << n;
+    std::mt19937_64 rng(9);
+    std::normal_distribution<double> g;
+    std::vector<double> x(N), m4(16), m2(4);
+    for (auto& v : x) v = g(rng);
+    for (auto& v : m4) v = g(rng);
+    for (auto& v : m2) v = g(rng);
+    std::vector<ROp> ops{ROp::new_matrix({7, 2}, m4), ROp::new_control({9}, {0}, ROp::new_matrix({0}, m2)), ROp::new_swap({1}, {8}),
+                         ROp::new_sparse({4}, {{{1, 2.5}, {0, -1.0}}, {{0, 0.5}}})};
+    for (const auto& op : ops) {
+      auto c = op.to_c();
+      std::vector<double> got(N, 0.25), want(N, 0.25);
+      it::apply_op(n, op, x, got, 0, 0);
+      qip_oracle_apply_op_f64((uint32_t)n, &c->op, x.data(), N, want.data(), N, 0, 0, 1, 1);
+      EXPECT(got == want);
+      std::vector<double> xin(x.begin() + 100, x.begin() + 700), gw(300), ww(300);
+      it::apply_op_overwrite(n, op, xin, gw, 100, 64);
+      qip_oracle_apply_op_f64((uint32_t)n, &c->op, xin.data(), xin.size(), ww.data(), ww.size(), 100, 64, 0, 1);
+      EXPECT(gw == ww);
+      EXPECT(it::apply_op_row(n, op, xin, 17, 100, 64) == ww[17]);
+    }
+    // i32 wraps (two's complement), as the oracle's restatement does
+    std::vector<int32_t> big{1 << 30, 2147483647}, out{0, 1}, want{0, 1};
+    auto w = qip::BasicMatrixOp<int32_t>::new_matrix({0}, {4, 0, 0, 1});
+    auto cw = w.to_c();
+    it::apply_op(1, w, big, out, 0, 0);
+    qip_oracle_apply_op_i32(1, &cw->op, big.data(), 2, want.data(), 2, 0, 0, 1, 1);
+    EXPECT(out == want && out[0] == 0 && out[1] == INT32_MIN);
+  }
+  std::printf("generic element types: i32 reference vectors, f64 vs the oracle (whole vector, window, row)\n");
+}
+
 static void gpu_checks() {
+  generic_element_checks();
   // test_apply_identity / test_apply_swap_mat / test_apply_swap_mat_first (matrix_ops.rs:306-344)
   {
     auto op = Op::new_matrix({0}, from_reals({1, 0, 0, 1}));
