@@ -53,6 +53,17 @@ def main():
         cop = op.to_c(_ffi.QIP_F64 if dt == np.float64 else _ffi.QIP_F32)  # (built once, as the reference's benches do)
         sec = gpu_time(lambda: q.apply_op_device(n, cop, d_in, d_out, accumulate=acc), 200 if n <= 20 else 20)
         by = np.dtype(dt).itemsize * N * (3 if acc else 2)
+        graph_us = None
+        if n <= 20:  # launch-bound sizes: 64 calls recorded into ONE hipGraph (the call is a plain kernel launch on the given stream)
+            side = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                q.apply_op_device(n, cop, d_in, d_out, accumulate=acc, stream=side.cuda_stream)
+                side.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(64):
+                        q.apply_op_device(n, cop, d_in, d_out, accumulate=acc, stream=side.cuda_stream)
+            graph_us = gpu_time(g.replay, 50) / 64 * 1e6
         # check: one more call from a known output against the oracle (bit-equal)
         d_out.zero_()
         q.apply_op_device(n, op, d_in, d_out, accumulate=acc)
@@ -69,7 +80,7 @@ def main():
                 O.apply_op(n, op, x, want, accumulate=acc, nthreads=nt)
             dt_cpu = (time.perf_counter() - t) / reps
             cpu = dt_cpu if cpu is None else min(cpu, dt_cpu)
-        print(f"| {n} | {np.dtype(dt).name} | {name} | {int(acc)} | {sec*1e6:.1f} | {by/sec/1e9:.0f} | {by/sec/8e12*100:.1f} % | {cpu*1e6:.0f} | {'bit-equal' if ok else 'DIFFERS'} |")
+        print(f"| {n} | {np.dtype(dt).name} | {name} | {int(acc)} | {sec*1e6:.1f} | {by/sec/1e9:.0f} | {by/sec/8e12*100:.1f} % | {cpu*1e6:.0f} | {'bit-equal' if ok else 'DIFFERS'}{'' if graph_us is None else '; %.2f us / call inside a 64-call hipGraph' % graph_us} |")
         del d_in, d_out
 
 
