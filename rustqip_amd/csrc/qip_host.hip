@@ -203,6 +203,113 @@ static int launch_real_groups_k(const FlatOp& f, const R* d_in, R* d_out, const 
   return QIP_OK;
 }
 
+// ---- ... with ONE index bit inside the 16-byte vector (positions 0 / 1: an op on the last qubits) -----------------------------
+// The vector then holds both values of that bit, so the group's partner rows along it sit in the SAME access: the lane reads
+// 2^(K-1) vectors instead of 2^K scalars and takes them apart in registers.  MODE 0: a vector of two = the bit at position 0
+// (8-byte P: 16 bytes; 4-byte P with positions 0 AND 1 in the op: 8 bytes).  4-byte P, 16-byte vectors of four: MODE 1 =
+// component bit 0 is the index bit at position 0 and component bit 1 a free index bit (two independent groups per lane),
+// MODE 2 = component bit 1 is the index bit at position 1, bit 0 free.  LB = which bit of the sub-index that position is.
+// Same folds, same order: bit-equal to k_real_groups / the literal kernel.  K <= 3 (wider ops with a low bit: V = 1 above).
+template <typename R, int K, int NC, bool SWAP, int LB, int MODE>
+__global__ __launch_bounds__(kBlock) void k_real_groups_low(const R* __restrict__ in, R* __restrict__ out, Ins ins, RealGroupDesc d,
+                                                            RealTab<R> tab) {
+  constexpr int VW = MODE == 0 ? 2 : 4, W = VW / 2;
+  using XV = typename RVec<R, VW>::type;
+  using F = typename RVec<R, W>::type;
+  constexpr int M = 1 << K, KOP = K - NC, SIDE = 1 << KOP, THR = M - SIDE, LOWBIT = 1 << LB;
+  const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= d.nitems) return;
+  const uint64_t base = insert_bits<K - 1>(w, ins);
+  const XV* inv = reinterpret_cast<const XV*>(in);
+  XV* outv = reinterpret_cast<XV*>(out);
+  F x[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (m & LOWBIT) continue;
+    const XV v = inv[base | d.off[m]];
+    if constexpr (MODE == 0) {
+      x[m] = v.x;
+      x[m | LOWBIT] = v.y;
+    } else if constexpr (MODE == 1) {
+      x[m] = F{v.x, v.z};
+      x[m | LOWBIT] = F{v.y, v.w};
+    } else {
+      x[m] = F{v.x, v.y};
+      x[m | LOWBIT] = F{v.z, v.w};
+    }
+  }
+  F o[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    F acc = (F)(R)0;
+    if (m < THR) {
+      acc = acc + (F)(R)1 * x[m];
+    } else if constexpr (SWAP) {
+      constexpr int HALF = KOP >> 1;
+      const int irow = m - THR;
+      const int col = ((irow & ((1 << HALF) - 1)) << HALF) + (irow >> HALF);
+      acc = acc + (F)(R)1 * x[col + THR];
+    } else {
+#pragma unroll
+      for (int c = 0; c < SIDE; ++c) {
+        const R v = tab.v[(m - THR) * SIDE + c];
+        if (!(v == (R)0)) acc = acc + (F)v * x[c + THR];
+      }
+    }
+    o[m] = acc;
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (m & LOWBIT) continue;
+    XV v;
+    if constexpr (MODE == 0) {
+      v = XV{o[m], o[m | LOWBIT]};
+    } else if constexpr (MODE == 1) {
+      v = XV{o[m].x, o[m | LOWBIT].x, o[m].y, o[m | LOWBIT].y};
+    } else {
+      v = XV{o[m].x, o[m].y, o[m | LOWBIT].x, o[m | LOWBIT].y};
+    }
+    const uint64_t at = base | d.off[m];
+    outv[at] = d.accumulate ? (XV)(outv[at] + v) : v;  // (non-temporal accesses measured here too: no gain, r06_real_p.md)
+  }
+}
+
+template <typename R, int K, int NC, bool SW, int MODE>
+static void launch_real_low_lb(int lb, dim3 grid, hipStream_t stream, const R* d_in, R* d_out, const Ins& ins, const RealGroupDesc& d,
+                               const RealTab<R>& tab) {
+#define RL(LBV) hipLaunchKernelGGL((k_real_groups_low<R, K, NC, SW, LBV, MODE>), grid, dim3(kBlock), 0, stream, d_in, d_out, ins, d, tab)
+  if (lb == 0) RL(0);
+  if constexpr (K >= 2) { if (lb == 1) RL(1); }
+  if constexpr (K >= 3) { if (lb == 2) RL(2); }
+#undef RL
+}
+
+template <typename R, int MODE>
+static int launch_real_low(const FlatOp& f, int lb, const R* d_in, R* d_out, const Ins& ins, const RealGroupDesc& d, const RealTab<R>& tab,
+                           hipStream_t stream) {
+  const dim3 grid((unsigned)((d.nitems + kBlock - 1) / kBlock));
+  const bool swap = f.inner->kind == QIP_OP_SWAP;
+  const int nc = (int)f.n_control;
+#define RLK(KK, NC, SW) launch_real_low_lb<R, KK, NC, SW, MODE>(lb, grid, stream, d_in, d_out, ins, d, tab)
+  switch (f.k_all) {
+    case 1: RLK(1, 0, false); break;
+    case 2:
+      if (swap) RLK(2, 0, true);
+      else if (nc == 0) RLK(2, 0, false);
+      else RLK(2, 1, false);
+      break;
+    default:
+      if (swap) RLK(3, 1, true);
+      else if (nc == 0) RLK(3, 0, false);
+      else if (nc == 1) RLK(3, 1, false);
+      else RLK(3, 2, false);
+      break;
+  }
+#undef RLK
+  HIPCHK(hipGetLastError());
+  return QIP_OK;
+}
+
 // true (and launched) when the op qualifies; false: the literal kernel takes it
 template <typename R>
 static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_out, int accumulate, hipStream_t stream, bool* done) {
@@ -221,6 +328,41 @@ static int launch_real_groups(uint32_t n, const FlatOp& f, const R* d_in, R* d_o
   }
   const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0);
   const bool vec = lowest >= LOGV && n >= K + LOGV && aligned;
+  if (!vec && aligned && K <= 3 && n >= K + 2) {  // one index bit inside the vector: k_real_groups_low
+    bool p0 = false, p1 = false;
+    for (uint32_t j = 0; j < K; ++j) {
+      p0 = p0 || pos[j] == 0;
+      p1 = p1 || pos[j] == 1;
+    }
+    const int mode = sizeof(R) == 8 ? (p0 ? 0 : -1) : (p0 && p1) ? 0 : p0 ? 1 : p1 ? 2 : -1;
+    if (mode >= 0) {
+      const uint32_t inpos = mode == 2 ? 1u : 0u, logvw = mode == 0 ? 1u : 2u;
+      uint32_t jl = 0;
+      for (uint32_t j = 0; j < K; ++j)
+        if (pos[j] == inpos) jl = j;
+      RealGroupDesc dl;
+      memset(&dl, 0, sizeof dl);
+      dl.nitems = 1ull << (n - (K - 1) - logvw);
+      dl.accumulate = accumulate;
+      std::vector<uint32_t> high;
+      for (uint32_t j = 0; j < K; ++j)
+        if (j != jl) high.push_back(pos[j] - logvw);
+      for (uint32_t m = 0; m < (1u << K); ++m)
+        for (uint32_t j = 0; j < K; ++j)
+          if (j != jl) dl.off[m] |= (uint64_t)((m >> (K - 1 - j)) & 1u) << (pos[j] - logvw);
+      const Ins insl = make_ins(high, 0);
+      RealTab<R> tabl;
+      memset(&tabl, 0, sizeof tabl);
+      if (f.inner->kind == QIP_OP_MATRIX) memcpy(tabl.v, f.inner->dense, sizeof(R) << (2 * f.n_op));
+      *done = true;
+      const int lb = (int)(K - 1 - jl);
+      if (mode == 0) return launch_real_low<R, 0>(f, lb, d_in, d_out, insl, dl, tabl, stream);
+      if constexpr (sizeof(R) == 4) {
+        if (mode == 1) return launch_real_low<R, 1>(f, lb, d_in, d_out, insl, dl, tabl, stream);
+        return launch_real_low<R, 2>(f, lb, d_in, d_out, insl, dl, tabl, stream);
+      }
+    }
+  }
   // a 4-byte P with its lowest index bit at position 1: pairs of rows (8-byte accesses) instead of single ones
   const bool half = !vec && sizeof(R) == 4 && lowest == 1 && n >= K + 1 && aligned;
   const uint32_t lv = vec ? LOGV : half ? 1u : 0u;

@@ -128,6 +128,12 @@ def test_whole_vector_group_kernel_every_shape(O, dtype):
                     sw = MatrixOp.new_swap(idx[nc:nc + h], idx[nc + h:])
                     shapes.append(sw if nc == 0 else MatrixOp.new_control(idx[:nc], idx[nc:], sw))
     shapes.append(MatrixOp.new_matrix([2, 5], [1, 0, 2, 0, 0, 0, 0, 3, 0, 0, 0, 0, -1, 0, 0, 0]))  # zero entries, a zero row
+    # both of the two lowest index bits in the op (a 4-byte P then keeps pairs), in either order, plain / controlled / swapped
+    for a_, b_ in ((n - 1, n - 2), (n - 2, n - 1)):
+        shapes += [MatrixOp.new_matrix([a_, b_], vals(16)), MatrixOp.new_swap([a_], [b_]), MatrixOp.new_matrix([a_, 1, b_], vals(64)),
+                   MatrixOp.new_control([a_], [b_], MatrixOp.new_matrix([b_], vals(4))),
+                   MatrixOp.new_control([2], [a_, b_], MatrixOp.new_swap([a_], [b_])),
+                   MatrixOp.new_control([a_, 3], [b_], MatrixOp.new_matrix([b_], vals(4)))]
     for op in shapes:
         x, y0 = vector(rng, N, dtype), vector(rng, N, dtype)
         if not integer:
