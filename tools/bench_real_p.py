@@ -28,7 +28,29 @@ def gpu_time(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def profile_workload():
+    """the fixed sequence rocprofv3 watches (tools/profile_real_p.sh): n = 28, three calls per shape, nothing else on the device"""
+    from rustqip_amd import _ffi
+
+    n = 28
+    rng = np.random.default_rng(3)
+    for dt in (np.float64, np.float32):
+        x = rng.standard_normal(1 << n).astype(dt)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros(1 << n, dtype=d_in.dtype, device="cuda")
+        for op, acc in ((MatrixOp.new_matrix([0], [1.0, 1.0, 1.0, 1.0]), True), (MatrixOp.new_matrix([n - 1], rng.standard_normal(4)), False),
+                        (MatrixOp.new_control([5], [20], MatrixOp.new_matrix([20], [0, 1, 1, 0])), False),
+                        (MatrixOp.new_matrix([2, 9, 17], rng.standard_normal(64)), False)):
+            cop = op.to_c(_ffi.QIP_F64 if dt == np.float64 else _ffi.QIP_F32)
+            for _ in range(3):
+                q.apply_op_device(n, cop, d_in, d_out, accumulate=acc)
+            torch.cuda.synchronize()
+        del d_in, d_out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--profile":
+        return profile_workload()
     from oracle.bench_parity import host_threads  # (OpenMP default, usable by affinity, cgroup quota, what the CPU legs use)
 
     threads = host_threads()[3]
