@@ -155,9 +155,11 @@ int qip_hip_apply_op_host(int dtype, uint32_t n, const qip_op* op,
 /* The same two functions on DEVICE slices, for any `P` of enum qip_dtype: `d_in` / `d_out` are device pointers to in_len /
  * out_len elements (not aliasing), `stream` a hipStream_t (NULL: the null stream) on `device`.  Every output row is the
  * reference's literal fold (one lane per row, columns in iterator order), so the result is bit-equal to the reference's for
- * every op kind, window and `P`.  A dense op on k <= 4 qubits (with or without controls) and Swap travel in the kernel
- * arguments: the call only launches and returns without synchronising; larger dense tables and SparseMatrix rows are
- * uploaded per call and the call synchronises `stream` before it returns.  A complex amplitude vector that takes many ops
+ * every op kind, window and `P`.  Real / integer `P`: a dense op on k <= 4 qubits (with or without controls) and Swap travel
+ * in the kernel arguments — the call only launches (it can be recorded into a hipGraph) and returns without synchronising;
+ * over the whole vector such an op on distinct qubits reads every input once (16-byte accesses); larger dense tables and
+ * SparseMatrix rows are uploaded per call and the call synchronises `stream` before it returns.  Complex `P`: the state
+ * path's literal kernel through a temporary handle, always synchronising — a complex amplitude vector that takes many ops
  * belongs in a state (qip_hip_state_wrap adopts device memory): that is where the specialised kernels are. */
 int qip_hip_apply_op_device(int dtype, int device, void* stream, uint32_t n, const qip_op* op,
                             const void* d_in, uint64_t in_len, void* d_out, uint64_t out_len,
