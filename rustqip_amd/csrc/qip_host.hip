@@ -78,25 +78,33 @@ template <typename R> struct RealTab {  // a dense op on k <= 4 qubits inside th
   R v[256];
 };
 
-template <typename R>
-__device__ __forceinline__ R r_term(const GatherDesc& d, uint64_t row, uint64_t col, R val, const R* __restrict__ in) {
+template <typename R, int V> struct RVec { using type = R __attribute__((ext_vector_type(V))); };
+template <typename R> struct RVec<R, 1> { using type = R; };
+
+// V > 1: the lane's V consecutive rows share every index bit the op looks at (no op / control position below log2 V, windows
+// and lengths multiples of V): one sub-index, one 16-byte access per term, a vector wholly inside or outside the input window
+template <typename R, int V>
+__device__ __forceinline__ typename RVec<R, V>::type r_term(const GatherDesc& d, uint64_t row, uint64_t col, R val, const R* __restrict__ in) {
+  using X = typename RVec<R, V>::type;
   const uint64_t colbits = g_sub_to_full(d, col, row);  // matrix_ops.rs:79
-  if (colbits < d.in_off) return (R)0;                   // :80-81
+  if (colbits < d.in_off) return (X)(R)0;                // :80-81
   const uint64_t vecrow = colbits - d.in_off;            // :83
-  if (vecrow >= d.in_len) return (R)0;                   // :84-85
-  return val * in[vecrow];                               // :87
+  if (vecrow >= d.in_len) return (X)(R)0;                // :84-85
+  return (X)val * reinterpret_cast<const X*>(in)[vecrow / V];  // :87
 }
 
-template <typename R, bool TAB>
-__global__ __launch_bounds__(kBlock) void k_gather_real(const R* __restrict__ in, R* __restrict__ out, GatherDesc d,
+template <typename R, bool TAB, int V>
+__global__ __launch_bounds__(kBlock) void k_gather_real(const R* __restrict__ in, R* __restrict__ out_, GatherDesc d,
                                                         RealTab<R> tab, const R* __restrict__ dense,
                                                         const uint64_t* __restrict__ rowptr, const uint64_t* __restrict__ cols,
                                                         const R* __restrict__ vals) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < d.out_len; r += stride) {
-    const uint64_t row = d.out_off + r;
+  using X = typename RVec<R, V>::type;
+  X* __restrict__ out = reinterpret_cast<X*>(out_);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock, nvec = d.out_len / V;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < nvec; r += stride) {
+    const uint64_t row = d.out_off + r * V;
     const uint64_t matrow = g_full_to_sub(d, row);
-    R acc = (R)0;
+    X acc = (X)(R)0;
     uint64_t shift = 0, irow = matrow;
     bool identity_row = false;
     if (d.n_control > 0) {
@@ -109,22 +117,22 @@ __global__ __launch_bounds__(kBlock) void k_gather_real(const R* __restrict__ in
       }
     }
     if (identity_row) {
-      acc = acc + r_term<R>(d, row, matrow, (R)1, in);
+      acc = acc + r_term<R, V>(d, row, matrow, (R)1, in);
     } else if (d.inner_kind == 0) {  // MATRIX
       const uint64_t side = 1ull << d.n_op;
       for (uint64_t c = 0; c < side; ++c) {
         const R v = TAB ? tab.v[irow * side + c] : dense[irow * side + c];
-        if (!(v == (R)0)) acc = acc + r_term<R>(d, row, c + shift, v, in);
+        if (!(v == (R)0)) acc = acc + r_term<R, V>(d, row, c + shift, v, in);
       }
     } else if (d.inner_kind == 1) {  // SPARSE
-      for (uint64_t p = rowptr[irow]; p < rowptr[irow + 1]; ++p) acc = acc + r_term<R>(d, row, cols[p] + shift, vals[p], in);
+      for (uint64_t p = rowptr[irow]; p < rowptr[irow + 1]; ++p) acc = acc + r_term<R, V>(d, row, cols[p] + shift, vals[p], in);
     } else {  // SWAP
       const uint32_t half_n = d.n_op >> 1;
       const uint64_t lower_mask = ~(~0ull << half_n);
       const uint64_t col = ((irow & lower_mask) << half_n) + (irow >> half_n);
-      acc = acc + r_term<R>(d, row, col + shift, (R)1, in);
+      acc = acc + r_term<R, V>(d, row, col + shift, (R)1, in);
     }
-    out[r] = d.accumulate ? (R)(out[r] + acc) : acc;
+    out[r] = d.accumulate ? (X)(out[r] + acc) : acc;
   }
 }
 
@@ -141,9 +149,6 @@ struct RealGroupDesc {
   uint64_t off[16];     // off[m] = the index bits of sub-index m (bit K-1-j of m at position pos[j]), in units of V rows
   int32_t accumulate;
 };
-
-template <typename R, int V> struct RVec { using type = R __attribute__((ext_vector_type(V))); };
-template <typename R> struct RVec<R, 1> { using type = R; };
 
 template <typename R, int V, int K, int NC, bool SWAP, bool NT>
 __global__ __launch_bounds__(kBlock) void k_real_groups(const R* __restrict__ in, R* __restrict__ out, Ins ins, RealGroupDesc d,
@@ -422,13 +427,22 @@ static int apply_op_real_device(uint32_t n, const qip_op* op, const R* d_in, uin
     QCHK(launch_real_groups<R>(n, f, d_in, d_out, accumulate, stream, &done));
     if (done) return QIP_OK;
   }
-  const dim3 grid(grid_stride(out_len)), block(kBlock);
+  // the literal kernel, V rows per lane when no index bit sits inside a 16-byte vector and both windows are made of whole vectors
+  constexpr int VMAX = 16 / (int)sizeof(R);
+  bool wide = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0) && in_off % VMAX == 0 && out_off % VMAX == 0 &&
+              in_len % VMAX == 0 && out_len % VMAX == 0;
+  for (uint32_t j = 0; j < f.k_all; ++j) wide = wide && d.pos[j] >= (sizeof(R) == 8 ? 1u : 2u);
+  const dim3 grid(grid_stride(wide ? out_len / VMAX : out_len)), block(kBlock);
   if (f.inner->kind == QIP_OP_SWAP || (f.inner->kind == QIP_OP_MATRIX && f.n_op <= 4)) {
     RealTab<R> tab;
     memset(&tab, 0, sizeof tab);
     if (f.inner->kind == QIP_OP_MATRIX) memcpy(tab.v, f.inner->dense, sizeof(R) << (2 * f.n_op));
-    hipLaunchKernelGGL((k_gather_real<R, true>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)nullptr,
-                       (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const R*)nullptr);
+    if (wide)
+      hipLaunchKernelGGL((k_gather_real<R, true, VMAX>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)nullptr,
+                         (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const R*)nullptr);
+    else
+      hipLaunchKernelGGL((k_gather_real<R, true, 1>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)nullptr,
+                         (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const R*)nullptr);
     HIPCHK(hipGetLastError());
     return QIP_OK;
   }
@@ -454,8 +468,12 @@ static int apply_op_real_device(uint32_t n, const qip_op* op, const R* d_in, uin
     if (b_vals) HIPCHK(hipMemcpyAsync(buf + o_vals, f.inner->sparse_vals, b_vals, hipMemcpyHostToDevice, stream));
     RealTab<R> tab;
     memset(&tab, 0, sizeof tab);
-    hipLaunchKernelGGL((k_gather_real<R, false>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)buf, (const uint64_t*)buf,
-                       (const uint64_t*)(buf + o_cols), (const R*)(buf + o_vals));
+    if (wide)
+      hipLaunchKernelGGL((k_gather_real<R, false, VMAX>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)buf, (const uint64_t*)buf,
+                         (const uint64_t*)(buf + o_cols), (const R*)(buf + o_vals));
+    else
+      hipLaunchKernelGGL((k_gather_real<R, false, 1>), grid, block, 0, stream, d_in, d_out, d, tab, (const R*)buf, (const uint64_t*)buf,
+                         (const uint64_t*)(buf + o_cols), (const R*)(buf + o_vals));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
     return QIP_OK;

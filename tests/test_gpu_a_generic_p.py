@@ -42,7 +42,10 @@ def device_sync():
 
     assert ctypes.CDLL("libamdhip64.so").hipDeviceSynchronize() == 0
 
-WINDOWS = lambda N: ((0, N, 0, N), (N // 8, N // 2 + 5, N // 16, N - N // 4), (0, 0, 3, 5), (N - 28, 28, 0, N), (0, N, N // 2, 0))  # noqa: E731
+# (whole vector; ragged windows; an empty input; the input's tail; an empty output; windows made of whole 16-byte vectors — the
+#  literal kernel's V-rows-per-lane form; the same shifted by one element — back to one row per lane)
+WINDOWS = lambda N: ((0, N, 0, N), (N // 8, N // 2 + 5, N // 16, N - N // 4), (0, 0, 3, 5), (N - 28, 28, 0, N), (0, N, N // 2, 0),  # noqa: E731
+                     (N // 8, N // 2, N // 4, N // 2), (N // 8 + 1, N // 2, N // 4 + 1, N // 2))
 
 
 def vector(rng, size, dtype):
@@ -91,7 +94,7 @@ def test_device_slices(O, dtype):
     real = not np.issubdtype(dtype, np.complexfloating)
     for op in random_real_ops(n, rng, integer):
         x, y0 = vector(rng, N, dtype), vector(rng, N, dtype)
-        for (io, il, oo, ol) in WINDOWS(N)[:4]:
+        for (io, il, oo, ol) in WINDOWS(N)[:4] + WINDOWS(N)[5:]:
             xin = np.ascontiguousarray(x[io:io + il])
             for acc in (True, False):
                 want = y0[:ol].copy()

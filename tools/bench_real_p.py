@@ -66,6 +66,10 @@ def main():
                        (n, dt, "dense on qubits 3, n-2", MatrixOp.new_matrix([3, n - 2], rng.standard_normal(16)), False),
                        (n, dt, "CNOT(5 -> 20)", MatrixOp.new_control([5], [20], MatrixOp.new_matrix([20], [0, 1, 1, 0])), False),
                        (n, dt, "Swap(1, n-1)", MatrixOp.new_swap([1], [n - 1]), False)]
+            if n == 28:  # what the literal kernel (k_gather_real) still takes: wider ops, SparseMatrix (windows: the GPU tests)
+                shapes += [(n, dt, "dense on qubits 2, 6, 11, 17, 23 (literal)", MatrixOp.new_matrix([2, 6, 11, 17, 23], rng.standard_normal(1024)), False),
+                           (n, dt, "SparseMatrix on qubits 4, 13, 21, two entries per row (literal)",
+                            MatrixOp.new_sparse([4, 13, 21], [[(int(r), 0.5), (int(r ^ 5), -1.25)] for r in range(8)]), False)]
     for n, dt, name, op, acc in shapes:
         N = 1 << n
         x = np.ones(N, dtype=dt) if "ones" in name else rng.standard_normal(N).astype(dt)
@@ -75,6 +79,13 @@ def main():
         cop = op.to_c(_ffi.QIP_F64 if dt == np.float64 else _ffi.QIP_F32)  # (built once, as the reference's benches do)
         sec = gpu_time(lambda: q.apply_op_device(n, cop, d_in, d_out, accumulate=acc), 200 if n <= 20 else 20)
         by = np.dtype(dt).itemsize * N * (3 if acc else 2)
+        one_row_us = None
+        if "(literal)" in name:  # A/B inside the run: buffers that start one element off a 16-byte boundary keep one row per lane
+            u_in = torch.empty(N + 1, dtype=d_in.dtype, device="cuda")
+            u_out = torch.zeros(N + 1, dtype=d_in.dtype, device="cuda")
+            u_in[1:].copy_(d_in)
+            one_row_us = gpu_time(lambda: q.apply_op_device(n, cop, u_in[1:], u_out[1:], accumulate=acc), 5) * 1e6
+            del u_in, u_out
         graph_us = None
         if n <= 20:  # launch-bound sizes: 64 calls recorded into ONE hipGraph (the call is a plain kernel launch on the given stream)
             side = torch.cuda.Stream()
@@ -102,7 +113,7 @@ def main():
                 O.apply_op(n, op, x, want, accumulate=acc, nthreads=nt)
             dt_cpu = (time.perf_counter() - t) / reps
             cpu = dt_cpu if cpu is None else min(cpu, dt_cpu)
-        print(f"| {n} | {np.dtype(dt).name} | {name} | {int(acc)} | {sec*1e6:.1f} | {by/sec/1e9:.0f} | {by/sec/8e12*100:.1f} % | {cpu*1e6:.0f} | {'bit-equal' if ok else 'DIFFERS'}{'' if graph_us is None else '; %.2f us / call inside a 64-call hipGraph' % graph_us} |")
+        print(f"| {n} | {np.dtype(dt).name} | {name} | {int(acc)} | {sec*1e6:.1f} | {by/sec/1e9:.0f} | {by/sec/8e12*100:.1f} % | {cpu*1e6:.0f} | {'bit-equal' if ok else 'DIFFERS'}{'' if graph_us is None else '; %.2f us / call inside a 64-call hipGraph' % graph_us}{'' if one_row_us is None else '; one row per lane (buffers off a 16-byte boundary): %.0f us' % one_row_us} |")
         del d_in, d_out
 
 
