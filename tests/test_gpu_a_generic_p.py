@@ -8,7 +8,7 @@ import pytest
 
 import rustqip_amd as q
 from rustqip_amd.ops import MatrixOp
-from test_oracle_golden import REAL_TYPES, random_real_ops
+from test_oracle_golden import REAL_TYPES, random_real_ops, windows_accumulate
 
 pytestmark = pytest.mark.gpu
 
@@ -156,6 +156,20 @@ def test_whole_vector_group_kernel_every_shape(O, dtype):
                     q.set_global_option("force_generic", 0)
             for got in outs:
                 assert np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got), np.signbit(want)) if not integer else np.array_equal(got, want), (op, dtype, acc)
+
+
+@pytest.mark.parametrize("dtype", (np.int64, np.int32))
+def test_input_windows_accumulate_to_the_whole_vector(O, dtype):
+    """the reference's provision for several devices (offset windows, matrix_ops.rs:96-97) through the HIP path: apply_op
+    accumulated over a partition of the input into four windows, into each of two output windows, is the whole product —
+    exactly, in integer arithmetic — and equals the oracle's whole-vector result"""
+    n = 10
+    rng = np.random.default_rng(18)
+    for op in random_real_ops(n, rng, True):
+        x = rng.integers(-(1 << 20), 1 << 20, size=1 << n).astype(dtype)
+        want = np.zeros(1 << n, dtype=dtype)
+        O.apply_op(n, op, x, want)
+        assert np.array_equal(windows_accumulate(q.apply_op, n, op, x, dtype), want), op
 
 
 def test_reference_bench_shape_ones(O):

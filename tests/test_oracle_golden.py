@@ -327,3 +327,28 @@ def test_real_payload_must_be_real():
         O.apply_op(1, MatrixOp.new_matrix([0], [1j, 0, 0, 1]), x, np.zeros(2))
     with pytest.raises(CircuitError, match="fractional"):
         O.apply_op(1, MatrixOp.new_matrix([0], [0.5, 0, 0, 1]), x.astype(np.int64), np.zeros(2, dtype=np.int64))
+
+
+def windows_accumulate(apply_op, n, op, x, dtype, parts_in=4, parts_out=2):
+    """the reference's only provision for more than one device (matrix_ops.rs:96-97): `input` / `output` are WINDOWS of the 2^n
+    vectors, a column outside the input window contributes zero — so accumulating apply_op over a partition of the input into
+    windows, into each output window, rebuilds the whole product.  In integer arithmetic (a ring, wrapping included) exactly."""
+    N = 1 << n
+    out = np.zeros(N, dtype=dtype)
+    for oo in range(0, N, N // parts_out):
+        y = np.zeros(N // parts_out, dtype=dtype)
+        for io in range(0, N, N // parts_in):
+            apply_op(n, op, np.ascontiguousarray(x[io:io + N // parts_in]), y, io, oo)
+        out[oo:oo + N // parts_out] = y
+    return out
+
+
+@pytest.mark.parametrize("dtype", (np.int64, np.int32))
+def test_input_windows_accumulate_to_the_whole_vector(dtype):
+    n = 8
+    rng = np.random.default_rng(17)
+    for op in random_real_ops(n, rng, True):
+        x = rng.integers(-(1 << 20), 1 << 20, size=1 << n).astype(dtype)
+        want = np.zeros(1 << n, dtype=dtype)
+        O.apply_op(n, op, x, want)
+        assert np.array_equal(windows_accumulate(O.apply_op, n, op, x, dtype), want), op
